@@ -1,0 +1,96 @@
+"""ctypes binding of libdynamorph_hip.so (the C ABI declared in include/dynamorph_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails this module
+raises, so a GPU box can never silently run something else than the HIP kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdynamorph_hip.so")
+
+DM_LOAD_IDENT, DM_LOAD_RELU, DM_LOAD_AFFINE, DM_LOAD_AFFINE_RELU, DM_LOAD_AFFINE2 = range(5)
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class Operand(C.Structure):
+    _fields_ = [("p0", vp), ("p1", vp), ("coef", vp), ("coef_bstride", i64), ("mode", i32), ("ones_channel", i32)]
+
+
+class WeightView(C.Structure):
+    _fields_ = [("w", vp), ("off", i64), ("sn", i64), ("sc", i64), ("sky", i64), ("skx", i64)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", vp), ("relu", i32), ("_pad", i32), ("mask", Operand), ("resid", vp), ("stat_q", vp),
+                ("stats", vp)]
+
+
+OP, WV, EP = C.POINTER(Operand), C.POINTER(WeightView), C.POINTER(Epilogue)
+
+# name -> (restype, argtypes); every symbol include/dynamorph_hip.h declares
+SIGNATURES = {
+    "dm_last_error": (C.c_char_p, []),
+    "dm_version": (C.c_int, []),
+    "dm_vq_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dm_vq_num_blocks": (C.c_int, [i64]),
+    "dm_vq_forward": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, vp]),
+    "dm_vq_decode": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [vp]),
+    "dm_vq_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp, vp]),
+    "dm_vq_backward": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),
+    "dm_conv4x4s2": (C.c_int, [OP, WV, vp, EP] + [C.c_int] * 5 + [vp]),
+    "dm_conv4x4s2_num_blocks": (C.c_int, [C.c_int] * 5),
+    "dm_conv3x3": (C.c_int, [OP, WV, vp, EP] + [C.c_int] * 7 + [vp]),
+    "dm_conv3x3_num_blocks": (C.c_int, [C.c_int] * 7),
+    "dm_wgrad_num_blocks": (C.c_int, [C.c_int] * 6),
+    "dm_wgrad": (C.c_int, [OP, OP, vp, vp] + [C.c_int] * 6 + [vp]),
+    "dm_bn_finalize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, vp, f32, f32, vp, vp, C.c_int, vp]),
+    "dm_bn_backward_finalize": (C.c_int, [vp, C.c_int, C.c_int, i64, vp, vp, vp, vp, vp, vp]),
+    "dm_apply": (C.c_int, [OP, vp, vp] + [C.c_int] * 4 + [vp]),
+    "dm_channel_stats_num_blocks": (C.c_int, [C.c_int] * 4),
+    "dm_channel_stats": (C.c_int, [vp, vp, vp] + [C.c_int] * 4 + [vp]),
+    "dm_sum_slabs": (C.c_int, [vp, C.c_int, C.c_int, f32, vp, vp]),
+    "dm_head_num_blocks": (C.c_int, [C.c_int] * 3),
+    "dm_head_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),
+    "dm_head_backward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
+    "dm_loss_finalize": (C.c_int, [vp, C.c_int, i64, vp, f32, f32, vp, vp]),
+    "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "dm_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
+    "dm_augment": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+}
+
+_lib = None
+
+
+class DynamorphHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise (never fall back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DynamorphHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dynamorph_amd/csrc`. There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Mirror the reference's only error convention: shape problems -> ValueError, the rest RuntimeError."""
+    if rc == 0:
+        return
+    msg = load().dm_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg}")
+    raise DynamorphHipError(f"{what}: HIP error {rc}: {msg}")

@@ -1,0 +1,255 @@
+// bn.hip -- training-mode BatchNorm2d finalisation (forward statistics -> affine
+// coefficients, backward reductions -> AFFINE2 coefficients), the elementwise
+// residual/affine apply, generic slab reductions, and the library's error plumbing.
+//
+// Reference: nn.BatchNorm2d as instantiated at HiddenStateExtractor/vq_vae.py:206,209,
+// 279,282,285,288 with PyTorch defaults (eps 1e-5, momentum 0.1, affine, running stats);
+// the path never calls .eval(), so batch statistics are always used.
+// The heavy per-element work (normalise, ReLU, BN backward formula) is NOT done here:
+// it is folded into the loads of the consuming convolution kernels via dm_operand.
+#include "dm_common.h"
+#include <string.h>
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+
+void dm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *dm_last_error(void) { return g_err; }
+extern "C" int dm_version(void) { return DM_VERSION; }
+
+namespace {
+
+// One block per channel.  Batch mode: all slabs form one group.  Per-sample mode: thread t
+// owns samples t, t+256, ... (each has slabs_per_group slabs), then thread 0 replays the
+// running-statistics recurrence sample by sample, as B successive batch-of-one calls would.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const double *__restrict__ stats, int nslabs, int spg, int C, long long count,
+    const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
+    float momentum, float eps, float *__restrict__ coef, float *__restrict__ saved, int per_sample)
+{
+    __shared__ double s_red[4];
+    const int c = blockIdx.x;
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const double n = (double)count;
+    const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
+    if (!per_sample) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = threadIdx.x; i < nslabs; i += blockDim.x) {
+            s1 += stats[((long long)i * C + c) * 2 + 0];
+            s2 += stats[((long long)i * C + c) * 2 + 1];
+        }
+        const double t1 = block_sum(s1, s_red);
+        const double t2 = block_sum(s2, s_red);
+        if (threadIdx.x == 0) {
+            const double mean = t1 / n;
+            double var = t2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float mean_f = (float)mean;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float scale = g * invstd;
+            coef[c * 4 + 0] = scale;
+            coef[c * 4 + 1] = 0.f;
+            coef[c * 4 + 2] = bt - mean_f * scale;
+            coef[c * 4 + 3] = 0.f;
+            saved[c * 2 + 0] = mean_f;
+            saved[c * 2 + 1] = invstd;
+            // ATen's CPU kernel evaluates these two updates in double (acc type) before the fp32 store
+            const double mom = (double)momentum;
+            if (running_mean) running_mean[c] = (float)(mom * mean + (1.0 - mom) * (double)running_mean[c]);
+            if (running_var) running_var[c] = (float)(mom * (var * unbias) + (1.0 - mom) * (double)running_var[c]);
+            if (nbt && c == 0) nbt[0] += 1;
+        }
+        return;
+    }
+    const int B = nslabs / spg;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < spg; ++i) {
+            s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
+            s2 += stats[((long long)(b * spg + i) * C + c) * 2 + 1];
+        }
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mean_f = (float)mean;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = g * invstd;
+        float *cf = coef + ((long long)b * C + c) * 4;
+        cf[0] = scale; cf[1] = 0.f; cf[2] = bt - mean_f * scale; cf[3] = (float)(var * unbias);
+        saved[((long long)b * C + c) * 2 + 0] = mean_f;
+        saved[((long long)b * C + c) * 2 + 1] = invstd;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (running_mean && running_var) {
+            float rm = running_mean[c], rv = running_var[c];
+            for (int b = 0; b < B; ++b) {
+                rm = momentum * saved[((long long)b * C + c) * 2 + 0] + (1.f - momentum) * rm;
+                rv = momentum * coef[((long long)b * C + c) * 4 + 3] + (1.f - momentum) * rv;
+            }
+            running_mean[c] = rm;
+            running_var[c] = rv;
+        }
+        if (nbt && c == 0) nbt[0] += B;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) coef[((long long)b * C + c) * 4 + 3] = 0.f;
+}
+
+// slabs hold (sum dy, sum dy*a).  x_hat = (a - mean)*invstd, so
+//   sum dy*x_hat = invstd * (sum dy*a - mean * sum dy).
+// da = scale*(dy - c1 - x_hat*c2) with c1 = mean(dy), c2 = mean(dy*x_hat)  ==>
+// da = A*dy + Bc*a + Cc,  A = scale, Bc = -scale*invstd*c2, Cc = -scale*c1 - Bc*mean.
+__global__ __launch_bounds__(256) void bn_backward_finalize_kernel(
+    const double *__restrict__ stats, int nslabs, int C, long long count,
+    const float *__restrict__ gamma, const float *__restrict__ saved,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef_bwd)
+{
+    __shared__ double s_red[4];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nslabs; i += blockDim.x) {
+        s1 += stats[((long long)i * C + c) * 2 + 0];
+        s2 += stats[((long long)i * C + c) * 2 + 1];
+    }
+    const double sum_dy = block_sum(s1, s_red);
+    const double sum_dya = block_sum(s2, s_red);
+    if (threadIdx.x == 0) {
+        const double n = (double)count;
+        const double mean = (double)saved[c * 2 + 0], invstd = (double)saved[c * 2 + 1];
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double sum_dyxh = invstd * (sum_dya - mean * sum_dy);
+        if (dgamma) dgamma[c] = (float)sum_dyxh;
+        if (dbeta) dbeta[c] = (float)sum_dy;
+        const double scale = g * invstd;
+        const double c1 = sum_dy / n, c2 = sum_dyxh / n;
+        const double Bc = -scale * invstd * c2;
+        coef_bwd[c * 4 + 0] = (float)scale;
+        coef_bwd[c * 4 + 1] = (float)Bc;
+        coef_bwd[c * 4 + 2] = (float)(-scale * c1 - Bc * mean);
+        coef_bwd[c * 4 + 3] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void apply_kernel(Operand in, const float *__restrict__ resid,
+                                                    float *__restrict__ out, int C, int HW4, long long total4)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long plane = i / HW4;          // b*C + c
+        const int c = (int)(plane % C), b = (int)(plane / C);
+        f32x4 v = operand_load4(in, i * 4, b, c);
+        if (resid) v += *reinterpret_cast<const f32x4 *>(resid + i * 4);
+        *reinterpret_cast<f32x4 *>(out + i * 4) = v;
+    }
+}
+
+// One block per (chunk of samples, channel): stats[chunk][c] = (sum p, sum p*q).
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restrict__ p, const float *__restrict__ q,
+                                                            double *__restrict__ stats, int B, int C, int HW4, int bchunk)
+{
+    __shared__ double s_red[4];
+    const int c = blockIdx.x % C, chunk = blockIdx.x / C;
+    const int b0 = chunk * bchunk, b1 = min(B, b0 + bchunk);
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = b0; b < b1; ++b) {
+        const long long base = ((long long)b * C + c) * HW4;
+        for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (base + i) * 4);
+            const f32x4 w = q ? *reinterpret_cast<const f32x4 *>(q + (base + i) * 4) : a;
+            s1 += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
+            s2 += (double)(a.x * w.x) + (double)(a.y * w.y) + (double)(a.z * w.z) + (double)(a.w * w.w);
+        }
+    }
+    const double t1 = block_sum(s1, s_red);
+    const double t2 = block_sum(s2, s_red);
+    if (threadIdx.x == 0) {
+        stats[((long long)chunk * C + c) * 2 + 0] = t1;
+        stats[((long long)chunk * C + c) * 2 + 1] = t2;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const double *__restrict__ stats, int nslabs, int N,
+                                                        float scale, float *__restrict__ dst)
+{
+    __shared__ double s_red[4];
+    const int n = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nslabs; i += blockDim.x) s += stats[((long long)i * N + n) * 2];
+    const double t = block_sum(s, s_red);
+    if (threadIdx.x == 0) dst[n] = (float)(t * (double)scale);
+}
+
+constexpr int STATS_BCHUNK = 8;
+
+}  // namespace
+
+extern "C" int dm_bn_finalize(const double *stats, int nslabs, int slabs_per_group, int C, int64_t count_per_group,
+                              const float *gamma, const float *beta, float *running_mean, float *running_var,
+                              int64_t *num_batches_tracked, float momentum, float eps,
+                              float *coef, float *saved, int per_sample, void *stream)
+{
+    DM_REQUIRE(stats && coef && saved, "dm_bn_finalize: NULL pointer");
+    DM_REQUIRE(nslabs > 0 && C > 0 && count_per_group > 0, "dm_bn_finalize: bad sizes");
+    DM_REQUIRE(!per_sample || (slabs_per_group > 0 && nslabs % slabs_per_group == 0),
+               "dm_bn_finalize: nslabs %d not a multiple of slabs_per_group %d", nslabs, slabs_per_group);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslabs,
+                       slabs_per_group, C, (long long)count_per_group, gamma, beta, running_mean, running_var,
+                       (long long *)num_batches_tracked, momentum, eps, coef, saved, per_sample);
+    return dm_launch_status("dm_bn_finalize");
+}
+
+extern "C" int dm_bn_backward_finalize(const double *stats, int nslabs, int C, int64_t count,
+                                       const float *gamma, const float *saved, float *dgamma, float *dbeta,
+                                       float *coef_bwd, void *stream)
+{
+    DM_REQUIRE(stats && saved && coef_bwd, "dm_bn_backward_finalize: NULL pointer");
+    DM_REQUIRE(nslabs > 0 && C > 0 && count > 0, "dm_bn_backward_finalize: bad sizes");
+    hipLaunchKernelGGL(bn_backward_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslabs, C,
+                       (long long)count, gamma, saved, dgamma, dbeta, coef_bwd);
+    return dm_launch_status("dm_bn_backward_finalize");
+}
+
+extern "C" int dm_apply(const dm_operand *in, const float *resid, float *out, int B, int C, int H, int W, void *stream)
+{
+    if (dm_check_operand(in, "dm_apply")) return -1;
+    DM_REQUIRE(out && B > 0 && C > 0 && H > 0 && W > 0, "dm_apply: bad argument");
+    DM_REQUIRE((H * W) % 4 == 0, "dm_apply: H*W must be a multiple of 4");
+    DM_REQUIRE(!in->ones_channel, "dm_apply: ones_channel not supported");
+    const int HW4 = H * W / 4;
+    const long long total4 = (long long)B * C * HW4;
+    const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, to_dev(in), resid, out, C, HW4, total4);
+    return dm_launch_status("dm_apply");
+}
+
+extern "C" int dm_channel_stats_num_blocks(int B, int C, int H, int W)
+{
+    (void)C; (void)H; (void)W;
+    return (B + STATS_BCHUNK - 1) / STATS_BCHUNK;
+}
+
+extern "C" int dm_channel_stats(const float *p, const float *q, double *stats, int B, int C, int H, int W, void *stream)
+{
+    DM_REQUIRE(p && stats && B > 0 && C > 0, "dm_channel_stats: bad argument");
+    DM_REQUIRE((H * W) % 4 == 0, "dm_channel_stats: H*W must be a multiple of 4");
+    const int chunks = dm_channel_stats_num_blocks(B, C, H, W);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(chunks * C), dim3(256), 0, (hipStream_t)stream, p, q, stats, B, C,
+                       H * W / 4, STATS_BCHUNK);
+    return dm_launch_status("dm_channel_stats");
+}
+
+extern "C" int dm_sum_slabs(const double *stats, int nslabs, int N, float scale, float *dst, void *stream)
+{
+    DM_REQUIRE(stats && dst && nslabs > 0 && N > 0, "dm_sum_slabs: bad argument");
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, stats, nslabs, N, scale, dst);
+    return dm_launch_status("dm_sum_slabs");
+}

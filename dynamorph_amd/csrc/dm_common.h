@@ -1,0 +1,150 @@
+// dm_common.h -- shared host/device helpers for libdynamorph_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/dynamorph_hip.h"
+
+#define DM_WAVE 64
+#define DM_BLOCK 256          // 4 waves: one per SIMD of a CU
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------ host errors
+void dm_set_error(const char *fmt, ...);
+#define DM_REQUIRE(cond, ...)                         \
+    do {                                              \
+        if (!(cond)) {                                \
+            dm_set_error(__VA_ARGS__);                \
+            return -1;                                \
+        }                                             \
+    } while (0)
+
+static inline int dm_launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dm_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------- device operands
+// Device-side copy of dm_operand (same fields; kept POD so it travels as a kernel argument).
+struct Operand {
+    const float *p0;
+    const float *p1;
+    const float *coef;
+    long long coef_bstride;
+    int mode;
+    int ones;
+};
+
+static inline Operand to_dev(const dm_operand *o)
+{
+    Operand r;
+    r.p0 = o->p0; r.p1 = o->p1; r.coef = o->coef; r.coef_bstride = o->coef_bstride;
+    r.mode = o->mode; r.ones = o->ones_channel;
+    return r;
+}
+
+static inline Operand null_operand()
+{
+    Operand r;
+    r.p0 = nullptr; r.p1 = nullptr; r.coef = nullptr; r.coef_bstride = 0; r.mode = DM_LOAD_IDENT; r.ones = 0;
+    return r;
+}
+
+struct WeightView {
+    const float *w;
+    long long off, sn, sc, sky, skx;
+};
+
+static inline WeightView to_dev(const dm_weight_view *v)
+{
+    WeightView r;
+    r.w = v->w; r.off = v->off; r.sn = v->sn; r.sc = v->sc; r.sky = v->sky; r.skx = v->skx;
+    return r;
+}
+
+struct Epilogue {
+    const float *bias;
+    int relu;
+    Operand mask;
+    const float *resid;
+    const float *stat_q;
+    double *stats;
+};
+
+static inline Epilogue to_dev(const dm_epilogue *e)
+{
+    Epilogue r;
+    if (!e) {
+        r.bias = nullptr; r.relu = 0; r.mask = null_operand(); r.resid = nullptr; r.stat_q = nullptr; r.stats = nullptr;
+        return r;
+    }
+    r.bias = e->bias; r.relu = e->relu; r.mask = to_dev(&e->mask); r.resid = e->resid;
+    r.stat_q = e->stat_q; r.stats = e->stats;
+    return r;
+}
+
+static inline int dm_check_operand(const dm_operand *o, const char *who)
+{
+    DM_REQUIRE(o && o->p0, "%s: operand p0 is NULL", who);
+    DM_REQUIRE(o->mode >= DM_LOAD_IDENT && o->mode <= DM_LOAD_AFFINE2, "%s: bad operand mode %d", who, o->mode);
+    DM_REQUIRE(o->mode < DM_LOAD_AFFINE || o->coef, "%s: operand mode %d needs coef", who, o->mode);
+    DM_REQUIRE(o->mode != DM_LOAD_AFFINE2 || o->p1, "%s: AFFINE2 operand needs p1", who);
+    return 0;
+}
+
+#ifdef __HIPCC__
+// Load 4 contiguous elements of channel c / sample b through the operand's transform.
+__device__ __forceinline__ f32x4 operand_load4(const Operand &op, long long off, int b, int c)
+{
+    f32x4 v = *reinterpret_cast<const f32x4 *>(op.p0 + off);
+    if (op.mode == DM_LOAD_IDENT) return v;
+    if (op.mode == DM_LOAD_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        return v;
+    }
+    const float *cf = op.coef + (long long)b * op.coef_bstride + c * 4;
+    const float c0 = cf[0], c2 = cf[2];
+    if (op.mode == DM_LOAD_AFFINE2) {
+        const float c1 = cf[1];
+        f32x4 u = *reinterpret_cast<const f32x4 *>(op.p1 + off);
+        v = c0 * v + (c1 * u + c2);
+        return v;
+    }
+    v = c0 * v + c2;
+    if (op.mode == DM_LOAD_AFFINE_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over the 256 threads of a block; result valid in thread 0.  scratch: >= 4 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *scratch)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += scratch[i];
+    }
+    return r;
+}
+#endif

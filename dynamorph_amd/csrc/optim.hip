@@ -1,0 +1,142 @@
+// optim.hip -- fused Adam, the enc.0 o enc.1 weight composition with its chain rule,
+// and the on-device flip/rot90 augmentation.
+//
+// Reference: run_training.py:485 (t.optim.Adam(model.parameters(), lr, betas=(.9,.999)),
+// eps 1e-8, no weight decay), run_training.py:396-403 (per-sample flip + rot90),
+// HiddenStateExtractor/vq_vae.py:277-278 (enc.0 1x1 conv feeding enc.1 4x4/s2 conv).
+#include "dm_common.h"
+
+namespace {
+
+// One launch over the flat parameter buffer (all 43 trainable tensors are views of it).
+// Same operation order as torch.optim.Adam's default path:
+//   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2);
+//   denom = sqrt(v)/sqrt(1-b2^t) + eps; p.addcdiv_(m, denom, value=-lr/(1-b1^t))
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, long long n,
+                                                   float lr, float b1, float b2, float eps,
+                                                   const float *__restrict__ step_dev)
+{
+    const double t = (double)step_dev[0];
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = 1.f - b1, w2 = 1.f - b2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + w1 * (gi - m[i]);
+        const float vi = v[i] * b2 + w2 * (gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+// Weff[c1][ci][t], ci in [0, NIN] (ci == NIN is the ones channel), t = ky*4+kx.
+__global__ void e1_compose_kernel(const float *__restrict__ w0, const float *__restrict__ b0,
+                                  const float *__restrict__ w1, float *__restrict__ weff, int NIN, int C0, int C1)
+{
+    const int total = C1 * (NIN + 1) * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i & 15, ci = (i >> 4) % (NIN + 1), c1 = (i >> 4) / (NIN + 1);
+        double s = 0.0;
+        for (int c = 0; c < C0; ++c) {
+            const double a = (double)w1[(c1 * C0 + c) * 16 + t];
+            s += a * (ci < NIN ? (double)w0[c * NIN + ci] : (double)b0[c]);
+        }
+        weff[i] = (float)s;
+    }
+}
+
+__global__ void e1_chain_kernel(const float *__restrict__ dweff, const float *__restrict__ w0,
+                                const float *__restrict__ b0, const float *__restrict__ w1,
+                                float *__restrict__ dw0, float *__restrict__ db0, float *__restrict__ dw1,
+                                int NIN, int C0, int C1)
+{
+    const int n_w1 = C1 * C0 * 16, n_w0 = C0 * NIN, total = n_w1 + n_w0 + C0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < n_w1) {
+            const int t = i & 15, c = (i >> 4) % C0, c1 = (i >> 4) / C0;
+            double s = (double)dweff[(c1 * (NIN + 1) + NIN) * 16 + t] * (double)b0[c];
+            for (int ci = 0; ci < NIN; ++ci)
+                s += (double)dweff[(c1 * (NIN + 1) + ci) * 16 + t] * (double)w0[c * NIN + ci];
+            dw1[i] = (float)s;
+        } else {
+            const int j = i - n_w1;
+            const bool is_bias = j >= n_w0;
+            const int c = is_bias ? j - n_w0 : j / NIN, ci = is_bias ? NIN : j % NIN;
+            double s = 0.0;
+            for (int c1 = 0; c1 < C1; ++c1)
+                for (int t = 0; t < 16; ++t)
+                    s += (double)w1[(c1 * C0 + c) * 16 + t] * (double)dweff[(c1 * (NIN + 1) + ci) * 16 + t];
+            if (is_bias) db0[c] = (float)s;
+            else dw0[j] = (float)s;
+        }
+    }
+}
+
+// out[b] = rot90(flip(in[b], flip), k) on (C, H, H) patches, gather form.
+__global__ __launch_bounds__(256) void augment_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                      const int *__restrict__ flip_code, const int *__restrict__ rot_code,
+                                                      int C, int H, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % H), y = (int)((i / H) % H);
+        const long long plane = i / ((long long)H * H);
+        const int b = (int)(plane / C);
+        const int k = rot_code[b] & 3, f = flip_code[b];
+        int sy, sx;
+        switch (k) {                      // torch.rot90(img, k, dims=[1, 2])
+        case 0: sy = y; sx = x; break;
+        case 1: sy = x; sx = H - 1 - y; break;
+        case 2: sy = H - 1 - y; sx = H - 1 - x; break;
+        default: sy = H - 1 - x; sx = y; break;
+        }
+        if (f == 1) sy = H - 1 - sy;      // torch.flip(img, dims=(1,))
+        else if (f == 2) sx = H - 1 - sx; // torch.flip(img, dims=(2,))
+        out[i] = in[plane * H * H + (long long)sy * H + sx];
+    }
+}
+
+}  // namespace
+
+extern "C" int dm_adam(float *param, const float *grad, float *m, float *v, int64_t n,
+                       float lr, float beta1, float beta2, float eps, const float *step_dev, void *stream)
+{
+    DM_REQUIRE(param && grad && m && v && step_dev && n > 0, "dm_adam: bad argument");
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n, lr,
+                       beta1, beta2, eps, step_dev);
+    return dm_launch_status("dm_adam");
+}
+
+extern "C" int dm_e1_compose(const float *w0, const float *b0, const float *w1, float *weff,
+                             int NIN, int C0, int C1, void *stream)
+{
+    DM_REQUIRE(w0 && b0 && w1 && weff && NIN > 0 && C0 > 0 && C1 > 0, "dm_e1_compose: bad argument");
+    hipLaunchKernelGGL(e1_compose_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, weff, NIN, C0, C1);
+    return dm_launch_status("dm_e1_compose");
+}
+
+extern "C" int dm_e1_chain(const float *dweff, const float *w0, const float *b0, const float *w1,
+                           float *dw0, float *db0, float *dw1, int NIN, int C0, int C1, void *stream)
+{
+    DM_REQUIRE(dweff && w0 && b0 && w1 && dw0 && db0 && dw1, "dm_e1_chain: NULL pointer");
+    hipLaunchKernelGGL(e1_chain_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, dweff, w0, b0, w1, dw0, db0, dw1,
+                       NIN, C0, C1);
+    return dm_launch_status("dm_e1_chain");
+}
+
+extern "C" int dm_augment(const float *in, float *out, const int32_t *flip_code, const int32_t *rot_code,
+                          int B, int C, int H, void *stream)
+{
+    DM_REQUIRE(in && out && flip_code && rot_code && B > 0 && C > 0 && H > 0, "dm_augment: bad argument");
+    DM_REQUIRE(in != out, "dm_augment: in-place not supported");
+    const long long total = (long long)B * C * H * H;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(augment_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, (const int *)flip_code,
+                       (const int *)rot_code, C, H, total);
+    return dm_launch_status("dm_augment");
+}

@@ -1,0 +1,289 @@
+// vq.hip -- VectorQuantizer kernels (reference: HiddenStateExtractor/vq_vae.py:52-116).
+//
+// Compiled with -ffp-contract=off: the reference materialises (z - e) and (z - e)^2 in
+// fp32 before summing over d (no FMA), and ATen's CPU reduction adds the squares
+// sequentially inside blocks of 16 consecutive d, block sums again sequentially.  The
+// kernels reproduce that order so argmin indices are bit-identical to the CPU path.
+//
+// Layout: one thread per latent position (b,h,w); the D-vector of a position is strided
+// by H*W in NCHW, so for every d a wave reads 64 consecutive floats (256 B, coalesced)
+// and keeps its D values in registers.  Codes are processed two at a time as packed fp32
+// (v_pk_add_f32 / v_pk_mul_f32, IEEE round-to-nearest, same results as scalar ops); the
+// codebook is first re-laid out as [K/2][D][2] so a pair's operands are adjacent and the
+// wave-uniform loads go through the scalar cache instead of LDS.
+#include "dm_common.h"
+
+namespace {
+
+constexpr int VQ_BLOCK = 256;
+constexpr int VQ_MAX_LDS_HIST = 4096;
+
+__global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ cbT, int K, int D)
+{
+    // cbT[p][d][j] = cb[2p + j][d]; for odd K the missing partner repeats code K-1 (never selected).
+    const int npairs = (K + 1) >> 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npairs * D * 2; i += gridDim.x * blockDim.x) {
+        const int j = i & 1, d = (i >> 1) % D, p = (i >> 1) / D;
+        int k = 2 * p + j;
+        if (k >= K) k = K - 1;
+        cbT[i] = cb[(long long)k * D + d];
+    }
+}
+
+// first-minimum with torch.argmax(-dist) NaN semantics: a NaN distance beats any number,
+// the first NaN wins (vq_vae.py:68).
+__device__ __forceinline__ bool vq_better(float cand, float best)
+{
+    if (best != best) return false;
+    if (cand != cand) return true;
+    return cand < best;
+}
+
+template <int D>
+__global__ __launch_bounds__(VQ_BLOCK) void vq_forward_kernel(
+    const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbT,
+    long long *__restrict__ idx, float *__restrict__ out, double *__restrict__ sse_slabs,
+    int *__restrict__ hist, int K, int HW, long long P)
+{
+    __shared__ int s_hist[VQ_MAX_LDS_HIST];
+    __shared__ double s_red[4];
+    const bool lds_hist = K <= VQ_MAX_LDS_HIST;
+    if (lds_hist)
+        for (int k = threadIdx.x; k < K; k += VQ_BLOCK) s_hist[k] = 0;
+    __syncthreads();
+
+    const long long pos = (long long)blockIdx.x * VQ_BLOCK + threadIdx.x;
+    const bool active = pos < P;
+    const long long b = active ? pos / HW : 0;
+    const long long p = active ? pos - b * HW : 0;
+    const long long base = b * (long long)D * HW + p;
+
+    float zr[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) zr[d] = active ? z[base + (long long)d * HW] : 0.f;
+
+    float bestd = 0.f;
+    int bi = 0;
+    const int npairs = K >> 1;
+    for (int kp = 0; kp < npairs; ++kp) {
+        const float *__restrict__ e = cbT + (long long)kp * (2 * D);   // wave-uniform address
+        f32x2 total = {0.f, 0.f};
+#pragma unroll
+        for (int d0 = 0; d0 < D; d0 += 16) {
+            f32x2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int d = d0; d < d0 + 16 && d < D; ++d) {
+                const f32x2 e2 = *reinterpret_cast<const f32x2 *>(e + 2 * d);
+                const f32x2 zz = {zr[d], zr[d]};
+                const f32x2 diff = zz - e2;
+                const f32x2 sq = diff * diff;
+                acc = acc + sq;
+            }
+            total = (d0 == 0) ? acc : total + acc;
+        }
+        const int k0 = 2 * kp;
+        if (kp == 0) { bestd = total.x; bi = 0; }
+        else if (vq_better(total.x, bestd)) { bestd = total.x; bi = k0; }
+        if (vq_better(total.y, bestd)) { bestd = total.y; bi = k0 + 1; }
+    }
+    if (K & 1) {   // odd tail, scalar
+        const int k = K - 1;
+        const float *__restrict__ e = cb + (long long)k * D;
+        float total = 0.f;
+#pragma unroll
+        for (int d0 = 0; d0 < D; d0 += 16) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = d0; d < d0 + 16 && d < D; ++d) {
+                const float diff = zr[d] - e[d];
+                acc = acc + diff * diff;
+            }
+            total = (d0 == 0) ? acc : total + acc;
+        }
+        if (k == 0) { bestd = total; bi = 0; }
+        else if (vq_better(total, bestd)) { bestd = total; bi = k; }
+    }
+
+    double sse = 0.0;
+    if (active) {
+        if (idx) idx[pos] = (long long)bi;
+        const float *__restrict__ q = cb + (long long)bi * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float diff = q[d] - zr[d];
+            if (out) out[base + (long long)d * HW] = zr[d] + diff;     // z + (q - z), vq_vae.py:71
+            const float sq = diff * diff;
+            sse += (double)sq;
+        }
+        if (lds_hist) atomicAdd(&s_hist[bi], 1);
+        else atomicAdd(&hist[bi], 1);
+    }
+    const double tot = block_sum(sse, s_red);
+    if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
+    if (lds_hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += VQ_BLOCK) {
+            const int c = s_hist[k];
+            if (c) atomicAdd(&hist[k], c);
+        }
+    }
+}
+
+__global__ void vq_decode_kernel(const long long *__restrict__ idx, const float *__restrict__ cb,
+                                 float *__restrict__ q, int D, int K, int HW, long long P)
+{
+    const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= P) return;
+    long long k = idx[pos];
+    if (k < 0) k = 0;
+    if (k >= K) k = K - 1;
+    const long long b = pos / HW, p = pos - b * HW;
+    for (int d = 0; d < D; ++d) q[(b * D + d) * HW + p] = cb[k * D + d];
+}
+
+__global__ void vq_finalize_kernel(const double *__restrict__ sse_slabs, int nslabs,
+                                   const int *__restrict__ hist, int K, long long P, int D,
+                                   float cc, float *__restrict__ scalars)
+{
+    __shared__ double s_red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nslabs; i += blockDim.x) s += sse_slabs[i];
+    const double sse = block_sum(s, s_red);
+    double e = 0.0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float pk = (float)hist[k] / (float)P;
+        e += (double)(pk * logf(pk + 1e-10f));
+    }
+    const double ent = block_sum(e, s_red);
+    if (threadIdx.x == 0) {
+        const float mse = (float)(sse / ((double)P * (double)D));
+        scalars[0] = mse + cc * mse;           // q_latent_loss + commitment_cost * e_latent_loss
+        scalars[1] = expf(-(float)ent);
+        scalars[2] = mse;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(VQ_BLOCK) void vq_backward_kernel(
+    const float *__restrict__ z, const float *__restrict__ cb, const long long *__restrict__ idx,
+    const float *__restrict__ g_out, const float *__restrict__ g_loss_dev, float cc,
+    float *__restrict__ dz, float *__restrict__ dw, int K, int HW, long long P, int use_lds)
+{
+    extern __shared__ float s_dw[];    // [K][D] when use_lds
+    if (use_lds) {
+        for (int i = threadIdx.x; i < K * D; i += VQ_BLOCK) s_dw[i] = 0.f;
+        __syncthreads();
+    }
+    const float g_loss = g_loss_dev ? g_loss_dev[0] : 1.f;
+    const double N = (double)P * (double)D;
+    const float sz = (float)(2.0 * (double)cc / N) * g_loss;   // d/dz of cc * mse(q.detach(), z)
+    const float sw = (float)(2.0 / N) * g_loss;                // d/dq of mse(q, z.detach())
+    const long long pos = (long long)blockIdx.x * VQ_BLOCK + threadIdx.x;
+    if (pos < P) {
+        const long long b = pos / HW, p = pos - b * HW;
+        const long long base = b * (long long)D * HW + p;
+        const long long k = idx[pos];
+        const float *__restrict__ q = cb + k * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const long long o = base + (long long)d * HW;
+            const float zv = z[o], qv = q[d];
+            if (dz) dz[o] = (g_out ? g_out[o] : 0.f) + sz * (zv - qv);
+            const float gw = sw * (qv - zv);
+            if (use_lds) atomicAdd(&s_dw[k * D + d], gw);
+            else atomicAdd(&dw[k * D + d], gw);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * D; i += VQ_BLOCK) {
+            const float v = s_dw[i];
+            if (v != 0.f) atomicAdd(&dw[i], v);
+        }
+    }
+}
+
+bool vq_dim_supported(int D) { return D == 8 || D == 16 || D == 32 || D == 64; }
+
+}  // namespace
+
+extern "C" size_t dm_vq_workspace_bytes(int K, int D)
+{
+    return (size_t)((K + 1) / 2) * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int dm_vq_num_blocks(int64_t positions)
+{
+    return (int)((positions + VQ_BLOCK - 1) / VQ_BLOCK);
+}
+
+extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *out,
+                             double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    DM_REQUIRE(z && codebook && sse_slabs && hist, "dm_vq_forward: NULL pointer");
+    DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
+    DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d not built (8/16/32/64)", D);
+    DM_REQUIRE(workspace && workspace_bytes >= dm_vq_workspace_bytes(K, D), "dm_vq_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = (long long)B * H * W;
+    float *cbT = (float *)workspace;
+    const int n = ((K + 1) / 2) * 2 * D;
+    hipLaunchKernelGGL(vq_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, codebook, cbT, K, D);
+    const int grid = dm_vq_num_blocks(P);
+#define DM_VQ_FWD(DD)                                                                              \
+    hipLaunchKernelGGL(vq_forward_kernel<DD>, dim3(grid), dim3(VQ_BLOCK), 0, s, z, codebook, cbT, \
+                       (long long *)idx, out, sse_slabs, (int *)hist, K, H * W, P)
+    switch (D) {
+    case 8: DM_VQ_FWD(8); break;
+    case 16: DM_VQ_FWD(16); break;
+    case 32: DM_VQ_FWD(32); break;
+    default: DM_VQ_FWD(64); break;
+    }
+#undef DM_VQ_FWD
+    return dm_launch_status("dm_vq_forward");
+}
+
+extern "C" int dm_vq_decode(const int64_t *idx, const float *codebook, float *q,
+                            int B, int D, int K, int H, int W, void *stream)
+{
+    DM_REQUIRE(idx && codebook && q, "dm_vq_decode: NULL pointer");
+    DM_REQUIRE(B > 0 && D > 0 && K > 0 && H > 0 && W > 0, "dm_vq_decode: bad shape");
+    const long long P = (long long)B * H * W;
+    hipLaunchKernelGGL(vq_decode_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)idx, codebook, q, D, K, H * W, P);
+    return dm_launch_status("dm_vq_decode");
+}
+
+extern "C" int dm_vq_finalize(const double *sse_slabs, int nslabs, const int32_t *hist, int K,
+                              int64_t positions, int D, float commitment_cost, float *scalars, void *stream)
+{
+    DM_REQUIRE(sse_slabs && hist && scalars && nslabs > 0 && K > 0 && positions > 0, "dm_vq_finalize: bad argument");
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       sse_slabs, nslabs, (const int *)hist, K, (long long)positions, D, commitment_cost, scalars);
+    return dm_launch_status("dm_vq_finalize");
+}
+
+extern "C" int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
+                              const float *g_out, const float *g_loss_dev, float commitment_cost,
+                              float *dz, float *dw, int B, int D, int K, int H, int W, void *stream)
+{
+    DM_REQUIRE(z && codebook && idx && dw, "dm_vq_backward: NULL pointer");
+    DM_REQUIRE(vq_dim_supported(D), "dm_vq_backward: embedding_dim %d not built (8/16/32/64)", D);
+    const long long P = (long long)B * H * W;
+    const size_t lds = (size_t)K * D * sizeof(float);
+    const int use_lds = lds <= 48 * 1024;
+    const int grid = dm_vq_num_blocks(P);
+    hipStream_t s = (hipStream_t)stream;
+#define DM_VQ_BWD(DD)                                                                                         \
+    hipLaunchKernelGGL(vq_backward_kernel<DD>, dim3(grid), dim3(VQ_BLOCK), use_lds ? lds : 0, s, z, codebook, \
+                       (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, K, H * W, P, use_lds)
+    switch (D) {
+    case 8: DM_VQ_BWD(8); break;
+    case 16: DM_VQ_BWD(16); break;
+    case 32: DM_VQ_BWD(32); break;
+    default: DM_VQ_BWD(64); break;
+    }
+#undef DM_VQ_BWD
+    return dm_launch_status("dm_vq_backward");
+}

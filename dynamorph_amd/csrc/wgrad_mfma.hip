@@ -1,0 +1,232 @@
+// wgrad_mfma.hip -- convolution weight gradients on v_mfma_f32_16x16x4_f32.
+//
+// Replaces aten::convolution_backward(weight) for every Conv2d / ConvTranspose2d of the
+// VQ-VAE (HiddenStateExtractor/vq_vae.py:203-209, 276-298) as driven by
+// total_loss.backward() in run_training.py:406.
+//
+//   R[cs][ct][ky][kx] = sum_{b,y,x} S[b,cs,y,x] * T[b,ct, y*s+ky-p, x*s+kx-p]
+//
+// GEMM view: M = S channels (16 per tile), N = (ct,ky,kx) (16 per tile), K = positions, four
+// consecutive x per MFMA step.  Conv2d: S = output gradient (BatchNorm backward folded into
+// the operand load), T = layer input (BatchNorm + ReLU folded in).  ConvTranspose2d: S = layer
+// input, T = output gradient.  In both cases R is already in the parameter's memory layout.
+//
+// Workgroups are persistent: each loops over many (sample, tile) pairs keeping its partial R in
+// MFMA accumulators; the four waves split the rows of a tile (split-K), are combined through LDS
+// in a fixed order, and each workgroup writes one slab.  A second kernel adds the slabs in slab
+// order -> bitwise reproducible, no float atomics.
+#include "dm_common.h"
+
+namespace {
+
+constexpr int WG_MAX_BLOCKS = 512;     // 2 workgroups per CU
+
+template <int CIN, int ROWS, int COLS4, int RS, int PS>
+__device__ __forceinline__ void wg_fill(float *__restrict__ lds, const Operand &op, int b, int Cphys,
+                                        int H, int W, int gy0, int gx0)
+{
+    constexpr int PER_C = ROWS * COLS4;
+    constexpr int TOTAL = CIN * PER_C;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < TOTAL; i += DM_BLOCK) {
+        const int c = i / PER_C;
+        const int rem = i - c * PER_C;
+        const int r = rem / COLS4;
+        const int j4 = rem - r * COLS4;
+        const int gy = gy0 + r, gx = gx0 + 4 * j4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (c < Cphys) v = operand_load4(op, (((long long)b * Cphys + c) * H + gy) * (long long)W + gx, b, c);
+            else v = (f32x4){1.f, 1.f, 1.f, 1.f};
+        }
+        *reinterpret_cast<f32x4 *>(lds + c * PS + r * RS + 4 * j4) = v;
+    }
+}
+
+template <int CS, int CT, int KK, int TH, int TW>
+__global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, float *__restrict__ slabs,
+                                                         int CTphys, int Hs, int Ws, int ntiles)
+{
+    constexpr int STRIDE = KK == 4 ? 2 : 1, PAD = KK == 1 ? 0 : 1;
+    constexpr int MT = (CS + 15) / 16, N = CT * KK * KK, NTT = (N + 15) / 16;
+    // S tile [CS][TH][TW], plane stride == 4 (mod 32) dwords (2-way conflict on the A read at worst)
+    constexpr int RSS = TW, PSS_RAW = TH * RSS, PSS = PSS_RAW + ((4 - (PSS_RAW % 32)) + 32) % 32;
+    // T tile [CT][TH*s + KK - s][TW*s + 8*PAD]; col 0 <-> global x = x0*s - 4*PAD
+    constexpr int TROWS = TH * STRIDE + KK - STRIDE, RST = TW * STRIDE + 8 * PAD, TCOLS4 = RST / 4;
+    constexpr int PST = TROWS * RST;
+    constexpr int RED = MT * NTT * 256;
+    constexpr int LDS_TILES = CS * PSS + CT * PST;
+    constexpr int LDS_FLOATS = LDS_TILES > RED ? LDS_TILES : RED;
+    static_assert(TH % 4 == 0 && TW % 4 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float *sS = lds, *sT = lds + CS * PSS;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int Ht = Hs * STRIDE, Wt = Ws * STRIDE;
+    const int tiles_x = Ws / TW, tiles_y = Hs / TH;
+
+    // B-operand gather offsets: lane column n = 16*t + m <-> (ct, ky, kx)
+    int boff[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+        int n = 16 * t + m;
+        if (n >= N) n = N - 1;                       // garbage column, dropped at write time
+        const int ct = n / (KK * KK), k2 = n % (KK * KK), ky = k2 / KK, kx = k2 % KK;
+        boff[t] = ct * PST + ky * RST + kx + 3 * PAD + kq * STRIDE;
+    }
+    int aoff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int cs = 16 * t + m;
+        if (cs >= CS) cs = CS - 1;                   // garbage row, dropped at write time
+        aoff[t] = cs * PSS + kq;
+    }
+
+    f32x4 acc[MT][NTT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tid = tile;
+        const int tx = tid % tiles_x; tid /= tiles_x;
+        const int ty = tid % tiles_y;
+        const int b = tid / tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();                             // previous tile fully consumed
+        wg_fill<CS, TH, TW / 4, RSS, PSS>(sS, S, b, CS, Hs, Ws, y0, x0);
+        wg_fill<CT, TROWS, TCOLS4, RST, PST>(sT, T, b, CTphys, Ht, Wt, y0 * STRIDE - PAD, x0 * STRIDE - 4 * PAD);
+        __syncthreads();
+        for (int r = wave; r < TH; r += 4) {
+#pragma unroll 2
+            for (int x4 = 0; x4 < TW / 4; ++x4) {
+                float a[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = sS[aoff[i] + r * RSS + 4 * x4];
+                const int tb = r * STRIDE * RST + 4 * x4 * STRIDE;
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    const float bv = sT[boff[t] + tb];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv, acc[i][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // combine the four waves in wave order (deterministic), then write this workgroup's slab
+    float *red = lds;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    f32x4 *p = reinterpret_cast<f32x4 *>(red + ((i * NTT + t) * 64 + lane) * 4);
+                    if (w == 0) *p = acc[i][t];
+                    else *p = *p + acc[i][t];
+                }
+        }
+    }
+    __syncthreads();
+    float *slab = slabs + (long long)blockIdx.x * (CS * N);
+    for (int i = threadIdx.x; i < RED; i += DM_BLOCK) {
+        const int j = i & 3, l = (i >> 2) & 63, tt = i >> 8;
+        const int t = tt % NTT, mi = tt / NTT;
+        const int cs = 16 * mi + 4 * (l >> 4) + j, n = 16 * t + (l & 15);
+        if (cs < CS && n < N) slab[cs * N + n] = red[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nslabs, int E,
+                                                          float *__restrict__ dst)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float s = 0.f;
+    for (int i = 0; i < nslabs; ++i) s += slabs[(long long)i * E + e];
+    dst[e] = s;
+}
+
+int wgrad_tw(int Ws) { return Ws < 64 ? Ws : 64; }
+
+// LDS floats of the S + T tiles for a TH-row tile; 8 rows unless that overflows the 64 KB static limit.
+constexpr int wgrad_tile_floats(int CS, int CT, int KK, int TH, int TW)
+{
+    const int s = KK == 4 ? 2 : 1, pad = KK == 1 ? 0 : 1;
+    const int pss_raw = TH * TW, pss = pss_raw + ((4 - (pss_raw % 32)) + 32) % 32;
+    return CS * pss + CT * (TH * s + KK - s) * (TW * s + 8 * pad);
+}
+constexpr int wgrad_th(int CS, int CT, int KK, int TW)
+{
+    return wgrad_tile_floats(CS, CT, KK, 8, TW) <= 15800 ? 8 : 4;
+}
+
+template <int CS, int CT, int KK, int TW>
+void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int CTphys, int Hs, int Ws, int grid,
+                  hipStream_t st)
+{
+    constexpr int TH = wgrad_th(CS, CT, KK, TW);
+    const int ntiles = B * (Hs / TH) * (Ws / TW);
+    hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs, CTphys, Hs,
+                       Ws, ntiles);
+}
+
+}  // namespace
+
+extern "C" int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k)
+{
+    const int TW = wgrad_tw(Ws);
+    if (TW <= 0 || (k != 4 && k != 3 && k != 1)) return -1;
+    const int TH = wgrad_th(CS, CT, k, TW);
+    if (Hs % TH || Ws % TW) return -1;
+    const long long ntiles = (long long)B * (Hs / TH) * (Ws / TW);
+    return (int)(ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS);
+}
+
+extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, float *dst,
+                        int B, int CS, int CT, int Hs, int Ws, int k, void *stream)
+{
+    if (dm_check_operand(S, "dm_wgrad(S)") || dm_check_operand(T, "dm_wgrad(T)")) return -1;
+    DM_REQUIRE(slabs && dst, "dm_wgrad: NULL output");
+    DM_REQUIRE(k == 4 || k == 3 || k == 1, "dm_wgrad: kernel size %d not built", k);
+    DM_REQUIRE(!S->ones_channel, "dm_wgrad: S cannot carry a ones channel");
+    const int TW = wgrad_tw(Ws), TH = wgrad_th(CS, CT, k, TW);
+    DM_REQUIRE((TW == 16 || TW == 32 || TW == 64) && Hs % TH == 0 && Ws % TW == 0,
+               "dm_wgrad: S spatial size %dx%d not tileable", Hs, Ws);
+    const int grid = dm_wgrad_num_blocks(B, CS, CT, Hs, Ws, k);
+    const int CTphys = CT - (T->ones_channel ? 1 : 0);
+    DM_REQUIRE(CTphys > 0, "dm_wgrad: no physical T channel");
+    hipStream_t st = (hipStream_t)stream;
+    const Operand s = to_dev(S), t = to_dev(T);
+    const int E = CS * CT * k * k;
+    bool done = false;
+#define DM_WG(CS_, CT_, K_, TW_)                                                         \
+    if (!done && CS == CS_ && CT == CT_ && k == K_ && TW == TW_) {                       \
+        launch_wgrad<CS_, CT_, K_, TW_>(s, t, slabs, B, CTphys, Hs, Ws, grid, st);       \
+        done = true;                                                                     \
+    }
+    // enc.0 o enc.1 composite (x with ones channel), enc.4, enc.7
+    DM_WG(8, 3, 4, 64) DM_WG(8, 3, 4, 32) DM_WG(8, 3, 4, 16) DM_WG(8, 5, 4, 64) DM_WG(8, 2, 4, 64) DM_WG(8, 4, 4, 64)
+    DM_WG(16, 8, 4, 32) DM_WG(16, 8, 4, 64) DM_WG(16, 8, 4, 16)
+    DM_WG(16, 16, 4, 16) DM_WG(16, 16, 4, 32)
+    // enc.10 and residual convs
+    DM_WG(16, 16, 3, 16) DM_WG(16, 16, 3, 32)
+    DM_WG(32, 16, 3, 16) DM_WG(32, 16, 3, 32)
+    DM_WG(16, 32, 1, 16) DM_WG(16, 32, 1, 32)
+    // decoder ConvTranspose2d layers (S = layer input, T = output gradient)
+    DM_WG(8, 4, 4, 32) DM_WG(8, 4, 4, 64)
+    DM_WG(4, 4, 4, 64)
+#undef DM_WG
+    if (!done) {
+        dm_set_error("dm_wgrad: no kernel built for CS=%d CT=%d k=%d width=%d", CS, CT, k, Ws);
+        return -1;
+    }
+    int rc = dm_launch_status("dm_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 255) / 256), dim3(256), 0, st, slabs, grid, E, dst);
+    return dm_launch_status("dm_wgrad(reduce)");
+}

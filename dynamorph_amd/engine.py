@@ -1,0 +1,268 @@
+"""Kernel orchestration for the VQ-VAE path: which HIP kernel runs on which tensor, in what order.
+
+Every function here only enqueues kernels from libdynamorph_hip.so on the current stream (via
+dynamorph_amd.ops); there is no ATen math and no host synchronisation, so a whole training step
+can be captured into a HIP graph.
+
+Layer map (reference HiddenStateExtractor/vq_vae.py:276-298, ResidualBlock :203-224):
+  enc.0 (1x1) o enc.1 (4x4/s2)  -> ONE 4x4/s2 conv on (x, 1): the composite weight is rebuilt
+                                    from the stored parameters every call (dm_e1_compose); the
+                                    ones channel carries enc.0's bias through the zero padding.
+  enc.2/3, enc.5/6, enc.8/9      -> BatchNorm(+ReLU) folded into the NEXT conv's operand load;
+                                    the producing conv's epilogue emits the (sum, sum^2) slabs.
+  enc.10, enc.11, enc.12         -> 3x3 conv, BN, residual stack (3x3 -> BN -> ReLU -> 1x1 -> BN, + skip)
+  dec.0/2/4 (ConvTranspose 4/2/1)-> 3x3-neighbourhood conv with N = 4 phases x Cout + pixel shuffle
+  dec.6 (1x1) + recon loss       -> fused VALU head kernel
+
+Backward mirrors it: each conv layer = one data-gradient kernel (whose epilogue applies the ReLU
+mask, joins the residual branch and emits the BatchNorm-backward reductions) + one weight-gradient
+kernel; BatchNorm backward itself is an AFFINE2 operand load.  Biases of convs that feed a
+train-mode BatchNorm have an identically zero gradient (the batch mean removes them) and are
+written as exact zeros.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .ops import (DM_LOAD_AFFINE, DM_LOAD_AFFINE2, DM_LOAD_AFFINE_RELU, DM_LOAD_IDENT, DM_LOAD_RELU, Op,
+                  weight_view)
+
+
+class Layers:
+    """Parameter handles resolved from a VQ_VAE-shaped nn.Module (state-dict names of the reference)."""
+
+    def __init__(self, model):
+        enc, dec = model.enc, model.dec
+        self.enc0, self.enc1, self.bn1 = enc[0], enc[1], enc[2]
+        self.enc4, self.bn2 = enc[4], enc[5]
+        self.enc7, self.bn3 = enc[7], enc[8]
+        self.enc10, self.bn4 = enc[10], enc[11]
+        self.res = [(l[1], l[2], l[4], l[5]) for l in enc[12].layers]
+        self.codebook = model.vq.w
+        self.dec0, self.dec2, self.dec4, self.dec6 = dec[0], dec[2], dec[4], dec[6]
+        self.channel_var = model.channel_var
+        self.nin = self.enc0.weight.shape[1]
+        self.nh = self.enc10.weight.shape[0]
+        self.nrh = self.res[0][0].weight.shape[0] if self.res else 0
+
+    def encoder_params(self):
+        ps = [self.enc0.weight, self.enc0.bias, self.enc1.weight, self.enc1.bias, self.bn1.weight, self.bn1.bias,
+              self.enc4.weight, self.enc4.bias, self.bn2.weight, self.bn2.bias,
+              self.enc7.weight, self.enc7.bias, self.bn3.weight, self.bn3.bias,
+              self.enc10.weight, self.enc10.bias, self.bn4.weight, self.bn4.bias]
+        for ca, bna, cb, bnb in self.res:
+            ps += [ca.weight, ca.bias, bna.weight, bna.bias, cb.weight, cb.bias, bnb.weight, bnb.bias]
+        return ps
+
+    def decoder_params(self):
+        return [self.dec0.weight, self.dec0.bias, self.dec2.weight, self.dec2.bias,
+                self.dec4.weight, self.dec4.bias, self.dec6.weight, self.dec6.bias]
+
+
+# ------------------------------------------------------------------------- BatchNorm glue
+def _bn_coef(stats, bn, count, per_sample, nbatch):
+    """Batch statistics -> (coef, saved).  eval() mode (never used by the reference path) takes the
+    running statistics instead; its coefficients are three tiny device ops, no HIP kernel needed."""
+    if not bn.training:
+        scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        coef = torch.stack([scale, torch.zeros_like(scale), bn.bias.detach() - bn.running_mean * scale,
+                            torch.zeros_like(scale)], 1).contiguous()
+        return coef, None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    spg = stats.shape[0] // nbatch if per_sample else 1
+    return ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                           bn.num_batches_tracked, momentum, bn.eps, per_sample=per_sample, slabs_per_group=spg)
+
+
+def _w(p):
+    return p.detach()
+
+
+# ------------------------------------------------------------------------------- encoder
+def encoder_forward(L, x, per_sample=False):
+    """x (B,NIN,H,W) -> z_before (B,nh,H/8,W/8).  per_sample=True normalises every BatchNorm with
+    that sample's own statistics = pipeline/patch_VAE.py:445-452 (batch-of-one calls in train mode)."""
+    B, NIN, H, W = x.shape
+    nh, nrh, c1 = L.nh, L.nrh, L.nh // 2
+    ps = per_sample
+    cx = SimpleNamespace(x=x, per_sample=ps, B=B, H=H, W=W, res=[])
+
+    weff = ops.e1_compose(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight))
+    H1, W1 = H // 2, W // 2
+    a1, st = ops.conv4x4s2(Op(x, ones=True), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN + 1, c1, H, W,
+                           want_stats=True, bias=_w(L.enc1.bias))
+    coef1, saved1 = _bn_coef(st, L.bn1, H1 * W1 * (1 if ps else B), ps, B)
+
+    H2, W2 = H1 // 2, W1 // 2
+    a2, st = ops.conv4x4s2(Op(a1, DM_LOAD_AFFINE_RELU, coef1, per_sample=ps), weight_view(_w(L.enc4.weight), c1 * 16, 16, 4, 1),
+                           B, c1, nh, H1, W1, want_stats=True, bias=_w(L.enc4.bias))
+    coef2, saved2 = _bn_coef(st, L.bn2, H2 * W2 * (1 if ps else B), ps, B)
+
+    H3, W3 = H2 // 2, W2 // 2
+    a3, st = ops.conv4x4s2(Op(a2, DM_LOAD_AFFINE_RELU, coef2, per_sample=ps), weight_view(_w(L.enc7.weight), nh * 16, 16, 4, 1),
+                           B, nh, nh, H2, W2, want_stats=True, bias=_w(L.enc7.bias))
+    n3 = H3 * W3 * (1 if ps else B)
+    coef3, saved3 = _bn_coef(st, L.bn3, n3, ps, B)
+
+    a4, st = ops.conv3x3(Op(a3, DM_LOAD_AFFINE_RELU, coef3, per_sample=ps), weight_view(_w(L.enc10.weight), nh * 9, 9, 3, 1),
+                         B, nh, nh, H3, W3, taps=9, want_stats=True, bias=_w(L.enc10.bias))
+    coef4, saved4 = _bn_coef(st, L.bn4, n3, ps, B)
+    h = ops.apply(Op(a4, DM_LOAD_AFFINE, coef4, per_sample=ps), B, nh, H3, W3)
+
+    cx.__dict__.update(a1=a1, a2=a2, a3=a3, a4=a4, coef1=coef1, coef2=coef2, coef3=coef3, coef4=coef4,
+                       saved1=saved1, saved2=saved2, saved3=saved3, saved4=saved4, dims=(H1, W1, H2, W2, H3, W3))
+    z, cx.res = residual_forward(L.res, h, ps)
+    return z, cx
+
+
+def residual_forward(res_layers, h, per_sample=False):
+    """ResidualBlock.forward (vq_vae.py:212-225) on a materialised h (B,nh,H,W)."""
+    B, nh, H, W = h.shape
+    n = H * W * (1 if per_sample else B)
+    saved = []
+    for ca, bna, cb, bnb in res_layers:
+        nrh = ca.weight.shape[0]
+        ra, st = ops.conv3x3(Op(h, DM_LOAD_RELU), weight_view(_w(ca.weight), nh * 9, 9, 3, 1), B, nh, nrh, H, W, taps=9,
+                             want_stats=True, bias=_w(ca.bias))
+        coefa, saveda = _bn_coef(st, bna, n, per_sample, B)
+        rb, st = ops.conv3x3(Op(ra, DM_LOAD_AFFINE_RELU, coefa, per_sample=per_sample), weight_view(_w(cb.weight), nrh, 1, 0, 0),
+                             B, nrh, nh, H, W, taps=1, want_stats=True, bias=_w(cb.bias))
+        coefb, savedb = _bn_coef(st, bnb, n, per_sample, B)
+        hn = ops.apply(Op(rb, DM_LOAD_AFFINE, coefb, per_sample=per_sample), B, nh, H, W, resid=h)
+        saved.append(SimpleNamespace(h_in=h, ra=ra, rb=rb, coefa=coefa, saveda=saveda, coefb=coefb, savedb=savedb))
+        h = hn
+    return h, saved
+
+
+def _zero(t):
+    t.zero_()
+
+
+def residual_backward(res_layers, saved, g_h, G, q_below):
+    """Gradient of the residual stack.  g_h: gradient w.r.t. its output.  q_below: the raw conv output
+    whose BatchNorm produced the stack's input (None if there is none); when given, the returned stats
+    are the (sum g, sum g*q_below) slabs that BatchNorm's backward needs.  Returns (g_in, stats)."""
+    if not saved:
+        return g_h, (ops.channel_stats(g_h, q_below) if q_below is not None else None)
+    B, nh, H, W = g_h.shape
+    cnt = B * H * W
+    stats = ops.channel_stats(g_h, saved[-1].rb)
+    for i in range(len(saved) - 1, -1, -1):
+        ca, bna, cb, bnb = res_layers[i]
+        s = saved[i]
+        nrh = ca.weight.shape[0]
+        if s.savedb is None or s.coefb.dim() != 2:
+            raise NotImplementedError("backward needs batch-statistics BatchNorm (train mode, per_sample=False)")
+        cb_bwd = ops.bn_backward_finalize(stats, cnt, _w(bnb.weight), s.savedb, G(bnb.weight), G(bnb.bias))
+        da_rb = Op(g_h, DM_LOAD_AFFINE2, cb_bwd, p1=s.rb)
+        ops.wgrad(da_rb, Op(s.ra, DM_LOAD_AFFINE_RELU, s.coefa), G(cb.weight), B, nh, nrh, H, W, 1)
+        _zero(G(cb.bias))
+        dy_ra, st = ops.conv3x3(da_rb, weight_view(_w(cb.weight), 1, nrh, 0, 0), B, nh, nrh, H, W, taps=1, want_stats=True,
+                                like=g_h, mask=Op(s.ra, DM_LOAD_AFFINE, s.coefa), stat_q=s.ra)
+        ca_bwd = ops.bn_backward_finalize(st, cnt, _w(bna.weight), s.saveda, G(bna.weight), G(bna.bias))
+        da_ra = Op(dy_ra, DM_LOAD_AFFINE2, ca_bwd, p1=s.ra)
+        ops.wgrad(da_ra, Op(s.h_in, DM_LOAD_RELU), G(ca.weight), B, nrh, nh, H, W, 3)
+        _zero(G(ca.bias))
+        q = saved[i - 1].rb if i > 0 else q_below
+        g_h, stats = ops.conv3x3(da_ra, weight_view(_w(ca.weight), 9, nh * 9, -3, -1, off=8), B, nrh, nh, H, W, taps=9,
+                                 want_stats=q is not None, like=g_h, mask=Op(s.h_in), resid=g_h, stat_q=q)
+    return g_h, stats
+
+
+def encoder_backward(L, cx, g_z, G):
+    """Accumulates nothing: every parameter gradient G(p) is overwritten.  No gradient flows to x."""
+    if cx.per_sample and cx.B > 1:
+        raise NotImplementedError("backward through per-sample BatchNorm statistics with B > 1")
+    if cx.saved1 is None:
+        raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
+    B, x = cx.B, cx.x
+    NIN, nh, c1 = L.nin, L.nh, L.nh // 2
+    H1, W1, H2, W2, H3, W3 = cx.dims
+    g_z = g_z.contiguous()
+
+    g_h, stats = residual_backward(L.res, cx.res, g_z, G, cx.a4)
+    cnt3 = B * H3 * W3
+    c4b = ops.bn_backward_finalize(stats, cnt3, _w(L.bn4.weight), cx.saved4, G(L.bn4.weight), G(L.bn4.bias))
+    da4 = Op(g_h, DM_LOAD_AFFINE2, c4b, p1=cx.a4)
+    ops.wgrad(da4, Op(cx.a3, DM_LOAD_AFFINE_RELU, cx.coef3), G(L.enc10.weight), B, nh, nh, H3, W3, 3)
+    _zero(G(L.enc10.bias))
+    dy3, st = ops.conv3x3(da4, weight_view(_w(L.enc10.weight), 9, nh * 9, -3, -1, off=8), B, nh, nh, H3, W3, taps=9,
+                          want_stats=True, like=g_h, mask=Op(cx.a3, DM_LOAD_AFFINE, cx.coef3), stat_q=cx.a3)
+
+    c3b = ops.bn_backward_finalize(st, cnt3, _w(L.bn3.weight), cx.saved3, G(L.bn3.weight), G(L.bn3.bias))
+    da3 = Op(dy3, DM_LOAD_AFFINE2, c3b, p1=cx.a3)
+    ops.wgrad(da3, Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), G(L.enc7.weight), B, nh, nh, H3, W3, 4)
+    _zero(G(L.enc7.bias))
+    dy2, st = ops.conv3x3(da3, weight_view(_w(L.enc7.weight), 16, nh * 16, 4, 1), B, nh, 4 * nh, H3, W3, taps=9,
+                          pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a2, DM_LOAD_AFFINE, cx.coef2),
+                          stat_q=cx.a2)
+
+    c2b = ops.bn_backward_finalize(st, B * H2 * W2, _w(L.bn2.weight), cx.saved2, G(L.bn2.weight), G(L.bn2.bias))
+    da2 = Op(dy2, DM_LOAD_AFFINE2, c2b, p1=cx.a2)
+    ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(L.enc4.weight), B, nh, c1, H2, W2, 4)
+    _zero(G(L.enc4.bias))
+    dy1, st = ops.conv3x3(da2, weight_view(_w(L.enc4.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
+                          pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
+                          stat_q=cx.a1)
+
+    c1b = ops.bn_backward_finalize(st, B * H1 * W1, _w(L.bn1.weight), cx.saved1, G(L.bn1.weight), G(L.bn1.bias))
+    da1 = Op(dy1, DM_LOAD_AFFINE2, c1b, p1=cx.a1)
+    dweff = torch.empty((c1, NIN + 1, 4, 4), device=x.device, dtype=torch.float32)
+    ops.wgrad(da1, Op(x, ones=True), dweff, B, c1, NIN + 1, H1, W1, 4)
+    ops.e1_chain(dweff, _w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight),
+                 G(L.enc0.weight), G(L.enc0.bias), G(L.enc1.weight))
+    _zero(G(L.enc1.bias))
+
+
+# ------------------------------------------------------------------------------------ VQ
+def vq_forward(codebook, z, commitment_cost, want_out=True):
+    B, D, H, W = z.shape
+    idx, out, slabs, hist = ops.vq_forward(z, _w(codebook), want_out=want_out)
+    scalars = ops.vq_finalize(slabs, hist, B * H * W, D, commitment_cost)     # (loss, perplexity, mse)
+    return out, idx, scalars
+
+
+# -------------------------------------------------------------------------------- decoder
+def decoder_forward(L, zq, x=None, mask=None):
+    B, nh, H3, W3 = zq.shape
+    c1, c2 = nh // 2, nh // 4
+    d0, _ = ops.conv3x3(Op(zq), weight_view(_w(L.dec0.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H3, W3, taps=9,
+                        pixel_shuffle=True, bias=_w(L.dec0.bias), relu=True)
+    d2, _ = ops.conv3x3(Op(d0), weight_view(_w(L.dec2.weight), 16, c2 * 16, 4, 1), B, c1, 4 * c2, 2 * H3, 2 * W3, taps=9,
+                        pixel_shuffle=True, bias=_w(L.dec2.bias), relu=True)
+    d4, _ = ops.conv3x3(Op(d2), weight_view(_w(L.dec4.weight), 16, c2 * 16, 4, 1), B, c2, 4 * c2, 4 * H3, 4 * W3, taps=9,
+                        pixel_shuffle=True, bias=_w(L.dec4.bias), relu=True)
+    dec, slabs = ops.head_forward(d4, _w(L.dec6.weight), _w(L.dec6.bias), x, mask, _w(L.channel_var).reshape(-1))
+    cx = SimpleNamespace(zq=zq, d0=d0, d2=d2, d4=d4, dec=dec, x=x, mask=mask, loss_slabs=slabs)
+    return dec, cx
+
+
+def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
+    """gscale: 1-element device tensor = d(total)/d(recon_loss) (None: no loss term);
+    gdec_ext: upstream gradient w.r.t. decoded (None: none)."""
+    zq = cx.zq
+    B, nh, H3, W3 = zq.shape
+    c1, c2 = nh // 2, nh // 4
+    NIN = L.dec6.weight.shape[0]
+    g4, part = ops.head_backward(cx.dec, cx.x, cx.mask, _w(L.channel_var).reshape(-1), cx.d4, _w(L.dec6.weight),
+                                 gscale, gdec_ext)
+    flat = torch.empty(part.shape[1], device=zq.device, dtype=torch.float32)
+    ops.sum_slabs(part, flat)
+    G(L.dec6.weight).copy_(flat[:NIN * c2].view_as(L.dec6.weight))
+    G(L.dec6.bias).copy_(flat[NIN * c2:NIN * c2 + NIN])
+    G(L.dec4.bias).copy_(flat[NIN * c2 + NIN:])
+
+    ops.wgrad(Op(cx.d2), Op(g4), G(L.dec4.weight), B, c2, c2, 4 * H3, 4 * W3, 4)
+    g2, st = ops.conv4x4s2(Op(g4), weight_view(_w(L.dec4.weight), c2 * 16, 16, 4, 1), B, c2, c2, 8 * H3, 8 * W3,
+                           want_stats=True, mask=Op(cx.d2))
+    ops.sum_slabs(st, G(L.dec2.bias))
+    ops.wgrad(Op(cx.d0), Op(g2), G(L.dec2.weight), B, c1, c2, 2 * H3, 2 * W3, 4)
+    g0, st = ops.conv4x4s2(Op(g2), weight_view(_w(L.dec2.weight), c2 * 16, 16, 4, 1), B, c2, c1, 4 * H3, 4 * W3,
+                           want_stats=True, mask=Op(cx.d0))
+    ops.sum_slabs(st, G(L.dec0.bias))
+    ops.wgrad(Op(zq), Op(g0), G(L.dec0.weight), B, nh, c1, H3, W3, 4)
+    if not want_gz:
+        return None
+    g_zq, _ = ops.conv4x4s2(Op(g0), weight_view(_w(L.dec0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H3, 2 * W3)
+    return g_zq

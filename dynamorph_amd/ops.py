@@ -1,0 +1,290 @@
+"""Tensor-level wrappers over the C ABI: they take CUDA (ROCm) torch tensors, pass raw
+device pointers and the current HIP stream, and allocate outputs with PyTorch.
+
+Nothing here computes on the host and nothing falls back to ATen: a tensor that is not a
+contiguous fp32 device tensor is an error.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import DM_LOAD_AFFINE, DM_LOAD_AFFINE2, DM_LOAD_AFFINE_RELU, DM_LOAD_IDENT, DM_LOAD_RELU  # noqa: F401
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("dynamorph_amd: tensor is not on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise ValueError(f"dynamorph_amd: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("dynamorph_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+class Op:
+    """A tensor together with its on-load transform (dm_operand)."""
+    __slots__ = ("p0", "p1", "coef", "mode", "ones", "bstride", "_keep")
+
+    def __init__(self, p0, mode=DM_LOAD_IDENT, coef=None, p1=None, ones=False, per_sample=False):
+        self.p0, self.p1, self.coef, self.mode, self.ones = p0, p1, coef, mode, ones
+        self.bstride = coef.shape[-2] * 4 if (per_sample and coef is not None) else 0
+
+    def struct(self):
+        return L.Operand(_ptr(self.p0), _ptr(self.p1), _ptr(self.coef), self.bstride, self.mode, 1 if self.ones else 0)
+
+
+def _null_operand():
+    return L.Operand(None, None, None, 0, DM_LOAD_IDENT, 0)
+
+
+class WView:
+    """dm_weight_view plus a reference to the tensor it points into (a bare struct would dangle as soon
+    as a temporary such as `w.to(device)` is collected and the caching allocator reuses its block)."""
+    __slots__ = ("struct", "_keep")
+
+    def __init__(self, w, sn, sc, sky, skx, off=0):
+        self._keep = w
+        self.struct = L.WeightView(_ptr(w), off, sn, sc, sky, skx)
+
+
+def weight_view(w, sn, sc, sky, skx, off=0):
+    return WView(w, sn, sc, sky, skx, off)
+
+
+def epilogue(bias=None, relu=False, mask=None, resid=None, stat_q=None, stats=None):
+    m = mask.struct() if mask is not None else _null_operand()
+    return L.Epilogue(_ptr(bias), 1 if relu else 0, 0, m, _ptr(resid), _ptr(stat_q), _ptr(stats, torch.float64))
+
+
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------- VQ
+def vq_forward(z, codebook, want_idx=True, want_out=True):
+    """Returns (idx int64 (B,H,W), out (B,D,H,W), sse_slabs, hist)."""
+    lib = L.load()
+    B, D, H, W = z.shape
+    K = codebook.shape[0]
+    nb = lib.dm_vq_num_blocks(B * H * W)
+    idx = _new((B, H, W), z, torch.int64) if want_idx else None
+    out = torch.empty_like(z) if want_out else None
+    slabs = _new((nb,), z, torch.float64)
+    hist = torch.zeros(K, device=z.device, dtype=torch.int32)
+    wsb = lib.dm_vq_workspace_bytes(K, D)
+    ws = _new((wsb // 4,), z)
+    L.check(lib.dm_vq_forward(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out), _ptr(slabs, torch.float64),
+                              _ptr(hist, torch.int32), B, D, K, H, W, _ptr(ws), wsb, _stream()), "dm_vq_forward")
+    return idx, out, slabs, hist
+
+
+def vq_finalize(slabs, hist, positions, D, commitment_cost):
+    lib = L.load()
+    scalars = _new((3,), slabs)
+    L.check(lib.dm_vq_finalize(_ptr(slabs, torch.float64), slabs.numel(), _ptr(hist, torch.int32), hist.numel(),
+                               positions, D, commitment_cost, _ptr(scalars), _stream()), "dm_vq_finalize")
+    return scalars
+
+
+def vq_decode(idx, codebook):
+    lib = L.load()
+    B, H, W = idx.shape
+    K, D = codebook.shape
+    q = _new((B, D, H, W), codebook)
+    L.check(lib.dm_vq_decode(_ptr(idx, torch.int64), _ptr(codebook), _ptr(q), B, D, K, H, W, _stream()), "dm_vq_decode")
+    return q
+
+
+def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_dz=True):
+    """g_loss: 1-element device tensor (or None = 1).  dw is accumulated into (zero it first)."""
+    lib = L.load()
+    B, D, H, W = z.shape
+    K = codebook.shape[0]
+    dz = torch.empty_like(z) if want_dz else None
+    if dw is None:
+        dw = torch.zeros_like(codebook)
+    L.check(lib.dm_vq_backward(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(g_out), _ptr(g_loss),
+                               commitment_cost, _ptr(dz), _ptr(dw), B, D, K, H, W, _stream()), "dm_vq_backward")
+    return dz, dw
+
+
+# ---------------------------------------------------------------------- convolutions
+def conv4x4s2(inp, wv, B, CIN, NOUT, H, W, ep=None, out=None, want_stats=False, like=None, **epkw):
+    lib = L.load()
+    like = like if like is not None else inp.p0
+    if out is None:
+        out = _new((B, NOUT, H // 2, W // 2), like)
+    stats = None
+    if want_stats:
+        nb = lib.dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W)
+        if nb <= 0:
+            raise ValueError(f"dm_conv4x4s2: shape {(B, CIN, NOUT, H, W)} not tileable")
+        stats = _new((nb, NOUT, 2), like, torch.float64)
+    e = epilogue(stats=stats, **epkw)
+    o = inp.struct()
+    L.check(lib.dm_conv4x4s2(C.byref(o), C.byref(wv.struct), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, _stream()),
+            "dm_conv4x4s2")
+    return out, stats
+
+
+def conv3x3(inp, wv, B, CIN, NOUT, H, W, taps=9, pixel_shuffle=False, out=None, want_stats=False, like=None, **epkw):
+    lib = L.load()
+    like = like if like is not None else inp.p0
+    co = NOUT // 4 if pixel_shuffle else NOUT
+    if out is None:
+        out = _new((B, co, 2 * H, 2 * W) if pixel_shuffle else (B, co, H, W), like)
+    stats = None
+    if want_stats:
+        nb = lib.dm_conv3x3_num_blocks(B, CIN, NOUT, H, W, taps, 1 if pixel_shuffle else 0)
+        if nb <= 0:
+            raise ValueError(f"dm_conv3x3: shape {(B, CIN, NOUT, H, W)} not tileable")
+        stats = _new((nb, co, 2), like, torch.float64)
+    e = epilogue(stats=stats, **epkw)
+    o = inp.struct()
+    L.check(lib.dm_conv3x3(C.byref(o), C.byref(wv.struct), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, taps,
+                           1 if pixel_shuffle else 0, _stream()), "dm_conv3x3")
+    return out, stats
+
+
+def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k):
+    """dst (CS*CT*k*k floats, any shape) <- sum over batch/positions; deterministic slab reduction."""
+    lib = L.load()
+    nb = lib.dm_wgrad_num_blocks(B, CS, CT, Hs, Ws, k)
+    if nb <= 0:
+        raise ValueError(f"dm_wgrad: shape {(B, CS, CT, Hs, Ws, k)} not tileable")
+    slabs = _new((nb, CS * CT * k * k), dst)
+    s, t = S.struct(), T.struct()
+    L.check(lib.dm_wgrad(C.byref(s), C.byref(t), _ptr(slabs), _ptr(dst), B, CS, CT, Hs, Ws, k, _stream()), "dm_wgrad")
+    return dst
+
+
+# ------------------------------------------------------------------------ BatchNorm
+def bn_finalize(stats, count_per_group, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                per_sample=False, slabs_per_group=1):
+    lib = L.load()
+    nslabs, Cn = stats.shape[0], stats.shape[1]
+    if per_sample:
+        Bn = nslabs // slabs_per_group
+        coef = _new((Bn, Cn, 4), gamma)
+        saved = _new((Bn, Cn, 2), gamma)
+    else:
+        coef = _new((Cn, 4), gamma)
+        saved = _new((Cn, 2), gamma)
+    L.check(lib.dm_bn_finalize(_ptr(stats, torch.float64), nslabs, slabs_per_group, Cn, count_per_group, _ptr(gamma),
+                               _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(nbt, torch.int64), momentum,
+                               eps, _ptr(coef), _ptr(saved), 1 if per_sample else 0, _stream()), "dm_bn_finalize")
+    return coef, saved
+
+
+def bn_backward_finalize(stats, count, gamma, saved, dgamma, dbeta):
+    lib = L.load()
+    nslabs, Cn = stats.shape[0], stats.shape[1]
+    coef_bwd = _new((Cn, 4), gamma)
+    L.check(lib.dm_bn_backward_finalize(_ptr(stats, torch.float64), nslabs, Cn, count, _ptr(gamma), _ptr(saved),
+                                        _ptr(dgamma), _ptr(dbeta), _ptr(coef_bwd), _stream()), "dm_bn_backward_finalize")
+    return coef_bwd
+
+
+def apply(inp, B, Cn, H, W, resid=None, out=None):
+    lib = L.load()
+    if out is None:
+        out = _new((B, Cn, H, W), inp.p0)
+    o = inp.struct()
+    L.check(lib.dm_apply(C.byref(o), _ptr(resid), _ptr(out), B, Cn, H, W, _stream()), "dm_apply")
+    return out
+
+
+def channel_stats(p, q=None):
+    lib = L.load()
+    B, Cn, H, W = p.shape
+    nb = lib.dm_channel_stats_num_blocks(B, Cn, H, W)
+    stats = _new((nb, Cn, 2), p, torch.float64)
+    L.check(lib.dm_channel_stats(_ptr(p), _ptr(q), _ptr(stats, torch.float64), B, Cn, H, W, _stream()), "dm_channel_stats")
+    return stats
+
+
+def sum_slabs(stats, dst, scale=1.0, n=None):
+    """dst[i] = scale * sum_slabs stats[slab][i][0] for the first n = dst.numel() entries of the slab rows."""
+    lib = L.load()
+    N = stats.shape[1]
+    L.check(lib.dm_sum_slabs(_ptr(stats, torch.float64), stats.shape[0], N, scale, _ptr(dst), _stream()), "dm_sum_slabs")
+    return dst
+
+
+# ------------------------------------------------------------------------------ head
+def head_forward(d4, w6, b6, x, mask, channel_var):
+    lib = L.load()
+    B, C4, H, W = d4.shape
+    NIN = w6.shape[0]
+    dec = _new((B, NIN, H, W), d4)
+    slabs = None
+    if x is not None:
+        slabs = _new((lib.dm_head_num_blocks(B, H, W),), d4, torch.float64)
+    mc = mask.shape[1] if mask is not None else 0
+    L.check(lib.dm_head_forward(_ptr(d4), _ptr(w6), _ptr(b6), _ptr(x), _ptr(mask), mc, _ptr(channel_var), _ptr(dec),
+                                _ptr(slabs, torch.float64), B, C4, NIN, H, W, _stream()), "dm_head_forward")
+    return dec, slabs
+
+
+def head_backward(dec, x, mask, channel_var, d4, w6, gscale, gdec_ext=None):
+    """Returns (g4, part) with part: (nblocks, NIN*C4 + NIN + C4, 2) float64 slabs."""
+    lib = L.load()
+    B, C4, H, W = d4.shape
+    NIN = w6.shape[0]
+    g4 = torch.empty_like(d4)
+    part = _new((lib.dm_head_num_blocks(B, H, W), NIN * C4 + NIN + C4, 2), d4, torch.float64)
+    mc = mask.shape[1] if mask is not None else 0
+    L.check(lib.dm_head_backward(_ptr(dec), _ptr(x), _ptr(mask), mc, _ptr(channel_var), _ptr(d4), _ptr(w6),
+                                 _ptr(gscale), _ptr(gdec_ext), _ptr(g4), _ptr(part, torch.float64), B, C4, NIN, H, W,
+                                 _stream()), "dm_head_backward")
+    return g4, part
+
+
+def loss_finalize(loss_slabs, count, vq_scalars, weight_recon, weight_commitment):
+    lib = L.load()
+    out = _new((4,), vq_scalars)
+    L.check(lib.dm_loss_finalize(_ptr(loss_slabs, torch.float64), loss_slabs.numel(), count, _ptr(vq_scalars),
+                                 weight_recon, weight_commitment, _ptr(out), _stream()), "dm_loss_finalize")
+    return out
+
+
+# ------------------------------------------------------------- composition / optimizer
+def e1_compose(w0, b0, w1):
+    lib = L.load()
+    C0, NIN = w0.shape[0], w0.shape[1]
+    C1 = w1.shape[0]
+    weff = _new((C1, NIN + 1, 4, 4), w1)
+    L.check(lib.dm_e1_compose(_ptr(w0), _ptr(b0), _ptr(w1), _ptr(weff), NIN, C0, C1, _stream()), "dm_e1_compose")
+    return weff
+
+
+def e1_chain(dweff, w0, b0, w1, dw0, db0, dw1):
+    lib = L.load()
+    C0, NIN = w0.shape[0], w0.shape[1]
+    C1 = w1.shape[0]
+    L.check(lib.dm_e1_chain(_ptr(dweff), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(dw0), _ptr(db0), _ptr(dw1), NIN, C0, C1,
+                            _stream()), "dm_e1_chain")
+
+
+def adam(param, grad, m, v, lr, beta1, beta2, eps, step_dev):
+    lib = L.load()
+    L.check(lib.dm_adam(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
+                        _ptr(step_dev), _stream()), "dm_adam")
+
+
+def augment(x, flip_code, rot_code):
+    lib = L.load()
+    B, Cn, H, W = x.shape
+    if H != W:
+        raise ValueError("dm_augment: square patches only")
+    out = torch.empty_like(x)
+    L.check(lib.dm_augment(_ptr(x), _ptr(out), _ptr(flip_code, torch.int32), _ptr(rot_code, torch.int32), B, Cn, H,
+                           _stream()), "dm_augment")
+    return out

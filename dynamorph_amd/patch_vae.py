@@ -1,0 +1,82 @@
+"""Latent-encoding driver: mirror of pipeline/patch_VAE.py::process_VAE (VQ branch, lines 343-462).
+
+The reference encodes one patch at a time (batch-of-one `model.enc` -> `model.vq` calls with the model
+left in train mode, two device->host copies per patch).  Here whole batches run through the HIP
+encoder with PER-SAMPLE BatchNorm statistics, which is arithmetically the same thing
+ and keeps samples independent -- the property that lets the path shard over GPUs
+with no collective (dynamorph_amd.dist.shard_range).
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import engine as E
+from .train_utils import zscore_patch
+
+
+def encode_patches(model, patches, device="cuda:0", batch_size=1024):
+    """patches: (N, C, H, W) float tensor/array on the host.  Returns (z_before, z_after) as float32
+    numpy arrays of shape (N, D*H/8*W/8), in input order (patch_VAE.py:454,459)."""
+    patches = torch.as_tensor(patches)
+    if patches.dim() != 4:
+        raise AssertionError("dataset tensor dimension can only be 4, not {}".format(patches.dim()))
+    layers = E.Layers(model)
+    z_bs, z_as = [], []
+    with torch.no_grad():
+        for i in range(0, patches.shape[0], batch_size):
+            x = patches[i:i + batch_size].to(device=device, dtype=torch.float32).contiguous()
+            z_b, _ = E.encoder_forward(layers, x, per_sample=True)
+            z_a, _, _ = E.vq_forward(layers.codebook.weight, z_b, float(model.commitment_cost))
+            z_bs.append(z_b.reshape(x.shape[0], -1).cpu())
+            z_as.append(z_a.reshape(x.shape[0], -1).cpu())
+    if not z_bs:
+        return np.zeros((0, 0), np.float32), np.zeros((0, 0), np.float32)
+    return torch.cat(z_bs, 0).numpy(), torch.cat(z_as, 0).numpy()
+
+
+def process_VAE(raw_folder, supp_folder, sites, config_, gpu=0, network_module=None, **kwargs):
+    """Same contract as the reference: reads <raw>/<well>_file_paths.pkl and <well>_static_patches.pkl,
+    loads <weights>/model.pt, writes <raw>/<model_name>/<well>_latent_space[_after].pkl (protocol 4)."""
+    le = config_.latent_encoding
+    channels = le.channels
+    network = le.network
+    weights_dir = le.weights
+    assert len(channels) > 0, "At least one channel must be specified"
+    model_path = os.path.join(weights_dir, 'model.pt')
+    model_name = os.path.basename(weights_dir)
+    output_dir = os.path.join(raw_folder, model_name)
+    os.makedirs(output_dir, exist_ok=True)
+    assert len(set(site[:2] for site in sites)) == 1, "Sites should be from a single well/condition"
+    well = sites[0][:2]
+
+    with open(os.path.join(raw_folder, '%s_file_paths.pkl' % well), 'rb') as f:
+        fs = pickle.load(f)
+    with open(os.path.join(raw_folder, '%s_static_patches.pkl' % well), 'rb') as f:
+        dataset = pickle.load(f)
+    dataset = zscore_patch(np.squeeze(dataset))
+    dataset = torch.from_numpy(dataset).float()
+    assert dataset.dim() == 4, "dataset tensor dimension can only be 4, not {}".format(dataset.dim())
+    assert len(fs) == dataset.shape[0]
+    device = torch.device('cuda:%d' % gpu)
+    if 'VAE' not in network:
+        raise ValueError('Network {} is not available'.format(network))
+    if network_module is None:
+        from . import vq_vae as network_module
+    model = getattr(network_module, network)(num_inputs=dataset.shape[1],
+                                             num_hiddens=le.num_hiddens,
+                                             num_residual_hiddens=le.num_residual_hiddens,
+                                             num_residual_layers=2,
+                                             num_embeddings=le.num_embeddings,
+                                             gpu=True).to(device)
+    try:
+        model.load_state_dict(torch.load(model_path, map_location=device))
+    except Exception as ex:
+        print(ex)
+        raise ValueError("Error in loading model weights for VQ-VAE")
+    z_b, z_a = encode_patches(model, dataset, device=device, batch_size=kwargs.get("batch_size", 1024))
+    for name, dats in (('%s_latent_space.pkl' % well, z_b), ('%s_latent_space_after.pkl' % well, z_a)):
+        with open(os.path.join(output_dir, name), 'wb') as f:
+            pickle.dump(dats, f, protocol=4)
+    return z_b, z_a

@@ -1,0 +1,344 @@
+"""Drop-in nn.Module surface of the reference's VQ-VAE, computed by the HIP kernels.
+
+Mirrors (constructor signatures, attribute / submodule names, state-dict keys, return values):
+  VectorQuantizer  HiddenStateExtractor/vq_vae.py:25-116  (== vae.py:12-103)
+  ResidualBlock    HiddenStateExtractor/vq_vae.py:180-225
+  VQ_VAE           HiddenStateExtractor/vq_vae.py:228-342
+  VQ_VAE_z16       HiddenStateExtractor/vae.py:216-346
+so `getattr(vae, network)(**kw).to(device)`, `load_state_dict(torch.load(model.pt))`,
+`model.enc(x)`, `model.vq(z)`, `model(batch, time_matching_mat=..., batch_mask=...)`,
+`total_loss.backward()` and `optimizer.step()` (run_training.py:885-910, 404-408;
+pipeline/patch_VAE.py:425-452) work unchanged.
+
+The nn.Conv2d / BatchNorm2d / ConvTranspose2d / Embedding children are parameter containers only
+(that is what keeps the 68 state-dict keys); their ATen forward is never called.  All compute goes
+through dynamorph_amd.engine -> libdynamorph_hip.so.  Inputs must live on the GPU: there is no CPU
+fallback (a CPU tensor raises).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from . import ops
+
+CHANNEL_VAR = np.array([1., 1.])
+
+
+def _require_gpu(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: input is on {t.device}; the dynamorph_amd HIP path only runs on the GPU "
+                           "(no CPU fallback). Move the model and the batch to cuda first.")
+
+
+def _prep(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _GradBag:
+    """G(param) -> the tensor a backward kernel writes that parameter's gradient into."""
+
+    def __init__(self):
+        self.store = {}
+
+    def __call__(self, p):
+        g = self.store.get(id(p))
+        if g is None:
+            g = torch.empty_like(p)
+            self.store[id(p)] = g
+        return g
+
+    def grads_for(self, params, needs):
+        return tuple(self.store.get(id(p)) if need else None for p, need in zip(params, needs))
+
+
+# =============================================================================== autograd
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, layers, per_sample, *params):
+        z, cx = E.encoder_forward(layers, x, per_sample=per_sample)
+        ctx.layers, ctx.cx, ctx.params = layers, cx, params
+        return z
+
+    @staticmethod
+    def backward(ctx, g_z):
+        G = _GradBag()
+        E.encoder_backward(ctx.layers, ctx.cx, g_z, G)
+        ctx.cx = None
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the input patches is not implemented (the reference never asks for it)")
+        return (None, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[3:])
+
+
+class _ResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, res_layers, *params):
+        out, saved = E.residual_forward(res_layers, h)
+        ctx.res_layers, ctx.saved, ctx.params = res_layers, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        G = _GradBag()
+        g_in, _ = E.residual_backward(ctx.res_layers, ctx.saved, g.contiguous(), G, None)
+        ctx.saved = None
+        return (g_in, None) + G.grads_for(ctx.params, ctx.needs_input_grad[2:])
+
+
+class _VQFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, codebook, commitment_cost):
+        out, idx, scalars = E.vq_forward(codebook, z, commitment_cost)
+        ctx.save_for_backward(z, codebook, idx)
+        ctx.cc = commitment_cost
+        ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
+        return out, scalars[0], scalars[1], idx
+
+    @staticmethod
+    def backward(ctx, g_out, g_loss, g_perp, _g_idx):
+        z, codebook, idx = ctx.saved_tensors
+        if g_out is not None:
+            g_out = g_out.contiguous()
+        if g_loss is None:
+            g_loss = torch.zeros(1, device=z.device)
+        dz, dw = ops.vq_backward(z, codebook.detach(), idx, g_out, g_loss.reshape(1).contiguous(), ctx.cc,
+                                 want_dz=ctx.needs_input_grad[0])
+        return dz, (dw if ctx.needs_input_grad[1] else None), None
+
+
+class _DecoderFn(torch.autograd.Function):
+    """decoded (and, when x is given, the masked reconstruction loss of vq_vae.py:320-322)."""
+
+    @staticmethod
+    def forward(ctx, zq, x, mask, layers, *params):
+        dec, cx = E.decoder_forward(layers, zq, x, mask)
+        ctx.layers, ctx.cx, ctx.params = layers, cx, params
+        ctx.set_materialize_grads(False)
+        if x is None:
+            return dec, None
+        B, NIN, H, W = x.shape
+        zeros = torch.zeros(2, device=x.device)
+        recon = ops.loss_finalize(cx.loss_slabs, B * NIN * H * W, zeros, 1.0, 0.0)[0]
+        return dec, recon
+
+    @staticmethod
+    def backward(ctx, g_dec, g_recon):
+        G = _GradBag()
+        gscale = g_recon.reshape(1).contiguous() if g_recon is not None else None
+        if g_dec is not None:
+            g_dec = g_dec.contiguous()
+        if gscale is None and g_dec is None:
+            return (None,) * (4 + len(ctx.params))
+        g_zq = E.decoder_backward(ctx.layers, ctx.cx, gscale, g_dec, G, want_gz=ctx.needs_input_grad[0])
+        ctx.cx = None
+        return (g_zq, None, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[4:])
+
+
+# ================================================================================ modules
+class VectorQuantizer(nn.Module):
+    """Vector quantizer of "Neural Discrete Representation Learning" (reference vq_vae.py:25-116)."""
+
+    def __init__(self, embedding_dim=128, num_embeddings=128, commitment_cost=0.25, device='cuda:0'):
+        super(VectorQuantizer, self).__init__()
+        self.embedding_dim = embedding_dim
+        self.num_embeddings = num_embeddings
+        self.commitment_cost = commitment_cost
+        self.device = device
+        self.w = nn.Embedding(num_embeddings, embedding_dim)
+
+    def forward(self, inputs):
+        """inputs (B, D, H, W) -> (output_quantized, loss, perplexity)   [vq_vae.py:52-84]"""
+        _require_gpu(inputs, "VectorQuantizer.forward")
+        out, loss, perplexity, _ = _VQFn.apply(_prep(inputs), self.w.weight, float(self.commitment_cost))
+        assert out.shape == inputs.shape
+        return out, loss, perplexity
+
+    @property
+    def embeddings(self):
+        return self.w.weight
+
+    def encode_inputs(self, inputs):
+        """Index tensor (B, H, W) int64 of the nearest embedding vectors   [vq_vae.py:90-103]"""
+        _require_gpu(inputs, "VectorQuantizer.encode_inputs")
+        idx, _, _, _ = ops.vq_forward(_prep(inputs.detach()), self.w.weight.detach(), want_out=False)
+        return idx
+
+    def decode_inputs(self, encoding_indices):
+        """Quantized encodings (B, D, H, W) assembled from indices   [vq_vae.py:105-116]"""
+        _require_gpu(encoding_indices, "VectorQuantizer.decode_inputs")
+        return ops.vq_decode(encoding_indices.contiguous(), self.w.weight.detach())
+
+
+def _res_layer(num_hiddens, num_residual_hiddens):
+    return nn.Sequential(
+        nn.ReLU(),
+        nn.Conv2d(num_hiddens, num_residual_hiddens, 3, padding=1),
+        nn.BatchNorm2d(num_residual_hiddens),
+        nn.ReLU(),
+        nn.Conv2d(num_residual_hiddens, num_hiddens, 1),
+        nn.BatchNorm2d(num_hiddens))
+
+
+class ResidualBlock(nn.Module):
+    """output = output + layers[i](output)   (reference vq_vae.py:180-225)."""
+
+    def __init__(self, num_hiddens=128, num_residual_hiddens=512, num_residual_layers=2):
+        super(ResidualBlock, self).__init__()
+        self.num_hiddens = num_hiddens
+        self.num_residual_layers = num_residual_layers
+        self.num_residual_hiddens = num_residual_hiddens
+        self.layers = nn.ModuleList([_res_layer(num_hiddens, num_residual_hiddens)
+                                     for _ in range(num_residual_layers)])
+
+    def _handles(self):
+        return [(l[1], l[2], l[4], l[5]) for l in self.layers]
+
+    def forward(self, x):
+        _require_gpu(x, "ResidualBlock.forward")
+        hs = self._handles()
+        params = [p for ca, bna, cb, bnb in hs for p in (ca.weight, ca.bias, bna.weight, bna.bias,
+                                                         cb.weight, cb.bias, bnb.weight, bnb.bias)]
+        return _ResidualFn.apply(_prep(x), hs, *params)
+
+
+class _HipEncoder(nn.Sequential):
+    """`model.enc`: the nn.Sequential of the reference (same child indices), computed as one HIP pipeline."""
+
+    per_sample_stats = False
+
+    def forward(self, x):
+        _require_gpu(x, "VQ_VAE.enc")
+        layers = E.Layers(self._owner())
+        return _EncoderFn.apply(_prep(x), layers, self.per_sample_stats, *layers.encoder_params())
+
+
+class _HipDecoder(nn.Sequential):
+    """`model.dec`."""
+
+    def forward(self, z):
+        _require_gpu(z, "VQ_VAE.dec")
+        layers = E.Layers(self._owner())
+        dec, _ = _DecoderFn.apply(_prep(z), None, None, layers, *layers.decoder_params())
+        return dec
+
+
+class VQ_VAE(nn.Module):
+    """Vector-Quantized VAE with a 16 x 16 x num_hiddens latent (reference vq_vae.py:228-342)."""
+
+    _z16_loss = False
+
+    def __init__(self,
+                 num_inputs=2,
+                 num_hiddens=16,
+                 num_residual_hiddens=32,
+                 num_residual_layers=2,
+                 num_embeddings=64,
+                 commitment_cost=0.25,
+                 channel_var=CHANNEL_VAR,
+                 weight_recon=1.,
+                 weight_commitment=1.,
+                 weight_matching=0.005,
+                 device="cuda:0",
+                 w_a=1.1,
+                 w_t=0.1,
+                 w_n=-0.5,
+                 margin=0.5,
+                 **kwargs):
+        # callers pass gpu=True (pipeline/patch_VAE.py:431) or alpha/gpu (plot_scripts/recon_loss.py:18);
+        # the reference forwards them to nn.Module.__init__ and crashes on current torch -- swallow them.
+        for k in ("gpu", "alpha", "extra_loss"):
+            kwargs.pop(k, None)
+        super(VQ_VAE, self).__init__(**kwargs)
+        self.num_inputs = num_inputs
+        self.num_hiddens = num_hiddens
+        self.num_residual_layers = num_residual_layers
+        self.num_residual_hiddens = num_residual_hiddens
+        self.num_embeddings = num_embeddings
+        self.commitment_cost = commitment_cost
+        self.channel_var = nn.Parameter(
+            torch.from_numpy(np.asarray(channel_var, dtype=np.float64)).float().reshape((1, num_inputs, 1, 1)),
+            requires_grad=False)
+        self.weight_recon = weight_recon
+        self.weight_commitment = weight_commitment
+        self.weight_matching = weight_matching
+        self.w_a, self.w_t, self.w_n, self.margin = w_a, w_t, w_n, margin
+        nh = num_hiddens
+        self.enc = _HipEncoder(
+            nn.Conv2d(num_inputs, nh // 2, 1),
+            nn.Conv2d(nh // 2, nh // 2, 4, stride=2, padding=1),
+            nn.BatchNorm2d(nh // 2),
+            nn.ReLU(),
+            nn.Conv2d(nh // 2, nh, 4, stride=2, padding=1),
+            nn.BatchNorm2d(nh),
+            nn.ReLU(),
+            nn.Conv2d(nh, nh, 4, stride=2, padding=1),
+            nn.BatchNorm2d(nh),
+            nn.ReLU(),
+            nn.Conv2d(nh, nh, 3, padding=1),
+            nn.BatchNorm2d(nh),
+            ResidualBlock(nh, num_residual_hiddens, num_residual_layers))
+        self.vq = VectorQuantizer(nh, num_embeddings, commitment_cost=commitment_cost, device=device)
+        self.dec = _HipDecoder(
+            nn.ConvTranspose2d(nh, nh // 2, 4, stride=2, padding=1),
+            nn.ReLU(),
+            nn.ConvTranspose2d(nh // 2, nh // 4, 4, stride=2, padding=1),
+            nn.ReLU(),
+            nn.ConvTranspose2d(nh // 4, nh // 4, 4, stride=2, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(nh // 4, num_inputs, 1))
+        # weak back-references (not registered as submodules: state_dict stays the reference's 68 keys)
+        import weakref
+        ref = weakref.ref(self)
+        object.__setattr__(self.enc, "_owner", ref)
+        object.__setattr__(self.dec, "_owner", ref)
+
+    # ---- reference semantics of the pairwise term (kept in torch: "next" row of the scope table) ----
+    def _time_matching(self, z_before, time_matching_mat):
+        zf = z_before.reshape((z_before.shape[0], -1))
+        n = zf.shape[1]
+        sim_mat = torch.pow(zf.reshape((1, -1, n)) - zf.reshape((-1, 1, n)), 2).mean(2)
+        assert sim_mat.shape == time_matching_mat.shape
+        if not self._z16_loss:
+            return (sim_mat * time_matching_mat).sum()                      # vq_vae.py:331
+        wts = time_matching_mat.clone()                                      # vae.py:327-335
+        wts[time_matching_mat == 2] = self.w_a
+        wts[time_matching_mat == 1] = self.w_t
+        wts[time_matching_mat == 0] = self.w_n
+        val = sim_mat * wts
+        val = torch.where(time_matching_mat == 0, torch.clamp(val + self.margin, min=0), val)
+        return val.mean()
+
+    def forward(self, inputs, time_matching_mat=None, batch_mask=None):
+        """inputs (B, C, H, W) -> (decoded, loss dict)   [vq_vae.py:300-338]"""
+        _require_gpu(inputs, "VQ_VAE.forward")
+        x = _prep(inputs)
+        layers = E.Layers(self)
+        z_before = _EncoderFn.apply(x, layers, self.enc.per_sample_stats, *layers.encoder_params())
+        z_after, c_loss, perplexity, _ = _VQFn.apply(z_before, self.vq.w.weight, float(self.commitment_cost))
+        mask = _prep(batch_mask) if batch_mask is not None else None
+        decoded, recon_loss = _DecoderFn.apply(z_after, x, mask, layers, *layers.decoder_params())
+        total_loss = self.weight_recon * recon_loss + self.weight_commitment * c_loss
+        time_matching_loss = 0.
+        if time_matching_mat is not None:
+            time_matching_loss = self._time_matching(z_before, time_matching_mat)
+            total_loss = total_loss + self.weight_matching * time_matching_loss
+        if self._z16_loss:
+            return decoded, {'recon_loss': recon_loss, 'commitment_loss': c_loss,
+                             'time_matching_loss': time_matching_loss, 'perplexity': perplexity,
+                             'total_loss': total_loss}
+        return decoded, {'recon_loss': recon_loss, 'commitment_loss': c_loss,
+                         'time_matching_loss': time_matching_loss, 'total_loss': total_loss,
+                         'perplexity': perplexity}
+
+    def predict(self, inputs):
+        """Prediction fn, same as forward pass."""
+        return self.forward(inputs)
+
+
+class VQ_VAE_z16(VQ_VAE):
+    """vae.py:216-346: same network and state dict as VQ_VAE; weighted hinge time-matching loss and
+    'perplexity' listed before 'total_loss'."""
+    _z16_loss = True

@@ -1,0 +1,237 @@
+/*
+ * dynamorph_hip.h -- C ABI of libdynamorph_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (mehta-lab/dynamorph) has NO native code and no FFI: its
+ * VQ-VAE latent-encoding path is a sequence of PyTorch ATen ops issued from
+ *   HiddenStateExtractor/vq_vae.py:52-84   VectorQuantizer.forward
+ *   HiddenStateExtractor/vq_vae.py:276-298 VQ_VAE.enc / .dec (nn.Sequential)
+ *   HiddenStateExtractor/vq_vae.py:300-338 VQ_VAE.forward (losses)
+ *   run_training.py:404-408, :485          backward + Adam
+ *   pipeline/patch_VAE.py:445-452          per-sample enc -> vq loop.
+ * Each entry point below replaces the ATen op(s) named in its comment, so the
+ * binding a reference maintainer would add is "call this instead of the
+ * nn.Module's ATen kernel" (ctypes stubs: INTEGRATION.md).
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory owned by the caller (PyTorch allocates all
+ *    tensors and workspaces); the library never allocates, frees or retains.
+ *  - tensors are fp32, contiguous NCHW; indices are int64.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*)
+ *    and returns; no hidden synchronisation, no global mutable state.
+ *  - return 0 = ok; < 0 = argument/shape error detected on the host before any
+ *    launch (message via dm_last_error()); > 0 = hipError_t of a failed launch.
+ */
+#ifndef DYNAMORPH_HIP_H
+#define DYNAMORPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_VERSION 100
+
+/* ---- on-load operand transform ------------------------------------------
+ * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
+ * BatchNorm-backward formula are folded into the load of the consuming kernel.
+ *   IDENT        v = p0
+ *   RELU         v = max(p0, 0)
+ *   AFFINE       v = c0*p0 + c2                  (BatchNorm apply)
+ *   AFFINE_RELU  v = max(c0*p0 + c2, 0)          (BatchNorm + ReLU)
+ *   AFFINE2      v = c0*p0 + c1*p1 + c2          (BatchNorm backward: p0 = dy, p1 = conv output)
+ * coef is [C][4] floats (c0,c1,c2,unused), or [B][C][4] when coef_bstride != 0
+ * (per-sample BatchNorm statistics = pipeline/patch_VAE.py batch-of-one calls). */
+enum { DM_LOAD_IDENT = 0, DM_LOAD_RELU = 1, DM_LOAD_AFFINE = 2, DM_LOAD_AFFINE_RELU = 3, DM_LOAD_AFFINE2 = 4 };
+
+typedef struct dm_operand {
+    const float *p0;
+    const float *p1;
+    const float *coef;
+    int64_t coef_bstride;   /* floats between consecutive samples in coef; 0 = shared */
+    int32_t mode;           /* DM_LOAD_* */
+    int32_t ones_channel;   /* 1: append a synthetic channel that is 1 inside the image, 0 in the zero padding */
+} dm_operand;
+
+/* ---- weight view ----------------------------------------------------------
+ * Logical weight W[n][c][ky][kx] of the GEMM a kernel runs, addressed as
+ *   w[off + n_ch*sn + c*sc + ky*sky + kx*skx]
+ * so one kernel serves forward convs (PyTorch layout [co][ci][k][k]), their
+ * data gradients (transposed / flipped views) and ConvTranspose2d layouts
+ * ([ci][co][k][k]) without materialising a re-laid-out copy. */
+typedef struct dm_weight_view {
+    const float *w;
+    int64_t off, sn, sc, sky, skx;
+} dm_weight_view;
+
+/* ---- epilogue ---------------------------------------------------------------
+ *   v = acc + bias[n]; if relu v = max(v,0);
+ *   if mask.p0: v = (load(mask) > 0) ? v : 0          (ReLU backward)
+ *   if resid:   v += resid                             (residual-branch join)
+ *   out = v;  if stats: partial sums (sum v, sum v*q), q = stat_q ? stat_q : v,
+ *   written as doubles to stats[block][n][2] (one slab per workgroup; reduced by
+ *   dm_bn_finalize / dm_bn_backward_finalize / dm_sum_slabs: deterministic). */
+typedef struct dm_epilogue {
+    const float *bias;
+    int32_t relu;
+    int32_t _pad;
+    dm_operand mask;
+    const float *resid;
+    const float *stat_q;
+    double *stats;
+} dm_epilogue;
+
+const char *dm_last_error(void);
+int dm_version(void);
+
+/* ===== VectorQuantizer (vq_vae.py:52-116) ==================================== */
+
+/* Bytes of workspace dm_vq_forward needs for a K x D codebook. */
+size_t dm_vq_workspace_bytes(int K, int D);
+
+/* Replaces vq_vae.py:65-82: distances + argmax(-dist) + embedding gather +
+ * straight-through value + squared-error sum + code histogram.
+ *   z (B,D,H,W); codebook (K,D); idx (B,H,W) int64 [may be NULL];
+ *   out (B,D,H,W) = z + (q - z) [may be NULL];
+ *   sse_slabs: one double per workgroup (dm_vq_num_blocks of them);
+ *   hist: K int32 counters, must be zeroed by the caller.
+ * Distances are summed in the reference's order (blocks of 16 along D,
+ * sequential, no FMA) so indices are bit-identical to the CPU path. */
+int dm_vq_num_blocks(int64_t positions);
+int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *out,
+                  double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* vq_vae.py:105-116 decode_inputs: q[b,d,h,w] = codebook[idx[b,h,w], d]. */
+int dm_vq_decode(const int64_t *idx, const float *codebook, float *q,
+                 int B, int D, int K, int H, int W, void *stream);
+
+/* Reduces the slabs/histogram to the three scalars the module returns
+ * (vq_vae.py:74-82): scalars[0] = loss = mse + cc*mse, [1] = perplexity, [2] = mse. */
+int dm_vq_finalize(const double *sse_slabs, int nslabs, const int32_t *hist, int K,
+                   int64_t positions, int D, float commitment_cost, float *scalars, void *stream);
+
+/* Autograd of vq_vae.py:71-76 for upstream (g_out, g_loss):
+ *   dz = g_out + g_loss*2*cc*(z-q)/N   [g_out may be NULL = 0]
+ *   dw[k] += g_loss * sum_{idx=k} 2*(q-z)/N   (dw must be zeroed by the caller)
+ * g_loss is read from device memory (g_loss_dev[0]) so no host sync is needed. */
+int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
+                   const float *g_out, const float *g_loss_dev, float commitment_cost,
+                   float *dz, float *dw, int B, int D, int K, int H, int W, void *stream);
+
+/* ===== convolutions (nn.Conv2d / nn.ConvTranspose2d, vq_vae.py:276-298) ======= */
+
+/* 4x4, stride 2, padding 1 implicit-GEMM convolution on MFMA f32 16x16x4.
+ * in: (B,CIN,H,W) [CIN counts the synthetic ones channel if requested];
+ * out: (B,NOUT,H/2,W/2).  Replaces aten::convolution for enc.1/enc.4/enc.7 and
+ * aten::convolution_backward(data) of dec.0/dec.2/dec.4. */
+int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
+                 int B, int CIN, int NOUT, int H, int W, void *stream);
+int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W);
+
+/* 3x3 stride 1 padding 1 (taps = 9) or 1x1 (taps = 1) convolution on MFMA.
+ * pixel_shuffle = 1 turns it into a ConvTranspose2d(4, stride 2, padding 1):
+ * logical output channel n = co*4 + py*2 + px is written to out[co][2y+py][2x+px],
+ * the weight view addresses the 4x4 transposed-conv kernel ([c][co][ky][kx]
+ * through sc/sn/sky/skx) and the 3x3 neighbourhood tap (ty,tx) of phase (py,px)
+ * uses kernel element ky = py+3-2*ty, kx = px+3-2*tx when that lies in 0..3.
+ * Replaces aten::convolution (enc.10, residual convs), aten::conv_transpose2d
+ * (dec.0/2/4) and aten::convolution_backward(data) of every encoder conv. */
+int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
+               int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, void *stream);
+int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle);
+
+/* Weight gradient:  R[cs][ct][ky][kx] = sum_{b,y,x} S[b,cs,y,x] * T[b,ct,y*s+ky-p,x*s+kx-p]
+ * (k,s,p) in {(4,2,1),(3,1,1),(1,1,0)}.  For a Conv2d: S = output gradient,
+ * T = layer input, R = dW [co][ci][k][k].  For a ConvTranspose2d: S = layer
+ * input, T = output gradient, R = dW [ci][co][k][k].  Partial results go to
+ * `slabs` (nblocks x CS*CT*k*k floats, nblocks = dm_wgrad_num_blocks) and are
+ * summed in slab order into `dst` (deterministic). Replaces
+ * aten::convolution_backward(weight). */
+int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k);
+int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, float *dst,
+             int B, int CS, int CT, int Hs, int Ws, int k, void *stream);
+
+/* ===== BatchNorm2d in training mode (vq_vae.py:206,209,279-288) =============== */
+
+/* Forward finalize: reduce stats slabs (sum x, sum x^2) -> batch mean / biased
+ * variance -> coef[c] = (gamma*invstd, 0, beta - mean*gamma*invstd, 0),
+ * saved[c] = (mean, invstd); running stats updated with momentum and the
+ * unbiased variance, num_batches_tracked incremented (nn.BatchNorm2d defaults).
+ * per_sample = 1: slabs are grouped per sample (slabs_per_group each), one
+ * (mean, invstd, coef) per (sample, channel); running stats are updated once per
+ * sample in order, as B successive batch-of-one calls would. */
+int dm_bn_finalize(const double *stats, int nslabs, int slabs_per_group, int C, int64_t count_per_group,
+                   const float *gamma, const float *beta, float *running_mean, float *running_var,
+                   int64_t *num_batches_tracked, float momentum, float eps,
+                   float *coef, float *saved, int per_sample, void *stream);
+
+/* Backward finalize: slabs hold (sum dy, sum dy*a).  Writes dgamma, dbeta and the
+ * AFFINE2 coefficients (A,B,C) with da = A*dy + B*a + C. */
+int dm_bn_backward_finalize(const double *stats, int nslabs, int C, int64_t count,
+                            const float *gamma, const float *saved, float *dgamma, float *dbeta,
+                            float *coef_bwd, void *stream);
+
+/* out = load(in) [+ resid];  used for h = BN(a) and h' = h + BN(r) (vq_vae.py:224). */
+int dm_apply(const dm_operand *in, const float *resid, float *out, int B, int C, int H, int W, void *stream);
+
+/* stats[block][c] = (sum p, sum p*q) over a (B,C,H,W) pair; blocks = dm_channel_stats_num_blocks. */
+int dm_channel_stats_num_blocks(int B, int C, int H, int W);
+int dm_channel_stats(const float *p, const float *q, double *stats, int B, int C, int H, int W, void *stream);
+
+/* dst[n] = scale * sum_over_slabs stats[slab][n][0]   (bias gradients from epilogue stats). */
+int dm_sum_slabs(const double *stats, int nslabs, int N, float scale, float *dst, void *stream);
+
+/* ===== decoder head + reconstruction loss (vq_vae.py:298, 320-323) ============ */
+
+/* decoded = Conv2d(C4 -> NIN, 1x1)(d4) + bias; loss partials
+ * sum ((decoded*m - x*m)^2 / channel_var[c]) as one double per workgroup.
+ * mask: (B,MC,H,W) with MC in {1, NIN}, or NULL (= ones).
+ * x = NULL: decoder-only call (VQ_VAE.dec(z)), no loss partials are written. */
+int dm_head_num_blocks(int B, int H, int W);
+int dm_head_forward(const float *d4, const float *w6, const float *b6, const float *x, const float *mask,
+                    int mask_channels, const float *channel_var, float *decoded, double *loss_slabs,
+                    int B, int C4, int NIN, int H, int W, void *stream);
+
+/* Gradient of the head: g_dec = gscale[0]*2*(dec*m - x*m)*m/(var*N) with
+ * N = B*NIN*H*W (skipped when gscale_dev is NULL) plus gdec_ext (an upstream
+ * gradient w.r.t. decoded, may be NULL); g4 = (W6^T g_dec) * (d4 > 0); partial
+ * sums per workgroup, laid out as dm_sum_slabs expects ([block][n][2]):
+ * n in [0, NIN*C4) = dW6, then NIN entries db6, then C4 entries sum g4 (bias grad of dec.4). */
+int dm_head_backward(const float *decoded, const float *x, const float *mask, int mask_channels,
+                     const float *channel_var, const float *d4, const float *w6, const float *gscale_dev,
+                     const float *gdec_ext, float *g4, double *part_slabs, int B, int C4, int NIN, int H, int W,
+                     void *stream);
+
+/* scalars_out = (recon, commitment, total, perplexity) from the loss slabs and
+ * the dm_vq_finalize scalars: recon = sum/N, total = w_recon*recon + w_commit*commitment. */
+int dm_loss_finalize(const double *loss_slabs, int nslabs, int64_t count, const float *vq_scalars,
+                     float weight_recon, float weight_commitment, float *scalars_out, void *stream);
+
+/* ===== enc.0 o enc.1 composition (vq_vae.py:277-278) ========================== */
+
+/* enc.1(enc.0(x)) is linear in (x, 1): Weff[c1][ci][ky][kx] = sum_c W1[c1][c][ky][kx]*W0[c][ci]
+ * for ci < NIN and Weff[c1][NIN][ky][kx] = sum_c W1[c1][c][ky][kx]*b0[c] (the
+ * ones channel carries enc.0's bias through enc.1's zero padding exactly). */
+int dm_e1_compose(const float *w0, const float *b0, const float *w1, float *weff,
+                  int NIN, int C0, int C1, void *stream);
+/* Chain rule back to the stored parameters from dWeff. */
+int dm_e1_chain(const float *dweff, const float *w0, const float *b0, const float *w1,
+                float *dw0, float *db0, float *dw1, int NIN, int C0, int C1, void *stream);
+
+/* ===== optimizer (run_training.py:485: Adam(lr, betas=(.9,.999)), eps 1e-8) ==== */
+/* step_dev[0] holds the 1-based step count as float (kept on device so the call is graph-capturable). */
+int dm_adam(float *param, const float *grad, float *m, float *v, int64_t n,
+            float lr, float beta1, float beta2, float eps, const float *step_dev, void *stream);
+
+/* ===== on-device augmentation (run_training.py:396-403) ======================= */
+/* out[b] = rot90(flip(in[b], flip_code[b]), k = rot_code[b]) on square (C,H,H) patches;
+ * flip_code 0 none / 1 flip H / 2 flip W, rot_code 0..3 (counter-clockwise, dims [1,2]). */
+int dm_augment(const float *in, float *out, const int32_t *flip_code, const int32_t *rot_code,
+               int B, int C, int H, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNAMORPH_HIP_H */

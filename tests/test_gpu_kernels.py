@@ -1,0 +1,412 @@
+"""Op-level parity of every HIP kernel (through the C ABI) against a PyTorch-CPU fp32 reference of
+the same op / the C oracle.  Tolerances: bit-exact for indices and the straight-through value;
+fp32 accumulation-order tolerance (stated per test) for everything else."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dynamorph_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def cvq():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return ctypes.CDLL(os.path.join(ROOT, "oracle", "libvq_oracle.so"))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e} (ref max {b.abs().max():.3e})"
+
+
+def load_ref(p0, mode, coef=None, p1=None):
+    """CPU restatement of dm_operand's transform; coef (C,4) or (B,C,4)."""
+    if mode == 0:
+        return p0
+    if mode == 1:
+        return p0.clamp(min=0)
+    c = coef if coef.dim() == 3 else coef.unsqueeze(0)
+    c0, c1, c2 = (c[..., i].unsqueeze(-1).unsqueeze(-1) for i in range(3))
+    if mode == 4:
+        return c0 * p0 + c1 * p1 + c2
+    v = c0 * p0 + c2
+    return v.clamp(min=0) if mode == 3 else v
+
+
+# =================================================================================== VQ
+def test_vq_forward_bit_exact_golden(ops, golden):
+    g4, g5 = golden("g4_vq_indices.npz"), golden("g5_vq_forward.npz")
+    z = torch.from_numpy(g5["z_before"]).to(DEV)
+    cb = torch.from_numpy(g4["codebook"]).to(DEV)
+    idx, out, slabs, hist = ops.vq_forward(z, cb)
+    sc = ops.vq_finalize(slabs, hist, idx.numel(), 16, 0.25).cpu().numpy()
+    assert np.array_equal(idx.cpu().numpy(), g4["idx"])
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), g5["quantized"].view(np.uint32))
+    assert abs(sc[0] - g5["loss"]) <= 1e-6 * abs(g5["loss"])
+    assert abs(sc[1] - g5["perplexity"]) <= 1e-5 * abs(g5["perplexity"])
+    assert np.array_equal(hist.cpu().numpy(), np.bincount(g4["idx"].ravel(), minlength=64))
+    q = ops.vq_decode(idx, cb).cpu()
+    assert torch.equal(q, torch.from_numpy(g4["codebook"])[torch.from_numpy(g4["idx"])].permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("name", ["g9_vq_k4096.npz", "g9_vq_d64.npz", "g9_vq_ties.npz"])
+def test_vq_forward_stress_golden(ops, golden, name):
+    g = golden(name)
+    z, cb = torch.from_numpy(g["z"]).to(DEV), torch.from_numpy(g["codebook"]).to(DEV)
+    idx, out, slabs, hist = ops.vq_forward(z, cb)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"]), name
+    if "loss" in g:
+        sc = ops.vq_finalize(slabs, hist, idx.numel(), z.shape[1], 0.25).cpu().numpy()
+        assert abs(sc[0] - g["loss"]) <= 1e-6 * abs(g["loss"])
+        assert abs(sc[1] - g["perplexity"]) <= 2e-5 * abs(g["perplexity"])
+
+
+@pytest.mark.parametrize("B,D,K,H,W", [(3, 16, 64, 16, 16), (2, 16, 63, 8, 12), (1, 32, 10, 4, 4), (5, 8, 7, 16, 16)])
+def test_vq_forward_vs_c_oracle(ops, cvq, B, D, K, H, W):
+    z = rnd(B, D, H, W, seed=B + D + K).numpy()
+    cb = rnd(K, D, seed=K).numpy()
+    idx_ref = np.empty((B, H, W), np.int64)
+    cvq.oracle_vq_encode(_p(z), _p(cb), _p(idx_ref), B, D, K, H, W)
+    idx, out, _, _ = ops.vq_forward(torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV))
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    q = cb[idx_ref].transpose(0, 3, 1, 2)
+    assert np.array_equal(out.cpu().numpy(), z + (q - z))
+
+
+def test_vq_backward_golden(ops, golden):
+    g6, g4 = golden("g6_vq_backward.npz"), golden("g4_vq_indices.npz")
+    z = torch.from_numpy(g6["z"]).to(DEV)
+    cb = torch.from_numpy(g4["codebook"]).to(DEV)
+    idx = torch.from_numpy(g4["idx"]).to(DEV)
+    gl = torch.tensor([float(g6["g_loss"])], device=DEV)
+    dz, dw = ops.vq_backward(z, cb, idx, torch.from_numpy(g6["g_out"]).to(DEV), gl, 0.25)
+    close(dz, torch.from_numpy(g6["dz"]), 1e-6, 1e-9, "dz")
+    close(dw, torch.from_numpy(g6["dw"]), 2e-5, 1e-8, "dw")
+
+
+# ========================================================================== convolutions
+def _stats_ref(out, q=None):
+    q = out if q is None else q
+    return torch.stack([out.double().sum((0, 2, 3)), (out.double() * q.double()).sum((0, 2, 3))], 1)
+
+
+@pytest.mark.parametrize("cin,nout,hw,ones,mode", [
+    (3, 8, 128, True, 0), (8, 16, 64, False, 3), (16, 16, 32, False, 3),
+    (4, 4, 128, False, 0), (4, 8, 64, False, 0), (8, 16, 32, False, 0), (5, 8, 128, True, 0), (16, 16, 64, False, 2),
+    (8, 16, 128, False, 1)])
+def test_conv4x4s2(ops, cin, nout, hw, ones, mode):
+    B = 3
+    cphys = cin - (1 if ones else 0)
+    x = rnd(B, cphys, hw, hw, seed=1)
+    w = rnd(nout, cin, 4, 4, seed=2, scale=0.2)
+    bias = rnd(nout, seed=3)
+    coef = torch.stack([rnd(cphys, seed=4).abs() + 0.5, torch.zeros(cphys), rnd(cphys, seed=5) * 0.3, torch.zeros(cphys)], 1)
+    xin = load_ref(x, mode, coef)
+    if ones:
+        xin = torch.cat([xin, torch.ones(B, 1, hw, hw)], 1)
+    ref = F.conv2d(xin, w, bias, stride=2, padding=1)
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, ones=ones),
+                            ops.weight_view(w.to(DEV), cin * 16, 16, 4, 1), B, cin, nout, hw, hw, want_stats=True,
+                            bias=bias.to(DEV))
+    close(out, ref, 2e-5, 2e-5, "conv4x4s2")
+    close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+
+
+def test_conv4x4s2_epilogue_mask_resid_and_convT_view(ops):
+    """Data gradient of a ConvTranspose2d(4,2,1): conv over g with the [ci][co] weight read in place."""
+    B, ci, co, h = 2, 8, 4, 32          # convT: (B,ci,h,h) -> (B,co,2h,2h)
+    wt = rnd(ci, co, 4, 4, seed=1, scale=0.2)
+    g = rnd(B, co, 2 * h, 2 * h, seed=2)
+    act = rnd(B, ci, h, h, seed=3)
+    resid = rnd(B, ci, h, h, seed=4)
+    ref = F.conv2d(g, wt, None, stride=2, padding=1) * (act > 0) + resid
+    out, st = ops.conv4x4s2(ops.Op(g.to(DEV)), ops.weight_view(wt.to(DEV), co * 16, 16, 4, 1), B, co, ci, 2 * h, 2 * h,
+                            want_stats=True, mask=ops.Op(act.to(DEV)), resid=resid.to(DEV), stat_q=act.to(DEV))
+    close(out, ref, 2e-5, 2e-5, "dgrad convT")
+    close(st.sum(0), _stats_ref(ref, act), 1e-5, 1e-3, "stats q")
+    # cross-check against autograd
+    inp = act.clone().requires_grad_(True)
+    F.conv_transpose2d(inp, wt, None, stride=2, padding=1).backward(g)
+    close(out.cpu() - resid, inp.grad * (act > 0), 2e-5, 2e-5, "autograd")
+
+
+@pytest.mark.parametrize("cin,nout,hw,taps", [(16, 16, 16, 9), (16, 32, 16, 9), (32, 16, 16, 9), (16, 16, 32, 9),
+                                              (32, 16, 16, 1), (16, 32, 16, 1), (32, 16, 32, 1), (16, 32, 32, 9)])
+@pytest.mark.parametrize("mode", [0, 1, 3])
+def test_conv3x3_plain(ops, cin, nout, hw, taps, mode):
+    B = 3
+    k = 3 if taps == 9 else 1
+    x = rnd(B, cin, hw, hw, seed=1)
+    w = rnd(nout, cin, k, k, seed=2, scale=0.2)
+    bias = rnd(nout, seed=3)
+    coef = torch.stack([rnd(cin, seed=4).abs() + 0.5, torch.zeros(cin), rnd(cin, seed=5) * 0.3, torch.zeros(cin)], 1)
+    ref = F.conv2d(load_ref(x, mode, coef), w, bias, padding=k // 2)
+    out, st = ops.conv3x3(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None),
+                          ops.weight_view(w.to(DEV), cin * k * k, k * k, k, 1), B, cin, nout, hw, hw, taps=taps,
+                          want_stats=True, bias=bias.to(DEV))
+    close(out, ref, 2e-5, 2e-5, "conv3x3")
+    close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+
+
+def test_conv3x3_dgrad_views_affine2_mask(ops):
+    """Data gradient of a 3x3 conv: flipped/transposed weight view + AFFINE2 load + AFFINE mask + resid."""
+    B, ci, co, h = 2, 16, 32, 16
+    w = rnd(co, ci, 3, 3, seed=1, scale=0.2)
+    dy, a = rnd(B, co, h, h, seed=2), rnd(B, co, h, h, seed=3)
+    coef = torch.stack([rnd(co, seed=4), rnd(co, seed=5) * 0.1, rnd(co, seed=6) * 0.1, torch.zeros(co)], 1)
+    prev = rnd(B, ci, h, h, seed=7)
+    mcoef = torch.stack([rnd(ci, seed=8), torch.zeros(ci), rnd(ci, seed=9) * 0.2, torch.zeros(ci)], 1)
+    resid = rnd(B, ci, h, h, seed=10)
+    da = load_ref(dy, 4, coef, a)
+    x = torch.zeros(B, ci, h, h, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(da)
+    ref = x.grad * (load_ref(prev, 2, mcoef) > 0) + resid
+    out, st = ops.conv3x3(ops.Op(dy.to(DEV), 4, coef.to(DEV), p1=a.to(DEV)),
+                          ops.weight_view(w.to(DEV), 9, ci * 9, -3, -1, off=8), B, co, ci, h, h, taps=9, want_stats=True,
+                          mask=ops.Op(prev.to(DEV), 2, mcoef.to(DEV)), resid=resid.to(DEV), stat_q=prev.to(DEV))
+    close(out, ref, 3e-5, 3e-5, "dgrad3x3")
+    close(st.sum(0), _stats_ref(ref, prev), 1e-5, 2e-3, "stats")
+    # 1x1 data gradient
+    w1 = rnd(ci, co, 1, 1, seed=11, scale=0.2)      # conv co -> ci ; dgrad maps (B,ci) grads -> (B,co)
+    gy = rnd(B, ci, h, h, seed=12)
+    x1 = torch.zeros(B, co, h, h, requires_grad=True)
+    F.conv2d(x1, w1).backward(gy)
+    out1, _ = ops.conv3x3(ops.Op(gy.to(DEV)), ops.weight_view(w1.to(DEV), 1, co, 0, 0), B, ci, co, h, h, taps=1)
+    close(out1, x1.grad, 2e-5, 2e-5, "dgrad1x1")
+
+
+@pytest.mark.parametrize("ci,co,hw", [(16, 8, 16), (8, 4, 32), (4, 4, 64), (16, 16, 16), (16, 8, 32), (16, 8, 64), (8, 4, 64)])
+def test_conv_transpose_pixel_shuffle(ops, ci, co, hw):
+    B = 2
+    x = rnd(B, ci, hw, hw, seed=1)
+    wt = rnd(ci, co, 4, 4, seed=2, scale=0.2)
+    bias = rnd(co, seed=3)
+    ref = F.relu(F.conv_transpose2d(x, wt, bias, stride=2, padding=1))
+    out, st = ops.conv3x3(ops.Op(x.to(DEV)), ops.weight_view(wt.to(DEV), 16, co * 16, 4, 1), B, ci, 4 * co, hw, hw,
+                          taps=9, pixel_shuffle=True, want_stats=True, bias=bias.to(DEV), relu=True)
+    close(out, ref, 2e-5, 2e-5, "convT")
+    close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+
+
+def test_conv_dgrad_of_strided_conv_pixel_shuffle(ops):
+    """Data gradient of Conv2d(8->16,4,2,1) = transposed conv read from the [co][ci] weight, with mask/stats."""
+    B, ci, co, h = 2, 8, 16, 32          # conv input (B,ci,2h,2h) -> output (B,co,h,h)
+    w = rnd(co, ci, 4, 4, seed=1, scale=0.2)
+    gy = rnd(B, co, h, h, seed=2)
+    a_prev = rnd(B, ci, 2 * h, 2 * h, seed=3)
+    mcoef = torch.stack([rnd(ci, seed=8), torch.zeros(ci), rnd(ci, seed=9) * 0.2, torch.zeros(ci)], 1)
+    x = torch.zeros(B, ci, 2 * h, 2 * h, requires_grad=True)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(gy)
+    ref = x.grad * (load_ref(a_prev, 2, mcoef) > 0)
+    out, st = ops.conv3x3(ops.Op(gy.to(DEV)), ops.weight_view(w.to(DEV), 16, ci * 16, 4, 1), B, co, 4 * ci, h, h, taps=9,
+                          pixel_shuffle=True, want_stats=True, mask=ops.Op(a_prev.to(DEV), 2, mcoef.to(DEV)),
+                          stat_q=a_prev.to(DEV))
+    close(out, ref, 3e-5, 3e-5, "dgrad strided")
+    close(st.sum(0), _stats_ref(ref, a_prev), 1e-5, 2e-3, "stats")
+
+
+# =============================================================================== wgrad
+@pytest.mark.parametrize("cs,ct,k,hs,ones,B", [
+    (8, 3, 4, 64, True, 3), (16, 8, 4, 32, False, 3), (16, 16, 4, 16, False, 5), (16, 16, 3, 16, False, 5),
+    (32, 16, 3, 16, False, 5), (16, 32, 1, 16, False, 5), (16, 8, 4, 16, False, 5), (8, 4, 4, 32, False, 3),
+    (4, 4, 4, 64, False, 3), (8, 5, 4, 64, True, 2), (16, 16, 4, 32, False, 2), (16, 8, 4, 64, False, 2), (8, 3, 4, 64, True, 70)])
+def test_wgrad(ops, cs, ct, k, hs, ones, B):
+    s, p = (2, 1) if k == 4 else ((1, 1) if k == 3 else (1, 0))
+    ht = hs * s
+    ctp = ct - (1 if ones else 0)
+    S = rnd(B, cs, hs, hs, seed=1)
+    T = rnd(B, ctp, ht, ht, seed=2)
+    Tin = torch.cat([T, torch.ones(B, 1, ht, ht)], 1) if ones else T
+    w = torch.zeros(cs, ct, k, k, requires_grad=True)
+    F.conv2d(Tin, w, None, stride=s, padding=p).backward(S)
+    dst = torch.empty(cs, ct, k, k, device=DEV)
+    ops.wgrad(ops.Op(S.to(DEV)), ops.Op(T.to(DEV), ones=ones), dst, B, cs, ct, hs, hs, k)
+    scale = w.grad.abs().max().item()
+    close(dst, w.grad, 2e-5, 2e-5 * scale, "wgrad")
+
+
+def test_wgrad_operand_modes_and_determinism(ops):
+    B, cs, ct, h = 4, 16, 16, 16
+    dy, a = rnd(B, cs, h, h, seed=1), rnd(B, cs, h, h, seed=2)
+    coef = torch.stack([rnd(cs, seed=3), rnd(cs, seed=4) * 0.1, rnd(cs, seed=5) * 0.1, torch.zeros(cs)], 1)
+    t = rnd(B, ct, 2 * h, 2 * h, seed=6)
+    tcoef = torch.stack([rnd(ct, seed=7), torch.zeros(ct), rnd(ct, seed=8) * 0.2, torch.zeros(ct)], 1)
+    w = torch.zeros(cs, ct, 4, 4, requires_grad=True)
+    F.conv2d(load_ref(t, 3, tcoef), w, None, stride=2, padding=1).backward(load_ref(dy, 4, coef, a))
+    outs = []
+    for _ in range(2):
+        dst = torch.empty(cs, ct, 4, 4, device=DEV)
+        ops.wgrad(ops.Op(dy.to(DEV), 4, coef.to(DEV), p1=a.to(DEV)), ops.Op(t.to(DEV), 3, tcoef.to(DEV)), dst, B, cs, ct, h, h, 4)
+        outs.append(dst.cpu())
+    close(outs[0], w.grad, 3e-5, 3e-5 * w.grad.abs().max().item(), "wgrad modes")
+    assert torch.equal(outs[0], outs[1]), "slab reduction must be bitwise reproducible"
+
+
+# ============================================================================ BatchNorm
+def test_bn_finalize_and_backward(ops):
+    B, Cn, h = 4, 16, 16
+    a = rnd(B, Cn, h, h, seed=1) * 2 + 0.7
+    bn = torch.nn.BatchNorm2d(Cn)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(Cn, seed=2).abs() + 0.5)
+        bn.bias.copy_(rnd(Cn, seed=3))
+    a_ref = a.clone().requires_grad_(True)
+    y_ref = bn(a_ref)
+    dy = rnd(B, Cn, h, h, seed=4)
+    y_ref.backward(dy)
+
+    stats = ops.channel_stats(a.to(DEV))
+    rm, rv = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    coef, saved = ops.bn_finalize(stats, B * h * h, bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), rm, rv, nbt, 0.1, 1e-5)
+    y = ops.apply(ops.Op(a.to(DEV), 2, coef), B, Cn, h, h)
+    close(y, y_ref, 1e-5, 1e-5, "bn apply")
+    close(rm, bn.running_mean, 1e-6, 1e-7, "running_mean")
+    close(rv, bn.running_var, 1e-6, 1e-7, "running_var")
+    assert int(nbt) == 1
+    st2 = ops.channel_stats(dy.to(DEV), a.to(DEV))
+    dgamma, dbeta = torch.empty(Cn, device=DEV), torch.empty(Cn, device=DEV)
+    cb = ops.bn_backward_finalize(st2, B * h * h, bn.weight.detach().to(DEV), saved, dgamma, dbeta)
+    da = ops.apply(ops.Op(dy.to(DEV), 4, cb, p1=a.to(DEV)), B, Cn, h, h)
+    close(da, a_ref.grad, 1e-4, 2e-6, "bn backward dx")
+    close(dgamma, bn.weight.grad, 1e-5, 1e-4, "dgamma")
+    close(dbeta, bn.bias.grad, 1e-5, 1e-4, "dbeta")
+
+
+def test_bn_per_sample_statistics(ops):
+    B, Cn, h = 3, 8, 16
+    a = rnd(B, Cn, h, h, seed=1) + 0.3
+    bn = torch.nn.BatchNorm2d(Cn)
+    ys = torch.cat([bn(a[i:i + 1]) for i in range(B)], 0)
+    stats = torch.cat([ops.channel_stats(a[i:i + 1].to(DEV)) for i in range(B)], 0)      # one slab per sample
+    rm, rv = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    g, b = torch.ones(Cn, device=DEV), torch.zeros(Cn, device=DEV)
+    coef, saved = ops.bn_finalize(stats, h * h, g, b, rm, rv, nbt, 0.1, 1e-5, per_sample=True, slabs_per_group=1)
+    y = ops.apply(ops.Op(a.to(DEV), 2, coef, per_sample=True), B, Cn, h, h)
+    close(y, ys, 1e-5, 1e-5, "per-sample bn")
+    close(rm, bn.running_mean, 1e-5, 1e-7, "running_mean")
+    close(rv, bn.running_var, 1e-5, 1e-7, "running_var")
+    assert int(nbt) == B
+
+
+# ================================================================================= head
+@pytest.mark.parametrize("nin,masked", [(2, False), (2, True), (4, True), (1, False)])
+def test_head_forward_backward(ops, nin, masked):
+    B, c4, h = 2, 4, 64
+    d4 = rnd(B, c4, h, h, seed=1).clamp(min=0)
+    w6 = rnd(nin, c4, 1, 1, seed=2).requires_grad_(True)
+    b6 = rnd(nin, seed=3).requires_grad_(True)
+    x = rnd(B, nin, h, h, seed=4)
+    mask = (torch.rand(B, 1, h, h, generator=torch.Generator().manual_seed(5)) > 0.4).float() * 0.5 + 0.5 if masked else None
+    var = torch.linspace(0.5, 1.5, nin)
+    d4r = d4.clone().requires_grad_(True)
+    dec_ref = F.conv2d(F.relu(d4r), w6, b6)
+    m = mask if masked else torch.ones_like(x)
+    loss_ref = torch.mean(F.mse_loss(dec_ref * m, x * m, reduction="none") / var.reshape(1, nin, 1, 1))
+    (loss_ref * 1.3).backward()
+
+    dv = [t.detach().to(DEV) for t in (d4, w6, b6, x, var)]
+    mk = mask.to(DEV) if masked else None
+    dec, slabs = ops.head_forward(dv[0], dv[1], dv[2], dv[3], mk, dv[4])
+    recon = ops.loss_finalize(slabs, x.numel(), torch.zeros(2, device=DEV), 1.0, 0.0)[0]
+    close(dec, dec_ref, 1e-5, 1e-5, "decoded")
+    assert abs(float(recon) - float(loss_ref)) <= 2e-6 * abs(float(loss_ref))
+    g4, part = ops.head_backward(dec, dv[3], mk, dv[4], dv[0], dv[1], torch.tensor([1.3], device=DEV))
+    flat = torch.empty(part.shape[1], device=DEV)
+    ops.sum_slabs(part, flat)
+    close(g4, d4r.grad, 1e-4, 1e-9, "g4")
+    close(flat[:nin * c4].reshape(nin, c4), w6.grad.reshape(nin, c4), 1e-4, 1e-7, "dW6")
+    close(flat[nin * c4:nin * c4 + nin], b6.grad, 1e-4, 1e-7, "db6")
+    close(flat[nin * c4 + nin:], d4r.grad.sum((0, 2, 3)), 1e-4, 1e-7, "sum g4")
+
+
+# ============================================================== composition / Adam / misc
+def test_e1_compose_and_chain(ops):
+    nin, c0, c1, B, h = 2, 8, 8, 2, 32
+    w0 = rnd(c0, nin, 1, 1, seed=1).requires_grad_(True)
+    b0 = rnd(c0, seed=2).requires_grad_(True)
+    w1 = rnd(c1, c0, 4, 4, seed=3, scale=0.2).requires_grad_(True)
+    x = rnd(B, nin, h, h, seed=4)
+    ref = F.conv2d(F.conv2d(x, w0, b0), w1, None, stride=2, padding=1)
+    weff = ops.e1_compose(w0.detach().to(DEV), b0.detach().to(DEV), w1.detach().to(DEV))
+    xin = torch.cat([x, torch.ones(B, 1, h, h)], 1)
+    close(F.conv2d(xin, weff.cpu(), None, stride=2, padding=1), ref, 1e-5, 1e-5, "composite conv")
+    g = rnd(*ref.shape, seed=5)
+    ref.backward(g)
+    wz = torch.zeros(c1, nin + 1, 4, 4, requires_grad=True)
+    F.conv2d(xin, wz, None, stride=2, padding=1).backward(g)
+    dw0, db0, dw1 = torch.empty(c0, nin, 1, 1, device=DEV), torch.empty(c0, device=DEV), torch.empty(c1, c0, 4, 4, device=DEV)
+    ops.e1_chain(wz.grad.to(DEV), w0.detach().to(DEV), b0.detach().to(DEV), w1.detach().to(DEV), dw0, db0, dw1)
+    close(dw0, w0.grad, 1e-4, 1e-4, "dw0")
+    close(db0, b0.grad, 1e-4, 1e-4, "db0")
+    close(dw1, w1.grad, 1e-4, 1e-4, "dw1")
+
+
+def test_adam_matches_torch(ops):
+    n = 5000
+    p0 = rnd(n, seed=1)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-4, betas=(.9, .999))
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, device=DEV)
+    for s in range(3):
+        g = rnd(n, seed=10 + s) * (10.0 ** (s - 3))
+        p_ref.grad = g.clone()
+        opt.step()
+        step += 1
+        ops.adam(p, g.to(DEV), m, v, 1e-4, 0.9, 0.999, 1e-8, step)
+    close(p, p_ref, 1e-6, 1e-7, "adam")
+
+
+def test_augment_matches_torch(ops):
+    B, Cn, h = 9, 2, 16
+    x = rnd(B, Cn, h, h, seed=1)
+    flips = torch.tensor([0, 1, 2, 0, 1, 2, 0, 1, 2], dtype=torch.int32)
+    rots = torch.tensor([0, 1, 2, 3, 0, 1, 2, 3, 1], dtype=torch.int32)
+    ref = []
+    for i in range(B):                       # run_training.py:397-403
+        img = x[i]
+        if flips[i] != 0:
+            img = torch.flip(img, dims=(int(flips[i]),))
+        ref.append(torch.rot90(img, k=int(rots[i]), dims=[1, 2]))
+    out = ops.augment(x.to(DEV), flips.to(DEV), rots.to(DEV))
+    assert torch.equal(out.cpu(), torch.stack(ref))
+
+
+def test_bad_arguments_raise(ops):
+    x = rnd(1, 16, 16, 16).to(DEV)
+    with pytest.raises(ValueError):
+        ops.vq_forward(rnd(1, 5, 4, 4).to(DEV), rnd(4, 5).to(DEV))       # embedding_dim 5 not built
+    with pytest.raises(ValueError):
+        ops.conv3x3(ops.Op(x), ops.weight_view(x, 1, 1, 1, 1), 1, 16, 16, 10, 10, taps=9)   # 10x10 not tileable
+    with pytest.raises(ValueError):
+        ops.vq_forward(rnd(1, 16, 4, 4), rnd(4, 16))                       # CPU tensors: no fallback

@@ -1,0 +1,294 @@
+"""Module-level parity of the HIP path (dynamorph_amd.VQ_VAE & friends, called exactly as
+run_training.py / pipeline/patch_VAE.py call the reference) against the golden vectors captured
+from the reference and against the CPU oracle on fresh seeded inputs.
+
+Gates (SURVEY.md section 7 "hard parts"):
+  * VQ on golden z_before: indices bit-identical (test_gpu_kernels.py).
+  * end to end: losses within 1e-5; indices identical except where the reference's own
+    best/second-best distance gap is below 1e-4 relative (count reported, must be tiny).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# conv biases that feed a train-mode BatchNorm: exact gradient is 0; the reference's autograd returns
+# rounding noise (~1e-9) which Adam then amplifies to +-lr.  They cannot (and need not) be matched.
+BN_FED_BIASES = ("enc.1.bias", "enc.4.bias", "enc.7.bias", "enc.10.bias",
+                 "enc.12.layers.0.1.bias", "enc.12.layers.0.4.bias", "enc.12.layers.1.1.bias", "enc.12.layers.1.4.bias")
+
+
+def fresh(golden, cls=None, **kw):
+    import dynamorph_amd
+    cls = cls or dynamorph_amd.VQ_VAE
+    m = cls(**kw).to(DEV)
+    g1 = golden("g1_state_dict.npz")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g1.items()})
+    return m
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e} (ref max {b.abs().max():.3e})"
+
+
+def near_tie_mask(z, codebook, rel=1e-4):
+    """positions whose reference top-2 distance gap is within `rel` of the best distance"""
+    d = ((z.unsqueeze(1) - codebook.reshape(1, *codebook.shape, 1, 1)) ** 2).sum(2)     # (B,K,H,W)
+    top2 = torch.topk(-d, 2, dim=1).values
+    return (top2[:, 0] - top2[:, 1]).abs() <= rel * top2[:, 0].abs()
+
+
+def test_encoder_layers_against_reference_activations(golden):
+    """Layer-by-layer check of the encoder kernels (localises a failure)."""
+    from dynamorph_amd import engine as E
+    m = fresh(golden)
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    acts = golden("g3_debug_acts.npz")
+    L = E.Layers(m)
+    z, cx = E.encoder_forward(L, x)
+    close(cx.a1, acts["enc1"], 2e-5, 2e-5, "enc.1 output")
+    close(cx.a2, acts["enc4"], 5e-5, 5e-5, "enc.4 output")
+    close(cx.a3, acts["enc7"], 1e-4, 1e-4, "enc.7 output")
+    close(cx.a4, acts["enc10"], 1e-4, 1e-4, "enc.10 output")
+    close(cx.res[0].h_in, acts["enc11"], 1e-4, 1e-4, "enc.11 output")
+    close(cx.res[0].ra, acts["res0_1"], 1e-4, 1e-4, "res0 conv3x3")
+    close(cx.res[0].rb, acts["res0_4"], 1e-4, 1e-4, "res0 conv1x1")
+    close(cx.res[1].rb, acts["res1_4"], 2e-4, 2e-4, "res1 conv1x1")
+    close(z, golden("g3_encoder.npz")["z_before"], 2e-4, 2e-4, "z_before")
+
+
+def test_encoder_batch_statistics_and_running_stats(golden):
+    m = fresh(golden)
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    g3 = golden("g3_encoder.npz")
+    z = m.enc(x)
+    close(z, g3["z_before"], 2e-4, 2e-4, "z_before")
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            close(v, g3["rs_batch/" + k], 1e-5, 1e-6, k)
+        if "tracked" in k:
+            assert int(v) == int(g3["rs_batch/" + k]), k
+
+
+def test_process_vae_semantics_per_sample(golden):
+    """pipeline/patch_VAE.py:445-452: enc -> vq on batches of one (train-mode BN) == per-sample statistics."""
+    from dynamorph_amd.patch_vae import encode_patches
+    m = fresh(golden)
+    x = torch.from_numpy(golden("g2_input.npz")["x"])
+    g3 = golden("g3_encoder.npz")
+    zb, za = encode_patches(m, x, device=DEV, batch_size=3)         # ragged last chunk on purpose
+    assert zb.shape == (4, 4096) and za.shape == (4, 4096)
+    close(zb, g3["z_before_per_sample"].reshape(4, -1), 2e-4, 2e-4, "z_before per sample")
+    cb = torch.from_numpy(golden("g4_vq_indices.npz")["codebook"])
+    zb_ref = torch.from_numpy(g3["z_before_per_sample"])
+    tie = near_tie_mask(zb_ref, cb).unsqueeze(1).expand(-1, 16, -1, -1).reshape(4, -1)
+    diff = (torch.from_numpy(za) - torch.from_numpy(g3["z_after_per_sample"]).reshape(4, -1)).abs() > 1e-4
+    assert not (diff & ~tie).any(), f"{int((diff & ~tie).sum())} quantized values differ away from ties"
+    assert tie.float().mean() < 1e-3
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            close(v, g3["rs_ps/" + k], 1e-4, 1e-5, k)
+        if "tracked" in k:
+            assert int(v) == int(g3["rs_ps/" + k]), k
+    # the same numbers from literal batch-of-one module calls, as the reference loop does it
+    m2 = fresh(golden)
+    z1 = m2.enc(x[1:2].to(DEV))
+    close(z1, g3["z_before_per_sample"][1:2], 2e-4, 2e-4, "batch-of-one call")
+
+
+def test_vq_module_surface(golden):
+    m = fresh(golden)
+    g4, g5 = golden("g4_vq_indices.npz"), golden("g5_vq_forward.npz")
+    z = torch.from_numpy(g5["z_before"]).to(DEV)
+    assert np.array_equal(m.vq.encode_inputs(z).cpu().numpy(), g4["idx"])
+    q, loss, perp = m.vq(z)
+    assert np.array_equal(q.detach().cpu().numpy().view(np.uint32), g5["quantized"].view(np.uint32))
+    assert abs(float(loss) - float(g5["loss"])) <= 1e-6 * float(g5["loss"])
+    assert abs(float(perp) - float(g5["perplexity"])) <= 1e-5 * float(g5["perplexity"])
+    dq = m.vq.decode_inputs(torch.from_numpy(g4["idx"]).to(DEV))
+    assert torch.equal(dq.cpu(), torch.from_numpy(g4["codebook"])[torch.from_numpy(g4["idx"])].permute(0, 3, 1, 2))
+    assert m.vq.embeddings is m.vq.w.weight
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_forward_losses_and_reconstruction(golden, masked):
+    m = fresh(golden)
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    g = golden("g5_forward_masked.npz" if masked else "g5_forward.npz")
+    mask = torch.from_numpy(g["mask"]).to(DEV) if masked else None
+    dec, ld = m(x, batch_mask=mask)
+    assert list(ld.keys()) == ["recon_loss", "commitment_loss", "time_matching_loss", "total_loss", "perplexity"]
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(g[k])) <= 1e-5, (k, float(ld[k]), float(g[k]))       # north-star tolerance
+    assert abs(float(ld["perplexity"]) - float(g["perplexity"])) <= 1e-3 * float(g["perplexity"])
+    assert ld["time_matching_loss"] == 0.
+    # decoded: identical codes except near-ties -> compare per sample where all codes agree
+    idx_ref = golden("g4_vq_indices.npz")["idx"]
+    idx = m.vq.encode_inputs(m.enc(x)).cpu().numpy()      # (running stats mutate: irrelevant here)
+    same = (idx == idx_ref).reshape(4, -1).all(1)
+    assert (idx != idx_ref).mean() < 1e-3
+    for b in range(4):
+        if same[b]:
+            close(dec[b], g["decoded"][b], 5e-4, 5e-4, f"decoded[{b}]")
+    if not masked:
+        acts = golden("g5_debug_dec_acts.npz")
+        from dynamorph_amd import engine as E
+        zq = torch.from_numpy(golden("g5_vq_forward.npz")["quantized"]).to(DEV)
+        d, cx = E.decoder_forward(E.Layers(m), zq, x)
+        close(cx.d0, acts["dec1"], 2e-5, 2e-5, "dec.0+relu")
+        close(cx.d2, acts["dec3"], 5e-5, 5e-5, "dec.2+relu")
+        close(cx.d4[:1], acts["dec5"], 1e-4, 1e-4, "dec.4+relu")
+        close(d, g["decoded"], 1e-4, 1e-4, "decoded from golden z_after")
+
+
+def test_gradients_against_reference(golden):
+    m = fresh(golden)
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    g6 = golden("g6_grads.npz")
+    dec, ld = m(x)
+    ld["total_loss"].backward()
+    assert m.channel_var.grad is None
+    worst = {}
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, k
+        ref = torch.from_numpy(g6["grad/" + k])
+        scale = max(ref.abs().max().item(), 1e-6)
+        err = (p.grad.cpu() - ref).abs().max().item()
+        worst[k] = err / scale
+        if k in BN_FED_BIASES:
+            assert p.grad.abs().max().item() == 0.0, k               # exact zero by construction
+            assert ref.abs().max().item() < 1e-6, k                  # the reference only has rounding noise there
+            continue
+        assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
+    print("max relative grad error:", max(worst.items(), key=lambda kv: kv[1]))
+
+
+def test_decoder_and_vq_gradients_in_isolation(golden):
+    """dz_after / dz_before of the reference graph, fed the golden z tensors (no encoder noise)."""
+    m = fresh(golden)
+    g6, g5 = golden("g6_grads.npz"), golden("g5_vq_forward.npz")
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    zb = torch.from_numpy(g5["z_before"]).to(DEV).requires_grad_(True)
+    za, closs, _ = m.vq(zb)
+    za.retain_grad()
+    from dynamorph_amd.vq_vae import _DecoderFn
+    from dynamorph_amd import engine as E
+    L = E.Layers(m)
+    dec, recon = _DecoderFn.apply(za, x, None, L, *L.decoder_params())
+    (recon + closs).backward()
+    close(za.grad, g6["dz_after"], 2e-4, 1e-9, "dz_after")
+    close(zb.grad, g6["dz_before"], 2e-4, 1e-9, "dz_before")
+    for k in ("dec.0.weight", "dec.0.bias", "dec.2.weight", "dec.2.bias", "dec.4.weight", "dec.4.bias",
+              "dec.6.weight", "dec.6.bias", "vq.w.weight"):
+        p = dict(m.named_parameters())[k]
+        ref = g6["grad/" + k]
+        close(p.grad, ref, 2e-4, 2e-4 * np.abs(ref).max(), k)
+
+
+def test_adam_steps_with_torch_optimizer(golden):
+    """run_training.py:404-408 loop with torch.optim.Adam driving the HIP model (drop-in check)."""
+    m = fresh(golden)
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    g7 = golden("g7_adam.npz")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, betas=(.9, .999))
+    m.zero_grad()
+    for step in range(3):
+        _, ld = m(x)
+        ld["total_loss"].backward()
+        opt.step()
+        m.zero_grad()
+        got = [float(ld[k]) for k in ("recon_loss", "commitment_loss", "total_loss")]
+        np.testing.assert_allclose(got, g7["losses"][step][:3], rtol=0, atol=2e-5)
+        if step == 0:
+            for k, v in m.state_dict().items():
+                if k in BN_FED_BIASES or "tracked" in k:
+                    continue
+                # one Adam step moves every weight by ~lr regardless of gradient scale: compare the step
+                close(v, g7["step1/" + k], 0, 2.5e-5 if "running" not in k else 1e-5, k)
+
+
+def test_oracle_parity_fresh_seed_larger_batch():
+    """Fresh seeded input + fresh seeded weights, B=16: HIP vs the CPU oracle (not a golden file)."""
+    import dynamorph_amd
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(123)
+    ref = O.OracleVQVAE()
+    x = torch.randn(16, 2, 128, 128, generator=torch.Generator().manual_seed(1234))
+    m = dynamorph_amd.VQ_VAE().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    dec_r, ld_r = ref(x)
+    ld_r["total_loss"].backward()
+    dec, ld = m(x.to(DEV))
+    ld["total_loss"].backward()
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(ld_r[k])) <= 1e-5, (k, float(ld[k]), float(ld_r[k]))
+    # a code flipped at a near-tie changes the gradient discretely (1 of 4096 positions): allow for it
+    ref2 = O.OracleVQVAE()
+    ref2.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    idx_ref = ref2.vq.encode_inputs(ref2.enc(x))
+    idx = m.vq.encode_inputs(m.enc(x.to(DEV))).cpu()
+    flips = int((idx != idx_ref).sum())
+    assert flips <= 4, flips
+    tol = 1e-3 if flips == 0 else 1e-2
+    gr = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        if p.requires_grad and k not in BN_FED_BIASES:
+            r = gr[k].grad
+            assert (p.grad.cpu() - r).abs().max().item() <= tol * max(r.abs().max().item(), 1e-6) + 1e-7, (k, flips)
+
+
+def test_z16_variant_time_matching(golden):
+    import dynamorph_amd
+    g = golden("g8_z16_time_matching.npz")
+    m = fresh(golden, cls=dynamorph_amd.VQ_VAE_z16, gpu=True)          # patch_VAE.py:431 passes gpu=True
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    dec, ld = m(x, time_matching_mat=torch.from_numpy(g["tm"]).to(DEV))
+    assert list(ld.keys()) == ["recon_loss", "commitment_loss", "time_matching_loss", "perplexity", "total_loss"]
+    for k in ("recon_loss", "commitment_loss", "time_matching_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(g[k])) <= 2e-5, (k, float(ld[k]), float(g[k]))
+    ld["total_loss"].backward()
+    for k in ("enc.10.weight", "enc.4.weight", "dec.0.weight"):
+        p = dict(m.named_parameters())[k]
+        ref = g["grad/" + k]
+        close(p.grad, ref, 0, 3e-3 * np.abs(ref).max(), k)
+    g2 = golden("g8_vqvae_time_matching.npz")
+    m = fresh(golden)
+    dec, ld = m(x, time_matching_mat=torch.from_numpy(g2["tm"]).to(DEV))
+    for k in ("time_matching_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(g2[k])) <= 1e-4 * max(1.0, abs(float(g2[k]))), (k, float(ld[k]), float(g2[k]))
+
+
+def test_round_trip_properties_full_size():
+    """Size-independent properties at BASELINE config sizes (B=1024 latents): decode(encode(z)) is a fixed
+    point of the quantiser, the histogram sums to P, loss == (1+beta)*mse, indices in range."""
+    import dynamorph_amd
+    from dynamorph_amd import ops
+    torch.manual_seed(0)
+    vq = dynamorph_amd.VectorQuantizer(16, 64).to(DEV)
+    z = torch.randn(1024, 16, 16, 16, device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+    idx = vq.encode_inputs(z)
+    assert idx.min() >= 0 and idx.max() < 64
+    q = vq.decode_inputs(idx)
+    assert torch.equal(vq.encode_inputs(q), idx)                     # idempotence
+    out, loss, perp = vq(z)
+    mse = torch.mean((q - z) ** 2)
+    assert abs(float(loss) - 1.25 * float(mse)) <= 2e-6 * float(loss)
+    _, _, slabs, hist = ops.vq_forward(z, vq.w.weight.detach())
+    assert int(hist.sum()) == idx.numel()
+    assert torch.equal(hist.cpu(), torch.bincount(idx.flatten().cpu(), minlength=64).int())
+    p = hist.double() / idx.numel()
+    assert abs(float(perp) - float(torch.exp(-(p * torch.log(p + 1e-10)).sum()))) < 1e-3
+
+
+def test_cpu_input_raises():
+    import dynamorph_amd
+    m = dynamorph_amd.VQ_VAE()
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 2, 128, 128))
