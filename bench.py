@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-patches/s of the VQ-VAE hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic 2x128x128 fp32 patches that is already
+resident in HBM.  Default workload = BASELINE.json configs[2]/[3]: one TRAINING step (forward + backward +
+Adam, batch 2048 per GPU; weak scaling, one RCCL all-reduce of the flat 96 KB gradient bucket per step).
+`--workload c2` times configs[1] instead (inference latents, batch 1024, per-sample BatchNorm statistics).
+
+Rank 0 prints ONE JSON line.  It also carries
+  roofline     -- the dominant kernel of the step, timed live with events on the launch stream
+  cpu_baseline -- the CPU oracle (oracle/vqvae_oracle.py, "port") timed on this host's cores on a bounded
+                  sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 2048 for c3, 1024 for c2)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters=20, warmup=3):
+    """Average duration of fn() on the current stream (the stream our kernels are launched on)."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline_dominant_kernel(model, x, workload):
+    """Dominant kernel of the step (profiles/: the enc.1 composite 4x4/s2 convolution's weight gradient for
+    c3, the enc.1 composite convolution itself for c2), launched alone with the bench shapes."""
+    from dynamorph_amd import engine as E
+    from dynamorph_amd import ops
+    from dynamorph_amd.ops import Op, weight_view
+    L = E.Layers(model)
+    B, NIN, H, W = x.shape
+    c1 = L.nh // 2
+    weff = ops.e1_compose(L.enc0.weight.detach(), L.enc0.bias.detach(), L.enc1.weight.detach())
+    a1 = torch.empty(B, c1, H // 2, W // 2, device=x.device)
+    if workload == "c2":
+        def fn():
+            ops.conv4x4s2(Op(x, ones=True), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN + 1, c1, H, W, out=a1,
+                          want_stats=True, bias=L.enc1.bias.detach())
+        name = "conv4x4s2_kernel<3,1,8,64> (enc.0 o enc.1 composite)"
+        algo_bytes = B * (NIN * H * W + c1 * (H // 2) * (W // 2)) * 4          # read x once, write a1 once
+    else:
+        torch.manual_seed(0)
+        dy = torch.randn_like(a1)
+        dweff = torch.empty(c1, NIN + 1, 4, 4, device=x.device)
+
+        def fn():
+            ops.wgrad(Op(dy), Op(x, ones=True), dweff, B, c1, NIN + 1, H // 2, W // 2, 4)
+        name = "wgrad_kernel<8,3,4,8,64> (enc.0 o enc.1 composite weight gradient)"
+        algo_bytes = B * (NIN * H * W + c1 * (H // 2) * (W // 2)) * 4          # read x once, read dy once
+    ms = event_time_ms(fn)
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+            "algorithmic_bytes_per_launch": algo_bytes}
+
+
+def cpu_baseline(workload, budget_s=15.0):
+    """The CPU oracle on a bounded sample of the same workload (train step / latents on 64-patch batches)."""
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(0)
+    ref = O.OracleVQVAE()
+    x = torch.randn(64, 2, 128, 128, generator=torch.Generator().manual_seed(1234))
+    if workload == "c3":
+        opt = O.make_adam(ref, 1e-4)
+
+        def one():
+            O.train_step(ref, opt, x)
+        sample = "training step (fwd+bwd+Adam) on batches of 64 patches, PyTorch CPU fp32"
+    else:
+        def one():
+            with torch.no_grad():
+                O.encode_per_sample(ref, x)
+        sample = "process_VAE loop (batch-of-one enc->vq) over 64 patches, PyTorch CPU fp32"
+    one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 40:
+            break
+    return {"value": round(64 * n / el, 1), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x {sample}; {os.cpu_count()} logical CPUs on host"}
+
+
+def main():
+    args = parse()
+    from dynamorph_amd import VQ_VAE
+    from dynamorph_amd import dist as D
+    from dynamorph_amd import engine as E
+    from dynamorph_amd.train import FusedTrainer
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = args.batch or (2048 if args.workload == "c3" else 1024)
+
+    torch.manual_seed(0)
+    model = VQ_VAE().to(dev)
+    x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+
+    if args.workload == "c3":
+        trainer = FusedTrainer(model, lr=1e-4, use_graph=not args.no_graph)
+
+        def step():
+            return trainer.step(x)
+    else:
+        L = E.Layers(model)
+
+        def step():
+            with torch.no_grad():
+                z_b, _ = E.encoder_forward(L, x, per_sample=True)
+                z_a, _, _ = E.vq_forward(L.codebook.weight, z_b, float(model.commitment_cost))
+            return z_a
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, device=dev)
+
+    losses = out.tolist() if args.workload == "c3" else None
+    roof = None if args.no_roofline or rank != 0 else roofline_dominant_kernel(model, x, args.workload)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload)
+
+    if rank == 0:
+        wl = ("C3: VQ_VAE training step (forward + backward + fused Adam), 2x128x128 fp32 synthetic patches"
+              if args.workload == "c3" else
+              "C2: VQ_VAE inference latents (enc + vq, per-sample BatchNorm statistics = process_VAE), 2x128x128 fp32")
+        line = {
+            "metric": "cell-patches/sec (128x128x2) VQ-VAE " + ("fwd+bwd" if args.workload == "c3" else "latent encoding"),
+            "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "hip_graph": (not args.no_graph) if args.workload == "c3" else False},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        if losses is not None:
+            line["final_losses"] = dict(zip(("recon", "commitment", "total", "perplexity"), [round(v, 6) for v in losses]))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference has no multi-device code at all; what the path needs is small:
+  * inference latents (process_VAE): patches are independent -> contiguous shards, NO collective;
+  * training: ONE all-reduce per step over a single flat fp32 gradient bucket (24 058 floats = 96 KB for
+    the default model, latency-bound), then the identical fused Adam on every rank.  Every loss is a mean
+    over the local batch (vq_vae.py:74-75, 322), so the mean of per-rank gradients is the gradient of the
+    global-batch mean loss given rank-local BatchNorm statistics (standard DDP semantics).
+
+Everything here is host logic on torch tensors of any device, so it is covered by gloo tests on the CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (RANK/WORLD_SIZE/MASTER_*).
+    Returns (rank, world, local_rank); a single-process run needs no group and returns (0, 1, 0)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def shard_range(n, rank, world):
+    """Contiguous shard [lo, hi) of n independent units for `rank`; sizes differ by at most one and the
+    shards tile [0, n) in rank order (so gathering in rank order restores file-path order)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatParams:
+    """All trainable tensors of a module as views of ONE flat buffer, gradients as views of a second one."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, device=dev, dtype=dt)
+        self.grad = torch.zeros(n, device=dev, dtype=dt)
+        self._gview = {}
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)        # parameter storage now lives in the flat buffer
+            self._gview[id(p)] = self.grad[off:off + k].view_as(p)
+            off += k
+
+    def gview(self, p):
+        return self._gview[id(p)]
+
+    def expose_grads(self):
+        for p in self.params:
+            p.grad = self._gview[id(p)]
+
+
+def broadcast_(flat, buffers=(), src=0, group=None):
+    """Same replica on every rank before the first step (parameters + BatchNorm buffers)."""
+    if world_size(group) == 1:
+        return
+    dist.broadcast(flat, src=src, group=group)
+    for b in buffers:
+        dist.broadcast(b, src=src, group=group)
+
+
+def allreduce_mean_(t, group=None):
+    """In-place mean over ranks of one flat bucket: a single collective per step."""
+    w = world_size(group)
+    if w == 1:
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t.mul_(1.0 / w)
+    return t
+
+
+def max_over_ranks(value, device=None, group=None):
+    """Scalar max over ranks (bench timing contract)."""
+    if world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

@@ -1,0 +1,216 @@
+"""Training step of the VQ-VAE path.
+
+Two ways to train, same kernels underneath:
+
+  * drop-in (reference call pattern, run_training.py:404-408):
+        _, loss_dict = model(batch, **kwargs); loss_dict['total_loss'].backward(); optimizer.step()
+    with any torch optimizer -- goes through torch.autograd (dynamorph_amd.vq_vae).
+
+  * FusedTrainer.step(batch): the MI355X-first path.  All 43 trainable tensors are views of ONE flat
+    fp32 buffer, their gradients views of a second one, so a step is
+        forward kernels -> backward kernels (write straight into the flat gradient buffer)
+        -> ONE RCCL all-reduce of that buffer (data parallel, one process per GPU)
+        -> ONE fused Adam launch,
+    no autograd bookkeeping, no host synchronisation, and the forward+backward launch sequence is
+    captured into a HIP graph and replayed (hipGraph instead of a tracing compiler).
+
+`run_one_batch` / `train` mirror run_training.py:377-417 / :455-551 (same arguments and loop).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import dist as D
+from . import engine as E
+from . import ops
+from .train_utils import EarlyStopping
+
+LOSS_KEYS = ("recon_loss", "commitment_loss", "total_loss", "perplexity")
+
+
+class FusedTrainer:
+    """Adam(lr, betas=(.9,.999), eps=1e-8) exactly as run_training.py:485 builds it, fused."""
+
+    def __init__(self, model, lr=1e-3, betas=(.9, .999), eps=1e-8, process_group=None, use_graph=True):
+        self.model = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.group = process_group
+        self.world = D.world_size(process_group)
+        params = [p for p in model.parameters() if p.requires_grad]
+        if params[0].device.type != "cuda":
+            raise RuntimeError("FusedTrainer: move the model to the GPU first (no CPU fallback)")
+        self.fp = D.FlatParams(params)
+        self.params, self.flat, self.grad = self.fp.params, self.fp.flat, self.fp.grad
+        dev, n = self.flat.device, self.flat.numel()
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.step_dev = torch.zeros(1, device=dev)
+        self.w_recon = torch.tensor([float(model.weight_recon)], device=dev)
+        self.w_commit = torch.tensor([float(model.weight_commitment)], device=dev)
+        self.use_graph = use_graph
+        self._graph = None
+        self._static_x = None
+        self._static_mask = None
+        self._static_out = None
+        D.broadcast_(self.flat, list(model.buffers()), group=self.group)    # same replica everywhere
+
+    # ------------------------------------------------------------------------------------------
+    def G(self, p):
+        return self.fp.gview(p)
+
+    def expose_grads(self):
+        """Make p.grad point at the flat gradient views (for inspection / torch tooling)."""
+        self.fp.expose_grads()
+
+    def forward_backward(self, x, mask=None):
+        """One forward + backward; returns the device tensor (recon, commitment, total, perplexity)."""
+        model = self.model
+        L = E.Layers(model)
+        cc = float(model.commitment_cost)
+        z, ecx = E.encoder_forward(L, x)
+        zq, idx, vsc = E.vq_forward(L.codebook.weight, z, cc)
+        dec, dcx = E.decoder_forward(L, zq, x, mask)
+        B, NIN, H, W = x.shape
+        scalars = ops.loss_finalize(dcx.loss_slabs, B * NIN * H * W, vsc, float(model.weight_recon),
+                                    float(model.weight_commitment))
+        g_zq = E.decoder_backward(L, dcx, self.w_recon, None, self.G)
+        gcb = self.G(L.codebook.weight)
+        gcb.zero_()
+        dz, _ = ops.vq_backward(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc, dw=gcb)
+        E.encoder_backward(L, ecx, dz, self.G)
+        return scalars
+
+    def _allreduce(self):
+        D.allreduce_mean_(self.grad, self.group)     # every loss is a mean over the local batch
+
+    def _adam(self):
+        self.step_dev += 1
+        ops.adam(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_dev)
+
+    def step(self, x, mask=None):
+        """One optimisation step on a device batch; returns the (4,) device tensor of LOSS_KEYS values."""
+        if not x.is_cuda:
+            raise RuntimeError("FusedTrainer.step: batch must be on the GPU")
+        x = x.contiguous()
+        if not self.use_graph:
+            out = self.forward_backward(x, mask)
+        else:
+            out = self._graph_step(x, mask)
+        self._allreduce()
+        self._adam()
+        return out
+
+    def _graph_step(self, x, mask):
+        key = (tuple(x.shape), None if mask is None else tuple(mask.shape))
+        if self._graph is None or self._graph_key != key:
+            self._static_x = torch.empty_like(x)
+            self._static_mask = torch.empty_like(mask) if mask is not None else None
+            self._static_x.copy_(x)
+            if mask is not None:
+                self._static_mask.copy_(mask)
+            # warm-up on a side stream (allocator + lazy init), then capture.  The warm-up really executes,
+            # so the BatchNorm running statistics it advanced are put back: only replays count as steps.
+            bufs = list(self.model.buffers())
+            saved = [b.clone() for b in bufs]
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.forward_backward(self._static_x, self._static_mask)
+            torch.cuda.current_stream().wait_stream(s)
+            for b, sv in zip(bufs, saved):
+                b.copy_(sv)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._static_out = self.forward_backward(self._static_x, self._static_mask)
+            self._graph, self._graph_key = g, key
+        else:
+            self._static_x.copy_(x)
+            if mask is not None:
+                self._static_mask.copy_(mask)
+        self._graph.replay()
+        return self._static_out
+
+
+# ================================================================ reference-style loop mirrors
+def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, transform=None, training=True):
+    """run_training.py:377-417.  `optimizer` may be a torch optimizer (autograd path) or a FusedTrainer."""
+    model_kwargs = model_kwargs or {}
+    if transform is not None:
+        flips = torch.from_numpy(np.random.choice([0, 1, 2], size=len(batch))).to(device=batch.device, dtype=torch.int32)
+        rots = torch.from_numpy(np.random.choice([0, 1, 2, 3], size=len(batch))).to(device=batch.device, dtype=torch.int32)
+        batch = ops.augment(batch.contiguous(), flips, rots)       # one kernel instead of the O(B) python loop
+    fused = isinstance(optimizer, FusedTrainer)
+    if fused and training and model_kwargs.get("time_matching_mat") is None:
+        vals = optimizer.step(batch, model_kwargs.get("batch_mask"))
+        vals = vals.tolist()                                           # one device sync per step (reference: five)
+        loss_dict = dict(zip(LOSS_KEYS, vals))
+        loss_dict["time_matching_loss"] = 0.
+    else:
+        if fused and training:
+            raise NotImplementedError("FusedTrainer has no time-matching term yet: pass a torch optimizer for it")
+        _, loss_dict = model(batch, **model_kwargs)
+        if training:
+            loss_dict['total_loss'].backward()
+            optimizer.step()
+            model.zero_grad()
+    for key, loss in loss_dict.items():
+        train_loss.setdefault(key, []).append(float(loss))
+    return model, train_loss
+
+
+def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10, lr=0.001, batch_size=16,
+          device='cuda:0', shuffle_data=False, transform=None, val_split_ratio=0.15, patience=20,
+          get_relation_tensor=None, get_mask=None, writer=None, fused=True):
+    """run_training.py:455-551: Adam, contiguous validation block, epoch/batch loops, EarlyStopping
+    checkpoint of the state_dict to <output_dir>/model.pt.  `dataset` is a TensorDataset-like object
+    indexable with a list of ids (dataset[ids][0] -> host tensor)."""
+    assert val_split_ratio is None or 0 < val_split_ratio < 1
+    if patience is not None:
+        assert val_split_ratio is not None
+    use_fused = fused and relation_mat is None
+    optimizer = FusedTrainer(model, lr=lr) if use_fused else torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
+    model.zero_grad()
+    n_samples = len(dataset)
+    sample_ids = list(range(n_samples))
+    split = int(np.floor(val_split_ratio * n_samples))
+    split_start = np.random.randint(0, n_samples - split)
+    if shuffle_data:
+        np.random.shuffle(sample_ids)
+    val_ids = sample_ids[split_start: split_start + split]
+    train_ids = sample_ids[:split_start] + sample_ids[split_start + split:]
+    n_train, n_val = len(train_ids), len(val_ids)
+    n_batches = int(np.ceil(n_train / batch_size))
+    n_val_batches = int(np.ceil(n_val / batch_size))
+    os.makedirs(output_dir, exist_ok=True)
+    model_path = os.path.join(output_dir, 'model.pt')
+    early_stopping = EarlyStopping(patience=patience, verbose=True, path=model_path)
+    for epoch in range(n_epochs):
+        train_loss, val_loss = {}, {}
+        print('start epoch %d' % epoch)
+        for phase, ids, nb, losses in (("train", train_ids, n_batches, train_loss), ("val", val_ids, n_val_batches, val_loss)):
+            for i in range(nb):
+                ids_batch = ids[i * batch_size:min((i + 1) * batch_size, len(ids))]
+                batch = dataset[ids_batch][0].to(device)
+                kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_batch, device=device) if get_relation_tensor else None,
+                      'batch_mask': get_mask(mask, ids_batch, device=device) if get_mask else None}
+                model, losses = run_one_batch(model, batch, losses, optimizer=optimizer, model_kwargs=kw,
+                                              transform=transform, training=(phase == "train"))
+        if shuffle_data:
+            np.random.shuffle(train_ids)
+        for key, loss in train_loss.items():
+            train_loss[key] = sum(loss) / len(loss)
+            if writer is not None:
+                writer.add_scalar('Loss/' + key, train_loss[key], epoch)
+        for key, loss in val_loss.items():
+            val_loss[key] = sum(loss) / len(loss)
+            if writer is not None:
+                writer.add_scalar('Val loss/' + key, val_loss[key], epoch)
+        early_stopping(val_loss['total_loss'], model)
+        if early_stopping.early_stop:
+            print("Early stopping")
+            break
+        print('epoch %d' % epoch)
+        print('train: ', ''.join(['{}:{:0.4f}  '.format(key, loss) for key, loss in train_loss.items()]))
+        print('validation: ', ''.join(['{}:{:0.4f}  '.format(key, loss) for key, loss in val_loss.items()]))
+    return model
