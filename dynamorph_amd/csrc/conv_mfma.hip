@@ -24,57 +24,62 @@
 // partial sums (sum v, sum v*q) in double -- one slab per workgroup, reduced deterministically
 // by the finalize kernels in bn.hip.
 #include "dm_common.h"
+#include "tile.h"
 
 namespace {
 
-// --------------------------------------------------------------------------- tile fill
-// Stage CIN planes of ROWS x (4*COLS4) floats into LDS.  Row 0 / col 0 of the tile are global
-// (gy0, gx0); gx0 is a multiple of 4 and W is a multiple of 4, so every float4 is either fully
-// inside the image or fully in the zero padding.  Padding is zero AFTER the operand transform.
-template <int CIN, int ROWS, int COLS4, int RS, int PS>
-__device__ __forceinline__ void fill_tile(float *__restrict__ lds, const Operand &op, int b, int Cphys,
-                                          int H, int W, int gy0, int gx0)
+// ----------------------------------------------------------------------------- epilogue
+// Side inputs of one output float4 (ReLU-backward mask tensor, residual, second-moment partner) are
+// loaded first for every tile of a pass and only then consumed, so the loads overlap.
+struct EpiIn {
+    f32x4 m, r, q;
+};
+
+__device__ __forceinline__ EpiIn epilogue_loads(const Epilogue &ep, long long off, bool valid)
 {
-    constexpr int PER_C = ROWS * COLS4;
-    constexpr int TOTAL = CIN * PER_C;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < TOTAL; i += DM_BLOCK) {
-        const int c = i / PER_C;
-        const int rem = i - c * PER_C;
-        const int r = rem / COLS4;
-        const int j4 = rem - r * COLS4;
-        const int gy = gy0 + r, gx = gx0 + 4 * j4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            if (c < Cphys) v = operand_load4(op, (((long long)b * Cphys + c) * H + gy) * (long long)W + gx, b, c);
-            else v = (f32x4){1.f, 1.f, 1.f, 1.f};
-        }
-        *reinterpret_cast<f32x4 *>(lds + c * PS + r * RS + 4 * j4) = v;
+    EpiIn e;
+    e.m = (f32x4){1.f, 1.f, 1.f, 1.f};
+    e.r = (f32x4){0.f, 0.f, 0.f, 0.f};
+    e.q = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        if (ep.mask.p0) e.m = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + off);
+        if (ep.resid) e.r = *reinterpret_cast<const f32x4 *>(ep.resid + off);
+        if (ep.stat_q) e.q = *reinterpret_cast<const f32x4 *>(ep.stat_q + off);
+    }
+    return e;
+}
+
+// mask coefficients (c0, c2) of the lane's output channel: keep v where c0*m + c2 > 0
+__device__ __forceinline__ void mask_coef(const Epilogue &ep, int b, int chan, float &c0, float &c2)
+{
+    c0 = 1.f; c2 = 0.f;
+    if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) {
+        const float *cf = ep.mask.coef + (long long)b * ep.mask.coef_bstride + chan * 4;
+        c0 = cf[0]; c2 = cf[2];
     }
 }
 
-// ----------------------------------------------------------------------------- epilogue
-// v: 4 consecutive output elements (along x) of channel `chan` at element offset `off`.
-__device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, float *__restrict__ out, long long off,
-                                              int b, int chan, double &s1, double &s2)
+// v: 4 consecutive output elements (along x) at element offset `off`.
+__device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, const EpiIn &e, float mc0, float mc2,
+                                              float *__restrict__ out, long long off, double &s1, double &s2)
 {
     if (ep.mask.p0) {
-        const f32x4 mv = operand_load4(ep.mask, off, b, chan);
+        const f32x4 mv = mc0 * e.m + mc2;
         v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
         v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
     }
-    if (ep.resid) v += *reinterpret_cast<const f32x4 *>(ep.resid + off);
+    v += e.r;
     *reinterpret_cast<f32x4 *>(out + off) = v;
     if (ep.stats) {
-        const f32x4 q = ep.stat_q ? *reinterpret_cast<const f32x4 *>(ep.stat_q + off) : v;
+        const f32x4 q = ep.stat_q ? e.q : v;
         s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
         s2 += (double)(v.x * q.x) + (double)(v.y * q.y) + (double)(v.z * q.z) + (double)(v.w * q.w);
     }
 }
 
-__device__ __forceinline__ f32x4 bias_relu(f32x4 v, const Epilogue &ep, int nb)
+__device__ __forceinline__ f32x4 bias_relu(f32x4 v, const Epilogue &ep, float bias)
 {
-    if (ep.bias) v += ep.bias[nb];
+    v += bias;
     if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
 }
@@ -118,7 +123,7 @@ __device__ __forceinline__ void stats_reduce(double (&s1)[NTT], double (&s2)[NTT
 }
 
 // ============================================================================ kernel A
-template <int CIN, int NT, int TH, int TW>
+template <int CIN, int NT, int TH, int TW, bool TWO>
 __global__ __launch_bounds__(DM_BLOCK) void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out,
                                                              Epilogue ep, int Cphys, int NOUT, int H, int W)
 {
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(DM_BLOCK) void conv4x4s2_kernel(Operand in, WeightV
     constexpr int KS = CIN * 4, CG = TW / 16, MT = TH * CG, MTW = MT / 4;
     static_assert(MTW % 2 == 0 && MTW >= 2, "need an even number of M tiles per wave");
     __shared__ __attribute__((aligned(16))) float tile[CIN * PS];
+    __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
     __shared__ double s_stat[4 * NT * 16][2];
 
     const int Ho = H >> 1, Wo = W >> 1;
@@ -136,17 +142,24 @@ __global__ __launch_bounds__(DM_BLOCK) void conv4x4s2_kernel(Operand in, WeightV
     const int b = bid / tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
 
-    fill_tile<CIN, IH, COLS4, RS, PS>(tile, in, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+    TileStage<CIN, IH, COLS4, RS, PS, TWO> stage;
+    stage.issue(in, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+    stage_coef(s_coef, in, b, Cphys);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
-    float wreg[NT][KS];
+    float wreg[NT][KS], bias[NT], mc0[NT], mc2[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = 16 * t + m;
+        const int nc = n < NOUT ? n : 0;
+        bias[t] = ep.bias ? ep.bias[nc] : 0.f;
+        mask_coef(ep, b, nc, mc0[t], mc2[t]);
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             wreg[t][s] = n < NOUT ? wv.w[wv.off + n * wv.sn + (s >> 2) * wv.sc + (s & 3) * wv.sky + kq * wv.skx] : 0.f;
     }
+    __syncthreads();
+    stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
     __syncthreads();
 
     double s1[NT], s2[NT];
@@ -159,6 +172,17 @@ __global__ __launch_bounds__(DM_BLOCK) void conv4x4s2_kernel(Operand in, WeightV
         const int r0 = t0 / CG, c0 = t0 % CG, r1 = t1 / CG, c1 = t1 % CG;
         const float *a0p = tile + (2 * r0) * RS + 32 * c0 + abase;
         const float *a1p = tile + (2 * r1) * RS + 32 * c1 + abase;
+        // side inputs of the epilogue first: they are in flight during the MFMA loop
+        EpiIn e0[NT], e1[NT];
+        long long o0[NT], o1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = 16 * t + m;
+            o0[t] = (((long long)b * NOUT + n) * Ho + (oy0 + r0)) * Wo + ox0 + 16 * c0 + 4 * kq;
+            o1[t] = (((long long)b * NOUT + n) * Ho + (oy0 + r1)) * Wo + ox0 + 16 * c1 + 4 * kq;
+            e0[t] = epilogue_loads(ep, o0[t], n < NOUT);
+            e1[t] = epilogue_loads(ep, o1[t], n < NOUT);
+        }
         f32x4 acc0[NT], acc1[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -174,12 +198,9 @@ __global__ __launch_bounds__(DM_BLOCK) void conv4x4s2_kernel(Operand in, WeightV
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int n = 16 * t + m;
-            if (n < NOUT) {
-                const long long o0 = (((long long)b * NOUT + n) * Ho + (oy0 + r0)) * Wo + ox0 + 16 * c0 + 4 * kq;
-                const long long o1 = (((long long)b * NOUT + n) * Ho + (oy0 + r1)) * Wo + ox0 + 16 * c1 + 4 * kq;
-                epilogue_tail(bias_relu(acc0[t], ep, n), ep, out, o0, b, n, s1[t], s2[t]);
-                epilogue_tail(bias_relu(acc1[t], ep, n), ep, out, o1, b, n, s1[t], s2[t]);
+            if (16 * t + m < NOUT) {
+                epilogue_tail(bias_relu(acc0[t], ep, bias[t]), ep, e0[t], mc0[t], mc2[t], out, o0[t], s1[t], s2[t]);
+                epilogue_tail(bias_relu(acc1[t], ep, bias[t]), ep, e1[t], mc0[t], mc2[t], out, o1[t], s1[t], s2[t]);
             }
         }
     }
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(DM_BLOCK) void conv4x4s2_kernel(Operand in, WeightV
 }
 
 // ============================================================================ kernel B
-template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW>
+template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO>
 __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out,
                                                            Epilogue ep, int Cphys, int NOUT, int H, int W)
 {
@@ -201,6 +222,7 @@ __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightVie
     static_assert(MTW % 2 == 0 && MTW >= 2, "need an even number of M tiles per wave");
     static_assert(!PIX || TAPS == 9, "pixel shuffle is the 3x3 formulation");
     __shared__ __attribute__((aligned(16))) float tile[CIN * PS];
+    __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
     __shared__ double s_stat[4 * NTT * 16][2];
 
     const int tiles_x = W / TW, tiles_y = H / TH;
@@ -210,7 +232,9 @@ __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightVie
     const int b = bid / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    fill_tile<CIN, IH, COLS4, RS, PS>(tile, in, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
+    TileStage<CIN, IH, COLS4, RS, PS, TWO> stage;
+    stage.issue(in, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
+    stage_coef(s_coef, in, b, Cphys);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
     const int CO = PIX ? NOUT >> 2 : NOUT;           // physical output channels
@@ -223,10 +247,13 @@ __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightVie
     const int abase = kq * PS + m + 3 * PADR;
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-        float wreg[NT][KS];
+        float wreg[NT][KS], bias[NT], mc0[NT], mc2[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = 16 * (pass * NT + t) + m;
+            const int nb = n < NOUT ? (PIX ? n >> 2 : n) : 0;
+            bias[t] = ep.bias ? ep.bias[nb] : 0.f;
+            mask_coef(ep, b, nb, mc0[t], mc2[t]);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int cg4 = s / TAPS, tap = s % TAPS;
@@ -246,13 +273,33 @@ __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightVie
                 wreg[t][s] = wvl;
             }
         }
-        if (pass == 0) __syncthreads();
+        if (pass == 0) {
+            __syncthreads();
+            stage.commit(tile, s_coef, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
+            __syncthreads();
+        }
 
         for (int p = 0; p < MTW / 2; ++p) {
             const int t0 = wave + 8 * p, t1 = t0 + 4;
             const int r0 = t0 / CG, c0 = t0 % CG, r1 = t1 / CG, c1 = t1 % CG;
             const float *a0p = tile + r0 * RS + 16 * c0 + abase;
             const float *a1p = tile + r1 * RS + 16 * c1 + abase;
+            EpiIn e0[NT], e1[NT];
+            long long o0[NT], o1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = 16 * (pass * NT + t) + m;
+                if (PIX) {
+                    const int nb = n >> 2, py = (n >> 1) & 1, px = n & 1;
+                    o0[t] = (((long long)b * CO + nb) * OH + 2 * (y0 + r0) + py) * OW + 2 * (x0 + 16 * c0 + 4 * kq) + 4 * px;
+                    o1[t] = (((long long)b * CO + nb) * OH + 2 * (y0 + r1) + py) * OW + 2 * (x0 + 16 * c1 + 4 * kq) + 4 * px;
+                } else {
+                    o0[t] = (((long long)b * CO + n) * OH + (y0 + r0)) * OW + x0 + 16 * c0 + 4 * kq;
+                    o1[t] = (((long long)b * CO + n) * OH + (y0 + r1)) * OW + x0 + 16 * c1 + 4 * kq;
+                }
+                e0[t] = epilogue_loads(ep, o0[t], n < NOUT);
+                e1[t] = epilogue_loads(ep, o1[t], n < NOUT);
+            }
             f32x4 acc0[NT], acc1[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -273,27 +320,19 @@ __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightVie
                 const int tt = pass * NT + t;
                 const int n = 16 * tt + m;
                 const bool valid = n < NOUT;
-                const int nb = PIX ? n >> 2 : n;
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
-                    const int r = which ? r1 : r0, cgi = which ? c1 : c0;
-                    f32x4 v = bias_relu(which ? acc1[t] : acc0[t], ep, valid ? nb : 0);
+                    f32x4 v = bias_relu(which ? acc1[t] : acc0[t], ep, bias[t]);
                     if (PIX) {
                         // partner lane (n ^ 1) holds the other x-phase of the same output row
                         f32x4 pv;
                         pv.x = __shfl_xor(v.x, 1, 64); pv.y = __shfl_xor(v.y, 1, 64);
                         pv.z = __shfl_xor(v.z, 1, 64); pv.w = __shfl_xor(v.w, 1, 64);
-                        const int py = (n >> 1) & 1, px = n & 1;
-                        const f32x4 o4 = px ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
-                        if (valid) {
-                            const long long off = (((long long)b * CO + nb) * OH + 2 * (y0 + r) + py) * OW +
-                                                  2 * (x0 + 16 * cgi + 4 * kq) + 4 * px;
-                            epilogue_tail(o4, ep, out, off, b, nb, s1[tt], s2[tt]);
-                        }
-                    } else if (valid) {
-                        const long long off = (((long long)b * CO + n) * OH + (y0 + r)) * OW + x0 + 16 * cgi + 4 * kq;
-                        epilogue_tail(v, ep, out, off, b, n, s1[tt], s2[tt]);
+                        v = (n & 1) ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
                     }
+                    if (valid)
+                        epilogue_tail(v, ep, which ? e1[t] : e0[t], mc0[t], mc2[t], out, which ? o1[t] : o0[t],
+                                      s1[tt], s2[tt]);
                 }
             }
         }
@@ -319,8 +358,12 @@ int launch_conv4(const ConvArgs &a)
 {
     constexpr int TH = 8;
     const int grid = a.B * ((a.H / 2) / TH) * ((a.W / 2) / TW);
-    hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW>), dim3(grid), dim3(DM_BLOCK), 0, a.stream,
-                       a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
+    if (a.in.mode == DM_LOAD_AFFINE2)
+        hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, true>), dim3(grid), dim3(DM_BLOCK), 0, a.stream,
+                           a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
+    else
+        hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, false>), dim3(grid), dim3(DM_BLOCK), 0, a.stream,
+                           a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
     return 0;
 }
 
@@ -332,8 +375,12 @@ int launch_conv3(const ConvArgs &a)
 {
     constexpr int TH = TW == 16 ? 16 : 8;
     const int grid = a.B * (a.H / TH) * (a.W / TW);
-    hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW>), dim3(grid), dim3(DM_BLOCK), 0, a.stream,
-                       a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
+    if (a.in.mode == DM_LOAD_AFFINE2)
+        hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, true>), dim3(grid), dim3(DM_BLOCK), 0,
+                           a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
+    else
+        hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, false>), dim3(grid), dim3(DM_BLOCK), 0,
+                           a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
     return 0;
 }
 
@@ -346,6 +393,7 @@ static int conv_common_checks(const char *who, const dm_operand *in, const dm_we
     if (dm_check_operand(in, who)) return -1;
     DM_REQUIRE(w && w->w && out, "%s: NULL weight or output", who);
     DM_REQUIRE(B > 0 && CIN > 0 && NOUT > 0 && H > 0 && W > 0, "%s: bad shape", who);
+    DM_REQUIRE(CIN <= DM_COEF_MAX_C, "%s: more than %d input channels", who, DM_COEF_MAX_C);
     DM_REQUIRE(CIN - (in->ones_channel ? 1 : 0) > 0, "%s: no physical input channel", who);
     if (ep && ep->mask.p0 && dm_check_operand(&ep->mask, who)) return -1;
     DM_REQUIRE(!(ep && ep->mask.p0 && ep->mask.ones_channel), "%s: mask operand cannot have a ones channel", who);

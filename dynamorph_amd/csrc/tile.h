@@ -1,0 +1,88 @@
+// tile.h -- staging of an input tile (with halo) from HBM into LDS through the operand transform.
+//
+// Two phases so that every global load of a tile is in flight at once:
+//   issue():  all of a thread's 16-byte loads (both tensors for AFFINE2) go out back to back, predicated
+//             only on "inside the image"; no branch depends on the operand mode.
+//   commit(): v = c0*p0 + c1*p1 + c2, optional ReLU, zero in the padding, 1 in the synthetic ones channel;
+//             one ds_write_b128 per element.  The per-channel coefficients come from a small LDS table
+//             (stage_coef) so commit issues no global loads.
+// IDENT/RELU use c0 = 1, c1 = c2 = 0, which leaves the value bit-identical.
+#pragma once
+#include "dm_common.h"
+
+constexpr int DM_COEF_MAX_C = 64;
+
+// LDS coefficient table [C][4] = (c0, c1, c2, relu_floor) for sample b.  relu_floor = 0 (ReLU) or -inf.
+__device__ __forceinline__ void stage_coef(float *__restrict__ s_coef, const Operand &op, int b, int C)
+{
+    const int c = threadIdx.x;
+    if (c < C) {
+        float c0 = 1.f, c1 = 0.f, c2 = 0.f;
+        if (op.mode >= DM_LOAD_AFFINE) {
+            const float *cf = op.coef + (long long)b * op.coef_bstride + c * 4;
+            c0 = cf[0]; c2 = cf[2];
+            if (op.mode == DM_LOAD_AFFINE2) c1 = cf[1];
+        }
+        const bool relu = op.mode == DM_LOAD_RELU || op.mode == DM_LOAD_AFFINE_RELU;
+        *reinterpret_cast<f32x4 *>(s_coef + c * 4) = (f32x4){c0, c1, c2, relu ? 0.f : -__builtin_inff()};
+    }
+}
+
+template <int CIN, int ROWS, int COLS4, int RS, int PS, bool TWO>
+struct TileStage {
+    static constexpr int PER_C = ROWS * COLS4;
+    static constexpr int TOTAL = CIN * PER_C;
+    static constexpr int N = (TOTAL + DM_BLOCK - 1) / DM_BLOCK;
+    f32x4 v[N];
+    f32x4 u[TWO ? N : 1];
+
+    __device__ __forceinline__ void issue(const Operand &op, int b, int Cphys, int H, int W, int gy0, int gx0)
+    {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = threadIdx.x + k * DM_BLOCK;
+            const int c = i / PER_C;
+            const int rem = i - c * PER_C;
+            const int r = rem / COLS4;
+            const int j4 = rem - r * COLS4;
+            const int gy = gy0 + r, gx = gx0 + 4 * j4;
+            const bool ok = i < TOTAL && c < Cphys && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const long long off = (((long long)b * Cphys + c) * H + gy) * (long long)W + gx;
+            v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ok) v[k] = *reinterpret_cast<const f32x4 *>(op.p0 + off);
+            if (TWO) {
+                u[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok) u[k] = *reinterpret_cast<const f32x4 *>(op.p1 + off);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void commit(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
+                                           int H, int W, int gy0, int gx0)
+    {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = threadIdx.x + k * DM_BLOCK;
+            const int c = i / PER_C;
+            const int rem = i - c * PER_C;
+            const int r = rem / COLS4;
+            const int j4 = rem - r * COLS4;
+            const int gy = gy0 + r, gx = gx0 + 4 * j4;
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            f32x4 val;
+            if (c < Cphys) {
+                const f32x4 cf = *reinterpret_cast<const f32x4 *>(s_coef + c * 4);
+                val = cf.x * v[k] + cf.z;
+                if (TWO) val += cf.y * u[k];
+                // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
+                val.x = val.x < cf.w ? cf.w : val.x; val.y = val.y < cf.w ? cf.w : val.y;
+                val.z = val.z < cf.w ? cf.w : val.z; val.w = val.w < cf.w ? cf.w : val.w;
+                if (!inside) val = (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+                const float one = inside ? 1.f : 0.f;
+                val = (f32x4){one, one, one, one};
+            }
+            if (i < TOTAL) *reinterpret_cast<f32x4 *>(lds + c * PS + r * RS + 4 * j4) = val;
+        }
+    }
+};

@@ -16,34 +16,13 @@
 // in a fixed order, and each workgroup writes one slab.  A second kernel adds the slabs in slab
 // order -> bitwise reproducible, no float atomics.
 #include "dm_common.h"
+#include "tile.h"
 
 namespace {
 
 constexpr int WG_MAX_BLOCKS = 512;     // 2 workgroups per CU
 
-template <int CIN, int ROWS, int COLS4, int RS, int PS>
-__device__ __forceinline__ void wg_fill(float *__restrict__ lds, const Operand &op, int b, int Cphys,
-                                        int H, int W, int gy0, int gx0)
-{
-    constexpr int PER_C = ROWS * COLS4;
-    constexpr int TOTAL = CIN * PER_C;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < TOTAL; i += DM_BLOCK) {
-        const int c = i / PER_C;
-        const int rem = i - c * PER_C;
-        const int r = rem / COLS4;
-        const int j4 = rem - r * COLS4;
-        const int gy = gy0 + r, gx = gx0 + 4 * j4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            if (c < Cphys) v = operand_load4(op, (((long long)b * Cphys + c) * H + gy) * (long long)W + gx, b, c);
-            else v = (f32x4){1.f, 1.f, 1.f, 1.f};
-        }
-        *reinterpret_cast<f32x4 *>(lds + c * PS + r * RS + 4 * j4) = v;
-    }
-}
-
-template <int CS, int CT, int KK, int TH, int TW>
+template <int CS, int CT, int KK, int TH, int TW, bool STWO>
 __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, float *__restrict__ slabs,
                                                          int CTphys, int Hs, int Ws, int ntiles)
 {
@@ -59,6 +38,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
     constexpr int LDS_FLOATS = LDS_TILES > RED ? LDS_TILES : RED;
     static_assert(TH % 4 == 0 && TW % 4 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_coefS[DM_COEF_MAX_C * 4];
+    __shared__ __attribute__((aligned(16))) float s_coefT[DM_COEF_MAX_C * 4];
     float *sS = lds, *sT = lds + CS * PSS;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
@@ -88,16 +69,36 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // software pipeline over this workgroup's tiles: the loads of tile i+1 are issued before the MFMA loop
+    // of tile i and written to LDS after it (register staging, single LDS buffer).
+    TileStage<CS, TH, TW / 4, RSS, PSS, STWO> stS;
+    TileStage<CT, TROWS, TCOLS4, RST, PST, false> stT;
+    int tile = blockIdx.x;
+    int cb = 0, cy0 = 0, cx0 = 0;
+    if (tile < ntiles) {
         int tid = tile;
         const int tx = tid % tiles_x; tid /= tiles_x;
-        const int ty = tid % tiles_y;
-        const int b = tid / tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
-        __syncthreads();                             // previous tile fully consumed
-        wg_fill<CS, TH, TW / 4, RSS, PSS>(sS, S, b, CS, Hs, Ws, y0, x0);
-        wg_fill<CT, TROWS, TCOLS4, RST, PST>(sT, T, b, CTphys, Ht, Wt, y0 * STRIDE - PAD, x0 * STRIDE - 4 * PAD);
+        cy0 = (tid % tiles_y) * TH; cb = tid / tiles_y; cx0 = tx * TW;
+        stS.issue(S, cb, CS, Hs, Ws, cy0, cx0);
+        stT.issue(T, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
+        stage_coef(s_coefS, S, cb, CS);
+        stage_coef(s_coefT, T, cb, CTphys);
+    }
+    while (tile < ntiles) {
+        __syncthreads();                             // previous tile fully consumed; coefficient tables visible
+        stS.commit(sS, s_coefS, CS, Hs, Ws, cy0, cx0);
+        stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
         __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            int tid = next;
+            const int tx = tid % tiles_x; tid /= tiles_x;
+            cy0 = (tid % tiles_y) * TH; cb = tid / tiles_y; cx0 = tx * TW;
+            stS.issue(S, cb, CS, Hs, Ws, cy0, cx0);
+            stT.issue(T, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
+            stage_coef(s_coefS, S, cb, CS);
+            stage_coef(s_coefT, T, cb, CTphys);
+        }
         for (int r = wave; r < TH; r += 4) {
 #pragma unroll 2
             for (int x4 = 0; x4 < TW / 4; ++x4) {
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
                 }
             }
         }
+        tile = next;
     }
 
     // combine the four waves in wave order (deterministic), then write this workgroup's slab
@@ -141,14 +143,32 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
     }
 }
 
+// dst[e] = sum over slabs, in a fixed order: 16 slab groups x 16 elements per block; each thread adds its
+// slabs (g, g+16, ...) sequentially with 4 loads in flight, the 16 group sums are then added in group order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nslabs, int E,
                                                           float *__restrict__ dst)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    float s = 0.f;
-    for (int i = 0; i < nslabs; ++i) s += slabs[(long long)i * E + e];
-    dst[e] = s;
+    __shared__ float part[16][17];
+    const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < E) {
+        int i = g;
+        for (; i + 48 < nslabs; i += 64) {
+            const float a = slabs[(long long)i * E + e], b = slabs[(long long)(i + 16) * E + e];
+            const float c = slabs[(long long)(i + 32) * E + e], d = slabs[(long long)(i + 48) * E + e];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; i < nslabs; i += 16) s0 += slabs[(long long)i * E + e];
+    }
+    part[g][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < E) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][el];
+        dst[e] = s;
+    }
 }
 
 int wgrad_tw(int Ws) { return Ws < 64 ? Ws : 64; }
@@ -171,8 +191,12 @@ void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
 {
     constexpr int TH = wgrad_th(CS, CT, KK, TW);
     const int ntiles = B * (Hs / TH) * (Ws / TW);
-    hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs, CTphys, Hs,
-                       Ws, ntiles);
+    if (S.mode == DM_LOAD_AFFINE2)
+        hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW, true>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs,
+                           CTphys, Hs, Ws, ntiles);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW, false>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs,
+                           CTphys, Hs, Ws, ntiles);
 }
 
 }  // namespace
@@ -227,6 +251,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     }
     int rc = dm_launch_status("dm_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 255) / 256), dim3(256), 0, st, slabs, grid, E, dst);
+    DM_REQUIRE(T->mode != DM_LOAD_AFFINE2, "dm_wgrad: T operand cannot be AFFINE2");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 15) / 16), dim3(256), 0, st, slabs, grid, E, dst);
     return dm_launch_status("dm_wgrad(reduce)");
 }
