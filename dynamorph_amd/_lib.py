@@ -23,7 +23,7 @@ class WeightView(C.Structure):
 
 
 class Epilogue(C.Structure):
-    _fields_ = [("bias", vp), ("relu", i32), ("_pad", i32), ("mask", Operand), ("resid", vp), ("stat_q", vp),
+    _fields_ = [("bias", vp), ("relu", i32), ("stats_per_tile", i32), ("mask", Operand), ("resid", vp), ("stat_q", vp),
                 ("stats", vp)]
 
 

@@ -7,7 +7,7 @@
 // GEMM view per workgroup: M = 16 consecutive output pixels of one row (one MFMA tile),
 // N = output channels (16 per tile), K = input channels x taps.  The input tile (with its
 // halo, after the on-load operand transform: BatchNorm apply / ReLU / BatchNorm backward)
-// is staged once in LDS; weights for the wave's N tiles live in registers for the whole
+// is staged in LDS; weights for the wave's N tiles live in registers for the whole
 // workgroup, so each MFMA needs exactly one 4-byte LDS read (the A operand).
 //
 //  kernel A  conv4x4s2: K step = (ci, ky), the 4 k-lanes of the MFMA are the 4 taps kx.
@@ -20,33 +20,44 @@
 //            with N = 4 phases x Cout; lane pairs exchange values so every lane still
 //            stores 16 contiguous bytes.
 //
+// Workgroups are persistent: weights, bias and mask coefficients are loaded once, then the workgroup
+// walks tiles blockIdx, blockIdx + gridDim, ...; the global loads of tile i+1 are issued before the MFMAs
+// and stores of tile i (register staging, tile.h), and inside a tile the LDS operands of K-chunk c+1 are
+// requested before the MFMAs of chunk c, so HBM latency, LDS latency, the matrix pipe and the store
+// stream overlap instead of adding up.
+//
 // Epilogue (dm_epilogue): bias, ReLU, ReLU-backward mask, residual add, store, and per-channel
-// partial sums (sum v, sum v*q) in double -- one slab per workgroup, reduced deterministically
-// by the finalize kernels in bn.hip.
+// partial sums (sum v, sum v*q) in double.  One statistics slab per TILE index (so the per-sample
+// grouping of dm_bn_finalize keeps working): a persistent workgroup writes its totals into the slab
+// of its first tile and zeros the others it owns; everything is reduced deterministically in bn.hip.
 #include "dm_common.h"
 #include "tile.h"
 
 namespace {
 
 // ----------------------------------------------------------------------------- epilogue
-// Side inputs of one output float4 (ReLU-backward mask tensor, residual, second-moment partner) are
-// loaded first for every tile of a pass and only then consumed, so the loads overlap.
-struct EpiIn {
-    f32x4 m, r, q;
-};
+// Side inputs of an output float4.  SIDE_NONE: none (forward convs).  SIDE_MASK: only the ReLU-backward
+// mask tensor, which is also the second-moment partner when stat_q is given (every data gradient that
+// feeds a BatchNorm backward).  SIDE_ALL: mask, residual and stat_q are three different tensors.
+// They are loaded before the MFMA loop of their tile so the loads overlap it.
+enum { SIDE_NONE = 0, SIDE_MASK = 1, SIDE_ALL = 2 };
 
-__device__ __forceinline__ EpiIn epilogue_loads(const Epilogue &ep, long long off, bool valid)
+template <int SIDE> struct EpiIn { f32x4 m; };
+template <> struct EpiIn<SIDE_ALL> { f32x4 m, r, q; };
+
+template <int SIDE>
+__device__ __forceinline__ void epilogue_loads(EpiIn<SIDE> &e, const Epilogue &ep, int off, bool valid)
 {
-    EpiIn e;
-    e.m = (f32x4){1.f, 1.f, 1.f, 1.f};
-    e.r = (f32x4){0.f, 0.f, 0.f, 0.f};
-    e.q = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-        if (ep.mask.p0) e.m = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + off);
-        if (ep.resid) e.r = *reinterpret_cast<const f32x4 *>(ep.resid + off);
-        if (ep.stat_q) e.q = *reinterpret_cast<const f32x4 *>(ep.stat_q + off);
+    if constexpr (SIDE != SIDE_NONE) {
+        e.m = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (valid && ep.mask.p0) e.m = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + off);
     }
-    return e;
+    if constexpr (SIDE == SIDE_ALL) {
+        e.r = (f32x4){0.f, 0.f, 0.f, 0.f};
+        e.q = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (valid && ep.resid) e.r = *reinterpret_cast<const f32x4 *>(ep.resid + off);
+        if (valid && ep.stat_q) e.q = *reinterpret_cast<const f32x4 *>(ep.stat_q + off);
+    }
 }
 
 // mask coefficients (c0, c2) of the lane's output channel: keep v where c0*m + c2 > 0
@@ -60,18 +71,24 @@ __device__ __forceinline__ void mask_coef(const Epilogue &ep, int b, int chan, f
 }
 
 // v: 4 consecutive output elements (along x) at element offset `off`.
-__device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, const EpiIn &e, float mc0, float mc2,
-                                              float *__restrict__ out, long long off, double &s1, double &s2)
+template <int SIDE>
+__device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, const EpiIn<SIDE> &e, float mc0, float mc2,
+                                              float *__restrict__ out, int off, double &s1, double &s2)
 {
-    if (ep.mask.p0) {
-        const f32x4 mv = mc0 * e.m + mc2;
-        v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
-        v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+    f32x4 q = v;
+    if constexpr (SIDE != SIDE_NONE) {
+        if (ep.mask.p0) {
+            const f32x4 mv = mc0 * e.m + mc2;
+            v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+            v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+        }
     }
-    v += e.r;
+    if constexpr (SIDE == SIDE_ALL) v += e.r;
     *reinterpret_cast<f32x4 *>(out + off) = v;
     if (ep.stats) {
-        const f32x4 q = ep.stat_q ? e.q : v;
+        q = v;
+        if constexpr (SIDE == SIDE_MASK) { if (ep.stat_q) q = e.m; }
+        if constexpr (SIDE == SIDE_ALL) { if (ep.stat_q) q = e.q; }
         s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
         s2 += (double)(v.x * q.x) + (double)(v.y * q.y) + (double)(v.z * q.z) + (double)(v.w * q.w);
     }
@@ -84,7 +101,7 @@ __device__ __forceinline__ f32x4 bias_relu(f32x4 v, const Epilogue &ep, float bi
     return v;
 }
 
-// Per-workgroup reduction of the per-lane channel partials -> stats[block][NCH][2].
+// Per-workgroup reduction of the per-lane channel partials -> stats[blockIdx][NCH][2].
 // Lane layout: channel n = 16*t + (lane & 15) (PIX: channel = n >> 2); partials of the 4 lane
 // quarters (lane >> 4) and, with PIX, of the 4 phase lanes are summed with shuffles.
 template <int NTT, bool PIX>
@@ -122,95 +139,163 @@ __device__ __forceinline__ void stats_reduce(double (&s1)[NTT], double (&s2)[NTT
     }
 }
 
+__device__ __forceinline__ void zero_extra_slabs(const Epilogue &ep, int NCH, int ntiles)
+{
+    for (int t2 = blockIdx.x + gridDim.x; t2 < ntiles; t2 += gridDim.x)
+        for (int i = threadIdx.x; i < NCH * 2; i += DM_BLOCK) ep.stats[(long long)t2 * NCH * 2 + i] = 0.0;
+}
+
+// The MFMA loop of MP M-tiles x NT N-tiles.  off(s) is the compile-time LDS offset of K step s.
+// Software pipeline over chunks of CH K-steps: the LDS operands of chunk c+1 are requested before the
+// MFMAs of chunk c are issued (two register buffers); sched_barrier keeps hipcc from sinking the reads
+// back next to their uses, which would expose the LDS latency once per MFMA group.
+template <int MP, int NT, int KS, int CH, class OFF>
+__device__ __forceinline__ void mfma_tiles(const float *const (&ap)[MP], const float (&wreg)[NT][KS],
+                                           f32x4 (&acc)[MP][NT], OFF off)
+{
+    constexpr int NC = (KS + CH - 1) / CH;
+    float av[2][MP][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+        if (j < KS) {
+#pragma unroll
+            for (int i = 0; i < MP; ++i) av[0][i][j] = ap[i][off(j)];
+        }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int s = (c + 1) * CH + j;
+                if (s < KS) {
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) av[(c + 1) & 1][i][j] = ap[i][off(s)];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int s = c * CH + j;
+            if (s < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < MP; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][i][j], wreg[t][s], acc[i][t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ============================================================================ kernel A
-template <int CIN, int NT, int TH, int TW, bool TWO>
-__global__ __launch_bounds__(DM_BLOCK) void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out,
-                                                             Epilogue ep, int Cphys, int NOUT, int H, int W)
+template <int CIN, int NT, int TH, int TW, int SIDE, int WPS>
+__global__ __launch_bounds__(DM_BLOCK, WPS)
+void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
+                      int W, int ntiles)
 {
     constexpr int IH = 2 * TH + 2, RS = 2 * TW + 8, COLS4 = RS / 4, PS = IH * RS;
     constexpr int KS = CIN * 4, CG = TW / 16, MT = TH * CG, MTW = MT / 4;
-    static_assert(MTW % 2 == 0 && MTW >= 2, "need an even number of M tiles per wave");
+    constexpr int MP = NT == 1 ? 2 : 1;                    // M tiles in flight: two MFMA chains either way
+    static_assert(MTW % MP == 0 && MTW >= MP, "M tiles per wave");
     __shared__ __attribute__((aligned(16))) float tile[CIN * PS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
     __shared__ double s_stat[4 * NT * 16][2];
 
     const int Ho = H >> 1, Wo = W >> 1;
     const int tiles_x = Wo / TW, tiles_y = Ho / TH;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-
-    TileStage<CIN, IH, COLS4, RS, PS, TWO> stage;
-    stage.issue(in, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
-    stage_coef(s_coef, in, b, Cphys);
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+
+    TileStage<CIN, IH, COLS4, RS, PS, false> stage;
+    stage.init();
+    int tidx = blockIdx.x, b = 0, oy0 = 0, ox0 = 0;
+    if (tidx < ntiles) {
+        int t = tidx;
+        ox0 = (t % tiles_x) * TW; t /= tiles_x;
+        oy0 = (t % tiles_y) * TH; b = t / tiles_y;
+        stage.issue(in, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+        stage_coef(s_coef, in, b, Cphys);
+    }
+
     float wreg[NT][KS], bias[NT], mc0[NT], mc2[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = 16 * t + m;
         const int nc = n < NOUT ? n : 0;
         bias[t] = ep.bias ? ep.bias[nc] : 0.f;
-        mask_coef(ep, b, nc, mc0[t], mc2[t]);
+        mask_coef(ep, 0, nc, mc0[t], mc2[t]);
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             wreg[t][s] = n < NOUT ? wv.w[wv.off + n * wv.sn + (s >> 2) * wv.sc + (s & 3) * wv.sky + kq * wv.skx] : 0.f;
     }
-    __syncthreads();
-    stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
-    __syncthreads();
 
     double s1[NT], s2[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
-
     const int abase = 2 * m + kq + 3;
-    for (int p = 0; p < MTW / 2; ++p) {
-        const int t0 = wave + 8 * p, t1 = t0 + 4;
-        const int r0 = t0 / CG, c0 = t0 % CG, r1 = t1 / CG, c1 = t1 % CG;
-        const float *a0p = tile + (2 * r0) * RS + 32 * c0 + abase;
-        const float *a1p = tile + (2 * r1) * RS + 32 * c1 + abase;
-        // side inputs of the epilogue first: they are in flight during the MFMA loop
-        EpiIn e0[NT], e1[NT];
-        long long o0[NT], o1[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = 16 * t + m;
-            o0[t] = (((long long)b * NOUT + n) * Ho + (oy0 + r0)) * Wo + ox0 + 16 * c0 + 4 * kq;
-            o1[t] = (((long long)b * NOUT + n) * Ho + (oy0 + r1)) * Wo + ox0 + 16 * c1 + 4 * kq;
-            e0[t] = epilogue_loads(ep, o0[t], n < NOUT);
-            e1[t] = epilogue_loads(ep, o1[t], n < NOUT);
+    auto off = [](int s) { return (s >> 2) * PS + (s & 3) * RS; };
+
+    while (tidx < ntiles) {
+        __syncthreads();                                   // previous tile consumed; coefficient table visible
+        stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+        __syncthreads();
+        const int cb = b, cy0 = oy0, cx0 = ox0;            // the tile now in LDS
+        const int next = tidx + gridDim.x;
+        if (next < ntiles) {                               // next tile's loads fly during this tile's MFMAs
+            int t = next;
+            ox0 = (t % tiles_x) * TW; t /= tiles_x;
+            oy0 = (t % tiles_y) * TH; b = t / tiles_y;
+            stage.issue(in, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+            stage_coef(s_coef, in, b, Cphys);
         }
-        f32x4 acc0[NT], acc1[NT];
+        if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < NT; ++t) mask_coef(ep, cb, 16 * t + m < NOUT ? 16 * t + m : 0, mc0[t], mc2[t]);
+        }
+        for (int p = 0; p < MTW / MP; ++p) {
+            const float *ap[MP];
+            int o[MP][NT];
+            EpiIn<SIDE> e[MP][NT];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int o = (s >> 2) * PS + (s & 3) * RS;
-            const float a0 = a0p[o], a1 = a1p[o];
+            for (int i = 0; i < MP; ++i) {
+                const int ti = wave + 4 * (MP * p + i);
+                const int r = ti / CG, cg = ti % CG;
+                ap[i] = tile + (2 * r) * RS + 32 * cg + abase;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[t][s], acc0[t], 0, 0, 0);
-                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[t][s], acc1[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const int n = 16 * t + m;
+                    o[i][t] = ((cb * NOUT + n) * Ho + (cy0 + r)) * Wo + cx0 + 16 * cg + 4 * kq;
+                    epilogue_loads<SIDE>(e[i][t], ep, o[i][t], n < NOUT);
+                }
             }
-        }
+            f32x4 acc[MP][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (16 * t + m < NOUT) {
-                epilogue_tail(bias_relu(acc0[t], ep, bias[t]), ep, e0[t], mc0[t], mc2[t], out, o0[t], s1[t], s2[t]);
-                epilogue_tail(bias_relu(acc1[t], ep, bias[t]), ep, e1[t], mc0[t], mc2[t], out, o1[t], s1[t], s2[t]);
-            }
+            for (int i = 0; i < MP; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mfma_tiles<MP, NT, KS, 4>(ap, wreg, acc, off);
+#pragma unroll
+            for (int i = 0; i < MP; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + m < NOUT)
+                        epilogue_tail<SIDE>(bias_relu(acc[i][t], ep, bias[t]), ep, e[i][t], mc0[t], mc2[t], out, o[i][t],
+                                            s1[t], s2[t]);
         }
+        tidx = next;
     }
-    if (ep.stats) stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT);
+    if (ep.stats) {
+        stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT);
+        zero_extra_slabs(ep, NOUT, ntiles);
+    }
 }
 
 // ============================================================================ kernel B
-template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO>
-__global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out,
-                                                           Epilogue ep, int Cphys, int NOUT, int H, int W)
+template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO, int SIDE, int WPS>
+__global__ __launch_bounds__(DM_BLOCK, WPS)
+void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
+                    int W, int ntiles)
 {
     constexpr int PADR = TAPS == 9 ? 1 : 0;
     constexpr int IH = TH + 2 * PADR, RS = TAPS == 9 ? TW + 8 : TW, COLS4 = RS / 4;
@@ -218,42 +303,50 @@ __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightVie
     constexpr int PS = PSRAW + ((16 - (PSRAW % 32)) + 32) % 32;      // PS == 16 (mod 32)
     constexpr int KS = (CIN / 4) * TAPS, CG = TW / 16, MT = TH * CG, MTW = MT / 4;
     constexpr int NTT = NT * NPASS;
+    constexpr int MP = NT == 1 ? 2 : 1;
     static_assert(CIN % 4 == 0, "channel groups of 4");
-    static_assert(MTW % 2 == 0 && MTW >= 2, "need an even number of M tiles per wave");
+    static_assert(MTW % MP == 0 && MTW >= MP, "M tiles per wave");
     static_assert(!PIX || TAPS == 9, "pixel shuffle is the 3x3 formulation");
     __shared__ __attribute__((aligned(16))) float tile[CIN * PS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
     __shared__ double s_stat[4 * NTT * 16][2];
 
     const int tiles_x = W / TW, tiles_y = H / TH;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-
-    TileStage<CIN, IH, COLS4, RS, PS, TWO> stage;
-    stage.issue(in, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
-    stage_coef(s_coef, in, b, Cphys);
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
     const int CO = PIX ? NOUT >> 2 : NOUT;           // physical output channels
     const int OH = PIX ? 2 * H : H, OW = PIX ? 2 * W : W;
 
+    TileStage<CIN, IH, COLS4, RS, PS, TWO> stage;
+    stage.init();
+
     double s1[NTT], s2[NTT];
 #pragma unroll
     for (int t = 0; t < NTT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
-
     const int abase = kq * PS + m + 3 * PADR;
+    auto off = [](int s) {
+        const int cg4 = s / TAPS, tap = s % TAPS;
+        return 4 * cg4 * PS + (TAPS == 9 ? (tap / 3) * RS + tap % 3 : 0);
+    };
+
+    // NPASS > 1 (more output-channel tiles than fit in registers): the tile walk is repeated per pass
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
+        int tidx = blockIdx.x, b = 0, y0 = 0, x0 = 0;
+        if (pass > 0) __syncthreads();                      // last tile of the previous pass fully consumed
+        if (tidx < ntiles) {
+            int t = tidx;
+            x0 = (t % tiles_x) * TW; t /= tiles_x;
+            y0 = (t % tiles_y) * TH; b = t / tiles_y;
+            stage.issue(in, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
+            stage_coef(s_coef, in, b, Cphys);
+        }
         float wreg[NT][KS], bias[NT], mc0[NT], mc2[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = 16 * (pass * NT + t) + m;
             const int nb = n < NOUT ? (PIX ? n >> 2 : n) : 0;
             bias[t] = ep.bias ? ep.bias[nb] : 0.f;
-            mask_coef(ep, b, nb, mc0[t], mc2[t]);
+            mask_coef(ep, 0, nb, mc0[t], mc2[t]);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int cg4 = s / TAPS, tap = s % TAPS;
@@ -273,79 +366,116 @@ __global__ __launch_bounds__(DM_BLOCK) void conv3x3_kernel(Operand in, WeightVie
                 wreg[t][s] = wvl;
             }
         }
-        if (pass == 0) {
+
+        while (tidx < ntiles) {
             __syncthreads();
             stage.commit(tile, s_coef, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
             __syncthreads();
-        }
-
-        for (int p = 0; p < MTW / 2; ++p) {
-            const int t0 = wave + 8 * p, t1 = t0 + 4;
-            const int r0 = t0 / CG, c0 = t0 % CG, r1 = t1 / CG, c1 = t1 % CG;
-            const float *a0p = tile + r0 * RS + 16 * c0 + abase;
-            const float *a1p = tile + r1 * RS + 16 * c1 + abase;
-            EpiIn e0[NT], e1[NT];
-            long long o0[NT], o1[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int n = 16 * (pass * NT + t) + m;
-                if (PIX) {
-                    const int nb = n >> 2, py = (n >> 1) & 1, px = n & 1;
-                    o0[t] = (((long long)b * CO + nb) * OH + 2 * (y0 + r0) + py) * OW + 2 * (x0 + 16 * c0 + 4 * kq) + 4 * px;
-                    o1[t] = (((long long)b * CO + nb) * OH + 2 * (y0 + r1) + py) * OW + 2 * (x0 + 16 * c1 + 4 * kq) + 4 * px;
-                } else {
-                    o0[t] = (((long long)b * CO + n) * OH + (y0 + r0)) * OW + x0 + 16 * c0 + 4 * kq;
-                    o1[t] = (((long long)b * CO + n) * OH + (y0 + r1)) * OW + x0 + 16 * c1 + 4 * kq;
-                }
-                e0[t] = epilogue_loads(ep, o0[t], n < NOUT);
-                e1[t] = epilogue_loads(ep, o1[t], n < NOUT);
+            const int cb = b, cy0 = y0, cx0 = x0;
+            const int next = tidx + gridDim.x;
+            if (next < ntiles) {
+                int t = next;
+                x0 = (t % tiles_x) * TW; t /= tiles_x;
+                y0 = (t % tiles_y) * TH; b = t / tiles_y;
+                stage.issue(in, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
+                stage_coef(s_coef, in, b, Cphys);
             }
-            f32x4 acc0[NT], acc1[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int cg4 = s / TAPS, tap = s % TAPS;
-                const int tyy = TAPS == 9 ? tap / 3 : 0, txx = TAPS == 9 ? tap % 3 : 0;
-                const int o = 4 * cg4 * PS + tyy * RS + txx;
-                const float a0 = a0p[o], a1 = a1p[o];
+            if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[t][s], acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[t][s], acc1[t], 0, 0, 0);
+                    const int n = 16 * (pass * NT + t) + m;
+                    mask_coef(ep, cb, n < NOUT ? (PIX ? n >> 2 : n) : 0, mc0[t], mc2[t]);
                 }
             }
+            for (int p = 0; p < MTW / MP; ++p) {
+                const float *ap[MP];
+                int o[MP][NT];
+                EpiIn<SIDE> e[MP][NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tt = pass * NT + t;
-                const int n = 16 * tt + m;
-                const bool valid = n < NOUT;
+                for (int i = 0; i < MP; ++i) {
+                    const int ti = wave + 4 * (MP * p + i);
+                    const int r = ti / CG, cg = ti % CG;
+                    ap[i] = tile + r * RS + 16 * cg + abase;
 #pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    f32x4 v = bias_relu(which ? acc1[t] : acc0[t], ep, bias[t]);
-                    if (PIX) {
-                        // partner lane (n ^ 1) holds the other x-phase of the same output row
-                        f32x4 pv;
-                        pv.x = __shfl_xor(v.x, 1, 64); pv.y = __shfl_xor(v.y, 1, 64);
-                        pv.z = __shfl_xor(v.z, 1, 64); pv.w = __shfl_xor(v.w, 1, 64);
-                        v = (n & 1) ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
+                    for (int t = 0; t < NT; ++t) {
+                        const int n = 16 * (pass * NT + t) + m;
+                        if (PIX) {
+                            const int nb = n >> 2, py = (n >> 1) & 1, px = n & 1;
+                            o[i][t] = ((cb * CO + nb) * OH + 2 * (cy0 + r) + py) * OW + 2 * (cx0 + 16 * cg + 4 * kq) + 4 * px;
+                        } else {
+                            o[i][t] = ((cb * CO + n) * OH + (cy0 + r)) * OW + cx0 + 16 * cg + 4 * kq;
+                        }
+                        epilogue_loads<SIDE>(e[i][t], ep, o[i][t], n < NOUT);
                     }
-                    if (valid)
-                        epilogue_tail(v, ep, which ? e1[t] : e0[t], mc0[t], mc2[t], out, which ? o1[t] : o0[t],
-                                      s1[tt], s2[tt]);
                 }
+                f32x4 acc[MP][NT];
+#pragma unroll
+                for (int i = 0; i < MP; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                mfma_tiles<MP, NT, KS, (TAPS == 9 ? 3 : 4)>(ap, wreg, acc, off);
+#pragma unroll
+                for (int i = 0; i < MP; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int tt = pass * NT + t;
+                        const int n = 16 * tt + m;
+                        f32x4 v = bias_relu(acc[i][t], ep, bias[t]);
+                        if (PIX) {
+                            // partner lane (n ^ 1) holds the other x-phase of the same output row
+                            f32x4 pv;
+                            pv.x = __shfl_xor(v.x, 1, 64); pv.y = __shfl_xor(v.y, 1, 64);
+                            pv.z = __shfl_xor(v.z, 1, 64); pv.w = __shfl_xor(v.w, 1, 64);
+                            v = (n & 1) ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
+                        }
+                        if (n < NOUT) epilogue_tail<SIDE>(v, ep, e[i][t], mc0[t], mc2[t], out, o[i][t], s1[tt], s2[tt]);
+                    }
             }
+            tidx = next;
         }
     }
-    if (ep.stats) stats_reduce<NTT, PIX>(s1, s2, s_stat, ep, CO);
+    if (ep.stats) {
+        stats_reduce<NTT, PIX>(s1, s2, s_stat, ep, CO);
+        zero_extra_slabs(ep, CO, ntiles);
+    }
 }
 
 // ------------------------------------------------------------------------------ dispatch
 struct ConvArgs {
     Operand in; WeightView wv; float *out; Epilogue ep;
-    int B, Cphys, CIN, NOUT, H, W;
+    int B, Cphys, CIN, NOUT, H, W, per_tile;
     hipStream_t stream;
 };
+
+int side_mode(const Epilogue &ep)
+{
+    if (!ep.mask.p0 && !ep.resid && !ep.stat_q) return SIDE_NONE;
+    if (ep.mask.p0 && !ep.resid && (!ep.stat_q || ep.stat_q == ep.mask.p0)) return SIDE_MASK;
+    return SIDE_ALL;
+}
+
+// persistent grid: as many workgroups as are co-resident, unless the caller needs one statistics slab
+// per tile with real contents (per-sample BatchNorm statistics)
+int conv_grid(int ntiles, int wgs_per_cu, int per_tile)
+{
+    if (per_tile) return ntiles;
+    const int cap = 256 * wgs_per_cu;
+    return ntiles < cap ? ntiles : cap;
+}
+
+constexpr int lds_wgs(int lds_bytes) { return (160 * 1024) / (lds_bytes + 3072); }
+constexpr int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Waves per SIMD the register allocator must leave room for (launch bound): 3 (<= 168 VGPRs) when the
+// weights, the staged next tile and the epilogue side inputs plausibly fit, else 2 (<= 256) -- a spilled
+// MFMA loop is far worse than one resident workgroup fewer.  Never more than the LDS admits.
+constexpr int conv_wps(int lds_bytes, int weights, int tile_f4, bool two, int mp, int nt, int side)
+{
+    const int stage = ((tile_f4 + DM_BLOCK - 1) / DM_BLOCK) * (two ? 9 : 5);
+    const int epi = mp * nt * (6 + (side == SIDE_ALL ? 12 : (side == SIDE_MASK ? 4 : 0)));
+    const int est = weights + stage + epi + 48;
+    return clampi(lds_wgs(lds_bytes), 1, est > 150 ? 2 : 3);
+}
 
 int conv4_tw(int CIN, int Wo)
 {
@@ -354,34 +484,52 @@ int conv4_tw(int CIN, int Wo)
 }
 
 template <int CIN, int TW>
-int launch_conv4(const ConvArgs &a)
+void launch_conv4(const ConvArgs &a)
 {
     constexpr int TH = 8;
-    const int grid = a.B * ((a.H / 2) / TH) * ((a.W / 2) / TW);
-    if (a.in.mode == DM_LOAD_AFFINE2)
-        hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, true>), dim3(grid), dim3(DM_BLOCK), 0, a.stream,
-                           a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
-    else
-        hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, false>), dim3(grid), dim3(DM_BLOCK), 0, a.stream,
-                           a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
-    return 0;
+    constexpr int F4 = CIN * (2 * TH + 2) * ((2 * TW + 8) / 4), LDS = 16 * F4;
+    const int ntiles = a.B * ((a.H / 2) / TH) * ((a.W / 2) / TW);
+#define DM_L4(SIDE_)                                                                                              \
+    {                                                                                                             \
+        constexpr int WPS = conv_wps(LDS, CIN * 4, F4, false, 2, 1, SIDE_);                                       \
+        hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS>), dim3(conv_grid(ntiles, WPS, a.per_tile)), \
+                           dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles); \
+    }
+    switch (side_mode(a.ep)) {
+    case SIDE_NONE: DM_L4(SIDE_NONE) break;
+    case SIDE_MASK: DM_L4(SIDE_MASK) break;
+    default: DM_L4(SIDE_ALL)
+    }
+#undef DM_L4
 }
 
 int conv3_tw(int W) { return W < 64 ? W : 64; }
-int conv3_th(int TW) { return TW == 16 ? 16 : 8; }
+// 16-wide tiles take 16 rows (a whole 16x16 latent), except with 32 input channels (staging registers)
+constexpr int conv3_th(int TW, int CIN) { return (TW == 16 && CIN < 32) ? 16 : 8; }
 
 template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TW>
-int launch_conv3(const ConvArgs &a)
+void launch_conv3(const ConvArgs &a)
 {
-    constexpr int TH = TW == 16 ? 16 : 8;
-    const int grid = a.B * (a.H / TH) * (a.W / TW);
-    if (a.in.mode == DM_LOAD_AFFINE2)
-        hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, true>), dim3(grid), dim3(DM_BLOCK), 0,
-                           a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
-    else
-        hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, false>), dim3(grid), dim3(DM_BLOCK), 0,
-                           a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W);
-    return 0;
+    constexpr int TH = conv3_th(TW, CIN);
+    constexpr int PADR = TAPS == 9 ? 1 : 0;
+    constexpr int F4 = CIN * (TH + 2 * PADR) * ((TW + 8 * PADR) / 4), LDS = 16 * F4 + 2048;
+    const int ntiles = a.B * (a.H / TH) * (a.W / TW);
+    const int side = side_mode(a.ep);
+    const bool two = a.in.mode == DM_LOAD_AFFINE2;
+#define DM_L3(TWO_, SIDE_)                                                                                        \
+    {                                                                                                             \
+        constexpr int WPS = conv_wps(LDS, NT * (CIN / 4) * TAPS, F4, TWO_, NT == 1 ? 2 : 1, NT, SIDE_);          \
+        hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS>),                 \
+                           dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
+                           a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles);                                       \
+    }
+    // built variants: forward (no side inputs), data gradients with a mask-only side input (with or without
+    // the BatchNorm-backward AFFINE2 operand), and the fully general one (residual join)
+    if (!two && side == SIDE_NONE) DM_L3(false, SIDE_NONE)
+    else if (!two && side == SIDE_MASK) DM_L3(false, SIDE_MASK)
+    else if (two && side != SIDE_ALL) DM_L3(true, SIDE_MASK)
+    else DM_L3(true, SIDE_ALL)        // TWO = true with a NULL p1 is safe: tile.h skips the second load
+#undef DM_L3
 }
 
 }  // namespace
@@ -394,9 +542,13 @@ static int conv_common_checks(const char *who, const dm_operand *in, const dm_we
     DM_REQUIRE(w && w->w && out, "%s: NULL weight or output", who);
     DM_REQUIRE(B > 0 && CIN > 0 && NOUT > 0 && H > 0 && W > 0, "%s: bad shape", who);
     DM_REQUIRE(CIN <= DM_COEF_MAX_C, "%s: more than %d input channels", who, DM_COEF_MAX_C);
+    DM_REQUIRE((long long)B * (CIN > NOUT ? CIN : NOUT) * H * W * 4 < (1LL << 31),
+               "%s: tensor too large for 32-bit offsets", who);
     DM_REQUIRE(CIN - (in->ones_channel ? 1 : 0) > 0, "%s: no physical input channel", who);
     if (ep && ep->mask.p0 && dm_check_operand(&ep->mask, who)) return -1;
     DM_REQUIRE(!(ep && ep->mask.p0 && ep->mask.ones_channel), "%s: mask operand cannot have a ones channel", who);
+    DM_REQUIRE(!(ep && ep->mask.p0 && ep->mask.mode != DM_LOAD_IDENT && ep->mask.mode != DM_LOAD_AFFINE),
+               "%s: mask operand must be IDENT or AFFINE", who);
     return 0;
 }
 
@@ -415,12 +567,13 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
     if (conv_common_checks("dm_conv4x4s2", in, w, out, ep, B, CIN, NOUT, H, W)) return -1;
     DM_REQUIRE(H % 16 == 0 && W % 32 == 0, "dm_conv4x4s2: H must be a multiple of 16 and W of 32 (got %dx%d)", H, W);
     DM_REQUIRE(NOUT <= 16, "dm_conv4x4s2: NOUT %d > 16 not built", NOUT);
+    DM_REQUIRE(in->mode != DM_LOAD_AFFINE2, "dm_conv4x4s2: AFFINE2 operand not built for this kernel");
     const int Wo = W / 2;
     const int TW = conv4_tw(CIN, Wo);
     DM_REQUIRE(TW == 16 || TW == 32 || TW == 64, "dm_conv4x4s2: output width %d not tileable", Wo);
     DM_REQUIRE(Wo % TW == 0, "dm_conv4x4s2: output width %d not a multiple of tile %d", Wo, TW);
     ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN - (in->ones_channel ? 1 : 0), CIN, NOUT, H, W,
-               (hipStream_t)stream};
+               ep ? ep->stats_per_tile : 0, (hipStream_t)stream};
 #define DM_C4(C, T) if (CIN == C && TW == T) { launch_conv4<C, T>(a); return dm_launch_status("dm_conv4x4s2"); }
     DM_C4(3, 64) DM_C4(3, 32) DM_C4(3, 16)
     DM_C4(4, 64) DM_C4(4, 32) DM_C4(4, 16)
@@ -435,8 +588,8 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
 
 extern "C" int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle)
 {
-    (void)CIN; (void)NOUT; (void)taps; (void)pixel_shuffle;
-    const int TW = conv3_tw(W), TH = conv3_th(TW);
+    (void)NOUT; (void)taps; (void)pixel_shuffle;
+    const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
     if (TW <= 0 || H % TH || W % TW) return -1;
     return B * (H / TH) * (W / TW);
 }
@@ -448,10 +601,11 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
     DM_REQUIRE(taps == 9 || taps == 1, "dm_conv3x3: taps must be 9 or 1");
     DM_REQUIRE(!pixel_shuffle || (taps == 9 && NOUT % 4 == 0), "dm_conv3x3: pixel_shuffle needs taps=9, NOUT%%4==0");
     DM_REQUIRE(!in->ones_channel, "dm_conv3x3: ones_channel not supported");
-    const int TW = conv3_tw(W), TH = conv3_th(TW);
+    const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
     DM_REQUIRE((TW == 16 || TW == 32 || TW == 64) && W % TW == 0 && H % TH == 0,
                "dm_conv3x3: spatial size %dx%d not tileable", H, W);
-    ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN, CIN, NOUT, H, W, (hipStream_t)stream};
+    ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN, CIN, NOUT, H, W, ep ? ep->stats_per_tile : 0,
+               (hipStream_t)stream};
     const int NTT = (NOUT + 15) / 16;
     const bool pix = pixel_shuffle != 0;
 #define DM_C3(C, NTOT, NT_, NP_, TP, PX, T)                                                \

@@ -1,6 +1,10 @@
 // tile.h -- staging of an input tile (with halo) from HBM into LDS through the operand transform.
 //
-// Two phases so that every global load of a tile is in flight at once:
+// Register-staged, two-phase, so a persistent workgroup can keep the NEXT tile's loads in flight while
+// it runs the MFMAs and stores of the current one (the LDS buffer is single, the registers are the
+// second buffer):
+//   init():   per-thread constants of its N tile elements (LDS offset, row, column, channel packed in one
+//             register each) -- tile independent, computed once per workgroup.
 //   issue():  all of a thread's 16-byte loads (both tensors for AFFINE2) go out back to back, predicated
 //             only on "inside the image"; no branch depends on the operand mode.
 //   commit(): v = c0*p0 + c1*p1 + c2, optional ReLU, zero in the padding, 1 in the synthetic ones channel;
@@ -33,10 +37,12 @@ struct TileStage {
     static constexpr int PER_C = ROWS * COLS4;
     static constexpr int TOTAL = CIN * PER_C;
     static constexpr int N = (TOTAL + DM_BLOCK - 1) / DM_BLOCK;
+    static_assert(CIN * PS < (1 << 14) && ROWS < 64 && COLS4 < 64 && CIN <= 64, "metadata packing");
     f32x4 v[N];
     f32x4 u[TWO ? N : 1];
+    int meta[N];     // lds offset | r << 14 | j4 << 20 | c << 26 ; -1 = no element
 
-    __device__ __forceinline__ void issue(const Operand &op, int b, int Cphys, int H, int W, int gy0, int gx0)
+    __device__ __forceinline__ void init()
     {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
@@ -45,14 +51,26 @@ struct TileStage {
             const int rem = i - c * PER_C;
             const int r = rem / COLS4;
             const int j4 = rem - r * COLS4;
+            meta[k] = i < TOTAL ? ((c * PS + r * RS + 4 * j4) | (r << 14) | (j4 << 20) | (c << 26)) : -1;
+        }
+    }
+
+    __device__ __forceinline__ void issue(const Operand &op, int b, int Cphys, int H, int W, int gy0, int gx0)
+    {
+        // tensors stay below 2^31 elements (checked on the host): 32-bit element offsets
+        const int base = ((b * Cphys) * H + gy0) * W + gx0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int mt = meta[k];
+            const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63, c = (mt >> 26) & 63;
             const int gy = gy0 + r, gx = gx0 + 4 * j4;
-            const bool ok = i < TOTAL && c < Cphys && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const long long off = (((long long)b * Cphys + c) * H + gy) * (long long)W + gx;
+            const bool ok = mt >= 0 && c < Cphys && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int off = base + (c * H + r) * W + 4 * j4;
             v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (ok) v[k] = *reinterpret_cast<const f32x4 *>(op.p0 + off);
             if (TWO) {
                 u[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok) u[k] = *reinterpret_cast<const f32x4 *>(op.p1 + off);
+                if (ok && op.p1) u[k] = *reinterpret_cast<const f32x4 *>(op.p1 + off);   // p1 == NULL: not AFFINE2
             }
         }
     }
@@ -62,11 +80,8 @@ struct TileStage {
     {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const int i = threadIdx.x + k * DM_BLOCK;
-            const int c = i / PER_C;
-            const int rem = i - c * PER_C;
-            const int r = rem / COLS4;
-            const int j4 = rem - r * COLS4;
+            const int mt = meta[k];
+            const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63, c = (mt >> 26) & 63;
             const int gy = gy0 + r, gx = gx0 + 4 * j4;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
             f32x4 val;
@@ -82,7 +97,7 @@ struct TileStage {
                 const float one = inside ? 1.f : 0.f;
                 val = (f32x4){one, one, one, one};
             }
-            if (i < TOTAL) *reinterpret_cast<f32x4 *>(lds + c * PS + r * RS + 4 * j4) = val;
+            if (mt >= 0) *reinterpret_cast<f32x4 *>(lds + (mt & 0x3fff)) = val;
         }
     }
 };

@@ -73,6 +73,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
     // of tile i and written to LDS after it (register staging, single LDS buffer).
     TileStage<CS, TH, TW / 4, RSS, PSS, STWO> stS;
     TileStage<CT, TROWS, TCOLS4, RST, PST, false> stT;
+    stS.init();
+    stT.init();
     int tile = blockIdx.x;
     int cb = 0, cy0 = 0, cx0 = 0;
     if (tile < ntiles) {
@@ -100,19 +102,29 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
             stage_coef(s_coefT, T, cb, CTphys);
         }
         for (int r = wave; r < TH; r += 4) {
-#pragma unroll 2
+            // software pipeline over the position steps of a row: operands of step x4+1 are requested before
+            // the MFMAs of step x4 (two register buffers, order pinned with sched_barrier)
+            float a[2][MT], bv[2][NTT];
+            const int rb = r * STRIDE * RST, ra = r * RSS;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[0][i] = sS[aoff[i] + ra];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) bv[0][t] = sT[boff[t] + rb];
+#pragma unroll
             for (int x4 = 0; x4 < TW / 4; ++x4) {
-                float a[MT];
+                if (x4 + 1 < TW / 4) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = sS[aoff[i] + r * RSS + 4 * x4];
-                const int tb = r * STRIDE * RST + 4 * x4 * STRIDE;
+                    for (int i = 0; i < MT; ++i) a[(x4 + 1) & 1][i] = sS[aoff[i] + ra + 4 * (x4 + 1)];
 #pragma unroll
-                for (int t = 0; t < NTT; ++t) {
-                    const float bv = sT[boff[t] + tb];
+                    for (int t = 0; t < NTT; ++t) bv[(x4 + 1) & 1][t] = sT[boff[t] + rb + 4 * (x4 + 1) * STRIDE];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv, acc[i][t], 0, 0, 0);
-                }
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x4 & 1][i], bv[x4 & 1][t], acc[i][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         tile = next;
@@ -216,6 +228,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
 {
     if (dm_check_operand(S, "dm_wgrad(S)") || dm_check_operand(T, "dm_wgrad(T)")) return -1;
     DM_REQUIRE(slabs && dst, "dm_wgrad: NULL output");
+    DM_REQUIRE((long long)B * (CS > 4 * CT ? CS : 4 * CT) * Hs * Ws < (1LL << 31), "dm_wgrad: tensor too large for 32-bit offsets");
     DM_REQUIRE(k == 4 || k == 3 || k == 1, "dm_wgrad: kernel size %d not built", k);
     DM_REQUIRE(!S->ones_channel, "dm_wgrad: S cannot carry a ones channel");
     const int TW = wgrad_tw(Ws), TH = wgrad_th(CS, CT, k, TW);

@@ -91,22 +91,22 @@ def encoder_forward(L, x, per_sample=False):
     weff = ops.e1_compose(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight))
     H1, W1 = H // 2, W // 2
     a1, st = ops.conv4x4s2(Op(x, ones=True), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN + 1, c1, H, W,
-                           want_stats=True, bias=_w(L.enc1.bias))
+                           want_stats=True, bias=_w(L.enc1.bias), per_tile=ps)
     coef1, saved1 = _bn_coef(st, L.bn1, H1 * W1 * (1 if ps else B), ps, B)
 
     H2, W2 = H1 // 2, W1 // 2
     a2, st = ops.conv4x4s2(Op(a1, DM_LOAD_AFFINE_RELU, coef1, per_sample=ps), weight_view(_w(L.enc4.weight), c1 * 16, 16, 4, 1),
-                           B, c1, nh, H1, W1, want_stats=True, bias=_w(L.enc4.bias))
+                           B, c1, nh, H1, W1, want_stats=True, bias=_w(L.enc4.bias), per_tile=ps)
     coef2, saved2 = _bn_coef(st, L.bn2, H2 * W2 * (1 if ps else B), ps, B)
 
     H3, W3 = H2 // 2, W2 // 2
     a3, st = ops.conv4x4s2(Op(a2, DM_LOAD_AFFINE_RELU, coef2, per_sample=ps), weight_view(_w(L.enc7.weight), nh * 16, 16, 4, 1),
-                           B, nh, nh, H2, W2, want_stats=True, bias=_w(L.enc7.bias))
+                           B, nh, nh, H2, W2, want_stats=True, bias=_w(L.enc7.bias), per_tile=ps)
     n3 = H3 * W3 * (1 if ps else B)
     coef3, saved3 = _bn_coef(st, L.bn3, n3, ps, B)
 
     a4, st = ops.conv3x3(Op(a3, DM_LOAD_AFFINE_RELU, coef3, per_sample=ps), weight_view(_w(L.enc10.weight), nh * 9, 9, 3, 1),
-                         B, nh, nh, H3, W3, taps=9, want_stats=True, bias=_w(L.enc10.bias))
+                         B, nh, nh, H3, W3, taps=9, want_stats=True, bias=_w(L.enc10.bias), per_tile=ps)
     coef4, saved4 = _bn_coef(st, L.bn4, n3, ps, B)
     h = ops.apply(Op(a4, DM_LOAD_AFFINE, coef4, per_sample=ps), B, nh, H3, W3)
 
@@ -124,10 +124,10 @@ def residual_forward(res_layers, h, per_sample=False):
     for ca, bna, cb, bnb in res_layers:
         nrh = ca.weight.shape[0]
         ra, st = ops.conv3x3(Op(h, DM_LOAD_RELU), weight_view(_w(ca.weight), nh * 9, 9, 3, 1), B, nh, nrh, H, W, taps=9,
-                             want_stats=True, bias=_w(ca.bias))
+                             want_stats=True, bias=_w(ca.bias), per_tile=per_sample)
         coefa, saveda = _bn_coef(st, bna, n, per_sample, B)
         rb, st = ops.conv3x3(Op(ra, DM_LOAD_AFFINE_RELU, coefa, per_sample=per_sample), weight_view(_w(cb.weight), nrh, 1, 0, 0),
-                             B, nrh, nh, H, W, taps=1, want_stats=True, bias=_w(cb.bias))
+                             B, nrh, nh, H, W, taps=1, want_stats=True, bias=_w(cb.bias), per_tile=per_sample)
         coefb, savedb = _bn_coef(st, bnb, n, per_sample, B)
         hn = ops.apply(Op(rb, DM_LOAD_AFFINE, coefb, per_sample=per_sample), B, nh, H, W, resid=h)
         saved.append(SimpleNamespace(h_in=h, ra=ra, rb=rb, coefa=coefa, saveda=saveda, coefb=coefb, savedb=savedb))

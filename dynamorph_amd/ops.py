@@ -58,9 +58,10 @@ def weight_view(w, sn, sc, sky, skx, off=0):
     return WView(w, sn, sc, sky, skx, off)
 
 
-def epilogue(bias=None, relu=False, mask=None, resid=None, stat_q=None, stats=None):
+def epilogue(bias=None, relu=False, mask=None, resid=None, stat_q=None, stats=None, per_tile=False):
     m = mask.struct() if mask is not None else _null_operand()
-    return L.Epilogue(_ptr(bias), 1 if relu else 0, 0, m, _ptr(resid), _ptr(stat_q), _ptr(stats, torch.float64))
+    return L.Epilogue(_ptr(bias), 1 if relu else 0, 1 if per_tile else 0, m, _ptr(resid), _ptr(stat_q),
+                      _ptr(stats, torch.float64))
 
 
 def _new(shape, like, dtype=torch.float32):

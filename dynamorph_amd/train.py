@@ -125,11 +125,16 @@ class FusedTrainer:
                 self._static_out = self.forward_backward(self._static_x, self._static_mask)
             self._graph, self._graph_key = g, key
         else:
-            self._static_x.copy_(x)
-            if mask is not None:
+            if x.data_ptr() != self._static_x.data_ptr():      # a loader may write straight into input_buffer()
+                self._static_x.copy_(x)
+            if mask is not None and mask.data_ptr() != self._static_mask.data_ptr():
                 self._static_mask.copy_(mask)
         self._graph.replay()
         return self._static_out
+
+    def input_buffer(self):
+        """The captured graph's input tensor (None before the first step): fill it in place to skip the copy."""
+        return self._static_x
 
 
 # ================================================================ reference-style loop mirrors

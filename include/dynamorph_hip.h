@@ -70,12 +70,13 @@ typedef struct dm_weight_view {
  *   if mask.p0: v = (load(mask) > 0) ? v : 0          (ReLU backward)
  *   if resid:   v += resid                             (residual-branch join)
  *   out = v;  if stats: partial sums (sum v, sum v*q), q = stat_q ? stat_q : v,
- *   written as doubles to stats[block][n][2] (one slab per workgroup; reduced by
+ *   written as doubles to stats[tile][n][2] (dm_conv*_num_blocks slabs, every one written; reduced by
  *   dm_bn_finalize / dm_bn_backward_finalize / dm_sum_slabs: deterministic). */
 typedef struct dm_epilogue {
     const float *bias;
     int32_t relu;
-    int32_t _pad;
+    int32_t stats_per_tile;   /* 1: one workgroup per tile, every stats slab holds that tile's sums (per-sample
+                                 BatchNorm statistics); 0: persistent workgroups, most slabs are zero */
     dm_operand mask;
     const float *resid;
     const float *stat_q;
