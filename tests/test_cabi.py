@@ -1,0 +1,82 @@
+"""`not gpu`: the C-ABI library loads and exports every symbol include/dynamorph_hip.h declares; host-side
+argument checking works without a device (no compute call is made here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "dynamorph_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "dynamorph_amd", "csrc")])
+    from dynamorph_amd import _lib
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from dynamorph_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 28
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported by the library"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in dynamorph_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+
+
+def test_struct_layouts_match_the_header():
+    from dynamorph_amd import _lib
+    assert ctypes.sizeof(_lib.Operand) == 40          # 3 pointers + int64 + 2 int32
+    assert ctypes.sizeof(_lib.WeightView) == 48
+    assert ctypes.sizeof(_lib.Epilogue) == 16 + 40 + 24
+    assert _lib.Epilogue.mask.offset == 16 and _lib.Epilogue.stats.offset == 72
+
+
+def test_version_and_host_only_queries(lib):
+    assert lib.dm_version() == 100
+    assert lib.dm_vq_workspace_bytes(64, 16) == 64 * 16 * 4
+    assert lib.dm_vq_workspace_bytes(63, 16) == 64 * 16 * 4           # odd K is padded to a pair
+    assert lib.dm_vq_num_blocks(524288) == 2048
+    assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128) == 2048 * 8
+    assert lib.dm_conv4x4s2_num_blocks(1, 3, 8, 100, 100) == -1      # not tileable
+    assert lib.dm_conv3x3_num_blocks(4, 16, 16, 16, 16, 9, 0) == 4
+    assert lib.dm_conv3x3_num_blocks(4, 32, 16, 16, 16, 9, 0) == 8   # 32 input channels: 8-row tiles
+    assert lib.dm_wgrad_num_blocks(2048, 8, 3, 64, 64, 4) == 512     # persistent grid cap
+    assert lib.dm_wgrad_num_blocks(1, 8, 3, 64, 64, 5) == -1
+    assert lib.dm_head_num_blocks(2048, 128, 128) == 2048
+    assert lib.dm_channel_stats_num_blocks(20, 16, 16, 16) == 3
+
+
+def test_argument_errors_are_reported_before_any_launch(lib):
+    """negative return + message, nothing is enqueued (no device needed)."""
+    from dynamorph_amd import _lib
+    rc = lib.dm_vq_forward(None, None, None, None, None, None, 1, 16, 64, 16, 16, None, 0, None)
+    assert rc == -1 and b"NULL" in lib.dm_last_error()
+    rc = lib.dm_vq_decode(None, None, None, 1, 16, 64, 16, 16, None)
+    assert rc == -1
+    op = _lib.Operand(None, None, None, 0, 0, 0)
+    rc = lib.dm_apply(ctypes.byref(op), None, None, 1, 1, 4, 4, None)
+    assert rc == -1 and b"p0 is NULL" in lib.dm_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "dm_apply")
+    rc = lib.dm_adam(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, None, None)
+    assert rc == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dynamorph_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DynamorphHipError):
+        _lib.load()

@@ -1,0 +1,128 @@
+"""`not gpu`: host-side logic of the drop-in surface (construction, state-dict contract, helpers, no compute)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import dynamorph_amd
+from dynamorph_amd import dist as D
+from dynamorph_amd import train_utils as TU
+
+
+def test_state_dict_contract_matches_reference(golden):
+    g1 = golden("g1_state_dict.npz")
+    for cls in (dynamorph_amd.VQ_VAE, dynamorph_amd.VQ_VAE_z16):
+        m = cls()
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(g1.keys()) and len(sd) == 68
+        for k, v in sd.items():
+            assert tuple(v.shape) == g1[k].shape and str(v.dtype).replace("torch.", "") == str(g1[k].dtype), k
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in g1.items()})
+        assert sum(p.numel() for p in m.parameters()) == 24060
+        assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 24058
+        assert not m.channel_var.requires_grad
+
+
+def test_constructor_surface():
+    m = dynamorph_amd.VQ_VAE(num_inputs=2, num_hiddens=16, num_residual_hiddens=32, num_residual_layers=2,
+                             num_embeddings=64, commitment_cost=0.25, channel_var=np.array([1., 1.]),
+                             weight_recon=1., weight_commitment=1., weight_matching=0.005, device="cuda:0")
+    assert (m.num_inputs, m.num_hiddens, m.num_embeddings) == (2, 16, 64)
+    assert isinstance(m.enc, torch.nn.Sequential) and isinstance(m.dec, torch.nn.Sequential)
+    assert isinstance(m.enc[12], dynamorph_amd.ResidualBlock) and len(m.enc) == 13 and len(m.dec) == 7
+    assert isinstance(m.vq, dynamorph_amd.VectorQuantizer) and m.vq.embeddings is m.vq.w.weight
+    # callers pass gpu=True (pipeline/patch_VAE.py:431) and alpha=... (plot_scripts/recon_loss.py:18)
+    dynamorph_amd.VQ_VAE_z16(num_inputs=2, num_hiddens=16, num_residual_hiddens=32, num_residual_layers=2,
+                             num_embeddings=64, gpu=True)
+    dynamorph_amd.VQ_VAE(alpha=0.0005, gpu=True)
+    z16 = dynamorph_amd.VQ_VAE_z16(w_a=1.2, w_t=0.2, w_n=-0.4, margin=0.3)
+    assert (z16.w_a, z16.w_t, z16.w_n, z16.margin) == (1.2, 0.2, -0.4, 0.3)
+    vq = dynamorph_amd.VectorQuantizer(embedding_dim=16, num_embeddings=8, commitment_cost=0.1, device="cpu")
+    assert vq.w.weight.shape == (8, 16) and vq.commitment_cost == 0.1
+    rb = dynamorph_amd.ResidualBlock(16, 32, 3)
+    assert len(rb.layers) == 3 and [type(l).__name__ for l in rb.layers[0]] == ["ReLU", "Conv2d", "BatchNorm2d", "ReLU", "Conv2d", "BatchNorm2d"]
+
+
+def test_no_cpu_fallback():
+    m = dynamorph_amd.VQ_VAE()
+    x = torch.randn(1, 2, 128, 128)
+    for call in (lambda: m(x), lambda: m.enc(x), lambda: m.vq(torch.randn(1, 16, 16, 16)),
+                 lambda: m.dec(torch.randn(1, 16, 16, 16)), lambda: m.vq.encode_inputs(torch.randn(1, 16, 16, 16)),
+                 lambda: m.enc[12](torch.randn(1, 16, 16, 16))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+    from dynamorph_amd.train import FusedTrainer
+    with pytest.raises(RuntimeError):
+        FusedTrainer(m)
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.dirname(os.path.abspath(dynamorph_amd.__file__))
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and "oracle" not in txt, os.path.join(dp, f)
+
+
+def test_zscore_helpers(golden):
+    g = golden("g9_zscore.npz")
+    p = np.squeeze(g["patches"])
+    np.testing.assert_allclose(TU.zscore_patch(p), g["zscore_patch"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(TU.zscore(p), g["zscore"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(TU.zscore(p, [40., 55.], [20., 30.]), g["zscore_given"], rtol=1e-12, atol=1e-12)
+    flat = np.ones((2, 2, 4, 4))                       # zero variance: eps keeps it finite
+    assert np.isfinite(TU.zscore_patch(flat)).all()
+
+
+def test_early_stopping_checkpoints_state_dict(tmp_path):
+    path = str(tmp_path / "model.pt")
+    m = torch.nn.Linear(2, 2)
+    es = TU.EarlyStopping(patience=2, verbose=False, path=path, trace_func=lambda *_: None)
+    es(1.0, m)
+    assert os.path.exists(path) and es.val_loss_min == 1.0
+    saved = torch.load(path)
+    assert set(saved) == {"weight", "bias"}
+    es(1.5, m); assert es.counter == 1 and not es.early_stop
+    es(0.5, m); assert es.counter == 0 and es.val_loss_min == 0.5
+    es(0.6, m); es(0.7, m)
+    assert es.early_stop
+
+
+def test_shard_range_tiles_the_units():
+    for n in (0, 1, 7, 64, 1000, 16384):
+        for w in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_flat_params_are_views():
+    m = dynamorph_amd.VQ_VAE()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    fp = D.FlatParams(m.parameters())
+    assert fp.flat.numel() == 24058 and len(fp.params) == 43
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k                      # values unchanged
+    p0 = fp.params[0]
+    assert p0.data_ptr() == fp.flat.data_ptr()
+    fp.flat.zero_()
+    assert float(m.enc[0].weight.abs().sum()) == 0.0            # the flat buffer IS the storage
+    fp.gview(p0).fill_(2.0)
+    assert float(fp.grad[:p0.numel()].sum()) == 2.0 * p0.numel()
+    fp.expose_grads()
+    assert m.enc[0].weight.grad.data_ptr() == fp.grad.data_ptr()
+    assert m.channel_var.grad is None
+    assert D.world_size() == 1 and D.allreduce_mean_(fp.grad) is fp.grad
+    assert D.max_over_ranks(3.5) == 3.5
+
+
+def test_process_vae_io_contract_signature():
+    import inspect
+    from dynamorph_amd import patch_vae
+    sig = inspect.signature(patch_vae.process_VAE)
+    assert list(sig.parameters)[:5] == ["raw_folder", "supp_folder", "sites", "config_", "gpu"]
