@@ -27,9 +27,9 @@
 // stream overlap instead of adding up.
 //
 // Epilogue (dm_epilogue): bias, ReLU, ReLU-backward mask, residual add, store, and per-channel
-// partial sums (sum v, sum v*q) in double.  One statistics slab per TILE index (so the per-sample
-// grouping of dm_bn_finalize keeps working): a persistent workgroup writes its totals into the slab
-// of its first tile and zeros the others it owns; everything is reduced deterministically in bn.hip.
+// partial sums (sum v, sum v*q) in double.  One statistics slab per WORKGROUP: dm_conv*_num_blocks tells the
+// caller how many (the persistent grid, or one per tile when stats_per_tile asks for per-sample grouping);
+// everything is reduced deterministically in bn.hip.
 #include "dm_common.h"
 #include "tile.h"
 
@@ -139,9 +139,10 @@ __device__ __forceinline__ void stats_reduce(double (&s1)[NTT], double (&s2)[NTT
     }
 }
 
-__device__ __forceinline__ void zero_extra_slabs(const Epilogue &ep, int NCH, int ntiles)
+// slabs [gridDim, nslabs) exist in the caller's buffer but belong to no workgroup of this variant: zero them
+__device__ __forceinline__ void zero_unowned_slabs(const Epilogue &ep, int NCH, int nslabs)
 {
-    for (int t2 = blockIdx.x + gridDim.x; t2 < ntiles; t2 += gridDim.x)
+    for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x)
         for (int i = threadIdx.x; i < NCH * 2; i += DM_BLOCK) ep.stats[(long long)t2 * NCH * 2 + i] = 0.0;
 }
 
@@ -193,7 +194,7 @@ __device__ __forceinline__ void mfma_tiles(const float *const (&ap)[MP], const f
 template <int CIN, int NT, int TH, int TW, int SIDE, int WPS>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
-                      int W, int ntiles)
+                      int W, int ntiles, int nslabs)
 {
     constexpr int IH = 2 * TH + 2, RS = 2 * TW + 8, COLS4 = RS / 4, PS = IH * RS;
     constexpr int KS = CIN * 4, CG = TW / 16, MT = TH * CG, MTW = MT / 4;
@@ -287,7 +288,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
     }
     if (ep.stats) {
         stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT);
-        zero_extra_slabs(ep, NOUT, ntiles);
+        zero_unowned_slabs(ep, NOUT, nslabs);
     }
 }
 
@@ -295,7 +296,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
 template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO, int SIDE, int WPS>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
-                    int W, int ntiles)
+                    int W, int ntiles, int nslabs)
 {
     constexpr int PADR = TAPS == 9 ? 1 : 0;
     constexpr int IH = TH + 2 * PADR, RS = TAPS == 9 ? TW + 8 : TW, COLS4 = RS / 4;
@@ -436,7 +437,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
     }
     if (ep.stats) {
         stats_reduce<NTT, PIX>(s1, s2, s_stat, ep, CO);
-        zero_extra_slabs(ep, CO, ntiles);
+        zero_unowned_slabs(ep, CO, nslabs);
     }
 }
 
@@ -462,6 +463,9 @@ int conv_grid(int ntiles, int wgs_per_cu, int per_tile)
     const int cap = 256 * wgs_per_cu;
     return ntiles < cap ? ntiles : cap;
 }
+
+// statistics slabs the caller allocated (dm_conv*_num_blocks): variant independent
+int conv_slabs(int ntiles, int per_tile) { return per_tile ? ntiles : (ntiles < 256 * 3 ? ntiles : 256 * 3); }
 
 constexpr int lds_wgs(int lds_bytes) { return (160 * 1024) / (lds_bytes + 3072); }
 constexpr int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -493,7 +497,8 @@ void launch_conv4(const ConvArgs &a)
     {                                                                                                             \
         constexpr int WPS = conv_wps(LDS, CIN * 4, F4, false, 2, 1, SIDE_);                                       \
         hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS>), dim3(conv_grid(ntiles, WPS, a.per_tile)), \
-                           dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles); \
+                           dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles,  \
+                           conv_slabs(ntiles, a.per_tile));                                                       \
     }
     switch (side_mode(a.ep)) {
     case SIDE_NONE: DM_L4(SIDE_NONE) break;
@@ -521,7 +526,7 @@ void launch_conv3(const ConvArgs &a)
         constexpr int WPS = conv_wps(LDS, NT * (CIN / 4) * TAPS, F4, TWO_, NT == 1 ? 2 : 1, NT, SIDE_);          \
         hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS>),                 \
                            dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
-                           a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles);                                       \
+                           a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));       \
     }
     // built variants: forward (no side inputs), data gradients with a mask-only side input (with or without
     // the BatchNorm-backward AFFINE2 operand), and the fully general one (residual join)
@@ -552,13 +557,13 @@ static int conv_common_checks(const char *who, const dm_operand *in, const dm_we
     return 0;
 }
 
-extern "C" int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W)
+extern "C" int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, int per_tile)
 {
     (void)NOUT;
     const int Wo = W / 2, Ho = H / 2;
     const int TW = conv4_tw(CIN, Wo);
     if (TW <= 0 || Ho % 8 || Wo % TW) return -1;
-    return B * (Ho / 8) * (Wo / TW);
+    return conv_slabs(B * (Ho / 8) * (Wo / TW), per_tile);
 }
 
 extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
@@ -586,12 +591,12 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
     return -1;
 }
 
-extern "C" int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle)
+extern "C" int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile)
 {
     (void)NOUT; (void)taps; (void)pixel_shuffle;
     const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
     if (TW <= 0 || H % TH || W % TW) return -1;
-    return B * (H / TH) * (W / TW);
+    return conv_slabs(B * (H / TH) * (W / TW), per_tile);
 }
 
 extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,

@@ -9,8 +9,8 @@
 // by H*W in NCHW, so for every d a wave reads 64 consecutive floats (256 B, coalesced)
 // and keeps its D values in registers.  Codes are processed two at a time as packed fp32
 // (v_pk_add_f32 / v_pk_mul_f32, IEEE round-to-nearest, same results as scalar ops); the
-// codebook is first re-laid out as [K/2][D][2] so a pair's operands are adjacent and the
-// wave-uniform loads go through the scalar cache instead of LDS.
+// codebook is first re-laid out as [K/2][D][2] so a pair's operands are adjacent, staged in
+// LDS per workgroup and read with wave-uniform (broadcast) ds_read_b128.
 #include "dm_common.h"
 
 namespace {
@@ -39,84 +39,121 @@ __device__ __forceinline__ bool vq_better(float cand, float best)
     return cand < best;
 }
 
-template <int D>
+// PP positions per lane (pos, pos + 256, ...): every codebook operand fetched from LDS is used PP times.
+// The pair-interleaved codebook is staged in LDS in chunks of CHUNK_PAIRS pairs; all lanes of a wave read the
+// same address (broadcast ds_read_b128, conflict free), and because DS reads return in order hipcc can keep the
+// next pair's operands in flight behind a counted lgkmcnt while the current pair's packed math runs -- scalar
+// (s_load) operands cannot be pipelined that way (SMEM returns out of order: every wait is lgkmcnt(0)), which
+// left the first version of this kernel 58 % parked on s_waitcnt.
+template <int D, int PP>
 __global__ __launch_bounds__(VQ_BLOCK) void vq_forward_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbT,
     long long *__restrict__ idx, float *__restrict__ out, double *__restrict__ sse_slabs,
     int *__restrict__ hist, int K, int HW, long long P)
 {
+    constexpr int CHUNK_PAIRS = 2048 / D;                 // 16 KB of LDS per chunk
+    __shared__ __attribute__((aligned(16))) float s_cb[CHUNK_PAIRS * D * 2];
     __shared__ int s_hist[VQ_MAX_LDS_HIST];
     __shared__ double s_red[4];
     const bool lds_hist = K <= VQ_MAX_LDS_HIST;
     if (lds_hist)
         for (int k = threadIdx.x; k < K; k += VQ_BLOCK) s_hist[k] = 0;
-    __syncthreads();
 
-    const long long pos = (long long)blockIdx.x * VQ_BLOCK + threadIdx.x;
-    const bool active = pos < P;
-    const long long b = active ? pos / HW : 0;
-    const long long p = active ? pos - b * HW : 0;
-    const long long base = b * (long long)D * HW + p;
-
-    float zr[D];
+    long long pos[PP], base[PP];
+    bool active[PP];
+    float zr[PP][D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) zr[d] = active ? z[base + (long long)d * HW] : 0.f;
+    for (int q = 0; q < PP; ++q) {
+        pos[q] = ((long long)blockIdx.x * PP + q) * VQ_BLOCK + threadIdx.x;
+        active[q] = pos[q] < P;
+        const long long b = active[q] ? pos[q] / HW : 0;
+        const long long p = active[q] ? pos[q] - b * HW : 0;
+        base[q] = b * (long long)D * HW + p;
+#pragma unroll
+        for (int d = 0; d < D; ++d) zr[q][d] = active[q] ? z[base[q] + (long long)d * HW] : 0.f;
+    }
 
-    float bestd = 0.f;
-    int bi = 0;
+    float bestd[PP];
+    int bi[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) { bestd[q] = 0.f; bi[q] = 0; }
     const int npairs = K >> 1;
-    for (int kp = 0; kp < npairs; ++kp) {
-        const float *__restrict__ e = cbT + (long long)kp * (2 * D);   // wave-uniform address
-        f32x2 total = {0.f, 0.f};
+    for (int c0 = 0; c0 < npairs; c0 += CHUNK_PAIRS) {
+        const int cn = min(CHUNK_PAIRS, npairs - c0);
+        __syncthreads();                                   // previous chunk consumed (and s_hist zeroed)
+        for (int i = threadIdx.x; i < cn * D * 2 / 4; i += VQ_BLOCK)
+            reinterpret_cast<f32x4 *>(s_cb)[i] = reinterpret_cast<const f32x4 *>(cbT + (long long)c0 * D * 2)[i];
+        __syncthreads();
+#pragma unroll 2
+        for (int kp = 0; kp < cn; ++kp) {
+            const float *e = s_cb + kp * (2 * D);          // wave-uniform LDS address: broadcast reads
+            f32x2 total[PP];
 #pragma unroll
-        for (int d0 = 0; d0 < D; d0 += 16) {
-            f32x2 acc = {0.f, 0.f};
+            for (int d0 = 0; d0 < D; d0 += 16) {
+                f32x2 acc[PP];
 #pragma unroll
-            for (int d = d0; d < d0 + 16 && d < D; ++d) {
-                const f32x2 e2 = *reinterpret_cast<const f32x2 *>(e + 2 * d);
-                const f32x2 zz = {zr[d], zr[d]};
-                const f32x2 diff = zz - e2;
-                const f32x2 sq = diff * diff;
-                acc = acc + sq;
+                for (int q = 0; q < PP; ++q) acc[q] = (f32x2){0.f, 0.f};
+#pragma unroll
+                for (int d = d0; d < d0 + 16 && d < D; ++d) {
+                    const f32x2 e2 = *reinterpret_cast<const f32x2 *>(e + 2 * d);
+#pragma unroll
+                    for (int q = 0; q < PP; ++q) {
+                        const f32x2 zz = {zr[q][d], zr[q][d]};
+                        const f32x2 diff = zz - e2;
+                        const f32x2 sq = diff * diff;
+                        acc[q] = acc[q] + sq;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PP; ++q) total[q] = (d0 == 0) ? acc[q] : total[q] + acc[q];
             }
-            total = (d0 == 0) ? acc : total + acc;
+            const int k0 = 2 * (c0 + kp);
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                if (k0 == 0) { bestd[q] = total[q].x; bi[q] = 0; }
+                else if (vq_better(total[q].x, bestd[q])) { bestd[q] = total[q].x; bi[q] = k0; }
+                if (vq_better(total[q].y, bestd[q])) { bestd[q] = total[q].y; bi[q] = k0 + 1; }
+            }
         }
-        const int k0 = 2 * kp;
-        if (kp == 0) { bestd = total.x; bi = 0; }
-        else if (vq_better(total.x, bestd)) { bestd = total.x; bi = k0; }
-        if (vq_better(total.y, bestd)) { bestd = total.y; bi = k0 + 1; }
     }
     if (K & 1) {   // odd tail, scalar
         const int k = K - 1;
         const float *__restrict__ e = cb + (long long)k * D;
-        float total = 0.f;
 #pragma unroll
-        for (int d0 = 0; d0 < D; d0 += 16) {
-            float acc = 0.f;
+        for (int q = 0; q < PP; ++q) {
+            float total = 0.f;
 #pragma unroll
-            for (int d = d0; d < d0 + 16 && d < D; ++d) {
-                const float diff = zr[d] - e[d];
-                acc = acc + diff * diff;
+            for (int d0 = 0; d0 < D; d0 += 16) {
+                float acc = 0.f;
+#pragma unroll
+                for (int d = d0; d < d0 + 16 && d < D; ++d) {
+                    const float diff = zr[q][d] - e[d];
+                    acc = acc + diff * diff;
+                }
+                total = (d0 == 0) ? acc : total + acc;
             }
-            total = (d0 == 0) ? acc : total + acc;
+            if (k == 0) { bestd[q] = total; bi[q] = 0; }
+            else if (vq_better(total, bestd[q])) { bestd[q] = total; bi[q] = k; }
         }
-        if (k == 0) { bestd = total; bi = 0; }
-        else if (vq_better(total, bestd)) { bestd = total; bi = k; }
     }
 
+    if (npairs == 0) __syncthreads();                      // s_hist zeroing visible even when the pair loop is empty
     double sse = 0.0;
-    if (active) {
-        if (idx) idx[pos] = (long long)bi;
-        const float *__restrict__ q = cb + (long long)bi * D;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float diff = q[d] - zr[d];
-            if (out) out[base + (long long)d * HW] = zr[d] + diff;     // z + (q - z), vq_vae.py:71
-            const float sq = diff * diff;
-            sse += (double)sq;
+    for (int q = 0; q < PP; ++q) {
+        if (active[q]) {
+            if (idx) idx[pos[q]] = (long long)bi[q];
+            const float *__restrict__ qv = cb + (long long)bi[q] * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float diff = qv[d] - zr[q][d];
+                if (out) out[base[q] + (long long)d * HW] = zr[q][d] + diff;     // z + (q - z), vq_vae.py:71
+                const float sq = diff * diff;
+                sse += (double)sq;
+            }
+            if (lds_hist) atomicAdd(&s_hist[bi[q]], 1);
+            else atomicAdd(&hist[bi[q]], 1);
         }
-        if (lds_hist) atomicAdd(&s_hist[bi], 1);
-        else atomicAdd(&hist[bi], 1);
     }
     const double tot = block_sum(sse, s_red);
     if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
@@ -212,9 +249,11 @@ extern "C" size_t dm_vq_workspace_bytes(int K, int D)
     return (size_t)((K + 1) / 2) * 2 * (size_t)D * sizeof(float);
 }
 
+constexpr int VQ_PP = 2;      // positions per lane in the forward kernel (1 for embedding_dim 64: registers)
+
 extern "C" int dm_vq_num_blocks(int64_t positions)
 {
-    return (int)((positions + VQ_BLOCK - 1) / VQ_BLOCK);
+    return (int)((positions + VQ_BLOCK - 1) / VQ_BLOCK);     // upper bound over all variants; unused slabs are zeroed
 }
 
 extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *out,
@@ -230,15 +269,17 @@ extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx
     float *cbT = (float *)workspace;
     const int n = ((K + 1) / 2) * 2 * D;
     hipLaunchKernelGGL(vq_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, codebook, cbT, K, D);
-    const int grid = dm_vq_num_blocks(P);
-#define DM_VQ_FWD(DD)                                                                              \
-    hipLaunchKernelGGL(vq_forward_kernel<DD>, dim3(grid), dim3(VQ_BLOCK), 0, s, z, codebook, cbT, \
-                       (long long *)idx, out, sse_slabs, (int *)hist, K, H * W, P)
+    const int nslabs = dm_vq_num_blocks(P);
+    // the kernel writes one slab per workgroup; with PP positions per lane there are fewer workgroups than slabs
+    hipMemsetAsync(sse_slabs, 0, sizeof(double) * (size_t)nslabs, s);
+#define DM_VQ_FWD(DD, PP_)                                                                                   \
+    hipLaunchKernelGGL((vq_forward_kernel<DD, PP_>), dim3((unsigned)((P + VQ_BLOCK * PP_ - 1) / (VQ_BLOCK * PP_))), \
+                       dim3(VQ_BLOCK), 0, s, z, codebook, cbT, (long long *)idx, out, sse_slabs, (int *)hist, K, H * W, P)
     switch (D) {
-    case 8: DM_VQ_FWD(8); break;
-    case 16: DM_VQ_FWD(16); break;
-    case 32: DM_VQ_FWD(32); break;
-    default: DM_VQ_FWD(64); break;
+    case 8: DM_VQ_FWD(8, VQ_PP); break;
+    case 16: DM_VQ_FWD(16, VQ_PP); break;
+    case 32: DM_VQ_FWD(32, VQ_PP); break;
+    default: DM_VQ_FWD(64, 1); break;
     }
 #undef DM_VQ_FWD
     return dm_launch_status("dm_vq_forward");

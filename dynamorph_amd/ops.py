@@ -124,7 +124,7 @@ def conv4x4s2(inp, wv, B, CIN, NOUT, H, W, ep=None, out=None, want_stats=False, 
         out = _new((B, NOUT, H // 2, W // 2), like)
     stats = None
     if want_stats:
-        nb = lib.dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W)
+        nb = lib.dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W, 1 if epkw.get("per_tile") else 0)
         if nb <= 0:
             raise ValueError(f"dm_conv4x4s2: shape {(B, CIN, NOUT, H, W)} not tileable")
         stats = _new((nb, NOUT, 2), like, torch.float64)
@@ -143,7 +143,7 @@ def conv3x3(inp, wv, B, CIN, NOUT, H, W, taps=9, pixel_shuffle=False, out=None, 
         out = _new((B, co, 2 * H, 2 * W) if pixel_shuffle else (B, co, H, W), like)
     stats = None
     if want_stats:
-        nb = lib.dm_conv3x3_num_blocks(B, CIN, NOUT, H, W, taps, 1 if pixel_shuffle else 0)
+        nb = lib.dm_conv3x3_num_blocks(B, CIN, NOUT, H, W, taps, 1 if pixel_shuffle else 0, 1 if epkw.get("per_tile") else 0)
         if nb <= 0:
             raise ValueError(f"dm_conv3x3: shape {(B, CIN, NOUT, H, W)} not tileable")
         stats = _new((nb, co, 2), like, torch.float64)

@@ -70,8 +70,8 @@ typedef struct dm_weight_view {
  *   if mask.p0: v = (load(mask) > 0) ? v : 0          (ReLU backward)
  *   if resid:   v += resid                             (residual-branch join)
  *   out = v;  if stats: partial sums (sum v, sum v*q), q = stat_q ? stat_q : v,
- *   written as doubles to stats[tile][n][2] (dm_conv*_num_blocks slabs, every one written; reduced by
- *   dm_bn_finalize / dm_bn_backward_finalize / dm_sum_slabs: deterministic). */
+ *   written as doubles to stats[workgroup][n][2]; dm_conv*_num_blocks(..., stats_per_tile) says how many
+ *   slabs that is (reduced by dm_bn_finalize / dm_bn_backward_finalize / dm_sum_slabs: deterministic). */
 typedef struct dm_epilogue {
     const float *bias;
     int32_t relu;
@@ -129,7 +129,7 @@ int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
  * aten::convolution_backward(data) of dec.0/dec.2/dec.4. */
 int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
                  int B, int CIN, int NOUT, int H, int W, void *stream);
-int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W);
+int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, int per_tile);
 
 /* 3x3 stride 1 padding 1 (taps = 9) or 1x1 (taps = 1) convolution on MFMA.
  * pixel_shuffle = 1 turns it into a ConvTranspose2d(4, stride 2, padding 1):
@@ -141,7 +141,7 @@ int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W);
  * (dec.0/2/4) and aten::convolution_backward(data) of every encoder conv. */
 int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
                int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, void *stream);
-int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle);
+int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile);
 
 /* Weight gradient:  R[cs][ct][ky][kx] = sum_{b,y,x} S[b,cs,y,x] * T[b,ct,y*s+ky-p,x*s+kx-p]
  * (k,s,p) in {(4,2,1),(3,1,1),(1,1,0)}.  For a Conv2d: S = output gradient,

@@ -48,10 +48,11 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_vq_workspace_bytes(64, 16) == 64 * 16 * 4
     assert lib.dm_vq_workspace_bytes(63, 16) == 64 * 16 * 4           # odd K is padded to a pair
     assert lib.dm_vq_num_blocks(524288) == 2048
-    assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128) == 2048 * 8
-    assert lib.dm_conv4x4s2_num_blocks(1, 3, 8, 100, 100) == -1      # not tileable
-    assert lib.dm_conv3x3_num_blocks(4, 16, 16, 16, 16, 9, 0) == 4
-    assert lib.dm_conv3x3_num_blocks(4, 32, 16, 16, 16, 9, 0) == 8   # 32 input channels: 8-row tiles
+    assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128, 1) == 2048 * 8   # one slab per tile (per-sample stats)
+    assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128, 0) == 768        # persistent grid
+    assert lib.dm_conv4x4s2_num_blocks(1, 3, 8, 100, 100, 0) == -1            # not tileable
+    assert lib.dm_conv3x3_num_blocks(4, 16, 16, 16, 16, 9, 0, 0) == 4
+    assert lib.dm_conv3x3_num_blocks(4, 32, 16, 16, 16, 9, 0, 1) == 8         # 32 input channels: 8-row tiles
     assert lib.dm_wgrad_num_blocks(2048, 8, 3, 64, 64, 4) == 512     # persistent grid cap
     assert lib.dm_wgrad_num_blocks(1, 8, 3, 64, 64, 5) == -1
     assert lib.dm_head_num_blocks(2048, 128, 128) == 2048
