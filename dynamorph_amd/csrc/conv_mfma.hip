@@ -32,6 +32,7 @@
 // everything is reduced deterministically in bn.hip.
 #include "dm_common.h"
 #include "tile.h"
+#include "mfma_util.h"
 
 namespace {
 
@@ -89,8 +90,9 @@ __device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, const
         q = v;
         if constexpr (SIDE == SIDE_MASK) { if (ep.stat_q) q = e.m; }
         if constexpr (SIDE == SIDE_ALL) { if (ep.stat_q) q = e.q; }
-        s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-        s2 += (double)(v.x * q.x) + (double)(v.y * q.y) + (double)(v.z * q.z) + (double)(v.w * q.w);
+        // four elements in fp32, then one promotion: fp64 converts/adds are half rate and this runs per tile
+        s1 += (double)((v.x + v.y) + (v.z + v.w));
+        s2 += (double)((v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w));
     }
 }
 
@@ -144,50 +146,6 @@ __device__ __forceinline__ void zero_unowned_slabs(const Epilogue &ep, int NCH, 
 {
     for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x)
         for (int i = threadIdx.x; i < NCH * 2; i += DM_BLOCK) ep.stats[(long long)t2 * NCH * 2 + i] = 0.0;
-}
-
-// The MFMA loop of MP M-tiles x NT N-tiles.  off(s) is the compile-time LDS offset of K step s.
-// Software pipeline over chunks of CH K-steps: the LDS operands of chunk c+1 are requested before the
-// MFMAs of chunk c are issued (two register buffers); sched_barrier keeps hipcc from sinking the reads
-// back next to their uses, which would expose the LDS latency once per MFMA group.
-template <int MP, int NT, int KS, int CH, class OFF>
-__device__ __forceinline__ void mfma_tiles(const float *const (&ap)[MP], const float (&wreg)[NT][KS],
-                                           f32x4 (&acc)[MP][NT], OFF off)
-{
-    constexpr int NC = (KS + CH - 1) / CH;
-    float av[2][MP][CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j)
-        if (j < KS) {
-#pragma unroll
-            for (int i = 0; i < MP; ++i) av[0][i][j] = ap[i][off(j)];
-        }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (c + 1 < NC) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int s = (c + 1) * CH + j;
-                if (s < KS) {
-#pragma unroll
-                    for (int i = 0; i < MP; ++i) av[(c + 1) & 1][i][j] = ap[i][off(s)];
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int s = c * CH + j;
-            if (s < KS) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int i = 0; i < MP; ++i)
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][i][j], wreg[t][s], acc[i][t], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
 }
 
 // ============================================================================ kernel A
@@ -424,9 +382,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                         f32x4 v = bias_relu(acc[i][t], ep, bias[t]);
                         if (PIX) {
                             // partner lane (n ^ 1) holds the other x-phase of the same output row
-                            f32x4 pv;
-                            pv.x = __shfl_xor(v.x, 1, 64); pv.y = __shfl_xor(v.y, 1, 64);
-                            pv.z = __shfl_xor(v.z, 1, 64); pv.w = __shfl_xor(v.w, 1, 64);
+                            const f32x4 pv = lane_xor1(v);
                             v = (n & 1) ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
                         }
                         if (n < NOUT) epilogue_tail<SIDE>(v, ep, e[i][t], mc0[t], mc2[t], out, o[i][t], s1[tt], s2[tt]);

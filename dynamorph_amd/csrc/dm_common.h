@@ -125,6 +125,21 @@ __device__ __forceinline__ f32x4 operand_load4(const Operand &op, long long off,
     return v;
 }
 
+// Lane exchanges inside a 16-lane row as DPP moves (VALU, no LDS crossbar round trip; __shfl_xor compiles to
+// ds_bpermute_b32).  xor 1/2: quad_perm; xor 4: row_half_mirror then quad reverse; xor 8: row_ror:8.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }
+__device__ __forceinline__ float lane_xor4(float v) { return dpp_mov<0x1B>(dpp_mov<0x141>(v)); }
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_mov<0x128>(v); }
+__device__ __forceinline__ f32x4 lane_xor1(f32x4 v) { return (f32x4){lane_xor1(v.x), lane_xor1(v.y), lane_xor1(v.z), lane_xor1(v.w)}; }
+__device__ __forceinline__ f32x4 lane_xor4(f32x4 v) { return (f32x4){lane_xor4(v.x), lane_xor4(v.y), lane_xor4(v.z), lane_xor4(v.w)}; }
+__device__ __forceinline__ f32x4 lane_xor8(f32x4 v) { return (f32x4){lane_xor8(v.x), lane_xor8(v.y), lane_xor8(v.z), lane_xor8(v.w)}; }
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

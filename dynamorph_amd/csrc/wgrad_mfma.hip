@@ -213,6 +213,13 @@ void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
 
 }  // namespace
 
+extern "C" int dm_reduce_slabs(const float *slabs, int nslabs, int E, float *dst, void *stream)
+{
+    DM_REQUIRE(slabs && dst && nslabs > 0 && E > 0, "dm_reduce_slabs: bad argument");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, E, dst);
+    return dm_launch_status("dm_reduce_slabs");
+}
+
 extern "C" int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k)
 {
     const int TW = wgrad_tw(Ws);

@@ -231,11 +231,25 @@ def decoder_forward(L, zq, x=None, mask=None):
                         pixel_shuffle=True, bias=_w(L.dec0.bias), relu=True)
     d2, _ = ops.conv3x3(Op(d0), weight_view(_w(L.dec2.weight), 16, c2 * 16, 4, 1), B, c1, 4 * c2, 2 * H3, 2 * W3, taps=9,
                         pixel_shuffle=True, bias=_w(L.dec2.bias), relu=True)
-    d4, _ = ops.conv3x3(Op(d2), weight_view(_w(L.dec4.weight), 16, c2 * 16, 4, 1), B, c2, 4 * c2, 4 * H3, 4 * W3, taps=9,
-                        pixel_shuffle=True, bias=_w(L.dec4.bias), relu=True)
-    dec, slabs = ops.head_forward(d4, _w(L.dec6.weight), _w(L.dec6.bias), x, mask, _w(L.channel_var).reshape(-1))
+    var = _w(L.channel_var).reshape(-1)
+    fused = ops.dec_tail_supported(c2, L.dec6.weight.shape[0], 4 * H3, 4 * W3)
+    if fused:
+        # dec.4 + ReLU + dec.6 (+ loss) in one kernel; the 4 x 128 x 128 tensor d4 is never stored
+        d4 = None
+        dec, slabs = ops.dec_tail_forward(d2, _w(L.dec4.weight), _w(L.dec4.bias), _w(L.dec6.weight), _w(L.dec6.bias),
+                                          x, mask, var)
+    else:
+        d4 = _dec4_forward(L, d2)
+        dec, slabs = ops.head_forward(d4, _w(L.dec6.weight), _w(L.dec6.bias), x, mask, var)
     cx = SimpleNamespace(zq=zq, d0=d0, d2=d2, d4=d4, dec=dec, x=x, mask=mask, loss_slabs=slabs)
     return dec, cx
+
+
+def _dec4_forward(L, d2):
+    B, c2, H, W = d2.shape
+    d4, _ = ops.conv3x3(Op(d2), weight_view(_w(L.dec4.weight), 16, c2 * 16, 4, 1), B, c2, 4 * c2, H, W, taps=9,
+                        pixel_shuffle=True, bias=_w(L.dec4.bias), relu=True)
+    return d4
 
 
 def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
@@ -245,18 +259,30 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
     B, nh, H3, W3 = zq.shape
     c1, c2 = nh // 2, nh // 4
     NIN = L.dec6.weight.shape[0]
-    g4, part = ops.head_backward(cx.dec, cx.x, cx.mask, _w(L.channel_var).reshape(-1), cx.d4, _w(L.dec6.weight),
-                                 gscale, gdec_ext)
-    flat = torch.empty(part.shape[1], device=zq.device, dtype=torch.float32)
-    ops.sum_slabs(part, flat)
-    G(L.dec6.weight).copy_(flat[:NIN * c2].view_as(L.dec6.weight))
-    G(L.dec6.bias).copy_(flat[NIN * c2:NIN * c2 + NIN])
-    G(L.dec4.bias).copy_(flat[NIN * c2 + NIN:])
-
-    ops.wgrad(Op(cx.d2), Op(g4), G(L.dec4.weight), B, c2, c2, 4 * H3, 4 * W3, 4)
-    g2, st = ops.conv4x4s2(Op(g4), weight_view(_w(L.dec4.weight), c2 * 16, 16, 4, 1), B, c2, c2, 8 * H3, 8 * W3,
-                           want_stats=True, mask=Op(cx.d2))
-    ops.sum_slabs(st, G(L.dec2.bias))
+    var = _w(L.channel_var).reshape(-1)
+    if cx.d4 is None and gdec_ext is None and gscale is not None:
+        # fused tail: recompute d4 from d2, g4 lives only in LDS
+        g2, part, wsl = ops.dec_tail_backward(cx.d2, _w(L.dec4.weight), _w(L.dec4.bias), _w(L.dec6.weight), cx.dec, cx.x,
+                                              cx.mask, var, gscale)
+        flat = torch.empty(part.shape[1], device=zq.device, dtype=torch.float32)
+        ops.sum_slabs(part, flat)
+        G(L.dec6.weight).copy_(flat[:NIN * c2].view_as(L.dec6.weight))
+        G(L.dec6.bias).copy_(flat[NIN * c2:NIN * c2 + NIN])
+        G(L.dec4.bias).copy_(flat[NIN * c2 + NIN:NIN * c2 + NIN + c2])
+        G(L.dec2.bias).copy_(flat[NIN * c2 + NIN + c2:])
+        ops.reduce_slabs(wsl, G(L.dec4.weight))
+    else:
+        d4 = cx.d4 if cx.d4 is not None else _dec4_forward(L, cx.d2)
+        g4, part = ops.head_backward(cx.dec, cx.x, cx.mask, var, d4, _w(L.dec6.weight), gscale, gdec_ext)
+        flat = torch.empty(part.shape[1], device=zq.device, dtype=torch.float32)
+        ops.sum_slabs(part, flat)
+        G(L.dec6.weight).copy_(flat[:NIN * c2].view_as(L.dec6.weight))
+        G(L.dec6.bias).copy_(flat[NIN * c2:NIN * c2 + NIN])
+        G(L.dec4.bias).copy_(flat[NIN * c2 + NIN:])
+        ops.wgrad(Op(cx.d2), Op(g4), G(L.dec4.weight), B, c2, c2, 4 * H3, 4 * W3, 4)
+        g2, st = ops.conv4x4s2(Op(g4), weight_view(_w(L.dec4.weight), c2 * 16, 16, 4, 1), B, c2, c2, 8 * H3, 8 * W3,
+                               want_stats=True, mask=Op(cx.d2))
+        ops.sum_slabs(st, G(L.dec2.bias))
     ops.wgrad(Op(cx.d0), Op(g2), G(L.dec2.weight), B, c1, c2, 2 * H3, 2 * W3, 4)
     g0, st = ops.conv4x4s2(Op(g2), weight_view(_w(L.dec2.weight), c2 * 16, 16, 4, 1), B, c2, c1, 4 * H3, 4 * W3,
                            want_stats=True, mask=Op(cx.d0))

@@ -248,6 +248,46 @@ def head_backward(dec, x, mask, channel_var, d4, w6, gscale, gdec_ext=None):
     return g4, part
 
 
+def dec_tail_supported(c2, nin, h2, w2):
+    return bool(L.load().dm_dec_tail_supported(c2, nin, h2, w2))
+
+
+def dec_tail_forward(d2, w4, b4, w6, b6, x, mask, channel_var):
+    """Fused dec.4 + ReLU + dec.6 (+ masked reconstruction loss partials when x is given)."""
+    lib = L.load()
+    B, C2, H2, W2 = d2.shape
+    NIN = w6.shape[0]
+    dec = _new((B, NIN, 2 * H2, 2 * W2), d2)
+    slabs = _new((lib.dm_dec_tail_num_blocks(B, H2, W2),), d2, torch.float64) if x is not None else None
+    mc = mask.shape[1] if mask is not None else 0
+    L.check(lib.dm_dec_tail_forward(_ptr(d2), _ptr(w4), _ptr(b4), _ptr(w6), _ptr(b6), _ptr(x), _ptr(mask), mc,
+                                    _ptr(channel_var), _ptr(dec), _ptr(slabs, torch.float64), B, C2, NIN, H2, W2,
+                                    _stream()), "dm_dec_tail_forward")
+    return dec, slabs
+
+
+def dec_tail_backward(d2, w4, b4, w6, dec, x, mask, channel_var, gscale):
+    """Returns (g2, part (nb, NIN*4+NIN+8, 2) float64, w_slabs (nb, 256) float32)."""
+    lib = L.load()
+    B, C2, H2, W2 = d2.shape
+    NIN = w6.shape[0]
+    nb = lib.dm_dec_tail_num_blocks(B, H2, W2)
+    g2 = torch.empty_like(d2)
+    part = _new((nb, NIN * C2 + NIN + 2 * C2, 2), d2, torch.float64)
+    wsl = _new((nb, C2 * C2 * 16), d2)
+    mc = mask.shape[1] if mask is not None else 0
+    L.check(lib.dm_dec_tail_backward(_ptr(d2), _ptr(w4), _ptr(b4), _ptr(w6), _ptr(dec), _ptr(x), _ptr(mask), mc,
+                                     _ptr(channel_var), _ptr(gscale), _ptr(g2), _ptr(part, torch.float64), _ptr(wsl),
+                                     B, C2, NIN, H2, W2, _stream()), "dm_dec_tail_backward")
+    return g2, part, wsl
+
+
+def reduce_slabs(slabs, dst):
+    lib = L.load()
+    L.check(lib.dm_reduce_slabs(_ptr(slabs), slabs.shape[0], slabs.shape[1], _ptr(dst), _stream()), "dm_reduce_slabs")
+    return dst
+
+
 def loss_finalize(loss_slabs, count, vq_scalars, weight_recon, weight_commitment):
     lib = L.load()
     out = _new((4,), vq_scalars)

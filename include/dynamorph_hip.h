@@ -205,6 +205,27 @@ int dm_head_backward(const float *decoded, const float *x, const float *mask, in
                      const float *gdec_ext, float *g4, double *part_slabs, int B, int C4, int NIN, int H, int W,
                      void *stream);
 
+/* ----- fused decoder tail (dec.4 + dec.5 + dec.6 + loss, vq_vae.py:296-298, 320-323) ---------------------
+ * The 4 x 2H2 x 2W2 tensor d4 = relu(dec.4(d2)) and its gradient are never written to HBM.
+ * Built for num_hiddens//4 = 4 channels and d2 exactly 64 wide; dm_dec_tail_supported() tells. */
+int dm_dec_tail_supported(int C2, int NIN, int H2, int W2);
+int dm_dec_tail_num_blocks(int B, int H2, int W2);
+/* d2 (B,4,H2,64) post-ReLU input of dec.4; w4 (4,4,4,4) ConvTranspose2d weight [ci][co][ky][kx]; w6 (NIN,4).
+ * decoded (B,NIN,2H2,128); loss_slabs: dm_dec_tail_num_blocks doubles (x = NULL: decoder-only, no loss). */
+int dm_dec_tail_forward(const float *d2, const float *w4, const float *b4, const float *w6, const float *b6,
+                        const float *x, const float *mask, int mask_channels, const float *channel_var,
+                        float *decoded, double *loss_slabs, int B, int C2, int NIN, int H2, int W2, void *stream);
+/* Backward of the same block for d(total)/d(recon_loss) = gscale_dev[0]:
+ *   g2 (B,4,H2,64) = gradient w.r.t. the PRE-ReLU output of dec.2 (already masked by d2 > 0);
+ *   part_slabs [nblocks][NIN*4 + NIN + 4 + 4][2] doubles = partial sums of dW6 | db6 | db4 | db2 (dm_sum_slabs);
+ *   w_slabs [nblocks][256] floats = partial dW4 in the parameter's layout (dm_reduce_slabs). */
+int dm_dec_tail_backward(const float *d2, const float *w4, const float *b4, const float *w6,
+                         const float *decoded, const float *x, const float *mask, int mask_channels,
+                         const float *channel_var, const float *gscale_dev, float *g2, double *part_slabs,
+                         float *w_slabs, int B, int C2, int NIN, int H2, int W2, void *stream);
+/* dst[e] = sum over slabs of slabs[slab][e], fixed order (bitwise reproducible). */
+int dm_reduce_slabs(const float *slabs, int nslabs, int E, float *dst, void *stream);
+
 /* scalars_out = (recon, commitment, total, perplexity) from the loss slabs and
  * the dm_vq_finalize scalars: recon = sum/N, total = w_recon*recon + w_commit*commitment. */
 int dm_loss_finalize(const double *loss_slabs, int nslabs, int64_t count, const float *vq_scalars,

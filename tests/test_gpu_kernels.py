@@ -410,3 +410,50 @@ def test_bad_arguments_raise(ops):
         ops.conv3x3(ops.Op(x), ops.weight_view(x, 1, 1, 1, 1), 1, 16, 16, 10, 10, taps=9)   # 10x10 not tileable
     with pytest.raises(ValueError):
         ops.vq_forward(rnd(1, 16, 4, 4), rnd(4, 16))                       # CPU tensors: no fallback
+
+
+# ===================================================================== fused decoder tail
+@pytest.mark.parametrize("nin,masked,B", [(2, False, 3), (2, True, 2), (4, True, 2), (1, False, 70)])
+def test_dec_tail_fused_forward_backward(ops, nin, masked, B):
+    """dec.4 + ReLU + dec.6 + masked loss in one kernel, and its fused backward, vs the ATen composition."""
+    c, h = 4, 64
+    pre = rnd(B, c, h, h, seed=1).requires_grad_(True)
+    w4 = (rnd(c, c, 4, 4, seed=2) * 0.3).requires_grad_(True)
+    b4 = rnd(c, seed=3).requires_grad_(True)
+    w6 = rnd(nin, c, 1, 1, seed=4).requires_grad_(True)
+    b6 = rnd(nin, seed=5).requires_grad_(True)
+    x = rnd(B, nin, 2 * h, 2 * h, seed=6)
+    mask = (torch.rand(B, 1, 2 * h, 2 * h, generator=torch.Generator().manual_seed(7)) > 0.4).float() * 0.5 + 0.5 if masked else None
+    var = torch.linspace(0.5, 1.5, nin)
+    d2 = F.relu(pre)
+    d4 = F.relu(F.conv_transpose2d(d2, w4, b4, stride=2, padding=1))
+    dec_ref = F.conv2d(d4, w6, b6)
+    mm = mask if masked else torch.ones_like(x)
+    loss_ref = torch.mean(F.mse_loss(dec_ref * mm, x * mm, reduction="none") / var.reshape(1, nin, 1, 1))
+    (loss_ref * 0.7).backward()
+
+    dv = [t.detach().to(DEV).contiguous() for t in (d2, w4, b4, w6, b6, x, var)]
+    mk = mask.to(DEV) if masked else None
+    dec, slabs = ops.dec_tail_forward(dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], mk, dv[6])
+    recon = ops.loss_finalize(slabs, x.numel(), torch.zeros(2, device=DEV), 1.0, 0.0)[0]
+    close(dec, dec_ref, 2e-5, 2e-5, "decoded")
+    assert abs(float(recon) - float(loss_ref)) <= 3e-6 * abs(float(loss_ref))
+    dec_only, none = ops.dec_tail_forward(dv[0], dv[1], dv[2], dv[3], dv[4], None, None, dv[6])
+    assert none is None and torch.equal(dec_only, dec)
+
+    g2, part, wsl = ops.dec_tail_backward(dv[0], dv[1], dv[2], dv[3], dec, dv[5], mk, dv[6], torch.tensor([0.7], device=DEV))
+    flat = torch.empty(part.shape[1], device=DEV)
+    ops.sum_slabs(part, flat)
+    dw4 = torch.empty(c, c, 4, 4, device=DEV)
+    ops.reduce_slabs(wsl, dw4)
+    sc = lambda t: t.abs().max().item()
+    close(g2, pre.grad, 1e-4, 2e-5 * sc(pre.grad), "g2 (masked by d2 > 0)")
+    close(dw4, w4.grad, 1e-4, 1e-4 * sc(w4.grad), "dW4")
+    close(flat[:nin * c].reshape(nin, c), w6.grad.reshape(nin, c), 1e-4, 1e-4 * sc(w6.grad), "dW6")
+    close(flat[nin * c:nin * c + nin], b6.grad, 1e-4, 1e-4 * sc(b6.grad), "db6")
+    close(flat[nin * c + nin:nin * c + nin + c], b4.grad, 1e-4, 1e-4 * sc(b4.grad), "db4")
+    close(flat[nin * c + nin + c:], pre.grad.sum((0, 2, 3)), 1e-4, 1e-4 * sc(pre.grad.sum((0, 2, 3))), "db2 = sum g2")
+    g2b, _, wsl2 = ops.dec_tail_backward(dv[0], dv[1], dv[2], dv[3], dec, dv[5], mk, dv[6], torch.tensor([0.7], device=DEV))
+    dw4b = torch.empty_like(dw4)
+    ops.reduce_slabs(wsl2, dw4b)
+    assert torch.equal(g2b, g2) and torch.equal(dw4b, dw4), "fused tail must be bitwise reproducible"
