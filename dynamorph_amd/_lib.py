@@ -27,6 +27,14 @@ class Epilogue(C.Structure):
                 ("stats", vp)]
 
 
+class Scatter(C.Structure):
+    _fields_ = [("nseg", i32), ("end", i32 * 8), ("dst", vp * 8)]
+
+
+class ReduceSeg(C.Structure):
+    _fields_ = [("slabs", vp), ("dst", vp), ("nslabs", i32), ("E", i32)]
+
+
 OP, WV, EP = C.POINTER(Operand), C.POINTER(WeightView), C.POINTER(Epilogue)
 
 # name -> (restype, argtypes); every symbol include/dynamorph_hip.h declares
@@ -51,6 +59,8 @@ SIGNATURES = {
     "dm_channel_stats_num_blocks": (C.c_int, [C.c_int] * 4),
     "dm_channel_stats": (C.c_int, [vp, vp, vp] + [C.c_int] * 4 + [vp]),
     "dm_sum_slabs": (C.c_int, [vp, C.c_int, C.c_int, f32, vp, vp]),
+    "dm_sum_slabs_scatter": (C.c_int, [vp, C.c_int, C.c_int, f32, C.POINTER(Scatter), vp]),
+    "dm_reduce_slabs_multi": (C.c_int, [C.POINTER(ReduceSeg), C.c_int, vp]),
     "dm_head_num_blocks": (C.c_int, [C.c_int] * 3),
     "dm_head_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_head_backward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),

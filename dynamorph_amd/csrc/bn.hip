@@ -188,6 +188,29 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const double *__restrict
     if (threadIdx.x == 0) dst[n] = (float)(t * (double)scale);
 }
 
+struct Scatter {
+    int nseg;
+    int end[8];
+    float *dst[8];
+};
+
+__global__ __launch_bounds__(256) void sum_slabs_scatter_kernel(const double *__restrict__ stats, int nslabs, int N,
+                                                                float scale, Scatter sc)
+{
+    __shared__ double s_red[4];
+    const int n = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nslabs; i += blockDim.x) s += stats[((long long)i * N + n) * 2];
+    const double t = block_sum(s, s_red);
+    if (threadIdx.x == 0) {
+        int start = 0;
+        for (int k = 0; k < sc.nseg; ++k) {
+            if (n < sc.end[k]) { sc.dst[k][n - start] = (float)(t * (double)scale); break; }
+            start = sc.end[k];
+        }
+    }
+}
+
 constexpr int STATS_BCHUNK = 8;
 
 }  // namespace
@@ -245,6 +268,18 @@ extern "C" int dm_channel_stats(const float *p, const float *q, double *stats, i
     hipLaunchKernelGGL(channel_stats_kernel, dim3(chunks * C), dim3(256), 0, (hipStream_t)stream, p, q, stats, B, C,
                        H * W / 4, STATS_BCHUNK);
     return dm_launch_status("dm_channel_stats");
+}
+
+extern "C" int dm_sum_slabs_scatter(const double *stats, int nslabs, int N, float scale, const dm_scatter *sc, void *stream)
+{
+    DM_REQUIRE(stats && sc && nslabs > 0 && N > 0, "dm_sum_slabs_scatter: bad argument");
+    DM_REQUIRE(sc->nseg >= 1 && sc->nseg <= 8 && sc->end[sc->nseg - 1] == N, "dm_sum_slabs_scatter: segments must cover N");
+    Scatter d;
+    d.nseg = sc->nseg;
+    for (int k = 0; k < 8; ++k) { d.end[k] = k < sc->nseg ? sc->end[k] : N; d.dst[k] = k < sc->nseg ? sc->dst[k] : nullptr; }
+    for (int k = 0; k < sc->nseg; ++k) DM_REQUIRE(d.dst[k], "dm_sum_slabs_scatter: NULL destination %d", k);
+    hipLaunchKernelGGL(sum_slabs_scatter_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, stats, nslabs, N, scale, d);
+    return dm_launch_status("dm_sum_slabs_scatter");
 }
 
 extern "C" int dm_sum_slabs(const double *stats, int nslabs, int N, float scale, float *dst, void *stream)

@@ -18,8 +18,12 @@ namespace {
 constexpr int VQ_BLOCK = 256;
 constexpr int VQ_MAX_LDS_HIST = 4096;
 
-__global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ cbT, int K, int D)
+__global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ cbT, int K, int D,
+                               int *__restrict__ hist, double *__restrict__ slabs, int nslabs)
 {
+    // also clears the outputs the forward kernel accumulates into (no separate memset launches)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) hist[i] = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nslabs; i += gridDim.x * blockDim.x) slabs[i] = 0.0;
     // cbT[p][d][j] = cb[2p + j][d]; for odd K the missing partner repeats code K-1 (never selected).
     const int npairs = (K + 1) >> 1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npairs * D * 2; i += gridDim.x * blockDim.x) {
@@ -268,10 +272,9 @@ extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx
     const long long P = (long long)B * H * W;
     float *cbT = (float *)workspace;
     const int n = ((K + 1) / 2) * 2 * D;
-    hipLaunchKernelGGL(vq_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, codebook, cbT, K, D);
     const int nslabs = dm_vq_num_blocks(P);
-    // the kernel writes one slab per workgroup; with PP positions per lane there are fewer workgroups than slabs
-    hipMemsetAsync(sse_slabs, 0, sizeof(double) * (size_t)nslabs, s);
+    hipLaunchKernelGGL(vq_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, codebook, cbT, K, D, (int *)hist, sse_slabs, nslabs);
+    // (vq_prep_kernel cleared hist and all slabs: with PP positions per lane there are fewer workgroups than slabs)
 #define DM_VQ_FWD(DD, PP_)                                                                                   \
     hipLaunchKernelGGL((vq_forward_kernel<DD, PP_>), dim3((unsigned)((P + VQ_BLOCK * PP_ - 1) / (VQ_BLOCK * PP_))), \
                        dim3(VQ_BLOCK), 0, s, z, codebook, cbT, (long long *)idx, out, sse_slabs, (int *)hist, K, H * W, P)

@@ -183,6 +183,45 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     }
 }
 
+struct ReduceSegs {
+    const float *slabs[16];
+    float *dst[16];
+    int nslabs[16];
+    int E[16];
+    int first_block[17];      // prefix sums of ceil(E/16)
+    int nseg;
+};
+
+// every (slabs, dst) pair of a backward pass in one launch; same arithmetic as slab_reduce_kernel
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceSegs rs)
+{
+    __shared__ float part[16][17];
+    int k = 0;
+    while (k + 1 < rs.nseg && (int)blockIdx.x >= rs.first_block[k + 1]) ++k;
+    const float *__restrict__ slabs = rs.slabs[k];
+    const int E = rs.E[k], nslabs = rs.nslabs[k];
+    const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e = ((int)blockIdx.x - rs.first_block[k]) * 16 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < E) {
+        int i = g;
+        for (; i + 48 < nslabs; i += 64) {
+            const float a = slabs[(long long)i * E + e], b = slabs[(long long)(i + 16) * E + e];
+            const float c = slabs[(long long)(i + 32) * E + e], d = slabs[(long long)(i + 48) * E + e];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; i < nslabs; i += 16) s0 += slabs[(long long)i * E + e];
+    }
+    part[g][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < E) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += part[j][el];
+        rs.dst[k][e] = s;
+    }
+}
+
 int wgrad_tw(int Ws) { return Ws < 64 ? Ws : 64; }
 
 // LDS floats of the S + T tiles for a TH-row tile; 8 rows unless that overflows the 64 KB static limit.
@@ -213,6 +252,25 @@ void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
 
 }  // namespace
 
+extern "C" int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *stream)
+{
+    DM_REQUIRE(segs && nseg >= 1 && nseg <= 16, "dm_reduce_slabs_multi: 1..16 segments");
+    ReduceSegs rs;
+    rs.nseg = nseg;
+    int blocks = 0;
+    for (int k = 0; k < 16; ++k) {
+        const bool on = k < nseg;
+        if (on) DM_REQUIRE(segs[k].slabs && segs[k].dst && segs[k].nslabs > 0 && segs[k].E > 0, "dm_reduce_slabs_multi: bad segment %d", k);
+        rs.slabs[k] = on ? segs[k].slabs : nullptr; rs.dst[k] = on ? segs[k].dst : nullptr;
+        rs.nslabs[k] = on ? segs[k].nslabs : 0; rs.E[k] = on ? segs[k].E : 0;
+        rs.first_block[k] = blocks;
+        if (on) blocks += (segs[k].E + 15) / 16;
+    }
+    rs.first_block[16] = blocks;
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rs);
+    return dm_launch_status("dm_reduce_slabs_multi");
+}
+
 extern "C" int dm_reduce_slabs(const float *slabs, int nslabs, int E, float *dst, void *stream)
 {
     DM_REQUIRE(slabs && dst && nslabs > 0 && E > 0, "dm_reduce_slabs: bad argument");
@@ -234,7 +292,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
                         int B, int CS, int CT, int Hs, int Ws, int k, void *stream)
 {
     if (dm_check_operand(S, "dm_wgrad(S)") || dm_check_operand(T, "dm_wgrad(T)")) return -1;
-    DM_REQUIRE(slabs && dst, "dm_wgrad: NULL output");
+    DM_REQUIRE(slabs, "dm_wgrad: NULL slabs");
     DM_REQUIRE((long long)B * (CS > 4 * CT ? CS : 4 * CT) * Hs * Ws < (1LL << 31), "dm_wgrad: tensor too large for 32-bit offsets");
     DM_REQUIRE(k == 4 || k == 3 || k == 1, "dm_wgrad: kernel size %d not built", k);
     DM_REQUIRE(!S->ones_channel, "dm_wgrad: S cannot carry a ones channel");
@@ -242,6 +300,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     DM_REQUIRE((TW == 16 || TW == 32 || TW == 64) && Hs % TH == 0 && Ws % TW == 0,
                "dm_wgrad: S spatial size %dx%d not tileable", Hs, Ws);
     const int grid = dm_wgrad_num_blocks(B, CS, CT, Hs, Ws, k);
+    DM_REQUIRE(T->mode != DM_LOAD_AFFINE2, "dm_wgrad: T operand cannot be AFFINE2");
     const int CTphys = CT - (T->ones_channel ? 1 : 0);
     DM_REQUIRE(CTphys > 0, "dm_wgrad: no physical T channel");
     hipStream_t st = (hipStream_t)stream;
@@ -270,8 +329,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
         return -1;
     }
     int rc = dm_launch_status("dm_wgrad");
-    if (rc) return rc;
-    DM_REQUIRE(T->mode != DM_LOAD_AFFINE2, "dm_wgrad: T operand cannot be AFFINE2");
+    if (rc || !dst) return rc;          // dst == NULL: the caller reduces the slabs later (dm_reduce_slabs_multi)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 15) / 16), dim3(256), 0, st, slabs, grid, E, dst);
     return dm_launch_status("dm_wgrad(reduce)");
 }

@@ -135,11 +135,12 @@ def residual_forward(res_layers, h, per_sample=False):
     return h, saved
 
 
-def _zero(t):
-    t.zero_()
+def _zero(t, do=True):
+    if do:
+        t.zero_()
 
 
-def residual_backward(res_layers, saved, g_h, G, q_below):
+def residual_backward(res_layers, saved, g_h, G, q_below, pending=None, zero_fed_biases=True):
     """Gradient of the residual stack.  g_h: gradient w.r.t. its output.  q_below: the raw conv output
     whose BatchNorm produced the stack's input (None if there is none); when given, the returned stats
     are the (sum g, sum g*q_below) slabs that BatchNorm's backward needs.  Returns (g_in, stats)."""
@@ -156,22 +157,25 @@ def residual_backward(res_layers, saved, g_h, G, q_below):
             raise NotImplementedError("backward needs batch-statistics BatchNorm (train mode, per_sample=False)")
         cb_bwd = ops.bn_backward_finalize(stats, cnt, _w(bnb.weight), s.savedb, G(bnb.weight), G(bnb.bias))
         da_rb = Op(g_h, DM_LOAD_AFFINE2, cb_bwd, p1=s.rb)
-        ops.wgrad(da_rb, Op(s.ra, DM_LOAD_AFFINE_RELU, s.coefa), G(cb.weight), B, nh, nrh, H, W, 1)
-        _zero(G(cb.bias))
+        ops.wgrad(da_rb, Op(s.ra, DM_LOAD_AFFINE_RELU, s.coefa), G(cb.weight), B, nh, nrh, H, W, 1, pending=pending)
+        _zero(G(cb.bias), zero_fed_biases)
         dy_ra, st = ops.conv3x3(da_rb, weight_view(_w(cb.weight), 1, nrh, 0, 0), B, nh, nrh, H, W, taps=1, want_stats=True,
                                 like=g_h, mask=Op(s.ra, DM_LOAD_AFFINE, s.coefa), stat_q=s.ra)
         ca_bwd = ops.bn_backward_finalize(st, cnt, _w(bna.weight), s.saveda, G(bna.weight), G(bna.bias))
         da_ra = Op(dy_ra, DM_LOAD_AFFINE2, ca_bwd, p1=s.ra)
-        ops.wgrad(da_ra, Op(s.h_in, DM_LOAD_RELU), G(ca.weight), B, nrh, nh, H, W, 3)
-        _zero(G(ca.bias))
+        ops.wgrad(da_ra, Op(s.h_in, DM_LOAD_RELU), G(ca.weight), B, nrh, nh, H, W, 3, pending=pending)
+        _zero(G(ca.bias), zero_fed_biases)
         q = saved[i - 1].rb if i > 0 else q_below
         g_h, stats = ops.conv3x3(da_ra, weight_view(_w(ca.weight), 9, nh * 9, -3, -1, off=8), B, nrh, nh, H, W, taps=9,
                                  want_stats=q is not None, like=g_h, mask=Op(s.h_in), resid=g_h, stat_q=q)
     return g_h, stats
 
 
-def encoder_backward(L, cx, g_z, G):
-    """Accumulates nothing: every parameter gradient G(p) is overwritten.  No gradient flows to x."""
+def encoder_backward(L, cx, g_z, G, zero_fed_biases=True):
+    """Accumulates nothing: every parameter gradient G(p) is overwritten.  No gradient flows to x.
+    zero_fed_biases=False skips writing the (identically zero) gradients of the conv biases that feed a
+    BatchNorm -- for callers whose gradient buffer is zero there already (FusedTrainer)."""
+    pending = []
     if cx.per_sample and cx.B > 1:
         raise NotImplementedError("backward through per-sample BatchNorm statistics with B > 1")
     if cx.saved1 is None:
@@ -181,27 +185,27 @@ def encoder_backward(L, cx, g_z, G):
     H1, W1, H2, W2, H3, W3 = cx.dims
     g_z = g_z.contiguous()
 
-    g_h, stats = residual_backward(L.res, cx.res, g_z, G, cx.a4)
+    g_h, stats = residual_backward(L.res, cx.res, g_z, G, cx.a4, pending=pending, zero_fed_biases=zero_fed_biases)
     cnt3 = B * H3 * W3
     c4b = ops.bn_backward_finalize(stats, cnt3, _w(L.bn4.weight), cx.saved4, G(L.bn4.weight), G(L.bn4.bias))
     da4 = Op(g_h, DM_LOAD_AFFINE2, c4b, p1=cx.a4)
-    ops.wgrad(da4, Op(cx.a3, DM_LOAD_AFFINE_RELU, cx.coef3), G(L.enc10.weight), B, nh, nh, H3, W3, 3)
-    _zero(G(L.enc10.bias))
+    ops.wgrad(da4, Op(cx.a3, DM_LOAD_AFFINE_RELU, cx.coef3), G(L.enc10.weight), B, nh, nh, H3, W3, 3, pending=pending)
+    _zero(G(L.enc10.bias), zero_fed_biases)
     dy3, st = ops.conv3x3(da4, weight_view(_w(L.enc10.weight), 9, nh * 9, -3, -1, off=8), B, nh, nh, H3, W3, taps=9,
                           want_stats=True, like=g_h, mask=Op(cx.a3, DM_LOAD_AFFINE, cx.coef3), stat_q=cx.a3)
 
     c3b = ops.bn_backward_finalize(st, cnt3, _w(L.bn3.weight), cx.saved3, G(L.bn3.weight), G(L.bn3.bias))
     da3 = Op(dy3, DM_LOAD_AFFINE2, c3b, p1=cx.a3)
-    ops.wgrad(da3, Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), G(L.enc7.weight), B, nh, nh, H3, W3, 4)
-    _zero(G(L.enc7.bias))
+    ops.wgrad(da3, Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), G(L.enc7.weight), B, nh, nh, H3, W3, 4, pending=pending)
+    _zero(G(L.enc7.bias), zero_fed_biases)
     dy2, st = ops.conv3x3(da3, weight_view(_w(L.enc7.weight), 16, nh * 16, 4, 1), B, nh, 4 * nh, H3, W3, taps=9,
                           pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a2, DM_LOAD_AFFINE, cx.coef2),
                           stat_q=cx.a2)
 
     c2b = ops.bn_backward_finalize(st, B * H2 * W2, _w(L.bn2.weight), cx.saved2, G(L.bn2.weight), G(L.bn2.bias))
     da2 = Op(dy2, DM_LOAD_AFFINE2, c2b, p1=cx.a2)
-    ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(L.enc4.weight), B, nh, c1, H2, W2, 4)
-    _zero(G(L.enc4.bias))
+    ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(L.enc4.weight), B, nh, c1, H2, W2, 4, pending=pending)
+    _zero(G(L.enc4.bias), zero_fed_biases)
     dy1, st = ops.conv3x3(da2, weight_view(_w(L.enc4.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
                           pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
                           stat_q=cx.a1)
@@ -209,10 +213,11 @@ def encoder_backward(L, cx, g_z, G):
     c1b = ops.bn_backward_finalize(st, B * H1 * W1, _w(L.bn1.weight), cx.saved1, G(L.bn1.weight), G(L.bn1.bias))
     da1 = Op(dy1, DM_LOAD_AFFINE2, c1b, p1=cx.a1)
     dweff = torch.empty((c1, NIN + 1, 4, 4), device=x.device, dtype=torch.float32)
-    ops.wgrad(da1, Op(x, ones=True), dweff, B, c1, NIN + 1, H1, W1, 4)
+    ops.wgrad(da1, Op(x, ones=True), dweff, B, c1, NIN + 1, H1, W1, 4, pending=pending)
+    ops.reduce_slabs_multi(pending)                  # all encoder weight gradients in one launch
     ops.e1_chain(dweff, _w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight),
                  G(L.enc0.weight), G(L.enc0.bias), G(L.enc1.weight))
-    _zero(G(L.enc1.bias))
+    _zero(G(L.enc1.bias), zero_fed_biases)
 
 
 # ------------------------------------------------------------------------------------ VQ
@@ -260,34 +265,27 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
     c1, c2 = nh // 2, nh // 4
     NIN = L.dec6.weight.shape[0]
     var = _w(L.channel_var).reshape(-1)
+    pending = []
     if cx.d4 is None and gdec_ext is None and gscale is not None:
         # fused tail: recompute d4 from d2, g4 lives only in LDS
         g2, part, wsl = ops.dec_tail_backward(cx.d2, _w(L.dec4.weight), _w(L.dec4.bias), _w(L.dec6.weight), cx.dec, cx.x,
                                               cx.mask, var, gscale)
-        flat = torch.empty(part.shape[1], device=zq.device, dtype=torch.float32)
-        ops.sum_slabs(part, flat)
-        G(L.dec6.weight).copy_(flat[:NIN * c2].view_as(L.dec6.weight))
-        G(L.dec6.bias).copy_(flat[NIN * c2:NIN * c2 + NIN])
-        G(L.dec4.bias).copy_(flat[NIN * c2 + NIN:NIN * c2 + NIN + c2])
-        G(L.dec2.bias).copy_(flat[NIN * c2 + NIN + c2:])
-        ops.reduce_slabs(wsl, G(L.dec4.weight))
+        ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias), G(L.dec2.bias)])
+        pending.append((wsl, G(L.dec4.weight)))
     else:
         d4 = cx.d4 if cx.d4 is not None else _dec4_forward(L, cx.d2)
         g4, part = ops.head_backward(cx.dec, cx.x, cx.mask, var, d4, _w(L.dec6.weight), gscale, gdec_ext)
-        flat = torch.empty(part.shape[1], device=zq.device, dtype=torch.float32)
-        ops.sum_slabs(part, flat)
-        G(L.dec6.weight).copy_(flat[:NIN * c2].view_as(L.dec6.weight))
-        G(L.dec6.bias).copy_(flat[NIN * c2:NIN * c2 + NIN])
-        G(L.dec4.bias).copy_(flat[NIN * c2 + NIN:])
-        ops.wgrad(Op(cx.d2), Op(g4), G(L.dec4.weight), B, c2, c2, 4 * H3, 4 * W3, 4)
+        ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias)])
+        ops.wgrad(Op(cx.d2), Op(g4), G(L.dec4.weight), B, c2, c2, 4 * H3, 4 * W3, 4, pending=pending)
         g2, st = ops.conv4x4s2(Op(g4), weight_view(_w(L.dec4.weight), c2 * 16, 16, 4, 1), B, c2, c2, 8 * H3, 8 * W3,
                                want_stats=True, mask=Op(cx.d2))
         ops.sum_slabs(st, G(L.dec2.bias))
-    ops.wgrad(Op(cx.d0), Op(g2), G(L.dec2.weight), B, c1, c2, 2 * H3, 2 * W3, 4)
+    ops.wgrad(Op(cx.d0), Op(g2), G(L.dec2.weight), B, c1, c2, 2 * H3, 2 * W3, 4, pending=pending)
     g0, st = ops.conv4x4s2(Op(g2), weight_view(_w(L.dec2.weight), c2 * 16, 16, 4, 1), B, c2, c1, 4 * H3, 4 * W3,
                            want_stats=True, mask=Op(cx.d0))
     ops.sum_slabs(st, G(L.dec0.bias))
-    ops.wgrad(Op(zq), Op(g0), G(L.dec0.weight), B, nh, c1, H3, W3, 4)
+    ops.wgrad(Op(zq), Op(g0), G(L.dec0.weight), B, nh, c1, H3, W3, 4, pending=pending)
+    ops.reduce_slabs_multi(pending)                  # all decoder weight gradients in one launch
     if not want_gz:
         return None
     g_zq, _ = ops.conv4x4s2(Op(g0), weight_view(_w(L.dec0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H3, 2 * W3)

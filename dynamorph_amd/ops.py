@@ -78,7 +78,7 @@ def vq_forward(z, codebook, want_idx=True, want_out=True):
     idx = _new((B, H, W), z, torch.int64) if want_idx else None
     out = torch.empty_like(z) if want_out else None
     slabs = _new((nb,), z, torch.float64)
-    hist = torch.zeros(K, device=z.device, dtype=torch.int32)
+    hist = _new((K,), z, torch.int32)          # cleared by dm_vq_forward itself
     wsb = lib.dm_vq_workspace_bytes(K, D)
     ws = _new((wsb // 4,), z)
     L.check(lib.dm_vq_forward(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out), _ptr(slabs, torch.float64),
@@ -154,16 +154,48 @@ def conv3x3(inp, wv, B, CIN, NOUT, H, W, taps=9, pixel_shuffle=False, out=None, 
     return out, stats
 
 
-def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k):
-    """dst (CS*CT*k*k floats, any shape) <- sum over batch/positions; deterministic slab reduction."""
+def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
+    """dst (CS*CT*k*k floats, any shape) <- sum over batch/positions; deterministic slab reduction.
+    pending: a list -> the slabs are left unreduced and (slabs, dst) is appended for reduce_slabs_multi."""
     lib = L.load()
     nb = lib.dm_wgrad_num_blocks(B, CS, CT, Hs, Ws, k)
     if nb <= 0:
         raise ValueError(f"dm_wgrad: shape {(B, CS, CT, Hs, Ws, k)} not tileable")
-    slabs = _new((nb, CS * CT * k * k), dst)
+    slabs = _new((nb, CS * CT * k * k), S.p0)
     s, t = S.struct(), T.struct()
-    L.check(lib.dm_wgrad(C.byref(s), C.byref(t), _ptr(slabs), _ptr(dst), B, CS, CT, Hs, Ws, k, _stream()), "dm_wgrad")
+    L.check(lib.dm_wgrad(C.byref(s), C.byref(t), _ptr(slabs), None if pending is not None else _ptr(dst), B, CS, CT, Hs,
+                         Ws, k, _stream()), "dm_wgrad")
+    if pending is not None:
+        pending.append((slabs, dst))
     return dst
+
+
+def reduce_slabs_multi(pending):
+    """One launch for every (slabs, dst) pair collected by wgrad(..., pending=...)."""
+    lib = L.load()
+    while pending:
+        chunk, pending[:] = pending[:16], pending[16:]
+        segs = (L.ReduceSeg * len(chunk))()
+        for i, (slabs, dst) in enumerate(chunk):
+            segs[i] = L.ReduceSeg(_ptr(slabs), _ptr(dst), slabs.shape[0], slabs.shape[1])
+        L.check(lib.dm_reduce_slabs_multi(segs, len(chunk), _stream()), "dm_reduce_slabs_multi")
+
+
+def sum_slabs_scatter(stats, dsts, scale=1.0):
+    """stats (nslabs, N, 2) float64 -> consecutive runs of the N sums written straight into the tensors `dsts`."""
+    lib = L.load()
+    N = stats.shape[1]
+    sc = L.Scatter()
+    sc.nseg = len(dsts)
+    end = 0
+    for k, d in enumerate(dsts):
+        end += d.numel()
+        sc.end[k] = end
+        sc.dst[k] = _ptr(d)
+    if end != N:
+        raise ValueError(f"dm_sum_slabs_scatter: destinations cover {end} of {N} entries")
+    L.check(lib.dm_sum_slabs_scatter(_ptr(stats, torch.float64), stats.shape[0], N, scale, C.byref(sc), _stream()),
+            "dm_sum_slabs_scatter")
 
 
 # ------------------------------------------------------------------------ BatchNorm

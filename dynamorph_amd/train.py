@@ -78,7 +78,8 @@ class FusedTrainer:
         gcb = self.G(L.codebook.weight)
         gcb.zero_()
         dz, _ = ops.vq_backward(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc, dw=gcb)
-        E.encoder_backward(L, ecx, dz, self.G)
+        # the flat gradient buffer starts at zero and nothing ever writes the BatchNorm-fed conv biases' slots
+        E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False)
         return scalars
 
     def _allreduce(self):

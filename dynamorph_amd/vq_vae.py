@@ -82,7 +82,9 @@ class _ResidualFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         G = _GradBag()
-        g_in, _ = E.residual_backward(ctx.res_layers, ctx.saved, g.contiguous(), G, None)
+        pending = []
+        g_in, _ = E.residual_backward(ctx.res_layers, ctx.saved, g.contiguous(), G, None, pending=pending)
+        ops.reduce_slabs_multi(pending)
         ctx.saved = None
         return (g_in, None) + G.grads_for(ctx.params, ctx.needs_input_grad[2:])
 

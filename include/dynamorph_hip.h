@@ -96,7 +96,7 @@ size_t dm_vq_workspace_bytes(int K, int D);
  *   z (B,D,H,W); codebook (K,D); idx (B,H,W) int64 [may be NULL];
  *   out (B,D,H,W) = z + (q - z) [may be NULL];
  *   sse_slabs: one double per workgroup (dm_vq_num_blocks of them);
- *   hist: K int32 counters, must be zeroed by the caller.
+ *   hist: K int32 counters (zeroed by the call).
  * Distances are summed in the reference's order (blocks of 16 along D,
  * sequential, no FMA) so indices are bit-identical to the CPU path. */
 int dm_vq_num_blocks(int64_t positions);
@@ -152,7 +152,7 @@ int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int 
  * aten::convolution_backward(weight). */
 int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k);
 int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, float *dst,
-             int B, int CS, int CT, int Hs, int Ws, int k, void *stream);
+             int B, int CS, int CT, int Hs, int Ws, int k, void *stream);   /* dst = NULL: leave the slabs unreduced */
 
 /* ===== BatchNorm2d in training mode (vq_vae.py:206,209,279-288) =============== */
 
@@ -183,6 +183,14 @@ int dm_channel_stats(const float *p, const float *q, double *stats, int B, int C
 
 /* dst[n] = scale * sum_over_slabs stats[slab][n][0]   (bias gradients from epilogue stats). */
 int dm_sum_slabs(const double *stats, int nslabs, int N, float scale, float *dst, void *stream);
+/* Same sums scattered to up to 8 destinations: entries [end[k-1], end[k]) go to dst[k] (one launch instead of a
+ * sum plus one copy per parameter). */
+typedef struct dm_scatter {
+    int32_t nseg;
+    int32_t end[8];
+    float *dst[8];
+} dm_scatter;
+int dm_sum_slabs_scatter(const double *stats, int nslabs, int N, float scale, const dm_scatter *sc, void *stream);
 
 /* ===== decoder head + reconstruction loss (vq_vae.py:298, 320-323) ============ */
 
@@ -225,6 +233,14 @@ int dm_dec_tail_backward(const float *d2, const float *w4, const float *b4, cons
                          float *w_slabs, int B, int C2, int NIN, int H2, int W2, void *stream);
 /* dst[e] = sum over slabs of slabs[slab][e], fixed order (bitwise reproducible). */
 int dm_reduce_slabs(const float *slabs, int nslabs, int E, float *dst, void *stream);
+/* The same for up to 16 (slabs, dst) pairs in ONE launch: the weight gradients of a whole backward pass. */
+typedef struct dm_reduce_seg {
+    const float *slabs;
+    float *dst;
+    int32_t nslabs;
+    int32_t E;
+} dm_reduce_seg;
+int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *stream);
 
 /* scalars_out = (recon, commitment, total, perplexity) from the loss slabs and
  * the dm_vq_finalize scalars: recon = sum/N, total = w_recon*recon + w_commit*commitment. */
