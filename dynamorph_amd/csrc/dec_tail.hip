@@ -6,11 +6,11 @@
 //
 // Unfused, d4 = relu(dec.4(d2)) and its gradient g4 are 262 144 B/patch each and are touched by five
 // kernels (29 % of the training step).  Here:
-//   forward   d2 -> [MFMA: dec.4 as a 3x3-neighbourhood conv, N = 4 phases x 4 channels] -> ReLU ->
-//             [shuffle-reduce over the 4 channel lanes: dec.6] -> decoded + loss partials.  d4 is never stored.
-//   backward  d2 -> recompute d4 the same way -> g_dec from (decoded, x) -> g4 = (W6^T g_dec)*(d4>0) written to an
-//             LDS tile (with the halo rows the strided conv needs) -> from LDS: data gradient of dec.4
-//             (4x4/s2 conv, masked by d2>0) and weight gradient of dec.4; dW6/db6/db4/db2 partial sums on the way.
+//   forward   d2 -> dec.4 + ReLU into an LDS tile (VALU: one wave per channel, one lane per column) -> dec.6 + loss
+//             partials from that tile.  d4 is never stored.
+//   backward  d2 -> recompute d4 the same way -> g_dec from (decoded, x) -> g4 = (W6^T g_dec)*(d4>0) in place in the
+//             LDS tile (with the halo rows the strided conv needs) -> from LDS: data gradient of dec.4 (VALU, masked
+//             by d2>0) and weight gradient of dec.4 (MFMA); dW6/db6/db4/db2 partial sums on the way.
 //             g4 never exists in HBM.
 // Algorithmic bytes/patch: forward 65 536 (d2) + 131 072 (x) + 131 072 (decoded) = 327 680;
 // backward 65 536 + 131 072 + 131 072 + 65 536 (g2) = 393 216  (unfused: 851 968 and 1 507 328).
@@ -25,40 +25,55 @@ namespace {
 
 constexpr int TT_C = 4;        // channels of d2 / d4
 constexpr int TT_TH = 8;       // d2 rows per tile
-constexpr int TT_W = 64;       // d2 width (one tile spans the full row)
-constexpr int TT_RS = TT_W + 8;             // d2 LDS row: col j <-> x = j - 4
-constexpr int TT_MAX_GRID = 512;            // 2 workgroups per CU (LDS-limited)
+constexpr int TT_W = 64;       // d2 width (one tile spans the full row = one lane per column)
+constexpr int TT_MAX_GRID = 768;            // 3 workgroups per CU (LDS-limited)
+constexpr int TT_DRS = 2 * TT_W + 8;        // d4 / g4 LDS row: col j <-> ox = j - 4 (zero pad columns for the MFMA weight gradient)
 
-// dec.4 weights for the pixel-shuffle formulation: lane n = co*4 + py*2 + px, K lane kq = input channel,
-// K step = tap (ty,tx) of the 3x3 neighbourhood; kernel element ky = py+3-2ty, kx = px+3-2tx when in 0..3.
-__device__ __forceinline__ void load_convT_weights(float (&wreg)[1][9], const float *__restrict__ w4, int m, int kq)
+// Thin layers (4 channels) waste 75 % of an MFMA tile, so dec.4 forward/recompute and its data gradient run on the
+// VALU: one wave per output channel (its 64 weights are wave-uniform), one lane per column; the left/right
+// neighbours of a column come from the adjacent lanes with wave-shift DPP moves, whose out-of-range reads return 0
+// = the zero padding at the image border (the tile spans the whole row).
+// The wave index, hidden from the compiler's uniformity analysis: weights indexed with it are then loaded with
+// vector loads into VGPRs.  Left uniform, hipcc keeps the 64-128 weights in SGPRs, runs out and spills them
+// through v_writelane / v_readlane (650 such moves in the first build of the backward kernel).
+__device__ __forceinline__ int wave_index_vgpr()
 {
-    const int co = m >> 2, py = (m >> 1) & 1, px = m & 1;
+    int w;
+    asm volatile("v_lshrrev_b32 %0, 6, %1" : "=v"(w) : "v"(threadIdx.x));
+    return w;
+}
+
+__device__ __forceinline__ float lane_from_left(float v)    // value of lane - 1, 0 for lane 0
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_from_right(float v)   // value of lane + 1, 0 for lane 63
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+// ConvTranspose2d(4,4,4,2,1) of one input row for ONE output channel: the 2x2 output pixels (2y+py, 2x+px) of every
+// column x.  sA rows rr-1, rr, rr+1 hold d2 rows y-1, y, y+1; w[ci*16 + ky*4 + kx] = W4[ci][co][ky][kx].
+// Phase (py,px) uses rows d = py-1..py and columns e = px-1..px with ky = py+1-2d, kx = px+1-2e.
+__device__ __forceinline__ void convT_row(const float *__restrict__ sA, int APS, int rr, int lane,
+                                          const float (&w)[64], float bias, float (&o)[2][2])
+{
+    o[0][0] = bias; o[0][1] = bias; o[1][0] = bias; o[1][1] = bias;
 #pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        const int ty = s / 3, tx = s % 3;
-        const int ky = py + 3 - 2 * ty, kx = px + 3 - 2 * tx;
-        float v = 0.f;
-        if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) v = w4[(kq * TT_C + co) * 16 + ky * 4 + kx];
-        wreg[0][s] = v;
+    for (int ci = 0; ci < TT_C; ++ci) {
+        float c[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const float v = sA[ci * APS + (rr - 1 + dy) * TT_W + lane];
+            c[dy][1] = v; c[dy][0] = lane_from_left(v); c[dy][2] = lane_from_right(v);
+        }
+        const float *wc = &w[ci * 16];
+        o[0][0] += c[0][0] * wc[3 * 4 + 3] + c[0][1] * wc[3 * 4 + 1] + c[1][0] * wc[1 * 4 + 3] + c[1][1] * wc[1 * 4 + 1];
+        o[0][1] += c[0][1] * wc[3 * 4 + 2] + c[0][2] * wc[3 * 4 + 0] + c[1][1] * wc[1 * 4 + 2] + c[1][2] * wc[1 * 4 + 0];
+        o[1][0] += c[1][0] * wc[2 * 4 + 3] + c[1][1] * wc[2 * 4 + 1] + c[2][0] * wc[0 * 4 + 3] + c[2][1] * wc[0 * 4 + 1];
+        o[1][1] += c[1][1] * wc[2 * 4 + 2] + c[1][2] * wc[2 * 4 + 0] + c[2][1] * wc[0 * 4 + 2] + c[2][2] * wc[0 * 4 + 0];
     }
 }
-
-// swap halves with the x-phase partner lane (n ^ 1): afterwards the lane holds 4 CONSECUTIVE output columns
-// starting at 2*(x of its first element) + 4*px, of output row 2y+py, channel co
-__device__ __forceinline__ f32x4 pixel_interleave(f32x4 v, int px)
-{
-    const f32x4 pv = lane_xor1(v);
-    return px ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
-}
-
-__device__ __forceinline__ f32x4 relu4(f32x4 v)
-{
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    return v;
-}
-
-__device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
 
 // =================================================================================== forward
 template <int NIN>
@@ -68,97 +83,97 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
                              const float *__restrict__ mask, int MC, const float *__restrict__ cvar,
                              float *__restrict__ dec, double *__restrict__ loss_slabs, int H2, int ntiles)
 {
-    constexpr int ROWS = TT_TH + 2, PS = ROWS * TT_RS;           // 720 == 16 (mod 32)
-    static_assert(PS % 32 == 16, "conflict-free plane stride");
-    __shared__ __attribute__((aligned(16))) float tile[TT_C * PS];
+    constexpr int AROWS = TT_TH + 2, APS = AROWS * TT_W + 4;     // d2 rows y0-1 .. y0+TH
+    constexpr int DROWS = 2 * TT_TH, DPS = DROWS * TT_DRS;       // d4 rows 2*y0 .. 2*y0+2*TH-1
+    __shared__ __attribute__((aligned(16))) float sA[TT_C * APS];
+    __shared__ __attribute__((aligned(16))) float sD[TT_C * DPS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
     __shared__ double s_red[4];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
-    const int co = m >> 2, py = (m >> 1) & 1, px = m & 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // = output channel in phase A
     const int tiles_y = H2 / TT_TH, OH = 2 * H2, OW = 2 * TT_W;
     Operand in;
     in.p0 = d2; in.p1 = nullptr; in.coef = nullptr; in.coef_bstride = 0; in.mode = DM_LOAD_IDENT; in.ones = 0;
 
-    TileStage<TT_C, ROWS, TT_RS / 4, TT_RS, PS, false> stage;
+    TileStage<TT_C, AROWS, TT_W / 4, TT_W, APS, false> stage;
     stage.init();
     int tidx = blockIdx.x, b = 0, y0 = 0;
     if (tidx < ntiles) {
         y0 = (tidx % tiles_y) * TT_TH; b = tidx / tiles_y;
-        stage.issue(in, b, TT_C, H2, TT_W, y0 - 1, -4);
+        stage.issue(in, b, TT_C, H2, TT_W, y0 - 1, 0);
     }
     if (threadIdx.x < TT_C) *reinterpret_cast<f32x4 *>(s_coef + threadIdx.x * 4) = (f32x4){1.f, 0.f, 0.f, -__builtin_inff()};
 
-    float wreg[1][9];
-    load_convT_weights(wreg, w4, m, kq);
-    const float bias4 = b4[co];
-    float w6c[NIN], b6c[NIN];
-    float ivar = 1.f / cvar[0];                     // 1/channel_var of the channel this lane stores (c == co)
+    const int wv = wave_index_vgpr();
+    float wA[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) wA[i] = w4[((i >> 4) * TT_C + wv) * 16 + (i & 15)];
+    const float bias4 = b4[wv];
+    float w6r[NIN][TT_C], b6r[NIN], ivar[NIN];
 #pragma unroll
     for (int c = 0; c < NIN; ++c) {
-        w6c[c] = w6[c * TT_C + co]; b6c[c] = b6 ? b6[c] : 0.f;
-        if (co == c) ivar = 1.f / cvar[c];
+        b6r[c] = b6 ? b6[c] : 0.f; ivar[c] = 1.f / cvar[c];
+#pragma unroll
+        for (int co = 0; co < TT_C; ++co) w6r[c][co] = w6[c * TT_C + co];
     }
-
-    const int abase = kq * PS + m + 3;
-    auto off = [](int s) { return (s / 3) * TT_RS + s % 3; };
     double loss = 0.0;
 
     while (tidx < ntiles) {
-        __syncthreads();
-        stage.commit(tile, s_coef, TT_C, H2, TT_W, y0 - 1, -4);
+        __syncthreads();                                   // previous tile done with sA / sD
+        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 1, 0);
         __syncthreads();
         const int cb = b, cy0 = y0;
         const int next = tidx + gridDim.x;
         if (next < ntiles) {
             y0 = (next % tiles_y) * TT_TH; b = next / tiles_y;
-            stage.issue(in, b, TT_C, H2, TT_W, y0 - 1, -4);
+            stage.issue(in, b, TT_C, H2, TT_W, y0 - 1, 0);
         }
-        float tl = 0.f;                                               // this tile's loss partial (fp32)
-        for (int p = 0; p < (TT_TH * 4 / 4) / 2; ++p) {              // 32 M tiles, 8 per wave, 2 in flight
-            const float *ap[2];
-            int r[2], cg[2];
+        // x / mask rows this wave needs in phase B: requested now, they land while phase A computes
+        f32x2 xr[DROWS / 4][NIN];       // (the optional batch_mask is read in phase B: rare path, no registers kept for it)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ti = wave + 4 * (2 * p + i);
-                r[i] = ti >> 2; cg[i] = ti & 3;
-                ap[i] = tile + r[i] * TT_RS + 16 * cg[i] + abase;
+        for (int j = 0; j < DROWS / 4; ++j) {
+            const int oy = 2 * cy0 + wave + 4 * j;
+#pragma unroll
+            for (int c = 0; c < NIN; ++c) {
+                xr[j][c] = (f32x2){0.f, 0.f};
+                if (x) xr[j][c] = *reinterpret_cast<const f32x2 *>(x + ((cb * NIN + c) * OH + oy) * OW + 2 * lane);
             }
-            // x / mask rows of the outputs this lane will own (channel c == co): in flight during the MFMAs
-            f32x4 xv[2], mv[2];
-            int oo[2];
+        }
+        // ---- phase A: d4[co = wave] = relu(dec.4(d2)) for the 16 output rows of this tile -> LDS ---------------
+#pragma unroll 2
+        for (int r = 0; r < TT_TH; ++r) {
+            float o[2][2];
+            convT_row(sA, APS, r + 1, lane, wA, bias4, o);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int oy = 2 * (cy0 + r[i]) + py, ox = 2 * (16 * cg[i] + 4 * kq) + 4 * px;
-                oo[i] = ((cb * NIN + co) * OH + oy) * OW + ox;
-                xv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                mv[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
-                if (co < NIN && x) {
-                    xv[i] = *reinterpret_cast<const f32x4 *>(x + oo[i]);
-                    if (mask) mv[i] = *reinterpret_cast<const f32x4 *>(mask + ((cb * MC + (MC == 1 ? 0 : co)) * OH + oy) * OW + ox);
-                }
-            }
-            f32x4 acc[2][1];
-            acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mfma_tiles<2, 1, 9, 3>(ap, wreg, acc, off);
+            for (int py = 0; py < 2; ++py)
+                *reinterpret_cast<f32x2 *>(sD + wave * DPS + (2 * r + py) * TT_DRS + 2 * lane + 4) =
+                    (f32x2){fmaxf(o[py][0], 0.f), fmaxf(o[py][1], 0.f)};
+        }
+        __syncthreads();
+        // ---- phase B: dec.6 (1x1) + loss; one wave per output row, one lane per column pair --------------------
+        float tl = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const f32x4 d4 = pixel_interleave(relu4(acc[i][0] + bias4), px);
-                // dec.6: sum over the 4 channel lanes (n differs in bits 2,3) of W6[c][co]*d4
-                f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < DROWS / 4; ++j) {
+            const int R = wave + 4 * j;
+            const int oy = 2 * cy0 + R;
+            f32x2 dv[TT_C];
 #pragma unroll
-                for (int c = 0; c < NIN; ++c) {
-                    f32x4 pc = w6c[c] * d4;
-                    pc += lane_xor4(pc);
-                    pc += lane_xor8(pc);
-                    if (co == c) mine = pc + b6c[c];
-                }
-                if (co < NIN) {
-                    *reinterpret_cast<f32x4 *>(dec + oo[i]) = mine;
-                    if (x) {
-                        const f32x4 t = mask ? mine * mv[i] - xv[i] * mv[i] : mine - xv[i];
-                        tl += hsum4(t * t) * ivar;
+            for (int co = 0; co < TT_C; ++co) dv[co] = *reinterpret_cast<const f32x2 *>(sD + co * DPS + R * TT_DRS + 2 * lane + 4);
+#pragma unroll
+            for (int c = 0; c < NIN; ++c) {
+                f32x2 o = {b6r[c], b6r[c]};
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co) o += w6r[c][co] * dv[co];
+                const int off = ((cb * NIN + c) * OH + oy) * OW + 2 * lane;
+                *reinterpret_cast<f32x2 *>(dec + off) = o;
+                if (x) {
+                    f32x2 t = o - xr[j][c];
+                    if (mask) {
+                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
+                        t = o * mv - xr[j][c] * mv;
                     }
+                    tl += (t.x * t.x + t.y * t.y) * ivar[c];
                 }
             }
         }
@@ -176,170 +191,193 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                               const float *__restrict__ w6, const float *__restrict__ decp, const float *__restrict__ x,
                               const float *__restrict__ mask, int MC, const float *__restrict__ cvar,
                               const float *__restrict__ gscale_dev, float *__restrict__ g2, double *__restrict__ part,
-                              float *__restrict__ wslabs, int H2, int ntiles, double inv_count)
+                              float *__restrict__ wslabs, int H2, int ntiles, double inv_count, int nslabs)
 {
-    constexpr int AROWS = TT_TH + 4, APS_RAW = AROWS * TT_RS, APS = APS_RAW + ((16 - (APS_RAW % 32)) + 32) % 32;
-    constexpr int GROWS = 2 * TT_TH + 2, GRS = 2 * TT_W + 8, GPS = GROWS * GRS;       // g4 tile: col j <-> ox = j - 4
-    constexpr int NP = NIN * TT_C + NIN + TT_C + TT_C;      // dW6 | db6 | db4 | db2
-    constexpr int NV = 2 * NIN + 1;                         // per-lane partials in phase 2
-    static_assert(APS % 32 == 16, "conflict-free plane stride");
+    constexpr int AROWS = TT_TH + 4, APS = AROWS * TT_W + 4;     // d2 rows y0-2 .. y0+TH+1
+    constexpr int GROWS = 2 * TT_TH + 2, GPS = GROWS * TT_DRS;   // g4 rows 2*y0-1 .. 2*y0+2*TH ; col j <-> ox = j - 4
+    constexpr int NP = NIN * TT_C + NIN + TT_C + TT_C;           // dW6 | db6 | db4 | db2
+    constexpr int NV = NIN * TT_C + NIN + TT_C;                  // per-lane partials of phase B
     __shared__ __attribute__((aligned(16))) float sA[TT_C * APS];
     __shared__ __attribute__((aligned(16))) float sG[TT_C * GPS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
-    __shared__ double s_part[4][TT_C][NV + 1];
+    __shared__ __attribute__((aligned(16))) float s_w4[TT_C * TT_C * 16];   // dec.4 weights, re-read per phase (broadcast)
+    __shared__ double s_part[4][NP];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
-    const int co = m >> 2, py = (m >> 1) & 1, px = m & 1;
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles_y = H2 / TT_TH, OH = 2 * H2, OW = 2 * TT_W;
     Operand in;
     in.p0 = d2; in.p1 = nullptr; in.coef = nullptr; in.coef_bstride = 0; in.mode = DM_LOAD_IDENT; in.ones = 0;
 
-    TileStage<TT_C, AROWS, TT_RS / 4, TT_RS, APS, false> stage;
+    TileStage<TT_C, AROWS, TT_W / 4, TT_W, APS, false> stage;
     stage.init();
     int tidx = blockIdx.x, b = 0, y0 = 0;
     if (tidx < ntiles) {
         y0 = (tidx % tiles_y) * TT_TH; b = tidx / tiles_y;
-        stage.issue(in, b, TT_C, H2, TT_W, y0 - 2, -4);
+        stage.issue(in, b, TT_C, H2, TT_W, y0 - 2, 0);
     }
     if (threadIdx.x < TT_C) *reinterpret_cast<f32x4 *>(s_coef + threadIdx.x * 4) = (f32x4){1.f, 0.f, 0.f, -__builtin_inff()};
     // the padding columns of the g4 tile (ox = -4..-1 and 128..131) are zero for every tile
     for (int i = threadIdx.x; i < TT_C * GROWS * 2; i += DM_BLOCK) {
         const int row = i >> 1, side = i & 1;
-        *reinterpret_cast<f32x4 *>(sG + row * GRS + (side ? GRS - 4 : 0)) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(sG + row * TT_DRS + (side ? TT_DRS - 4 : 0)) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    float wT[1][9];                                  // dec.4 forward (recompute), pixel-shuffle form
-    load_convT_weights(wT, w4, m, kq);
-    float wD[1][16];                                 // dec.4 data gradient: 4x4/s2 conv over g4, W[n=ci][c=co][ky][kx=kq]
-#pragma unroll
-    for (int s = 0; s < 16; ++s) wD[0][s] = m < TT_C ? w4[(m * TT_C + (s >> 2)) * 16 + (s & 3) * 4 + kq] : 0.f;
-    const float bias4 = b4[co];
+    // wave-uniform weights: phase A (recompute, co = wave): W4[ci][wave][ky][kx]; phase 3 (data gradient, ci = wave):
+    // W4[wave][co][ky][kx] (64 contiguous floats)
+    const int wv = wave_index_vgpr();
+    s_w4[threadIdx.x] = w4[threadIdx.x];             // 256 threads, 256 weights
+    const float bias4 = b4[wv];
     const float gs = (float)(2.0 * inv_count) * gscale_dev[0];
-    float w6c[NIN], gsv[NIN];
+    float w6r[NIN][TT_C], gsv[NIN];
 #pragma unroll
-    for (int c = 0; c < NIN; ++c) { w6c[c] = w6[c * TT_C + co]; gsv[c] = gs / cvar[c]; }
+    for (int c = 0; c < NIN; ++c) {
+        gsv[c] = gs / cvar[c];
+#pragma unroll
+        for (int co = 0; co < TT_C; ++co) w6r[c][co] = w6[c * TT_C + co];
+    }
 
-    // weight-gradient operands: S = d2 (rows of A), T = g4 tile; lane column n = 16*t + m <-> (ct = t, ky = m>>2, kx = m&3)
+    // weight-gradient (MFMA) operands: S = d2 (rows of sA), T = g4 tile; lane column n = 16*t + m <-> (ct = t, ky = m>>2, kx = m&3)
     int boff[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) boff[t] = t * GPS + (m >> 2) * GRS + (m & 3) + 3 + 2 * kq;
-    const int aoffw = (m < TT_C ? m : TT_C - 1) * APS + kq + 4;
+    for (int t = 0; t < 4; ++t) boff[t] = t * GPS + (m >> 2) * TT_DRS + (m & 3) + 3 + 2 * kq;
+    const int aoffw = (m < TT_C ? m : TT_C - 1) * APS + kq;
     f32x4 wacc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    double pv[NV], pb2 = 0.0;                         // dW6[c][co], sum g_dec[c], db4[co] ; db2[m]
+    // per-lane partial sums over this workgroup's tiles (a few hundred fp32 terms each; the cross-lane / cross-
+    // workgroup reductions are done in double): dW6[c][co] | db6[c] | db4[co] ; db2[ci = wave]
+    float pv[NV], pb2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) pv[k] = 0.0;
-
-    const int abaseT = kq * APS + m + 3;
-    auto offT = [](int s) { return (s / 3) * TT_RS + s % 3; };
-    const int abaseD = 2 * m + kq + 3;
-    auto offD = [](int s) { return (s >> 2) * GPS + (s & 3) * GRS; };
+    for (int k = 0; k < NV; ++k) pv[k] = 0.f;
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA and sG
-        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 2, -4);
+        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 2, 0);
         __syncthreads();
         const int cb = b, cy0 = y0;
         const int next = tidx + gridDim.x;
         if (next < ntiles) {
             y0 = (next % tiles_y) * TT_TH; b = next / tiles_y;
-            stage.issue(in, b, TT_C, H2, TT_W, y0 - 2, -4);
+            stage.issue(in, b, TT_C, H2, TT_W, y0 - 2, 0);
         }
 
-        // ---- phase 2: recompute d4 on position rows y0-1 .. y0+TH, build g4 in LDS ------------------------
-        float tv[NV], tb2 = 0.f;                                      // this tile's partial sums (fp32)
+        // g_dec of the g4 rows this wave handles in phase B: its decoded / x / mask loads are issued now and land
+        // while phase A computes
+        constexpr int BR = (GROWS + 3) / 4;
+        f32x2 gd[BR][NIN];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) tv[k] = 0.f;
-        for (int p = 0; p < ((TT_TH + 2) * 4 / 4) / 2; ++p) {         // 40 M tiles, 10 per wave, 2 in flight
-            const float *ap[2];
-            int pr[2], cg[2], oy[2], ox[2];
-            bool live[2];
-            f32x4 dv[2][NIN], xv[2][NIN], mv[2][NIN];
+        for (int j = 0; j < BR; ++j) {
+            const int gr = wave + 4 * j, oy = 2 * cy0 - 1 + gr;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ti = wave + 4 * (2 * p + i);
-                pr[i] = ti >> 2; cg[i] = ti & 3;
-                ap[i] = sA + pr[i] * TT_RS + 16 * cg[i] + abaseT;     // LDS rows pr..pr+2 <-> d2 rows y-1..y+1
-                oy[i] = 2 * (cy0 - 1 + pr[i]) + py;
-                ox[i] = 2 * (16 * cg[i] + 4 * kq) + 4 * px;
-                const int gr = 2 * pr[i] + py - 1;
-                live[i] = gr >= 0 && gr < GROWS && oy[i] >= 0 && oy[i] < OH;
-#pragma unroll
-                for (int c = 0; c < NIN; ++c) {
-                    dv[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; xv[i][c] = dv[i][c];
-                    mv[i][c] = (f32x4){1.f, 1.f, 1.f, 1.f};
-                    if (live[i]) {
-                        const int o = ((cb * NIN + c) * OH + oy[i]) * OW + ox[i];
-                        dv[i][c] = *reinterpret_cast<const f32x4 *>(decp + o);
-                        xv[i][c] = *reinterpret_cast<const f32x4 *>(x + o);
-                        if (mask) mv[i][c] = *reinterpret_cast<const f32x4 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy[i]) * OW + ox[i]);
+            for (int c = 0; c < NIN; ++c) {
+                gd[j][c] = (f32x2){0.f, 0.f};
+                if (gr < GROWS && oy >= 0 && oy < OH) {
+                    const int off = ((cb * NIN + c) * OH + oy) * OW + 2 * lane;
+                    const f32x2 dv = *reinterpret_cast<const f32x2 *>(decp + off);
+                    const f32x2 xv = *reinterpret_cast<const f32x2 *>(x + off);
+                    f32x2 t = dv - xv;
+                    if (mask) {
+                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
+                        t = (dv * mv - xv * mv) * mv;
                     }
+                    gd[j][c] = t * gsv[c];
                 }
             }
-            f32x4 acc[2][1];
-            acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mfma_tiles<2, 1, 9, 3>(ap, wT, acc, offT);
+        }
+        // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
+        {
+        float wA[64];                                 // W4[ci][co = wave][ky][kx], live in this phase only
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const f32x4 d4 = pixel_interleave(relu4(acc[i][0] + bias4), px);
-                const int gr = 2 * pr[i] + py - 1;
-                const bool owned = live[i] && gr >= 1 && gr <= 2 * TT_TH;      // rows 2*y0 .. 2*y0+2*TH-1
-                f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+        for (int ci = 0; ci < TT_C; ++ci)
 #pragma unroll
-                for (int c = 0; c < NIN; ++c) {
-                    f32x4 g = mask ? (dv[i][c] * mv[i][c] - xv[i][c] * mv[i][c]) * mv[i][c] : dv[i][c] - xv[i][c];
-                    g = g * gsv[c];
-                    g4 += w6c[c] * g;
-                    if (owned) {
-                        tv[c] += hsum4(g * d4);           // dW6[c][co]
-                        tv[NIN + c] += hsum4(g);          // db6[c] (taken from the co == 0 lanes)
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + (ci * TT_C + wv) * 16 + 4 * t4);
+                wA[ci * 16 + 4 * t4 + 0] = q.x; wA[ci * 16 + 4 * t4 + 1] = q.y;
+                wA[ci * 16 + 4 * t4 + 2] = q.z; wA[ci * 16 + 4 * t4 + 3] = q.w;
+            }
+#pragma unroll 2
+        for (int pr = 0; pr < TT_TH + 2; ++pr) {
+            float o[2][2];
+            convT_row(sA, APS, pr + 1, lane, wA, bias4, o);      // sA row pr+1 <-> d2 row y0-1+pr
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int gr = 2 * pr + py - 1;
+                if (gr >= 0 && gr < GROWS)
+                    *reinterpret_cast<f32x2 *>(sG + wave * GPS + gr * TT_DRS + 2 * lane + 4) =
+                        (f32x2){fmaxf(o[py][0], 0.f), fmaxf(o[py][1], 0.f)};
+            }
+        }
+        }
+        __syncthreads();
+
+        // ---- phase B: g4 = (W6^T g_dec) * (d4 > 0) in place; dW6 / db6 / db4 partial sums ---------------------------
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int gr = wave + 4 * j;
+            if (gr < GROWS) {
+                const int oy = 2 * cy0 - 1 + gr;
+                const bool live = oy >= 0 && oy < OH;
+                const bool owned = gr >= 1 && gr <= 2 * TT_TH;       // rows 2*y0 .. 2*y0+2*TH-1 belong to this tile
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co) {
+                    float *pd = sG + co * GPS + gr * TT_DRS + 2 * lane + 4;
+                    const f32x2 d4 = *reinterpret_cast<const f32x2 *>(pd);
+                    f32x2 g4 = {0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < NIN; ++c) {
+                        g4 += w6r[c][co] * gd[j][c];
+                        if (owned) pv[c * TT_C + co] += gd[j][c].x * d4.x + gd[j][c].y * d4.y;
                     }
+                    g4.x = d4.x > 0.f ? g4.x : 0.f;
+                    g4.y = d4.y > 0.f ? g4.y : 0.f;
+                    if (!live) g4 = (f32x2){0.f, 0.f};               // rows outside the image are zero padding
+                    if (owned) pv[NIN * TT_C + NIN + co] += g4.x + g4.y;
+                    *reinterpret_cast<f32x2 *>(pd) = g4;
                 }
-                g4.x = d4.x > 0.f ? g4.x : 0.f; g4.y = d4.y > 0.f ? g4.y : 0.f;
-                g4.z = d4.z > 0.f ? g4.z : 0.f; g4.w = d4.w > 0.f ? g4.w : 0.f;
-                if (!live[i]) g4 = (f32x4){0.f, 0.f, 0.f, 0.f};               // rows outside the image: zero padding
-                if (owned) tv[2 * NIN] += hsum4(g4);                           // db4[co]
-                if (gr >= 0 && gr < GROWS) *reinterpret_cast<f32x4 *>(sG + co * GPS + gr * GRS + ox[i] + 4) = g4;
+                if (owned) {
+#pragma unroll
+                    for (int c = 0; c < NIN; ++c) pv[NIN * TT_C + c] += gd[j][c].x + gd[j][c].y;
+                }
             }
         }
         __syncthreads();
 
-        // ---- phase 3: data gradient of dec.4 = 4x4/s2 conv over the g4 tile, masked by d2 > 0 -------------
-        for (int p = 0; p < (TT_TH * 4 / 4) / 2; ++p) {               // 32 M tiles, 8 per wave
-            const float *ap[2];
-            int r[2], cg[2];
+        // ---- phase 3: data gradient of dec.4 for input channel ci = wave:  g2[ci][y][x] = sum_co,ky,kx
+        //      g4[co][2y-1+ky][2x-1+kx] * W4[ci][co][ky][kx], masked by d2 > 0 ------------------------------------------
+        {
+        float wD[64];                                 // W4[ci = wave][co][ky][kx], live in this phase only
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ti = wave + 4 * (2 * p + i);
-                r[i] = ti >> 2; cg[i] = ti & 3;
-                ap[i] = sG + (2 * r[i]) * GRS + 32 * cg[i] + abaseD;
-            }
-            f32x4 acc[2][1];
-            acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mfma_tiles<2, 1, 16, 4>(ap, wD, acc, offD);
-            if (m < TT_C) {
+        for (int t4 = 0; t4 < 16; ++t4) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + wv * 64 + 4 * t4);
+            wD[4 * t4 + 0] = q.x; wD[4 * t4 + 1] = q.y; wD[4 * t4 + 2] = q.z; wD[4 * t4 + 3] = q.w;
+        }
+#pragma unroll 2
+        for (int r = 0; r < TT_TH; ++r) {
+            float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const f32x4 dd = *reinterpret_cast<const f32x4 *>(sA + m * APS + (r[i] + 2) * TT_RS + 16 * cg[i] + 4 * kq + 4);
-                    f32x4 v = acc[i][0];
-                    v.x = dd.x > 0.f ? v.x : 0.f; v.y = dd.y > 0.f ? v.y : 0.f;
-                    v.z = dd.z > 0.f ? v.z : 0.f; v.w = dd.w > 0.f ? v.w : 0.f;
-                    *reinterpret_cast<f32x4 *>(g2 + ((cb * TT_C + m) * H2 + cy0 + r[i]) * TT_W + 16 * cg[i] + 4 * kq) = v;
-                    tb2 += hsum4(v);
+            for (int co = 0; co < TT_C; ++co) {
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    const f32x2 mid = *reinterpret_cast<const f32x2 *>(sG + co * GPS + (2 * r + ky) * TT_DRS + 2 * lane + 4);
+                    const float left = lane_from_left(mid.y);       // column 2x-1
+                    const float right = lane_from_right(mid.x);     // column 2x+2
+                    const float *wc = &wD[co * 16 + ky * 4];
+                    acc += left * wc[0] + mid.x * wc[1] + mid.y * wc[2] + right * wc[3];
                 }
             }
+            const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
+            acc = dd > 0.f ? acc : 0.f;
+            g2[((cb * TT_C + wave) * H2 + cy0 + r) * TT_W + lane] = acc;
+            pb2 += acc;
+        }
         }
 
-#pragma unroll
-        for (int k = 0; k < NV; ++k) pv[k] += (double)tv[k];
-        pb2 += (double)tb2;
-
-        // ---- phase 4: weight gradient of dec.4: R[ci][co][ky][kx] += sum d2[ci,y,x] * g4[co,2y-1+ky,2x-1+kx] ---
+        // ---- phase 4 (MFMA): weight gradient of dec.4: R[ci][co][ky][kx] += sum d2[ci,y,x] * g4[co,2y-1+ky,2x-1+kx] ---
         for (int r = wave; r < TT_TH; r += 4) {
             float a[2], bv[2][4];
-            const int ra = (r + 2) * TT_RS, rb = 2 * r * GRS;
+            const int ra = (r + 2) * TT_W, rb = 2 * r * TT_DRS;
             a[0] = sA[aoffw + ra];
 #pragma unroll
             for (int t = 0; t < 4; ++t) bv[0][t] = sG[boff[t] + rb];
@@ -360,31 +398,25 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         tidx = next;
     }
 
-    // ---- partial sums: reduce over the lanes of a channel, then over the 4 waves ---------------------------
+    // ---- partial sums: every lane holds partials of all NV phase-B sums; db2 is per wave (ci = wave) ---------------
+    double pvd[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double v = pv[k];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        pv[k] = v;
-    }
-    pb2 += __shfl_xor(pb2, 16, 64); pb2 += __shfl_xor(pb2, 32, 64);
+    for (int k = 0; k < NV; ++k) pvd[k] = wave_sum((double)pv[k]);
+    const double pb2d = wave_sum((double)pb2);
     __syncthreads();
-    if (kq == 0 && (m & 3) == 0) {
+    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) s_part[wave][co][k] = pv[k];
+        for (int k = 0; k < NV; ++k) s_part[wave][k] = pvd[k];
     }
-    if (kq == 0 && m < TT_C) s_part[wave][m][NV] = pb2;
     __syncthreads();
-    for (int n = threadIdx.x; n < NP; n += DM_BLOCK) {
-        int ch, k;
-        if (n < NIN * TT_C) { ch = n % TT_C; k = n / TT_C; }                    // dW6[c][co]: k = c
-        else if (n < NIN * TT_C + NIN) { ch = 0; k = NIN + (n - NIN * TT_C); }   // db6[c] from the co == 0 lanes
-        else if (n < NIN * TT_C + NIN + TT_C) { ch = n - NIN * TT_C - NIN; k = 2 * NIN; }   // db4[co]
-        else { ch = n - NIN * TT_C - NIN - TT_C; k = NV; }                        // db2[ci]
-        const double s = s_part[0][ch][k] + s_part[1][ch][k] + s_part[2][ch][k] + s_part[3][ch][k];
-        part[((long long)blockIdx.x * NP + n) * 2 + 0] = s;
+    for (int n = threadIdx.x; n < NV; n += DM_BLOCK) {
+        const double sm = s_part[0][n] + s_part[1][n] + s_part[2][n] + s_part[3][n];
+        part[((long long)blockIdx.x * NP + n) * 2 + 0] = sm;
         part[((long long)blockIdx.x * NP + n) * 2 + 1] = 0.0;
+    }
+    if (lane == 0) {                                        // db2[ci = wave]
+        part[((long long)blockIdx.x * NP + NV + wave) * 2 + 0] = pb2d;
+        part[((long long)blockIdx.x * NP + NV + wave) * 2 + 1] = 0.0;
     }
 
     // ---- weight-gradient slab: combine the four waves in wave order (deterministic) --------------------------
@@ -407,9 +439,15 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         const int cs = 4 * (l >> 4) + j, n = 16 * t + (l & 15);
         if (cs < TT_C) slab[cs * (TT_C * 16) + n] = red[i];
     }
+    // slabs [gridDim, nslabs) exist in the caller's buffers (sized for the forward kernel's grid) but have no owner
+    for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x) {
+        for (int i = threadIdx.x; i < NP * 2; i += DM_BLOCK) part[(long long)t2 * NP * 2 + i] = 0.0;
+        wslabs[(long long)t2 * (TT_C * TT_C * 16) + threadIdx.x] = 0.f;
+    }
 }
 
-int tail_grid(int ntiles) { return ntiles < TT_MAX_GRID ? ntiles : TT_MAX_GRID; }
+int tail_grid(int ntiles) { return ntiles < TT_MAX_GRID ? ntiles : TT_MAX_GRID; }               // forward: 3 per CU
+int tail_grid_bwd(int ntiles) { return ntiles < 512 ? ntiles : 512; }                           // backward: 2 per CU
 
 int tail_checks(const char *who, int B, int C2, int NIN, int H2, int W2)
 {
@@ -461,12 +499,12 @@ extern "C" int dm_dec_tail_backward(const float *d2, const float *w4, const floa
                "dm_dec_tail_backward: NULL pointer");
     DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "dm_dec_tail_backward: mask channels %d", mask_channels);
     if (tail_checks("dm_dec_tail_backward", B, C2, NIN, H2, W2)) return -1;
-    const int ntiles = B * (H2 / TT_TH), grid = tail_grid(ntiles);
+    const int ntiles = B * (H2 / TT_TH), grid = tail_grid_bwd(ntiles), nslabs = tail_grid(ntiles);
     const double inv_count = 1.0 / ((double)B * NIN * (2.0 * H2) * (2.0 * W2));
     hipStream_t st = (hipStream_t)stream;
 #define DM_TB(N_) hipLaunchKernelGGL((dec_tail_backward_kernel<N_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, w6, \
                                      decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, part_slabs, w_slabs, \
-                                     H2, ntiles, inv_count)
+                                     H2, ntiles, inv_count, nslabs)
     switch (NIN) { case 1: DM_TB(1); break; case 2: DM_TB(2); break; case 3: DM_TB(3); break; default: DM_TB(4); }
 #undef DM_TB
     return dm_launch_status("dm_dec_tail_backward");
