@@ -56,36 +56,61 @@ def event_time_ms(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters
 
 
+def pmc_traffic(kernel_key, batch):
+    """HBM bytes per launch of the roofline kernel, from the separate `rocprofv3 --pmc` passes summarised in
+    profiles/r01_pmc_traffic.json (tools/pmc_traffic.py writes it; bench.py cannot run under the profiler
+    itself).  None when no measurement for this kernel and batch has been committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(kernel_key)
+    except (OSError, ValueError):
+        return None
+    if not rec or rec.get("batch") != batch:
+        return None
+    return rec.get("hbm_bytes_per_launch")
+
+
 def roofline_dominant_kernel(model, x, workload):
-    """Dominant kernel of the step (profiles/: the enc.1 composite 4x4/s2 convolution's weight gradient for
-    c3, the enc.1 composite convolution itself for c2), launched alone with the bench shapes."""
+    """Dominant kernel of the step by total time in profiles/ (c3: the fused backward decoder tail,
+    dec_tail_backward_kernel; c2: the enc.0 o enc.1 composite 4x4/s2 convolution), launched alone on the bench
+    shapes and timed with events on the launch stream.  achieved = algorithmic bytes / average duration."""
     from dynamorph_amd import engine as E
     from dynamorph_amd import ops
     from dynamorph_amd.ops import Op, weight_view
     L = E.Layers(model)
     B, NIN, H, W = x.shape
-    c1 = L.nh // 2
-    weff = ops.e1_compose(L.enc0.weight.detach(), L.enc0.bias.detach(), L.enc1.weight.detach())
-    a1 = torch.empty(B, c1, H // 2, W // 2, device=x.device)
     if workload == "c2":
+        c1 = L.nh // 2
+        weff = ops.e1_compose(L.enc0.weight.detach(), L.enc0.bias.detach(), L.enc1.weight.detach())
+        a1 = torch.empty(B, c1, H // 2, W // 2, device=x.device)
+
         def fn():
             ops.conv4x4s2(Op(x, ones=True), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN + 1, c1, H, W, out=a1,
                           want_stats=True, bias=L.enc1.bias.detach())
-        name = "conv4x4s2_kernel<3,1,8,64> (enc.0 o enc.1 composite)"
+        key, name = "conv4x4s2_e1", "conv4x4s2_kernel<3,1,...> (enc.0 o enc.1 composite)"
         algo_bytes = B * (NIN * H * W + c1 * (H // 2) * (W // 2)) * 4          # read x once, write a1 once
     else:
+        c2 = L.dec4.weight.shape[0]
+        if not ops.dec_tail_supported(c2, NIN, H // 2, W // 2):
+            return None
         torch.manual_seed(0)
-        dy = torch.randn_like(a1)
-        dweff = torch.empty(c1, NIN + 1, 4, 4, device=x.device)
+        d2 = torch.randn(B, c2, H // 2, W // 2, device=x.device).clamp_(min=0)
+        w4, b4 = L.dec4.weight.detach(), L.dec4.bias.detach()
+        w6, b6 = L.dec6.weight.detach(), L.dec6.bias.detach()
+        var = L.channel_var.detach().to(x.device, torch.float32).reshape(-1).contiguous()
+        gs = torch.ones(1, device=x.device)
+        dec, _ = ops.dec_tail_forward(d2, w4, b4, w6, b6, x, None, var)
 
         def fn():
-            ops.wgrad(Op(dy), Op(x, ones=True), dweff, B, c1, NIN + 1, H // 2, W // 2, 4)
-        name = "wgrad_kernel<8,3,4,8,64> (enc.0 o enc.1 composite weight gradient)"
-        algo_bytes = B * (NIN * H * W + c1 * (H // 2) * (W // 2)) * 4          # read x once, read dy once
+            ops.dec_tail_backward(d2, w4, b4, w6, dec, x, None, var, gs)
+        key, name = "dec_tail_backward", f"dec_tail_backward_kernel<{NIN}> (dec.4/dec.5/dec.6 + loss backward, fused)"
+        # read d2, decoded and x once, write g2 once (DESIGN.md section 3)
+        algo_bytes = B * (2 * c2 * (H // 2) * (W // 2) + 2 * NIN * H * W) * 4
     ms = event_time_ms(fn)
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key, B), "avg_launch_ms": round(ms, 4),
             "algorithmic_bytes_per_launch": algo_bytes}
 
 

@@ -252,6 +252,27 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 #pragma unroll
     for (int k = 0; k < NV; ++k) pv[k] = 0.f;
 
+    // decoded / x rows of the g4 rows this wave handles in phase B (gr = wave + 4j).  They are requested one tile
+    // ahead and only CONSUMED in phase B (consuming them earlier would put the s_waitcnt right after the issue).
+    constexpr int BR = (GROWS + 3) / 4;
+    f32x2 rdv[BR][NIN], rxv[BR][NIN];
+    auto issue_rows = [&](int tb, int ty0) {
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int gr = wave + 4 * j, oy = 2 * ty0 - 1 + gr;
+#pragma unroll
+            for (int c = 0; c < NIN; ++c) {
+                rdv[j][c] = (f32x2){0.f, 0.f}; rxv[j][c] = (f32x2){0.f, 0.f};
+                if (gr < GROWS && oy >= 0 && oy < OH) {
+                    const int off = ((tb * NIN + c) * OH + oy) * OW + 2 * lane;
+                    rdv[j][c] = *reinterpret_cast<const f32x2 *>(decp + off);
+                    rxv[j][c] = *reinterpret_cast<const f32x2 *>(x + off);
+                }
+            }
+        }
+    };
+    if (tidx < ntiles) issue_rows(b, y0);
+
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA and sG
         stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 2, 0);
@@ -263,29 +284,6 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             stage.issue(in, b, TT_C, H2, TT_W, y0 - 2, 0);
         }
 
-        // g_dec of the g4 rows this wave handles in phase B: its decoded / x / mask loads are issued now and land
-        // while phase A computes
-        constexpr int BR = (GROWS + 3) / 4;
-        f32x2 gd[BR][NIN];
-#pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const int gr = wave + 4 * j, oy = 2 * cy0 - 1 + gr;
-#pragma unroll
-            for (int c = 0; c < NIN; ++c) {
-                gd[j][c] = (f32x2){0.f, 0.f};
-                if (gr < GROWS && oy >= 0 && oy < OH) {
-                    const int off = ((cb * NIN + c) * OH + oy) * OW + 2 * lane;
-                    const f32x2 dv = *reinterpret_cast<const f32x2 *>(decp + off);
-                    const f32x2 xv = *reinterpret_cast<const f32x2 *>(x + off);
-                    f32x2 t = dv - xv;
-                    if (mask) {
-                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
-                        t = (dv * mv - xv * mv) * mv;
-                    }
-                    gd[j][c] = t * gsv[c];
-                }
-            }
-        }
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
         {
         float wA[64];                                 // W4[ci][co = wave][ky][kx], live in this phase only
@@ -320,6 +318,16 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 const int oy = 2 * cy0 - 1 + gr;
                 const bool live = oy >= 0 && oy < OH;
                 const bool owned = gr >= 1 && gr <= 2 * TT_TH;       // rows 2*y0 .. 2*y0+2*TH-1 belong to this tile
+                f32x2 gd[NIN];
+#pragma unroll
+                for (int c = 0; c < NIN; ++c) {
+                    f32x2 t = rdv[j][c] - rxv[j][c];
+                    if (mask && live) {
+                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
+                        t = (rdv[j][c] * mv - rxv[j][c] * mv) * mv;
+                    }
+                    gd[c] = t * gsv[c];
+                }
 #pragma unroll
                 for (int co = 0; co < TT_C; ++co) {
                     float *pd = sG + co * GPS + gr * TT_DRS + 2 * lane + 4;
@@ -327,8 +335,8 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     f32x2 g4 = {0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < NIN; ++c) {
-                        g4 += w6r[c][co] * gd[j][c];
-                        if (owned) pv[c * TT_C + co] += gd[j][c].x * d4.x + gd[j][c].y * d4.y;
+                        g4 += w6r[c][co] * gd[c];
+                        if (owned) pv[c * TT_C + co] += gd[c].x * d4.x + gd[c].y * d4.y;
                     }
                     g4.x = d4.x > 0.f ? g4.x : 0.f;
                     g4.y = d4.y > 0.f ? g4.y : 0.f;
@@ -338,10 +346,11 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 }
                 if (owned) {
 #pragma unroll
-                    for (int c = 0; c < NIN; ++c) pv[NIN * TT_C + c] += gd[j][c].x + gd[j][c].y;
+                    for (int c = 0; c < NIN; ++c) pv[NIN * TT_C + c] += gd[c].x + gd[c].y;
                 }
             }
         }
+        if (next < ntiles) issue_rows(b, y0);              // next tile's rows fly during the dgrad / wgrad phases
         __syncthreads();
 
         // ---- phase 3: data gradient of dec.4 for input channel ci = wave:  g2[ci][y][x] = sum_co,ky,kx

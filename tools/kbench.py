@@ -1,28 +1,50 @@
 #!/usr/bin/env python3
-"""Kernel micro-bench at BASELINE C3 shapes (B=2048): times single launches with events, prints GB/s."""
+"""Kernel micro-bench at BASELINE C3 shapes (B=2048): single launches timed with events, algorithmic GB/s.
+
+    gpurun -- python tools/kbench.py            # all kernels below
+    KB_B=256 python tools/kbench.py tail        # subset by name prefix, smaller batch
+"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dynamorph_amd import ops
 from dynamorph_amd.ops import Op, weight_view
 
+
 def t_ms(fn, iters=10, warm=2):
-    for _ in range(warm): fn()
+    for _ in range(warm):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): fn()
+    for _ in range(iters):
+        fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / iters
 
+
 dev = "cuda:0"; B = int(os.environ.get("KB_B", "2048"))
+want = sys.argv[1:] or [""]
 torch.manual_seed(0)
 x = torch.randn(B, 2, 128, 128, device=dev)
-w = torch.randn(8, 3, 4, 4, device=dev) * 0.1
-bias = torch.randn(8, device=dev)
+cases = {}
+
+w1 = torch.randn(8, 3, 4, 4, device=dev) * 0.1; bias1 = torch.randn(8, device=dev)
 a1 = torch.empty(B, 8, 64, 64, device=dev)
-def e1():
-    ops.conv4x4s2(Op(x, ones=True), weight_view(w, 48, 16, 4, 1), B, 3, 8, 128, 128, out=a1, want_stats=True, bias=bias)
-for dbg in (0,):
-    os.environ["DM_CONV_DBG"] = str(dbg)
-    ms = t_ms(e1)
-    print(f"E1 conv dbg={dbg} (1=noMFMA 2=noStore 4=noLoad): {ms*1e3:8.1f} us   {B*(2*128*128+8*64*64)*4/ms/1e6:8.1f} GB/s")
-os.environ["DM_CONV_DBG"] = "0"
+cases["e1_conv"] = (lambda: ops.conv4x4s2(Op(x, ones=True), weight_view(w1, 48, 16, 4, 1), B, 3, 8, 128, 128,
+                                          out=a1, want_stats=True, bias=bias1), B * (2 * 128 * 128 + 8 * 64 * 64) * 4)
+
+d2 = torch.randn(B, 4, 64, 64, device=dev).clamp(min=0)
+w4 = torch.randn(4, 4, 4, 4, device=dev) * .3; b4 = torch.randn(4, device=dev)
+w6 = torch.randn(2, 4, 1, 1, device=dev); b6 = torch.randn(2, device=dev)
+var = torch.ones(2, device=dev); gs = torch.ones(1, device=dev)
+dec, _ = ops.dec_tail_forward(d2, w4, b4, w6, b6, x, None, var)
+cases["tail_fwd"] = (lambda: ops.dec_tail_forward(d2, w4, b4, w6, b6, x, None, var), B * 327680)
+cases["tail_bwd"] = (lambda: ops.dec_tail_backward(d2, w4, b4, w6, dec, x, None, var, gs), B * 393216)
+
+src = torch.randn(64 << 20, device=dev); dst = torch.empty_like(src)          # 256 MiB each: past the Infinity Cache
+cases["copy_calib"] = (lambda: torch.add(src, 1.0, out=dst), 2 * src.numel() * 4)            # known bytes: calibrates the PMC counters
+
+for name, (fn, nbytes) in cases.items():
+    if not any(name.startswith(p) for p in want):
+        continue
+    ms = t_ms(fn)
+    print(f"{name:10s} {ms * 1e3:8.1f} us   {nbytes / ms / 1e6:8.1f} GB/s (algorithmic)")
