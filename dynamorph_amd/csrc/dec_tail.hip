@@ -52,28 +52,55 @@ __device__ __forceinline__ float lane_from_right(float v)   // value of lane + 1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
 }
 
-// ConvTranspose2d(4,4,4,2,1) of one input row for ONE output channel: the 2x2 output pixels (2y+py, 2x+px) of every
-// column x.  sA rows rr-1, rr, rr+1 hold d2 rows y-1, y, y+1; w[ci*16 + ky*4 + kx] = W4[ci][co][ky][kx].
-// Phase (py,px) uses rows d = py-1..py and columns e = px-1..px with ky = py+1-2d, kx = px+1-2e.
-__device__ __forceinline__ void convT_row(const float *__restrict__ sA, int APS, int rr, int lane,
-                                          const float (&w)[64], float bias, float (&o)[2][2])
+// ConvTranspose2d(4,4,4,2,1) for ONE output channel, in packed fp32 (v_pk_fma_f32 does two FMAs per issue; the
+// kernel is VALU-issue bound).  A lane owns column x and produces the output pair (ox = 2x, 2x+1):
+//   out[oy][2x]   = sum_ci,d  in[d][x-1] * w[ky][3] + in[d][x]   * w[ky][1]
+//   out[oy][2x+1] = sum_ci,d  in[d][x]   * w[ky][2] + in[d][x+1] * w[ky][0]
+// so with L = (in[x-1], in[x]) and R = (in[x], in[x+1]) the pair is  L * (w3, w2) + R * (w1, w0).
+// Output rows 2y-1 and 2y both read exactly the input rows y-1 ("P") and y ("C"):
+//   row 2y-1: P with ky = 2, C with ky = 0        row 2y: P with ky = 3, C with ky = 1
+struct RowPairs {
+    f32x2 L[TT_C], R[TT_C];
+};
+__device__ __forceinline__ void load_row(const float *__restrict__ sA, int APS, int row, int lane, float (&v)[TT_C])
 {
-    o[0][0] = bias; o[0][1] = bias; o[1][0] = bias; o[1][1] = bias;
+#pragma unroll
+    for (int ci = 0; ci < TT_C; ++ci) v[ci] = sA[ci * APS + row * TT_W + lane];
+}
+__device__ __forceinline__ void make_row_pairs(const float (&v)[TT_C], RowPairs &p)
+{
 #pragma unroll
     for (int ci = 0; ci < TT_C; ++ci) {
-        float c[3][3];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const float v = sA[ci * APS + (rr - 1 + dy) * TT_W + lane];
-            c[dy][1] = v; c[dy][0] = lane_from_left(v); c[dy][2] = lane_from_right(v);
-        }
-        const float *wc = &w[ci * 16];
-        o[0][0] += c[0][0] * wc[3 * 4 + 3] + c[0][1] * wc[3 * 4 + 1] + c[1][0] * wc[1 * 4 + 3] + c[1][1] * wc[1 * 4 + 1];
-        o[0][1] += c[0][1] * wc[3 * 4 + 2] + c[0][2] * wc[3 * 4 + 0] + c[1][1] * wc[1 * 4 + 2] + c[1][2] * wc[1 * 4 + 0];
-        o[1][0] += c[1][0] * wc[2 * 4 + 3] + c[1][1] * wc[2 * 4 + 1] + c[2][0] * wc[0 * 4 + 3] + c[2][1] * wc[0 * 4 + 1];
-        o[1][1] += c[1][1] * wc[2 * 4 + 2] + c[1][2] * wc[2 * 4 + 0] + c[2][1] * wc[0 * 4 + 2] + c[2][2] * wc[0 * 4 + 0];
+        p.L[ci] = (f32x2){lane_from_left(v[ci]), v[ci]};
+        p.R[ci] = (f32x2){v[ci], lane_from_right(v[ci])};
     }
 }
+// wp[ci][ky][0] = (w[ky][3], w[ky][2]), wp[ci][ky][1] = (w[ky][1], w[ky][0]) of W4[ci][co] for this wave's co
+__device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, int wv, f32x2 (&wp)[TT_C][4][2])
+{
+#pragma unroll
+    for (int ci = 0; ci < TT_C; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(w + (ci * TT_C + wv) * 16 + 4 * ky);
+            wp[ci][ky][0] = (f32x2){q.w, q.z};
+            wp[ci][ky][1] = (f32x2){q.y, q.x};
+        }
+}
+__device__ __forceinline__ void convT_pair(const RowPairs &P, const RowPairs &C, const f32x2 (&wp)[TT_C][4][2], float bias,
+                                           f32x2 &lo, f32x2 &hi)
+{
+    lo = (f32x2){bias, bias}; hi = (f32x2){bias, bias};
+#pragma unroll
+    for (int ci = 0; ci < TT_C; ++ci) {
+        // one statement per product: each contracts to a single v_pk_fma_f32 on the accumulator
+        lo += P.L[ci] * wp[ci][2][0]; hi += P.L[ci] * wp[ci][3][0];
+        lo += P.R[ci] * wp[ci][2][1]; hi += P.R[ci] * wp[ci][3][1];
+        lo += C.L[ci] * wp[ci][0][0]; hi += C.L[ci] * wp[ci][1][0];
+        lo += C.R[ci] * wp[ci][0][1]; hi += C.R[ci] * wp[ci][1][1];
+    }
+}
+__device__ __forceinline__ f32x2 relu2(f32x2 v) { return (f32x2){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}; }
 
 // =================================================================================== forward
 template <int NIN>
@@ -106,9 +133,8 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
     if (threadIdx.x < TT_C) *reinterpret_cast<f32x4 *>(s_coef + threadIdx.x * 4) = (f32x4){1.f, 0.f, 0.f, -__builtin_inff()};
 
     const int wv = wave_index_vgpr();
-    float wA[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) wA[i] = w4[((i >> 4) * TT_C + wv) * 16 + (i & 15)];
+    f32x2 wp[TT_C][4][2];
+    load_convT_weights(w4, wv, wp);
     const float bias4 = b4[wv];
     float w6r[NIN][TT_C], b6r[NIN], ivar[NIN];
 #pragma unroll
@@ -141,14 +167,25 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
             }
         }
         // ---- phase A: d4[co = wave] = relu(dec.4(d2)) for the 16 output rows of this tile -> LDS ---------------
-#pragma unroll 2
-        for (int r = 0; r < TT_TH; ++r) {
-            float o[2][2];
-            convT_row(sA, APS, r + 1, lane, wA, bias4, o);
+        {
+            RowPairs P, C;                               // d2 rows y-1 and y; sA row 0 <-> d2 row y0-1
+            float nv[TT_C];                              // the next row's values: LDS reads one row ahead of their use
+            load_row(sA, APS, 0, lane, nv);
+            make_row_pairs(nv, P);
+            load_row(sA, APS, 1, lane, nv);
 #pragma unroll
-            for (int py = 0; py < 2; ++py)
-                *reinterpret_cast<f32x2 *>(sD + wave * DPS + (2 * r + py) * TT_DRS + 2 * lane + 4) =
-                    (f32x2){fmaxf(o[py][0], 0.f), fmaxf(o[py][1], 0.f)};
+            for (int pr = 0; pr <= TT_TH; ++pr) {        // y = y0 + pr -> d4 rows 2y-1 (lo) and 2y (hi)
+                make_row_pairs(nv, C);
+                if (pr < TT_TH) load_row(sA, APS, pr + 2, lane, nv);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x2 lo, hi;
+                convT_pair(P, C, wp, bias4, lo, hi);
+                float *row = sD + wave * DPS + 2 * pr * TT_DRS + 2 * lane + 4;
+                if (pr > 0) *reinterpret_cast<f32x2 *>(row - TT_DRS) = relu2(lo);
+                if (pr < TT_TH) *reinterpret_cast<f32x2 *>(row) = relu2(hi);
+                P = C;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
         // ---- phase B: dec.6 (1x1) + loss; one wave per output row, one lane per column pair --------------------
@@ -182,6 +219,32 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
     }
     const double tot = block_sum(loss, s_red);
     if (threadIdx.x == 0 && loss_slabs) loss_slabs[blockIdx.x] = tot;
+}
+
+// Weight gradient of dec.4 on the MFMA with a full 16x16 tile.  R[ci][co][ky][kx] = sum_{y,x} d2[ci][y][x] *
+// g4[co][2y-1+ky][2x-1+kx]; writing ky = 2*sy + py, kx = 2*sx + px and summing over Y = y + sy, X = x + sx instead:
+//     R[ci][co][2sy+py][2sx+px] = sum_{Y,X} d2[ci][Y-sy][X-sx] * g4[co][2Y-1+py][2X-1+px]
+// so M = (ci, sy, sx) = 16 rows of shifted d2, N = (co, py, px) = 16 columns of g4 at even/odd offsets, K = the
+// (TH+1) x (W+1) positions (Y, X) of the tile.  One MFMA per four positions (a [ci] x [co,ky,kx] mapping needs four:
+// only 4 of its 16 M rows are real).  Terms whose d2 row/column falls outside the tile's own rows / the image are
+// zeroed on the A side; the g4 tile has zero padding columns, and its halo rows belong to the neighbour's terms.
+// Steps S0 .. S0+NS-1 of one position row (step s covers X = 4s .. 4s+3; s = 16 is X = 64, only sx = 1 is real).
+template <int NS, bool FIRST, bool LAST>
+__device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const float *__restrict__ sG, int aoff, int boff,
+                                            float rowmul, bool first_bad, bool last_ok, f32x4 (&acc)[2])
+{
+    float a[2], bq[2];
+    a[0] = sA[aoff]; bq[0] = sG[boff];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) { a[(s + 1) & 1] = sA[aoff + 4 * (s + 1)]; bq[(s + 1) & 1] = sG[boff + 8 * (s + 1)]; }
+        __builtin_amdgcn_sched_barrier(0);
+        float av = a[s & 1] * rowmul;
+        if (FIRST && s == 0) av = first_bad ? 0.f : av;
+        if (LAST && s == NS - 1) av = last_ok ? av : 0.f;
+        acc[s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[s & 1], acc[s & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ================================================================================== backward
@@ -237,20 +300,23 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         for (int co = 0; co < TT_C; ++co) w6r[c][co] = w6[c * TT_C + co];
     }
 
-    // weight-gradient (MFMA) operands: S = d2 (rows of sA), T = g4 tile; lane column n = 16*t + m <-> (ct = t, ky = m>>2, kx = m&3)
-    int boff[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) boff[t] = t * GPS + (m >> 2) * TT_DRS + (m & 3) + 3 + 2 * kq;
-    const int aoffw = (m < TT_C ? m : TT_C - 1) * APS + kq;
-    f32x4 wacc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // weight-gradient (MFMA) operands (wgrad_steps): lane (m, kq) feeds A row m = (ci, sy, sx) and B column m = (co, py, px)
+    // at position X = 4*step + kq of position row Yr = Y - y0:  sA row of d2 row Y-sy is Yr+2-sy, g4-tile row is 2*Yr+py,
+    // g4-tile column of ox = 2X-1+px is 2X+3+px
+    const int wsy = (m >> 1) & 1, wsx = m & 1;
+    const int wa_base = (m >> 2) * APS + (2 - wsy) * TT_W + kq - wsx;
+    const int wb_base = (m >> 2) * GPS + wsy * TT_DRS + 3 + wsx + 2 * kq;
+    const bool w_first_bad = wsx == 1 && kq == 0;        // X = 0 with sx = 1: column -1
+    const bool w_last_ok = wsx == 1 && kq == 0;          // X = 64: only column 63 of the sx = 1 rows
+    f32x4 wacc[2];
+    wacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // per-lane partial sums over this workgroup's tiles (a few hundred fp32 terms each; the cross-lane / cross-
     // workgroup reductions are done in double): dW6[c][co] | db6[c] | db4[co] ; db2[ci = wave]
-    float pv[NV], pb2 = 0.f;
+    f32x2 pv[NV];                                     // (even column, odd column) partials, added at the end
+    float pb2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) pv[k] = 0.f;
+    for (int k = 0; k < NV; ++k) pv[k] = (f32x2){0.f, 0.f};
 
     // decoded / x rows of the g4 rows this wave handles in phase B (gr = wave + 4j).  They are requested one tile
     // ahead and only CONSUMED in phase B (consuming them earlier would put the s_waitcnt right after the issue).
@@ -286,26 +352,25 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
         {
-        float wA[64];                                 // W4[ci][co = wave][ky][kx], live in this phase only
+        f32x2 wp[TT_C][4][2];                         // W4[ci][co = wave] as packed pairs, live in this phase only
+        load_convT_weights(s_w4, wv, wp);
+        RowPairs P, C;                                // sA row 0 <-> d2 row y0-2
+        float nv[TT_C];                               // the next row's values: LDS reads one row ahead of their use
+        load_row(sA, APS, 1, lane, nv);
+        make_row_pairs(nv, P);
+        load_row(sA, APS, 2, lane, nv);
 #pragma unroll
-        for (int ci = 0; ci < TT_C; ++ci)
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + (ci * TT_C + wv) * 16 + 4 * t4);
-                wA[ci * 16 + 4 * t4 + 0] = q.x; wA[ci * 16 + 4 * t4 + 1] = q.y;
-                wA[ci * 16 + 4 * t4 + 2] = q.z; wA[ci * 16 + 4 * t4 + 3] = q.w;
-            }
-#pragma unroll 2
-        for (int pr = 0; pr < TT_TH + 2; ++pr) {
-            float o[2][2];
-            convT_row(sA, APS, pr + 1, lane, wA, bias4, o);      // sA row pr+1 <-> d2 row y0-1+pr
-#pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                const int gr = 2 * pr + py - 1;
-                if (gr >= 0 && gr < GROWS)
-                    *reinterpret_cast<f32x2 *>(sG + wave * GPS + gr * TT_DRS + 2 * lane + 4) =
-                        (f32x2){fmaxf(o[py][0], 0.f), fmaxf(o[py][1], 0.f)};
-            }
+        for (int pr = 0; pr <= TT_TH; ++pr) {         // y = y0 + pr -> g4-tile rows 2pr (d4 row 2y-1) and 2pr+1 (row 2y)
+            make_row_pairs(nv, C);
+            if (pr < TT_TH) load_row(sA, APS, pr + 3, lane, nv);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x2 lo, hi;
+            convT_pair(P, C, wp, bias4, lo, hi);
+            float *row = sG + wave * GPS + 2 * pr * TT_DRS + 2 * lane + 4;
+            *reinterpret_cast<f32x2 *>(row) = relu2(lo);
+            *reinterpret_cast<f32x2 *>(row + TT_DRS) = relu2(hi);
+            P = C;
+            __builtin_amdgcn_sched_barrier(0);
         }
         }
         __syncthreads();
@@ -317,36 +382,33 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             if (gr < GROWS) {
                 const int oy = 2 * cy0 - 1 + gr;
                 const bool live = oy >= 0 && oy < OH;
-                const bool owned = gr >= 1 && gr <= 2 * TT_TH;       // rows 2*y0 .. 2*y0+2*TH-1 belong to this tile
-                f32x2 gd[NIN];
+                // rows 2*y0 .. 2*y0+2*TH-1 belong to this tile: the halo rows get their g4 but add nothing to the sums
+                const float own = (gr >= 1 && gr <= 2 * TT_TH) ? 1.f : 0.f;
+                f32x2 gd[NIN], gdo[NIN];
 #pragma unroll
                 for (int c = 0; c < NIN; ++c) {
-                    f32x2 t = rdv[j][c] - rxv[j][c];
+                    f32x2 t = rdv[j][c] - rxv[j][c];     // rows outside the image were loaded as 0: g_dec = 0, g4 = 0
                     if (mask && live) {
                         const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
                         t = (rdv[j][c] * mv - rxv[j][c] * mv) * mv;
                     }
                     gd[c] = t * gsv[c];
+                    gdo[c] = gd[c] * own;
+                    pv[NIN * TT_C + c] += gdo[c];
                 }
 #pragma unroll
                 for (int co = 0; co < TT_C; ++co) {
                     float *pd = sG + co * GPS + gr * TT_DRS + 2 * lane + 4;
                     const f32x2 d4 = *reinterpret_cast<const f32x2 *>(pd);
-                    f32x2 g4 = {0.f, 0.f};
+                    f32x2 g4 = w6r[0][co] * gd[0];
 #pragma unroll
-                    for (int c = 0; c < NIN; ++c) {
-                        g4 += w6r[c][co] * gd[c];
-                        if (owned) pv[c * TT_C + co] += gd[c].x * d4.x + gd[c].y * d4.y;
-                    }
+                    for (int c = 1; c < NIN; ++c) g4 += w6r[c][co] * gd[c];
+#pragma unroll
+                    for (int c = 0; c < NIN; ++c) pv[c * TT_C + co] += gdo[c] * d4;
                     g4.x = d4.x > 0.f ? g4.x : 0.f;
                     g4.y = d4.y > 0.f ? g4.y : 0.f;
-                    if (!live) g4 = (f32x2){0.f, 0.f};               // rows outside the image are zero padding
-                    if (owned) pv[NIN * TT_C + NIN + co] += g4.x + g4.y;
+                    pv[NIN * TT_C + NIN + co] += g4 * own;
                     *reinterpret_cast<f32x2 *>(pd) = g4;
-                }
-                if (owned) {
-#pragma unroll
-                    for (int c = 0; c < NIN; ++c) pv[NIN * TT_C + c] += gd[c].x + gd[c].y;
                 }
             }
         }
@@ -356,53 +418,66 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         // ---- phase 3: data gradient of dec.4 for input channel ci = wave:  g2[ci][y][x] = sum_co,ky,kx
         //      g4[co][2y-1+ky][2x-1+kx] * W4[ci][co][ky][kx], masked by d2 > 0 ------------------------------------------
         {
-        float wD[64];                                 // W4[ci = wave][co][ky][kx], live in this phase only
+        // per g4 value pair mid = (col 2x, 2x+1), left = col 2x-1, right = col 2x+2:
+        //   left*w[ky][0] + mid.x*w[ky][1] + mid.y*w[ky][2] + right*w[ky][3] = mid * (w1, w2) + (left, right) * (w0, w3)
+        f32x2 wm[TT_C][4], wo[TT_C][4];               // W4[ci = wave][co][ky] as (w1, w2) and (w0, w3)
 #pragma unroll
-        for (int t4 = 0; t4 < 16; ++t4) {
-            const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + wv * 64 + 4 * t4);
-            wD[4 * t4 + 0] = q.x; wD[4 * t4 + 1] = q.y; wD[4 * t4 + 2] = q.z; wD[4 * t4 + 3] = q.w;
-        }
-#pragma unroll 2
-        for (int r = 0; r < TT_TH; ++r) {
-            float acc = 0.f;
+        for (int co = 0; co < TT_C; ++co)
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + (wv * TT_C + co) * 16 + 4 * ky);
+                wm[co][ky] = (f32x2){q.y, q.z};
+                wo[co][ky] = (f32x2){q.x, q.w};
+            }
+        f32x2 acc[TT_TH];
+#pragma unroll
+        for (int r = 0; r < TT_TH; ++r) acc[r] = (f32x2){0.f, 0.f};
+        f32x2 nm[TT_C];                               // the next g4 row: LDS reads one row ahead of their use
+#pragma unroll
+        for (int co = 0; co < TT_C; ++co) nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + 2 * lane + 4);
+#pragma unroll
+        for (int gr = 0; gr < GROWS; ++gr) {          // g4-tile row gr = 2r + ky: every row is read once, feeds <= 2 output rows
+            f32x2 mid[TT_C];
+#pragma unroll
+            for (int co = 0; co < TT_C; ++co) mid[co] = nm[co];
+            if (gr + 1 < GROWS) {
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co)
+                    nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + (gr + 1) * TT_DRS + 2 * lane + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int co = 0; co < TT_C; ++co) {
-#pragma unroll
-                for (int ky = 0; ky < 4; ++ky) {
-                    const f32x2 mid = *reinterpret_cast<const f32x2 *>(sG + co * GPS + (2 * r + ky) * TT_DRS + 2 * lane + 4);
-                    const float left = lane_from_left(mid.y);       // column 2x-1
-                    const float right = lane_from_right(mid.x);     // column 2x+2
-                    const float *wc = &wD[co * 16 + ky * 4];
-                    acc += left * wc[0] + mid.x * wc[1] + mid.y * wc[2] + right * wc[3];
-                }
+                const f32x2 lr = {lane_from_left(mid[co].y), lane_from_right(mid[co].x)};
+                const int r1 = gr >> 1, k1 = gr & 1;               // ky = k1 for row r1, ky = k1 + 2 for row r1 - 1
+                if (r1 < TT_TH) { acc[r1] += mid[co] * wm[co][k1]; acc[r1] += lr * wo[co][k1]; }
+                if (r1 >= 1) { acc[r1 - 1] += mid[co] * wm[co][k1 + 2]; acc[r1 - 1] += lr * wo[co][k1 + 2]; }
             }
-            const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
-            acc = dd > 0.f ? acc : 0.f;
-            g2[((cb * TT_C + wave) * H2 + cy0 + r) * TT_W + lane] = acc;
-            pb2 += acc;
+            if ((gr & 1) && gr >= 3) {                             // row r = (gr - 3) / 2 is complete
+                const int r = (gr - 3) >> 1;
+                const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
+                const float v = dd > 0.f ? acc[r].x + acc[r].y : 0.f;
+                g2[((cb * TT_C + wave) * H2 + cy0 + r) * TT_W + lane] = v;
+                pb2 += v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         }
 
-        // ---- phase 4 (MFMA): weight gradient of dec.4: R[ci][co][ky][kx] += sum d2[ci,y,x] * g4[co,2y-1+ky,2x-1+kx] ---
-        for (int r = wave; r < TT_TH; r += 4) {
-            float a[2], bv[2][4];
-            const int ra = (r + 2) * TT_W, rb = 2 * r * TT_DRS;
-            a[0] = sA[aoffw + ra];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bv[0][t] = sG[boff[t] + rb];
-#pragma unroll
-            for (int x4 = 0; x4 < TT_W / 4; ++x4) {
-                if (x4 + 1 < TT_W / 4) {
-                    a[(x4 + 1) & 1] = sA[aoffw + ra + 4 * (x4 + 1)];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) bv[(x4 + 1) & 1][t] = sG[boff[t] + rb + 8 * (x4 + 1)];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x4 & 1], bv[x4 & 1][t], wacc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        // ---- phase 4 (MFMA): weight gradient of dec.4 (wgrad_steps).  Position rows Yr = 0..TH: this wave takes rows
+        //      wave and wave+4 whole and a quarter of row TH.  Row 0 has no own d2 row for sy = 1, row TH none for sy = 0.
+        {
+            const float rm0 = (wave == 0 && wsy == 1) ? 0.f : 1.f;
+            wgrad_steps<17, true, true>(sA, sG, wa_base + wave * TT_W, wb_base + 2 * wave * TT_DRS, rm0, w_first_bad,
+                                        w_last_ok, wacc);
+            wgrad_steps<17, true, true>(sA, sG, wa_base + (wave + 4) * TT_W, wb_base + 2 * (wave + 4) * TT_DRS, 1.f,
+                                        w_first_bad, w_last_ok, wacc);
+            const float rm8 = wsy == 1 ? 1.f : 0.f;
+            const int a8 = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
+            if (wave < 3)
+                wgrad_steps<4, true, false>(sA, sG, a8, b8, rm8, w_first_bad && wave == 0, false, wacc);
+            else
+                wgrad_steps<5, false, true>(sA, sG, a8, b8, rm8, false, w_last_ok, wacc);
         }
         tidx = next;
     }
@@ -410,7 +485,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     // ---- partial sums: every lane holds partials of all NV phase-B sums; db2 is per wave (ci = wave) ---------------
     double pvd[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) pvd[k] = wave_sum((double)pv[k]);
+    for (int k = 0; k < NV; ++k) pvd[k] = wave_sum((double)pv[k].x + (double)pv[k].y);
     const double pb2d = wave_sum((double)pb2);
     __syncthreads();
     if (lane == 0) {
@@ -428,25 +503,24 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         part[((long long)blockIdx.x * NP + NV + wave) * 2 + 1] = 0.0;
     }
 
-    // ---- weight-gradient slab: combine the four waves in wave order (deterministic) --------------------------
+    // ---- weight-gradient slab: combine the four waves in wave order (deterministic).  Lane l, element j holds
+    //      M row 4*(l>>4)+j = (ci = l>>4, sy = j>>1, sx = j&1) and N column l&15 = (co, py, px)
     float *red = sG;
+    const f32x4 wsum = wacc[0] + wacc[1];
     for (int w = 0; w < 4; ++w) {
         __syncthreads();
         if (wave == w) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f32x4 *pp = reinterpret_cast<f32x4 *>(red + (t * 64 + lane) * 4);
-                if (w == 0) *pp = wacc[t];
-                else *pp = *pp + wacc[t];
-            }
+            f32x4 *pp = reinterpret_cast<f32x4 *>(red + lane * 4);
+            if (w == 0) *pp = wsum;
+            else *pp = *pp + wsum;
         }
     }
     __syncthreads();
     float *slab = wslabs + (long long)blockIdx.x * (TT_C * TT_C * 16);
-    for (int i = threadIdx.x; i < 4 * 256; i += DM_BLOCK) {
-        const int j = i & 3, l = (i >> 2) & 63, t = i >> 8;
-        const int cs = 4 * (l >> 4) + j, n = 16 * t + (l & 15);
-        if (cs < TT_C) slab[cs * (TT_C * 16) + n] = red[i];
+    {
+        const int i = threadIdx.x, j = i & 3, l = i >> 2, n = l & 15;
+        const int ky = 2 * (j >> 1) + ((n >> 1) & 1), kx = 2 * (j & 1) + (n & 1);
+        slab[(l >> 4) * (TT_C * 16) + (n >> 2) * 16 + ky * 4 + kx] = red[i];
     }
     // slabs [gridDim, nslabs) exist in the caller's buffers (sized for the forward kernel's grid) but have no owner
     for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x) {
