@@ -100,13 +100,13 @@ def roofline_dominant_kernel(model, x, workload):
         w6, b6 = L.dec6.weight.detach(), L.dec6.bias.detach()
         var = L.channel_var.detach().to(x.device, torch.float32).reshape(-1).contiguous()
         gs = torch.ones(1, device=x.device)
-        dec, _ = ops.dec_tail_forward(d2, w4, b4, w6, b6, x, None, var)
 
         def fn():
-            ops.dec_tail_backward(d2, w4, b4, w6, dec, x, None, var, gs)
-        key, name = "dec_tail_backward", f"dec_tail_backward_kernel<{NIN}> (dec.4/dec.5/dec.6 + loss backward, fused)"
-        # read d2, decoded and x once, write g2 once
-        algo_bytes = B * (2 * c2 * (H // 2) * (W // 2) + 2 * NIN * H * W) * 4
+            ops.dec_tail_train(d2, w4, b4, w6, b6, x, None, var, gs)
+        key = "dec_tail_train"
+        name = f"dec_tail_backward_kernel<{NIN}, true> (dm_dec_tail_train: dec.4/dec.5/dec.6 + loss, forward and backward fused)"
+        # read d2 and x once, write g2 once
+        algo_bytes = B * (2 * c2 * (H // 2) * (W // 2) + NIN * H * W) * 4
     ms = event_time_ms(fn)
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

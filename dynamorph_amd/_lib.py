@@ -68,6 +68,7 @@ SIGNATURES = {
     "dm_dec_tail_num_blocks": (C.c_int, [C.c_int] * 3),
     "dm_dec_tail_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_dec_tail_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
+    "dm_dec_tail_train": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_reduce_slabs": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "dm_loss_finalize": (C.c_int, [vp, C.c_int, i64, vp, f32, f32, vp, vp]),
     "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -248,10 +248,13 @@ __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const 
 }
 
 // ================================================================================== backward
-template <int NIN>
+// FUSED (training pass, dm_dec_tail_train): decoded is not read but formed in phase B from the recomputed d4 tile
+// (dec.6 is 1x1), the reconstruction-loss partials are taken there too, and `decoded` never exists in HBM.
+template <int NIN, bool FUSED>
 __global__ __launch_bounds__(DM_BLOCK, 2)
 void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restrict__ w4, const float *__restrict__ b4,
-                              const float *__restrict__ w6, const float *__restrict__ decp, const float *__restrict__ x,
+                              const float *__restrict__ w6, const float *__restrict__ b6, double *__restrict__ loss_slabs,
+                              const float *__restrict__ decp, const float *__restrict__ x,
                               const float *__restrict__ mask, int MC, const float *__restrict__ cvar,
                               const float *__restrict__ gscale_dev, float *__restrict__ g2, double *__restrict__ part,
                               float *__restrict__ wslabs, int H2, int ntiles, double inv_count, int nslabs)
@@ -292,10 +295,11 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     s_w4[threadIdx.x] = w4[threadIdx.x];             // 256 threads, 256 weights
     const float bias4 = b4[wv];
     const float gs = (float)(2.0 * inv_count) * gscale_dev[0];
-    float w6r[NIN][TT_C], gsv[NIN];
+    float w6r[NIN][TT_C], gsv[NIN], b6r[NIN], ivar[NIN];
 #pragma unroll
     for (int c = 0; c < NIN; ++c) {
         gsv[c] = gs / cvar[c];
+        b6r[c] = (FUSED && b6) ? b6[c] : 0.f; ivar[c] = 1.f / cvar[c];
 #pragma unroll
         for (int co = 0; co < TT_C; ++co) w6r[c][co] = w6[c * TT_C + co];
     }
@@ -331,13 +335,14 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 rdv[j][c] = (f32x2){0.f, 0.f}; rxv[j][c] = (f32x2){0.f, 0.f};
                 if (gr < GROWS && oy >= 0 && oy < OH) {
                     const int off = ((tb * NIN + c) * OH + oy) * OW + 2 * lane;
-                    rdv[j][c] = *reinterpret_cast<const f32x2 *>(decp + off);
+                    if (!FUSED) rdv[j][c] = *reinterpret_cast<const f32x2 *>(decp + off);
                     rxv[j][c] = *reinterpret_cast<const f32x2 *>(x + off);
                 }
             }
         }
     };
     if (tidx < ntiles) issue_rows(b, y0);
+    double loss = 0.0;
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA and sG
@@ -376,6 +381,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         __syncthreads();
 
         // ---- phase B: g4 = (W6^T g_dec) * (d4 > 0) in place; dW6 / db6 / db4 partial sums ---------------------------
+        f32x2 tl = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             const int gr = wave + 4 * j;
@@ -384,14 +390,28 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 const bool live = oy >= 0 && oy < OH;
                 // rows 2*y0 .. 2*y0+2*TH-1 belong to this tile: the halo rows get their g4 but add nothing to the sums
                 const float own = (gr >= 1 && gr <= 2 * TT_TH) ? 1.f : 0.f;
-                f32x2 gd[NIN], gdo[NIN];
+                f32x2 gd[NIN], gdo[NIN], d4v[TT_C];
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co)
+                    d4v[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + gr * TT_DRS + 2 * lane + 4);
 #pragma unroll
                 for (int c = 0; c < NIN; ++c) {
-                    f32x2 t = rdv[j][c] - rxv[j][c];     // rows outside the image were loaded as 0: g_dec = 0, g4 = 0
+                    f32x2 dv = rdv[j][c];
+                    if (FUSED) {                         // decoded = dec.6(d4); rows outside the image carry no gradient
+                        dv = (f32x2){b6r[c], b6r[c]};
+#pragma unroll
+                        for (int co = 0; co < TT_C; ++co) dv += w6r[c][co] * d4v[co];
+                    }
+                    f32x2 t = dv - rxv[j][c];            // not FUSED: rows outside the image were loaded as 0
                     if (mask && live) {
                         const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
-                        t = (rdv[j][c] * mv - rxv[j][c] * mv) * mv;
+                        t = dv * mv - rxv[j][c] * mv;
+                        if (FUSED) tl += (t * t * own) * ivar[c];
+                        t = t * mv;
+                    } else if (FUSED) {
+                        tl += (t * t * own) * ivar[c];
                     }
+                    if (FUSED) t = t * (live ? 1.f : 0.f);
                     gd[c] = t * gsv[c];
                     gdo[c] = gd[c] * own;
                     pv[NIN * TT_C + c] += gdo[c];
@@ -399,7 +419,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 #pragma unroll
                 for (int co = 0; co < TT_C; ++co) {
                     float *pd = sG + co * GPS + gr * TT_DRS + 2 * lane + 4;
-                    const f32x2 d4 = *reinterpret_cast<const f32x2 *>(pd);
+                    const f32x2 d4 = d4v[co];
                     f32x2 g4 = w6r[0][co] * gd[0];
 #pragma unroll
                     for (int c = 1; c < NIN; ++c) g4 += w6r[c][co] * gd[c];
@@ -412,6 +432,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 }
             }
         }
+        if (FUSED) loss += (double)tl.x + (double)tl.y;
         if (next < ntiles) issue_rows(b, y0);              // next tile's rows fly during the dgrad / wgrad phases
         __syncthreads();
 
@@ -503,6 +524,14 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         part[((long long)blockIdx.x * NP + NV + wave) * 2 + 1] = 0.0;
     }
 
+    if (FUSED) {                                            // reconstruction-loss partial of this workgroup
+        const double wl = wave_sum(loss);
+        __syncthreads();
+        if (lane == 0) s_part[wave][0] = wl;
+        __syncthreads();
+        if (threadIdx.x == 0) loss_slabs[blockIdx.x] = s_part[0][0] + s_part[1][0] + s_part[2][0] + s_part[3][0];
+    }
+
     // ---- weight-gradient slab: combine the four waves in wave order (deterministic).  Lane l, element j holds
     //      M row 4*(l>>4)+j = (ci = l>>4, sy = j>>1, sx = j&1) and N column l&15 = (co, py, px)
     float *red = sG;
@@ -525,6 +554,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     // slabs [gridDim, nslabs) exist in the caller's buffers (sized for the forward kernel's grid) but have no owner
     for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x) {
         for (int i = threadIdx.x; i < NP * 2; i += DM_BLOCK) part[(long long)t2 * NP * 2 + i] = 0.0;
+        if (FUSED && threadIdx.x == 0) loss_slabs[t2] = 0.0;
         wslabs[(long long)t2 * (TT_C * TT_C * 16) + threadIdx.x] = 0.f;
     }
 }
@@ -573,22 +603,46 @@ extern "C" int dm_dec_tail_forward(const float *d2, const float *w4, const float
     return dm_launch_status("dm_dec_tail_forward");
 }
 
+namespace {
+int tail_backward_launch(const char *who, bool fused, const float *d2, const float *w4, const float *b4, const float *w6,
+                         const float *b6, double *loss_slabs, const float *decoded, const float *x, const float *mask,
+                         int mask_channels, const float *channel_var, const float *gscale_dev, float *g2,
+                         double *part_slabs, float *w_slabs, int B, int C2, int NIN, int H2, int W2, void *stream)
+{
+    DM_REQUIRE(d2 && w4 && b4 && w6 && x && channel_var && gscale_dev && g2 && part_slabs && w_slabs, "%s: NULL pointer", who);
+    DM_REQUIRE(fused ? loss_slabs != nullptr : decoded != nullptr, "%s: NULL pointer", who);
+    DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "%s: mask channels %d", who, mask_channels);
+    if (tail_checks(who, B, C2, NIN, H2, W2)) return -1;
+    const int ntiles = B * (H2 / TT_TH), grid = tail_grid_bwd(ntiles), nslabs = tail_grid(ntiles);
+    const double inv_count = 1.0 / ((double)B * NIN * (2.0 * H2) * (2.0 * W2));
+    hipStream_t st = (hipStream_t)stream;
+#define DM_TB(N_, F_) hipLaunchKernelGGL((dec_tail_backward_kernel<N_, F_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, \
+                                         w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
+                                         part_slabs, w_slabs, H2, ntiles, inv_count, nslabs)
+    if (fused) {
+        switch (NIN) { case 1: DM_TB(1, true); break; case 2: DM_TB(2, true); break; case 3: DM_TB(3, true); break; default: DM_TB(4, true); }
+    } else {
+        switch (NIN) { case 1: DM_TB(1, false); break; case 2: DM_TB(2, false); break; case 3: DM_TB(3, false); break; default: DM_TB(4, false); }
+    }
+#undef DM_TB
+    return dm_launch_status(who);
+}
+}  // namespace
+
 extern "C" int dm_dec_tail_backward(const float *d2, const float *w4, const float *b4, const float *w6,
                                     const float *decoded, const float *x, const float *mask, int mask_channels,
                                     const float *channel_var, const float *gscale_dev, float *g2, double *part_slabs,
                                     float *w_slabs, int B, int C2, int NIN, int H2, int W2, void *stream)
 {
-    DM_REQUIRE(d2 && w4 && b4 && w6 && decoded && x && channel_var && gscale_dev && g2 && part_slabs && w_slabs,
-               "dm_dec_tail_backward: NULL pointer");
-    DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "dm_dec_tail_backward: mask channels %d", mask_channels);
-    if (tail_checks("dm_dec_tail_backward", B, C2, NIN, H2, W2)) return -1;
-    const int ntiles = B * (H2 / TT_TH), grid = tail_grid_bwd(ntiles), nslabs = tail_grid(ntiles);
-    const double inv_count = 1.0 / ((double)B * NIN * (2.0 * H2) * (2.0 * W2));
-    hipStream_t st = (hipStream_t)stream;
-#define DM_TB(N_) hipLaunchKernelGGL((dec_tail_backward_kernel<N_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, w6, \
-                                     decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, part_slabs, w_slabs, \
-                                     H2, ntiles, inv_count, nslabs)
-    switch (NIN) { case 1: DM_TB(1); break; case 2: DM_TB(2); break; case 3: DM_TB(3); break; default: DM_TB(4); }
-#undef DM_TB
-    return dm_launch_status("dm_dec_tail_backward");
+    return tail_backward_launch("dm_dec_tail_backward", false, d2, w4, b4, w6, nullptr, nullptr, decoded, x, mask,
+                                mask_channels, channel_var, gscale_dev, g2, part_slabs, w_slabs, B, C2, NIN, H2, W2, stream);
+}
+
+extern "C" int dm_dec_tail_train(const float *d2, const float *w4, const float *b4, const float *w6, const float *b6,
+                                 const float *x, const float *mask, int mask_channels, const float *channel_var,
+                                 const float *gscale_dev, float *g2, double *part_slabs, float *w_slabs,
+                                 double *loss_slabs, int B, int C2, int NIN, int H2, int W2, void *stream)
+{
+    return tail_backward_launch("dm_dec_tail_train", true, d2, w4, b4, w6, b6, loss_slabs, nullptr, x, mask,
+                                mask_channels, channel_var, gscale_dev, g2, part_slabs, w_slabs, B, C2, NIN, H2, W2, stream);
 }

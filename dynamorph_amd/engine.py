@@ -229,7 +229,10 @@ def vq_forward(codebook, z, commitment_cost, want_out=True):
 
 
 # -------------------------------------------------------------------------------- decoder
-def decoder_forward(L, zq, x=None, mask=None):
+def decoder_forward(L, zq, x=None, mask=None, defer_tail=False):
+    """defer_tail (training pass only): when the fused tail is available, leave dec.4/dec.6 and the reconstruction
+    loss to decoder_backward, which then runs them together with their backward in one kernel
+    (ops.dec_tail_train); `decoded` is not produced and cx.loss_slabs is filled by decoder_backward."""
     B, nh, H3, W3 = zq.shape
     c1, c2 = nh // 2, nh // 4
     d0, _ = ops.conv3x3(Op(zq), weight_view(_w(L.dec0.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H3, W3, taps=9,
@@ -238,6 +241,9 @@ def decoder_forward(L, zq, x=None, mask=None):
                         pixel_shuffle=True, bias=_w(L.dec2.bias), relu=True)
     var = _w(L.channel_var).reshape(-1)
     fused = ops.dec_tail_supported(c2, L.dec6.weight.shape[0], 4 * H3, 4 * W3)
+    if fused and defer_tail and x is not None:
+        cx = SimpleNamespace(zq=zq, d0=d0, d2=d2, d4=None, dec=None, x=x, mask=mask, loss_slabs=None, deferred=True)
+        return None, cx
     if fused:
         # dec.4 + ReLU + dec.6 (+ loss) in one kernel; the 4 x 128 x 128 tensor d4 is never stored
         d4 = None
@@ -246,7 +252,7 @@ def decoder_forward(L, zq, x=None, mask=None):
     else:
         d4 = _dec4_forward(L, d2)
         dec, slabs = ops.head_forward(d4, _w(L.dec6.weight), _w(L.dec6.bias), x, mask, var)
-    cx = SimpleNamespace(zq=zq, d0=d0, d2=d2, d4=d4, dec=dec, x=x, mask=mask, loss_slabs=slabs)
+    cx = SimpleNamespace(zq=zq, d0=d0, d2=d2, d4=d4, dec=dec, x=x, mask=mask, loss_slabs=slabs, deferred=False)
     return dec, cx
 
 
@@ -266,7 +272,14 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
     NIN = L.dec6.weight.shape[0]
     var = _w(L.channel_var).reshape(-1)
     pending = []
-    if cx.d4 is None and gdec_ext is None and gscale is not None:
+    if cx.deferred:
+        if gdec_ext is not None or gscale is None:
+            raise ValueError("decoder_backward: a deferred tail takes the reconstruction-loss gradient only")
+        g2, part, wsl, cx.loss_slabs = ops.dec_tail_train(cx.d2, _w(L.dec4.weight), _w(L.dec4.bias), _w(L.dec6.weight),
+                                                          _w(L.dec6.bias), cx.x, cx.mask, var, gscale)
+        ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias), G(L.dec2.bias)])
+        pending.append((wsl, G(L.dec4.weight)))
+    elif cx.d4 is None and gdec_ext is None and gscale is not None:
         # fused tail: recompute d4 from d2, g4 lives only in LDS
         g2, part, wsl = ops.dec_tail_backward(cx.d2, _w(L.dec4.weight), _w(L.dec4.bias), _w(L.dec6.weight), cx.dec, cx.x,
                                               cx.mask, var, gscale)

@@ -314,6 +314,24 @@ def dec_tail_backward(d2, w4, b4, w6, dec, x, mask, channel_var, gscale):
     return g2, part, wsl
 
 
+def dec_tail_train(d2, w4, b4, w6, b6, x, mask, channel_var, gscale):
+    """Forward loss + backward of the decoder tail in one kernel (no `decoded`).
+    Returns (g2, part, w_slabs, loss_slabs)."""
+    lib = L.load()
+    B, C2, H2, W2 = d2.shape
+    NIN = w6.shape[0]
+    nb = lib.dm_dec_tail_num_blocks(B, H2, W2)
+    g2 = torch.empty_like(d2)
+    part = _new((nb, NIN * C2 + NIN + 2 * C2, 2), d2, torch.float64)
+    wsl = _new((nb, C2 * C2 * 16), d2)
+    loss = _new((nb,), d2, torch.float64)
+    mc = mask.shape[1] if mask is not None else 0
+    L.check(lib.dm_dec_tail_train(_ptr(d2), _ptr(w4), _ptr(b4), _ptr(w6), _ptr(b6), _ptr(x), _ptr(mask), mc,
+                                  _ptr(channel_var), _ptr(gscale), _ptr(g2), _ptr(part, torch.float64), _ptr(wsl),
+                                  _ptr(loss, torch.float64), B, C2, NIN, H2, W2, _stream()), "dm_dec_tail_train")
+    return g2, part, wsl, loss
+
+
 def reduce_slabs(slabs, dst):
     lib = L.load()
     L.check(lib.dm_reduce_slabs(_ptr(slabs), slabs.shape[0], slabs.shape[1], _ptr(dst), _stream()), "dm_reduce_slabs")

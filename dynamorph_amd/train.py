@@ -70,11 +70,12 @@ class FusedTrainer:
         cc = float(model.commitment_cost)
         z, ecx = E.encoder_forward(L, x)
         zq, idx, vsc = E.vq_forward(L.codebook.weight, z, cc)
-        dec, dcx = E.decoder_forward(L, zq, x, mask)
+        # the tail of the decoder (dec.4, dec.6, loss) runs inside decoder_backward, fused with its own backward
+        dec, dcx = E.decoder_forward(L, zq, x, mask, defer_tail=True)
         B, NIN, H, W = x.shape
+        g_zq = E.decoder_backward(L, dcx, self.w_recon, None, self.G)
         scalars = ops.loss_finalize(dcx.loss_slabs, B * NIN * H * W, vsc, float(model.weight_recon),
                                     float(model.weight_commitment))
-        g_zq = E.decoder_backward(L, dcx, self.w_recon, None, self.G)
         gcb = self.G(L.codebook.weight)
         gcb.zero_()
         dz, _ = ops.vq_backward(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc, dw=gcb)

@@ -231,6 +231,15 @@ int dm_dec_tail_backward(const float *d2, const float *w4, const float *b4, cons
                          const float *decoded, const float *x, const float *mask, int mask_channels,
                          const float *channel_var, const float *gscale_dev, float *g2, double *part_slabs,
                          float *w_slabs, int B, int C2, int NIN, int H2, int W2, void *stream);
+/* Training pass of the decoder tail: dm_dec_tail_forward's loss and dm_dec_tail_backward's gradients in ONE kernel
+ * (run_training.py:404-406: model(batch) -> total_loss.backward()).  The reconstruction-loss gradient needs no
+ * global reduction, so `decoded` (vq_vae.py:298,319) is formed per tile in LDS, used for the loss partials and for
+ * g_dec, and never written: 262 144 B/patch (d2 + x read, g2 written) instead of 720 896 for the two kernels.
+ *   loss_slabs [nblocks] doubles as in dm_dec_tail_forward; the other outputs as in dm_dec_tail_backward. */
+int dm_dec_tail_train(const float *d2, const float *w4, const float *b4, const float *w6, const float *b6,
+                      const float *x, const float *mask, int mask_channels, const float *channel_var,
+                      const float *gscale_dev, float *g2, double *part_slabs, float *w_slabs, double *loss_slabs,
+                      int B, int C2, int NIN, int H2, int W2, void *stream);
 /* dst[e] = sum over slabs of slabs[slab][e], fixed order (bitwise reproducible). */
 int dm_reduce_slabs(const float *slabs, int nslabs, int E, float *dst, void *stream);
 /* The same for up to 16 (slabs, dst) pairs in ONE launch: the weight gradients of a whole backward pass. */

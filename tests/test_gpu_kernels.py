@@ -457,3 +457,19 @@ def test_dec_tail_fused_forward_backward(ops, nin, masked, B):
     dw4b = torch.empty_like(dw4)
     ops.reduce_slabs(wsl2, dw4b)
     assert torch.equal(g2b, g2) and torch.equal(dw4b, dw4), "fused tail must be bitwise reproducible"
+
+    # training pass: the loss of the forward kernel and the gradients of the backward kernel from ONE kernel
+    g2t, part_t, wsl_t, loss_t = ops.dec_tail_train(dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], mk, dv[6],
+                                                    torch.tensor([0.7], device=DEV))
+    recon_t = ops.loss_finalize(loss_t, x.numel(), torch.zeros(2, device=DEV), 1.0, 0.0)[0]
+    assert abs(float(recon_t) - float(loss_ref)) <= 3e-6 * abs(float(loss_ref))
+    flat_t = torch.empty_like(flat)
+    ops.sum_slabs(part_t, flat_t)
+    dw4t = torch.empty_like(dw4)
+    ops.reduce_slabs(wsl_t, dw4t)
+    close(g2t, pre.grad, 1e-4, 2e-5 * sc(pre.grad), "train: g2")
+    close(dw4t, w4.grad, 1e-4, 1e-4 * sc(w4.grad), "train: dW4")
+    close(flat_t[:nin * c].reshape(nin, c), w6.grad.reshape(nin, c), 1e-4, 1e-4 * sc(w6.grad), "train: dW6")
+    close(flat_t[nin * c:nin * c + nin], b6.grad, 1e-4, 1e-4 * sc(b6.grad), "train: db6")
+    close(flat_t[nin * c + nin:nin * c + nin + c], b4.grad, 1e-4, 1e-4 * sc(b4.grad), "train: db4")
+    close(flat_t[nin * c + nin + c:], pre.grad.sum((0, 2, 3)), 1e-4, 1e-4 * sc(pre.grad.sum((0, 2, 3))), "train: db2")

@@ -39,6 +39,7 @@ var = torch.ones(2, device=dev); gs = torch.ones(1, device=dev)
 dec, _ = ops.dec_tail_forward(d2, w4, b4, w6, b6, x, None, var)
 cases["tail_fwd"] = (lambda: ops.dec_tail_forward(d2, w4, b4, w6, b6, x, None, var), B * 327680)
 cases["tail_bwd"] = (lambda: ops.dec_tail_backward(d2, w4, b4, w6, dec, x, None, var, gs), B * 393216)
+cases["tail_train"] = (lambda: ops.dec_tail_train(d2, w4, b4, w6, b6, x, None, var, gs), B * 262144)
 
 src = torch.randn(64 << 20, device=dev); dst = torch.empty_like(src)          # 256 MiB each: past the Infinity Cache
 cases["copy_calib"] = (lambda: torch.add(src, 1.0, out=dst), 2 * src.numel() * 4)            # known bytes: calibrates the PMC counters

@@ -15,7 +15,8 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 KEYS = {                       # key in the JSON -> substring of the kernel name
-    "dec_tail_backward": "dec_tail_backward_kernel",
+    "dec_tail_train": "true>(float const",            # dec_tail_backward_kernel<NIN, true>
+    "dec_tail_backward": "false>(float const",        # dec_tail_backward_kernel<NIN, false>
     "dec_tail_forward": "dec_tail_forward_kernel",
     "conv4x4s2_e1": "conv4x4s2_kernel",
     "copy_calib": "elementwise_kernel",
