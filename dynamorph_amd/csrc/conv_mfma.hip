@@ -46,25 +46,48 @@ enum { SIDE_NONE = 0, SIDE_MASK = 1, SIDE_ALL = 2 };
 template <int SIDE> struct EpiIn { f32x4 m; };
 template <> struct EpiIn<SIDE_ALL> { f32x4 m, r, q; };
 
-template <int SIDE>
-__device__ __forceinline__ void epilogue_loads(EpiIn<SIDE> &e, const Epilogue &ep, int off, bool valid)
+// Output and side tensors go through buffer descriptors rebased to the tile's sample, with NO lane predicate and no
+// branch: a lane without an output channel (n >= NOUT) carries a byte offset beyond the descriptor, so its loads
+// return 0 and its stores vanish; an absent tensor gets an empty descriptor.  With every memory operation issued
+// unconditionally the compiler knows how many stores follow the next tile's loads and waits for the loads alone
+// (s_waitcnt vmcnt(#stores)) instead of draining the stores of the finished tile before the next commit.
+constexpr unsigned DM_RSRC_FLAGS = 0x00020000u;       // raw buffer, 32-bit data format (gfx9 family)
+constexpr int DM_VOFF_NONE = 0x40000000;              // byte offset no sample reaches (checked on the host)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sample_rsrc(const float *base, long long sample_elems, int b)
 {
-    if constexpr (SIDE != SIDE_NONE) {
-        e.m = (f32x4){1.f, 1.f, 1.f, 1.f};
-        if (valid && ep.mask.p0) e.m = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + off);
+    return base ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + sample_elems * b), 0,
+                                                    (int)(sample_elems * 4), DM_RSRC_FLAGS)
+                : __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, DM_RSRC_FLAGS);
+}
+
+template <int SIDE> struct EpiCtx {
+    __amdgpu_buffer_rsrc_t out_r, m_r, r_r, q_r;
+    __device__ __forceinline__ void rebase(const Epilogue &ep, float *out, long long sample_elems, int b)
+    {
+        out_r = sample_rsrc(out, sample_elems, b);
+        if constexpr (SIDE != SIDE_NONE) m_r = sample_rsrc(ep.mask.p0, sample_elems, b);
+        if constexpr (SIDE == SIDE_ALL) {
+            r_r = sample_rsrc(ep.resid, sample_elems, b);
+            q_r = sample_rsrc(ep.stat_q, sample_elems, b);
+        }
     }
+};
+
+template <int SIDE>
+__device__ __forceinline__ void epilogue_loads(EpiIn<SIDE> &e, const EpiCtx<SIDE> &cx, int voff)
+{
+    if constexpr (SIDE != SIDE_NONE) e.m = __builtin_amdgcn_raw_buffer_load_b128(cx.m_r, voff, 0, 0);
     if constexpr (SIDE == SIDE_ALL) {
-        e.r = (f32x4){0.f, 0.f, 0.f, 0.f};
-        e.q = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (valid && ep.resid) e.r = *reinterpret_cast<const f32x4 *>(ep.resid + off);
-        if (valid && ep.stat_q) e.q = *reinterpret_cast<const f32x4 *>(ep.stat_q + off);
+        e.r = __builtin_amdgcn_raw_buffer_load_b128(cx.r_r, voff, 0, 0);
+        e.q = __builtin_amdgcn_raw_buffer_load_b128(cx.q_r, voff, 0, 0);
     }
 }
 
-// mask coefficients (c0, c2) of the lane's output channel: keep v where c0*m + c2 > 0
+// mask coefficients (c0, c2) of the lane's output channel: keep v where c0*m + c2 > 0 (no mask tensor: 0*m + 1)
 __device__ __forceinline__ void mask_coef(const Epilogue &ep, int b, int chan, float &c0, float &c2)
 {
-    c0 = 1.f; c2 = 0.f;
+    c0 = ep.mask.p0 ? 1.f : 0.f; c2 = ep.mask.p0 ? 0.f : 1.f;
     if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) {
         const float *cf = ep.mask.coef + (long long)b * ep.mask.coef_bstride + chan * 4;
         c0 = cf[0]; c2 = cf[2];
@@ -73,19 +96,17 @@ __device__ __forceinline__ void mask_coef(const Epilogue &ep, int b, int chan, f
 
 // v: 4 consecutive output elements (along x) at element offset `off`.
 template <int SIDE>
-__device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, const EpiIn<SIDE> &e, float mc0, float mc2,
-                                              float *__restrict__ out, int off, double &s1, double &s2)
+__device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, const EpiCtx<SIDE> &cx, const EpiIn<SIDE> &e,
+                                              float mc0, float mc2, int voff, double &s1, double &s2)
 {
     f32x4 q = v;
     if constexpr (SIDE != SIDE_NONE) {
-        if (ep.mask.p0) {
-            const f32x4 mv = mc0 * e.m + mc2;
-            v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
-            v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
-        }
+        const f32x4 mv = mc0 * e.m + mc2;
+        v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+        v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
     }
     if constexpr (SIDE == SIDE_ALL) v += e.r;
-    *reinterpret_cast<f32x4 *>(out + off) = v;
+    __builtin_amdgcn_raw_buffer_store_b128(v, cx.out_r, voff, 0, 0);
     if (ep.stats) {
         q = v;
         if constexpr (SIDE == SIDE_MASK) { if (ep.stat_q) q = e.m; }
@@ -194,10 +215,15 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
     for (int t = 0; t < NT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
     const int abase = 2 * m + kq + 3;
     auto off = [](int s) { return (s >> 2) * PS + (s & 3) * RS; };
+    EpiCtx<SIDE> cx;
+    const long long sample_elems = (long long)NOUT * Ho * Wo;
+    int chan_off[NT];                                      // byte offset of the lane's channel plane (+ its x quad)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) chan_off[t] = 16 * t + m < NOUT ? ((16 * t + m) * Ho * Wo + 4 * kq) * 4 : DM_VOFF_NONE;
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile consumed; coefficient table visible
-        stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+        stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4, in.mode);
         __syncthreads();
         const int cb = b, cy0 = oy0, cx0 = ox0;            // the tile now in LDS
         const int next = tidx + gridDim.x;
@@ -212,6 +238,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
 #pragma unroll
             for (int t = 0; t < NT; ++t) mask_coef(ep, cb, 16 * t + m < NOUT ? 16 * t + m : 0, mc0[t], mc2[t]);
         }
+        cx.rebase(ep, out, sample_elems, cb);
         for (int p = 0; p < MTW / MP; ++p) {
             const float *ap[MP];
             int o[MP][NT];
@@ -223,9 +250,8 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
                 ap[i] = tile + (2 * r) * RS + 32 * cg + abase;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int n = 16 * t + m;
-                    o[i][t] = ((cb * NOUT + n) * Ho + (cy0 + r)) * Wo + cx0 + 16 * cg + 4 * kq;
-                    epilogue_loads<SIDE>(e[i][t], ep, o[i][t], n < NOUT);
+                    o[i][t] = chan_off[t] + ((cy0 + r) * Wo + cx0 + 16 * cg) * 4;
+                    epilogue_loads<SIDE>(e[i][t], cx, o[i][t]);
                 }
             }
             f32x4 acc[MP][NT];
@@ -238,9 +264,8 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
             for (int i = 0; i < MP; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (16 * t + m < NOUT)
-                        epilogue_tail<SIDE>(bias_relu(acc[i][t], ep, bias[t]), ep, e[i][t], mc0[t], mc2[t], out, o[i][t],
-                                            s1[t], s2[t]);
+                    epilogue_tail<SIDE>(bias_relu(acc[i][t], ep, bias[t]), ep, cx, e[i][t], mc0[t], mc2[t], o[i][t],
+                                        s1[t], s2[t]);
         }
         tidx = next;
     }
@@ -287,6 +312,9 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
         return 4 * cg4 * PS + (TAPS == 9 ? (tap / 3) * RS + tap % 3 : 0);
     };
 
+    EpiCtx<SIDE> cx;
+    const long long sample_elems = (long long)CO * OH * OW;
+
     // NPASS > 1 (more output-channel tiles than fit in registers): the tile walk is repeated per pass
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -326,9 +354,21 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
             }
         }
 
+        int chan_off[NT];                                  // byte offset of the lane's channel plane, phase row / x quad
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = 16 * (pass * NT + t) + m;
+            if (PIX) {
+                const int nb = n >> 2, py = (n >> 1) & 1, px = n & 1;
+                chan_off[t] = n < NOUT ? ((nb * OH + py) * OW + 8 * kq + 4 * px) * 4 : DM_VOFF_NONE;
+            } else {
+                chan_off[t] = n < NOUT ? (n * OH * OW + 4 * kq) * 4 : DM_VOFF_NONE;
+            }
+        }
+
         while (tidx < ntiles) {
             __syncthreads();
-            stage.commit(tile, s_coef, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
+            stage.commit(tile, s_coef, Cphys, H, W, y0 - PADR, x0 - 4 * PADR, in.mode);
             __syncthreads();
             const int cb = b, cy0 = y0, cx0 = x0;
             const int next = tidx + gridDim.x;
@@ -346,6 +386,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                     mask_coef(ep, cb, n < NOUT ? (PIX ? n >> 2 : n) : 0, mc0[t], mc2[t]);
                 }
             }
+            cx.rebase(ep, out, sample_elems, cb);
             for (int p = 0; p < MTW / MP; ++p) {
                 const float *ap[MP];
                 int o[MP][NT];
@@ -357,14 +398,9 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                     ap[i] = tile + r * RS + 16 * cg + abase;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const int n = 16 * (pass * NT + t) + m;
-                        if (PIX) {
-                            const int nb = n >> 2, py = (n >> 1) & 1, px = n & 1;
-                            o[i][t] = ((cb * CO + nb) * OH + 2 * (cy0 + r) + py) * OW + 2 * (cx0 + 16 * cg + 4 * kq) + 4 * px;
-                        } else {
-                            o[i][t] = ((cb * CO + n) * OH + (cy0 + r)) * OW + cx0 + 16 * cg + 4 * kq;
-                        }
-                        epilogue_loads<SIDE>(e[i][t], ep, o[i][t], n < NOUT);
+                        if (PIX) o[i][t] = chan_off[t] + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
+                        else o[i][t] = chan_off[t] + ((cy0 + r) * OW + cx0 + 16 * cg) * 4;
+                        epilogue_loads<SIDE>(e[i][t], cx, o[i][t]);
                     }
                 }
                 f32x4 acc[MP][NT];
@@ -385,7 +421,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                             const f32x4 pv = lane_xor1(v);
                             v = (n & 1) ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
                         }
-                        if (n < NOUT) epilogue_tail<SIDE>(v, ep, e[i][t], mc0[t], mc2[t], out, o[i][t], s1[tt], s2[tt]);
+                        epilogue_tail<SIDE>(v, ep, cx, e[i][t], mc0[t], mc2[t], o[i][t], s1[tt], s2[tt]);
                     }
             }
             tidx = next;
@@ -506,6 +542,7 @@ static int conv_common_checks(const char *who, const dm_operand *in, const dm_we
     DM_REQUIRE((long long)B * (CIN > NOUT ? CIN : NOUT) * H * W * 4 < (1LL << 31),
                "%s: tensor too large for 32-bit offsets", who);
     DM_REQUIRE(CIN - (in->ones_channel ? 1 : 0) > 0, "%s: no physical input channel", who);
+    DM_REQUIRE((long long)NOUT * H * W * 4 < DM_VOFF_NONE, "%s: one output sample must stay below 1 GiB", who);
     if (ep && ep->mask.p0 && dm_check_operand(&ep->mask, who)) return -1;
     DM_REQUIRE(!(ep && ep->mask.p0 && ep->mask.ones_channel), "%s: mask operand cannot have a ones channel", who);
     DM_REQUIRE(!(ep && ep->mask.p0 && ep->mask.mode != DM_LOAD_IDENT && ep->mask.mode != DM_LOAD_AFFINE),

@@ -147,7 +147,7 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA / sD
-        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 1, 0);
+        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 1, 0, DM_LOAD_IDENT);
         __syncthreads();
         const int cb = b, cy0 = y0;
         const int next = tidx + gridDim.x;
@@ -346,7 +346,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA and sG
-        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 2, 0);
+        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 2, 0, DM_LOAD_IDENT);
         __syncthreads();
         const int cb = b, cy0 = y0;
         const int next = tidx + gridDim.x;

@@ -75,9 +75,34 @@ struct TileStage {
         }
     }
 
+    // mode: the operand's load mode (workgroup uniform).  IDENT tiles skip the transform altogether (their padding is
+    // already zero: issue() leaves unloaded elements at 0); RELU tiles only clamp; the AFFINE family takes the
+    // per-channel coefficients from the LDS table.
     __device__ __forceinline__ void commit(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
-                                           int H, int W, int gy0, int gx0)
+                                           int H, int W, int gy0, int gx0, int mode)
     {
+        if (mode == DM_LOAD_IDENT || mode == DM_LOAD_RELU) {
+            const float fl = mode == DM_LOAD_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int mt = meta[k];
+                f32x4 val = v[k];
+                if (mode == DM_LOAD_RELU) {
+                    // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
+                    val.x = val.x < fl ? fl : val.x; val.y = val.y < fl ? fl : val.y;
+                    val.z = val.z < fl ? fl : val.z; val.w = val.w < fl ? fl : val.w;
+                }
+                const int c = (mt >> 26) & 63;
+                if (c >= Cphys) {                          // synthetic ones channel: 1 inside the image, 0 in the padding
+                    const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63;
+                    const int gy = gy0 + r, gx = gx0 + 4 * j4;
+                    const float one = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1.f : 0.f;
+                    val = (f32x4){one, one, one, one};
+                }
+                if (mt >= 0) *reinterpret_cast<f32x4 *>(lds + (mt & 0x3fff)) = val;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const int mt = meta[k];
@@ -87,12 +112,13 @@ struct TileStage {
             f32x4 val;
             if (c < Cphys) {
                 const f32x4 cf = *reinterpret_cast<const f32x4 *>(s_coef + c * 4);
-                val = cf.x * v[k] + cf.z;
+                // padding: v (and u) are 0 there, so only the shift has to go; relu_floor <= 0 leaves the 0 alone
+                const float cz = inside ? cf.z : 0.f;
+                val = cf.x * v[k] + cz;
                 if (TWO) val += cf.y * u[k];
                 // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
                 val.x = val.x < cf.w ? cf.w : val.x; val.y = val.y < cf.w ? cf.w : val.y;
                 val.z = val.z < cf.w ? cf.w : val.z; val.w = val.w < cf.w ? cf.w : val.w;
-                if (!inside) val = (f32x4){0.f, 0.f, 0.f, 0.f};
             } else {
                 const float one = inside ? 1.f : 0.f;
                 val = (f32x4){one, one, one, one};

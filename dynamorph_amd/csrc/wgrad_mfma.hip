@@ -88,8 +88,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
     }
     while (tile < ntiles) {
         __syncthreads();                             // previous tile fully consumed; coefficient tables visible
-        stS.commit(sS, s_coefS, CS, Hs, Ws, cy0, cx0);
-        stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
+        stS.commit(sS, s_coefS, CS, Hs, Ws, cy0, cx0, S.mode);
+        stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD, T.mode);
         __syncthreads();
         const int next = tile + gridDim.x;
         if (next < ntiles) {
