@@ -26,21 +26,19 @@ extern "C" int dm_version(void) { return DM_VERSION; }
 
 namespace {
 
-// One block per channel.  Batch mode: all slabs form one group.  Per-sample mode: thread t
-// owns samples t, t+256, ... (each has slabs_per_group slabs), then thread 0 replays the
-// running-statistics recurrence sample by sample, as B successive batch-of-one calls would.
+// Batch mode: one block per channel, all slabs form one group.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const double *__restrict__ stats, int nslabs, int spg, int C, long long count,
+    const double *__restrict__ stats, int nslabs, int C, long long count,
     const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
-    float momentum, float eps, float *__restrict__ coef, float *__restrict__ saved, int per_sample)
+    float momentum, float eps, float *__restrict__ coef, float *__restrict__ saved)
 {
     __shared__ double s_red[4];
     const int c = blockIdx.x;
     const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
     const double n = (double)count;
     const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
-    if (!per_sample) {
+    {
         double s1 = 0.0, s2 = 0.0;
         for (int i = threadIdx.x; i < nslabs; i += blockDim.x) {
             s1 += stats[((long long)i * C + c) * 2 + 0];
@@ -69,39 +67,67 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         }
         return;
     }
-    const int B = nslabs / spg;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = 0; i < spg; ++i) {
-            s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
-            s2 += stats[((long long)(b * spg + i) * C + c) * 2 + 1];
-        }
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float mean_f = (float)mean;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float scale = g * invstd;
-        float *cf = coef + ((long long)b * C + c) * 4;
-        cf[0] = scale; cf[1] = 0.f; cf[2] = bt - mean_f * scale; cf[3] = (float)(var * unbias);
-        saved[((long long)b * C + c) * 2 + 0] = mean_f;
-        saved[((long long)b * C + c) * 2 + 1] = invstd;
+}
+
+// Per-sample mode (process_VAE: every patch is its own batch), first half: one thread per (sample, channel) sums that
+// sample's slabs_per_group slabs and writes its coefficients; coef[..][3] carries the unbiased variance to the replay.
+__global__ __launch_bounds__(256) void bn_finalize_per_sample_kernel(
+    const double *__restrict__ stats, int B, int spg, int C, long long count, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float eps, float *__restrict__ coef, float *__restrict__ saved)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const double n = (double)count;
+    const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < spg; ++i) {
+        s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
+        s2 += stats[((long long)(b * spg + i) * C + c) * 2 + 1];
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (running_mean && running_var) {
-            float rm = running_mean[c], rv = running_var[c];
-            for (int b = 0; b < B; ++b) {
-                rm = momentum * saved[((long long)b * C + c) * 2 + 0] + (1.f - momentum) * rm;
-                rv = momentum * coef[((long long)b * C + c) * 4 + 3] + (1.f - momentum) * rv;
-            }
-            running_mean[c] = rm;
-            running_var[c] = rv;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mean_f = (float)mean;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = g * invstd;
+    *reinterpret_cast<f32x4 *>(coef + (long long)idx * 4) = (f32x4){scale, 0.f, bt - mean_f * scale, (float)(var * unbias)};
+    saved[(long long)idx * 2 + 0] = mean_f;
+    saved[(long long)idx * 2 + 1] = invstd;
+}
+
+// Second half: the running statistics after B successive batch-of-one calls (the recurrence is sequential in b, so
+// the block first stages the channel's per-sample values in LDS and one thread replays them), then coef[..][3] = 0.
+constexpr int REPLAY_CHUNK = 2048;
+__global__ __launch_bounds__(256) void bn_running_replay_kernel(
+    int B, int C, float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
+    float momentum, float *__restrict__ coef, const float *__restrict__ saved)
+{
+    __shared__ float s_mean[REPLAY_CHUNK], s_var[REPLAY_CHUNK];
+    const int c = blockIdx.x;
+    const bool track = running_mean && running_var;
+    float rm = track ? running_mean[c] : 0.f, rv = track ? running_var[c] : 0.f;
+    for (int b0 = 0; b0 < B; b0 += REPLAY_CHUNK) {
+        const int nb = B - b0 < REPLAY_CHUNK ? B - b0 : REPLAY_CHUNK;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+            s_mean[i] = saved[((long long)(b0 + i) * C + c) * 2 + 0];
+            s_var[i] = coef[((long long)(b0 + i) * C + c) * 4 + 3];
         }
+        __syncthreads();
+        if (threadIdx.x == 0 && track) {
+            for (int i = 0; i < nb; ++i) {
+                rm = momentum * s_mean[i] + (1.f - momentum) * rm;
+                rv = momentum * s_var[i] + (1.f - momentum) * rv;
+            }
+        }
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) coef[((long long)(b0 + i) * C + c) * 4 + 3] = 0.f;
+    }
+    if (threadIdx.x == 0) {
+        if (track) { running_mean[c] = rm; running_var[c] = rv; }
         if (nbt && c == 0) nbt[0] += B;
     }
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) coef[((long long)b * C + c) * 4 + 3] = 0.f;
 }
 
 // slabs hold (sum dy, sum dy*a).  x_hat = (a - mean)*invstd, so
@@ -224,9 +250,18 @@ extern "C" int dm_bn_finalize(const double *stats, int nslabs, int slabs_per_gro
     DM_REQUIRE(nslabs > 0 && C > 0 && count_per_group > 0, "dm_bn_finalize: bad sizes");
     DM_REQUIRE(!per_sample || (slabs_per_group > 0 && nslabs % slabs_per_group == 0),
                "dm_bn_finalize: nslabs %d not a multiple of slabs_per_group %d", nslabs, slabs_per_group);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslabs,
-                       slabs_per_group, C, (long long)count_per_group, gamma, beta, running_mean, running_var,
-                       (long long *)num_batches_tracked, momentum, eps, coef, saved, per_sample);
+    if (per_sample) {
+        const int B = nslabs / slabs_per_group;
+        DM_REQUIRE((long long)B * C < (1LL << 30), "dm_bn_finalize: too many (sample, channel) pairs");
+        hipLaunchKernelGGL(bn_finalize_per_sample_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           stats, B, slabs_per_group, C, (long long)count_per_group, gamma, beta, eps, coef, saved);
+        hipLaunchKernelGGL(bn_running_replay_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, running_mean,
+                           running_var, (long long *)num_batches_tracked, momentum, coef, saved);
+        return dm_launch_status("dm_bn_finalize");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslabs, C,
+                       (long long)count_per_group, gamma, beta, running_mean, running_var,
+                       (long long *)num_batches_tracked, momentum, eps, coef, saved);
     return dm_launch_status("dm_bn_finalize");
 }
 
