@@ -55,6 +55,39 @@ struct TileStage {
         }
     }
 
+    // ---- one element at a time, through buffer descriptors -------------------------------------------------
+    // A CU keeps only so many bytes in flight: a workgroup that issues a whole tile's loads in one burst stalls
+    // at the issue point until earlier requests return (measured: 24-38 % of a wave's time in the conv and
+    // weight-gradient kernels).  begin() prepares the tile's descriptors, issue_one(k) requests element k; the
+    // kernels call it between the MFMA steps of the current tile so the requests trickle out under the matrix
+    // work.  Elements outside the image (and every element when there is no next tile: empty descriptor) carry
+    // an out-of-range offset -> the load returns 0 without a branch, which is exactly the zero padding.
+    struct Ctx {
+        __amdgpu_buffer_rsrc_t r0, r1;
+        int H, W, Cphys, gy0, gx0;
+    };
+    __device__ __forceinline__ Ctx begin(const Operand &op, bool live, int b, int Cphys, int H, int W, int gy0, int gx0) const
+    {
+        Ctx cx;
+        const long long se = (long long)Cphys * H * W;
+        const int bytes = live ? (int)(se * 4) : 0;
+        cx.r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(op.p0 + se * b), 0, bytes, 0x00020000);
+        cx.r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((TWO && op.p1 ? op.p1 : op.p0) + se * b), 0,
+                                                  (TWO && op.p1) ? bytes : 0, 0x00020000);
+        cx.H = H; cx.W = W; cx.Cphys = Cphys; cx.gy0 = gy0; cx.gx0 = gx0;
+        return cx;
+    }
+    __device__ __forceinline__ void issue_one(int k, const Ctx &cx)
+    {
+        const int mt = meta[k];
+        const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63, c = (mt >> 26) & 63;
+        const int gy = cx.gy0 + r, gx = cx.gx0 + 4 * j4;
+        const bool ok = mt >= 0 && c < cx.Cphys && (unsigned)gy < (unsigned)cx.H && (unsigned)gx < (unsigned)cx.W;
+        const int voff = ok ? ((c * cx.H + gy) * cx.W + gx) * 4 : 0x7ffffff0;
+        v[k] = __builtin_amdgcn_raw_buffer_load_b128(cx.r0, voff, 0, 0);
+        if (TWO) u[k] = __builtin_amdgcn_raw_buffer_load_b128(cx.r1, voff, 0, 0);
+    }
+
     __device__ __forceinline__ void issue(const Operand &op, int b, int Cphys, int H, int W, int gy0, int gx0)
     {
         // tensors stay below 2^31 elements (checked on the host): 32-bit element offsets

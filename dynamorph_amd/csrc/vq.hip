@@ -38,9 +38,8 @@ __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__
 // the first NaN wins (vq_vae.py:68).
 __device__ __forceinline__ bool vq_better(float cand, float best)
 {
-    if (best != best) return false;
-    if (cand != cand) return true;
-    return cand < best;
+    // best is a number AND (cand is NaN OR cand < best); bitwise so that no branch splits the loop body
+    return (best == best) & !(cand >= best);
 }
 
 // PP positions per lane (pos, pos + 256, ...): every codebook operand fetched from LDS is used PP times.
@@ -50,7 +49,7 @@ __device__ __forceinline__ bool vq_better(float cand, float best)
 // (s_load) operands cannot be pipelined that way (SMEM returns out of order: every wait is lgkmcnt(0)), which
 // left the first version of this kernel 58 % parked on s_waitcnt.
 template <int D, int PP>
-__global__ __launch_bounds__(VQ_BLOCK) void vq_forward_kernel(
+__global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : 2)) void vq_forward_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbT,
     long long *__restrict__ idx, float *__restrict__ out, double *__restrict__ sse_slabs,
     int *__restrict__ hist, int K, int HW, long long P)
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_forward_kernel(
     float bestd[PP];
     int bi[PP];
 #pragma unroll
-    for (int q = 0; q < PP; ++q) { bestd[q] = 0.f; bi[q] = 0; }
+    for (int q = 0; q < PP; ++q) { bestd[q] = __builtin_inff(); bi[q] = 0; }
     const int npairs = K >> 1;
     for (int c0 = 0; c0 < npairs; c0 += CHUNK_PAIRS) {
         const int cn = min(CHUNK_PAIRS, npairs - c0);
@@ -97,16 +96,39 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_forward_kernel(
                 f32x2 acc[PP];
 #pragma unroll
                 for (int q = 0; q < PP; ++q) acc[q] = (f32x2){0.f, 0.f};
+                // the additions of a block are a sequential chain (ATen's order); the subtractions and squares are
+                // not, so they are formed eight d at a time ahead of the chain to keep independent work in the pipe
 #pragma unroll
-                for (int d = d0; d < d0 + 16 && d < D; ++d) {
-                    const f32x2 e2 = *reinterpret_cast<const f32x2 *>(e + 2 * d);
+                for (int h = d0; h < d0 + 16 && h < D; h += 8) {
+                    // (the empty asm statements pin each stage: hipcc otherwise sinks every sub and mul next to its add
+                    // and runs sub -> mul -> add per d on two registers, each instruction waiting for the previous one)
+                    f32x2 sq[PP][8];
 #pragma unroll
-                    for (int q = 0; q < PP; ++q) {
-                        const f32x2 zz = {zr[q][d], zr[q][d]};
-                        const f32x2 diff = zz - e2;
-                        const f32x2 sq = diff * diff;
-                        acc[q] = acc[q] + sq;
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x2 e2 = *reinterpret_cast<const f32x2 *>(e + 2 * (h + j));
+#pragma unroll
+                        for (int q = 0; q < PP; ++q) {
+                            const f32x2 zz = {zr[q][h + j], zr[q][h + j]};
+                            sq[q][j] = zz - e2;
+                        }
                     }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int q = 0; q < PP; ++q) asm volatile("" : "+v"(sq[q][j]));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int q = 0; q < PP; ++q) sq[q][j] = sq[q][j] * sq[q][j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int q = 0; q < PP; ++q) asm volatile("" : "+v"(sq[q][j]));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int q = 0; q < PP; ++q)
+                            acc[q] = (h == d0 && j == 0) ? sq[q][0] : acc[q] + sq[q][j];   // 0 + s == s for a square (never -0)
                 }
 #pragma unroll
                 for (int q = 0; q < PP; ++q) total[q] = (d0 == 0) ? acc[q] : total[q] + acc[q];
@@ -114,9 +136,11 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_forward_kernel(
             const int k0 = 2 * (c0 + kp);
 #pragma unroll
             for (int q = 0; q < PP; ++q) {
-                if (k0 == 0) { bestd[q] = total[q].x; bi[q] = 0; }
-                else if (vq_better(total[q].x, bestd[q])) { bestd[q] = total[q].x; bi[q] = k0; }
-                if (vq_better(total[q].y, bestd[q])) { bestd[q] = total[q].y; bi[q] = k0 + 1; }
+                // bestd starts at +inf with index 0: code 0 wins unless a later code is strictly smaller (or NaN)
+                const bool b0 = vq_better(total[q].x, bestd[q]);
+                bestd[q] = b0 ? total[q].x : bestd[q]; bi[q] = b0 ? k0 : bi[q];
+                const bool b1 = vq_better(total[q].y, bestd[q]);
+                bestd[q] = b1 ? total[q].y : bestd[q]; bi[q] = b1 ? k0 + 1 : bi[q];
             }
         }
     }
@@ -136,8 +160,8 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_forward_kernel(
                 }
                 total = (d0 == 0) ? acc : total + acc;
             }
-            if (k == 0) { bestd[q] = total; bi[q] = 0; }
-            else if (vq_better(total, bestd[q])) { bestd[q] = total; bi[q] = k; }
+            const bool bt = vq_better(total, bestd[q]);
+            bestd[q] = bt ? total : bestd[q]; bi[q] = bt ? k : bi[q];
         }
     }
 

@@ -92,16 +92,23 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
         stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD, T.mode);
         __syncthreads();
         const int next = tile + gridDim.x;
-        if (next < ntiles) {
-            int tid = next;
+        {
+            int tid = next < ntiles ? next : tile;       // (no next tile: empty descriptors, every load returns 0)
             const int tx = tid % tiles_x; tid /= tiles_x;
             cy0 = (tid % tiles_y) * TH; cb = tid / tiles_y; cx0 = tx * TW;
-            stS.issue(S, cb, CS, Hs, Ws, cy0, cx0);
-            stT.issue(T, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
+        }
+        // the next tile's loads are requested element by element between the MFMA steps below (tile.h: issue_one)
+        const auto cxS = stS.begin(S, next < ntiles, cb, CS, Hs, Ws, cy0, cx0);
+        const auto cxT = stT.begin(T, next < ntiles, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
+        if (next < ntiles) {
             stage_coef(s_coefS, S, cb, CS);
             stage_coef(s_coefT, T, cb, CTphys);
         }
-        for (int r = wave; r < TH; r += 4) {
+        constexpr int NES = decltype(stS)::N, NET = decltype(stT)::N, NE = NES + NET;
+        constexpr int ROWS_W = TH / 4, NSTEPS = ROWS_W * (TW / 4);
+#pragma unroll
+        for (int ri = 0; ri < ROWS_W; ++ri) {
+            const int r = wave + 4 * ri;
             // software pipeline over the position steps of a row: operands of step x4+1 are requested before
             // the MFMAs of step x4 (two register buffers, order pinned with sched_barrier)
             float a[2][MT], bv[2][NTT];
@@ -117,6 +124,16 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
                     for (int i = 0; i < MT; ++i) a[(x4 + 1) & 1][i] = sS[aoff[i] + ra + 4 * (x4 + 1)];
 #pragma unroll
                     for (int t = 0; t < NTT; ++t) bv[(x4 + 1) & 1][t] = sT[boff[t] + rb + 4 * (x4 + 1) * STRIDE];
+                }
+                {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int s = ri * (TW / 4) + x4;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e)
+                        if (e >= s * NE / NSTEPS && e < (s + 1) * NE / NSTEPS) {
+                            if (e < NES) stS.issue_one(e, cxS);
+                            else stT.issue_one(e - NES, cxT);
+                        }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
