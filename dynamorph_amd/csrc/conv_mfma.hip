@@ -227,19 +227,25 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
         __syncthreads();
         const int cb = b, cy0 = oy0, cx0 = ox0;            // the tile now in LDS
         const int next = tidx + gridDim.x;
-        if (next < ntiles) {                               // next tile's loads fly during this tile's MFMAs
-            int t = next;
+        {                                                  // (no next tile: empty descriptor, every load returns 0)
+            int t = next < ntiles ? next : tidx;
             ox0 = (t % tiles_x) * TW; t /= tiles_x;
             oy0 = (t % tiles_y) * TH; b = t / tiles_y;
-            stage.issue(in, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
-            stage_coef(s_coef, in, b, Cphys);
         }
+        // the next tile's loads are requested element by element between the M tiles below (tile.h: issue_one)
+        const auto scx = stage.begin(in, next < ntiles, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+        if (next < ntiles) stage_coef(s_coef, in, b, Cphys);
         if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) mask_coef(ep, cb, 16 * t + m < NOUT ? 16 * t + m : 0, mc0[t], mc2[t]);
         }
         cx.rebase(ep, out, sample_elems, cb);
-        for (int p = 0; p < MTW / MP; ++p) {
+        constexpr int NP = MTW / MP, NE = decltype(stage)::N;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (e >= p * NE / NP && e < (p + 1) * NE / NP) stage.issue_one(e, scx);
             const float *ap[MP];
             int o[MP][NT];
             EpiIn<SIDE> e[MP][NT];
@@ -372,13 +378,14 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
             __syncthreads();
             const int cb = b, cy0 = y0, cx0 = x0;
             const int next = tidx + gridDim.x;
-            if (next < ntiles) {
-                int t = next;
+            {                                              // (no next tile: empty descriptor, every load returns 0)
+                int t = next < ntiles ? next : tidx;
                 x0 = (t % tiles_x) * TW; t /= tiles_x;
                 y0 = (t % tiles_y) * TH; b = t / tiles_y;
-                stage.issue(in, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
-                stage_coef(s_coef, in, b, Cphys);
             }
+            // the next tile's loads are requested element by element between the M tiles below (tile.h: issue_one)
+            const auto scx = stage.begin(in, next < ntiles, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
+            if (next < ntiles) stage_coef(s_coef, in, b, Cphys);
             if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -387,7 +394,12 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                 }
             }
             cx.rebase(ep, out, sample_elems, cb);
-            for (int p = 0; p < MTW / MP; ++p) {
+            constexpr int NP = MTW / MP, NE = decltype(stage)::N;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    if (e >= p * NE / NP && e < (p + 1) * NE / NP) stage.issue_one(e, scx);
                 const float *ap[MP];
                 int o[MP][NT];
                 EpiIn<SIDE> e[MP][NT];
@@ -470,7 +482,7 @@ constexpr int conv_wps(int lds_bytes, int weights, int tile_f4, bool two, int mp
     const int stage = ((tile_f4 + DM_BLOCK - 1) / DM_BLOCK) * (two ? 9 : 5);
     const int epi = mp * nt * (6 + (side == SIDE_ALL ? 12 : (side == SIDE_MASK ? 4 : 0)));
     const int est = weights + stage + epi + 48;
-    return clampi(lds_wgs(lds_bytes), 1, est > 150 ? 2 : 3);
+    return clampi(lds_wgs(lds_bytes), 1, est > 145 ? 2 : 3);
 }
 
 int conv4_tw(int CIN, int Wo)
