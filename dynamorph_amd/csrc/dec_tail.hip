@@ -326,22 +326,35 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     // ahead and only CONSUMED in phase B (consuming them earlier would put the s_waitcnt right after the issue).
     constexpr int BR = (GROWS + 3) / 4;
     f32x2 rdv[BR][NIN], rxv[BR][NIN];
-    auto issue_rows = [&](int tb, int ty0) {
-#pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const int gr = wave + 4 * j, oy = 2 * ty0 - 1 + gr;
-#pragma unroll
-            for (int c = 0; c < NIN; ++c) {
-                rdv[j][c] = (f32x2){0.f, 0.f}; rxv[j][c] = (f32x2){0.f, 0.f};
-                if (gr < GROWS && oy >= 0 && oy < OH) {
-                    const int off = ((tb * NIN + c) * OH + oy) * OW + 2 * lane;
-                    if (!FUSED) rdv[j][c] = *reinterpret_cast<const f32x2 *>(decp + off);
-                    rxv[j][c] = *reinterpret_cast<const f32x2 *>(x + off);
-                }
-            }
-        }
+    // one (row, channel) at a time through buffer descriptors rebased to the sample: rows outside the image (and
+    // every row when there is no next tile: empty descriptor) get an out-of-range offset and read as 0.  The
+    // requests are spread over the MFMA (weight-gradient) phase instead of going out in one burst (a CU keeps only so many bytes
+    // in flight; a burst stalls the wave at the issue point).
+    struct RowCtx { __amdgpu_buffer_rsrc_t rx, rd; int ty0; };
+    auto rows_begin = [&](bool live, int tb, int ty0) {
+        RowCtx rc;
+        const long long se = (long long)NIN * OH * OW;
+        const int bytes = live ? (int)(se * 4) : 0;
+        rc.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + se * tb), 0, bytes, 0x00020000);
+        rc.rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((FUSED ? x : decp) + se * tb), 0, FUSED ? 0 : bytes,
+                                                  0x00020000);
+        rc.ty0 = ty0;
+        return rc;
     };
-    if (tidx < ntiles) issue_rows(b, y0);
+    auto issue_row = [&](const RowCtx &rc, int j, int c) {
+        const int gr = wave + 4 * j, oy = 2 * rc.ty0 - 1 + gr;
+        const bool ok = gr < GROWS && (unsigned)oy < (unsigned)OH;
+        const int voff = ok ? ((c * OH + oy) * OW + 2 * lane) * 4 : 0x7ffffff0;
+        if (!FUSED) rdv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rd, voff, 0, 0);
+        rxv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rx, voff, 0, 0);
+    };
+    {
+        const RowCtx rc0 = rows_begin(tidx < ntiles, b, y0);
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+#pragma unroll
+            for (int c = 0; c < NIN; ++c) issue_row(rc0, j, c);
+    }
     double loss = 0.0;
 
     while (tidx < ntiles) {
@@ -350,10 +363,8 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         __syncthreads();
         const int cb = b, cy0 = y0;
         const int next = tidx + gridDim.x;
-        if (next < ntiles) {
-            y0 = (next % tiles_y) * TT_TH; b = next / tiles_y;
-            stage.issue(in, b, TT_C, H2, TT_W, y0 - 2, 0);
-        }
+        if (next < ntiles) { y0 = (next % tiles_y) * TT_TH; b = next / tiles_y; }
+        const auto scx = stage.begin(in, next < ntiles, b, TT_C, H2, TT_W, y0 - 2, 0);   // requested during phase A
 
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
         {
@@ -366,6 +377,12 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         load_row(sA, APS, 2, lane, nv);
 #pragma unroll
         for (int pr = 0; pr <= TT_TH; ++pr) {         // y = y0 + pr -> g4-tile rows 2pr (d4 row 2y-1) and 2pr+1 (row 2y)
+            {
+                constexpr int NE = decltype(stage)::N;
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    if (e >= pr * NE / (TT_TH + 1) && e < (pr + 1) * NE / (TT_TH + 1)) stage.issue_one(e, scx);
+            }
             make_row_pairs(nv, C);
             if (pr < TT_TH) load_row(sA, APS, pr + 3, lane, nv);
             __builtin_amdgcn_sched_barrier(0);
@@ -433,7 +450,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             }
         }
         if (FUSED) loss += (double)tl.x + (double)tl.y;
-        if (next < ntiles) issue_rows(b, y0);              // next tile's rows fly during the dgrad / wgrad phases
+        const RowCtx rcn = rows_begin(next < ntiles, b, y0);   // next tile's rows: requested during the wgrad phase
         __syncthreads();
 
         // ---- phase 3: data gradient of dec.4 for input channel ci = wave:  g2[ci][y][x] = sum_co,ky,kx
@@ -488,11 +505,20 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         // ---- phase 4 (MFMA): weight gradient of dec.4 (wgrad_steps).  Position rows Yr = 0..TH: this wave takes rows
         //      wave and wave+4 whole and a quarter of row TH.  Row 0 has no own d2 row for sy = 1, row TH none for sy = 0.
         {
+            constexpr int NR = BR * NIN;                   // next tile's (row, channel) requests, a third before each part
+            auto issue_part = [&](int part) {
+#pragma unroll
+                for (int e = 0; e < NR; ++e)
+                    if (e >= part * NR / 3 && e < (part + 1) * NR / 3) issue_row(rcn, e / NIN, e % NIN);
+            };
             const float rm0 = (wave == 0 && wsy == 1) ? 0.f : 1.f;
+            issue_part(0);
             wgrad_steps<17, true, true>(sA, sG, wa_base + wave * TT_W, wb_base + 2 * wave * TT_DRS, rm0, w_first_bad,
                                         w_last_ok, wacc);
+            issue_part(1);
             wgrad_steps<17, true, true>(sA, sG, wa_base + (wave + 4) * TT_W, wb_base + 2 * (wave + 4) * TT_DRS, 1.f,
                                         w_first_bad, w_last_ok, wacc);
+            issue_part(2);
             const float rm8 = wsy == 1 ? 1.f : 0.f;
             const int a8 = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
             if (wave < 3)
