@@ -445,6 +445,164 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
     }
 }
 
+// ============================================================================ kernel C
+// ConvTranspose2d(4,2,1) decomposed by output phase.  The 3x3-neighbourhood formulation of kernel B multiplies every
+// phase (py,px) by all 9 taps although it only touches 2x2 of them (5/9 of its MFMA work is zero weights).  Here
+//   COUT = 16: one N tile per phase (n = co), K = CIN x its 2x2 taps          -> 4 x CIN   MFMAs per 16 positions (9 x CIN there)
+//   COUT =  8: one N tile per phase ROW py (n = px*8 + co), K = CIN x 2x3 taps -> 3 x CIN                      (4.5 x CIN there)
+// The A operand is no longer shared between N tiles (each phase reads its own shifted window), which costs LDS reads,
+// not matrix-pipe time -- and these kernels are matrix-pipe bound (60-70 % busy).
+// Output: the two x phases of a row are interleaved in registers (COUT = 16: both live in the lane, two 16-byte
+// stores per row; COUT = 8: lanes m and m^8 swap halves, one store), so stores stay 16 contiguous bytes per lane.
+template <int CIN, int COUT, int TH, int TW, bool TWO, int SIDE, int WPS>
+__global__ __launch_bounds__(DM_BLOCK, WPS)
+void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int H, int W,
+                        int ntiles, int nslabs)
+{
+    static_assert(COUT == 8 || COUT == 16, "built for 8 or 16 output channels");
+    constexpr int IH = TH + 2, RS = TW + 8, COLS4 = RS / 4;
+    constexpr int PSRAW = IH * RS;
+    constexpr int PS = PSRAW + ((16 - (PSRAW % 32)) + 32) % 32;      // PS == 16 (mod 32)
+    constexpr int CG = TW / 16, MT = TH * CG, MTW = MT / 4, MP = 2;
+    constexpr int NPX = COUT == 16 ? 2 : 1;                // N tiles per phase row
+    constexpr int TAPX = COUT == 16 ? 2 : 3;               // x taps per N tile
+    constexpr int KS = (CIN / 4) * 2 * TAPX;               // K steps per N tile
+    static_assert(CIN % 4 == 0 && MTW % MP == 0 && MTW >= MP, "shape");
+    __shared__ __attribute__((aligned(16))) float tile[CIN * PS];
+    __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
+    __shared__ double s_stat[4 * 16][2];
+
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int OH = 2 * H, OW = 2 * W;
+    const int co = COUT == 16 ? m : (m & 7), pxl = COUT == 16 ? 0 : (m >> 3);   // lane's channel, x phase (COUT = 8)
+
+    TileStage<CIN, IH, COLS4, RS, PS, TWO> stage;
+    stage.init();
+    int tidx = blockIdx.x, b = 0, y0 = 0, x0 = 0;
+    if (tidx < ntiles) {
+        int t = tidx;
+        x0 = (t % tiles_x) * TW; t /= tiles_x;
+        y0 = (t % tiles_y) * TH; b = t / tiles_y;
+        stage.issue(in, b, Cphys, H, W, y0 - 1, x0 - 4);
+        stage_coef(s_coef, in, b, Cphys);
+    }
+
+    // weights of N tile (py, pxt): step s = (cg4, a, bb) <-> input channel 4*cg4 + kq, tap row py + a, tap column
+    // (COUT = 16: pxt + bb, COUT = 8: bb); ky = py + 3 - 2*row, kx = px + 3 - 2*col (zero when outside 0..3)
+    float wreg[2][NPX][1][KS];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int pxt = 0; pxt < NPX; ++pxt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                const int c = 4 * cg4 + kq;
+                const int px = COUT == 16 ? pxt : pxl;
+                const int row = py + a, col = COUT == 16 ? pxt + bb : bb;
+                const int ky = py + 3 - 2 * row, kx = px + 3 - 2 * col;
+                float wvl = 0.f;
+                if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
+                wreg[py][pxt][0][s] = wvl;
+            }
+    const float bias = ep.bias ? ep.bias[co] : 0.f;
+    float mc0, mc2;
+    mask_coef(ep, 0, co, mc0, mc2);
+
+    double s1 = 0.0, s2 = 0.0;
+    const int abase = kq * PS + m + 3;
+    EpiCtx<SIDE> cx;
+    const long long sample_elems = (long long)COUT * OH * OW;
+    // byte offset of the lane's channel plane + its 8 (COUT = 16) or 4 (COUT = 8) output columns of a 16-position group
+    const int chan_off = (co * OH * OW + 8 * kq + 4 * pxl) * 4;
+
+    while (tidx < ntiles) {
+        __syncthreads();
+        stage.commit(tile, s_coef, Cphys, H, W, y0 - 1, x0 - 4, in.mode);
+        __syncthreads();
+        const int cb = b, cy0 = y0, cx0 = x0;
+        const int next = tidx + gridDim.x;
+        {                                              // (no next tile: empty descriptor, every load returns 0)
+            int t = next < ntiles ? next : tidx;
+            x0 = (t % tiles_x) * TW; t /= tiles_x;
+            y0 = (t % tiles_y) * TH; b = t / tiles_y;
+        }
+        const auto scx = stage.begin(in, next < ntiles, b, Cphys, H, W, y0 - 1, x0 - 4);
+        if (next < ntiles) stage_coef(s_coef, in, b, Cphys);
+        if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) mask_coef(ep, cb, co, mc0, mc2);
+        cx.rebase(ep, out, sample_elems, cb);
+        constexpr int NP = MTW / MP, NE = decltype(stage)::N;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (e >= p * NE / NP && e < (p + 1) * NE / NP) stage.issue_one(e, scx);
+            const float *ap[MP];
+            int obase[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) {
+                const int ti = wave + 4 * (MP * p + i);
+                const int r = ti / CG, cg = ti % CG;
+                ap[i] = tile + r * RS + 16 * cg + abase;
+                obase[i] = chan_off + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
+            }
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                EpiIn<SIDE> e[MP][NPX];
+#pragma unroll
+                for (int i = 0; i < MP; ++i)
+#pragma unroll
+                    for (int h = 0; h < NPX; ++h) epilogue_loads<SIDE>(e[i][h], cx, obase[i] + py * OW * 4 + 16 * h);
+                f32x4 acc[NPX][MP][1];
+#pragma unroll
+                for (int pxt = 0; pxt < NPX; ++pxt) {
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) acc[pxt][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    auto off = [py, pxt](int s) {
+                        const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                        return 4 * cg4 * PS + (py + a) * RS + (COUT == 16 ? pxt + bb : bb);
+                    };
+                    mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py][pxt], acc[pxt], off);
+                }
+#pragma unroll
+                for (int i = 0; i < MP; ++i) {
+                    if constexpr (COUT == 16) {
+                        const f32x4 v0 = bias_relu(acc[0][i][0], ep, bias), v1 = bias_relu(acc[1][i][0], ep, bias);
+                        epilogue_tail<SIDE>((f32x4){v0.x, v1.x, v0.y, v1.y}, ep, cx, e[i][0], mc0, mc2,
+                                            obase[i] + py * OW * 4, s1, s2);
+                        epilogue_tail<SIDE>((f32x4){v0.z, v1.z, v0.w, v1.w}, ep, cx, e[i][1], mc0, mc2,
+                                            obase[i] + py * OW * 4 + 16, s1, s2);
+                    } else {
+                        const f32x4 v = bias_relu(acc[0][i][0], ep, bias);
+                        const f32x4 pv = lane_xor8(v);     // partner lane holds the other x phase of the same channel
+                        epilogue_tail<SIDE>(pxl ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y}, ep, cx,
+                                            e[i][0], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
+                    }
+                }
+            }
+        }
+        tidx = next;
+    }
+    if (ep.stats) {
+        // channel of a lane: m (COUT = 16) or m & 7 (COUT = 8: lanes m and m^8 hold the two x phases)
+        double a = s1, c = s2;
+        a += __shfl_xor(a, 16, 64); c += __shfl_xor(c, 16, 64);
+        a += __shfl_xor(a, 32, 64); c += __shfl_xor(c, 32, 64);
+        if (COUT == 8) { a += __shfl_xor(a, 8, 64); c += __shfl_xor(c, 8, 64); }
+        if (lane < COUT) { s_stat[wave * 16 + lane][0] = a; s_stat[wave * 16 + lane][1] = c; }
+        __syncthreads();
+        if (threadIdx.x < COUT) {
+            double ta = 0.0, tc = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { ta += s_stat[w * 16 + threadIdx.x][0]; tc += s_stat[w * 16 + threadIdx.x][1]; }
+            ep.stats[((long long)blockIdx.x * COUT + threadIdx.x) * 2 + 0] = ta;
+            ep.stats[((long long)blockIdx.x * COUT + threadIdx.x) * 2 + 1] = tc;
+        }
+        zero_unowned_slabs(ep, COUT, nslabs);
+    }
+}
+
 // ------------------------------------------------------------------------------ dispatch
 struct ConvArgs {
     Operand in; WeightView wv; float *out; Epilogue ep;
@@ -541,6 +699,29 @@ void launch_conv3(const ConvArgs &a)
 #undef DM_L3
 }
 
+template <int CIN, int COUT, int TW>
+void launch_convT_phase(const ConvArgs &a)
+{
+    constexpr int TH = conv3_th(TW, CIN);
+    constexpr int F4 = CIN * (TH + 2) * ((TW + 8) / 4), LDS = 16 * F4 + 2048;
+    constexpr int KSW = (CIN / 4) * (COUT == 16 ? 4 : 6) * (COUT == 16 ? 4 : 2);      // weight registers
+    const int ntiles = a.B * (a.H / TH) * (a.W / TW);
+    const int side = side_mode(a.ep);
+    const bool two = a.in.mode == DM_LOAD_AFFINE2;
+#define DM_LP(TWO_, SIDE_)                                                                                        \
+    {                                                                                                             \
+        constexpr int WPS = clampi(conv_wps(LDS, KSW, F4, TWO_, 2, COUT == 16 ? 2 : 1, SIDE_), 1, 2);             \
+        hipLaunchKernelGGL((convT_phase_kernel<CIN, COUT, TH, TW, TWO_, SIDE_, WPS>),                             \
+                           dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
+                           a.out, a.ep, a.Cphys, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));               \
+    }
+    if (!two && side == SIDE_NONE) DM_LP(false, SIDE_NONE)
+    else if (!two && side == SIDE_MASK) DM_LP(false, SIDE_MASK)
+    else if (two && side != SIDE_ALL) DM_LP(true, SIDE_MASK)
+    else DM_LP(true, SIDE_ALL)
+#undef DM_LP
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -618,6 +799,15 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
                (hipStream_t)stream};
     const int NTT = (NOUT + 15) / 16;
     const bool pix = pixel_shuffle != 0;
+    // ConvTranspose2d with 16 input and 8 / 16 output channels (dec.0, data gradients of enc.4 / enc.7): phase-decomposed
+    // kernel C; per-tile statistics slabs (per-sample BatchNorm) stay with the neighbourhood kernel B
+#define DM_CP(CO, T)                                                                       \
+    if (pix && CIN == 16 && NOUT == 4 * CO && TW == T && !a.per_tile) {                    \
+        launch_convT_phase<16, CO, T>(a);                                                  \
+        return dm_launch_status("dm_conv3x3");                                             \
+    }
+    DM_CP(8, 16) DM_CP(8, 32) DM_CP(16, 16) DM_CP(16, 32)
+#undef DM_CP
 #define DM_C3(C, NTOT, NT_, NP_, TP, PX, T)                                                \
     if (CIN == C && NTT == NTOT && taps == TP && pix == PX && TW == T) {                   \
         launch_conv3<C, NT_, NP_, TP, PX, T>(a);                                           \
