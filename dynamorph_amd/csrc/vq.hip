@@ -228,40 +228,53 @@ __global__ void vq_finalize_kernel(const double *__restrict__ sse_slabs, int nsl
     }
 }
 
+// 1024-thread workgroups walking the positions with a grid stride: the codebook gradient is accumulated in LDS
+// over ALL of a workgroup's positions and flushed once, so the global float atomics (K*D addresses that every
+// workgroup hits) number grid*K*D instead of (P/256)*K*D -- at B = 2048 that flush, not the streaming, was the cost.
+constexpr int VQ_BWD_BLOCK = 1024;
 template <int D>
-__global__ __launch_bounds__(VQ_BLOCK) void vq_backward_kernel(
+__global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const long long *__restrict__ idx,
     const float *__restrict__ g_out, const float *__restrict__ g_loss_dev, float cc,
     float *__restrict__ dz, float *__restrict__ dw, int K, int HW, long long P, int use_lds)
 {
     extern __shared__ float s_dw[];    // [K][D] when use_lds
     if (use_lds) {
-        for (int i = threadIdx.x; i < K * D; i += VQ_BLOCK) s_dw[i] = 0.f;
+        for (int i = threadIdx.x; i < K * D; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
         __syncthreads();
     }
     const float g_loss = g_loss_dev ? g_loss_dev[0] : 1.f;
     const double N = (double)P * (double)D;
     const float sz = (float)(2.0 * (double)cc / N) * g_loss;   // d/dz of cc * mse(q.detach(), z)
     const float sw = (float)(2.0 / N) * g_loss;                // d/dq of mse(q, z.detach())
-    const long long pos = (long long)blockIdx.x * VQ_BLOCK + threadIdx.x;
-    if (pos < P) {
+    for (long long pos = (long long)blockIdx.x * VQ_BWD_BLOCK + threadIdx.x; pos < P;
+         pos += (long long)gridDim.x * VQ_BWD_BLOCK) {
         const long long b = pos / HW, p = pos - b * HW;
         const long long base = b * (long long)D * HW + p;
         const long long k = idx[pos];
         const float *__restrict__ q = cb + k * D;
+        constexpr int DC = D < 16 ? D : 16;                // d in chunks of 16 (register budget of a 1024-thread group)
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const long long o = base + (long long)d * HW;
-            const float zv = z[o], qv = q[d];
-            if (dz) dz[o] = (g_out ? g_out[o] : 0.f) + sz * (zv - qv);
-            const float gw = sw * (qv - zv);
-            if (use_lds) atomicAdd(&s_dw[k * D + d], gw);
-            else atomicAdd(&dw[k * D + d], gw);
+        for (int d0 = 0; d0 < D; d0 += DC) {
+            float zv[DC], gv[DC], qv[DC];
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {                 // all loads of the chunk first: one round trip, not DC
+                const long long o = base + (long long)(d0 + j) * HW;
+                zv[j] = z[o]; qv[j] = q[d0 + j];
+                gv[j] = g_out ? g_out[o] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                if (dz) dz[base + (long long)(d0 + j) * HW] = gv[j] + sz * (zv[j] - qv[j]);
+                const float gw = sw * (qv[j] - zv[j]);
+                if (use_lds) atomicAdd(&s_dw[k * D + d0 + j], gw);
+                else atomicAdd(&dw[k * D + d0 + j], gw);
+            }
         }
     }
     if (use_lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < K * D; i += VQ_BLOCK) {
+        for (int i = threadIdx.x; i < K * D; i += VQ_BWD_BLOCK) {
             const float v = s_dw[i];
             if (v != 0.f) atomicAdd(&dw[i], v);
         }
@@ -341,10 +354,11 @@ extern "C" int dm_vq_backward(const float *z, const float *codebook, const int64
     const long long P = (long long)B * H * W;
     const size_t lds = (size_t)K * D * sizeof(float);
     const int use_lds = lds <= 48 * 1024;
-    const int grid = dm_vq_num_blocks(P);
+    const long long want = (P + VQ_BWD_BLOCK - 1) / VQ_BWD_BLOCK;
+    const int grid = (int)(want < 512 ? want : 512);       // two 1024-thread workgroups per CU
     hipStream_t s = (hipStream_t)stream;
 #define DM_VQ_BWD(DD)                                                                                         \
-    hipLaunchKernelGGL(vq_backward_kernel<DD>, dim3(grid), dim3(VQ_BLOCK), use_lds ? lds : 0, s, z, codebook, \
+    hipLaunchKernelGGL(vq_backward_kernel<DD>, dim3(grid), dim3(VQ_BWD_BLOCK), use_lds ? lds : 0, s, z, codebook, \
                        (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, K, H * W, P, use_lds)
     switch (D) {
     case 8: DM_VQ_BWD(8); break;
