@@ -82,13 +82,14 @@ def roofline_dominant_kernel(model, x, workload):
     B, NIN, H, W = x.shape
     if workload == "c2":
         c1 = L.nh // 2
-        weff = ops.e1_compose(L.enc0.weight.detach(), L.enc0.bias.detach(), L.enc1.weight.detach())
+        weff, border = ops.e1_compose_border(L.enc0.weight.detach(), L.enc0.bias.detach(), L.enc1.weight.detach(),
+                                             L.enc1.bias.detach())
         a1 = torch.empty(B, c1, H // 2, W // 2, device=x.device)
 
         def fn():
-            ops.conv4x4s2(Op(x, ones=True), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN + 1, c1, H, W, out=a1,
-                          want_stats=True, bias=L.enc1.bias.detach())
-        key, name = "conv4x4s2_e1", "conv4x4s2_kernel<3,1,...> (enc.0 o enc.1 composite)"
+            ops.conv4x4s2(Op(x), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN, c1, H, W, out=a1,
+                          want_stats=True, bias_border=border)
+        key, name = "conv4x4s2_e1", "conv4x4s2_kernel<2,1,...,true> (enc.0 o enc.1 composite, border-bias table)"
         algo_bytes = B * (NIN * H * W + c1 * (H // 2) * (W // 2)) * 4          # read x once, write a1 once
     else:
         c2 = L.dec4.weight.shape[0]

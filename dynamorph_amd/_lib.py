@@ -23,8 +23,8 @@ class WeightView(C.Structure):
 
 
 class Epilogue(C.Structure):
-    _fields_ = [("bias", vp), ("relu", i32), ("stats_per_tile", i32), ("mask", Operand), ("resid", vp), ("stat_q", vp),
-                ("stats", vp)]
+    _fields_ = [("bias", vp), ("bias_border", vp), ("relu", i32), ("stats_per_tile", i32), ("mask", Operand),
+                ("resid", vp), ("stat_q", vp), ("stats", vp)]
 
 
 class Scatter(C.Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "dm_reduce_slabs": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "dm_loss_finalize": (C.c_int, [vp, C.c_int, i64, vp, f32, f32, vp, vp]),
     "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "dm_e1_compose_border": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
     "dm_augment": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -170,7 +170,9 @@ __device__ __forceinline__ void zero_unowned_slabs(const Epilogue &ep, int NCH, 
 }
 
 // ============================================================================ kernel A
-template <int CIN, int NT, int TH, int TW, int SIDE, int WPS>
+// BB: per-position bias from ep.bias_border[3][3][NOUT] (first / interior / last output row x column) instead of
+// ep.bias -- the enc.0 bias seen through enc.1's zero padding, so the first conv needs no ones channel (K = 32, not 48).
+template <int CIN, int NT, int TH, int TW, int SIDE, int WPS, bool BB>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
                       int W, int ntiles, int nslabs)
@@ -198,6 +200,14 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
         stage_coef(s_coef, in, b, Cphys);
     }
 
+    static_assert(!BB || NT == 1, "bias_border: one N tile");
+    float tb00 = 0.f, tb01 = 0.f, tb02 = 0.f, tb10 = 0.f, tb11 = 0.f, tb12 = 0.f, tb20 = 0.f, tb21 = 0.f, tb22 = 0.f;
+    if constexpr (BB) {                                    // bias_border[row class][column class] of the lane's channel
+        const float *tp = ep.bias_border + (m < NOUT ? m : 0);
+        tb00 = tp[0 * NOUT]; tb01 = tp[1 * NOUT]; tb02 = tp[2 * NOUT];
+        tb10 = tp[3 * NOUT]; tb11 = tp[4 * NOUT]; tb12 = tp[5 * NOUT];
+        tb20 = tp[6 * NOUT]; tb21 = tp[7 * NOUT]; tb22 = tp[8 * NOUT];
+    }
     float wreg[NT][KS], bias[NT], mc0[NT], mc2[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -270,8 +280,23 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
             for (int i = 0; i < MP; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    epilogue_tail<SIDE>(bias_relu(acc[i][t], ep, bias[t]), ep, cx, e[i][t], mc0[t], mc2[t], o[i][t],
-                                        s1[t], s2[t]);
+                {
+                    f32x4 v = acc[i][t];
+                    if constexpr (BB) {
+                        // row class of this M tile (uniform), column class of the quad's first / last element
+                        const int ti = wave + 4 * (MP * p + i);
+                        const int y = cy0 + ti / CG, xq = cx0 + 16 * (ti % CG) + 4 * kq;
+                        const bool r0 = y == 0, r2 = y == Ho - 1;
+                        const float bl = r0 ? tb00 : (r2 ? tb20 : tb10);
+                        const float bm = r0 ? tb01 : (r2 ? tb21 : tb11);
+                        const float br = r0 ? tb02 : (r2 ? tb22 : tb12);
+                        v += (f32x4){xq == 0 ? bl : bm, bm, bm, xq + 3 == Wo - 1 ? br : bm};
+                        v = bias_relu(v, ep, 0.f);
+                    } else {
+                        v = bias_relu(v, ep, bias[t]);
+                    }
+                    epilogue_tail<SIDE>(v, ep, cx, e[i][t], mc0[t], mc2[t], o[i][t], s1[t], s2[t]);
+                }
         }
         tidx = next;
     }
@@ -658,9 +683,14 @@ void launch_conv4(const ConvArgs &a)
 #define DM_L4(SIDE_)                                                                                              \
     {                                                                                                             \
         constexpr int WPS = conv_wps(LDS, CIN * 4, F4, false, 2, 1, SIDE_);                                       \
-        hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS>), dim3(conv_grid(ntiles, WPS, a.per_tile)), \
-                           dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles,  \
-                           conv_slabs(ntiles, a.per_tile));                                                       \
+        if (SIDE_ == SIDE_NONE && CIN <= 5 && a.ep.bias_border)                                                   \
+            hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_NONE, WPS, true>),                              \
+                               dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
+                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));       \
+        else                                                                                                      \
+            hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS, false>),                                 \
+                               dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
+                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));       \
     }
     switch (side_mode(a.ep)) {
     case SIDE_NONE: DM_L4(SIDE_NONE) break;
@@ -759,6 +789,8 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
     DM_REQUIRE(H % 16 == 0 && W % 32 == 0, "dm_conv4x4s2: H must be a multiple of 16 and W of 32 (got %dx%d)", H, W);
     DM_REQUIRE(NOUT <= 16, "dm_conv4x4s2: NOUT %d > 16 not built", NOUT);
     DM_REQUIRE(in->mode != DM_LOAD_AFFINE2, "dm_conv4x4s2: AFFINE2 operand not built for this kernel");
+    DM_REQUIRE(!(ep && ep->bias_border) || (CIN <= 5 && !ep->mask.p0 && !ep->resid && !ep->stat_q && W / 2 >= 8),
+               "dm_conv4x4s2: bias_border is built for the first layer only (CIN <= 5, no side inputs)");
     const int Wo = W / 2;
     const int TW = conv4_tw(CIN, Wo);
     DM_REQUIRE(TW == 16 || TW == 32 || TW == 64, "dm_conv4x4s2: output width %d not tileable", Wo);

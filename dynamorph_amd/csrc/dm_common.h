@@ -72,6 +72,7 @@ static inline WeightView to_dev(const dm_weight_view *v)
 
 struct Epilogue {
     const float *bias;
+    const float *bias_border;
     int relu;
     Operand mask;
     const float *resid;
@@ -83,10 +84,10 @@ static inline Epilogue to_dev(const dm_epilogue *e)
 {
     Epilogue r;
     if (!e) {
-        r.bias = nullptr; r.relu = 0; r.mask = null_operand(); r.resid = nullptr; r.stat_q = nullptr; r.stats = nullptr;
+        r.bias = nullptr; r.bias_border = nullptr; r.relu = 0; r.mask = null_operand(); r.resid = nullptr; r.stat_q = nullptr; r.stats = nullptr;
         return r;
     }
-    r.bias = e->bias; r.relu = e->relu; r.mask = to_dev(&e->mask); r.resid = e->resid;
+    r.bias = e->bias; r.bias_border = e->bias_border; r.relu = e->relu; r.mask = to_dev(&e->mask); r.resid = e->resid;
     r.stat_q = e->stat_q; r.stats = e->stats;
     return r;
 }

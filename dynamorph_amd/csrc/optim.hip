@@ -36,8 +36,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 
 // Weff[c1][ci][t], ci in [0, NIN] (ci == NIN is the ones channel), t = ky*4+kx.
 __global__ void e1_compose_kernel(const float *__restrict__ w0, const float *__restrict__ b0,
-                                  const float *__restrict__ w1, float *__restrict__ weff, int NIN, int C0, int C1)
+                                  const float *__restrict__ w1, const float *__restrict__ b1, float *__restrict__ weff,
+                                  float *__restrict__ bias_border, int NIN, int C0, int C1)
 {
+    // bias_border[ry][rx][c1] = b1[c1] + sum over the taps inside the image of the ones-channel weights
+    // (row class 0 = first output row: ky = 0 falls into the padding; class 2 = last row: ky = 3 does)
+    if (bias_border) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 9 * C1; i += gridDim.x * blockDim.x) {
+            const int c1 = i % C1, rx = (i / C1) % 3, ry = i / (3 * C1);
+            double s = b1 ? (double)b1[c1] : 0.0;
+            for (int ky = (ry == 0 ? 1 : 0); ky < (ry == 2 ? 3 : 4); ++ky)
+                for (int kx = (rx == 0 ? 1 : 0); kx < (rx == 2 ? 3 : 4); ++kx)
+                    for (int c = 0; c < C0; ++c) s += (double)w1[(c1 * C0 + c) * 16 + ky * 4 + kx] * (double)b0[c];
+            bias_border[i] = (float)s;
+        }
+    }
     const int total = C1 * (NIN + 1) * 16;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int t = i & 15, ci = (i >> 4) % (NIN + 1), c1 = (i >> 4) / (NIN + 1);
@@ -116,8 +129,18 @@ extern "C" int dm_e1_compose(const float *w0, const float *b0, const float *w1, 
                              int NIN, int C0, int C1, void *stream)
 {
     DM_REQUIRE(w0 && b0 && w1 && weff && NIN > 0 && C0 > 0 && C1 > 0, "dm_e1_compose: bad argument");
-    hipLaunchKernelGGL(e1_compose_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, weff, NIN, C0, C1);
+    hipLaunchKernelGGL(e1_compose_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, (const float *)nullptr,
+                       weff, (float *)nullptr, NIN, C0, C1);
     return dm_launch_status("dm_e1_compose");
+}
+
+extern "C" int dm_e1_compose_border(const float *w0, const float *b0, const float *w1, const float *b1, float *weff,
+                                    float *bias_border, int NIN, int C0, int C1, void *stream)
+{
+    DM_REQUIRE(w0 && b0 && w1 && weff && bias_border && NIN > 0 && C0 > 0 && C1 > 0, "dm_e1_compose_border: bad argument");
+    hipLaunchKernelGGL(e1_compose_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, weff, bias_border,
+                       NIN, C0, C1);
+    return dm_launch_status("dm_e1_compose_border");
 }
 
 extern "C" int dm_e1_chain(const float *dweff, const float *w0, const float *b0, const float *w1,

@@ -88,10 +88,11 @@ def encoder_forward(L, x, per_sample=False):
     ps = per_sample
     cx = SimpleNamespace(x=x, per_sample=ps, B=B, H=H, W=W, res=[])
 
-    weff = ops.e1_compose(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight))
+    # forward: K = 16*NIN; the ones channel of the composite is folded into a per-position bias table (bias_border)
+    weff, border = ops.e1_compose_border(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight), _w(L.enc1.bias))
     H1, W1 = H // 2, W // 2
-    a1, st = ops.conv4x4s2(Op(x, ones=True), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN + 1, c1, H, W,
-                           want_stats=True, bias=_w(L.enc1.bias), per_tile=ps)
+    a1, st = ops.conv4x4s2(Op(x), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN, c1, H, W,
+                           want_stats=True, bias_border=border, per_tile=ps)
     coef1, saved1 = _bn_coef(st, L.bn1, H1 * W1 * (1 if ps else B), ps, B)
 
     H2, W2 = H1 // 2, W1 // 2

@@ -58,10 +58,10 @@ def weight_view(w, sn, sc, sky, skx, off=0):
     return WView(w, sn, sc, sky, skx, off)
 
 
-def epilogue(bias=None, relu=False, mask=None, resid=None, stat_q=None, stats=None, per_tile=False):
+def epilogue(bias=None, relu=False, mask=None, resid=None, stat_q=None, stats=None, per_tile=False, bias_border=None):
     m = mask.struct() if mask is not None else _null_operand()
-    return L.Epilogue(_ptr(bias), 1 if relu else 0, 1 if per_tile else 0, m, _ptr(resid), _ptr(stat_q),
-                      _ptr(stats, torch.float64))
+    return L.Epilogue(_ptr(bias), _ptr(bias_border), 1 if relu else 0, 1 if per_tile else 0, m, _ptr(resid),
+                      _ptr(stat_q), _ptr(stats, torch.float64))
 
 
 def _new(shape, like, dtype=torch.float32):
@@ -354,6 +354,18 @@ def e1_compose(w0, b0, w1):
     weff = _new((C1, NIN + 1, 4, 4), w1)
     L.check(lib.dm_e1_compose(_ptr(w0), _ptr(b0), _ptr(w1), _ptr(weff), NIN, C0, C1, _stream()), "dm_e1_compose")
     return weff
+
+
+def e1_compose_border(w0, b0, w1, b1):
+    """(weff, bias_border): bias_border (3, 3, C1) replaces the ones channel in the forward conv."""
+    lib = L.load()
+    C0, NIN = w0.shape[0], w0.shape[1]
+    C1 = w1.shape[0]
+    weff = _new((C1, NIN + 1, 4, 4), w1)
+    table = _new((3, 3, C1), w1)
+    L.check(lib.dm_e1_compose_border(_ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(weff), _ptr(table), NIN, C0, C1,
+                                     _stream()), "dm_e1_compose_border")
+    return weff, table
 
 
 def e1_chain(dweff, w0, b0, w1, dw0, db0, dw1):

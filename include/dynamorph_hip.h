@@ -74,6 +74,9 @@ typedef struct dm_weight_view {
  *   slabs that is (reduced by dm_bn_finalize / dm_bn_backward_finalize / dm_sum_slabs: deterministic). */
 typedef struct dm_epilogue {
     const float *bias;
+    const float *bias_border; /* dm_conv4x4s2 only, [3][3][NOUT] (row class, column class, channel) with classes
+                                 first / interior / last output row or column: replaces `bias` by a per-position bias
+                                 (the enc.0 bias seen through enc.1's zero padding, dm_e1_compose); NULL: plain bias */
     int32_t relu;
     int32_t stats_per_tile;   /* 1: one workgroup per tile, every stats slab holds that tile's sums (per-sample
                                  BatchNorm statistics); 0: persistent workgroups, most slabs are zero */
@@ -263,6 +266,12 @@ int dm_loss_finalize(const double *loss_slabs, int nslabs, int64_t count, const 
  * ones channel carries enc.0's bias through enc.1's zero padding exactly). */
 int dm_e1_compose(const float *w0, const float *b0, const float *w1, float *weff,
                   int NIN, int C0, int C1, void *stream);
+/* The same plus the forward pass's shortcut for the ones channel: out = conv(x, Weff[:, :NIN]) + bias_border where
+ * bias_border[ry][rx][c1] = b1[c1] + sum over the taps (ky,kx) that stay inside the image for an output position of
+ * row class ry / column class rx of Weff[c1][NIN][ky][kx] (4x4, stride 2, padding 1: the first row misses ky = 0,
+ * the last row ky = 3, likewise for columns).  dm_conv4x4s2 then runs K = 16*NIN instead of 16*(NIN+1). */
+int dm_e1_compose_border(const float *w0, const float *b0, const float *w1, const float *b1, float *weff,
+                         float *bias_border, int NIN, int C0, int C1, void *stream);
 /* Chain rule back to the stored parameters from dWeff. */
 int dm_e1_chain(const float *dweff, const float *w0, const float *b0, const float *w1,
                 float *dw0, float *db0, float *dw1, int NIN, int C0, int C1, void *stream);

@@ -39,8 +39,8 @@ def test_struct_layouts_match_the_header():
     from dynamorph_amd import _lib
     assert ctypes.sizeof(_lib.Operand) == 40          # 3 pointers + int64 + 2 int32
     assert ctypes.sizeof(_lib.WeightView) == 48
-    assert ctypes.sizeof(_lib.Epilogue) == 16 + 40 + 24
-    assert _lib.Epilogue.mask.offset == 16 and _lib.Epilogue.stats.offset == 72
+    assert ctypes.sizeof(_lib.Epilogue) == 24 + 40 + 24   # bias, bias_border, relu, stats_per_tile | mask | 3 pointers
+    assert _lib.Epilogue.mask.offset == 24 and _lib.Epilogue.stats.offset == 80
 
 
 def test_version_and_host_only_queries(lib):

@@ -412,6 +412,27 @@ def test_bad_arguments_raise(ops):
         ops.vq_forward(rnd(1, 16, 4, 4), rnd(4, 16))                       # CPU tensors: no fallback
 
 
+def test_e1_border_bias_table_replaces_the_ones_channel(ops):
+    """enc.1(enc.0(x)) (vq_vae.py:277-278) as ONE conv over x alone: enc.0's bias reaches the output through a
+    per-position bias table (first / interior / last row x column), bit-for-bit the same mathematics as the
+    ones-channel composite but with K = 16*NIN."""
+    B, NIN, C0, C1, H = 3, 2, 8, 8, 128
+    x = rnd(B, NIN, H, H, seed=11)
+    w0, b0 = rnd(C0, NIN, 1, 1, seed=12), rnd(C0, seed=13)
+    w1, b1 = rnd(C1, C0, 4, 4, seed=14) * 0.2, rnd(C1, seed=15)
+    ref = F.conv2d(F.conv2d(x, w0, b0), w1, b1, stride=2, padding=1)
+    dv = [t.to(DEV).contiguous() for t in (x, w0, b0, w1, b1)]
+    weff, border = ops.e1_compose_border(dv[1], dv[2], dv[3], dv[4])
+    out, st = ops.conv4x4s2(ops.Op(dv[0]), ops.weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN, C1, H, H,
+                            want_stats=True, bias_border=border)
+    close(out, ref, 2e-5, 2e-5, "border-bias composite")
+    ones, _ = ops.conv4x4s2(ops.Op(dv[0], ones=True), ops.weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN + 1, C1, H, H,
+                            bias=dv[4])
+    close(out, ones, 2e-5, 2e-5, "border-bias vs ones channel")
+    tot = torch.empty(C1, 2, device=DEV, dtype=torch.float64)
+    assert torch.allclose(st.sum(0)[:, 0].cpu(), ref.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
 # ===================================================================== fused decoder tail
 @pytest.mark.parametrize("nin,masked,B", [(2, False, 3), (2, True, 2), (4, True, 2), (1, False, 70)])
 def test_dec_tail_fused_forward_backward(ops, nin, masked, B):

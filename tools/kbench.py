@@ -29,8 +29,9 @@ cases = {}
 
 w1 = torch.randn(8, 3, 4, 4, device=dev) * 0.1; bias1 = torch.randn(8, device=dev)
 a1 = torch.empty(B, 8, 64, 64, device=dev)
-cases["e1_conv"] = (lambda: ops.conv4x4s2(Op(x, ones=True), weight_view(w1, 48, 16, 4, 1), B, 3, 8, 128, 128,
-                                          out=a1, want_stats=True, bias=bias1), B * (2 * 128 * 128 + 8 * 64 * 64) * 4)
+border1 = torch.randn(3, 3, 8, device=dev)
+cases["e1_conv"] = (lambda: ops.conv4x4s2(Op(x), weight_view(w1, 48, 16, 4, 1), B, 2, 8, 128, 128,
+                                          out=a1, want_stats=True, bias_border=border1), B * (2 * 128 * 128 + 8 * 64 * 64) * 4)
 
 d2 = torch.randn(B, 4, 64, 64, device=dev).clamp(min=0)
 w4 = torch.randn(4, 4, 4, 4, device=dev) * .3; b4 = torch.randn(4, device=dev)
