@@ -172,6 +172,137 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
     }
 }
 
+// ---- 4x4 / stride 2 with 8 S channels (enc.0 o enc.1, dec.2): the direct mapping fills only 8 of the 16 M rows.
+// Writing ky = 2*sy + py and summing over Y = y + sy instead of y,
+//     R[cs][ct][2sy+py][kx] = sum_{Y,x} S[cs][Y-sy][x] * T[ct][2Y-1+py][2x-1+kx],
+// M = (cs, sy) = 16 full rows and N = (ct, py, kx) = 8*CT columns: half the MFMAs per position step (a third with
+// the extra position row: TH+1 rows Y per tile; S rows outside the tile's own TH rows are zeroed on the A side,
+// they belong to the neighbouring tile's terms).  Each wave takes a quarter of the x steps of every row.
+template <int CT, int TH, int TW, bool STWO>
+__global__ __launch_bounds__(DM_BLOCK) void wgrad_ys_kernel(Operand S, Operand T, float *__restrict__ slabs,
+                                                            int CTphys, int Hs, int Ws, int ntiles)
+{
+    constexpr int CS = 8, KK = 4, STRIDE = 2, PAD = 1;
+    constexpr int N = CT * 8, NTT = (N + 15) / 16, NOUT = CT * 16;
+    constexpr int RSS = TW, PSS_RAW = TH * RSS, PSS = PSS_RAW + ((4 - (PSS_RAW % 32)) + 32) % 32;
+    constexpr int TROWS = TH * STRIDE + KK - STRIDE, RST = TW * STRIDE + 8 * PAD, TCOLS4 = RST / 4;
+    constexpr int PST = TROWS * RST;
+    constexpr int RED = NTT * 256;
+    constexpr int LDS_TILES = CS * PSS + CT * PST;
+    constexpr int LDS_FLOATS = LDS_TILES > RED ? LDS_TILES : RED;
+    constexpr int XW = TW / 16;                          // x steps (of 4 positions) per wave and row
+    static_assert(TW % 16 == 0 && TH % 4 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_coefS[DM_COEF_MAX_C * 4];
+    __shared__ __attribute__((aligned(16))) float s_coefT[DM_COEF_MAX_C * 4];
+    float *sS = lds, *sT = lds + CS * PSS;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int Ht = Hs * STRIDE, Wt = Ws * STRIDE;
+    const int tiles_x = Ws / TW, tiles_y = Hs / TH;
+
+    // A row m = (cs, sy): S[cs][Y - sy][x];  B column n = 16t + m = (ct, py, kx): T tile row 2Y + py, column 2x + 3 + kx
+    const int sy = m & 1;
+    const int aoff = (m >> 1) * PSS + kq + 4 * XW * wave;          // + (Y - sy) * RSS, never below row 0 (masked there)
+    int boff[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+        int n = 16 * t + m;
+        if (n >= N) n = N - 1;                           // garbage column, dropped at write time
+        boff[t] = (n >> 3) * PST + ((n >> 2) & 1) * RST + (n & 3) + 3 + 2 * kq + 8 * XW * wave;
+    }
+    f32x4 acc[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    TileStage<CS, TH, TW / 4, RSS, PSS, STWO> stS;
+    TileStage<CT, TROWS, TCOLS4, RST, PST, false> stT;
+    stS.init();
+    stT.init();
+    int tile = blockIdx.x;
+    int cb = 0, cy0 = 0, cx0 = 0;
+    if (tile < ntiles) {
+        int tid = tile;
+        const int tx = tid % tiles_x; tid /= tiles_x;
+        cy0 = (tid % tiles_y) * TH; cb = tid / tiles_y; cx0 = tx * TW;
+        stS.issue(S, cb, CS, Hs, Ws, cy0, cx0);
+        stT.issue(T, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
+        stage_coef(s_coefS, S, cb, CS);
+        stage_coef(s_coefT, T, cb, CTphys);
+    }
+    while (tile < ntiles) {
+        __syncthreads();                             // previous tile fully consumed; coefficient tables visible
+        stS.commit(sS, s_coefS, CS, Hs, Ws, cy0, cx0, S.mode);
+        stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD, T.mode);
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        {
+            int tid = next < ntiles ? next : tile;       // (no next tile: empty descriptors, every load returns 0)
+            const int tx = tid % tiles_x; tid /= tiles_x;
+            cy0 = (tid % tiles_y) * TH; cb = tid / tiles_y; cx0 = tx * TW;
+        }
+        const auto cxS = stS.begin(S, next < ntiles, cb, CS, Hs, Ws, cy0, cx0);
+        const auto cxT = stT.begin(T, next < ntiles, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
+        if (next < ntiles) {
+            stage_coef(s_coefS, S, cb, CS);
+            stage_coef(s_coefT, T, cb, CTphys);
+        }
+        constexpr int NES = decltype(stS)::N, NET = decltype(stT)::N, NE = NES + NET;
+        constexpr int NSTEPS = (TH + 1) * XW;
+        // position rows Y = 0 .. TH; operands of step s+1 are requested before the MFMAs of step s
+        float a[2], bv[2][NTT];
+        a[0] = sS[aoff];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) bv[0][t] = sT[boff[t]];
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            const int Y = s / XW, xs = s % XW;
+            if (s + 1 < NSTEPS) {
+                const int Yn = (s + 1) / XW, xn = (s + 1) % XW;
+                a[(s + 1) & 1] = sS[aoff + (Yn == 0 ? 0 : Yn * RSS - sy * RSS) + 4 * xn];
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) bv[(s + 1) & 1][t] = sT[boff[t] + 2 * Yn * RST + 8 * xn];
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (e >= s * NE / NSTEPS && e < (s + 1) * NE / NSTEPS) {
+                    if (e < NES) stS.issue_one(e, cxS);
+                    else stT.issue_one(e - NES, cxT);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            float av = a[s & 1];
+            if (Y == 0) av = sy ? 0.f : av;              // S row -1: the neighbouring tile's term
+            if (Y == TH) av = sy ? av : 0.f;             // S row TH likewise
+            (void)xs;
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s & 1][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile = next;
+    }
+
+    // combine the four waves in wave order (deterministic), then write this workgroup's slab
+    float *red = lds;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+                f32x4 *p = reinterpret_cast<f32x4 *>(red + (t * 64 + lane) * 4);
+                if (w == 0) *p = acc[t];
+                else *p = *p + acc[t];
+            }
+        }
+    }
+    __syncthreads();
+    float *slab = slabs + (long long)blockIdx.x * (CS * NOUT);
+    for (int i = threadIdx.x; i < RED; i += DM_BLOCK) {
+        const int j = i & 3, l = (i >> 2) & 63, t = i >> 8;
+        const int mm = 4 * (l >> 4) + j, n = 16 * t + (l & 15);          // M row (cs, sy), N column (ct, py, kx)
+        if (n < N) slab[(mm >> 1) * NOUT + (n >> 3) * 16 + (2 * (mm & 1) + ((n >> 2) & 1)) * 4 + (n & 3)] = red[i];
+    }
+}
+
 // dst[e] = sum over slabs, in a fixed order: 16 slab groups x 16 elements per block; each thread adds its
 // slabs (g, g+16, ...) sequentially with 4 loads in flight, the 16 group sums are then added in group order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nslabs, int E,
@@ -259,6 +390,15 @@ void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
 {
     constexpr int TH = wgrad_th(CS, CT, KK, TW);
     const int ntiles = B * (Hs / TH) * (Ws / TW);
+    if constexpr (CS == 8 && KK == 4) {
+        if (S.mode == DM_LOAD_AFFINE2)
+            hipLaunchKernelGGL((wgrad_ys_kernel<CT, TH, TW, true>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs, CTphys,
+                               Hs, Ws, ntiles);
+        else
+            hipLaunchKernelGGL((wgrad_ys_kernel<CT, TH, TW, false>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs, CTphys,
+                               Hs, Ws, ntiles);
+        return;
+    }
     if (S.mode == DM_LOAD_AFFINE2)
         hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW, true>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs,
                            CTphys, Hs, Ws, ntiles);
