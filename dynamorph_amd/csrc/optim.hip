@@ -15,9 +15,12 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, long long n,
                                                    float lr, float b1, float b2, float eps,
-                                                   const float *__restrict__ step_dev)
+                                                   const float *__restrict__ step_dev, float *__restrict__ step_next)
 {
-    const double t = (double)step_dev[0];
+    // step_next given: step_dev holds the number of COMPLETED steps, this is step t = that + 1, and t is written to
+    // step_next (a different word: the caller ping-pongs two counters, so no launch is spent on "step += 1")
+    const double t = (double)step_dev[0] + (step_next ? 1.0 : 0.0);
+    if (step_next && blockIdx.x == 0 && threadIdx.x == 0) step_next[0] = (float)t;
     const double bc1 = 1.0 - pow((double)b1, t);
     const double bc2 = 1.0 - pow((double)b2, t);
     const float step_size = (float)((double)lr / bc1);
@@ -121,8 +124,19 @@ extern "C" int dm_adam(float *param, const float *grad, float *m, float *v, int6
     DM_REQUIRE(param && grad && m && v && step_dev && n > 0, "dm_adam: bad argument");
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n, lr,
-                       beta1, beta2, eps, step_dev);
+                       beta1, beta2, eps, step_dev, (float *)nullptr);
     return dm_launch_status("dm_adam");
+}
+
+extern "C" int dm_adam_counted(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1,
+                               float beta2, float eps, const float *steps_done, float *steps_done_next, void *stream)
+{
+    DM_REQUIRE(param && grad && m && v && steps_done && steps_done_next && steps_done != steps_done_next && n > 0,
+               "dm_adam_counted: bad argument");
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n, lr,
+                       beta1, beta2, eps, steps_done, steps_done_next);
+    return dm_launch_status("dm_adam_counted");
 }
 
 extern "C" int dm_e1_compose(const float *w0, const float *b0, const float *w1, float *weff,

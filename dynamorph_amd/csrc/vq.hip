@@ -236,7 +236,8 @@ template <int D>
 __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const long long *__restrict__ idx,
     const float *__restrict__ g_out, const float *__restrict__ g_loss_dev, float cc,
-    float *__restrict__ dz, float *__restrict__ dw, int K, int HW, long long P, int use_lds)
+    float *__restrict__ dz, float *__restrict__ dw, float *__restrict__ dw_slabs, int K, int HW, long long P,
+    int use_lds)
 {
     extern __shared__ float s_dw[];    // [K][D] when use_lds
     if (use_lds) {
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
         __syncthreads();
         for (int i = threadIdx.x; i < K * D; i += VQ_BWD_BLOCK) {
             const float v = s_dw[i];
-            if (v != 0.f) atomicAdd(&dw[i], v);
+            if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + i] = v;   // deterministic: dm_reduce_slabs adds them
+            else if (v != 0.f) atomicAdd(&dw[i], v);
         }
     }
 }
@@ -345,21 +347,28 @@ extern "C" int dm_vq_finalize(const double *sse_slabs, int nslabs, const int32_t
     return dm_launch_status("dm_vq_finalize");
 }
 
-extern "C" int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
-                              const float *g_out, const float *g_loss_dev, float commitment_cost,
-                              float *dz, float *dw, int B, int D, int K, int H, int W, void *stream)
+namespace {
+int vq_backward_grid(long long P)
 {
-    DM_REQUIRE(z && codebook && idx && dw, "dm_vq_backward: NULL pointer");
-    DM_REQUIRE(vq_dim_supported(D), "dm_vq_backward: embedding_dim %d not built (8/16/32/64)", D);
+    const long long want = (P + VQ_BWD_BLOCK - 1) / VQ_BWD_BLOCK;
+    return (int)(want < 512 ? want : 512);                 // two 1024-thread workgroups per CU
+}
+
+int vq_backward_launch(const char *who, const float *z, const float *codebook, const int64_t *idx, const float *g_out,
+                       const float *g_loss_dev, float commitment_cost, float *dz, float *dw, float *dw_slabs,
+                       int B, int D, int K, int H, int W, void *stream)
+{
+    DM_REQUIRE(z && codebook && idx && (dw || dw_slabs), "%s: NULL pointer", who);
+    DM_REQUIRE(vq_dim_supported(D), "%s: embedding_dim %d not built (8/16/32/64)", who, D);
     const long long P = (long long)B * H * W;
     const size_t lds = (size_t)K * D * sizeof(float);
     const int use_lds = lds <= 48 * 1024;
-    const long long want = (P + VQ_BWD_BLOCK - 1) / VQ_BWD_BLOCK;
-    const int grid = (int)(want < 512 ? want : 512);       // two 1024-thread workgroups per CU
+    DM_REQUIRE(!dw_slabs || use_lds, "%s: the slab form needs the codebook gradient in LDS (K*D*4 <= 48 KB)", who);
+    const int grid = vq_backward_grid(P);
     hipStream_t s = (hipStream_t)stream;
 #define DM_VQ_BWD(DD)                                                                                         \
     hipLaunchKernelGGL(vq_backward_kernel<DD>, dim3(grid), dim3(VQ_BWD_BLOCK), use_lds ? lds : 0, s, z, codebook, \
-                       (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, K, H * W, P, use_lds)
+                       (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, dw_slabs, K, H * W, P, use_lds)
     switch (D) {
     case 8: DM_VQ_BWD(8); break;
     case 16: DM_VQ_BWD(16); break;
@@ -367,5 +376,24 @@ extern "C" int dm_vq_backward(const float *z, const float *codebook, const int64
     default: DM_VQ_BWD(64); break;
     }
 #undef DM_VQ_BWD
-    return dm_launch_status("dm_vq_backward");
+    return dm_launch_status(who);
+}
+}  // namespace
+
+extern "C" int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
+                              const float *g_out, const float *g_loss_dev, float commitment_cost,
+                              float *dz, float *dw, int B, int D, int K, int H, int W, void *stream)
+{
+    return vq_backward_launch("dm_vq_backward", z, codebook, idx, g_out, g_loss_dev, commitment_cost, dz, dw, nullptr,
+                              B, D, K, H, W, stream);
+}
+
+extern "C" int dm_vq_backward_num_slabs(int64_t positions) { return vq_backward_grid(positions); }
+
+extern "C" int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *idx,
+                                    const float *g_out, const float *g_loss_dev, float commitment_cost,
+                                    float *dz, float *dw_slabs, int B, int D, int K, int H, int W, void *stream)
+{
+    return vq_backward_launch("dm_vq_backward_slabs", z, codebook, idx, g_out, g_loss_dev, commitment_cost, dz, nullptr,
+                              dw_slabs, B, D, K, H, W, stream);
 }

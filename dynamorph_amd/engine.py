@@ -172,11 +172,11 @@ def residual_backward(res_layers, saved, g_h, G, q_below, pending=None, zero_fed
     return g_h, stats
 
 
-def encoder_backward(L, cx, g_z, G, zero_fed_biases=True):
+def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
     """Accumulates nothing: every parameter gradient G(p) is overwritten.  No gradient flows to x.
     zero_fed_biases=False skips writing the (identically zero) gradients of the conv biases that feed a
     BatchNorm -- for callers whose gradient buffer is zero there already (FusedTrainer)."""
-    pending = []
+    pending = list(pending_extra)                    # (slabs, dst) pairs that ride along in the one slab reduction
     if cx.per_sample and cx.B > 1:
         raise NotImplementedError("backward through per-sample BatchNorm statistics with B > 1")
     if cx.saved1 is None:

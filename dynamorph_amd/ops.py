@@ -116,6 +116,20 @@ def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_
     return dz, dw
 
 
+def vq_backward_slabs(z, codebook, idx, g_out, g_loss, commitment_cost, want_dz=True):
+    """Like vq_backward, but the codebook gradient comes back as per-workgroup slabs (nslabs, K*D) for
+    reduce_slabs / reduce_slabs_multi: no float atomics, nothing to zero."""
+    lib = L.load()
+    B, D, H, W = z.shape
+    K = codebook.shape[0]
+    dz = torch.empty_like(z) if want_dz else None
+    slabs = _new((lib.dm_vq_backward_num_slabs(B * H * W), K * D), z)
+    L.check(lib.dm_vq_backward_slabs(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(g_out), _ptr(g_loss),
+                                     commitment_cost, _ptr(dz), _ptr(slabs), B, D, K, H, W, _stream()),
+            "dm_vq_backward_slabs")
+    return dz, slabs
+
+
 # ---------------------------------------------------------------------- convolutions
 def conv4x4s2(inp, wv, B, CIN, NOUT, H, W, ep=None, out=None, want_stats=False, like=None, **epkw):
     lib = L.load()
@@ -380,6 +394,12 @@ def adam(param, grad, m, v, lr, beta1, beta2, eps, step_dev):
     lib = L.load()
     L.check(lib.dm_adam(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
                         _ptr(step_dev), _stream()), "dm_adam")
+
+
+def adam_counted(param, grad, m, v, lr, beta1, beta2, eps, steps_done, steps_done_next):
+    lib = L.load()
+    L.check(lib.dm_adam_counted(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
+                                _ptr(steps_done), _ptr(steps_done_next), _stream()), "dm_adam_counted")
 
 
 def augment(x, flip_code, rot_code):

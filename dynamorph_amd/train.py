@@ -45,7 +45,8 @@ class FusedTrainer:
         dev, n = self.flat.device, self.flat.numel()
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
-        self.step_dev = torch.zeros(1, device=dev)
+        self.step_dev = torch.zeros(2, device=dev)        # completed-step counter, ping-ponged between the two words
+        self._step_slot = 0
         self.w_recon = torch.tensor([float(model.weight_recon)], device=dev)
         self.w_commit = torch.tensor([float(model.weight_commitment)], device=dev)
         self.use_graph = use_graph
@@ -77,18 +78,27 @@ class FusedTrainer:
         scalars = ops.loss_finalize(dcx.loss_slabs, B * NIN * H * W, vsc, float(model.weight_recon),
                                     float(model.weight_commitment))
         gcb = self.G(L.codebook.weight)
-        gcb.zero_()
-        dz, _ = ops.vq_backward(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc, dw=gcb)
+        K, D = L.codebook.weight.shape
+        if K * D * 4 <= 48 * 1024:
+            # codebook gradient as slabs, added in the encoder's single slab reduction: no atomics, nothing to zero
+            dz, cb_slabs = ops.vq_backward_slabs(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc)
+            extra = [(cb_slabs, gcb)]
+        else:
+            gcb.zero_()
+            dz, _ = ops.vq_backward(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc, dw=gcb)
+            extra = []
         # the flat gradient buffer starts at zero and nothing ever writes the BatchNorm-fed conv biases' slots
-        E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False)
+        E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False, pending_extra=extra)
         return scalars
 
     def _allreduce(self):
         D.allreduce_mean_(self.grad, self.group)     # every loss is a mean over the local batch
 
     def _adam(self):
-        self.step_dev += 1
-        ops.adam(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_dev)
+        a, b = self._step_slot, 1 - self._step_slot
+        ops.adam_counted(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                         self.step_dev[a:a + 1], self.step_dev[b:b + 1])
+        self._step_slot = b
 
     def step(self, x, mask=None):
         """One optimisation step on a device batch; returns the (4,) device tensor of LOSS_KEYS values."""

@@ -124,6 +124,14 @@ int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
                    const float *g_out, const float *g_loss_dev, float commitment_cost,
                    float *dz, float *dw, int B, int D, int K, int H, int W, void *stream);
 
+/* The same with the codebook gradient as per-workgroup slabs [dm_vq_backward_num_slabs(P)][K*D] instead of float
+ * atomics: dm_reduce_slabs / dm_reduce_slabs_multi adds them in a fixed order (bitwise reproducible, and nothing has to
+ * be zeroed first).  Needs K*D*4 <= 48 KB. */
+int dm_vq_backward_num_slabs(int64_t positions);
+int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *idx,
+                         const float *g_out, const float *g_loss_dev, float commitment_cost,
+                         float *dz, float *dw_slabs, int B, int D, int K, int H, int W, void *stream);
+
 /* ===== convolutions (nn.Conv2d / nn.ConvTranspose2d, vq_vae.py:276-298) ======= */
 
 /* 4x4, stride 2, padding 1 implicit-GEMM convolution on MFMA f32 16x16x4.
@@ -280,6 +288,11 @@ int dm_e1_chain(const float *dweff, const float *w0, const float *b0, const floa
 /* step_dev[0] holds the 1-based step count as float (kept on device so the call is graph-capturable). */
 int dm_adam(float *param, const float *grad, float *m, float *v, int64_t n,
             float lr, float beta1, float beta2, float eps, const float *step_dev, void *stream);
+
+/* The same keeping the count itself: steps_done[0] = completed steps, this call is step steps_done[0] + 1 and writes
+ * that to steps_done_next[0] (a different word; callers alternate two counters), so the step needs no "+= 1" launch. */
+int dm_adam_counted(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, const float *steps_done, float *steps_done_next, void *stream);
 
 /* ===== on-device augmentation (run_training.py:396-403) ======================= */
 /* out[b] = rot90(flip(in[b], flip_code[b]), k = rot_code[b]) on square (C,H,H) patches;
