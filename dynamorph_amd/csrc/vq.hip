@@ -277,7 +277,7 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
         __syncthreads();
         for (int i = threadIdx.x; i < K * D; i += VQ_BWD_BLOCK) {
             const float v = s_dw[i];
-            if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + i] = v;   // deterministic: dm_reduce_slabs adds them
+            if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + i] = v;   // dm_reduce_slabs adds them in slab order
             else if (v != 0.f) atomicAdd(&dw[i], v);
         }
     }

@@ -118,7 +118,7 @@ def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_
 
 def vq_backward_slabs(z, codebook, idx, g_out, g_loss, commitment_cost, want_dz=True):
     """Like vq_backward, but the codebook gradient comes back as per-workgroup slabs (nslabs, K*D) for
-    reduce_slabs / reduce_slabs_multi: no float atomics, nothing to zero."""
+    reduce_slabs / reduce_slabs_multi: no global float atomics, nothing to zero."""
     lib = L.load()
     B, D, H, W = z.shape
     K = codebook.shape[0]

@@ -124,9 +124,9 @@ int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
                    const float *g_out, const float *g_loss_dev, float commitment_cost,
                    float *dz, float *dw, int B, int D, int K, int H, int W, void *stream);
 
-/* The same with the codebook gradient as per-workgroup slabs [dm_vq_backward_num_slabs(P)][K*D] instead of float
- * atomics: dm_reduce_slabs / dm_reduce_slabs_multi adds them in a fixed order (bitwise reproducible, and nothing has to
- * be zeroed first).  Needs K*D*4 <= 48 KB. */
+/* The same with the codebook gradient as per-workgroup slabs [dm_vq_backward_num_slabs(P)][K*D] instead of global
+ * float atomics: dm_reduce_slabs / dm_reduce_slabs_multi adds them in a fixed order and nothing has to be zeroed
+ * first (inside a workgroup the LDS adds still arrive in hardware order).  Needs K*D*4 <= 48 KB. */
 int dm_vq_backward_num_slabs(int64_t positions);
 int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *idx,
                          const float *g_out, const float *g_loss_dev, float commitment_cost,

@@ -387,6 +387,42 @@ def test_adam_matches_torch(ops):
     close(p, p_ref, 1e-6, 1e-7, "adam")
 
 
+def test_adam_counted_keeps_its_own_step(ops):
+    """dm_adam_counted: same update as dm_adam, the step count lives in two ping-ponged device words."""
+    n = 3000
+    p0 = rnd(n, seed=2)
+    pa, pb = p0.clone().to(DEV), p0.clone().to(DEV)
+    ma, va = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    mb, vb = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, device=DEV)
+    cnt = torch.zeros(2, device=DEV)
+    for s in range(4):
+        g = (rnd(n, seed=20 + s) * 0.1).to(DEV)
+        step += 1
+        ops.adam(pa, g, ma, va, 1e-3, 0.9, 0.999, 1e-8, step)
+        a, b = s % 2, 1 - s % 2
+        ops.adam_counted(pb, g, mb, vb, 1e-3, 0.9, 0.999, 1e-8, cnt[a:a + 1], cnt[b:b + 1])
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert float(cnt[0]) == 4.0                            # four completed steps, last written to word 0
+
+
+def test_vq_backward_slabs_equal_the_atomic_form(ops):
+    """The codebook gradient as per-workgroup slabs (no global float atomics, nothing to zero) sums to the atomic
+    result (inside a workgroup the LDS adds still come in arrival order, so bits may differ run to run)."""
+    B, D, K, H = 70, 16, 64, 16
+    z = rnd(B, D, H, H, seed=31).to(DEV)
+    cb = rnd(K, D, seed=32).to(DEV)
+    g = rnd(B, D, H, H, seed=33).to(DEV)
+    idx, _, _, _ = ops.vq_forward(z, cb, want_out=False)
+    gl = torch.tensor([0.7], device=DEV)
+    dz_a, dw_a = ops.vq_backward(z, cb, idx, g, gl, 0.25)
+    dz_s, slabs = ops.vq_backward_slabs(z, cb, idx, g, gl, 0.25)
+    dw_s = torch.empty(K * D, device=DEV)
+    ops.reduce_slabs(slabs, dw_s)
+    assert torch.equal(dz_a, dz_s)
+    close(dw_s.reshape(K, D), dw_a, 1e-5, 1e-7 * float(dw_a.abs().max()) + 1e-9, "codebook gradient (slabs)")
+
+
 def test_augment_matches_torch(ops):
     B, Cn, h = 9, 2, 16
     x = rnd(B, Cn, h, h, seed=1)
