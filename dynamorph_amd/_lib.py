@@ -73,6 +73,8 @@ SIGNATURES = {
     "dm_dec_tail_train": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_reduce_slabs": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "dm_loss_finalize": (C.c_int, [vp, C.c_int, i64, vp, f32, f32, vp, vp]),
+    "dm_pair_msd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "dm_pair_msd_backward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_compose_border": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

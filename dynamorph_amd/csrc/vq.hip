@@ -87,7 +87,6 @@ __global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : 2)) void vq_forward_kernel
         for (int i = threadIdx.x; i < cn * D * 2 / 4; i += VQ_BLOCK)
             reinterpret_cast<f32x4 *>(s_cb)[i] = reinterpret_cast<const f32x4 *>(cbT + (long long)c0 * D * 2)[i];
         __syncthreads();
-#pragma unroll 2
         for (int kp = 0; kp < cn; ++kp) {
             const float *e = s_cb + kp * (2 * D);          // wave-uniform LDS address: broadcast reads
             f32x2 total[PP];

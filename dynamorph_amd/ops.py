@@ -360,6 +360,24 @@ def loss_finalize(loss_slabs, count, vq_scalars, weight_recon, weight_commitment
     return out
 
 
+# ------------------------------------------------------------------ time-matching loss
+def pair_msd(z):
+    """z (B, n) contiguous -> sim (B, B), sim[i][j] = mean((z[i] - z[j])**2)."""
+    lib = L.load()
+    B, n = z.shape
+    sim = _new((B, B), z)
+    L.check(lib.dm_pair_msd(_ptr(z), _ptr(sim), B, n, _stream()), "dm_pair_msd")
+    return sim
+
+
+def pair_msd_backward(z, g_sim):
+    lib = L.load()
+    B, n = z.shape
+    dz = torch.empty_like(z)
+    L.check(lib.dm_pair_msd_backward(_ptr(z), _ptr(g_sim), _ptr(dz), B, n, _stream()), "dm_pair_msd_backward")
+    return dz
+
+
 # ------------------------------------------------------------- composition / optimizer
 def e1_compose(w0, b0, w1):
     lib = L.load()

@@ -140,6 +140,22 @@ class _DecoderFn(torch.autograd.Function):
 
 
 # ================================================================================ modules
+class _PairMSDFn(torch.autograd.Function):
+    """sim[i][j] = mean((z[i] - z[j])**2)  (vq_vae.py:327-329) on the HIP kernels dm_pair_msd(_backward)."""
+
+    @staticmethod
+    def forward(ctx, zf):
+        _require_gpu(zf, "time-matching loss")
+        z = zf.detach().contiguous().float()
+        ctx.save_for_backward(z)
+        return ops.pair_msd(z)
+
+    @staticmethod
+    def backward(ctx, g_sim):
+        (z,) = ctx.saved_tensors
+        return ops.pair_msd_backward(z, g_sim.contiguous().float())
+
+
 class VectorQuantizer(nn.Module):
     """Vector quantizer of "Neural Discrete Representation Learning" (reference vq_vae.py:25-116)."""
 
@@ -297,11 +313,11 @@ class VQ_VAE(nn.Module):
         object.__setattr__(self.enc, "_owner", ref)
         object.__setattr__(self.dec, "_owner", ref)
 
-    # ---- reference semantics of the pairwise term (kept in torch: "next" row of the scope table) ----
+    # ---- the pairwise term: the (B, B) mean-squared latent distances come from the HIP kernel (no (B, B, n)
+    #      intermediate); weights / hinge / reduction over the B*B matrix are the reference's torch expressions ----
     def _time_matching(self, z_before, time_matching_mat):
         zf = z_before.reshape((z_before.shape[0], -1))
-        n = zf.shape[1]
-        sim_mat = torch.pow(zf.reshape((1, -1, n)) - zf.reshape((-1, 1, n)), 2).mean(2)
+        sim_mat = _PairMSDFn.apply(zf)
         assert sim_mat.shape == time_matching_mat.shape
         if not self._z16_loss:
             return (sim_mat * time_matching_mat).sum()                      # vq_vae.py:331

@@ -267,6 +267,15 @@ int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *stream);
 int dm_loss_finalize(const double *loss_slabs, int nslabs, int64_t count, const float *vq_scalars,
                      float weight_recon, float weight_commitment, float *scalars_out, void *stream);
 
+/* ===== time-matching loss (vq_vae.py:324-332, vae.py:322-336) ================= */
+
+/* sim[i][j] = mean_d (z[i][d] - z[j][d])^2 for the B flattened latents z (B, n) -- the reference's
+ * pow(z.reshape(1,B,n) - z.reshape(B,1,n), 2).mean(2) without its (B, B, n) intermediate.  The weighting, hinge and
+ * mean over the (B, B) matrix stay with the caller (B*B elements). */
+int dm_pair_msd(const float *z, float *sim, int B, int n, void *stream);
+/* Its backward: dz[i] = (2/n) * sum_j (g_sim[i][j] + g_sim[j][i]) * (z[i] - z[j]). */
+int dm_pair_msd_backward(const float *z, const float *g_sim, float *dz, int B, int n, void *stream);
+
 /* ===== enc.0 o enc.1 composition (vq_vae.py:277-278) ========================== */
 
 /* enc.1(enc.0(x)) is linear in (x, 1): Weff[c1][ci][ky][kx] = sum_c W1[c1][c][ky][kx]*W0[c][ci]

@@ -423,6 +423,20 @@ def test_vq_backward_slabs_equal_the_atomic_form(ops):
     close(dw_s.reshape(K, D), dw_a, 1e-5, 1e-7 * float(dw_a.abs().max()) + 1e-9, "codebook gradient (slabs)")
 
 
+@pytest.mark.parametrize("B,n", [(4, 4096), (19, 4096), (33, 100), (1, 64)])
+def test_pair_msd_forward_backward(ops, B, n):
+    """Pairwise mean-squared latent distance of the time-matching loss (vq_vae.py:327-329) and its gradient."""
+    z = rnd(B, n, seed=41).requires_grad_(True)
+    sim_ref = torch.pow(z.reshape((1, -1, n)) - z.reshape((-1, 1, n)), 2).mean(2)
+    g = rnd(B, B, seed=42)
+    (sim_ref * g).sum().backward()
+    zd = z.detach().to(DEV)
+    sim = ops.pair_msd(zd)
+    close(sim, sim_ref, 2e-6, 1e-7, "sim_mat")
+    dz = ops.pair_msd_backward(zd, g.to(DEV))
+    close(dz, z.grad, 2e-5, 2e-6 * float(z.grad.abs().max()) + 1e-12, "d sim / d z")
+
+
 def test_augment_matches_torch(ops):
     B, Cn, h = 9, 2, 16
     x = rnd(B, Cn, h, h, seed=1)
