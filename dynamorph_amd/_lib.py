@@ -73,6 +73,9 @@ SIGNATURES = {
     "dm_dec_tail_train": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_reduce_slabs": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "dm_loss_finalize": (C.c_int, [vp, C.c_int, i64, vp, f32, f32, vp, vp]),
+    "dm_recon_loss_num_blocks": (C.c_int, [C.c_int] * 4),
+    "dm_recon_loss": (C.c_int, [vp, vp, vp, C.c_int, vp, vp] + [C.c_int] * 4 + [vp]),
+    "dm_recon_loss_backward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp] + [C.c_int] * 4 + [vp]),
     "dm_pair_msd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "dm_pair_msd_backward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

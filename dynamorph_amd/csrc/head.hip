@@ -130,6 +130,73 @@ __global__ __launch_bounds__(256) void head_backward_kernel(
     }
 }
 
+// ---- plain masked reconstruction loss on a decoder output (VQ_VAE_z32: vae.py:450-452, the decoder ends in a
+//      ConvTranspose2d, there is no 1x1 head to fuse with) ------------------------------------------------------------
+// loss_slabs[block] = sum ((dec*m - x*m)^2 / var[c]);  one thread per 4 consecutive pixels of one channel plane
+__global__ __launch_bounds__(256) void recon_loss_kernel(
+    const float *__restrict__ dec, const float *__restrict__ x, const float *__restrict__ mask, int MC,
+    const float *__restrict__ cvar, double *__restrict__ loss_slabs, int NIN, int HW4, long long total4)
+{
+    __shared__ double s_red[4];
+    double loss = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long plane = i / HW4, p = i - plane * HW4;
+        const long long b = plane / NIN;
+        const int c = (int)(plane - b * NIN);
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(dec + i * 4);
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + i * 4);
+        f32x4 t = o - xv;
+        if (mask) {
+            const f32x4 mv = *reinterpret_cast<const f32x4 *>(mask + ((b * MC + (MC == 1 ? 0 : c)) * HW4 + p) * 4);
+            t = o * mv - xv * mv;
+        }
+        const f32x4 sq = t * t;
+        const float v = cvar[c];
+        loss += (double)(sq.x / v) + (double)(sq.y / v) + (double)(sq.z / v) + (double)(sq.w / v);
+    }
+    const double tot = block_sum(loss, s_red);
+    if (threadIdx.x == 0) loss_slabs[blockIdx.x] = tot;
+}
+
+// g_dec = gscale * 2/N * (dec*m - x*m) * m / var[c]; bias_slabs[block][c][2] = (sum g_dec over channel c, 0)
+// (blocks walk whole channel planes so that a block's partial sum belongs to one channel at a time)
+__global__ __launch_bounds__(256) void recon_loss_backward_kernel(
+    const float *__restrict__ dec, const float *__restrict__ x, const float *__restrict__ mask, int MC,
+    const float *__restrict__ cvar, const float *__restrict__ gscale_dev, float *__restrict__ gdec,
+    double *__restrict__ bias_slabs, int NIN, int HW4, long long nplanes, double inv_count)
+{
+    __shared__ double s_red[4];
+    const float gs = (float)(2.0 * inv_count) * gscale_dev[0];
+    for (int c = threadIdx.x; c < NIN; c += blockDim.x) {
+        bias_slabs[((long long)blockIdx.x * NIN + c) * 2 + 0] = 0.0;
+        bias_slabs[((long long)blockIdx.x * NIN + c) * 2 + 1] = 0.0;
+    }
+    __syncthreads();
+    for (long long plane = blockIdx.x; plane < nplanes; plane += gridDim.x) {
+        const long long b = plane / NIN;
+        const int c = (int)(plane - b * NIN);
+        const float sc = gs / cvar[c];
+        double part = 0.0;
+        for (int p = threadIdx.x; p < HW4; p += blockDim.x) {
+            const long long i = plane * HW4 + p;
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(dec + i * 4);
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + i * 4);
+            f32x4 t = o - xv;
+            if (mask) {
+                const f32x4 mv = *reinterpret_cast<const f32x4 *>(mask + ((b * MC + (MC == 1 ? 0 : c)) * HW4 + p) * 4);
+                t = (o * mv - xv * mv) * mv;
+            }
+            const f32x4 g = t * sc;
+            *reinterpret_cast<f32x4 *>(gdec + i * 4) = g;
+            part += (double)((g.x + g.y) + (g.z + g.w));
+        }
+        const double tot = block_sum(part, s_red);
+        if (threadIdx.x == 0) bias_slabs[((long long)blockIdx.x * NIN + c) * 2 + 0] += tot;
+        __syncthreads();
+    }
+}
+
 __global__ void loss_finalize_kernel(const double *__restrict__ loss_slabs, int nslabs, long long count,
                                      const float *__restrict__ vq_scalars, float w_recon, float w_commit,
                                      float *__restrict__ out)
@@ -212,4 +279,40 @@ extern "C" int dm_loss_finalize(const double *loss_slabs, int nslabs, int64_t co
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_slabs, nslabs,
                        (long long)count, vq_scalars, weight_recon, weight_commitment, scalars_out);
     return dm_launch_status("dm_loss_finalize");
+}
+
+extern "C" int dm_recon_loss_num_blocks(int B, int NIN, int H, int W)
+{
+    (void)H; (void)W;
+    const long long planes = (long long)B * NIN;
+    return (int)(planes < 1024 ? planes : 1024);
+}
+
+extern "C" int dm_recon_loss(const float *decoded, const float *x, const float *mask, int mask_channels,
+                             const float *channel_var, double *loss_slabs, int B, int NIN, int H, int W, void *stream)
+{
+    DM_REQUIRE(decoded && x && channel_var && loss_slabs && B > 0 && NIN > 0, "dm_recon_loss: bad argument");
+    DM_REQUIRE((H * W) % 4 == 0, "dm_recon_loss: H*W must be a multiple of 4");
+    DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "dm_recon_loss: mask channels %d", mask_channels);
+    const int HW4 = H * W / 4;
+    const long long total4 = (long long)B * NIN * HW4;
+    hipLaunchKernelGGL(recon_loss_kernel, dim3(dm_recon_loss_num_blocks(B, NIN, H, W)), dim3(256), 0, (hipStream_t)stream,
+                       decoded, x, mask, mask_channels, channel_var, loss_slabs, NIN, HW4, total4);
+    return dm_launch_status("dm_recon_loss");
+}
+
+extern "C" int dm_recon_loss_backward(const float *decoded, const float *x, const float *mask, int mask_channels,
+                                      const float *channel_var, const float *gscale_dev, float *g_decoded,
+                                      double *bias_slabs, int B, int NIN, int H, int W, void *stream)
+{
+    DM_REQUIRE(decoded && x && channel_var && gscale_dev && g_decoded && bias_slabs && B > 0 && NIN > 0,
+               "dm_recon_loss_backward: bad argument");
+    DM_REQUIRE((H * W) % 4 == 0, "dm_recon_loss_backward: H*W must be a multiple of 4");
+    DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "dm_recon_loss_backward: mask channels %d", mask_channels);
+    const int HW4 = H * W / 4;
+    const double inv_count = 1.0 / ((double)B * NIN * H * W);
+    hipLaunchKernelGGL(recon_loss_backward_kernel, dim3(dm_recon_loss_num_blocks(B, NIN, H, W)), dim3(256), 0,
+                       (hipStream_t)stream, decoded, x, mask, mask_channels, channel_var, gscale_dev, g_decoded, bias_slabs,
+                       NIN, HW4, (long long)B * NIN, inv_count);
+    return dm_launch_status("dm_recon_loss_backward");
 }

@@ -304,3 +304,95 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
         return None
     g_zq, _ = ops.conv4x4s2(Op(g0), weight_view(_w(L.dec0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H3, 2 * W3)
     return g_zq
+
+
+# ======================================================================== VQ_VAE_z32 (vae.py:348-474)
+# 32x32 latent: enc = Conv(4,2,1) BN ReLU Conv(4,2,1) BN ResidualBlock; dec = ResidualBlock ConvT BN ReLU ConvT.
+# The residual stacks are the ResidualBlock module itself (residual_forward/backward); these four functions are the
+# two conv "stems" around them.  Same conventions as above: raw conv outputs + statistics slabs, BatchNorm applied by
+# the consumer's operand load, BatchNorm backward as an AFFINE2 operand.
+def z32_stem_forward(conv0, bn0, conv1, bn1, x):
+    """x (B,NIN,H,W) -> h = BN(conv1(relu(BN(conv0(x))))) (B,nh,H/4,W/4), materialised for the residual stack."""
+    B, NIN, H, W = x.shape
+    c1, nh = conv0.weight.shape[0], conv1.weight.shape[0]
+    H1, W1, H2, W2 = H // 2, W // 2, H // 4, W // 4
+    a1, st = ops.conv4x4s2(Op(x), weight_view(_w(conv0.weight), NIN * 16, 16, 4, 1), B, NIN, c1, H, W,
+                           want_stats=True, bias=_w(conv0.bias))
+    coef1, saved1 = _bn_coef(st, bn0, B * H1 * W1, False, B)
+    a2, st = ops.conv4x4s2(Op(a1, DM_LOAD_AFFINE_RELU, coef1), weight_view(_w(conv1.weight), c1 * 16, 16, 4, 1),
+                           B, c1, nh, H1, W1, want_stats=True, bias=_w(conv1.bias))
+    coef2, saved2 = _bn_coef(st, bn1, B * H2 * W2, False, B)
+    h = ops.apply(Op(a2, DM_LOAD_AFFINE, coef2), B, nh, H2, W2)
+    cx = SimpleNamespace(x=x, a1=a1, a2=a2, coef1=coef1, coef2=coef2, saved1=saved1, saved2=saved2,
+                         dims=(B, NIN, c1, nh, H1, W1, H2, W2))
+    return h, cx
+
+
+def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G):
+    if cx.saved1 is None or cx.saved2 is None:
+        raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
+    B, NIN, c1, nh, H1, W1, H2, W2 = cx.dims
+    g_h = g_h.contiguous()
+    pending = []
+    stats = ops.channel_stats(g_h, cx.a2)
+    c2b = ops.bn_backward_finalize(stats, B * H2 * W2, _w(bn1.weight), cx.saved2, G(bn1.weight), G(bn1.bias))
+    da2 = Op(g_h, DM_LOAD_AFFINE2, c2b, p1=cx.a2)
+    ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(conv1.weight), B, nh, c1, H2, W2, 4, pending=pending)
+    G(conv1.bias).zero_()                            # feeds a train-mode BatchNorm: identically zero
+    dy1, st = ops.conv3x3(da2, weight_view(_w(conv1.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
+                          pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
+                          stat_q=cx.a1)
+    c1b = ops.bn_backward_finalize(st, B * H1 * W1, _w(bn0.weight), cx.saved1, G(bn0.weight), G(bn0.bias))
+    da1 = Op(dy1, DM_LOAD_AFFINE2, c1b, p1=cx.a1)
+    ops.wgrad(da1, Op(cx.x), G(conv0.weight), B, c1, NIN, H1, W1, 4, pending=pending)
+    G(conv0.bias).zero_()
+    ops.reduce_slabs_multi(pending)
+
+
+def z32_tail_forward(up0, bn, up1, r, x, mask, channel_var):
+    """r (B,nh,H2,W2) -> decoded (B,NIN,4*H2,4*W2) (+ loss slabs when x is given)."""
+    B, nh, H2, W2 = r.shape
+    c1, NIN = up0.weight.shape[1], up1.weight.shape[1]
+    d1, st = ops.conv3x3(Op(r), weight_view(_w(up0.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
+                         pixel_shuffle=True, want_stats=True, bias=_w(up0.bias))
+    coefd, savedd = _bn_coef(st, bn, B * 4 * H2 * W2, False, B)
+    dec, _ = ops.conv3x3(Op(d1, DM_LOAD_AFFINE_RELU, coefd), weight_view(_w(up1.weight), 16, NIN * 16, 4, 1), B, c1,
+                         4 * NIN, 2 * H2, 2 * W2, taps=9, pixel_shuffle=True, bias=_w(up1.bias))
+    var = _w(channel_var).reshape(-1)
+    slabs = ops.recon_loss(dec, x, mask, var) if x is not None else None
+    cx = SimpleNamespace(r=r, d1=d1, coefd=coefd, savedd=savedd, dec=dec, x=x, mask=mask, var=var, loss_slabs=slabs,
+                         dims=(B, nh, c1, NIN, H2, W2))
+    return dec, cx
+
+
+def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True):
+    """gscale: 1-element device tensor d(total)/d(recon_loss) or None; gdec_ext: upstream gradient w.r.t. decoded or None."""
+    if cx.savedd is None:
+        raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
+    B, nh, c1, NIN, H2, W2 = cx.dims
+    pending = []
+    if gscale is not None:
+        g, part = ops.recon_loss_backward(cx.dec, cx.x, cx.mask, cx.var, gscale)
+        if gdec_ext is not None:
+            g = g + gdec_ext
+            part = None
+    else:
+        g, part = gdec_ext.contiguous(), None
+    if part is not None:
+        ops.sum_slabs(part, G(up1.bias))
+    else:
+        ops.sum_slabs(ops.channel_stats(g), G(up1.bias))
+    ops.wgrad(Op(cx.d1, DM_LOAD_AFFINE_RELU, cx.coefd), Op(g), G(up1.weight), B, c1, NIN, 2 * H2, 2 * W2, 4,
+              pending=pending)
+    dy, st = ops.conv4x4s2(Op(g), weight_view(_w(up1.weight), NIN * 16, 16, 4, 1), B, NIN, c1, 4 * H2, 4 * W2,
+                           want_stats=True, mask=Op(cx.d1, DM_LOAD_AFFINE, cx.coefd), stat_q=cx.d1)
+    cdb = ops.bn_backward_finalize(st, B * 4 * H2 * W2, _w(bn.weight), cx.savedd, G(bn.weight), G(bn.bias))
+    # the weight-gradient kernel takes the BatchNorm-backward transform on its S operand only: materialise it here
+    da = ops.apply(Op(dy, DM_LOAD_AFFINE2, cdb, p1=cx.d1), B, c1, 2 * H2, 2 * W2)
+    ops.wgrad(Op(cx.r), Op(da), G(up0.weight), B, nh, c1, H2, W2, 4, pending=pending)
+    G(up0.bias).zero_()
+    g_r = None
+    if want_gr:
+        g_r, _ = ops.conv4x4s2(Op(da), weight_view(_w(up0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H2, 2 * W2)
+    ops.reduce_slabs_multi(pending)
+    return g_r

@@ -360,6 +360,30 @@ def loss_finalize(loss_slabs, count, vq_scalars, weight_recon, weight_commitment
     return out
 
 
+# ------------------------------------------------------------------ plain reconstruction loss
+def recon_loss(dec, x, mask, channel_var):
+    """Partial sums (nblocks,) float64 of (dec*m - x*m)^2 / var for loss_finalize."""
+    lib = L.load()
+    B, NIN, H, W = dec.shape
+    slabs = _new((lib.dm_recon_loss_num_blocks(B, NIN, H, W),), dec, torch.float64)
+    mc = mask.shape[1] if mask is not None else 0
+    L.check(lib.dm_recon_loss(_ptr(dec), _ptr(x), _ptr(mask), mc, _ptr(channel_var), _ptr(slabs, torch.float64),
+                              B, NIN, H, W, _stream()), "dm_recon_loss")
+    return slabs
+
+
+def recon_loss_backward(dec, x, mask, channel_var, gscale):
+    """(g_decoded, bias_slabs (nblocks, NIN, 2) float64)."""
+    lib = L.load()
+    B, NIN, H, W = dec.shape
+    g = torch.empty_like(dec)
+    part = _new((lib.dm_recon_loss_num_blocks(B, NIN, H, W), NIN, 2), dec, torch.float64)
+    mc = mask.shape[1] if mask is not None else 0
+    L.check(lib.dm_recon_loss_backward(_ptr(dec), _ptr(x), _ptr(mask), mc, _ptr(channel_var), _ptr(gscale), _ptr(g),
+                                       _ptr(part, torch.float64), B, NIN, H, W, _stream()), "dm_recon_loss_backward")
+    return g, part
+
+
 # ------------------------------------------------------------------ time-matching loss
 def pair_msd(z):
     """z (B, n) contiguous -> sim (B, B), sim[i][j] = mean((z[i] - z[j])**2)."""

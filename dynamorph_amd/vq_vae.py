@@ -360,3 +360,149 @@ class VQ_VAE_z16(VQ_VAE):
     """vae.py:216-346: same network and state dict as VQ_VAE; weighted hinge time-matching loss and
     'perplexity' listed before 'total_loss'."""
     _z16_loss = True
+
+
+# ================================================================================ VQ_VAE_z32
+class _Z32StemFn(torch.autograd.Function):
+    """enc[0:5] of VQ_VAE_z32: Conv(4,2,1) BN ReLU Conv(4,2,1) BN."""
+
+    @staticmethod
+    def forward(ctx, x, mods, *params):
+        h, cx = E.z32_stem_forward(*mods, x)
+        ctx.mods, ctx.cx, ctx.params = mods, cx, params
+        return h
+
+    @staticmethod
+    def backward(ctx, g_h):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the input patches is not implemented (the reference never asks for it)")
+        G = _GradBag()
+        E.z32_stem_backward(*ctx.mods, ctx.cx, g_h, G)
+        ctx.cx = None
+        return (None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[2:])
+
+
+class _Z32TailFn(torch.autograd.Function):
+    """dec[1:5] of VQ_VAE_z32: ConvT BN ReLU ConvT (+ the masked reconstruction loss when x is given)."""
+
+    @staticmethod
+    def forward(ctx, r, x, mask, channel_var, mods, *params):
+        dec, cx = E.z32_tail_forward(*mods, r, x, mask, channel_var)
+        ctx.mods, ctx.cx, ctx.params = mods, cx, params
+        ctx.set_materialize_grads(False)
+        if x is None:
+            return dec, None
+        B, NIN, H, W = x.shape
+        recon = ops.loss_finalize(cx.loss_slabs, B * NIN * H * W, torch.zeros(2, device=x.device), 1.0, 0.0)[0]
+        return dec, recon
+
+    @staticmethod
+    def backward(ctx, g_dec, g_recon):
+        gscale = g_recon.reshape(1).contiguous() if g_recon is not None else None
+        if g_dec is not None:
+            g_dec = g_dec.contiguous()
+        if gscale is None and g_dec is None:
+            return (None,) * (5 + len(ctx.params))
+        G = _GradBag()
+        g_r = E.z32_tail_backward(*ctx.mods, ctx.cx, gscale, g_dec, G, want_gr=ctx.needs_input_grad[0])
+        ctx.cx = None
+        return (g_r, None, None, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[5:])
+
+
+class _Z32Encoder(nn.Sequential):
+    """`model.enc` of VQ_VAE_z32 (same child indices as the reference's nn.Sequential)."""
+
+    def forward(self, x):
+        _require_gpu(x, "VQ_VAE_z32.enc")
+        mods = (self[0], self[1], self[3], self[4])
+        params = [p for m in mods for p in (m.weight, m.bias)]
+        h = _Z32StemFn.apply(_prep(x), mods, *params)
+        return self[5](h)
+
+
+class _Z32Decoder(nn.Sequential):
+    """`model.dec` of VQ_VAE_z32."""
+
+    def _tail(self, r, x, mask, channel_var):
+        mods = (self[1], self[2], self[4])
+        params = [p for m in mods for p in (m.weight, m.bias)]
+        return _Z32TailFn.apply(r, x, mask, channel_var, mods, *params)
+
+    def forward(self, z):
+        _require_gpu(z, "VQ_VAE_z32.dec")
+        dec, _ = self._tail(self[0](_prep(z)), None, None, self._owner().channel_var)
+        return dec
+
+
+class VQ_VAE_z32(nn.Module):
+    """Vector-Quantized VAE with a 32 x 32 x num_hiddens latent (reference vae.py:348-474): two stride-2 convs and a
+    residual stack in the encoder, a residual stack, BatchNorm and two transposed convs in the decoder, the
+    weighted-hinge time-matching loss on z_after.  Built for the default channel family (num_hiddens 16,
+    num_residual_hiddens 32); other sizes raise ValueError("no kernel built ...")."""
+
+    def __init__(self, num_inputs=2, num_hiddens=16, num_residual_hiddens=32, num_residual_layers=2, num_embeddings=64,
+                 commitment_cost=0.25, channel_var=np.ones(2), weight_matching=0.005, w_a=1.1, w_t=0.1, w_n=-0.5,
+                 margin=0.5, extra_loss=None, device="cuda:0", **kwargs):
+        for k in ("gpu", "alpha"):
+            kwargs.pop(k, None)
+        super(VQ_VAE_z32, self).__init__(**kwargs)
+        if extra_loss is not None:
+            raise NotImplementedError("extra_loss is not part of the HIP path")
+        self.num_inputs = num_inputs
+        self.num_hiddens = num_hiddens
+        self.num_residual_layers = num_residual_layers
+        self.num_residual_hiddens = num_residual_hiddens
+        self.num_embeddings = num_embeddings
+        self.commitment_cost = commitment_cost
+        self.channel_var = nn.Parameter(
+            torch.from_numpy(np.asarray(channel_var, dtype=np.float64)).float().reshape((1, num_inputs, 1, 1)),
+            requires_grad=False)
+        self.weight_matching = weight_matching
+        self.w_a, self.w_t, self.w_n, self.margin = w_a, w_t, w_n, margin
+        nh = num_hiddens
+        self.enc = _Z32Encoder(
+            nn.Conv2d(num_inputs, nh // 2, 4, stride=2, padding=1),
+            nn.BatchNorm2d(nh // 2),
+            nn.ReLU(),
+            nn.Conv2d(nh // 2, nh, 4, stride=2, padding=1),
+            nn.BatchNorm2d(nh),
+            ResidualBlock(nh, num_residual_hiddens, num_residual_layers))
+        self.vq = VectorQuantizer(nh, num_embeddings, commitment_cost=commitment_cost, device=device)
+        self.dec = _Z32Decoder(
+            ResidualBlock(nh, num_residual_hiddens, num_residual_layers),
+            nn.ConvTranspose2d(nh, nh // 2, 4, stride=2, padding=1),
+            nn.BatchNorm2d(nh // 2),
+            nn.ReLU(),
+            nn.ConvTranspose2d(nh // 2, num_inputs, 4, stride=2, padding=1))
+        self.extra_loss = None
+        import weakref
+        object.__setattr__(self.dec, "_owner", weakref.ref(self))
+
+    def forward(self, inputs, labels=None, time_matching_mat=None, batch_mask=None):
+        """inputs (B, C, H, W) -> (decoded, loss dict)   [vae.py:430-470]"""
+        _require_gpu(inputs, "VQ_VAE_z32.forward")
+        x = _prep(inputs)
+        z_before = self.enc(x)
+        z_after, c_loss, perplexity = self.vq(z_before)
+        mask = _prep(batch_mask) if batch_mask is not None else None
+        decoded, recon_loss = self.dec._tail(self.dec[0](z_after), x, mask, self.channel_var)
+        total_loss = recon_loss + c_loss
+        time_matching_loss = 0
+        if time_matching_mat is not None:
+            sim_mat = _PairMSDFn.apply(z_after.reshape((z_after.shape[0], -1)))
+            assert sim_mat.shape == time_matching_mat.shape
+            wts = time_matching_mat.clone()
+            wts[time_matching_mat == 2] = self.w_a
+            wts[time_matching_mat == 1] = self.w_t
+            wts[time_matching_mat == 0] = self.w_n
+            val = sim_mat * wts
+            val = torch.where(time_matching_mat == 0, torch.clamp(val + self.margin, min=0), val)
+            time_matching_loss = val.mean()
+            total_loss = total_loss + time_matching_loss * self.weight_matching
+        return decoded, {'recon_loss': recon_loss, 'commitment_loss': c_loss,
+                         'time_matching_loss': time_matching_loss, 'perplexity': perplexity,
+                         'total_loss': total_loss}
+
+    def predict(self, inputs):
+        """Prediction fn, same as forward pass."""
+        return self.forward(inputs)

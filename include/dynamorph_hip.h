@@ -267,6 +267,17 @@ int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *stream);
 int dm_loss_finalize(const double *loss_slabs, int nslabs, int64_t count, const float *vq_scalars,
                      float weight_recon, float weight_commitment, float *scalars_out, void *stream);
 
+/* ===== plain reconstruction loss (VQ_VAE_z32, vae.py:450-452: no 1x1 head to fuse with) ==== */
+/* loss_slabs[dm_recon_loss_num_blocks] = partial sums of (dec*m - x*m)^2 / var[c]  (dm_loss_finalize divides by N). */
+int dm_recon_loss_num_blocks(int B, int NIN, int H, int W);
+int dm_recon_loss(const float *decoded, const float *x, const float *mask, int mask_channels,
+                  const float *channel_var, double *loss_slabs, int B, int NIN, int H, int W, void *stream);
+/* g_decoded = gscale * 2/N * (dec*m - x*m) * m / var[c]; bias_slabs[num_blocks][NIN][2] = per-channel sums of g_decoded
+ * (the gradient of the last layer's bias; dm_sum_slabs). */
+int dm_recon_loss_backward(const float *decoded, const float *x, const float *mask, int mask_channels,
+                           const float *channel_var, const float *gscale_dev, float *g_decoded,
+                           double *bias_slabs, int B, int NIN, int H, int W, void *stream);
+
 /* ===== time-matching loss (vq_vae.py:324-332, vae.py:322-336) ================= */
 
 /* sim[i][j] = mean_d (z[i][d] - z[j][d])^2 for the B flattened latents z (B, n) -- the reference's

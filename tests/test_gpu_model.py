@@ -348,3 +348,61 @@ def test_fused_trainer_equals_autograd_path(golden):
         tr.step(x)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         close(a, b, 1e-6, 1e-7, k)
+
+
+# ===================================================================================== VQ_VAE_z32
+Z32_BN_FED_BIASES = ("enc.0.bias", "enc.3.bias", "dec.1.bias") + tuple(
+    f"{blk}.layers.{i}.{j}.bias" for blk in ("enc.5", "dec.0") for i in (0, 1) for j in (1, 4))
+
+
+def test_z32_forward_against_reference(golden):
+    """VQ_VAE_z32 (vae.py:348-474): latents, reconstruction and losses vs the vectors captured from the reference."""
+    import dynamorph_amd
+    g = golden("g8_z32.npz")
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    m = dynamorph_amd.VQ_VAE_z32().to(DEV)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd/")})
+    zb = m.enc(x)
+    close(zb, g["z_before"], 2e-5, 2e-5, "z32 z_before")
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd/")})
+    dec, ld = m(x)
+    assert list(ld.keys()) == ["recon_loss", "commitment_loss", "time_matching_loss", "perplexity", "total_loss"]
+    close(dec, g["decoded"], 1e-4, 1e-4, "z32 decoded")
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(g[k])) <= 1e-5, (k, float(ld[k]), float(g[k]))
+    assert abs(float(ld["perplexity"]) - float(g["perplexity"])) <= 1e-3 * float(g["perplexity"])
+
+
+def test_z32_gradients_against_oracle():
+    """Fresh weights and inputs, masked loss + time matching: every gradient vs the fp64 oracle (same gate as the
+    16x16 model: as close to the truth as the reference's own fp32 path, x1.5)."""
+    import copy
+    import dynamorph_amd
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(77)
+    ref = O.OracleVQVAEz32()
+    x = torch.randn(6, 2, 128, 128, generator=torch.Generator().manual_seed(78))
+    mask = (torch.rand(6, 1, 128, 128, generator=torch.Generator().manual_seed(79)) > 0.3).float()
+    tm = torch.randint(0, 3, (6, 6), generator=torch.Generator().manual_seed(80)).float()
+    ref64 = copy.deepcopy(ref).double()
+    m = dynamorph_amd.VQ_VAE_z32().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    _, ld_r = ref(x, time_matching_mat=tm, batch_mask=mask)
+    ld_r["total_loss"].backward()
+    _, ld64 = ref64(x.double(), time_matching_mat=tm.double(), batch_mask=mask.double())
+    ld64["total_loss"].backward()
+    _, ld = m(x.to(DEV), time_matching_mat=tm.to(DEV), batch_mask=mask.to(DEV))
+    ld["total_loss"].backward()
+    for k in ("recon_loss", "commitment_loss", "time_matching_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(ld_r[k])) <= 1e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+    ref2 = O.OracleVQVAEz32()
+    ref2.load_state_dict(ref.state_dict())       # BatchNorm buffers moved in the call above: fine for the index check
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for k, p in m.named_parameters():
+        if not p.requires_grad or k in Z32_BN_FED_BIASES:
+            continue
+        truth = g64[k].grad
+        scale = max(truth.abs().max().item(), 1e-6)
+        e_ref = (g32[k].grad.double() - truth).abs().max().item()
+        e_hip = (p.grad.cpu().double() - truth).abs().max().item()
+        assert e_hip <= max(1.5 * e_ref, 5e-4 * scale) + 1e-9, (k, e_hip, e_ref, scale)
