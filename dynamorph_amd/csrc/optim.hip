@@ -45,13 +45,19 @@ __global__ void e1_compose_kernel(const float *__restrict__ w0, const float *__r
     // bias_border[ry][rx][c1] = b1[c1] + sum over the taps inside the image of the ones-channel weights
     // (row class 0 = first output row: ky = 0 falls into the padding; class 2 = last row: ky = 3 does)
     if (bias_border) {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 9 * C1; i += gridDim.x * blockDim.x) {
-            const int c1 = i % C1, rx = (i / C1) % 3, ry = i / (3 * C1);
-            double s = b1 ? (double)b1[c1] : 0.0;
-            for (int ky = (ry == 0 ? 1 : 0); ky < (ry == 2 ? 3 : 4); ++ky)
-                for (int kx = (rx == 0 ? 1 : 0); kx < (rx == 2 ? 3 : 4); ++kx)
-                    for (int c = 0; c < C0; ++c) s += (double)w1[(c1 * C0 + c) * 16 + ky * 4 + kx] * (double)b0[c];
-            bias_border[i] = (float)s;
+        // 16 lanes per table entry, one per tap: its ones-channel weight (if the tap stays inside the image for that
+        // row / column class), then a 16-lane sum
+        const int gt = blockIdx.x * blockDim.x + threadIdx.x, t = gt & 15;
+        const int ky = t >> 2, kx = t & 3;
+        for (int i = gt >> 4; i < ((9 * C1 + 15) & ~15); i += (gridDim.x * blockDim.x) >> 4) {
+            const bool live = i < 9 * C1;
+            const int c1 = live ? i % C1 : 0, rx = live ? (i / C1) % 3 : 1, ry = live ? i / (3 * C1) : 1;
+            const bool inside = !(ry == 0 && ky == 0) && !(ry == 2 && ky == 3) && !(rx == 0 && kx == 0) && !(rx == 2 && kx == 3);
+            double s = 0.0;
+            if (live && inside)
+                for (int c = 0; c < C0; ++c) s += (double)w1[(c1 * C0 + c) * 16 + t] * (double)b0[c];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            if (live && t == 0) bias_border[i] = (float)(s + (b1 ? (double)b1[c1] : 0.0));
         }
     }
     const int total = C1 * (NIN + 1) * 16;
@@ -152,7 +158,7 @@ extern "C" int dm_e1_compose_border(const float *w0, const float *b0, const floa
                                     float *bias_border, int NIN, int C0, int C1, void *stream)
 {
     DM_REQUIRE(w0 && b0 && w1 && weff && bias_border && NIN > 0 && C0 > 0 && C1 > 0, "dm_e1_compose_border: bad argument");
-    hipLaunchKernelGGL(e1_compose_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, weff, bias_border,
+    hipLaunchKernelGGL(e1_compose_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, weff, bias_border,
                        NIN, C0, C1);
     return dm_launch_status("dm_e1_compose_border");
 }
