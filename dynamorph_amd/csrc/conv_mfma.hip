@@ -129,7 +129,7 @@ __device__ __forceinline__ f32x4 bias_relu(f32x4 v, const Epilogue &ep, float bi
 // quarters (lane >> 4) and, with PIX, of the 4 phase lanes are summed with shuffles.
 template <int NTT, bool PIX>
 __device__ __forceinline__ void stats_reduce(double (&s1)[NTT], double (&s2)[NTT], double (*s_stat)[2],
-                                             const Epilogue &ep, int NCH)
+                                             const Epilogue &ep, int NCH, long long slab)
 {
     // s_stat: [4 waves][NTT*16][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -157,8 +157,8 @@ __device__ __forceinline__ void stats_reduce(double (&s1)[NTT], double (&s2)[NTT
             a += s_stat[(w * NTT + t) * 16 + l][0];
             c += s_stat[(w * NTT + t) * 16 + l][1];
         }
-        ep.stats[((long long)blockIdx.x * NCH + ch) * 2 + 0] = a;
-        ep.stats[((long long)blockIdx.x * NCH + ch) * 2 + 1] = c;
+        ep.stats[(slab * NCH + ch) * 2 + 0] = a;
+        ep.stats[(slab * NCH + ch) * 2 + 1] = c;
     }
 }
 
@@ -175,7 +175,7 @@ __device__ __forceinline__ void zero_unowned_slabs(const Epilogue &ep, int NCH, 
 template <int CIN, int NT, int TH, int TW, int SIDE, int WPS, bool BB>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
-                      int W, int ntiles, int nslabs)
+                      int W, int ntiles, int nslabs, int per_tile)
 {
     constexpr int IH = 2 * TH + 2, RS = 2 * TW + 8, COLS4 = RS / 4, PS = IH * RS;
     constexpr int KS = CIN * 4, CG = TW / 16, MT = TH * CG, MTW = MT / 4;
@@ -298,10 +298,15 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
                     epilogue_tail<SIDE>(v, ep, cx, e[i][t], mc0[t], mc2[t], o[i][t], s1[t], s2[t]);
                 }
         }
+        if (per_tile && ep.stats) {                         // per-sample BatchNorm statistics: one slab per TILE
+            stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT, tidx);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
+        }
         tidx = next;
     }
-    if (ep.stats) {
-        stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT);
+    if (ep.stats && !per_tile) {
+        stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT, blockIdx.x);
         zero_unowned_slabs(ep, NOUT, nslabs);
     }
 }
@@ -310,7 +315,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
 template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO, int SIDE, int WPS>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
-                    int W, int ntiles, int nslabs)
+                    int W, int ntiles, int nslabs, int per_tile)
 {
     constexpr int PADR = TAPS == 9 ? 1 : 0;
     constexpr int IH = TH + 2 * PADR, RS = TAPS == 9 ? TW + 8 : TW, COLS4 = RS / 4;
@@ -461,11 +466,17 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                         epilogue_tail<SIDE>(v, ep, cx, e[i][t], mc0[t], mc2[t], o[i][t], s1[tt], s2[tt]);
                     }
             }
+            if (NPASS == 1 && per_tile && ep.stats) {       // per-sample BatchNorm statistics: one slab per TILE
+                stats_reduce<NTT, PIX>(s1, s2, s_stat, ep, CO, tidx);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
+            }
             tidx = next;
         }
     }
-    if (ep.stats) {
-        stats_reduce<NTT, PIX>(s1, s2, s_stat, ep, CO);
+    if (ep.stats && !(NPASS == 1 && per_tile)) {
+        // (NPASS > 1 with per-tile slabs: the launcher gives every tile its own workgroup, blockIdx.x == tile)
+        stats_reduce<NTT, PIX>(s1, s2, s_stat, ep, CO, blockIdx.x);
         zero_unowned_slabs(ep, CO, nslabs);
     }
 }
@@ -644,9 +655,9 @@ int side_mode(const Epilogue &ep)
 
 // persistent grid: as many workgroups as are co-resident, unless the caller needs one statistics slab
 // per tile with real contents (per-sample BatchNorm statistics)
-int conv_grid(int ntiles, int wgs_per_cu, int per_tile)
+int conv_grid(int ntiles, int wgs_per_cu, int per_tile, int npass = 1)
 {
-    if (per_tile) return ntiles;
+    if (per_tile && npass > 1) return ntiles;              // multi-pass kernels write their slab once, at the end
     const int cap = 256 * wgs_per_cu;
     return ntiles < cap ? ntiles : cap;
 }
@@ -686,11 +697,13 @@ void launch_conv4(const ConvArgs &a)
         if (SIDE_ == SIDE_NONE && CIN <= 5 && a.ep.bias_border)                                                   \
             hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_NONE, WPS, true>),                              \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
-                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));       \
+                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
+                               a.per_tile);                                                                           \
         else                                                                                                      \
             hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS, false>),                                 \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
-                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));       \
+                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
+                               a.per_tile);                                                                           \
     }
     switch (side_mode(a.ep)) {
     case SIDE_NONE: DM_L4(SIDE_NONE) break;
@@ -717,8 +730,8 @@ void launch_conv3(const ConvArgs &a)
     {                                                                                                             \
         constexpr int WPS = conv_wps(LDS, NT * (CIN / 4) * TAPS, F4, TWO_, NT == 1 ? 2 : 1, NT, SIDE_);          \
         hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS>),                 \
-                           dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
-                           a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));       \
+                           dim3(conv_grid(ntiles, WPS, a.per_tile, NPASS)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
+                           a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile), a.per_tile); \
     }
     // built variants: forward (no side inputs), data gradients with a mask-only side input (with or without
     // the BatchNorm-backward AFFINE2 operand), and the fully general one (residual join)
