@@ -69,18 +69,56 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     }
 }
 
-// Per-sample mode (process_VAE: every patch is its own batch), first half: one thread per (sample, channel) sums that
-// sample's slabs_per_group slabs and writes its coefficients; coef[..][3] carries the unbiased variance to the replay.
+// Per-sample mode (process_VAE: every patch is its own batch), ONE launch:
+//   blocks [0, nb): one thread per (sample, channel) sums that sample's slabs_per_group slabs and writes its coefficients;
+//   blocks [nb, nb + C): channel c = blockIdx - nb replays the running statistics of B successive batch-of-one calls.
+//     The recurrence r <- m*x_b + (1-m)*r unrolls to r = (1-m)^B r0 + sum_b m (1-m)^(B-1-b) x_b: every thread takes
+//     samples b, b+256, ... (statistics recomputed from the slabs, weight evaluated in double), one block sum per
+//     channel.  (The sequential fp32 form took 17 us at B = 1024; the closed form differs from it by fp32 rounding.)
 __global__ __launch_bounds__(256) void bn_finalize_per_sample_kernel(
     const double *__restrict__ stats, int B, int spg, int C, long long count, const float *__restrict__ gamma,
-    const float *__restrict__ beta, float eps, float *__restrict__ coef, float *__restrict__ saved)
+    const float *__restrict__ beta, float eps, float *__restrict__ coef, float *__restrict__ saved, int nb,
+    float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt, float momentum)
 {
+    const double n = (double)count;
+    const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
+    if ((int)blockIdx.x >= nb) {
+        __shared__ double s_red[4];
+        const int c = blockIdx.x - nb;
+        const bool track = running_mean && running_var;
+        const double m = (double)momentum, keep = 1.0 - m;
+        double sm = 0.0, sv = 0.0;
+        if (track) {
+            for (int b = threadIdx.x; b < B; b += blockDim.x) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int i = 0; i < spg; ++i) {
+                    s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
+                    s2 += stats[((long long)(b * spg + i) * C + c) * 2 + 1];
+                }
+                const double mean = s1 / n;
+                double var = s2 / n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const double w = m * pow(keep, (double)(B - 1 - b));
+                sm += w * (double)(float)mean;                       // the fp32 values a batch-of-one call would feed
+                sv += w * (double)(float)(var * unbias);
+            }
+        }
+        const double tm = block_sum(sm, s_red);
+        const double tv = block_sum(sv, s_red);
+        if (threadIdx.x == 0) {
+            if (track) {
+                const double k = pow(keep, (double)B);
+                running_mean[c] = (float)(k * (double)running_mean[c] + tm);
+                running_var[c] = (float)(k * (double)running_var[c] + tv);
+            }
+            if (nbt && c == 0) nbt[0] += B;
+        }
+        return;
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx - b * C;
     const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-    const double n = (double)count;
-    const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
     double s1 = 0.0, s2 = 0.0;
     for (int i = 0; i < spg; ++i) {
         s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
@@ -92,41 +130,9 @@ __global__ __launch_bounds__(256) void bn_finalize_per_sample_kernel(
     const float mean_f = (float)mean;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float scale = g * invstd;
-    *reinterpret_cast<f32x4 *>(coef + (long long)idx * 4) = (f32x4){scale, 0.f, bt - mean_f * scale, (float)(var * unbias)};
+    *reinterpret_cast<f32x4 *>(coef + (long long)idx * 4) = (f32x4){scale, 0.f, bt - mean_f * scale, 0.f};
     saved[(long long)idx * 2 + 0] = mean_f;
     saved[(long long)idx * 2 + 1] = invstd;
-}
-
-// Second half: the running statistics after B successive batch-of-one calls.  The recurrence
-// r <- m*x_b + (1-m)*r unrolls to r = (1-m)^B r0 + sum_b m (1-m)^(B-1-b) x_b: every thread takes samples b, b+256, ...
-// with the weight evaluated in double, one block sum per channel (the sequential fp32 form took 17 us at B = 1024;
-// the closed form differs from it by fp32 rounding only).  Then coef[..][3] = 0.
-__global__ __launch_bounds__(256) void bn_running_replay_kernel(
-    int B, int C, float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
-    float momentum, float *__restrict__ coef, const float *__restrict__ saved)
-{
-    __shared__ double s_red[4];
-    const int c = blockIdx.x;
-    const bool track = running_mean && running_var;
-    const double m = (double)momentum, keep = 1.0 - m;
-    double sm = 0.0, sv = 0.0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const double w = m * pow(keep, (double)(B - 1 - b));
-        sm += w * (double)saved[((long long)b * C + c) * 2 + 0];
-        sv += w * (double)coef[((long long)b * C + c) * 4 + 3];
-    }
-    const double tm = block_sum(sm, s_red);
-    const double tv = block_sum(sv, s_red);
-    __syncthreads();                                   // every read of coef[..][3] is done
-    for (int b = threadIdx.x; b < B; b += blockDim.x) coef[((long long)b * C + c) * 4 + 3] = 0.f;
-    if (threadIdx.x == 0) {
-        if (track) {
-            const double k = pow(keep, (double)B);
-            running_mean[c] = (float)(k * (double)running_mean[c] + tm);
-            running_var[c] = (float)(k * (double)running_var[c] + tv);
-        }
-        if (nbt && c == 0) nbt[0] += B;
-    }
 }
 
 // slabs hold (sum dy, sum dy*a).  x_hat = (a - mean)*invstd, so
@@ -252,10 +258,10 @@ extern "C" int dm_bn_finalize(const double *stats, int nslabs, int slabs_per_gro
     if (per_sample) {
         const int B = nslabs / slabs_per_group;
         DM_REQUIRE((long long)B * C < (1LL << 30), "dm_bn_finalize: too many (sample, channel) pairs");
-        hipLaunchKernelGGL(bn_finalize_per_sample_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                           stats, B, slabs_per_group, C, (long long)count_per_group, gamma, beta, eps, coef, saved);
-        hipLaunchKernelGGL(bn_running_replay_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, running_mean,
-                           running_var, (long long *)num_batches_tracked, momentum, coef, saved);
+        const int nb = (B * C + 255) / 256;
+        hipLaunchKernelGGL(bn_finalize_per_sample_kernel, dim3(nb + C), dim3(256), 0, (hipStream_t)stream, stats, B,
+                           slabs_per_group, C, (long long)count_per_group, gamma, beta, eps, coef, saved, nb, running_mean,
+                           running_var, (long long *)num_batches_tracked, momentum);
         return dm_launch_status("dm_bn_finalize");
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslabs, C,
