@@ -83,6 +83,7 @@ SIGNATURES = {
     "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
     "dm_adam_counted": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp, vp]),
+    "dm_zscore_patch": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "dm_augment": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
 }
 

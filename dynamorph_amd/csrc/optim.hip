@@ -124,6 +124,35 @@ __global__ __launch_bounds__(256) void augment_kernel(const float *__restrict__ 
 
 }  // namespace
 
+// Per-patch, per-channel z-score (pipeline/train_utils.py:252-274 zscore_patch, applied at patch_VAE.py:413-419 on a
+// float64 array that is then cast to float32): out = float((x - mean) / (std + eps)) with the population std over
+// H x W, all in double.  One workgroup per (patch, channel) plane; the plane is read twice (mean, then variance about
+// the mean -- numpy's np.std is the same two-pass form), the second and third read come from L2.
+template <typename T>
+__global__ __launch_bounds__(256) void zscore_patch_kernel(const T *__restrict__ in, float *__restrict__ out, int HW)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_bc[2];
+    const T *p = in + (long long)blockIdx.x * HW;
+    float *q = out + (long long)blockIdx.x * HW;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += (double)p[i];
+    const double tot = block_sum(s, s_red);
+    if (threadIdx.x == 0) s_bc[0] = tot / (double)HW;
+    __syncthreads();
+    const double mean = s_bc[0];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const double d = (double)p[i] - mean;
+        v += d * d;
+    }
+    const double var = block_sum(v, s_red);
+    if (threadIdx.x == 0) s_bc[1] = sqrt(var / (double)HW) + 2.220446049250313e-16;
+    __syncthreads();
+    const double denom = s_bc[1];
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) q[i] = (float)(((double)p[i] - mean) / denom);
+}
+
 extern "C" int dm_adam(float *param, const float *grad, float *m, float *v, int64_t n,
                        float lr, float beta1, float beta2, float eps, const float *step_dev, void *stream)
 {
@@ -182,4 +211,14 @@ extern "C" int dm_augment(const float *in, float *out, const int32_t *flip_code,
     hipLaunchKernelGGL(augment_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, (const int *)flip_code,
                        (const int *)rot_code, C, H, total);
     return dm_launch_status("dm_augment");
+}
+
+extern "C" int dm_zscore_patch(const void *in, int in_is_f64, float *out, int planes, int HW, void *stream)
+{
+    DM_REQUIRE(in && out && planes > 0 && HW > 0, "dm_zscore_patch: bad argument");
+    if (in_is_f64)
+        hipLaunchKernelGGL(zscore_patch_kernel<double>, dim3(planes), dim3(256), 0, (hipStream_t)stream, (const double *)in, out, HW);
+    else
+        hipLaunchKernelGGL(zscore_patch_kernel<float>, dim3(planes), dim3(256), 0, (hipStream_t)stream, (const float *)in, out, HW);
+    return dm_launch_status("dm_zscore_patch");
 }

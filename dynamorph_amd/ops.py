@@ -444,6 +444,19 @@ def adam_counted(param, grad, m, v, lr, beta1, beta2, eps, steps_done, steps_don
                                 _ptr(steps_done), _ptr(steps_done_next), _stream()), "dm_adam_counted")
 
 
+def zscore_patch(x):
+    """x (N, C, H, W) float64 or float32 device tensor -> float32 z-scored patches (per patch and channel)."""
+    lib = L.load()
+    if x.dtype not in (torch.float64, torch.float32):
+        raise ValueError("dm_zscore_patch: float64 or float32 input")
+    x = x.contiguous()
+    N, Cn, H, W = x.shape
+    out = torch.empty((N, Cn, H, W), device=x.device, dtype=torch.float32)
+    L.check(lib.dm_zscore_patch(C.c_void_p(x.data_ptr()), 1 if x.dtype == torch.float64 else 0, _ptr(out), N * Cn, H * W,
+                                _stream()), "dm_zscore_patch")
+    return out
+
+
 def augment(x, flip_code, rot_code):
     lib = L.load()
     B, Cn, H, W = x.shape

@@ -16,9 +16,12 @@ from . import engine as E
 from .train_utils import zscore_patch
 
 
-def encode_patches(model, patches, device="cuda:0", batch_size=1024):
+def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_device=False):
     """patches: (N, C, H, W) float tensor/array on the host.  Returns (z_before, z_after) as float32
-    numpy arrays of shape (N, D*H/8*W/8), in input order (patch_VAE.py:454,459)."""
+    numpy arrays of shape (N, D*H/8*W/8), in input order (patch_VAE.py:454,459).
+    zscore_on_device: `patches` are the RAW (float64) patches; each batch is z-scored per patch and channel on
+    the GPU (dm_zscore_patch, double arithmetic) instead of on the host (patch_VAE.py:413-419)."""
+    from . import ops
     patches = torch.as_tensor(patches)
     if patches.dim() != 4:
         raise AssertionError("dataset tensor dimension can only be 4, not {}".format(patches.dim()))
@@ -26,7 +29,10 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024):
     z_bs, z_as = [], []
     with torch.no_grad():
         for i in range(0, patches.shape[0], batch_size):
-            x = patches[i:i + batch_size].to(device=device, dtype=torch.float32).contiguous()
+            if zscore_on_device:
+                x = ops.zscore_patch(patches[i:i + batch_size].to(device=device))
+            else:
+                x = patches[i:i + batch_size].to(device=device, dtype=torch.float32).contiguous()
             z_b, _ = E.encoder_forward(layers, x, per_sample=True)
             z_a, _, _ = E.vq_forward(layers.codebook.weight, z_b, float(model.commitment_cost))
             z_bs.append(z_b.reshape(x.shape[0], -1).cpu())
@@ -55,8 +61,12 @@ def process_VAE(raw_folder, supp_folder, sites, config_, gpu=0, network_module=N
         fs = pickle.load(f)
     with open(os.path.join(raw_folder, '%s_static_patches.pkl' % well), 'rb') as f:
         dataset = pickle.load(f)
-    dataset = zscore_patch(np.squeeze(dataset))
-    dataset = torch.from_numpy(dataset).float()
+    on_dev = bool(kwargs.get("zscore_on_device", False))
+    if on_dev:
+        dataset = torch.from_numpy(np.ascontiguousarray(np.squeeze(dataset)))       # raw float64; z-scored per batch on the GPU
+    else:
+        dataset = zscore_patch(np.squeeze(dataset))
+        dataset = torch.from_numpy(dataset).float()
     assert dataset.dim() == 4, "dataset tensor dimension can only be 4, not {}".format(dataset.dim())
     assert len(fs) == dataset.shape[0]
     device = torch.device('cuda:%d' % gpu)
@@ -75,7 +85,8 @@ def process_VAE(raw_folder, supp_folder, sites, config_, gpu=0, network_module=N
     except Exception as ex:
         print(ex)
         raise ValueError("Error in loading model weights for VQ-VAE")
-    z_b, z_a = encode_patches(model, dataset, device=device, batch_size=kwargs.get("batch_size", 1024))
+    z_b, z_a = encode_patches(model, dataset, device=device, batch_size=kwargs.get("batch_size", 1024),
+                              zscore_on_device=on_dev)
     for name, dats in (('%s_latent_space.pkl' % well, z_b), ('%s_latent_space_after.pkl' % well, z_a)):
         with open(os.path.join(output_dir, name), 'wb') as f:
             pickle.dump(dats, f, protocol=4)

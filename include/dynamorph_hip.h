@@ -314,6 +314,12 @@ int dm_adam(float *param, const float *grad, float *m, float *v, int64_t n,
 int dm_adam_counted(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
                     float eps, const float *steps_done, float *steps_done_next, void *stream);
 
+/* ===== per-patch z-score (pipeline/train_utils.py:252-274, applied at patch_VAE.py:413-419) ============ */
+/* out[plane] = float((in[plane] - mean) / (std + eps)), population std over the HW elements of each of the `planes`
+ * (patch, channel) planes, arithmetic in double; `in` is float64 (in_is_f64 = 1, what the reference z-scores) or
+ * float32. */
+int dm_zscore_patch(const void *in, int in_is_f64, float *out, int planes, int HW, void *stream);
+
 /* ===== on-device augmentation (run_training.py:396-403) ======================= */
 /* out[b] = rot90(flip(in[b], flip_code[b]), k = rot_code[b]) on square (C,H,H) patches;
  * flip_code 0 none / 1 flip H / 2 flip W, rot_code 0..3 (counter-clockwise, dims [1,2]). */

@@ -437,6 +437,20 @@ def test_pair_msd_forward_backward(ops, B, n):
     close(dz, z.grad, 2e-5, 2e-6 * float(z.grad.abs().max()) + 1e-12, "d sim / d z")
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_zscore_patch_matches_numpy(ops, dtype):
+    """pipeline/train_utils.py:252-274 zscore_patch (float64 numpy, population std, + eps) then .float()."""
+    g = torch.Generator().manual_seed(51)
+    x = (torch.rand(5, 2, 128, 128, generator=g, dtype=torch.float64) * 3000 + 100).to(dtype)
+    xn = x.numpy().astype(np.float64)
+    ref = ((xn - xn.mean((2, 3), keepdims=True)) / (xn.std((2, 3), keepdims=True) + np.finfo(float).eps)).astype(np.float32)
+    out = ops.zscore_patch(x.to(DEV))
+    assert out.dtype == torch.float32
+    close(out, torch.from_numpy(ref), 2e-7, 2e-7, "zscore_patch")
+    const = ops.zscore_patch(torch.full((1, 1, 8, 8), 7.0, dtype=dtype, device=DEV))     # zero variance: 0 / eps
+    assert torch.equal(const.cpu(), torch.zeros(1, 1, 8, 8))
+
+
 def test_augment_matches_torch(ops):
     B, Cn, h = 9, 2, 16
     x = rnd(B, Cn, h, h, seed=1)
