@@ -815,6 +815,7 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
     DM_C4(4, 64) DM_C4(4, 32) DM_C4(4, 16)
     DM_C4(5, 64) DM_C4(5, 32) DM_C4(5, 16)
     DM_C4(2, 64) DM_C4(2, 32) DM_C4(2, 16)
+    DM_C4(1, 64) DM_C4(1, 32) DM_C4(1, 16)
     DM_C4(8, 32) DM_C4(8, 16)
     DM_C4(16, 16)
 #undef DM_C4

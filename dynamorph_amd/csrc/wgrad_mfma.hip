@@ -471,6 +471,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     }
     // enc.0 o enc.1 composite (x with ones channel), enc.4, enc.7
     DM_WG(8, 3, 4, 64) DM_WG(8, 3, 4, 32) DM_WG(8, 3, 4, 16) DM_WG(8, 5, 4, 64) DM_WG(8, 2, 4, 64) DM_WG(8, 4, 4, 64)
+    DM_WG(8, 1, 4, 64)
     DM_WG(16, 8, 4, 32) DM_WG(16, 8, 4, 64) DM_WG(16, 8, 4, 16)
     DM_WG(16, 16, 4, 16) DM_WG(16, 16, 4, 32)
     // enc.10 and residual convs

@@ -406,3 +406,54 @@ def test_z32_gradients_against_oracle():
         e_ref = (g32[k].grad.double() - truth).abs().max().item()
         e_hip = (p.grad.cpu().double() - truth).abs().max().item()
         assert e_hip <= max(1.5 * e_ref, 5e-4 * scale) + 1e-9, (k, e_hip, e_ref, scale)
+
+
+@pytest.mark.parametrize("B,nin,hw,masked", [(1, 2, 128, False), (3, 1, 128, True), (5, 3, 128, False), (2, 4, 256, True),
+                                             (7, 2, 128, True)])
+def test_shape_sweep_losses_and_gradients(B, nin, hw, masked):
+    """Odd batches, 1-4 input channels, 128 and 256 pixel patches: losses and a few gradients vs the CPU oracle
+    (the unfused decoder tail and the first-layer kernels for every num_inputs are exercised here)."""
+    import dynamorph_amd
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(1000 + B * 10 + nin)
+    kw = dict(num_inputs=nin, channel_var=np.linspace(0.5, 1.5, nin))
+    ref = O.OracleVQVAE(**kw)
+    x = torch.randn(B, nin, hw, hw, generator=torch.Generator().manual_seed(B))
+    mask = ((torch.rand(B, 1, hw, hw, generator=torch.Generator().manual_seed(B + 1)) > 0.5).float() if masked else None)
+    m = dynamorph_amd.VQ_VAE(**kw).to(DEV)
+    m.load_state_dict(ref.state_dict())
+    _, ld_r = ref(x, batch_mask=mask)
+    ld_r["total_loss"].backward()
+    dec, ld = m(x.to(DEV), batch_mask=None if mask is None else mask.to(DEV))
+    ld["total_loss"].backward()
+    assert dec.shape == x.shape
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+    g_ref = dict(ref.named_parameters())
+    for k in ("dec.6.weight", "dec.6.bias", "dec.4.weight", "dec.0.weight", "enc.0.weight", "enc.4.weight", "vq.w.weight"):
+        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("nin", [1, 3])
+def test_z32_other_input_channel_counts(nin):
+    import dynamorph_amd
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(500 + nin)
+    kw = dict(num_inputs=nin, channel_var=np.ones(nin))
+    ref = O.OracleVQVAEz32(**kw)
+    x = torch.randn(3, nin, 128, 128, generator=torch.Generator().manual_seed(nin))
+    m = dynamorph_amd.VQ_VAE_z32(**kw).to(DEV)
+    m.load_state_dict(ref.state_dict())
+    _, ld_r = ref(x)
+    ld_r["total_loss"].backward()
+    _, ld = m(x.to(DEV))
+    ld["total_loss"].backward()
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+    g_ref = dict(ref.named_parameters())
+    for k in ("dec.4.weight", "dec.4.bias", "dec.1.weight", "enc.0.weight", "enc.3.weight"):
+        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
