@@ -457,3 +457,34 @@ def test_z32_other_input_channel_counts(nin):
         a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
         scale = max(b.abs().max().item(), 1e-6)
         assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("B,nin,masked,use_graph", [(5, 1, True, False), (3, 4, True, True), (6, 3, False, True)])
+def test_fused_trainer_shape_sweep(B, nin, masked, use_graph):
+    """FusedTrainer (training tail in one kernel, slab codebook gradient, counted Adam) vs the oracle's
+    model(x) / backward / torch.optim.Adam.step for other channel counts, odd batches and masks."""
+    import dynamorph_amd
+    from dynamorph_amd.train import FusedTrainer
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(2000 + nin)
+    kw = dict(num_inputs=nin, channel_var=np.linspace(0.7, 1.3, nin))
+    ref = O.OracleVQVAE(**kw)
+    m = dynamorph_amd.VQ_VAE(**kw).to(DEV)
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(B, nin, 128, 128, generator=torch.Generator().manual_seed(B))
+    mask = ((torch.rand(B, 1, 128, 128, generator=torch.Generator().manual_seed(B + 7)) > 0.4).float() if masked else None)
+    opt = O.make_adam(ref, 1e-4)
+    tr = FusedTrainer(m, lr=1e-4, use_graph=use_graph)
+    xd, md = x.to(DEV), (None if mask is None else mask.to(DEV))
+    for step in range(2):
+        kw2 = {} if mask is None else {"batch_mask": mask}
+        ld_r = O.train_step(ref, opt, x, **kw2)
+        vals = tr.step(xd, md).tolist()
+        for i, k in enumerate(("recon_loss", "commitment_loss", "total_loss")):
+            assert abs(vals[i] - float(ld_r[k])) <= 3e-5 * max(1.0, abs(float(ld_r[k]))), (step, k, vals[i], float(ld_r[k]))
+    sd_r = ref.state_dict()
+    for k, v in m.state_dict().items():
+        if k in BN_FED_BIASES or "tracked" in k:
+            continue
+        # two Adam steps move every weight by at most 2*lr; compare the positions, not the noise-level directions
+        close(v, sd_r[k], 0, 2.5e-4 if "running" not in k else 2e-5, k)

@@ -95,3 +95,31 @@ def test_train_loop_mirror_runs_and_checkpoints(tmp_path):
     assert list(ck.keys()) == list(before.keys())
     assert any(not torch.equal(ck[k].cpu(), before[k].cpu()) for k in ck if "weight" in k)
     assert int(m.enc[2].num_batches_tracked) > 0
+
+
+@pytest.mark.parametrize("N,nin,hw", [(5, 1, 128), (3, 4, 128), (2, 3, 256)])
+def test_encode_patches_per_sample_shape_sweep(N, nin, hw):
+    """process_VAE semantics (batch-of-one enc -> vq calls, train-mode BatchNorm) for other channel counts and
+    patch sizes: the batched per-sample-statistics encoder vs the oracle's loop."""
+    import dynamorph_amd
+    from dynamorph_amd.patch_vae import encode_patches
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(300 + nin)
+    kw = dict(num_inputs=nin, channel_var=np.ones(nin))
+    ref = O.OracleVQVAE(**kw)
+    m = dynamorph_amd.VQ_VAE(**kw).to("cuda:0")
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(N, nin, hw, hw, generator=torch.Generator().manual_seed(N))
+    with torch.no_grad():
+        zb_r, za_r = O.encode_per_sample(ref, x)
+    zb, za = encode_patches(m, x, device="cuda:0", batch_size=4)
+    zb_r = zb_r.reshape(N, -1).numpy()
+    assert zb.shape == zb_r.shape
+    np.testing.assert_allclose(zb, zb_r, rtol=2e-4, atol=2e-4)
+    # codes: identical except at reference near-ties
+    flips = int((np.abs(za - za_r.reshape(N, -1).numpy()) > 1e-3).any(axis=0).sum())
+    assert flips <= za.shape[1] // 200, flips
+    # the running statistics advanced by N batch-of-one calls
+    assert int(m.enc[2].num_batches_tracked) == N
+    np.testing.assert_allclose(m.enc[2].running_mean.cpu().numpy(), ref.enc[2].running_mean.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.enc[2].running_var.cpu().numpy(), ref.enc[2].running_var.numpy(), rtol=1e-4, atol=1e-6)
