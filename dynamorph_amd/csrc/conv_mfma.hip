@@ -775,8 +775,9 @@ static int conv_common_checks(const char *who, const dm_operand *in, const dm_we
     DM_REQUIRE(w && w->w && out, "%s: NULL weight or output", who);
     DM_REQUIRE(B > 0 && CIN > 0 && NOUT > 0 && H > 0 && W > 0, "%s: bad shape", who);
     DM_REQUIRE(CIN <= DM_COEF_MAX_C, "%s: more than %d input channels", who, DM_COEF_MAX_C);
-    DM_REQUIRE((long long)B * (CIN > NOUT ? CIN : NOUT) * H * W * 4 < (1LL << 31),
-               "%s: tensor too large for 32-bit offsets", who);
+    // element offsets are 32-bit ints (byte offsets only appear relative to a sample, through the buffer descriptors)
+    DM_REQUIRE((long long)B * (CIN > NOUT ? CIN : NOUT) * H * W < (1LL << 31),
+               "%s: tensor too large for 32-bit element offsets", who);
     DM_REQUIRE(CIN - (in->ones_channel ? 1 : 0) > 0, "%s: no physical input channel", who);
     DM_REQUIRE((long long)NOUT * H * W * 4 < DM_VOFF_NONE, "%s: one output sample must stay below 1 GiB", who);
     if (ep && ep->mask.p0 && dm_check_operand(&ep->mask, who)) return -1;
