@@ -488,3 +488,26 @@ def test_fused_trainer_shape_sweep(B, nin, masked, use_graph):
             continue
         # two Adam steps move every weight by at most 2*lr; compare the positions, not the noise-level directions
         close(v, sd_r[k], 0, 2.5e-4 if "running" not in k else 2e-5, k)
+
+
+@pytest.mark.parametrize("H,W", [(128, 256), (256, 128)])
+def test_non_square_patches(H, W):
+    import dynamorph_amd
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(4242)
+    ref = O.OracleVQVAE()
+    x = torch.randn(2, 2, H, W, generator=torch.Generator().manual_seed(H + W))
+    m = dynamorph_amd.VQ_VAE().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    dec_r, ld_r = ref(x)
+    ld_r["total_loss"].backward()
+    dec, ld = m(x.to(DEV))
+    ld["total_loss"].backward()
+    close(dec, dec_r, 2e-4, 2e-4, "decoded")
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+    g_ref = dict(ref.named_parameters())
+    for k in ("dec.4.weight", "dec.2.weight", "enc.0.weight", "enc.7.weight"):
+        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
