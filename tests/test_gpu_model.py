@@ -511,3 +511,33 @@ def test_non_square_patches(H, W):
         a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
         scale = max(b.abs().max().item(), 1e-6)
         assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("nlayers,K", [(1, 64), (3, 100), (0, 7)])
+def test_other_residual_depths_and_codebook_sizes(nlayers, K):
+    import dynamorph_amd
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(77 + nlayers)
+    kw = dict(num_residual_layers=nlayers, num_embeddings=K)
+    ref = O.OracleVQVAE(**kw)
+    x = torch.randn(3, 2, 128, 128, generator=torch.Generator().manual_seed(nlayers))
+    m = dynamorph_amd.VQ_VAE(**kw).to(DEV)
+    m.load_state_dict(ref.state_dict())
+    _, ld_r = ref(x)
+    ld_r["total_loss"].backward()
+    _, ld = m(x.to(DEV))
+    ld["total_loss"].backward()
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+    g_ref = dict(ref.named_parameters())
+    for k in ("enc.10.weight", "enc.0.weight", "vq.w.weight", "dec.0.weight"):
+        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+
+
+def test_unbuilt_channel_family_raises():
+    import dynamorph_amd
+    m = dynamorph_amd.VQ_VAE(num_hiddens=64, num_residual_hiddens=64).to(DEV)
+    with pytest.raises(ValueError):
+        m(torch.randn(1, 2, 128, 128, device=DEV))
