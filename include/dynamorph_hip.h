@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 100
+#define DM_VERSION 101
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the

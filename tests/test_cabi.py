@@ -44,7 +44,7 @@ def test_struct_layouts_match_the_header():
 
 
 def test_version_and_host_only_queries(lib):
-    assert lib.dm_version() == 100
+    assert lib.dm_version() == 101          # 101: dm_epilogue gained bias_border
     assert lib.dm_vq_workspace_bytes(64, 16) == 64 * 16 * 4
     assert lib.dm_vq_workspace_bytes(63, 16) == 64 * 16 * 4           # odd K is padded to a pair
     assert lib.dm_vq_num_blocks(524288) == 2048
