@@ -159,6 +159,7 @@ def main():
     rank, world, local = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = local % max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B = args.batch or (2048 if args.workload == "c3" else 1024)
