@@ -53,6 +53,7 @@ class FusedTrainer:
         self._graph = None
         self._static_x = None
         self._static_mask = None
+        self._static_tm = None
         self._static_out = None
         D.broadcast_(self.flat, list(model.buffers()), group=self.group)    # same replica everywhere
 
@@ -64,8 +65,23 @@ class FusedTrainer:
         """Make p.grad point at the flat gradient views (for inspection / torch tooling)."""
         self.fp.expose_grads()
 
-    def forward_backward(self, x, mask=None):
-        """One forward + backward; returns the device tensor (recon, commitment, total, perplexity)."""
+    def _time_matching(self, sim, tm):
+        """(loss, d loss / d sim) of the pairwise term on the (B, B) matrix of mean-squared latent distances:
+        vq_vae.py:330-331 (sum of sim * matrix) or, for VQ_VAE_z16, vae.py:327-336 (weights, hinge, mean)."""
+        model = self.model
+        if not getattr(model, "_z16_loss", False):
+            return (sim * tm).sum(), tm
+        wts = torch.where(tm == 2, torch.full_like(tm, model.w_a),
+                          torch.where(tm == 1, torch.full_like(tm, model.w_t),
+                                      torch.where(tm == 0, torch.full_like(tm, model.w_n), tm)))
+        val = sim * wts
+        hinge = tm == 0
+        live = torch.where(hinge, (val + model.margin >= 0).to(sim.dtype), torch.ones_like(sim))
+        val = torch.where(hinge, torch.clamp(val + model.margin, min=0), val)
+        return val.mean(), wts * live / float(sim.numel())
+
+    def forward_backward(self, x, mask=None, time_matching_mat=None):
+        """One forward + backward; returns the device tensor (recon, commitment, total, perplexity[, time matching])."""
         model = self.model
         L = E.Layers(model)
         cc = float(model.commitment_cost)
@@ -87,6 +103,15 @@ class FusedTrainer:
             gcb.zero_()
             dz, _ = ops.vq_backward(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc, dw=gcb)
             extra = []
+        if time_matching_mat is not None:
+            # pairwise term on z_before (vq_vae.py:324-332): HIP kernels for the (B, B) distances and their gradient,
+            # the B*B weighting in torch
+            zf = z.reshape(B, -1)
+            sim = ops.pair_msd(zf)
+            tml, g_sim = self._time_matching(sim, time_matching_mat.to(sim.dtype))
+            wm = float(model.weight_matching)
+            dz = dz + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(z.shape)
+            scalars = torch.cat([scalars[:2], (scalars[2] + wm * tml).reshape(1), scalars[3:4], tml.reshape(1)])
         # the flat gradient buffer starts at zero and nothing ever writes the BatchNorm-fed conv biases' slots
         E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False, pending_extra=extra)
         return scalars
@@ -100,27 +125,31 @@ class FusedTrainer:
                          self.step_dev[a:a + 1], self.step_dev[b:b + 1])
         self._step_slot = b
 
-    def step(self, x, mask=None):
-        """One optimisation step on a device batch; returns the (4,) device tensor of LOSS_KEYS values."""
+    def step(self, x, mask=None, time_matching_mat=None):
+        """One optimisation step on a device batch; returns the device tensor of LOSS_KEYS values (+ the time-matching
+        loss as a fifth entry when a matrix is given)."""
         if not x.is_cuda:
             raise RuntimeError("FusedTrainer.step: batch must be on the GPU")
         x = x.contiguous()
         if not self.use_graph:
-            out = self.forward_backward(x, mask)
+            out = self.forward_backward(x, mask, time_matching_mat)
         else:
-            out = self._graph_step(x, mask)
+            out = self._graph_step(x, mask, time_matching_mat)
         self._allreduce()
         self._adam()
         return out
 
-    def _graph_step(self, x, mask):
-        key = (tuple(x.shape), None if mask is None else tuple(mask.shape))
+    def _graph_step(self, x, mask, tm=None):
+        key = (tuple(x.shape), None if mask is None else tuple(mask.shape), None if tm is None else tuple(tm.shape))
         if self._graph is None or self._graph_key != key:
             self._static_x = torch.empty_like(x)
             self._static_mask = torch.empty_like(mask) if mask is not None else None
+            self._static_tm = torch.empty_like(tm, dtype=torch.float32) if tm is not None else None
             self._static_x.copy_(x)
             if mask is not None:
                 self._static_mask.copy_(mask)
+            if tm is not None:
+                self._static_tm.copy_(tm)
             # warm-up on a side stream (allocator + lazy init), then capture.  The warm-up really executes,
             # so the BatchNorm running statistics it advanced are put back: only replays count as steps.
             bufs = list(self.model.buffers())
@@ -128,19 +157,21 @@ class FusedTrainer:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.forward_backward(self._static_x, self._static_mask)
+                self.forward_backward(self._static_x, self._static_mask, self._static_tm)
             torch.cuda.current_stream().wait_stream(s)
             for b, sv in zip(bufs, saved):
                 b.copy_(sv)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._static_out = self.forward_backward(self._static_x, self._static_mask)
+                self._static_out = self.forward_backward(self._static_x, self._static_mask, self._static_tm)
             self._graph, self._graph_key = g, key
         else:
             if x.data_ptr() != self._static_x.data_ptr():      # a loader may write straight into input_buffer()
                 self._static_x.copy_(x)
             if mask is not None and mask.data_ptr() != self._static_mask.data_ptr():
                 self._static_mask.copy_(mask)
+            if tm is not None:
+                self._static_tm.copy_(tm)
         self._graph.replay()
         return self._static_out
 
@@ -158,14 +189,12 @@ def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, t
         rots = torch.from_numpy(np.random.choice([0, 1, 2, 3], size=len(batch))).to(device=batch.device, dtype=torch.int32)
         batch = ops.augment(batch.contiguous(), flips, rots)       # one kernel instead of the O(B) python loop
     fused = isinstance(optimizer, FusedTrainer)
-    if fused and training and model_kwargs.get("time_matching_mat") is None:
-        vals = optimizer.step(batch, model_kwargs.get("batch_mask"))
+    if fused and training:
+        vals = optimizer.step(batch, model_kwargs.get("batch_mask"), model_kwargs.get("time_matching_mat"))
         vals = vals.tolist()                                           # one device sync per step (reference: five)
         loss_dict = dict(zip(LOSS_KEYS, vals))
-        loss_dict["time_matching_loss"] = 0.
+        loss_dict["time_matching_loss"] = vals[4] if len(vals) > 4 else 0.
     else:
-        if fused and training:
-            raise NotImplementedError("FusedTrainer has no time-matching term yet: pass a torch optimizer for it")
         _, loss_dict = model(batch, **model_kwargs)
         if training:
             loss_dict['total_loss'].backward()
@@ -185,8 +214,7 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     assert val_split_ratio is None or 0 < val_split_ratio < 1
     if patience is not None:
         assert val_split_ratio is not None
-    use_fused = fused and relation_mat is None
-    optimizer = FusedTrainer(model, lr=lr) if use_fused else torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
+    optimizer = FusedTrainer(model, lr=lr) if fused else torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
     model.zero_grad()
     n_samples = len(dataset)
     sample_ids = list(range(n_samples))

@@ -541,3 +541,32 @@ def test_unbuilt_channel_family_raises():
     m = dynamorph_amd.VQ_VAE(num_hiddens=64, num_residual_hiddens=64).to(DEV)
     with pytest.raises(ValueError):
         m(torch.randn(1, 2, 128, 128, device=DEV))
+
+
+@pytest.mark.parametrize("z16,use_graph", [(False, False), (True, True)])
+def test_fused_trainer_time_matching(z16, use_graph):
+    """FusedTrainer with the pairwise time-matching term (always on in the real run_training.py loop):
+    vq_vae.py:324-332 / vae.py:322-336 through dm_pair_msd(_backward), vs the oracle's autograd + Adam."""
+    import dynamorph_amd
+    from dynamorph_amd.train import FusedTrainer
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(909)
+    ref = O.OracleVQVAE(variant="z16") if z16 else O.OracleVQVAE()
+    m = (dynamorph_amd.VQ_VAE_z16 if z16 else dynamorph_amd.VQ_VAE)().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    B = 6
+    x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(5))
+    tm = torch.randint(0, 3, (B, B), generator=torch.Generator().manual_seed(6)).float()
+    opt = O.make_adam(ref, 1e-4)
+    tr = FusedTrainer(m, lr=1e-4, use_graph=use_graph)
+    for step in range(2):
+        ld_r = O.train_step(ref, opt, x, time_matching_mat=tm)
+        vals = tr.step(x.to(DEV), None, tm.to(DEV)).tolist()
+        assert len(vals) == 5
+        for i, k in ((0, "recon_loss"), (1, "commitment_loss"), (2, "total_loss"), (4, "time_matching_loss")):
+            assert abs(vals[i] - float(ld_r[k])) <= 3e-5 * max(1.0, abs(float(ld_r[k]))), (step, k, vals[i], float(ld_r[k]))
+    sd_r = ref.state_dict()
+    for k, v in m.state_dict().items():
+        if k in BN_FED_BIASES or "tracked" in k:
+            continue
+        close(v, sd_r[k], 0, 2.5e-4 if "running" not in k else 2e-5, k)
