@@ -33,6 +33,9 @@ class FusedTrainer:
     """Adam(lr, betas=(.9,.999), eps=1e-8) exactly as run_training.py:485 builds it, fused."""
 
     def __init__(self, model, lr=1e-3, betas=(.9, .999), eps=1e-8, process_group=None, use_graph=True):
+        from .vq_vae import VQ_VAE
+        if not isinstance(model, VQ_VAE):
+            raise TypeError("FusedTrainer is built for VQ_VAE / VQ_VAE_z16; train other modules with a torch optimizer")
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = process_group
@@ -214,7 +217,10 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     assert val_split_ratio is None or 0 < val_split_ratio < 1
     if patience is not None:
         assert val_split_ratio is not None
-    optimizer = FusedTrainer(model, lr=lr) if fused else torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
+    from .vq_vae import VQ_VAE
+    # the fused path is built for the 16x16-latent architecture; other modules (VQ_VAE_z32) train through autograd
+    use_fused = fused and isinstance(model, VQ_VAE)
+    optimizer = FusedTrainer(model, lr=lr) if use_fused else torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
     model.zero_grad()
     n_samples = len(dataset)
     sample_ids = list(range(n_samples))
