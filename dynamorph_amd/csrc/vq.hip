@@ -49,7 +49,7 @@ __device__ __forceinline__ bool vq_better(float cand, float best)
 // (s_load) operands cannot be pipelined that way (SMEM returns out of order: every wait is lgkmcnt(0)), which
 // left the first version of this kernel 58 % parked on s_waitcnt.
 template <int D, int PP>
-__global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : 2)) void vq_forward_kernel(
+__global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : (D <= 64 ? 2 : 1))) void vq_forward_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbT,
     long long *__restrict__ idx, float *__restrict__ out, double *__restrict__ sse_slabs,
     int *__restrict__ hist, int K, int HW, long long P)
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
     }
 }
 
-bool vq_dim_supported(int D) { return D == 8 || D == 16 || D == 32 || D == 64; }
+bool vq_dim_supported(int D) { return D == 8 || D == 16 || D == 32 || D == 64 || D == 128; }
 
 }  // namespace
 
@@ -304,7 +304,7 @@ extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx
 {
     DM_REQUIRE(z && codebook && sse_slabs && hist, "dm_vq_forward: NULL pointer");
     DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
-    DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d not built (8/16/32/64)", D);
+    DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d not built (8/16/32/64/128)", D);
     DM_REQUIRE(workspace && workspace_bytes >= dm_vq_workspace_bytes(K, D), "dm_vq_forward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)B * H * W;
@@ -320,7 +320,8 @@ extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx
     case 8: DM_VQ_FWD(8, VQ_PP); break;
     case 16: DM_VQ_FWD(16, VQ_PP); break;
     case 32: DM_VQ_FWD(32, VQ_PP); break;
-    default: DM_VQ_FWD(64, 1); break;
+    case 64: DM_VQ_FWD(64, 1); break;
+    default: DM_VQ_FWD(128, 1); break;        // VectorQuantizer's own default embedding_dim (vq_vae.py:35)
     }
 #undef DM_VQ_FWD
     return dm_launch_status("dm_vq_forward");
@@ -358,7 +359,7 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
                        int B, int D, int K, int H, int W, void *stream)
 {
     DM_REQUIRE(z && codebook && idx && (dw || dw_slabs), "%s: NULL pointer", who);
-    DM_REQUIRE(vq_dim_supported(D), "%s: embedding_dim %d not built (8/16/32/64)", who, D);
+    DM_REQUIRE(vq_dim_supported(D), "%s: embedding_dim %d not built (8/16/32/64/128)", who, D);
     const long long P = (long long)B * H * W;
     const size_t lds = (size_t)K * D * sizeof(float);
     const int use_lds = lds <= 48 * 1024;
@@ -372,7 +373,8 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
     case 8: DM_VQ_BWD(8); break;
     case 16: DM_VQ_BWD(16); break;
     case 32: DM_VQ_BWD(32); break;
-    default: DM_VQ_BWD(64); break;
+    case 64: DM_VQ_BWD(64); break;
+    default: DM_VQ_BWD(128); break;
     }
 #undef DM_VQ_BWD
     return dm_launch_status(who);

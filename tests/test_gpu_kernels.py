@@ -88,7 +88,8 @@ def test_vq_forward_stress_golden(ops, golden, name):
         assert abs(sc[1] - g["perplexity"]) <= 2e-5 * abs(g["perplexity"])
 
 
-@pytest.mark.parametrize("B,D,K,H,W", [(3, 16, 64, 16, 16), (2, 16, 63, 8, 12), (1, 32, 10, 4, 4), (5, 8, 7, 16, 16)])
+@pytest.mark.parametrize("B,D,K,H,W", [(3, 16, 64, 16, 16), (2, 16, 63, 8, 12), (1, 32, 10, 4, 4), (5, 8, 7, 16, 16),
+                                       (2, 64, 40, 8, 8), (2, 128, 128, 8, 8)])
 def test_vq_forward_vs_c_oracle(ops, cvq, B, D, K, H, W):
     z = rnd(B, D, H, W, seed=B + D + K).numpy()
     cb = rnd(K, D, seed=K).numpy()
