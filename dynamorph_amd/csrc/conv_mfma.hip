@@ -34,6 +34,11 @@
 #include "tile.h"
 #include "mfma_util.h"
 
+// fallbacks for shapes / channel families without an MFMA instantiation (conv_generic.hip)
+int dm_generic_conv_slabs(int B, int per_tile);
+int dm_generic_conv(int form, const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys,
+                    int CIN, int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st);
+
 namespace {
 
 // ----------------------------------------------------------------------------- epilogue
@@ -787,48 +792,61 @@ static int conv_common_checks(const char *who, const dm_operand *in, const dm_we
     return 0;
 }
 
-extern "C" int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, int per_tile)
+// tile width of the MFMA path for this shape, 0 when the shape is not tileable by it
+static int conv4_fast_tw(int CIN, int NOUT, int H, int W)
 {
-    (void)NOUT;
     const int Wo = W / 2, Ho = H / 2;
     const int TW = conv4_tw(CIN, Wo);
-    if (TW <= 0 || Ho % 8 || Wo % TW) return -1;
-    return conv_slabs(B * (Ho / 8) * (Wo / TW), per_tile);
+    if (H % 16 || W % 32 || NOUT > 16 || (TW != 16 && TW != 32 && TW != 64) || Ho % 8 || Wo % TW) return 0;
+    return TW;
+}
+
+extern "C" int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, int per_tile)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return -1;
+    const int TW = conv4_fast_tw(CIN, NOUT, H, W);
+    if (!TW) return dm_generic_conv_slabs(B, per_tile);
+    return conv_slabs(B * ((H / 2) / 8) * ((W / 2) / TW), per_tile);
 }
 
 extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
                             int B, int CIN, int NOUT, int H, int W, void *stream)
 {
     if (conv_common_checks("dm_conv4x4s2", in, w, out, ep, B, CIN, NOUT, H, W)) return -1;
-    DM_REQUIRE(H % 16 == 0 && W % 32 == 0, "dm_conv4x4s2: H must be a multiple of 16 and W of 32 (got %dx%d)", H, W);
-    DM_REQUIRE(NOUT <= 16, "dm_conv4x4s2: NOUT %d > 16 not built", NOUT);
-    DM_REQUIRE(in->mode != DM_LOAD_AFFINE2, "dm_conv4x4s2: AFFINE2 operand not built for this kernel");
-    DM_REQUIRE(!(ep && ep->bias_border) || (CIN <= 5 && !ep->mask.p0 && !ep->resid && !ep->stat_q && W / 2 >= 8),
-               "dm_conv4x4s2: bias_border is built for the first layer only (CIN <= 5, no side inputs)");
-    const int Wo = W / 2;
-    const int TW = conv4_tw(CIN, Wo);
-    DM_REQUIRE(TW == 16 || TW == 32 || TW == 64, "dm_conv4x4s2: output width %d not tileable", Wo);
-    DM_REQUIRE(Wo % TW == 0, "dm_conv4x4s2: output width %d not a multiple of tile %d", Wo, TW);
+    DM_REQUIRE(H % 2 == 0 && W % 2 == 0, "dm_conv4x4s2: H and W must be even (got %dx%d)", H, W);
     ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN - (in->ones_channel ? 1 : 0), CIN, NOUT, H, W,
                ep ? ep->stats_per_tile : 0, (hipStream_t)stream};
+    const int TW = conv4_fast_tw(CIN, NOUT, H, W);
+    const bool border_ok = !(ep && ep->bias_border) || (CIN <= 5 && !ep->mask.p0 && !ep->resid && !ep->stat_q && W / 2 >= 8);
+    if (TW && in->mode != DM_LOAD_AFFINE2 && border_ok) {
 #define DM_C4(C, T) if (CIN == C && TW == T) { launch_conv4<C, T>(a); return dm_launch_status("dm_conv4x4s2"); }
-    DM_C4(3, 64) DM_C4(3, 32) DM_C4(3, 16)
-    DM_C4(4, 64) DM_C4(4, 32) DM_C4(4, 16)
-    DM_C4(5, 64) DM_C4(5, 32) DM_C4(5, 16)
-    DM_C4(2, 64) DM_C4(2, 32) DM_C4(2, 16)
-    DM_C4(1, 64) DM_C4(1, 32) DM_C4(1, 16)
-    DM_C4(8, 32) DM_C4(8, 16)
-    DM_C4(16, 16)
+        DM_C4(3, 64) DM_C4(3, 32) DM_C4(3, 16)
+        DM_C4(4, 64) DM_C4(4, 32) DM_C4(4, 16)
+        DM_C4(5, 64) DM_C4(5, 32) DM_C4(5, 16)
+        DM_C4(2, 64) DM_C4(2, 32) DM_C4(2, 16)
+        DM_C4(1, 64) DM_C4(1, 32) DM_C4(1, 16)
+        DM_C4(8, 32) DM_C4(8, 16)
+        DM_C4(16, 16)
 #undef DM_C4
-    dm_set_error("dm_conv4x4s2: no kernel built for CIN=%d (tile width %d)", CIN, TW);
-    return -1;
+    }
+    // no MFMA instantiation for this channel count / shape / operand mode: generic kernel (conv_generic.hip)
+    dm_generic_conv(0, a.in, a.wv, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, 16,
+                    dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W, a.per_tile), a.per_tile, a.stream);
+    return dm_launch_status("dm_conv4x4s2");
+}
+
+static bool conv3_fast_tileable(int CIN, int H, int W)
+{
+    const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
+    return (TW == 16 || TW == 32 || TW == 64) && W % TW == 0 && H % TH == 0 && CIN % 4 == 0 && CIN <= 32;
 }
 
 extern "C" int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile)
 {
     (void)NOUT; (void)taps; (void)pixel_shuffle;
+    if (B <= 0 || H <= 0 || W <= 0) return -1;
+    if (!conv3_fast_tileable(CIN, H, W)) return dm_generic_conv_slabs(B, per_tile);
     const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
-    if (TW <= 0 || H % TH || W % TW) return -1;
     return conv_slabs(B * (H / TH) * (W / TW), per_tile);
 }
 
@@ -839,13 +857,13 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
     DM_REQUIRE(taps == 9 || taps == 1, "dm_conv3x3: taps must be 9 or 1");
     DM_REQUIRE(!pixel_shuffle || (taps == 9 && NOUT % 4 == 0), "dm_conv3x3: pixel_shuffle needs taps=9, NOUT%%4==0");
     DM_REQUIRE(!in->ones_channel, "dm_conv3x3: ones_channel not supported");
-    const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
-    DM_REQUIRE((TW == 16 || TW == 32 || TW == 64) && W % TW == 0 && H % TH == 0,
-               "dm_conv3x3: spatial size %dx%d not tileable", H, W);
+    const int TW = conv3_tw(W);
+    const bool fast = conv3_fast_tileable(CIN, H, W);
     ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN, CIN, NOUT, H, W, ep ? ep->stats_per_tile : 0,
                (hipStream_t)stream};
     const int NTT = (NOUT + 15) / 16;
     const bool pix = pixel_shuffle != 0;
+    if (fast) {
     // ConvTranspose2d with 16 input and 8 / 16 output channels (dec.0, data gradients of enc.4 / enc.7): phase-decomposed
     // kernel C; per-tile statistics slabs (per-sample BatchNorm) stay with the neighbourhood kernel B
 #define DM_CP(CO, T)                                                                       \
@@ -873,7 +891,9 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
     DM_C3(8, 1, 1, 1, 9, true, 32) DM_C3(8, 1, 1, 1, 9, true, 64)
     DM_C3(4, 1, 1, 1, 9, true, 64)
 #undef DM_C3
-    dm_set_error("dm_conv3x3: no kernel built for CIN=%d NOUT=%d taps=%d pixel_shuffle=%d width=%d", CIN, NOUT, taps,
-                 pixel_shuffle, W);
-    return -1;
+    }
+    // no MFMA instantiation for this channel count / shape: generic kernel (conv_generic.hip)
+    dm_generic_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps,
+                    dm_conv3x3_num_blocks(B, CIN, NOUT, H, W, taps, pixel_shuffle, a.per_tile), a.per_tile, a.stream);
+    return dm_launch_status("dm_conv3x3");
 }

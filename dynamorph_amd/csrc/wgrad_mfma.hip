@@ -18,6 +18,10 @@
 #include "dm_common.h"
 #include "tile.h"
 
+// fallback for shapes / channel families without an MFMA instantiation (conv_generic.hip)
+int dm_generic_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int CTphys, int Hs, int Ws,
+                     int KK, int nslabs, hipStream_t st);
+
 namespace {
 
 constexpr int WG_MAX_BLOCKS = 512;     // 2 workgroups per CU
@@ -435,12 +439,19 @@ extern "C" int dm_reduce_slabs(const float *slabs, int nslabs, int E, float *dst
     return dm_launch_status("dm_reduce_slabs");
 }
 
-extern "C" int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k)
+static bool wgrad_fast_tileable(int CS, int CT, int Hs, int Ws, int k)
 {
     const int TW = wgrad_tw(Ws);
-    if (TW <= 0 || (k != 4 && k != 3 && k != 1)) return -1;
+    if (TW != 16 && TW != 32 && TW != 64) return false;
     const int TH = wgrad_th(CS, CT, k, TW);
-    if (Hs % TH || Ws % TW) return -1;
+    return Hs % TH == 0 && Ws % TW == 0;
+}
+
+extern "C" int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k)
+{
+    if (B <= 0 || (k != 4 && k != 3 && k != 1)) return -1;
+    if (!wgrad_fast_tileable(CS, CT, Hs, Ws, k)) return B < WG_MAX_BLOCKS ? B : WG_MAX_BLOCKS;
+    const int TW = wgrad_tw(Ws), TH = wgrad_th(CS, CT, k, TW);
     const long long ntiles = (long long)B * (Hs / TH) * (Ws / TW);
     return (int)(ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS);
 }
@@ -453,9 +464,8 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     DM_REQUIRE((long long)B * (CS > 4 * CT ? CS : 4 * CT) * Hs * Ws < (1LL << 31), "dm_wgrad: tensor too large for 32-bit offsets");
     DM_REQUIRE(k == 4 || k == 3 || k == 1, "dm_wgrad: kernel size %d not built", k);
     DM_REQUIRE(!S->ones_channel, "dm_wgrad: S cannot carry a ones channel");
-    const int TW = wgrad_tw(Ws), TH = wgrad_th(CS, CT, k, TW);
-    DM_REQUIRE((TW == 16 || TW == 32 || TW == 64) && Hs % TH == 0 && Ws % TW == 0,
-               "dm_wgrad: S spatial size %dx%d not tileable", Hs, Ws);
+    const int TW = wgrad_tw(Ws);
+    const bool fast = wgrad_fast_tileable(CS, CT, Hs, Ws, k);
     const int grid = dm_wgrad_num_blocks(B, CS, CT, Hs, Ws, k);
     DM_REQUIRE(T->mode != DM_LOAD_AFFINE2, "dm_wgrad: T operand cannot be AFFINE2");
     const int CTphys = CT - (T->ones_channel ? 1 : 0);
@@ -465,7 +475,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     const int E = CS * CT * k * k;
     bool done = false;
 #define DM_WG(CS_, CT_, K_, TW_)                                                         \
-    if (!done && CS == CS_ && CT == CT_ && k == K_ && TW == TW_) {                       \
+    if (fast && !done && CS == CS_ && CT == CT_ && k == K_ && TW == TW_) {               \
         launch_wgrad<CS_, CT_, K_, TW_>(s, t, slabs, B, CTphys, Hs, Ws, grid, st);       \
         done = true;                                                                     \
     }
@@ -482,10 +492,8 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     DM_WG(8, 4, 4, 32) DM_WG(8, 4, 4, 64)
     DM_WG(4, 4, 4, 64)
 #undef DM_WG
-    if (!done) {
-        dm_set_error("dm_wgrad: no kernel built for CS=%d CT=%d k=%d width=%d", CS, CT, k, Ws);
-        return -1;
-    }
+    if (!done)       // no MFMA instantiation for this channel pair / shape: generic kernel (conv_generic.hip)
+        dm_generic_wgrad(s, t, slabs, B, CS, CT, CTphys, Hs, Ws, k, grid, st);
     int rc = dm_launch_status("dm_wgrad");
     if (rc || !dst) return rc;          // dst == NULL: the caller reduces the slabs later (dm_reduce_slabs_multi)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 15) / 16), dim3(256), 0, st, slabs, grid, E, dst);

@@ -50,7 +50,8 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_vq_num_blocks(524288) == 2048
     assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128, 1) == 2048 * 8   # one slab per tile (per-sample stats)
     assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128, 0) == 768        # persistent grid
-    assert lib.dm_conv4x4s2_num_blocks(1, 3, 8, 100, 100, 0) == -1            # not tileable
+    assert lib.dm_conv4x4s2_num_blocks(1, 3, 8, 100, 100, 0) == 1             # not tileable by the MFMA path: generic kernel, one slab per sample
+    assert lib.dm_conv4x4s2_num_blocks(1, 3, 8, 101, 100, 0) == -1            # odd height: no 4x4/s2 output grid
     assert lib.dm_conv3x3_num_blocks(4, 16, 16, 16, 16, 9, 0, 0) == 4
     assert lib.dm_conv3x3_num_blocks(4, 32, 16, 16, 16, 9, 0, 1) == 8         # 32 input channels: 8-row tiles
     assert lib.dm_wgrad_num_blocks(2048, 8, 3, 64, 64, 4) == 512     # persistent grid cap

@@ -233,6 +233,69 @@ def test_conv_dgrad_of_strided_conv_pixel_shuffle(ops):
     close(st.sum(0), _stats_ref(ref, a_prev), 1e-5, 2e-3, "stats")
 
 
+# ===================================================================== generic fallback kernels
+@pytest.mark.parametrize("cin,nout,h,w,mode,ones", [(24, 40, 20, 36, 3, False), (6, 33, 128, 128, 0, True), (32, 64, 64, 64, 3, False)])
+def test_generic_conv4x4s2(ops, cin, nout, h, w, mode, ones):
+    """Channel counts / sizes without an MFMA instantiation fall through to conv_generic.hip (same semantics)."""
+    B = 3
+    cphys = cin - (1 if ones else 0)
+    x = rnd(B, cphys, h, w, seed=1)
+    wt = rnd(nout, cin, 4, 4, seed=2, scale=0.2)
+    bias = rnd(nout, seed=3)
+    coef = torch.stack([rnd(cphys, seed=4).abs() + 0.5, torch.zeros(cphys), rnd(cphys, seed=5) * 0.3, torch.zeros(cphys)], 1)
+    xin = load_ref(x, mode, coef)
+    if ones:
+        xin = torch.cat([xin, torch.ones(B, 1, h, w)], 1)
+    ref = F.conv2d(xin, wt, bias, stride=2, padding=1)
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, ones=ones),
+                            ops.weight_view(wt.to(DEV), cin * 16, 16, 4, 1), B, cin, nout, h, w, want_stats=True,
+                            bias=bias.to(DEV))
+    close(out, ref, 5e-5, 5e-5, "generic conv4x4s2")
+    close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+
+
+@pytest.mark.parametrize("cin,nout,hw,taps", [(20, 12, 10, 9), (64, 64, 16, 9), (64, 32, 16, 1), (48, 16, 12, 1)])
+def test_generic_conv3x3(ops, cin, nout, hw, taps):
+    B = 2
+    x = rnd(B, cin, hw, hw, seed=1)
+    k = 3 if taps == 9 else 1
+    wt = rnd(nout, cin, k, k, seed=2, scale=0.2)
+    act, resid = rnd(B, nout, hw, hw, seed=3), rnd(B, nout, hw, hw, seed=4)
+    ref = F.conv2d(F.relu(x), wt, None, padding=k // 2) * (act > 0) + resid
+    out, st = ops.conv3x3(ops.Op(x.to(DEV), 1), ops.weight_view(wt.to(DEV), cin * taps, taps, 3 if taps == 9 else 0, 1 if taps == 9 else 0),
+                          B, cin, nout, hw, hw, taps=taps, want_stats=True, mask=ops.Op(act.to(DEV)), resid=resid.to(DEV),
+                          stat_q=act.to(DEV))
+    close(out, ref, 5e-5, 5e-5, "generic conv3x3")
+    close(st.sum(0), _stats_ref(ref, act), 1e-5, 1e-3, "stats q")
+
+
+@pytest.mark.parametrize("ci,co,hw", [(12, 6, 6), (64, 32, 16), (32, 16, 32)])
+def test_generic_conv_transpose(ops, ci, co, hw):
+    B = 2
+    x = rnd(B, ci, hw, hw, seed=1)
+    wt = rnd(ci, co, 4, 4, seed=2, scale=0.2)
+    bias = rnd(co, seed=3)
+    ref = F.relu(F.conv_transpose2d(x, wt, bias, stride=2, padding=1))
+    out, st = ops.conv3x3(ops.Op(x.to(DEV)), ops.weight_view(wt.to(DEV), 16, co * 16, 4, 1), B, ci, 4 * co, hw, hw,
+                          taps=9, pixel_shuffle=True, want_stats=True, bias=bias.to(DEV), relu=True)
+    close(out, ref, 5e-5, 5e-5, "generic conv transpose")
+    close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+
+
+@pytest.mark.parametrize("cs,ct,k,hs", [(12, 20, 4, 10), (64, 64, 3, 16), (32, 64, 1, 16), (64, 32, 4, 16)])
+def test_generic_wgrad(ops, cs, ct, k, hs):
+    B = 3
+    s, p = (2, 1) if k == 4 else ((1, 1) if k == 3 else (1, 0))
+    ht = hs * s
+    S = rnd(B, cs, hs, hs, seed=1)
+    T = rnd(B, ct, ht, ht, seed=2)
+    w = torch.zeros(cs, ct, k, k, requires_grad=True)
+    F.conv2d(T, w, None, stride=s, padding=p).backward(S)
+    dst = torch.empty(cs, ct, k, k, device=DEV)
+    ops.wgrad(ops.Op(S.to(DEV)), ops.Op(T.to(DEV)), dst, B, cs, ct, hs, hs, k)
+    close(dst, w.grad, 5e-5, 5e-5 * w.grad.abs().max().item(), "generic wgrad")
+
+
 # =============================================================================== wgrad
 @pytest.mark.parametrize("cs,ct,k,hs,ones,B", [
     (8, 3, 4, 64, True, 3), (16, 8, 4, 32, False, 3), (16, 16, 4, 16, False, 5), (16, 16, 3, 16, False, 5),
@@ -472,7 +535,7 @@ def test_bad_arguments_raise(ops):
     with pytest.raises(ValueError):
         ops.vq_forward(rnd(1, 5, 4, 4).to(DEV), rnd(4, 5).to(DEV))       # embedding_dim 5 not built
     with pytest.raises(ValueError):
-        ops.conv3x3(ops.Op(x), ops.weight_view(x, 1, 1, 1, 1), 1, 16, 16, 10, 10, taps=9)   # 10x10 not tileable
+        ops.conv3x3(ops.Op(x), ops.weight_view(x, 1, 1, 1, 1), 1, 16, 16, 16, 16, taps=5)   # only 3x3 and 1x1
     with pytest.raises(ValueError):
         ops.vq_forward(rnd(1, 16, 4, 4), rnd(4, 16))                       # CPU tensors: no fallback
 
