@@ -63,6 +63,7 @@ SIGNATURES = {
     "dm_sum_slabs": (C.c_int, [vp, C.c_int, C.c_int, f32, vp, vp]),
     "dm_sum_slabs_scatter": (C.c_int, [vp, C.c_int, C.c_int, f32, C.POINTER(Scatter), vp]),
     "dm_reduce_slabs_multi": (C.c_int, [C.POINTER(ReduceSeg), C.c_int, vp]),
+    "dm_head_supported": (C.c_int, [C.c_int] * 2),
     "dm_head_num_blocks": (C.c_int, [C.c_int] * 3),
     "dm_head_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_head_backward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),

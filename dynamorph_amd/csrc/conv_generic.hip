@@ -135,13 +135,18 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(Operand S, Operand T
     const int E = CS * CT * KK * KK;
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
         const int kx = e % KK, ky = (e / KK) % KK, ct = (e / (KK * KK)) % CT, cs = e / (KK * KK * CT);
-        float acc = 0.f;
+        // rows are summed in fp32, rows into a double: the gradients of weights that see a BatchNorm-backward operand
+        // are small differences of large sums, and one long fp32 chain loses them
+        double acc = 0.0;
         for (int b = blockIdx.x; b < B; b += gridDim.x)
-            for (int y = 0; y < Hs; ++y)
+            for (int y = 0; y < Hs; ++y) {
+                float row = 0.f;
                 for (int x = 0; x < Ws; ++x)
-                    acc += gen_load(S, b, cs, y, x, CS, Hs, Ws) *
+                    row += gen_load(S, b, cs, y, x, CS, Hs, Ws) *
                            gen_load(T, b, ct, y * stride + ky - pad, x * stride + kx - pad, CTphys, Ht, Wt);
-        slabs[(long long)blockIdx.x * E + e] = acc;
+                acc += (double)row;
+            }
+        slabs[(long long)blockIdx.x * E + e] = (float)acc;
     }
     for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x)
         for (int e = threadIdx.x; e < E; e += blockDim.x) slabs[(long long)t2 * E + e] = 0.f;

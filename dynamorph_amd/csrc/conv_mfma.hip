@@ -779,7 +779,6 @@ static int conv_common_checks(const char *who, const dm_operand *in, const dm_we
     if (dm_check_operand(in, who)) return -1;
     DM_REQUIRE(w && w->w && out, "%s: NULL weight or output", who);
     DM_REQUIRE(B > 0 && CIN > 0 && NOUT > 0 && H > 0 && W > 0, "%s: bad shape", who);
-    DM_REQUIRE(CIN <= DM_COEF_MAX_C, "%s: more than %d input channels", who, DM_COEF_MAX_C);
     // element offsets are 32-bit ints (byte offsets only appear relative to a sample, through the buffer descriptors)
     DM_REQUIRE((long long)B * (CIN > NOUT ? CIN : NOUT) * H * W < (1LL << 31),
                "%s: tensor too large for 32-bit element offsets", who);

@@ -224,13 +224,26 @@ extern "C" int dm_head_num_blocks(int B, int H, int W)
     return (int)(g < HEAD_MAX_BLOCKS ? g : HEAD_MAX_BLOCKS);
 }
 
-#define DM_HEAD_DISPATCH(KERNEL, ...)                                                                   \
+#define DM_HEAD_NIN(KERNEL, C4V, ...)                                                                   \
     switch (NIN) {                                                                                      \
-    case 1: hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;       \
-    case 2: hipLaunchKernelGGL((KERNEL<4, 2>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;       \
-    case 3: hipLaunchKernelGGL((KERNEL<4, 3>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;       \
-    default: hipLaunchKernelGGL((KERNEL<4, 4>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;      \
+    case 1: hipLaunchKernelGGL((KERNEL<C4V, 1>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;     \
+    case 2: hipLaunchKernelGGL((KERNEL<C4V, 2>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;     \
+    case 3: hipLaunchKernelGGL((KERNEL<C4V, 3>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;     \
+    default: hipLaunchKernelGGL((KERNEL<C4V, 4>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;    \
     }
+#define DM_HEAD_DISPATCH(KERNEL, ...)                                                                   \
+    switch (C4) {                                                                                       \
+    case 4: DM_HEAD_NIN(KERNEL, 4, __VA_ARGS__) break;                                                  \
+    case 8: DM_HEAD_NIN(KERNEL, 8, __VA_ARGS__) break;                                                  \
+    default: DM_HEAD_NIN(KERNEL, 16, __VA_ARGS__) break;                                                \
+    }
+
+// num_hiddens 16/32/64 x num_inputs 1..4 are instantiated; anything else goes through the generic 1x1 convolution
+// (dm_conv3x3 taps=1) + dm_recon_loss(_backward) on the host side (engine.py)
+extern "C" int dm_head_supported(int C4, int NIN)
+{
+    return (C4 == 4 || C4 == 8 || C4 == 16) && NIN >= 1 && NIN <= 4;
+}
 
 extern "C" int dm_head_forward(const float *d4, const float *w6, const float *b6, const float *x, const float *mask,
                                int mask_channels, const float *channel_var, float *decoded, double *loss_slabs,
@@ -238,7 +251,7 @@ extern "C" int dm_head_forward(const float *d4, const float *w6, const float *b6
 {
     DM_REQUIRE(d4 && w6 && channel_var && decoded, "dm_head_forward: NULL pointer");
     DM_REQUIRE(!x || loss_slabs, "dm_head_forward: loss_slabs required when x is given");
-    DM_REQUIRE(C4 == 4, "dm_head_forward: num_hiddens//4 = %d not built (4)", C4);
+    DM_REQUIRE(C4 == 4 || C4 == 8 || C4 == 16, "dm_head_forward: num_hiddens//4 = %d not built (4, 8, 16)", C4);
     DM_REQUIRE(NIN >= 1 && NIN <= 4, "dm_head_forward: num_inputs %d not built (1..4)", NIN);
     DM_REQUIRE((H * W) % 4 == 0 && B > 0, "dm_head_forward: bad shape");
     DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "dm_head_forward: mask channels %d", mask_channels);
@@ -258,7 +271,7 @@ extern "C" int dm_head_backward(const float *decoded, const float *x, const floa
     DM_REQUIRE(channel_var && d4 && w6 && g4 && part_slabs, "dm_head_backward: NULL pointer");
     DM_REQUIRE(gscale_dev || gdec_ext, "dm_head_backward: need gscale_dev and/or gdec_ext");
     DM_REQUIRE(!gscale_dev || (decoded && x), "dm_head_backward: loss gradient needs decoded and x");
-    DM_REQUIRE(C4 == 4, "dm_head_backward: num_hiddens//4 = %d not built (4)", C4);
+    DM_REQUIRE(C4 == 4 || C4 == 8 || C4 == 16, "dm_head_backward: num_hiddens//4 = %d not built (4, 8, 16)", C4);
     DM_REQUIRE(NIN >= 1 && NIN <= 4, "dm_head_backward: num_inputs %d not built (1..4)", NIN);
     DM_REQUIRE((H * W) % 4 == 0 && B > 0, "dm_head_backward: bad shape");
     DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "dm_head_backward: mask channels %d", mask_channels);

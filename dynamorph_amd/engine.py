@@ -252,7 +252,14 @@ def decoder_forward(L, zq, x=None, mask=None, defer_tail=False):
                                           x, mask, var)
     else:
         d4 = _dec4_forward(L, d2)
-        dec, slabs = ops.head_forward(d4, _w(L.dec6.weight), _w(L.dec6.bias), x, mask, var)
+        if ops.head_supported(c2, L.dec6.weight.shape[0]):
+            dec, slabs = ops.head_forward(d4, _w(L.dec6.weight), _w(L.dec6.bias), x, mask, var)
+        else:
+            # widths without a fused head: dec.6 as a plain 1x1 convolution, the loss as its own pass
+            nin = L.dec6.weight.shape[0]
+            dec, _ = ops.conv3x3(Op(d4), weight_view(_w(L.dec6.weight), c2, 1, 0, 0), B, c2, nin, 8 * H3, 8 * W3, taps=1,
+                                 bias=_w(L.dec6.bias))
+            slabs = ops.recon_loss(dec, x, mask, var) if x is not None else None
     cx = SimpleNamespace(zq=zq, d0=d0, d2=d2, d4=d4, dec=dec, x=x, mask=mask, loss_slabs=slabs, deferred=False)
     return dec, cx
 
@@ -262,6 +269,25 @@ def _dec4_forward(L, d2):
     d4, _ = ops.conv3x3(Op(d2), weight_view(_w(L.dec4.weight), 16, c2 * 16, 4, 1), B, c2, 4 * c2, H, W, taps=9,
                         pixel_shuffle=True, bias=_w(L.dec4.bias), relu=True)
     return d4
+
+
+def _head_backward_unfused(L, cx, d4, var, gscale, gdec_ext, G, pending):
+    """dec.6 backward for widths the fused head is not built for: loss gradient, bias sums, the 1x1 weight gradient
+    and the input gradient (masked by dec.4's ReLU, its channel sums = dec.4's bias gradient) as separate launches."""
+    B, c2, H, W = d4.shape
+    NIN = L.dec6.weight.shape[0]
+    if gscale is not None:
+        g, part = ops.recon_loss_backward(cx.dec, cx.x, cx.mask, var, gscale)
+        if gdec_ext is not None:
+            g, part = g + gdec_ext, None
+    else:
+        g, part = gdec_ext.contiguous(), None
+    ops.sum_slabs(part if part is not None else ops.channel_stats(g), G(L.dec6.bias))
+    ops.wgrad(Op(g), Op(d4), G(L.dec6.weight), B, NIN, c2, H, W, 1, pending=pending)
+    g4, st = ops.conv3x3(Op(g), weight_view(_w(L.dec6.weight), 1, c2, 0, 0), B, NIN, c2, H, W, taps=1, want_stats=True,
+                         mask=Op(d4))
+    ops.sum_slabs(st, G(L.dec4.bias))
+    return g4
 
 
 def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
@@ -288,8 +314,11 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
         pending.append((wsl, G(L.dec4.weight)))
     else:
         d4 = cx.d4 if cx.d4 is not None else _dec4_forward(L, cx.d2)
-        g4, part = ops.head_backward(cx.dec, cx.x, cx.mask, var, d4, _w(L.dec6.weight), gscale, gdec_ext)
-        ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias)])
+        if ops.head_supported(c2, NIN):
+            g4, part = ops.head_backward(cx.dec, cx.x, cx.mask, var, d4, _w(L.dec6.weight), gscale, gdec_ext)
+            ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias)])
+        else:
+            g4 = _head_backward_unfused(L, cx, d4, var, gscale, gdec_ext, G, pending)
         ops.wgrad(Op(cx.d2), Op(g4), G(L.dec4.weight), B, c2, c2, 4 * H3, 4 * W3, 4, pending=pending)
         g2, st = ops.conv4x4s2(Op(g4), weight_view(_w(L.dec4.weight), c2 * 16, 16, 4, 1), B, c2, c2, 8 * H3, 8 * W3,
                                want_stats=True, mask=Op(cx.d2))

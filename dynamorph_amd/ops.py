@@ -294,6 +294,10 @@ def head_backward(dec, x, mask, channel_var, d4, w6, gscale, gdec_ext=None):
     return g4, part
 
 
+def head_supported(c4, nin):
+    return bool(L.load().dm_head_supported(c4, nin))
+
+
 def dec_tail_supported(c2, nin, h2, w2):
     return bool(L.load().dm_dec_tail_supported(c2, nin, h2, w2))
 

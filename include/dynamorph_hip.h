@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 101
+#define DM_VERSION 102
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -208,7 +208,10 @@ int dm_sum_slabs_scatter(const double *stats, int nslabs, int N, float scale, co
 /* decoded = Conv2d(C4 -> NIN, 1x1)(d4) + bias; loss partials
  * sum ((decoded*m - x*m)^2 / channel_var[c]) as one double per workgroup.
  * mask: (B,MC,H,W) with MC in {1, NIN}, or NULL (= ones).
- * x = NULL: decoder-only call (VQ_VAE.dec(z)), no loss partials are written. */
+ * x = NULL: decoder-only call (VQ_VAE.dec(z)), no loss partials are written.
+ * Built for C4 = num_hiddens//4 in {4, 8, 16} and NIN 1..4 (dm_head_supported tells); other widths run the same
+ * arithmetic as dm_conv3x3(taps=1) + dm_recon_loss + dm_wgrad. */
+int dm_head_supported(int C4, int NIN);
 int dm_head_num_blocks(int B, int H, int W);
 int dm_head_forward(const float *d4, const float *w6, const float *b6, const float *x, const float *mask,
                     int mask_channels, const float *channel_var, float *decoded, double *loss_slabs,

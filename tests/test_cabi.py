@@ -44,7 +44,7 @@ def test_struct_layouts_match_the_header():
 
 
 def test_version_and_host_only_queries(lib):
-    assert lib.dm_version() == 101          # 101: dm_epilogue gained bias_border
+    assert lib.dm_version() == 102          # 102: dm_head_supported, generic fallback kernels
     assert lib.dm_vq_workspace_bytes(64, 16) == 64 * 16 * 4
     assert lib.dm_vq_workspace_bytes(63, 16) == 64 * 16 * 4           # odd K is padded to a pair
     assert lib.dm_vq_num_blocks(524288) == 2048
@@ -57,6 +57,7 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_wgrad_num_blocks(2048, 8, 3, 64, 64, 4) == 512     # persistent grid cap
     assert lib.dm_wgrad_num_blocks(1, 8, 3, 64, 64, 5) == -1
     assert lib.dm_head_num_blocks(2048, 128, 128) == 2048
+    assert lib.dm_head_supported(4, 2) == 1 and lib.dm_head_supported(16, 4) == 1 and lib.dm_head_supported(12, 2) == 0
     assert lib.dm_channel_stats_num_blocks(20, 16, 16, 16) == 3
 
 
