@@ -38,6 +38,11 @@
 int dm_generic_conv_slabs(int B, int per_tile);
 int dm_generic_conv(int form, const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys,
                     int CIN, int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st);
+// arbitrary channel counts on the MFMA, 8 x 16 tiles (conv_wide.hip); form 0: 4x4/s2, 1: 3x3 or 1x1, 2: transposed
+bool dm_wide_conv_ok(int form, int H, int W);
+int dm_wide_conv_slabs(int form, int B, int H, int W, int per_tile);
+int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                 int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st);
 
 namespace {
 
@@ -800,12 +805,21 @@ static int conv4_fast_tw(int CIN, int NOUT, int H, int W)
     return TW;
 }
 
+// the register-resident kernels instantiated below (DM_C4 table)
+static bool conv4_has_kernel(int CIN, int TW)
+{
+    if (CIN >= 1 && CIN <= 5) return TW == 64 || TW == 32 || TW == 16;
+    if (CIN == 8) return TW == 32 || TW == 16;
+    return CIN == 16 && TW == 16;
+}
+
 extern "C" int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, int per_tile)
 {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return -1;
     const int TW = conv4_fast_tw(CIN, NOUT, H, W);
-    if (!TW) return dm_generic_conv_slabs(B, per_tile);
-    return conv_slabs(B * ((H / 2) / 8) * ((W / 2) / TW), per_tile);
+    if (TW && conv4_has_kernel(CIN, TW)) return conv_slabs(B * ((H / 2) / 8) * ((W / 2) / TW), per_tile);
+    if (dm_wide_conv_ok(0, H, W)) return dm_wide_conv_slabs(0, B, H, W, per_tile);
+    return dm_generic_conv_slabs(B, per_tile);
 }
 
 extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
@@ -817,7 +831,7 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
                ep ? ep->stats_per_tile : 0, (hipStream_t)stream};
     const int TW = conv4_fast_tw(CIN, NOUT, H, W);
     const bool border_ok = !(ep && ep->bias_border) || (CIN <= 5 && !ep->mask.p0 && !ep->resid && !ep->stat_q && W / 2 >= 8);
-    if (TW && in->mode != DM_LOAD_AFFINE2 && border_ok) {
+    if (TW && conv4_has_kernel(CIN, TW) && in->mode != DM_LOAD_AFFINE2 && border_ok) {
 #define DM_C4(C, T) if (CIN == C && TW == T) { launch_conv4<C, T>(a); return dm_launch_status("dm_conv4x4s2"); }
         DM_C4(3, 64) DM_C4(3, 32) DM_C4(3, 16)
         DM_C4(4, 64) DM_C4(4, 32) DM_C4(4, 16)
@@ -828,9 +842,13 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
         DM_C4(16, 16)
 #undef DM_C4
     }
-    // no MFMA instantiation for this channel count / shape / operand mode: generic kernel (conv_generic.hip)
-    dm_generic_conv(0, a.in, a.wv, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, 16,
-                    dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W, a.per_tile), a.per_tile, a.stream);
+    // no register-resident instantiation for this channel count / shape / operand mode: the implicit-GEMM kernel
+    // (conv_wide.hip) when the output tiles by 8 x 16, else the generic kernel (conv_generic.hip)
+    const int nslabs = dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W, a.per_tile);
+    if (dm_wide_conv_ok(0, H, W))
+        dm_wide_conv(0, a.in, a.wv, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, 16, nslabs, a.per_tile, a.stream);
+    else
+        dm_generic_conv(0, a.in, a.wv, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, 16, nslabs, a.per_tile, a.stream);
     return dm_launch_status("dm_conv4x4s2");
 }
 
@@ -840,13 +858,34 @@ static bool conv3_fast_tileable(int CIN, int H, int W)
     return (TW == 16 || TW == 32 || TW == 64) && W % TW == 0 && H % TH == 0 && CIN % 4 == 0 && CIN <= 32;
 }
 
+// the register-resident kernels instantiated below (DM_CP / DM_C3 tables)
+static bool conv3_has_kernel(int CIN, int NOUT, int H, int W, int taps, bool pix, int per_tile)
+{
+    if (!conv3_fast_tileable(CIN, H, W)) return false;
+    const int TW = conv3_tw(W), NTT = (NOUT + 15) / 16;
+    const bool t13 = TW == 16 || TW == 32;
+    if (pix && CIN == 16 && (NOUT == 32 || NOUT == 64) && t13 && !per_tile) return true;
+    if (!pix && taps == 9) return t13 && ((CIN == 16 && (NTT == 1 || NTT == 2)) || (CIN == 32 && NTT == 1));
+    if (!pix && taps == 1) return t13 && ((CIN == 32 && NTT == 1) || (CIN == 16 && NTT == 2));
+    if (pix && taps == 9) {
+        if (CIN == 16 && NTT == 2) return true;
+        if (CIN == 16 && NTT == 4) return t13;
+        if (CIN == 8 && NTT == 1) return TW == 32 || TW == 64;
+        if (CIN == 4 && NTT == 1) return TW == 64;
+    }
+    return false;
+}
+
 extern "C" int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile)
 {
-    (void)NOUT; (void)taps; (void)pixel_shuffle;
     if (B <= 0 || H <= 0 || W <= 0) return -1;
-    if (!conv3_fast_tileable(CIN, H, W)) return dm_generic_conv_slabs(B, per_tile);
-    const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
-    return conv_slabs(B * (H / TH) * (W / TW), per_tile);
+    if (conv3_has_kernel(CIN, NOUT, H, W, taps, pixel_shuffle != 0, per_tile)) {
+        const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
+        return conv_slabs(B * (H / TH) * (W / TW), per_tile);
+    }
+    const int form = pixel_shuffle ? 2 : 1;
+    if (dm_wide_conv_ok(form, H, W)) return dm_wide_conv_slabs(form, B, H, W, per_tile);
+    return dm_generic_conv_slabs(B, per_tile);
 }
 
 extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
@@ -857,7 +896,7 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
     DM_REQUIRE(!pixel_shuffle || (taps == 9 && NOUT % 4 == 0), "dm_conv3x3: pixel_shuffle needs taps=9, NOUT%%4==0");
     DM_REQUIRE(!in->ones_channel, "dm_conv3x3: ones_channel not supported");
     const int TW = conv3_tw(W);
-    const bool fast = conv3_fast_tileable(CIN, H, W);
+    const bool fast = conv3_has_kernel(CIN, NOUT, H, W, taps, pixel_shuffle != 0, ep ? ep->stats_per_tile : 0);
     ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN, CIN, NOUT, H, W, ep ? ep->stats_per_tile : 0,
                (hipStream_t)stream};
     const int NTT = (NOUT + 15) / 16;
@@ -891,8 +930,16 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
     DM_C3(4, 1, 1, 1, 9, true, 64)
 #undef DM_C3
     }
-    // no MFMA instantiation for this channel count / shape: generic kernel (conv_generic.hip)
-    dm_generic_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps,
-                    dm_conv3x3_num_blocks(B, CIN, NOUT, H, W, taps, pixel_shuffle, a.per_tile), a.per_tile, a.stream);
+    // no register-resident instantiation for this channel count / shape: the implicit-GEMM kernel (conv_wide.hip)
+    // when the base grid tiles by 8 x 16, else the generic kernel (conv_generic.hip)
+    const int nslabs = dm_conv3x3_num_blocks(B, CIN, NOUT, H, W, taps, pixel_shuffle, a.per_tile);
+    if (fast) {
+        dm_set_error("dm_conv3x3: kernel table and conv3_has_kernel disagree (CIN %d NOUT %d %dx%d)", CIN, NOUT, H, W);
+        return -1;
+    }
+    if (dm_wide_conv_ok(pix ? 2 : 1, H, W))
+        dm_wide_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps, nslabs, a.per_tile, a.stream);
+    else
+        dm_generic_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps, nslabs, a.per_tile, a.stream);
     return dm_launch_status("dm_conv3x3");
 }

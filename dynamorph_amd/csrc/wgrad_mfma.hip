@@ -21,6 +21,11 @@
 // fallback for shapes / channel families without an MFMA instantiation (conv_generic.hip)
 int dm_generic_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int CTphys, int Hs, int Ws,
                      int KK, int nslabs, hipStream_t st);
+// arbitrary channel counts on the MFMA, 8 x 16 tiles (conv_wide.hip)
+bool dm_wide_wgrad_ok(int Hs, int Ws);
+int dm_wide_wgrad_slabs(int B, int CS, int CT, int Hs, int Ws, int k);
+int dm_wide_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int CTphys, int Hs, int Ws,
+                  int k, int nslabs, hipStream_t st);
 
 namespace {
 
@@ -447,10 +452,31 @@ static bool wgrad_fast_tileable(int CS, int CT, int Hs, int Ws, int k)
     return Hs % TH == 0 && Ws % TW == 0;
 }
 
+// the register-resident kernels instantiated below (DM_WG table)
+static bool wgrad_has_kernel(int CS, int CT, int Hs, int Ws, int k)
+{
+    if (!wgrad_fast_tileable(CS, CT, Hs, Ws, k)) return false;
+    const int TW = wgrad_tw(Ws);
+    const bool t13 = TW == 16 || TW == 32;
+    if (k == 4 && CS == 8) {
+        if (CT == 3) return true;
+        if (CT == 5 || CT == 2 || CT == 1) return TW == 64;
+        if (CT == 4) return TW == 64 || TW == 32;
+    }
+    if (k == 4 && CS == 16) return CT == 8 || (CT == 16 && t13);
+    if (k == 4 && CS == 4) return CT == 4 && TW == 64;
+    if (k == 3) return (CS == 16 || CS == 32) && CT == 16 && t13;
+    if (k == 1) return CS == 16 && CT == 32 && t13;
+    return false;
+}
+
 extern "C" int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k)
 {
     if (B <= 0 || (k != 4 && k != 3 && k != 1)) return -1;
-    if (!wgrad_fast_tileable(CS, CT, Hs, Ws, k)) return B < WG_MAX_BLOCKS ? B : WG_MAX_BLOCKS;
+    if (!wgrad_has_kernel(CS, CT, Hs, Ws, k)) {
+        if (dm_wide_wgrad_ok(Hs, Ws)) return dm_wide_wgrad_slabs(B, CS, CT, Hs, Ws, k);
+        return B < WG_MAX_BLOCKS ? B : WG_MAX_BLOCKS;
+    }
     const int TW = wgrad_tw(Ws), TH = wgrad_th(CS, CT, k, TW);
     const long long ntiles = (long long)B * (Hs / TH) * (Ws / TW);
     return (int)(ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS);
@@ -465,7 +491,7 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     DM_REQUIRE(k == 4 || k == 3 || k == 1, "dm_wgrad: kernel size %d not built", k);
     DM_REQUIRE(!S->ones_channel, "dm_wgrad: S cannot carry a ones channel");
     const int TW = wgrad_tw(Ws);
-    const bool fast = wgrad_fast_tileable(CS, CT, Hs, Ws, k);
+    const bool fast = wgrad_has_kernel(CS, CT, Hs, Ws, k);
     const int grid = dm_wgrad_num_blocks(B, CS, CT, Hs, Ws, k);
     DM_REQUIRE(T->mode != DM_LOAD_AFFINE2, "dm_wgrad: T operand cannot be AFFINE2");
     const int CTphys = CT - (T->ones_channel ? 1 : 0);
@@ -492,8 +518,14 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     DM_WG(8, 4, 4, 32) DM_WG(8, 4, 4, 64)
     DM_WG(4, 4, 4, 64)
 #undef DM_WG
-    if (!done)       // no MFMA instantiation for this channel pair / shape: generic kernel (conv_generic.hip)
-        dm_generic_wgrad(s, t, slabs, B, CS, CT, CTphys, Hs, Ws, k, grid, st);
+    if (!done && fast) {
+        dm_set_error("dm_wgrad: kernel table and wgrad_has_kernel disagree (CS %d CT %d k %d %dx%d)", CS, CT, k, Hs, Ws);
+        return -1;
+    }
+    if (!done) {     // no register-resident instantiation: implicit-GEMM kernel (conv_wide.hip), else the generic one
+        if (dm_wide_wgrad_ok(Hs, Ws)) dm_wide_wgrad(s, t, slabs, B, CS, CT, CTphys, Hs, Ws, k, grid, st);
+        else dm_generic_wgrad(s, t, slabs, B, CS, CT, CTphys, Hs, Ws, k, grid, st);
+    }
     int rc = dm_launch_status("dm_wgrad");
     if (rc || !dst) return rc;          // dst == NULL: the caller reduces the slabs later (dm_reduce_slabs_multi)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 15) / 16), dim3(256), 0, st, slabs, grid, E, dst);

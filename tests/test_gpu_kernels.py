@@ -296,6 +296,121 @@ def test_generic_wgrad(ops, cs, ct, k, hs):
     close(dst, w.grad, 5e-5, 5e-5 * w.grad.abs().max().item(), "generic wgrad")
 
 
+# ===================================================================== implicit-GEMM kernels (conv_wide.hip)
+# channel counts without a register-resident instantiation whose base grid tiles by 8 x 16
+@pytest.mark.parametrize("B,cin,nout,h,w,mode,ones,per_tile", [
+    (3, 32, 64, 64, 64, 3, False, False), (2, 64, 64, 32, 32, 4, False, False), (5, 3, 32, 128, 128, 0, True, False),
+    (4, 32, 64, 32, 64, 3, False, True), (2, 20, 72, 16, 32, 1, False, False), (40, 32, 16, 32, 32, 0, False, False)])
+def test_wide_conv4x4s2(ops, B, cin, nout, h, w, mode, ones, per_tile):
+    cphys = cin - (1 if ones else 0)
+    x, x1 = rnd(B, cphys, h, w, seed=1), rnd(B, cphys, h, w, seed=11)
+    wt = rnd(nout, cin, 4, 4, seed=2, scale=0.2)
+    bias = rnd(nout, seed=3)
+    coef = torch.stack([rnd(cphys, seed=4).abs() + 0.5, rnd(cphys, seed=6) * 0.2, rnd(cphys, seed=5) * 0.3, torch.zeros(cphys)], 1)
+    xin = load_ref(x, mode, coef, x1)
+    if ones:
+        xin = torch.cat([xin, torch.ones(B, 1, h, w)], 1)
+    ref = F.conv2d(xin, wt, bias, stride=2, padding=1)
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, p1=x1.to(DEV) if mode == 4 else None, ones=ones),
+                            ops.weight_view(wt.to(DEV), cin * 16, 16, 4, 1), B, cin, nout, h, w, want_stats=True,
+                            bias=bias.to(DEV), per_tile=per_tile)
+    close(out, ref, 5e-5, 5e-5, "wide conv4x4s2")
+    if per_tile:
+        assert st.shape[0] % B == 0
+        per = st.reshape(B, -1, nout, 2).sum(1)
+        for b in range(B):
+            close(per[b], _stats_ref(ref[b:b + 1]), 1e-5, 1e-3, f"per-sample stats {b}")
+    else:
+        close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+
+
+def test_wide_conv4x4s2_border_bias(ops):
+    """enc.0 o enc.1 of a wide encoder: 2 -> 32 channels with the border-bias table instead of a ones channel."""
+    B, nin, c1, h = 3, 2, 32, 128
+    x = rnd(B, nin, h, h, seed=1)
+    w0, b0 = rnd(nin, nin, 1, 1, seed=2), rnd(nin, seed=3)
+    w1, b1 = rnd(c1, nin, 4, 4, seed=4, scale=0.2), rnd(c1, seed=5)
+    ref = F.conv2d(F.conv2d(x, w0, b0), w1, b1, stride=2, padding=1)
+    weff, border = ops.e1_compose_border(w0.to(DEV), b0.to(DEV), w1.to(DEV), b1.to(DEV))
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV)), ops.weight_view(weff, (nin + 1) * 16, 16, 4, 1), B, nin, c1, h, h,
+                            want_stats=True, bias_border=border)
+    close(out, ref, 5e-5, 5e-5, "wide conv4x4s2 with border bias")
+    close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+
+
+@pytest.mark.parametrize("B,cin,nout,h,w,taps,per_tile", [(2, 64, 64, 16, 16, 9, False), (3, 64, 64, 32, 32, 9, False),
+                                                          (2, 64, 64, 16, 16, 1, False), (3, 128, 40, 8, 32, 1, False),
+                                                          (2, 48, 136, 16, 16, 9, False), (4, 64, 64, 16, 16, 9, True),
+                                                          (70, 64, 32, 16, 16, 9, False)])
+def test_wide_conv3x3(ops, B, cin, nout, h, w, taps, per_tile):
+    x = rnd(B, cin, h, w, seed=1)
+    k = 3 if taps == 9 else 1
+    wt = rnd(nout, cin, k, k, seed=2, scale=0.1)
+    act, resid = rnd(B, nout, h, w, seed=3), rnd(B, nout, h, w, seed=4)
+    mcoef = torch.stack([rnd(nout, seed=7), torch.zeros(nout), rnd(nout, seed=8) * 0.3, torch.zeros(nout)], 1)
+    gate = (mcoef[:, 0].view(1, -1, 1, 1) * act + mcoef[:, 2].view(1, -1, 1, 1)) > 0
+    ref = F.conv2d(F.relu(x), wt, None, padding=k // 2) * gate + resid
+    out, st = ops.conv3x3(ops.Op(x.to(DEV), 1), ops.weight_view(wt.to(DEV), cin * taps, taps, 3 if taps == 9 else 0, 1 if taps == 9 else 0),
+                          B, cin, nout, h, w, taps=taps, want_stats=True, mask=ops.Op(act.to(DEV), 2, mcoef.to(DEV)),
+                          resid=resid.to(DEV), stat_q=act.to(DEV), per_tile=per_tile)
+    close(out, ref, 5e-5, 5e-5, "wide conv3x3")
+    if per_tile:
+        per = st.reshape(B, -1, nout, 2).sum(1)
+        for b in range(B):
+            close(per[b], _stats_ref(ref[b:b + 1], act[b:b + 1]), 1e-5, 1e-3, f"per-sample stats {b}")
+    else:
+        close(st.sum(0), _stats_ref(ref, act), 1e-5, 1e-3, "stats q")
+
+
+def test_wide_conv3x3_flipped_view(ops):
+    """data gradient of a 3x3 convolution: the same kernel through a transposed, flipped weight view."""
+    B, ci, co, hw = 2, 64, 48, 16
+    g = rnd(B, co, hw, hw, seed=1)
+    wt = rnd(co, ci, 3, 3, seed=2, scale=0.1)
+    x = torch.zeros(B, ci, hw, hw, requires_grad=True)
+    F.conv2d(x, wt, None, padding=1).backward(g)
+    out, _ = ops.conv3x3(ops.Op(g.to(DEV)), ops.weight_view(wt.to(DEV), 9, ci * 9, -3, -1, off=8), B, co, ci, hw, hw, taps=9)
+    close(out, x.grad, 5e-5, 5e-5, "wide conv3x3 data gradient")
+
+
+@pytest.mark.parametrize("B,ci,co,h,w", [(2, 64, 32, 16, 16), (2, 32, 2, 64, 64), (3, 64, 64, 8, 16), (2, 32, 16, 32, 32),
+                                         (50, 16, 16, 32, 64)])
+def test_wide_conv_transpose(ops, B, ci, co, h, w):
+    x = rnd(B, ci, h, w, seed=1)
+    wt = rnd(ci, co, 4, 4, seed=2, scale=0.2)
+    bias = rnd(co, seed=3)
+    act = rnd(B, co, 2 * h, 2 * w, seed=5)
+    ref = F.relu(F.conv_transpose2d(x, wt, bias, stride=2, padding=1)) * (act > 0)
+    out, st = ops.conv3x3(ops.Op(x.to(DEV)), ops.weight_view(wt.to(DEV), 16, co * 16, 4, 1), B, ci, 4 * co, h, w,
+                          taps=9, pixel_shuffle=True, want_stats=True, bias=bias.to(DEV), relu=True, mask=ops.Op(act.to(DEV)),
+                          stat_q=act.to(DEV))
+    close(out, ref, 5e-5, 5e-5, "wide conv transpose")
+    close(st.sum(0), _stats_ref(ref, act), 1e-5, 1e-3, "stats")
+
+
+@pytest.mark.parametrize("B,cs,ct,k,hs,ws,ones", [(3, 64, 64, 3, 16, 16, False), (3, 64, 64, 1, 16, 16, False),
+                                                 (3, 64, 32, 4, 16, 16, False), (2, 32, 3, 4, 64, 64, True),
+                                                 (2, 32, 2, 4, 64, 64, False), (2, 128, 20, 3, 8, 32, False),
+                                                 (40, 32, 64, 4, 32, 32, False), (3, 64, 100, 1, 16, 32, False)])
+def test_wide_wgrad(ops, B, cs, ct, k, hs, ws, ones):
+    s, p = (2, 1) if k == 4 else ((1, 1) if k == 3 else (1, 0))
+    ctp = ct - (1 if ones else 0)
+    dy, a = rnd(B, cs, hs, ws, seed=1), rnd(B, cs, hs, ws, seed=2)
+    coef = torch.stack([rnd(cs, seed=3), rnd(cs, seed=4) * 0.1, rnd(cs, seed=5) * 0.1, torch.zeros(cs)], 1)
+    t = rnd(B, ctp, hs * s, ws * s, seed=6)
+    tcoef = torch.stack([rnd(ctp, seed=7), torch.zeros(ctp), rnd(ctp, seed=8) * 0.2, torch.zeros(ctp)], 1)
+    tin = load_ref(t, 3, tcoef)
+    if ones:
+        tin = torch.cat([tin, torch.ones(B, 1, hs * s, ws * s)], 1)
+    w = torch.zeros(cs, ct, k, k, requires_grad=True)
+    F.conv2d(tin, w, None, stride=s, padding=p).backward(load_ref(dy, 4, coef, a))
+    dst = torch.empty(cs, ct, k, k, device=DEV)
+    ops.wgrad(ops.Op(dy.to(DEV), 4, coef.to(DEV), p1=a.to(DEV)), ops.Op(t.to(DEV), 3, tcoef.to(DEV), ones=ones), dst, B, cs, ct,
+              hs, ws, k)
+    scale = w.grad.abs().max().item()
+    close(dst, w.grad, 5e-5, 5e-5 * scale, "wide wgrad")
+
+
 # =============================================================================== wgrad
 @pytest.mark.parametrize("cs,ct,k,hs,ones,B", [
     (8, 3, 4, 64, True, 3), (16, 8, 4, 32, False, 3), (16, 16, 4, 16, False, 5), (16, 16, 3, 16, False, 5),
