@@ -19,7 +19,8 @@ class Operand(C.Structure):
 
 
 class WeightView(C.Structure):
-    _fields_ = [("w", vp), ("off", i64), ("sn", i64), ("sc", i64), ("sky", i64), ("skx", i64)]
+    _fields_ = [("w", vp), ("off", i64), ("sn", i64), ("sc", i64), ("sky", i64), ("skx", i64), ("scratch", vp),
+                ("scratch_floats", i64)]
 
 
 class Epilogue(C.Structure):
@@ -51,8 +52,10 @@ SIGNATURES = {
     "dm_vq_backward_slabs": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_conv4x4s2": (C.c_int, [OP, WV, vp, EP] + [C.c_int] * 5 + [vp]),
     "dm_conv4x4s2_num_blocks": (C.c_int, [C.c_int] * 6),
+    "dm_conv4x4s2_scratch_floats": (i64, [C.c_int] * 5),
     "dm_conv3x3": (C.c_int, [OP, WV, vp, EP] + [C.c_int] * 7 + [vp]),
     "dm_conv3x3_num_blocks": (C.c_int, [C.c_int] * 8),
+    "dm_conv3x3_scratch_floats": (i64, [C.c_int] * 7),
     "dm_wgrad_num_blocks": (C.c_int, [C.c_int] * 6),
     "dm_wgrad": (C.c_int, [OP, OP, vp, vp] + [C.c_int] * 6 + [vp]),
     "dm_bn_finalize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, vp, f32, f32, vp, vp, C.c_int, vp]),

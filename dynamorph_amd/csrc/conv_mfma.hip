@@ -41,8 +41,9 @@ int dm_generic_conv(int form, const Operand &in, const WeightView &wv, float *ou
 // arbitrary channel counts on the MFMA, 8 x 16 tiles (conv_wide.hip); form 0: 4x4/s2, 1: 3x3 or 1x1, 2: transposed
 bool dm_wide_conv_ok(int form, int H, int W);
 int dm_wide_conv_slabs(int form, int B, int H, int W, int per_tile);
-int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
-                 int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st);
+long long dm_wide_conv_scratch_floats(int form, int CIN, int NOUT, int taps);
+int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scratch, float *out, const Epilogue &ep, int B,
+                 int Cphys, int CIN, int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st);
 
 namespace {
 
@@ -822,6 +823,16 @@ extern "C" int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, i
     return dm_generic_conv_slabs(B, per_tile);
 }
 
+// scratch the weight view should carry (dm_weight_view.scratch): 0 when a register-resident kernel takes the shape.
+// fallback != 0: the caller knows that kernel cannot be used (AFFINE2 input, border-bias table with side inputs).
+extern "C" int64_t dm_conv4x4s2_scratch_floats(int CIN, int NOUT, int H, int W, int fallback)
+{
+    if (CIN <= 0 || NOUT <= 0 || !dm_wide_conv_ok(0, H, W)) return 0;
+    const int TW = conv4_fast_tw(CIN, NOUT, H, W);
+    if (TW && conv4_has_kernel(CIN, TW) && !fallback) return 0;
+    return dm_wide_conv_scratch_floats(0, CIN, NOUT, 16);
+}
+
 extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
                             int B, int CIN, int NOUT, int H, int W, void *stream)
 {
@@ -845,8 +856,8 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
     // no register-resident instantiation for this channel count / shape / operand mode: the implicit-GEMM kernel
     // (conv_wide.hip) when the output tiles by 8 x 16, else the generic kernel (conv_generic.hip)
     const int nslabs = dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W, a.per_tile);
-    if (dm_wide_conv_ok(0, H, W))
-        dm_wide_conv(0, a.in, a.wv, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, 16, nslabs, a.per_tile, a.stream);
+    if (dm_wide_conv_ok(0, H, W) && w->scratch && w->scratch_floats >= dm_wide_conv_scratch_floats(0, CIN, NOUT, 16))
+        dm_wide_conv(0, a.in, a.wv, w->scratch, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, 16, nslabs, a.per_tile, a.stream);
     else
         dm_generic_conv(0, a.in, a.wv, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, 16, nslabs, a.per_tile, a.stream);
     return dm_launch_status("dm_conv4x4s2");
@@ -886,6 +897,14 @@ extern "C" int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int
     const int form = pixel_shuffle ? 2 : 1;
     if (dm_wide_conv_ok(form, H, W)) return dm_wide_conv_slabs(form, B, H, W, per_tile);
     return dm_generic_conv_slabs(B, per_tile);
+}
+
+extern "C" int64_t dm_conv3x3_scratch_floats(int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile)
+{
+    const int form = pixel_shuffle ? 2 : 1;
+    if (CIN <= 0 || NOUT <= 0 || (taps != 9 && taps != 1) || !dm_wide_conv_ok(form, H, W)) return 0;
+    if (conv3_has_kernel(CIN, NOUT, H, W, taps, pixel_shuffle != 0, per_tile)) return 0;
+    return dm_wide_conv_scratch_floats(form, CIN, NOUT, taps);
 }
 
 extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
@@ -937,8 +956,9 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
         dm_set_error("dm_conv3x3: kernel table and conv3_has_kernel disagree (CIN %d NOUT %d %dx%d)", CIN, NOUT, H, W);
         return -1;
     }
-    if (dm_wide_conv_ok(pix ? 2 : 1, H, W))
-        dm_wide_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps, nslabs, a.per_tile, a.stream);
+    if (dm_wide_conv_ok(pix ? 2 : 1, H, W) && w->scratch &&
+        w->scratch_floats >= dm_wide_conv_scratch_floats(pix ? 2 : 1, CIN, NOUT, taps))
+        dm_wide_conv(pix ? 2 : 1, a.in, a.wv, w->scratch, out, a.ep, B, CIN, CIN, NOUT, H, W, taps, nslabs, a.per_tile, a.stream);
     else
         dm_generic_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps, nslabs, a.per_tile, a.stream);
     return dm_launch_status("dm_conv3x3");

@@ -4,7 +4,7 @@
 // default family (num_hiddens 16).  The reference's example configuration (config_example.yml: VQ_VAE_z32 with
 // num_hiddens 64, num_residual_hiddens 64, 512 codes) has 64 -> 64 channel 3x3 layers: 147 KB of weights, MFMA bound.
 // These kernels are the classic implicit GEMM for that regime:
-//   convolution     M = 8 x 16 pixels of one sample, N = up to 128 output channels, K = (tap, channel) in chunks of
+//   convolution     M = 8 x 16 pixels of one sample, N = up to 64 output channels per pass, K = (tap, channel) in chunks of
 //                   8 channels; the input chunk (operand transform, zero padding, ones channel applied) and the weight
 //                   chunk (re-laid as [tap][channel][n]) are staged in LDS, every wave owns 2 pixel rows x all N;
 //   weight gradient M = 64 S channels (one 16-row tile per wave), N = (T channel, tap) flattened, K = the 128 pixels
@@ -36,17 +36,243 @@ __device__ __forceinline__ float wide_load(const Operand &op, int b, int c, int 
     return v;
 }
 
+// Stage `nch` channels (first channel c_first, channels >= c_limit are zero, channel Cphys is the ones channel) of the
+// ROWS x LCOLS window at (gy0, gx0) of sample b into LDS, operand transform and zero padding applied.  Loads are issued
+// in batches of 8 per thread before any of them is consumed (one exposed latency per batch instead of one per load);
+// AFFINE coefficients come from LDS (s_cf[channel - c_first][4], staged by the caller).
+// PLANES: columns are split into even / odd planes of COLS columns (stride-2 readers then step by 1).
+template <int ROWS, int LCOLS, int COLS, int CHS, bool PLANES>
+__device__ __forceinline__ void stage_window(const Operand &op, const float *s_cf, float *s_dst, int nch, int c_first,
+                                             int c_limit, int Cphys, int b, int gy0, int gx0, int H, int W, int tid)
+{
+    constexpr int PER = ROWS * LCOLS, PLS = ROWS * COLS;
+    const int total = nch * PER;
+    const long long sample = (long long)b * Cphys * H * W;
+    const int mode = op.mode;
+#pragma unroll 1
+    for (int base = 0; base < total; base += 256 * 8) {
+        float v[8], u[8];
+        int la[8], cc[8], off[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = base + j * 256 + tid;
+            const int c = idx / PER, rem = idx - c * PER, iy = rem / LCOLS, ix = rem - iy * LCOLS;
+            const int gy = gy0 + iy, gx = gx0 + ix, chn = c_first + c;
+            const bool ok = idx < total;
+            const bool inimg = ok && gy >= 0 && gy < H && gx >= 0 && gx < W && chn < c_limit;
+            const bool phys = inimg && chn < Cphys;
+            off[j] = phys ? (chn * H + gy) * W + gx : 0;
+            la[j] = ok ? (PLANES ? c * CHS + (ix & 1) * PLS + iy * COLS + (ix >> 1) : c * CHS + iy * COLS + ix) : -1;
+            cc[j] = phys ? c : (inimg ? -1 : -2);            // -1: ones channel, -2: zero
+            v[j] = op.p0[sample + off[j]];
+        }
+        if (mode == DM_LOAD_AFFINE2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = op.p1[sample + off[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (la[j] < 0) continue;
+            float x = v[j];
+            if (cc[j] >= 0) {
+                if (mode == DM_LOAD_RELU) x = x < 0.f ? 0.f : x;
+                else if (mode == DM_LOAD_AFFINE2) x = s_cf[cc[j] * 4] * x + (s_cf[cc[j] * 4 + 1] * u[j] + s_cf[cc[j] * 4 + 2]);
+                else if (mode >= DM_LOAD_AFFINE) {
+                    x = s_cf[cc[j] * 4] * x + s_cf[cc[j] * 4 + 2];
+                    if (mode == DM_LOAD_AFFINE_RELU) x = x < 0.f ? 0.f : x;
+                }
+            } else {
+                x = cc[j] == -1 ? 1.f : 0.f;
+            }
+            s_dst[la[j]] = x;
+        }
+    }
+}
+
+// coefficient rows of channels [c_first, c_first + nch) of sample b -> s_cf[nch][4] (caller synchronises)
+__device__ __forceinline__ void stage_coef(const Operand &op, float *s_cf, int nch, int c_first, int Cphys, int b, int tid)
+{
+    if (op.mode < DM_LOAD_AFFINE) return;
+    for (int i = tid; i < nch * 4; i += 256) {
+        const int c = c_first + (i >> 2);
+        s_cf[i] = c < Cphys ? op.coef[(long long)b * op.coef_bstride + c * 4 + (i & 3)] : 0.f;
+    }
+}
+
 template <int FORM, int TAPS>
 struct WideGeom {
     static constexpr int S = FORM == W_S2 ? 2 : 1;                       // stride
     static constexpr int R = FORM == W_S2 ? 1 : (TAPS == 9 ? 1 : 0);     // halo
     static constexpr int T = FORM == W_S2 ? 16 : TAPS;                   // taps of the K loop
     static constexpr int ROWS = FORM == W_S2 ? 18 : 8 + 2 * R;           // input rows of a tile
-    static constexpr int LCOLS = FORM == W_S2 ? 34 : 16 + 2 * R;         // logical input columns of a tile
-    static constexpr int COLS = FORM == W_S2 ? 17 : LCOLS;               // columns of an LDS row (S2: one parity plane)
-    static constexpr int PLS = ROWS * COLS;                              // plane size (S2)
+    static constexpr int QW = FORM == W_S2 ? 8 : 4;                      // aligned float4 per input row (the interior)
+    static constexpr bool HALO = R > 0;
+    // LDS image of one channel.  Plain forms: rows of RS floats, interior at column OFFC (16-byte aligned), halos at
+    // OFFC-1 and OFFC+16.  Stride-2 form: two parity planes of 18 x 18 (odd window columns -> plane 1 at column wx>>1,
+    // even ones -> plane 0 at column (wx>>1)+1), so that a stride-2 reader steps by 1 and the interior float4 of a row
+    // lands as two aligned float2.
+    static constexpr int RS = FORM == W_S2 ? 18 : (R ? 24 : 16);
+    static constexpr int OFFC = (FORM != W_S2 && R) ? 4 : 0;
+    static constexpr int PLS = ROWS * RS;
     static constexpr int RAW = FORM == W_S2 ? 2 * PLS : PLS;
-    static constexpr int CHS = ((RAW - 16 + 63) / 64) * 64 + 16;         // channel stride, = 16 (mod 64)
+    static constexpr int CHS = ((RAW - 16 + 31) / 32) * 32 + 16;         // channel stride = 16 (mod 32): see WideW
+};
+
+// Weight chunk in LDS: address = tap*W_TS + (cl >> 1)*W_PS + (cl & 1)*NS + n.  ds_read_b32 / ds_write_b32 bank = dword
+// address mod 32 within each 32-lane half: the reader's two k lanes of a half (channels cl, cl+1) sit NS = 16 (mod 32)
+// apart.  The same image is what dm_wide_pack writes to the caller's scratch, one block per (pass, chunk), so that the
+// conv kernel stages a weight chunk as a straight float4 copy.
+template <int FORM, int TAPS, int NPW>
+struct WideW {
+    static constexpr int T = FORM == W_S2 ? 16 : TAPS;
+    static constexpr int NS = NPW == 1 ? 16 : 16 * NPW + 16;
+    static constexpr int W_PS = 2 * NS + 9;
+    static constexpr int W_TS = ((WKC / 2) * W_PS + 30) / 32 * 32 + 1;
+    static constexpr int BLK = (T * W_TS + 3) / 4 * 4;                   // floats per block
+    static constexpr int NPASS = 16 * NPW;
+};
+
+// scratch[(pass*nchunks + chunk)*BLK + ...] <- the weight view's values in LDS layout (0 where a transposed-conv tap
+// does not reach an output parity, past CIN / NOUT).  grid (nchunks, passes).
+template <int FORM, int TAPS, int NPW>
+__global__ __launch_bounds__(256) void wide_pack_kernel(WeightView wv, float *__restrict__ scratch, int CIN, int NOUT)
+{
+    using P = WideW<FORM, TAPS, NPW>;
+    const int c0 = blockIdx.x * WKC, n0 = blockIdx.y * P::NPASS;
+    float *dst = scratch + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * P::BLK;
+    for (int idx = threadIdx.x; idx < P::T * WKC * P::NPASS; idx += 256) {
+        const int tap = idx % P::T, cl = (idx / P::T) % WKC, nl = idx / (P::T * WKC);
+        const int n = n0 + nl, c = c0 + cl;
+        float v = 0.f;
+        if (n < NOUT && c < CIN) {
+            if (FORM == W_PIX) {
+                const int co = n >> 2, py = (n >> 1) & 1, px = n & 1, tyy = tap / 3, txx = tap - tyy * 3;
+                const int da = tyy - py, db = txx - px;
+                if (da >= 0 && da <= 1 && db >= 0 && db <= 1)
+                    v = wv.w[wv.off + co * wv.sn + c * wv.sc + (py + 3 - 2 * tyy) * wv.sky + (px + 3 - 2 * txx) * wv.skx];
+            } else {
+                constexpr int KW = FORM == W_S2 ? 4 : (TAPS == 9 ? 3 : 1);
+                const int ky = tap / KW, kx = tap - ky * KW;
+                v = wv.w[wv.off + n * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
+            }
+        }
+        dst[tap * P::W_TS + (cl >> 1) * P::W_PS + (cl & 1) * P::NS + nl] = v;
+    }
+}
+
+// Input chunk (WKC channels of one tile's window) through registers: issue() starts the loads of chunk c+1 before the
+// MFMAs of chunk c, commit() transforms and writes LDS after them.  A row is QW aligned float4 (the interior) plus two
+// halo scalars, so a thread handles 2-5 float4 and 1-2 scalars per chunk instead of 6-20 scalars, each of which cost
+// ~25 integer instructions of index arithmetic (measured: 10 VALU instructions per MFMA, no overlap with the MFMAs).
+// P1: also prefetch the second tensor of an AFFINE2 operand (otherwise commit() reads it: exposed latency, rare path).
+template <int FORM, int TAPS, bool P1>
+struct RowPrefetch {
+    using G = WideGeom<FORM, TAPS>;
+    static constexpr int NU4 = WKC * G::ROWS * G::QW, J4 = (NU4 + 255) / 256;
+    static constexpr int NH = G::HALO ? WKC * G::ROWS * 2 : 0, JH = (NH + 255) / 256;
+    f32x4 v[J4], u[P1 ? J4 : 1];
+    float hv[JH ? JH : 1], hu[(P1 && JH) ? JH : 1];
+    int b, c0, gy0, gxi;
+    unsigned phys_mask, ones_mask;       // bit j: float4 unit j, bit 16+j: halo unit j (of the chunk in flight)
+
+    // live == false (no next chunk): empty descriptors, every load returns 0 without touching memory.  The call itself must
+    // stay unconditional: loads under a branch make hipcc merge the two paths with register copies behind s_waitcnt vmcnt(0),
+    // i.e. wait for the prefetch right where it was issued.
+    __device__ __forceinline__ void issue(const Operand &op, bool live, int b_, int c0_, int CIN, int Cphys, int gy0_, int gxi_,
+                                          int H, int W, int tid)
+    {
+        b = b_; c0 = c0_; gy0 = gy0_; gxi = gxi_;
+        const long long se = (long long)Cphys * H * W;
+        const int bytes = live ? (int)(se * 4) : 0;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(op.p0 + se * b), 0, bytes, 0x00020000);
+        const bool two = P1 && op.mode == DM_LOAD_AFFINE2;
+        const __amdgpu_buffer_rsrc_t r1 =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((two ? op.p1 : op.p0) + se * b), 0, two ? bytes : 0, 0x00020000);
+        phys_mask = 0; ones_mask = 0;
+#pragma unroll
+        for (int j = 0; j < J4; ++j) {
+            const int unit = j * 256 + tid, row = unit / G::QW, q = unit - row * G::QW;
+            const int c = row / G::ROWS, iy = row - c * G::ROWS, chn = c0 + c, gy = gy0 + iy;
+            const bool inimg = unit < NU4 && chn < CIN && (unsigned)gy < (unsigned)H;
+            const bool phys = inimg && chn < Cphys;
+            phys_mask |= phys ? 1u << j : 0u;
+            ones_mask |= (inimg && !phys) ? 1u << j : 0u;
+            const int voff = phys ? ((chn * H + gy) * W + gxi + 4 * q) * 4 : 0x7ffffff0;
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, voff, 0, 0);
+            if (P1) u[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < JH; ++j) {
+            const int unit = j * 256 + tid, row = unit >> 1, side = unit & 1;
+            const int c = row / G::ROWS, iy = row - c * G::ROWS, chn = c0 + c, gy = gy0 + iy;
+            const int gx = side ? gxi + 4 * G::QW : gxi - 1;
+            const bool inimg = unit < NH && chn < CIN && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const bool phys = inimg && chn < Cphys;
+            phys_mask |= phys ? 1u << (16 + j) : 0u;
+            ones_mask |= (inimg && !phys) ? 1u << (16 + j) : 0u;
+            const int voff = phys ? ((chn * H + gy) * W + gx) * 4 : 0x7ffffff0;
+            hv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, voff, 0, 0));
+            if (P1) hu[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, voff, 0, 0));
+        }
+    }
+
+    __device__ __forceinline__ float xform(const Operand &op, const float *cf, float x, float uu) const
+    {
+        const int mode = op.mode;
+        if (mode == DM_LOAD_RELU) return x < 0.f ? 0.f : x;
+        if (mode == DM_LOAD_AFFINE2) return cf[0] * x + (cf[1] * uu + cf[2]);
+        if (mode >= DM_LOAD_AFFINE) {
+            x = cf[0] * x + cf[2];
+            if (mode == DM_LOAD_AFFINE_RELU) x = x < 0.f ? 0.f : x;
+        }
+        return x;
+    }
+
+    __device__ __forceinline__ void commit(const Operand &op, const float *s_cf, float *s_dst, int Cphys, int H, int W, int tid) const
+    {
+        const bool slow_p1 = !P1 && op.mode == DM_LOAD_AFFINE2;
+#pragma unroll
+        for (int j = 0; j < J4; ++j) {
+            const int unit = j * 256 + tid, row = unit / G::QW, q = unit - row * G::QW;
+            if (unit >= NU4) continue;
+            const int c = row / G::ROWS, iy = row - c * G::ROWS;
+            f32x4 x = v[j];
+            if ((phys_mask >> j) & 1) {
+                f32x4 uu = P1 ? u[j] : x;
+                if (slow_p1) uu = *reinterpret_cast<const f32x4 *>(op.p1 + (((long long)b * Cphys + c0 + c) * H + gy0 + iy) * W + gxi + 4 * q);
+                const float *cf = s_cf + c * 4;
+                x = (f32x4){xform(op, cf, x.x, uu.x), xform(op, cf, x.y, uu.y), xform(op, cf, x.z, uu.z), xform(op, cf, x.w, uu.w)};
+            } else {
+                const float f = (ones_mask >> j) & 1 ? 1.f : 0.f;
+                x = (f32x4){f, f, f, f};
+            }
+            if (FORM == W_S2) {
+                float *base = s_dst + c * G::CHS + iy * G::RS + 2 * q;
+                *reinterpret_cast<f32x2 *>(base + G::PLS) = (f32x2){x.x, x.z};      // odd window columns 1+4q, 3+4q
+                *reinterpret_cast<f32x2 *>(base + 2) = (f32x2){x.y, x.w};           // even window columns 2+4q, 4+4q
+            } else {
+                *reinterpret_cast<f32x4 *>(s_dst + c * G::CHS + iy * G::RS + G::OFFC + 4 * q) = x;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JH; ++j) {
+            const int unit = j * 256 + tid, row = unit >> 1, side = unit & 1;
+            if (unit >= NH) continue;
+            const int c = row / G::ROWS, iy = row - c * G::ROWS;
+            float x = hv[j];
+            if ((phys_mask >> (16 + j)) & 1) {
+                float uu = P1 ? hu[j] : x;
+                if (slow_p1) uu = op.p1[(((long long)b * Cphys + c0 + c) * H + gy0 + iy) * W + (side ? gxi + 4 * G::QW : gxi - 1)];
+                x = xform(op, s_cf + c * 4, x, uu);
+            } else {
+                x = (ones_mask >> (16 + j)) & 1 ? 1.f : 0.f;
+            }
+            int a;
+            if (FORM == W_S2) a = c * G::CHS + iy * G::RS + (side ? G::PLS + 16 : 1);
+            else a = c * G::CHS + iy * G::RS + (side ? G::OFFC + 16 : G::OFFC - 1);
+            s_dst[a] = x;
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------- convolution
@@ -54,17 +280,19 @@ struct WideGeom {
 //   per_tile == 0: workgroup x walks tiles x, x+gx, ...; statistics of all of them -> slab x; slabs >= gx are zeroed.
 //   per_tile != 0: workgroup x walks samples x, x+gx, ...; statistics of a sample -> slab b*(nslabs/B), the sample's
 //                  other slabs are zeroed (per-sample BatchNorm sums the slabs of a sample).
+// wpk: the packed weights (wide_pack_kernel, same <FORM, TAPS, NPW>).
 template <int FORM, int TAPS, int NPW>
-__global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep,
-                                                        int B, int Cphys, int CIN, int NOUT, int H, int W, int nslabs,
-                                                        int per_tile)
+__global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float *__restrict__ wpk, float *__restrict__ out,
+                                                        Epilogue ep, int B, int Cphys, int CIN, int NOUT, int H, int W,
+                                                        int nslabs, int per_tile)
 {
     using G = WideGeom<FORM, TAPS>;
-    constexpr int NS = NPW == 1 ? 16 : 16 * NPW + 16;     // weight row stride (floats), distinct banks for the 4 k lanes
-    constexpr int NPASS = 16 * NPW;
+    using P = WideW<FORM, TAPS, NPW>;
+    constexpr int NS = P::NS, W_PS = P::W_PS, W_TS = P::W_TS, NPASS = P::NPASS;
     __shared__ __attribute__((aligned(16))) float s_in[WKC * G::CHS];
-    __shared__ __attribute__((aligned(16))) float s_w[G::T * WKC * NS];
+    __shared__ __attribute__((aligned(16))) float s_w[P::BLK];
     __shared__ double s_red[4 * NPW * 16 * 2];
+    __shared__ float s_cf[2][WKC * 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
     const int CO = FORM == W_PIX ? NOUT >> 2 : NOUT;
@@ -75,6 +303,9 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, WeightView w
     const int nchunks = (CIN + WKC - 1) / WKC;
     const int spg = per_tile ? nslabs / B : 1;
     const int ngroups = per_tile ? B : 1;
+    const __amdgpu_buffer_rsrc_t wr_live = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(wpk + (long long)blockIdx.y * nchunks * P::BLK), 0, nchunks * P::BLK * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wpk), 0, 0, 0x00020000);
 
     for (int g = per_tile ? blockIdx.x : 0; g < ngroups; g += per_tile ? gridDim.x : 1) {
         double st1[NPW], st2[NPW];
@@ -82,6 +313,36 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, WeightView w
         for (int t = 0; t < NPW; ++t) { st1[t] = 0.0; st2[t] = 0.0; }
         const int t_begin = per_tile ? g * tps : blockIdx.x, t_end = per_tile ? (g + 1) * tps : B * tps;
         const int t_step = per_tile ? 1 : gridDim.x;
+        constexpr int JW = (P::BLK / 4 + 255) / 256;
+        RowPrefetch<FORM, TAPS, FORM != W_S2> pin;
+        f32x4 pw[JW];
+        int par = 0;
+
+        // chunk (tile, ch) -> registers: input rows, the packed weight block, coefficient rows (double-buffered in LDS)
+        auto issue = [&](int tile, int ch, bool live) {
+            const int b = tile / tps, r = tile - b * tps;
+            const int y0 = (r / tx_n) << 3, x0 = (r - (r / tx_n) * tx_n) << 4;
+            const int c0 = ch * WKC;
+            par ^= 1;
+            stage_coef(in, s_cf[par], WKC, c0, Cphys, b, tid);
+            pin.issue(in, live, b, c0, CIN, Cphys, G::S * y0 - G::R, G::S * x0, H, W, tid);
+            const __amdgpu_buffer_rsrc_t wr = live ? wr_live : wr_dead;
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int idx = j * 256 + tid;
+                pw[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, idx < P::BLK / 4 ? (ch * P::BLK + idx * 4) * 4 : 0x7ffffff0, 0, 0);
+            }
+        };
+        auto commit = [&]() {
+            pin.commit(in, s_cf[par], s_in, Cphys, H, W, tid);
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int idx = j * 256 + tid;
+                if (idx < P::BLK / 4) *reinterpret_cast<f32x4 *>(&s_w[idx * 4]) = pw[j];
+            }
+        };
+
+        issue(t_begin < t_end ? t_begin : 0, 0, t_begin < t_end);
         for (int tile = t_begin; tile < t_end; tile += t_step) {
             const int b = tile / tps, r = tile - b * tps;
             const int y0 = (r / tx_n) << 3, x0 = (r - (r / tx_n) * tx_n) << 4;
@@ -92,52 +353,36 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, WeightView w
                 for (int t = 0; t < NPW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
             for (int ch = 0; ch < nchunks; ++ch) {
-                const int c0 = ch * WKC;
+                __syncthreads();                 // the previous chunk's MFMAs are done with s_in / s_w
+                commit();
                 __syncthreads();
-                // ---- input chunk: WKC channels x ROWS x LCOLS, transform + padding applied
-                for (int idx = tid; idx < WKC * G::ROWS * G::LCOLS; idx += 256) {
-                    const int c = idx / (G::ROWS * G::LCOLS), rem = idx - c * (G::ROWS * G::LCOLS);
-                    const int iy = rem / G::LCOLS, ix = rem - iy * G::LCOLS;
-                    float v = 0.f;
-                    if (c0 + c < CIN) v = wide_load(in, b, c0 + c, G::S * y0 - G::R + iy, G::S * x0 - G::R + ix, Cphys, H, W);
-                    const int a = FORM == W_S2 ? c * G::CHS + (ix & 1) * G::PLS + iy * G::COLS + (ix >> 1)
-                                               : c * G::CHS + iy * G::COLS + ix;
-                    s_in[a] = v;
+                // next chunk's loads fly during this chunk's MFMAs (and, across tiles, during the epilogue)
+                {
+                    const bool wrap = ch + 1 == nchunks;
+                    const int ntile = wrap ? tile + t_step : tile;
+                    const bool live = ntile < t_end;
+                    issue(live ? ntile : tile, wrap ? 0 : ch + 1, live);
                 }
-                // ---- weight chunk as [tap][channel][n]
-                for (int idx = tid; idx < G::T * WKC * NPASS; idx += 256) {
-                    const int tap = idx % G::T, cl = (idx / G::T) % WKC, nl = idx / (G::T * WKC);
-                    const int n = n0 + nl, c = c0 + cl;
-                    float v = 0.f;
-                    if (n < NOUT && c < CIN) {
-                        if (FORM == W_PIX) {
-                            const int co = n >> 2, py = (n >> 1) & 1, px = n & 1, tyy = tap / 3, txx = tap - tyy * 3;
-                            const int da = tyy - py, db = txx - px;
-                            if (da >= 0 && da <= 1 && db >= 0 && db <= 1)
-                                v = wv.w[wv.off + co * wv.sn + c * wv.sc + (py + 3 - 2 * tyy) * wv.sky + (px + 3 - 2 * txx) * wv.skx];
-                        } else {
-                            constexpr int KW = FORM == W_S2 ? 4 : (TAPS == 9 ? 3 : 1);
-                            const int ky = tap / KW, kx = tap - ky * KW;
-                            v = wv.w[wv.off + n * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
-                        }
-                    }
-                    s_w[(tap * WKC + cl) * NS + nl] = v;
-                }
-                __syncthreads();
-                // ---- MFMAs: wave owns base rows 2*wave, 2*wave+1
-#pragma unroll
+                // ---- MFMAs: wave owns base rows 2*wave, 2*wave+1 (taps not unrolled: a fully unrolled loop hoists every
+                //      LDS read to the top and spills)
+#pragma unroll 1
                 for (int tap = 0; tap < G::T; ++tap) {
                     int toff;
-                    if (FORM == W_S2) toff = (tap & 1) * G::PLS + (tap >> 2) * G::COLS + ((tap & 3) >> 1);
-                    else toff = TAPS == 9 ? (tap / 3) * G::COLS + (tap % 3) : 0;
+                    if (FORM == W_S2) {
+                        const int ky = tap >> 2, kx = tap & 3;
+                        toff = (kx & 1) * G::PLS + ky * G::RS + (kx >> 1) + ((kx & 1) ? 0 : 1);
+                    } else {
+                        toff = TAPS == 9 ? (tap / 3) * G::RS + (tap % 3) + G::OFFC - 1 : 0;
+                    }
 #pragma unroll
                     for (int cq = 0; cq < WKC / 4; ++cq) {
                         float av[2], bv[NPW];
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            av[i] = s_in[(cq * 4 + kq) * G::CHS + toff + (G::S * (2 * wave + i)) * G::COLS + p];
+                            av[i] = s_in[(cq * 4 + kq) * G::CHS + toff + (G::S * (2 * wave + i)) * G::RS + p];
 #pragma unroll
-                        for (int t = 0; t < NPW; ++t) bv[t] = s_w[(tap * WKC + cq * 4 + kq) * NS + t * 16 + p];
+                        for (int t = 0; t < NPW; ++t)
+                            bv[t] = s_w[tap * W_TS + (cq * 2 + (kq >> 1)) * W_PS + (kq & 1) * NS + t * 16 + p];
 #pragma unroll
                         for (int t = 0; t < NPW; ++t)
 #pragma unroll
@@ -263,12 +508,13 @@ struct WgGeom {
     static constexpr int COLS = KK == 4 ? 17 : LCOLS;
     static constexpr int PLS = ROWS * COLS;
     static constexpr int RAW = KK == 4 ? 2 * PLS : PLS;
-    static constexpr int CTS = ((RAW - 4 + 63) / 64) * 64 + 4;           // T channel stride, = 4 (mod 64)
-    static constexpr int NTW = KK == 1 ? 4 : 8;                          // N tiles (of 16) per pass
-    static constexpr int NCTP = 16 * NTW / T2;                           // T channels per pass: 64 / 14 / 8
+    static constexpr int CTM = KK == 1 ? 2 : 8;                          // T channel stride mod 32 (bank spread of the N lanes)
+    static constexpr int CTS = ((RAW - CTM + 31) / 32) * 32 + CTM;
+    static constexpr int NTW = KK == 1 ? 4 : 16;                         // N tiles (of 16) per pass
+    static constexpr int NCTP = 16 * NTW / T2;                           // T channels per pass: 64 / 28 / 16
     static constexpr int ROWSTEP = S * COLS;                             // LDS step of one S-grid row
 };
-constexpr int WG_CSS = 132;            // S channel stride (128 pixels, = 4 mod 64)
+constexpr int WG_CSS = 130;            // S channel stride: the 16 channel lanes x 2 k lanes of a half hit 32 distinct banks
 
 // grid (x: persistent over (sample, tile) units -> slab x, y: passes of NCTP T channels, z: passes of 64 S channels)
 template <int KK>
@@ -278,10 +524,12 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
     using G = WgGeom<KK>;
     __shared__ __attribute__((aligned(16))) float s_S[64 * WG_CSS];
     __shared__ __attribute__((aligned(16))) float s_T[G::NCTP * G::CTS];
+    __shared__ float s_cfS[64 * 4], s_cfT[G::NCTP * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
     const int ct0 = blockIdx.y * G::NCTP, cs0 = blockIdx.z * 64;
     const int nct = CT - ct0 < G::NCTP ? CT - ct0 : G::NCTP;           // T channels of this pass
     const int ntw = (nct * G::T2 + 15) >> 4;                          // N tiles in use
+    const int ncs = CS - cs0 < 64 ? CS - cs0 : 64;
     const int Ht = Hs * G::S, Wt = Ws * G::S;
     const int tx_n = Ws >> 4, tps = (Hs >> 3) * tx_n;
     const long long E = (long long)CS * CT * G::T2;
@@ -291,7 +539,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
     for (int nt = 0; nt < G::NTW; ++nt) {
         const int n = nt * 16 + p, ctl = n / G::T2, tap = n - ctl * G::T2;
         const int ky = tap / KK, kx = tap - ky * KK;
-        int o = ctl * G::CTS + (KK == 4 ? (kx & 1) * G::PLS + ky * G::COLS + (kx >> 1) : ky * G::COLS + kx);
+        const int o = ctl * G::CTS + (KK == 4 ? (kx & 1) * G::PLS + ky * G::COLS + (kx >> 1) : ky * G::COLS + kx);
         boff[nt] = ctl < nct ? o : 0;
     }
     f32x4 acc[G::NTW];
@@ -302,36 +550,57 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
         const int b = u / tps, r = u - b * tps;
         const int y0 = (r / tx_n) << 3, x0 = (r - (r / tx_n) * tx_n) << 4;
+        stage_coef(S, s_cfS, ncs, cs0, CS, b, tid);
+        stage_coef(T, s_cfT, nct, ct0, CTphys, b, tid);
         __syncthreads();
-        // S tile: 64 channels x 8 rows x 16 columns as float4
-        for (int idx = tid; idx < 64 * 32; idx += 256) {
-            const int cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cs0 + cl < CS) {
-                const long long off = (((long long)b * CS + cs0 + cl) * Hs + y0 + rr) * Ws + x0 + c4 * 4;
-                v = operand_load4(S, off, b, cs0 + cl);
+        // S tile: 64 channels x 8 rows x 16 columns as float4, all loads in flight before the first use
+        const long long sample = (long long)b * CS * Hs * Ws;
+        const int smode = S.mode;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x4 sv[4], su[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = (half * 4 + j) * 256 + tid, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
+                const int off = cl < ncs ? ((cs0 + cl) * Hs + y0 + rr) * Ws + x0 + c4 * 4 : 0;
+                sv[j] = *reinterpret_cast<const f32x4 *>(S.p0 + sample + off);
+                if (smode == DM_LOAD_AFFINE2) su[j] = *reinterpret_cast<const f32x4 *>(S.p1 + sample + off);
             }
-            *reinterpret_cast<f32x4 *>(&s_S[cl * WG_CSS + rr * 16 + c4 * 4]) = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = (half * 4 + j) * 256 + tid, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
+                f32x4 v = sv[j];
+                if (smode == DM_LOAD_RELU) {
+                    v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                } else if (smode == DM_LOAD_AFFINE2) {
+                    v = s_cfS[cl * 4] * v + (s_cfS[cl * 4 + 1] * su[j] + s_cfS[cl * 4 + 2]);
+                } else if (smode >= DM_LOAD_AFFINE) {
+                    v = s_cfS[cl * 4] * v + s_cfS[cl * 4 + 2];
+                    if (smode == DM_LOAD_AFFINE_RELU) {
+                        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                    }
+                }
+                if (cl >= ncs) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x2 *dst = reinterpret_cast<f32x2 *>(&s_S[cl * WG_CSS + rr * 16 + c4 * 4]);   // rows are only 8-byte aligned
+                dst[0] = (f32x2){v.x, v.y};
+                dst[1] = (f32x2){v.z, v.w};
+            }
         }
         // T tile with halo
-        for (int idx = tid; idx < nct * G::ROWS * G::LCOLS; idx += 256) {
-            const int c = idx / (G::ROWS * G::LCOLS), rem = idx - c * (G::ROWS * G::LCOLS);
-            const int iy = rem / G::LCOLS, ix = rem - iy * G::LCOLS;
-            const float v = wide_load(T, b, ct0 + c, G::S * y0 - G::R + iy, G::S * x0 - G::R + ix, CTphys, Ht, Wt);
-            const int a = KK == 4 ? c * G::CTS + (ix & 1) * G::PLS + iy * G::COLS + (ix >> 1) : c * G::CTS + iy * G::COLS + ix;
-            s_T[a] = v;
-        }
+        stage_window<G::ROWS, G::LCOLS, G::COLS, G::CTS, KK == 4>(T, s_cfT, s_T, nct, ct0, CT, CTphys, b, G::S * y0 - G::R,
+                                                                 G::S * x0 - G::R, Ht, Wt, tid);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 1
         for (int ks = 0; ks < 32; ++ks) {
             const float av = s_S[(wave * 16 + p) * WG_CSS + ks * 4 + kq];
             const int po = (ks >> 2) * G::ROWSTEP + (ks & 3) * 4 + kq;
+            float bv[G::NTW];
 #pragma unroll
             for (int nt = 0; nt < G::NTW; ++nt)
-                if (nt < ntw) {
-                    const float bv = s_T[boff[nt] + po];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
-                }
+                if (nt < ntw) bv[nt] = s_T[boff[nt] + po];
+#pragma unroll
+            for (int nt = 0; nt < G::NTW; ++nt)
+                if (nt < ntw) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
         }
     }
 
@@ -370,42 +639,57 @@ int dm_wide_conv_slabs(int form, int B, int H, int W, int per_tile)
     return (int)(nt < WIDE_MAX_BLOCKS ? nt : WIDE_MAX_BLOCKS);
 }
 
-int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
-                 int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st)
+// output channels per pass / 16: wider passes put the accumulators plus the prefetch registers past 256
+// (the stride-2 form stages 2.5x as much input per chunk: 32 channels per pass there)
+static int wide_npw(int form, int NOUT) { return NOUT <= 16 ? 1 : ((NOUT <= 32 || form == W_S2) ? 2 : 4); }
+
+template <int FORM, int TAPS, int NPW>
+static long long wide_scratch_floats_t(int CIN, int NOUT)
+{
+    const long long passes = (NOUT + 16 * NPW - 1) / (16 * NPW), nchunks = (CIN + WKC - 1) / WKC;
+    return passes * nchunks * WideW<FORM, TAPS, NPW>::BLK;
+}
+
+#define DM_WIDE_SWITCH(CALL)                                                                                    \
+    if (form == W_S2) {                                                                                         \
+        if (np == 1) CALL(W_S2, 16, 1) else if (np == 2) CALL(W_S2, 16, 2) else CALL(W_S2, 16, 4)              \
+    } else if (form == W_PIX) {                                                                                 \
+        if (np == 1) CALL(W_PIX, 9, 1) else if (np == 2) CALL(W_PIX, 9, 2) else CALL(W_PIX, 9, 4)              \
+    } else if (taps == 9) {                                                                                     \
+        if (np == 1) CALL(W_S1, 9, 1) else if (np == 2) CALL(W_S1, 9, 2) else CALL(W_S1, 9, 4)                 \
+    } else {                                                                                                    \
+        if (np == 1) CALL(W_S1, 1, 1) else if (np == 2) CALL(W_S1, 1, 2) else CALL(W_S1, 1, 4)                 \
+    }
+
+// floats of caller scratch (dm_weight_view.scratch) the packed weights of this convolution take
+long long dm_wide_conv_scratch_floats(int form, int CIN, int NOUT, int taps)
+{
+    const int np = wide_npw(form, NOUT);
+    long long r = 0;
+#define DM_WS(F, TP, NP_) { r = wide_scratch_floats_t<F, TP, NP_>(CIN, NOUT); }
+    DM_WIDE_SWITCH(DM_WS)
+#undef DM_WS
+    return r;
+}
+
+int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scratch, float *out, const Epilogue &ep, int B,
+                 int Cphys, int CIN, int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st)
 {
     const int BH = form == W_S2 ? H / 2 : H, BW = form == W_S2 ? W / 2 : W;
     const long long ntiles = (long long)B * (BH / 8) * (BW / 16);
     long long gx = per_tile ? B : ntiles;
     if (gx > WIDE_MAX_BLOCKS) gx = WIDE_MAX_BLOCKS;
     if (ep.stats && !per_tile && gx > nslabs) gx = nslabs;
-    const int maxnp = form == W_S2 ? 4 : 8;
-    int np = NOUT <= 16 ? 1 : (NOUT <= 32 ? 2 : (NOUT <= 64 ? 4 : 8));
-    if (np > maxnp) np = maxnp;
-    const dim3 grid((unsigned)gx, (unsigned)((NOUT + 16 * np - 1) / (16 * np)));
+    const int np = wide_npw(form, NOUT);
+    const int passes = (NOUT + 16 * np - 1) / (16 * np), nchunks = (CIN + WKC - 1) / WKC;
+    const dim3 grid((unsigned)gx, (unsigned)passes), pgrid((unsigned)nchunks, (unsigned)passes);
 #define DM_WL(F, TP, NP_)                                                                                           \
-    hipLaunchKernelGGL((conv_wide_kernel<F, TP, NP_>), grid, dim3(256), 0, st, in, wv, out, ep, B, Cphys, CIN, NOUT, \
-                       H, W, nslabs, per_tile)
-#define DM_WN(F, TP)                                                              \
-    switch (np) {                                                                 \
-    case 1: DM_WL(F, TP, 1); break;                                               \
-    case 2: DM_WL(F, TP, 2); break;                                               \
-    case 4: DM_WL(F, TP, 4); break;                                               \
-    default: DM_WL(F, TP, 8); break;                                              \
+    {                                                                                                               \
+        hipLaunchKernelGGL((wide_pack_kernel<F, TP, NP_>), pgrid, dim3(256), 0, st, wv, scratch, CIN, NOUT);        \
+        hipLaunchKernelGGL((conv_wide_kernel<F, TP, NP_>), grid, dim3(256), 0, st, in, (const float *)scratch, out, ep, B,   \
+                           Cphys, CIN, NOUT, H, W, nslabs, per_tile);                                               \
     }
-    if (form == W_S2) {
-        switch (np) {
-        case 1: DM_WL(W_S2, 16, 1); break;
-        case 2: DM_WL(W_S2, 16, 2); break;
-        default: DM_WL(W_S2, 16, 4); break;
-        }
-    } else if (form == W_PIX) {
-        DM_WN(W_PIX, 9)
-    } else if (taps == 9) {
-        DM_WN(W_S1, 9)
-    } else {
-        DM_WN(W_S1, 1)
-    }
-#undef DM_WN
+    DM_WIDE_SWITCH(DM_WL)
 #undef DM_WL
     return 0;
 }

@@ -61,12 +61,15 @@ static inline Operand null_operand()
 struct WeightView {
     const float *w;
     long long off, sn, sc, sky, skx;
+    float *scratch;
+    long long scratch_floats;
 };
 
 static inline WeightView to_dev(const dm_weight_view *v)
 {
     WeightView r;
     r.w = v->w; r.off = v->off; r.sn = v->sn; r.sc = v->sc; r.sky = v->sky; r.skx = v->skx;
+    r.scratch = v->scratch; r.scratch_floats = v->scratch_floats;
     return r;
 }
 

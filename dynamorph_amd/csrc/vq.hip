@@ -230,19 +230,23 @@ __global__ void vq_finalize_kernel(const double *__restrict__ sse_slabs, int nsl
 // 1024-thread workgroups walking the positions with a grid stride: the codebook gradient is accumulated in LDS
 // over ALL of a workgroup's positions and flushed once, so the global float atomics (K*D addresses that every
 // workgroup hits) number grid*K*D instead of (P/256)*K*D -- at B = 2048 that flush, not the streaming, was the cost.
+// Codebooks larger than the LDS window (512 x 64, 4096 x 16) are split into windows of codes over grid.y.
 constexpr int VQ_BWD_BLOCK = 1024;
+constexpr int VQ_BWD_LDS = 128 * 1024;     // codebook-gradient window per workgroup (gfx950: 160 KB of LDS per CU)
+// grid (x: positions, grid stride; y: windows of Kc codes).  A workgroup only touches the positions whose code falls
+// into its window, so z / g_out / dz are still streamed once; idx is read once per window.
 template <int D>
 __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const long long *__restrict__ idx,
     const float *__restrict__ g_out, const float *__restrict__ g_loss_dev, float cc,
     float *__restrict__ dz, float *__restrict__ dw, float *__restrict__ dw_slabs, int K, int HW, long long P,
-    int use_lds)
+    int Kc)
 {
-    extern __shared__ float s_dw[];    // [K][D] when use_lds
-    if (use_lds) {
-        for (int i = threadIdx.x; i < K * D; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
-        __syncthreads();
-    }
+    extern __shared__ float s_dw[];    // [Kc][D]
+    const long long k_lo = (long long)blockIdx.y * Kc;
+    const int kn = K - k_lo < Kc ? (int)(K - k_lo) : Kc;
+    for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
+    __syncthreads();
     const float g_loss = g_loss_dev ? g_loss_dev[0] : 1.f;
     const double N = (double)P * (double)D;
     const float sz = (float)(2.0 * (double)cc / N) * g_loss;   // d/dz of cc * mse(q.detach(), z)
@@ -252,7 +256,9 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
         const long long b = pos / HW, p = pos - b * HW;
         const long long base = b * (long long)D * HW + p;
         const long long k = idx[pos];
+        if (k < k_lo || k >= k_lo + kn) continue;
         const float *__restrict__ q = cb + k * D;
+        const int kl = (int)(k - k_lo);
         constexpr int DC = D < 16 ? D : 16;                // d in chunks of 16 (register budget of a 1024-thread group)
 #pragma unroll
         for (int d0 = 0; d0 < D; d0 += DC) {
@@ -266,19 +272,15 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
 #pragma unroll
             for (int j = 0; j < DC; ++j) {
                 if (dz) dz[base + (long long)(d0 + j) * HW] = gv[j] + sz * (zv[j] - qv[j]);
-                const float gw = sw * (qv[j] - zv[j]);
-                if (use_lds) atomicAdd(&s_dw[k * D + d0 + j], gw);
-                else atomicAdd(&dw[k * D + d0 + j], gw);
+                atomicAdd(&s_dw[kl * D + d0 + j], sw * (qv[j] - zv[j]));
             }
         }
     }
-    if (use_lds) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < K * D; i += VQ_BWD_BLOCK) {
-            const float v = s_dw[i];
-            if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + i] = v;   // dm_reduce_slabs adds them in slab order
-            else if (v != 0.f) atomicAdd(&dw[i], v);
-        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) {
+        const float v = s_dw[i];
+        if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + k_lo * D + i] = v;   // dm_reduce_slabs adds them in slab order
+        else if (v != 0.f) atomicAdd(&dw[k_lo * D + i], v);
     }
 }
 
@@ -361,14 +363,18 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
     DM_REQUIRE(z && codebook && idx && (dw || dw_slabs), "%s: NULL pointer", who);
     DM_REQUIRE(vq_dim_supported(D), "%s: embedding_dim %d not built (8/16/32/64/128)", who, D);
     const long long P = (long long)B * H * W;
-    const size_t lds = (size_t)K * D * sizeof(float);
-    const int use_lds = lds <= 48 * 1024;
-    DM_REQUIRE(!dw_slabs || use_lds, "%s: the slab form needs the codebook gradient in LDS (K*D*4 <= 48 KB)", who);
+    int Kc = VQ_BWD_LDS / (D * (int)sizeof(float));
+    if (Kc > K) Kc = K;
+    const size_t lds = (size_t)Kc * D * sizeof(float);
     const int grid = vq_backward_grid(P);
+    const dim3 g3((unsigned)grid, (unsigned)((K + Kc - 1) / Kc));
     hipStream_t s = (hipStream_t)stream;
-#define DM_VQ_BWD(DD)                                                                                         \
-    hipLaunchKernelGGL(vq_backward_kernel<DD>, dim3(grid), dim3(VQ_BWD_BLOCK), use_lds ? lds : 0, s, z, codebook, \
-                       (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, dw_slabs, K, H * W, P, use_lds)
+#define DM_VQ_BWD(DD)                                                                                          \
+    if (lds > 48 * 1024)                                                                                       \
+        (void)hipFuncSetAttribute((const void *)vq_backward_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)lds);                                                                   \
+    hipLaunchKernelGGL(vq_backward_kernel<DD>, g3, dim3(VQ_BWD_BLOCK), lds, s, z, codebook,                    \
+                       (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, dw_slabs, K, H * W, P, Kc)
     switch (D) {
     case 8: DM_VQ_BWD(8); break;
     case 16: DM_VQ_BWD(16); break;

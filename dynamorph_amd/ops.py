@@ -47,11 +47,20 @@ def _null_operand():
 class WView:
     """dm_weight_view plus a reference to the tensor it points into (a bare struct would dangle as soon
     as a temporary such as `w.to(device)` is collected and the caching allocator reuses its block)."""
-    __slots__ = ("struct", "_keep")
+    __slots__ = ("struct", "_keep", "_scratch")
 
     def __init__(self, w, sn, sc, sky, skx, off=0):
         self._keep = w
-        self.struct = L.WeightView(_ptr(w), off, sn, sc, sky, skx)
+        self._scratch = None
+        self.struct = L.WeightView(_ptr(w), off, sn, sc, sky, skx, None, 0)
+
+    def with_scratch(self, nfloats):
+        """Attach `nfloats` of device scratch (dm_weight_view.scratch; what dm_conv*_scratch_floats asked for)."""
+        if nfloats > 0 and (self._scratch is None or self._scratch.numel() < nfloats):
+            self._scratch = torch.empty(nfloats, device=self._keep.device, dtype=torch.float32)
+            self.struct.scratch = self._scratch.data_ptr()
+            self.struct.scratch_floats = nfloats
+        return self
 
 
 def weight_view(w, sn, sc, sky, skx, off=0):
@@ -104,13 +113,15 @@ def vq_decode(idx, codebook):
 
 
 def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_dz=True):
-    """g_loss: 1-element device tensor (or None = 1).  dw is accumulated into (zero it first)."""
+    """g_loss: 1-element device tensor (or None = 1).  dw given: accumulated into with float atomics (zero it first);
+    dw None: a fresh tensor from the deterministic slab form."""
     lib = L.load()
     B, D, H, W = z.shape
     K = codebook.shape[0]
-    dz = torch.empty_like(z) if want_dz else None
     if dw is None:
-        dw = torch.zeros_like(codebook)
+        dz, slabs = vq_backward_slabs(z, codebook, idx, g_out, g_loss, commitment_cost, want_dz=want_dz)
+        return dz, reduce_slabs(slabs, torch.empty_like(codebook))
+    dz = torch.empty_like(z) if want_dz else None
     L.check(lib.dm_vq_backward(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(g_out), _ptr(g_loss),
                                commitment_cost, _ptr(dz), _ptr(dw), B, D, K, H, W, _stream()), "dm_vq_backward")
     return dz, dw
@@ -144,6 +155,9 @@ def conv4x4s2(inp, wv, B, CIN, NOUT, H, W, ep=None, out=None, want_stats=False, 
         stats = _new((nb, NOUT, 2), like, torch.float64)
     e = epilogue(stats=stats, **epkw)
     o = inp.struct()
+    fallback = inp.mode == L.DM_LOAD_AFFINE2 or (epkw.get("bias_border") is not None and
+                                                  any(epkw.get(k) is not None for k in ("mask", "resid", "stat_q")))
+    wv.with_scratch(lib.dm_conv4x4s2_scratch_floats(CIN, NOUT, H, W, 1 if fallback else 0))
     L.check(lib.dm_conv4x4s2(C.byref(o), C.byref(wv.struct), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, _stream()),
             "dm_conv4x4s2")
     return out, stats
@@ -163,6 +177,8 @@ def conv3x3(inp, wv, B, CIN, NOUT, H, W, taps=9, pixel_shuffle=False, out=None, 
         stats = _new((nb, co, 2), like, torch.float64)
     e = epilogue(stats=stats, **epkw)
     o = inp.struct()
+    wv.with_scratch(lib.dm_conv3x3_scratch_floats(CIN, NOUT, H, W, taps, 1 if pixel_shuffle else 0,
+                                                  1 if epkw.get("per_tile") else 0))
     L.check(lib.dm_conv3x3(C.byref(o), C.byref(wv.struct), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, taps,
                            1 if pixel_shuffle else 0, _stream()), "dm_conv3x3")
     return out, stats

@@ -97,15 +97,9 @@ class FusedTrainer:
         scalars = ops.loss_finalize(dcx.loss_slabs, B * NIN * H * W, vsc, float(model.weight_recon),
                                     float(model.weight_commitment))
         gcb = self.G(L.codebook.weight)
-        K, D = L.codebook.weight.shape
-        if K * D * 4 <= 48 * 1024:
-            # codebook gradient as slabs, added in the encoder's single slab reduction: no atomics, nothing to zero
-            dz, cb_slabs = ops.vq_backward_slabs(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc)
-            extra = [(cb_slabs, gcb)]
-        else:
-            gcb.zero_()
-            dz, _ = ops.vq_backward(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc, dw=gcb)
-            extra = []
+        # codebook gradient as slabs, added in the encoder's single slab reduction: no atomics, nothing to zero
+        dz, cb_slabs = ops.vq_backward_slabs(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc)
+        extra = [(cb_slabs, gcb)]
         if time_matching_mat is not None:
             # pairwise term on z_before (vq_vae.py:324-332): HIP kernels for the (B, B) distances and their gradient,
             # the B*B weighting in torch

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 102
+#define DM_VERSION 103
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -63,6 +63,9 @@ typedef struct dm_operand {
 typedef struct dm_weight_view {
     const float *w;
     int64_t off, sn, sc, sky, skx;
+    float *scratch;          /* device scratch of >= dm_conv*_scratch_floats(...) floats, or NULL.  Channel counts without a */
+    int64_t scratch_floats;  /* register-resident kernel run an implicit GEMM that first re-lays the weights into it; without
+                                scratch those shapes take the (much slower) generic kernel.  Contents are don't-care. */
 } dm_weight_view;
 
 /* ---- epilogue ---------------------------------------------------------------
@@ -126,7 +129,8 @@ int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
 
 /* The same with the codebook gradient as per-workgroup slabs [dm_vq_backward_num_slabs(P)][K*D] instead of global
  * float atomics: dm_reduce_slabs / dm_reduce_slabs_multi adds them in a fixed order and nothing has to be zeroed
- * first (inside a workgroup the LDS adds still arrive in hardware order).  Needs K*D*4 <= 48 KB. */
+ * first (inside a workgroup the LDS adds still arrive in hardware order).  Codebooks above the 128 KB LDS window
+ * (512 x 64, 4096 x 16) are processed in windows of codes over grid.y. */
 int dm_vq_backward_num_slabs(int64_t positions);
 int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *idx,
                          const float *g_out, const float *g_loss_dev, float commitment_cost,
@@ -141,6 +145,9 @@ int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *i
 int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
                  int B, int CIN, int NOUT, int H, int W, void *stream);
 int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, int per_tile);
+/* floats of dm_weight_view.scratch this call wants (0: none).  fallback != 0: the input is AFFINE2 or the border-bias
+ * table comes with side inputs, which the register-resident kernels do not take. */
+int64_t dm_conv4x4s2_scratch_floats(int CIN, int NOUT, int H, int W, int fallback);
 
 /* 3x3 stride 1 padding 1 (taps = 9) or 1x1 (taps = 1) convolution on MFMA.
  * pixel_shuffle = 1 turns it into a ConvTranspose2d(4, stride 2, padding 1):
@@ -153,6 +160,7 @@ int dm_conv4x4s2_num_blocks(int B, int CIN, int NOUT, int H, int W, int per_tile
 int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *out, const dm_epilogue *ep,
                int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, void *stream);
 int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile);
+int64_t dm_conv3x3_scratch_floats(int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile);
 
 /* Weight gradient:  R[cs][ct][ky][kx] = sum_{b,y,x} S[b,cs,y,x] * T[b,ct,y*s+ky-p,x*s+kx-p]
  * (k,s,p) in {(4,2,1),(3,1,1),(1,1,0)}.  For a Conv2d: S = output gradient,

@@ -38,13 +38,13 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layouts_match_the_header():
     from dynamorph_amd import _lib
     assert ctypes.sizeof(_lib.Operand) == 40          # 3 pointers + int64 + 2 int32
-    assert ctypes.sizeof(_lib.WeightView) == 48
+    assert ctypes.sizeof(_lib.WeightView) == 64          # 6 words + scratch pointer + scratch size
     assert ctypes.sizeof(_lib.Epilogue) == 24 + 40 + 24   # bias, bias_border, relu, stats_per_tile | mask | 3 pointers
     assert _lib.Epilogue.mask.offset == 24 and _lib.Epilogue.stats.offset == 80
 
 
 def test_version_and_host_only_queries(lib):
-    assert lib.dm_version() == 102          # 102: dm_head_supported, generic fallback kernels
+    assert lib.dm_version() == 103          # 103: dm_weight_view.scratch, implicit-GEMM kernels for wide channel counts
     assert lib.dm_vq_workspace_bytes(64, 16) == 64 * 16 * 4
     assert lib.dm_vq_workspace_bytes(63, 16) == 64 * 16 * 4           # odd K is padded to a pair
     assert lib.dm_vq_num_blocks(524288) == 2048

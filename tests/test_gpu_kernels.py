@@ -594,12 +594,36 @@ def test_vq_backward_slabs_equal_the_atomic_form(ops):
     g = rnd(B, D, H, H, seed=33).to(DEV)
     idx, _, _, _ = ops.vq_forward(z, cb, want_out=False)
     gl = torch.tensor([0.7], device=DEV)
-    dz_a, dw_a = ops.vq_backward(z, cb, idx, g, gl, 0.25)
+    dz_a, dw_a = ops.vq_backward(z, cb, idx, g, gl, 0.25, dw=torch.zeros(K, D, device=DEV))
     dz_s, slabs = ops.vq_backward_slabs(z, cb, idx, g, gl, 0.25)
     dw_s = torch.empty(K * D, device=DEV)
     ops.reduce_slabs(slabs, dw_s)
     assert torch.equal(dz_a, dz_s)
     close(dw_s.reshape(K, D), dw_a, 1e-5, 1e-7 * float(dw_a.abs().max()) + 1e-9, "codebook gradient (slabs)")
+
+
+@pytest.mark.parametrize("K,D,H", [(512, 64, 32), (4096, 16, 32), (300, 128, 8)])
+def test_vq_backward_large_codebooks(ops, K, D, H):
+    """Codebooks above the LDS window (config_example.yml: 512 x 64; the stress case: 4096 x 16) go through windows
+    of codes; both forms against embedding_dense_backward / mse_loss_backward restated with index_add."""
+    B = 5
+    z = rnd(B, D, H, H, seed=51)
+    cb = rnd(K, D, seed=52)
+    g = rnd(B, D, H, H, seed=53)
+    zd, cbd = z.to(DEV), cb.to(DEV)
+    idx, _, _, _ = ops.vq_forward(zd, cbd, want_out=False)
+    gl = torch.tensor([1.3], device=DEV)
+    q = cb[idx.cpu()].permute(0, 3, 1, 2)
+    N = z.numel()
+    dz_ref = g + 1.3 * 2 * 0.25 * (z - q) / N
+    dw_ref = torch.zeros(K, D).index_add_(0, idx.cpu().reshape(-1), (1.3 * 2 * (q - z) / N).permute(0, 2, 3, 1).reshape(-1, D))
+    dz_a, dw_a = ops.vq_backward(zd, cbd, idx, g.to(DEV), gl, 0.25, dw=torch.zeros(K, D, device=DEV))
+    dz_s, dw_s = ops.vq_backward(zd, cbd, idx, g.to(DEV), gl, 0.25)
+    close(dz_a, dz_ref, 1e-6, 1e-9, "dz")
+    assert torch.equal(dz_a, dz_s)
+    tol = 1e-6 * float(dw_ref.abs().max())
+    close(dw_a, dw_ref, 1e-5, tol, "codebook gradient (atomics)")
+    close(dw_s, dw_ref, 1e-5, tol, "codebook gradient (slabs)")
 
 
 @pytest.mark.parametrize("B,n", [(4, 4096), (19, 4096), (33, 100), (1, 64)])

@@ -13,8 +13,10 @@ def run(cls, kw, B, steps=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print(f"{cls.__name__} {kw} B={B}: {dt*1e3:.2f} ms/step = {B/dt:.0f} patches/s", flush=True)
-run(dynamorph_amd.VQ_VAE_z32, {}, 512, 10)
-run(dynamorph_amd.VQ_VAE, {}, 512, 10)
 ex = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)
-run(dynamorph_amd.VQ_VAE_z32, ex, 64, 3)
-run(dynamorph_amd.VQ_VAE, ex, 64, 3)
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+if which in ("all", "z32"):
+    run(dynamorph_amd.VQ_VAE_z32, ex, B, 5)
+if which in ("all", "vq"):
+    run(dynamorph_amd.VQ_VAE, ex, B, 5)
