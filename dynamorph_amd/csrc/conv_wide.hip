@@ -107,6 +107,7 @@ struct WideGeom {
     static constexpr int ROWS = FORM == W_S2 ? 18 : 8 + 2 * R;           // input rows of a tile
     static constexpr int QW = FORM == W_S2 ? 8 : 4;                      // aligned float4 per input row (the interior)
     static constexpr bool HALO = R > 0;
+    static constexpr bool PLANES = FORM == W_S2;
     // LDS image of one channel.  Plain forms: rows of RS floats, interior at column OFFC (16-byte aligned), halos at
     // OFFC-1 and OFFC+16.  Stride-2 form: two parity planes of 18 x 18 (odd window columns -> plane 1 at column wx>>1,
     // even ones -> plane 0 at column (wx>>1)+1), so that a stride-2 reader steps by 1 and the interior float4 of a row
@@ -165,11 +166,10 @@ __global__ __launch_bounds__(256) void wide_pack_kernel(WeightView wv, float *__
 // halo scalars, so a thread handles 2-5 float4 and 1-2 scalars per chunk instead of 6-20 scalars, each of which cost
 // ~25 integer instructions of index arithmetic (measured: 10 VALU instructions per MFMA, no overlap with the MFMAs).
 // P1: also prefetch the second tensor of an AFFINE2 operand (otherwise commit() reads it: exposed latency, rare path).
-template <int FORM, int TAPS, bool P1>
+template <class G, int NCH, bool P1>
 struct RowPrefetch {
-    using G = WideGeom<FORM, TAPS>;
-    static constexpr int NU4 = WKC * G::ROWS * G::QW, J4 = (NU4 + 255) / 256;
-    static constexpr int NH = G::HALO ? WKC * G::ROWS * 2 : 0, JH = (NH + 255) / 256;
+    static constexpr int NU4 = NCH * G::ROWS * G::QW, J4 = (NU4 + 255) / 256;
+    static constexpr int NH = G::HALO ? NCH * G::ROWS * 2 : 0, JH = (NH + 255) / 256;
     f32x4 v[J4], u[P1 ? J4 : 1];
     float hv[JH ? JH : 1], hu[(P1 && JH) ? JH : 1];
     int b, c0, gy0, gxi;
@@ -246,7 +246,7 @@ struct RowPrefetch {
                 const float f = (ones_mask >> j) & 1 ? 1.f : 0.f;
                 x = (f32x4){f, f, f, f};
             }
-            if (FORM == W_S2) {
+            if (G::PLANES) {
                 float *base = s_dst + c * G::CHS + iy * G::RS + 2 * q;
                 *reinterpret_cast<f32x2 *>(base + G::PLS) = (f32x2){x.x, x.z};      // odd window columns 1+4q, 3+4q
                 *reinterpret_cast<f32x2 *>(base + 2) = (f32x2){x.y, x.w};           // even window columns 2+4q, 4+4q
@@ -268,7 +268,7 @@ struct RowPrefetch {
                 x = (ones_mask >> (16 + j)) & 1 ? 1.f : 0.f;
             }
             int a;
-            if (FORM == W_S2) a = c * G::CHS + iy * G::RS + (side ? G::PLS + 16 : 1);
+            if (G::PLANES) a = c * G::CHS + iy * G::RS + (side ? G::PLS + 16 : 1);
             else a = c * G::CHS + iy * G::RS + (side ? G::OFFC + 16 : G::OFFC - 1);
             s_dst[a] = x;
         }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
         const int t_begin = per_tile ? g * tps : blockIdx.x, t_end = per_tile ? (g + 1) * tps : B * tps;
         const int t_step = per_tile ? 1 : gridDim.x;
         constexpr int JW = (P::BLK / 4 + 255) / 256;
-        RowPrefetch<FORM, TAPS, FORM != W_S2> pin;
+        RowPrefetch<G, WKC, FORM != W_S2> pin;
         f32x4 pw[JW];
         int par = 0;
 
@@ -363,10 +363,12 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                     const bool live = ntile < t_end;
                     issue(live ? ntile : tile, wrap ? 0 : ch + 1, live);
                 }
-                // ---- MFMAs: wave owns base rows 2*wave, 2*wave+1 (taps not unrolled: a fully unrolled loop hoists every
-                //      LDS read to the top and spills)
-#pragma unroll 1
-                for (int tap = 0; tap < G::T; ++tap) {
+                // ---- MFMAs: wave owns base rows 2*wave, 2*wave+1.  K steps of 4 channels: step = 2*tap + channel quad.
+                // The LDS operands of step s+1 are requested before the MFMAs of step s are issued (two register sets),
+                // otherwise every group of MFMAs starts by waiting out an LDS round trip.  Not unrolled further: a fully
+                // unrolled loop hoists every LDS read to the top and spills.
+                auto lds_step = [&](int step, float (&av)[2], float (&bv)[NPW]) {
+                    const int tap = step >> 1, cq = step & 1;
                     int toff;
                     if (FORM == W_S2) {
                         const int ky = tap >> 2, kx = tap & 3;
@@ -374,21 +376,34 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                     } else {
                         toff = TAPS == 9 ? (tap / 3) * G::RS + (tap % 3) + G::OFFC - 1 : 0;
                     }
+                    const float *ap = s_in + (cq * 4 + kq) * G::CHS + toff + (G::S * 2 * wave) * G::RS + p;
+                    av[0] = ap[0];
+                    av[1] = ap[G::S * G::RS];
+                    const float *bp = s_w + tap * W_TS + (cq * 2 + (kq >> 1)) * W_PS + (kq & 1) * NS + p;
 #pragma unroll
-                    for (int cq = 0; cq < WKC / 4; ++cq) {
-                        float av[2], bv[NPW];
+                    for (int t = 0; t < NPW; ++t) bv[t] = bp[t * 16];
+                };
+                auto mfma_step = [&](const float (&av)[2], const float (&bv)[NPW]) {
+#pragma unroll
+                    for (int t = 0; t < NPW; ++t)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            av[i] = s_in[(cq * 4 + kq) * G::CHS + toff + (G::S * (2 * wave + i)) * G::RS + p];
-#pragma unroll
-                        for (int t = 0; t < NPW; ++t)
-                            bv[t] = s_w[tap * W_TS + (cq * 2 + (kq >> 1)) * W_PS + (kq & 1) * NS + t * 16 + p];
-#pragma unroll
-                        for (int t = 0; t < NPW; ++t)
-#pragma unroll
-                            for (int i = 0; i < 2; ++i)
-                                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
-                    }
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
+                };
+                static_assert(WKC == 8, "two channel quads per tap");
+                constexpr int NSTEP = 2 * G::T;
+                float a0[2], b0[NPW], a1[2], b1[NPW];
+                lds_step(0, a0, b0);
+#pragma unroll 1
+                for (int step = 0; step < NSTEP; step += 2) {
+                    lds_step(step + 1, a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds_step(step + 2 < NSTEP ? step + 2 : step, a0, b0);       // last round: a harmless re-read
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 
@@ -498,21 +513,26 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient
+// T tile geometry (same LDS images as the convolution input: RowPrefetch stages it)
 template <int KK>
 struct WgGeom {
     static constexpr int S = KK == 4 ? 2 : 1;
     static constexpr int R = KK == 1 ? 0 : 1;
     static constexpr int T2 = KK * KK;
     static constexpr int ROWS = KK == 4 ? 18 : 8 + 2 * R;
-    static constexpr int LCOLS = KK == 4 ? 34 : 16 + 2 * R;
-    static constexpr int COLS = KK == 4 ? 17 : LCOLS;
-    static constexpr int PLS = ROWS * COLS;
+    static constexpr int QW = KK == 4 ? 8 : 4;
+    static constexpr bool HALO = R > 0;
+    static constexpr bool PLANES = KK == 4;
+    static constexpr int RS = KK == 4 ? 18 : (R ? 24 : 16);
+    static constexpr int OFFC = KK == 3 ? 4 : 0;
+    static constexpr int PLS = ROWS * RS;
     static constexpr int RAW = KK == 4 ? 2 * PLS : PLS;
-    static constexpr int CTM = KK == 1 ? 2 : 8;                          // T channel stride mod 32 (bank spread of the N lanes)
-    static constexpr int CTS = ((RAW - CTM + 31) / 32) * 32 + CTM;
+    // channel stride: multiple of 4 (aligned float4 / float2 rows); = 4 (mod 32) so that the taps of neighbouring
+    // channels inside one 16-lane N tile spread over the banks
+    static constexpr int CHS = KK == 4 ? RAW : ((RAW - 4 + 31) / 32) * 32 + 4;
     static constexpr int NTW = KK == 1 ? 4 : 16;                         // N tiles (of 16) per pass
     static constexpr int NCTP = 16 * NTW / T2;                           // T channels per pass: 64 / 28 / 16
-    static constexpr int ROWSTEP = S * COLS;                             // LDS step of one S-grid row
+    static constexpr int ROWSTEP = S * RS;                               // LDS step of one S-grid row
 };
 constexpr int WG_CSS = 130;            // S channel stride: the 16 channel lanes x 2 k lanes of a half hit 32 distinct banks
 
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
 {
     using G = WgGeom<KK>;
     __shared__ __attribute__((aligned(16))) float s_S[64 * WG_CSS];
-    __shared__ __attribute__((aligned(16))) float s_T[G::NCTP * G::CTS];
+    __shared__ __attribute__((aligned(16))) float s_T[G::NCTP * G::CHS];
     __shared__ float s_cfS[64 * 4], s_cfT[G::NCTP * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
     const int ct0 = blockIdx.y * G::NCTP, cs0 = blockIdx.z * 64;
@@ -534,41 +554,51 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
     const int tx_n = Ws >> 4, tps = (Hs >> 3) * tx_n;
     const long long E = (long long)CS * CT * G::T2;
 
-    int boff[G::NTW];
+    // LDS offset of this lane's (T channel, tap) of N tile nt at pixel (0, kq); rows add ROWSTEP, k steps add 4
+    int tb[G::NTW];
 #pragma unroll
     for (int nt = 0; nt < G::NTW; ++nt) {
         const int n = nt * 16 + p, ctl = n / G::T2, tap = n - ctl * G::T2;
         const int ky = tap / KK, kx = tap - ky * KK;
-        const int o = ctl * G::CTS + (KK == 4 ? (kx & 1) * G::PLS + ky * G::COLS + (kx >> 1) : ky * G::COLS + kx);
-        boff[nt] = ctl < nct ? o : 0;
+        int o = ctl * G::CHS + kq;
+        if (KK == 4) o += (kx & 1) * G::PLS + ky * G::RS + (kx >> 1) + ((kx & 1) ? 0 : 1);
+        else if (KK == 3) o += ky * G::RS + kx + G::OFFC - 1;
+        tb[nt] = ctl < nct ? o : kq;
     }
     f32x4 acc[G::NTW];
 #pragma unroll
     for (int nt = 0; nt < G::NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    RowPrefetch<G, G::NCTP, false> pt;
     const int units = B * tps;
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
         const int b = u / tps, r = u - b * tps;
         const int y0 = (r / tx_n) << 3, x0 = (r - (r / tx_n) * tx_n) << 4;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));      // staging index arithmetic is redone per unit, not hoisted into ~100 registers
         stage_coef(S, s_cfS, ncs, cs0, CS, b, tid);
         stage_coef(T, s_cfT, nct, ct0, CTphys, b, tid);
         __syncthreads();
-        // S tile: 64 channels x 8 rows x 16 columns as float4, all loads in flight before the first use
+        // T tile with halo (all of its loads in flight together), then the S tile in two halves
+        pt.issue(T, true, b, ct0, CT, CTphys, G::S * y0 - G::R, G::S * x0, Ht, Wt, tid);
+        pt.commit(T, s_cfT, s_T, CTphys, Ht, Wt, tid);
+        // S tile: 64 channels x 8 rows x 16 columns as float4
         const long long sample = (long long)b * CS * Hs * Ws;
         const int smode = S.mode;
+        constexpr int SB = KK == 3 ? 2 : 4;        // float4 per thread in flight (register budget: 2 workgroups per CU)
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            f32x4 sv[4], su[4];
+        for (int part = 0; part < 8 / SB; ++part) {
+            f32x4 sv[SB], su[SB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = (half * 4 + j) * 256 + tid, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
+            for (int j = 0; j < SB; ++j) {
+                const int idx = (part * SB + j) * 256 + tid, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
                 const int off = cl < ncs ? ((cs0 + cl) * Hs + y0 + rr) * Ws + x0 + c4 * 4 : 0;
                 sv[j] = *reinterpret_cast<const f32x4 *>(S.p0 + sample + off);
                 if (smode == DM_LOAD_AFFINE2) su[j] = *reinterpret_cast<const f32x4 *>(S.p1 + sample + off);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = (half * 4 + j) * 256 + tid, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
+            for (int j = 0; j < SB; ++j) {
+                const int idx = (part * SB + j) * 256 + tid, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
                 f32x4 v = sv[j];
                 if (smode == DM_LOAD_RELU) {
                     v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
@@ -586,22 +616,28 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
                 dst[1] = (f32x2){v.z, v.w};
             }
         }
-        // T tile with halo
-        stage_window<G::ROWS, G::LCOLS, G::COLS, G::CTS, KK == 4>(T, s_cfT, s_T, nct, ct0, CT, CTphys, b, G::S * y0 - G::R,
-                                                                 G::S * x0 - G::R, Ht, Wt, tid);
         __syncthreads();
+        // K = the 128 pixels: 8 rows x 4 steps of 4 columns.  Inside a row every LDS address is tb[nt] + constant.
+        const float *sp = s_S + (wave * 16 + p) * WG_CSS + kq;
 #pragma unroll 1
-        for (int ks = 0; ks < 32; ++ks) {
-            const float av = s_S[(wave * 16 + p) * WG_CSS + ks * 4 + kq];
-            const int po = (ks >> 2) * G::ROWSTEP + (ks & 3) * 4 + kq;
-            float bv[G::NTW];
+        for (int row = 0; row < 8; ++row) {
 #pragma unroll
-            for (int nt = 0; nt < G::NTW; ++nt)
-                if (nt < ntw) bv[nt] = s_T[boff[nt] + po];
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float av = sp[row * 16 + k4 * 4];
+                float bv[G::NTW];
 #pragma unroll
-            for (int nt = 0; nt < G::NTW; ++nt)
-                if (nt < ntw) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < G::NTW; ++nt)
+                    if (nt < ntw) bv[nt] = s_T[tb[nt] + k4 * 4];
+#pragma unroll
+                for (int nt = 0; nt < G::NTW; ++nt)
+                    if (nt < ntw) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);          // keep the four steps' LDS reads from all moving to the top
+            }
+#pragma unroll
+            for (int nt = 0; nt < G::NTW; ++nt) tb[nt] += G::ROWSTEP;
         }
+#pragma unroll
+        for (int nt = 0; nt < G::NTW; ++nt) tb[nt] -= 8 * G::ROWSTEP;
     }
 
     // lane holds R[cs = cs0 + 16*wave + 4*kq + j][n = 16*nt + p]
