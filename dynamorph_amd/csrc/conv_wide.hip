@@ -13,6 +13,7 @@
 // the fp32 MFMA (v_mfma_f32_16x16x4_f32) keeps full precision.  LDS strides are chosen so that the 4 x 16 lane groups
 // of an MFMA operand read fall into distinct banks (channel stride = 16 mod 64 floats for conv, 4 mod 64 for wgrad).
 #include "dm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -661,8 +662,15 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
 
 // ---- entry points used by the dispatchers in conv_mfma.hip / wgrad_mfma.hip (not part of the public header) ----------
 // base grid (output pixels for the strided / plain forms, input pixels for the transposed form) must tile by 8 x 16
+static int wide_disabled()
+{
+    static const int v = getenv("DM_NO_WIDE") ? atoi(getenv("DM_NO_WIDE")) : 0;       // debugging aid: 1 conv, 2 wgrad, 3 both
+    return v;
+}
+
 bool dm_wide_conv_ok(int form, int H, int W)
 {
+    if ((wide_disabled() & 1) || (wide_disabled() & (4 << form))) return false;       // 4 / 8 / 16: one form only
     const int BH = form == W_S2 ? H / 2 : H, BW = form == W_S2 ? W / 2 : W;
     return BH > 0 && BW > 0 && BH % 8 == 0 && BW % 16 == 0 && (form != W_S2 || (H % 2 == 0 && W % 2 == 0));
 }
@@ -719,10 +727,18 @@ int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scrat
     const int np = wide_npw(form, NOUT);
     const int passes = (NOUT + 16 * np - 1) / (16 * np), nchunks = (CIN + WKC - 1) / WKC;
     const dim3 grid((unsigned)gx, (unsigned)passes), pgrid((unsigned)nchunks, (unsigned)passes);
+    // persistent grid = what is resident at once (workgroups per CU by registers / LDS x 256 CUs): with more, the late
+    // starters run on a half-empty machine
 #define DM_WL(F, TP, NP_)                                                                                           \
     {                                                                                                               \
+        static int occ = 0;                                                                                         \
+        if (!occ && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wide_kernel<F, TP, NP_>, 256, 0) != hipSuccess) \
+            occ = 2;                                                                                                \
+        const unsigned cap = (unsigned)(occ > 0 ? occ : 1) * 256u;                                                  \
+        dim3 grid2 = grid;                                                                                          \
+        if (grid2.x * grid2.y > cap) grid2.x = cap / grid2.y > 0 ? cap / grid2.y : 1;                               \
         hipLaunchKernelGGL((wide_pack_kernel<F, TP, NP_>), pgrid, dim3(256), 0, st, wv, scratch, CIN, NOUT);        \
-        hipLaunchKernelGGL((conv_wide_kernel<F, TP, NP_>), grid, dim3(256), 0, st, in, (const float *)scratch, out, ep, B,   \
+        hipLaunchKernelGGL((conv_wide_kernel<F, TP, NP_>), grid2, dim3(256), 0, st, in, (const float *)scratch, out, ep, B,  \
                            Cphys, CIN, NOUT, H, W, nslabs, per_tile);                                               \
     }
     DM_WIDE_SWITCH(DM_WL)
@@ -730,7 +746,7 @@ int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scrat
     return 0;
 }
 
-bool dm_wide_wgrad_ok(int Hs, int Ws) { return Hs > 0 && Ws > 0 && Hs % 8 == 0 && Ws % 16 == 0; }
+bool dm_wide_wgrad_ok(int Hs, int Ws) { return !(wide_disabled() & 2) && Hs > 0 && Ws > 0 && Hs % 8 == 0 && Ws % 16 == 0; }
 
 static void wide_wgrad_grid(int CS, int CT, int k, int &gy, int &gz, int &cap)
 {

@@ -113,6 +113,17 @@ def test_vq_backward_golden(ops, golden):
 
 
 # ========================================================================== convolutions
+def close_stats(st, out, q=None, what="stats"):
+    """Statistics slabs against double sums of the reference output, tolerance relative to the sum of magnitudes
+    (a loose absolute tolerance hides a dropped row)."""
+    q = out if q is None else q
+    ref = _stats_ref(out, q)
+    mag = torch.stack([out.double().abs().sum((0, 2, 3)), (out.double() * q.double()).abs().sum((0, 2, 3))], 1)
+    err = (st.detach().cpu().double() - ref).abs()
+    bad = err > 3e-5 * mag + 1e-9
+    assert not bad.any(), f"{what}: {int(bad.sum())} sums off, worst {float((err / (mag + 1e-30)).max()):.2e} of the magnitude sum"
+
+
 def _stats_ref(out, q=None):
     q = out if q is None else q
     return torch.stack([out.double().sum((0, 2, 3)), (out.double() * q.double()).sum((0, 2, 3))], 1)
@@ -319,9 +330,9 @@ def test_wide_conv4x4s2(ops, B, cin, nout, h, w, mode, ones, per_tile):
         assert st.shape[0] % B == 0
         per = st.reshape(B, -1, nout, 2).sum(1)
         for b in range(B):
-            close(per[b], _stats_ref(ref[b:b + 1]), 1e-5, 1e-3, f"per-sample stats {b}")
+            close_stats(per[b], ref[b:b + 1], None, f"per-sample stats {b}")
     else:
-        close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+        close_stats(st.sum(0), ref)
 
 
 def test_wide_conv4x4s2_border_bias(ops):
@@ -341,7 +352,8 @@ def test_wide_conv4x4s2_border_bias(ops):
 @pytest.mark.parametrize("B,cin,nout,h,w,taps,per_tile", [(2, 64, 64, 16, 16, 9, False), (3, 64, 64, 32, 32, 9, False),
                                                           (2, 64, 64, 16, 16, 1, False), (3, 128, 40, 8, 32, 1, False),
                                                           (2, 48, 136, 16, 16, 9, False), (4, 64, 64, 16, 16, 9, True),
-                                                          (70, 64, 32, 16, 16, 9, False)])
+                                                          (70, 64, 32, 16, 16, 9, False), (2, 16, 128, 16, 16, 9, False),
+                                                          (2, 16, 128, 16, 16, 1, False)])
 def test_wide_conv3x3(ops, B, cin, nout, h, w, taps, per_tile):
     x = rnd(B, cin, h, w, seed=1)
     k = 3 if taps == 9 else 1
@@ -357,20 +369,29 @@ def test_wide_conv3x3(ops, B, cin, nout, h, w, taps, per_tile):
     if per_tile:
         per = st.reshape(B, -1, nout, 2).sum(1)
         for b in range(B):
-            close(per[b], _stats_ref(ref[b:b + 1], act[b:b + 1]), 1e-5, 1e-3, f"per-sample stats {b}")
+            close_stats(per[b], ref[b:b + 1], act[b:b + 1], f"per-sample stats {b}")
     else:
-        close(st.sum(0), _stats_ref(ref, act), 1e-5, 1e-3, "stats q")
+        close_stats(st.sum(0), ref, act, "stats q")
 
 
-def test_wide_conv3x3_flipped_view(ops):
-    """data gradient of a 3x3 convolution: the same kernel through a transposed, flipped weight view."""
-    B, ci, co, hw = 2, 64, 48, 16
-    g = rnd(B, co, hw, hw, seed=1)
-    wt = rnd(co, ci, 3, 3, seed=2, scale=0.1)
+@pytest.mark.parametrize("B,ci,co,hw,taps", [(2, 64, 48, 16, 9), (2, 128, 16, 16, 9), (2, 16, 128, 16, 1), (3, 128, 16, 16, 1)])
+def test_wide_conv_data_gradient_with_bn_backward_operand(ops, B, ci, co, hw, taps):
+    """Data gradient of a 3x3 / 1x1 convolution as the encoder backward pass calls it: input = BatchNorm backward
+    folded into the load (AFFINE2), transposed (and for 3x3 flipped) weight view, ReLU gate, residual, statistics."""
+    k = 3 if taps == 9 else 1
+    dy, a = rnd(B, co, hw, hw, seed=1), rnd(B, co, hw, hw, seed=2)
+    coef = torch.stack([rnd(co, seed=3), rnd(co, seed=4) * 0.1, rnd(co, seed=5) * 0.1, torch.zeros(co)], 1)
+    g = load_ref(dy, 4, coef, a)
+    wt = rnd(co, ci, k, k, seed=6, scale=0.1)
     x = torch.zeros(B, ci, hw, hw, requires_grad=True)
-    F.conv2d(x, wt, None, padding=1).backward(g)
-    out, _ = ops.conv3x3(ops.Op(g.to(DEV)), ops.weight_view(wt.to(DEV), 9, ci * 9, -3, -1, off=8), B, co, ci, hw, hw, taps=9)
-    close(out, x.grad, 5e-5, 5e-5, "wide conv3x3 data gradient")
+    F.conv2d(x, wt, None, padding=k // 2).backward(g)
+    gate, resid, q = rnd(B, ci, hw, hw, seed=7), rnd(B, ci, hw, hw, seed=8), rnd(B, ci, hw, hw, seed=9)
+    ref = x.grad * (gate > 0) + resid
+    wv = ops.weight_view(wt.to(DEV), 9, ci * 9, -3, -1, off=8) if taps == 9 else ops.weight_view(wt.to(DEV), 1, ci, 0, 0)
+    out, st = ops.conv3x3(ops.Op(dy.to(DEV), 4, coef.to(DEV), p1=a.to(DEV)), wv, B, co, ci, hw, hw, taps=taps, want_stats=True,
+                          mask=ops.Op(gate.to(DEV)), resid=resid.to(DEV), stat_q=q.to(DEV))
+    close(out, ref, 5e-5, 5e-5, "data gradient")
+    close_stats(st.sum(0), ref, q)
 
 
 @pytest.mark.parametrize("B,ci,co,h,w", [(2, 64, 32, 16, 16), (2, 32, 2, 64, 64), (3, 64, 64, 8, 16), (2, 32, 16, 32, 32),
@@ -385,7 +406,7 @@ def test_wide_conv_transpose(ops, B, ci, co, h, w):
                           taps=9, pixel_shuffle=True, want_stats=True, bias=bias.to(DEV), relu=True, mask=ops.Op(act.to(DEV)),
                           stat_q=act.to(DEV))
     close(out, ref, 5e-5, 5e-5, "wide conv transpose")
-    close(st.sum(0), _stats_ref(ref, act), 1e-5, 1e-3, "stats")
+    close_stats(st.sum(0), ref, act)
 
 
 @pytest.mark.parametrize("B,cs,ct,k,hs,ws,ones", [(3, 64, 64, 3, 16, 16, False), (3, 64, 64, 1, 16, 16, False),
