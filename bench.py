@@ -35,8 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 2048 for c3, 1024 for c2)")
+    ap.add_argument("--workload", choices=["c3", "c2", "z32ex"], default="c3")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 2048 for c3, 1024 for c2, 256 for z32ex)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -69,6 +69,31 @@ def pmc_traffic(kernel_key, batch):
     if not rec or rec.get("batch") != batch:
         return None
     return rec.get("hbm_bytes_per_launch")
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # 256 CUs x 256 FLOP/clk (v_mfma_f32_16x16x4_f32) x 2.4 GHz, MI355X_MICROARCH.md
+
+EXAMPLE_CONFIG = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)     # config_example.yml:157-163
+
+
+def roofline_wide_conv(B):
+    """z32ex: the 3x3 64 -> 64 convolution of the residual blocks on the 32 x 32 latent (conv_wide_kernel<1, 9, 4>, the
+    largest share of that step), alone, timed with events.  MFMA bound: achieved = 2*P*64*64*9 FLOP / duration."""
+    from dynamorph_amd import ops
+    C, HW = 64, 32
+    x = torch.randn(B, C, HW, HW, device="cuda")
+    w = torch.randn(C, C, 3, 3, device="cuda") * 0.05
+    out = torch.empty(B, C, HW, HW, device="cuda")
+    wv = ops.weight_view(w, C * 9, 9, 3, 1)
+
+    def fn():
+        ops.conv3x3(ops.Op(x, 1), wv, B, C, C, HW, HW, taps=9, out=out, want_stats=True)
+    ms = event_time_ms(fn)
+    flops = 2.0 * B * HW * HW * C * C * 9
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "wide_pack_kernel + conv_wide_kernel<1, 9, 4> (residual 3x3, 64 -> 64 channels, 32 x 32)", "bound": "mfma",
+            "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops}
 
 
 def roofline_dominant_kernel(model, x, workload):
@@ -124,9 +149,18 @@ def cpu_baseline(workload, budget_s=15.0):
     """The CPU oracle on a bounded sample of the same workload (train step / latents on 64-patch batches)."""
     from oracle import vqvae_oracle as O
     torch.manual_seed(0)
-    ref = O.OracleVQVAE()
-    x = torch.randn(64, 2, 128, 128, generator=torch.Generator().manual_seed(1234))
-    if workload == "c3":
+    nb = 16 if workload == "z32ex" else 64
+    ref = O.OracleVQVAEz32(**EXAMPLE_CONFIG) if workload == "z32ex" else O.OracleVQVAE()
+    x = torch.randn(nb, 2, 128, 128, generator=torch.Generator().manual_seed(1234))
+    if workload == "z32ex":
+        opt = O.make_adam(ref, 1e-4)
+
+        def one():
+            opt.zero_grad()
+            ref(x)[1]["total_loss"].backward()
+            opt.step()
+        sample = "VQ_VAE_z32 (64/64/512) training step on batches of 16 patches, PyTorch CPU fp32"
+    elif workload == "c3":
         opt = O.make_adam(ref, 1e-4)
 
         def one():
@@ -145,7 +179,7 @@ def cpu_baseline(workload, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 40:
             break
-    return {"value": round(64 * n / el, 1), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(nb * n / el, 1), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} x {sample}; {os.cpu_count()} logical CPUs on host"}
 
 
@@ -162,13 +196,32 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B = args.batch or (2048 if args.workload == "c3" else 1024)
+    B = args.batch or {"c3": 2048, "c2": 1024, "z32ex": 256}[args.workload]
 
     torch.manual_seed(0)
-    model = VQ_VAE().to(dev)
     x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    if args.workload == "z32ex":
+        # the variant and widths the reference's example configuration trains; the
+        # run_training.py loop as it is (autograd + torch.optim.Adam), every conv on the implicit-GEMM kernels
+        if world != 1:
+            raise SystemExit("--workload z32ex is a single-GPU measurement")
+        from dynamorph_amd import VQ_VAE_z32
+        model = VQ_VAE_z32(**EXAMPLE_CONFIG).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
-    if args.workload == "c3":
+        def step():
+            _, ld = model(x)
+            ld["total_loss"].backward()
+            opt.step()
+            model.zero_grad()
+            return torch.stack([ld["recon_loss"].detach(), ld["commitment_loss"].detach(), ld["total_loss"].detach(),
+                                ld["perplexity"].detach()])
+    else:
+        model = VQ_VAE().to(dev)
+
+    if args.workload == "z32ex":
+        pass
+    elif args.workload == "c3":
         trainer = FusedTrainer(model, lr=1e-4, use_graph=not args.no_graph)
 
         def step():
@@ -198,18 +251,24 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device=dev)
 
-    losses = out.tolist() if args.workload == "c3" else None
-    roof = None if args.no_roofline or rank != 0 else roofline_dominant_kernel(model, x, args.workload)
+    losses = out.tolist() if args.workload in ("c3", "z32ex") else None
+    if args.no_roofline or rank != 0:
+        roof = None
+    elif args.workload == "z32ex":
+        roof = roofline_wide_conv(B)
+    else:
+        roof = roofline_dominant_kernel(model, x, args.workload)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload)
 
     if rank == 0:
-        wl = ("C3: VQ_VAE training step (forward + backward + fused Adam), 2x128x128 fp32 synthetic patches"
-              if args.workload == "c3" else
-              "C2: VQ_VAE inference latents (enc + vq, per-sample BatchNorm statistics = process_VAE), 2x128x128 fp32")
+        wl = {"c3": "C3: VQ_VAE training step (forward + backward + fused Adam), 2x128x128 fp32 synthetic patches",
+              "c2": "C2: VQ_VAE inference latents (enc + vq, per-sample BatchNorm statistics = process_VAE), 2x128x128 fp32",
+              "z32ex": "VQ_VAE_z32 with the reference's example widths (num_hiddens 64, num_residual_hiddens 64, 512 codes): "
+                       "training step (forward + backward + torch Adam), 2x128x128 fp32 synthetic patches"}[args.workload]
         line = {
-            "metric": "cell-patches/sec (128x128x2) VQ-VAE " + ("fwd+bwd" if args.workload == "c3" else "latent encoding"),
+            "metric": "cell-patches/sec (128x128x2) VQ-VAE " + ("latent encoding" if args.workload == "c2" else "fwd+bwd"),
             "value": round(world * B * args.steps / elapsed, 1),
             "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
