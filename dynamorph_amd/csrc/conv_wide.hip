@@ -14,6 +14,7 @@
 // of an MFMA operand read fall into distinct banks (channel stride = 16 mod 64 floats for conv, 4 mod 64 for wgrad).
 #include "dm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -179,74 +180,101 @@ struct RowPrefetch {
     // live == false (no next chunk): empty descriptors, every load returns 0 without touching memory.  The call itself must
     // stay unconditional: loads under a branch make hipcc merge the two paths with register copies behind s_waitcnt vmcnt(0),
     // i.e. wait for the prefetch right where it was issued.
-    __device__ __forceinline__ void issue(const Operand &op, bool live, int b_, int c0_, int CIN, int Cphys, int gy0_, int gxi_,
-                                          int H, int W, int tid)
+    // begin() fixes the chunk and its descriptors, slot(k) requests one float4 unit (k < J4) or one halo scalar: the
+    // kernel spreads the slots over its MFMA steps.  A CU keeps only so many bytes in flight; a wave that issues a whole
+    // chunk in one burst stalls at the issue point, in front of its MFMAs, until earlier requests return.
+    __amdgpu_buffer_rsrc_t r0, r1;
+    int CINl, Cph, Hh, Ww;
+    static constexpr int NSLOT = J4 + JH;
+    __device__ __forceinline__ void begin(const Operand &op, bool live, int b_, int c0_, int CIN, int Cphys, int gy0_, int gxi_,
+                                          int H, int W)
     {
-        b = b_; c0 = c0_; gy0 = gy0_; gxi = gxi_;
+        b = b_; c0 = c0_; gy0 = gy0_; gxi = gxi_; CINl = CIN; Cph = Cphys; Hh = H; Ww = W;
         const long long se = (long long)Cphys * H * W;
         const int bytes = live ? (int)(se * 4) : 0;
-        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(op.p0 + se * b), 0, bytes, 0x00020000);
+        r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(op.p0 + se * b), 0, bytes, 0x00020000);
         const bool two = P1 && op.mode == DM_LOAD_AFFINE2;
-        const __amdgpu_buffer_rsrc_t r1 =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((two ? op.p1 : op.p0) + se * b), 0, two ? bytes : 0, 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((two ? op.p1 : op.p0) + se * b), 0, two ? bytes : 0, 0x00020000);
         phys_mask = 0; ones_mask = 0;
-#pragma unroll
-        for (int j = 0; j < J4; ++j) {
+    }
+    template <int K>
+    __device__ __forceinline__ void slot(int tid)
+    {
+        if constexpr (K < J4) {
+            constexpr int j = K;
             const int unit = j * 256 + tid, row = unit / G::QW, q = unit - row * G::QW;
             const int c = row / G::ROWS, iy = row - c * G::ROWS, chn = c0 + c, gy = gy0 + iy;
-            const bool inimg = unit < NU4 && chn < CIN && (unsigned)gy < (unsigned)H;
-            const bool phys = inimg && chn < Cphys;
+            const bool inimg = unit < NU4 && chn < CINl && (unsigned)gy < (unsigned)Hh;
+            const bool phys = inimg && chn < Cph;
             phys_mask |= phys ? 1u << j : 0u;
             ones_mask |= (inimg && !phys) ? 1u << j : 0u;
-            const int voff = phys ? ((chn * H + gy) * W + gxi + 4 * q) * 4 : 0x7ffffff0;
+            const int voff = phys ? ((chn * Hh + gy) * Ww + gxi + 4 * q) * 4 : 0x7ffffff0;
             v[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, voff, 0, 0);
             if (P1) u[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < JH; ++j) {
+        } else if constexpr (K < NSLOT) {
+            constexpr int j = K - J4;
             const int unit = j * 256 + tid, row = unit >> 1, side = unit & 1;
             const int c = row / G::ROWS, iy = row - c * G::ROWS, chn = c0 + c, gy = gy0 + iy;
             const int gx = side ? gxi + 4 * G::QW : gxi - 1;
-            const bool inimg = unit < NH && chn < CIN && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const bool phys = inimg && chn < Cphys;
+            const bool inimg = unit < NH && chn < CINl && (unsigned)gy < (unsigned)Hh && (unsigned)gx < (unsigned)Ww;
+            const bool phys = inimg && chn < Cph;
             phys_mask |= phys ? 1u << (16 + j) : 0u;
             ones_mask |= (inimg && !phys) ? 1u << (16 + j) : 0u;
-            const int voff = phys ? ((chn * H + gy) * W + gx) * 4 : 0x7ffffff0;
+            const int voff = phys ? ((chn * Hh + gy) * Ww + gx) * 4 : 0x7ffffff0;
             hv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, voff, 0, 0));
             if (P1) hu[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, voff, 0, 0));
         }
     }
-
-    __device__ __forceinline__ float xform(const Operand &op, const float *cf, float x, float uu) const
+    template <int K = 0>
+    __device__ __forceinline__ void slots_all(int tid)
     {
-        const int mode = op.mode;
-        if (mode == DM_LOAD_RELU) return x < 0.f ? 0.f : x;
-        if (mode == DM_LOAD_AFFINE2) return cf[0] * x + (cf[1] * uu + cf[2]);
-        if (mode >= DM_LOAD_AFFINE) {
-            x = cf[0] * x + cf[2];
-            if (mode == DM_LOAD_AFFINE_RELU) x = x < 0.f ? 0.f : x;
-        }
-        return x;
+        if constexpr (K < NSLOT) { slot<K>(tid); slots_all<K + 1>(tid); }
     }
+    // live == false (no next chunk): empty descriptors, every load returns 0 without touching memory.  The calls themselves
+    // must stay unconditional: loads under a branch make hipcc merge the two paths with register copies behind
+    // s_waitcnt vmcnt(0), i.e. wait for the prefetch right where it was issued.
+    __device__ __forceinline__ void issue(const Operand &op, bool live, int b_, int c0_, int CIN, int Cphys, int gy0_, int gxi_,
+                                          int H, int W, int tid)
+    {
+        begin(op, live, b_, c0_, CIN, Cphys, gy0_, gxi_, H, W);
+        slots_all<0>(tid);
+    }
+
+    // Operand transform without control flow: the mode is uniform, so every choice is a v_cndmask on a scalar condition.
+    // (As nested ifs per element hipcc produced ~30 basic blocks per float4, each with its own s_waitcnt: the commit of
+    //  3 units per thread cost as much as the chunk's 144 MFMAs.)
+    struct Xf {
+        bool aff, two, relu;
+        __device__ __forceinline__ float one(float x, float uu, float c0, float c1, float c2) const
+        {
+            const float t = two ? c1 * uu + c2 : c2;
+            const float y = c0 * x + t;
+            x = aff ? y : x;
+            const float lo = relu ? 0.f : -__builtin_inff();
+            return x < lo ? lo : x;                       // a NaN stays NaN
+        }
+    };
 
     __device__ __forceinline__ void commit(const Operand &op, const float *s_cf, float *s_dst, int Cphys, int H, int W, int tid) const
     {
-        const bool slow_p1 = !P1 && op.mode == DM_LOAD_AFFINE2;
+        const int mode = op.mode;
+        const Xf xf{mode >= DM_LOAD_AFFINE, mode == DM_LOAD_AFFINE2, mode == DM_LOAD_RELU || mode == DM_LOAD_AFFINE_RELU};
+        const bool slow_p1 = !P1 && mode == DM_LOAD_AFFINE2;
 #pragma unroll
         for (int j = 0; j < J4; ++j) {
             const int unit = j * 256 + tid, row = unit / G::QW, q = unit - row * G::QW;
             if (unit >= NU4) continue;
             const int c = row / G::ROWS, iy = row - c * G::ROWS;
             f32x4 x = v[j];
-            if ((phys_mask >> j) & 1) {
-                f32x4 uu = P1 ? u[j] : x;
-                if (slow_p1) uu = *reinterpret_cast<const f32x4 *>(op.p1 + (((long long)b * Cphys + c0 + c) * H + gy0 + iy) * W + gxi + 4 * q);
-                const float *cf = s_cf + c * 4;
-                x = (f32x4){xform(op, cf, x.x, uu.x), xform(op, cf, x.y, uu.y), xform(op, cf, x.z, uu.z), xform(op, cf, x.w, uu.w)};
-            } else {
-                const float f = (ones_mask >> j) & 1 ? 1.f : 0.f;
-                x = (f32x4){f, f, f, f};
-            }
+            f32x4 uu = P1 ? u[j] : x;
+            if (slow_p1 && ((phys_mask >> j) & 1))
+                uu = *reinterpret_cast<const f32x4 *>(op.p1 + (((long long)b * Cphys + c0 + c) * H + gy0 + iy) * W + gxi + 4 * q);
+            float k0 = 1.f, k1 = 0.f, k2 = 0.f;
+            if (xf.aff) { k0 = s_cf[c * 4]; k1 = s_cf[c * 4 + 1]; k2 = s_cf[c * 4 + 2]; }
+            x = (f32x4){xf.one(x.x, uu.x, k0, k1, k2), xf.one(x.y, uu.y, k0, k1, k2), xf.one(x.z, uu.z, k0, k1, k2),
+                        xf.one(x.w, uu.w, k0, k1, k2)};
+            const float f = (ones_mask >> j) & 1 ? 1.f : 0.f;
+            if (!((phys_mask >> j) & 1)) x = (f32x4){f, f, f, f};
             if (G::PLANES) {
                 float *base = s_dst + c * G::CHS + iy * G::RS + 2 * q;
                 *reinterpret_cast<f32x2 *>(base + G::PLS) = (f32x2){x.x, x.z};      // odd window columns 1+4q, 3+4q
@@ -261,13 +289,13 @@ struct RowPrefetch {
             if (unit >= NH) continue;
             const int c = row / G::ROWS, iy = row - c * G::ROWS;
             float x = hv[j];
-            if ((phys_mask >> (16 + j)) & 1) {
-                float uu = P1 ? hu[j] : x;
-                if (slow_p1) uu = op.p1[(((long long)b * Cphys + c0 + c) * H + gy0 + iy) * W + (side ? gxi + 4 * G::QW : gxi - 1)];
-                x = xform(op, s_cf + c * 4, x, uu);
-            } else {
-                x = (ones_mask >> (16 + j)) & 1 ? 1.f : 0.f;
-            }
+            float uu = P1 ? hu[j] : x;
+            if (slow_p1 && ((phys_mask >> (16 + j)) & 1))
+                uu = op.p1[(((long long)b * Cphys + c0 + c) * H + gy0 + iy) * W + (side ? gxi + 4 * G::QW : gxi - 1)];
+            float k0 = 1.f, k1 = 0.f, k2 = 0.f;
+            if (xf.aff) { k0 = s_cf[c * 4]; k1 = s_cf[c * 4 + 1]; k2 = s_cf[c * 4 + 2]; }
+            x = xf.one(x, uu, k0, k1, k2);
+            if (!((phys_mask >> (16 + j)) & 1)) x = (ones_mask >> (16 + j)) & 1 ? 1.f : 0.f;
             int a;
             if (G::PLANES) a = c * G::CHS + iy * G::RS + (side ? G::PLS + 16 : 1);
             else a = c * G::CHS + iy * G::RS + (side ? G::OFFC + 16 : G::OFFC - 1);
@@ -319,20 +347,38 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
         f32x4 pw[JW];
         int par = 0;
 
-        // chunk (tile, ch) -> registers: input rows, the packed weight block, coefficient rows (double-buffered in LDS)
-        auto issue = [&](int tile, int ch, bool live) {
+        // chunk (tile, ch) -> registers: input rows, the packed weight block, coefficient rows (double-buffered in LDS).
+        // issue_begin fixes the chunk; issue_slot<K> requests one piece (input unit, halo scalar or weight float4).
+        constexpr int NSLOT = decltype(pin)::NSLOT + JW;
+        __amdgpu_buffer_rsrc_t wr;
+        int wbase = 0;
+        auto issue_begin = [&](int tile, int ch, bool live) {
             const int b = tile / tps, r = tile - b * tps;
             const int y0 = (r / tx_n) << 3, x0 = (r - (r / tx_n) * tx_n) << 4;
             const int c0 = ch * WKC;
             par ^= 1;
             stage_coef(in, s_cf[par], WKC, c0, Cphys, b, tid);
-            pin.issue(in, live, b, c0, CIN, Cphys, G::S * y0 - G::R, G::S * x0, H, W, tid);
-            const __amdgpu_buffer_rsrc_t wr = live ? wr_live : wr_dead;
-#pragma unroll
-            for (int j = 0; j < JW; ++j) {
+            pin.begin(in, live, b, c0, CIN, Cphys, G::S * y0 - G::R, G::S * x0, H, W);
+            wr = live ? wr_live : wr_dead;
+            wbase = ch * P::BLK;
+        };
+        auto issue_slot = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (K < decltype(pin)::NSLOT) {
+                pin.template slot<K>(tid);
+            } else if constexpr (K < NSLOT) {
+                constexpr int j = K - decltype(pin)::NSLOT;
                 const int idx = j * 256 + tid;
-                pw[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, idx < P::BLK / 4 ? (ch * P::BLK + idx * 4) * 4 : 0x7ffffff0, 0, 0);
+                pw[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, idx < P::BLK / 4 ? (wbase + idx * 4) * 4 : 0x7ffffff0, 0, 0);
             }
+        };
+        auto issue_all = [&](auto self, auto kc) -> void {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (K < NSLOT) { issue_slot(kc); self(self, std::integral_constant<int, K + 1>{}); }
+        };
+        auto issue = [&](int tile, int ch, bool live) {
+            issue_begin(tile, ch, live);
+            issue_all(issue_all, std::integral_constant<int, 0>{});
         };
         auto commit = [&]() {
             pin.commit(in, s_cf[par], s_in, Cphys, H, W, tid);
@@ -357,17 +403,17 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                 __syncthreads();                 // the previous chunk's MFMAs are done with s_in / s_w
                 commit();
                 __syncthreads();
-                // next chunk's loads fly during this chunk's MFMAs (and, across tiles, during the epilogue)
+                // next chunk's loads fly during this chunk's MFMAs (and, across tiles, during the epilogue); they are
+                // requested a few at a time between the MFMA steps
                 {
                     const bool wrap = ch + 1 == nchunks;
                     const int ntile = wrap ? tile + t_step : tile;
                     const bool live = ntile < t_end;
-                    issue(live ? ntile : tile, wrap ? 0 : ch + 1, live);
+                    issue_begin(live ? ntile : tile, wrap ? 0 : ch + 1, live);
                 }
                 // ---- MFMAs: wave owns base rows 2*wave, 2*wave+1.  K steps of 4 channels: step = 2*tap + channel quad.
                 // The LDS operands of step s+1 are requested before the MFMAs of step s are issued (two register sets),
-                // otherwise every group of MFMAs starts by waiting out an LDS round trip.  Not unrolled further: a fully
-                // unrolled loop hoists every LDS read to the top and spills.
+                // otherwise every group of MFMAs starts by waiting out an LDS round trip.
                 auto lds_step = [&](int step, float (&av)[2], float (&bv)[NPW]) {
                     const int tap = step >> 1, cq = step & 1;
                     int toff;
@@ -392,20 +438,34 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                             acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
                 };
                 static_assert(WKC == 8, "two channel quads per tap");
-                constexpr int NSTEP = 2 * G::T;
+                constexpr int NSTEP = 2 * G::T, NIT = G::T;
+                constexpr int SPI = (NSLOT + NIT - 1) / NIT;          // load slots per iteration
                 float a0[2], b0[NPW], a1[2], b1[NPW];
                 lds_step(0, a0, b0);
-#pragma unroll 1
-                for (int step = 0; step < NSTEP; step += 2) {
-                    lds_step(step + 1, a1, b1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_step(a0, b0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    lds_step(step + 2 < NSTEP ? step + 2 : step, a0, b0);       // last round: a harmless re-read
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_step(a1, b1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                auto round = [&](auto self, auto itc) -> void {
+                    constexpr int IT = decltype(itc)::value;
+                    if constexpr (IT < NIT) {
+                        constexpr int step = 2 * IT;
+                        lds_step(step + 1, a1, b1);
+                        auto slots = [&](auto self2, auto kc) -> void {
+                            constexpr int K = decltype(kc)::value;
+                            if constexpr (K < SPI) {
+                                issue_slot(std::integral_constant<int, IT * SPI + K>{});
+                                self2(self2, std::integral_constant<int, K + 1>{});
+                            }
+                        };
+                        slots(slots, std::integral_constant<int, 0>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_step(a0, b0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds_step(step + 2 < NSTEP ? step + 2 : step, a0, b0);       // last round: a harmless re-read
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_step(a1, b1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        self(self, std::integral_constant<int, IT + 1>{});
+                    }
+                };
+                round(round, std::integral_constant<int, 0>{});
             }
 
             // ---- epilogue: lane holds pixels (row 2*wave+i, columns 4*kq .. 4*kq+3) of channel n0 + 16*t + p
@@ -684,8 +744,9 @@ int dm_wide_conv_slabs(int form, int B, int H, int W, int per_tile)
 }
 
 // output channels per pass / 16: wider passes put the accumulators plus the prefetch registers past 256
-// (the stride-2 form stages 2.5x as much input per chunk: 32 channels per pass there)
-static int wide_npw(int form, int NOUT) { return NOUT <= 16 ? 1 : ((NOUT <= 32 || form == W_S2) ? 2 : 4); }
+// (the stride-2 form stages 2.5x as much input per chunk and the transposed form's unrolled loop is register-hungry:
+//  32 channels per pass there)
+static int wide_npw(int form, int NOUT) { return NOUT <= 16 ? 1 : ((NOUT <= 32 || form != W_S1) ? 2 : 4); }
 
 template <int FORM, int TAPS, int NPW>
 static long long wide_scratch_floats_t(int CIN, int NOUT)
