@@ -202,6 +202,29 @@ def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, t
     return model, train_loss
 
 
+def get_relation_tensor(relation_mat, sample_ids, device='cuda:0'):
+    """run_training.py:335-355: the (B, B) block of the symmetric sample-relation matrix (scipy sparse or dense) for
+    this batch as a float32 tensor -- the `time_matching_mat` argument of VQ_VAE.forward."""
+    if relation_mat is None:
+        return None
+    block = relation_mat[sample_ids, :][:, sample_ids]
+    if hasattr(block, "todense"):
+        block = block.todense()
+    out = torch.from_numpy(np.ascontiguousarray(np.asarray(block), dtype=np.float32))
+    return out.to(device) if device else out
+
+
+def get_mask(mask, sample_ids, device='cuda:0'):
+    """run_training.py:358-374: cell masks of this batch.  `mask` is a TensorDataset-like object whose first tensor is
+    (N, 2, H, W) in {-1, 1}; the second channel (the large mask) is kept and mapped to {0, 1} -> (B, 1, H, W), the
+    `batch_mask` argument of VQ_VAE.forward."""
+    if mask is None:
+        return None
+    m = mask[sample_ids][0][:, 1:2, :, :]
+    m = (m + 1.) / 2.
+    return m.to(device)
+
+
 def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10, lr=0.001, batch_size=16,
           device='cuda:0', shuffle_data=False, transform=None, val_split_ratio=0.15, patience=20,
           get_relation_tensor=None, get_mask=None, writer=None, fused=True):
@@ -212,6 +235,10 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     if patience is not None:
         assert val_split_ratio is not None
     from .vq_vae import VQ_VAE
+    if get_relation_tensor is None and relation_mat is not None:
+        get_relation_tensor = globals()["get_relation_tensor"]
+    if get_mask is None and mask is not None:
+        get_mask = globals()["get_mask"]
     # the fused path is built for the 16x16-latent architecture; other modules (VQ_VAE_z32) train through autograd
     use_fused = fused and isinstance(model, VQ_VAE)
     optimizer = FusedTrainer(model, lr=lr) if use_fused else torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))

@@ -126,3 +126,26 @@ def test_process_vae_io_contract_signature():
     from dynamorph_amd import patch_vae
     sig = inspect.signature(patch_vae.process_VAE)
     assert list(sig.parameters)[:5] == ["raw_folder", "supp_folder", "sites", "config_", "gpu"]
+
+
+def test_relation_tensor_and_mask_slicing():
+    """run_training.py:335-374 restated in dynamorph_amd.train: batch block of the sparse relation matrix, large-mask
+    channel mapped from {-1, 1} to {0, 1}."""
+    import scipy.sparse as sp
+    from torch.utils.data import TensorDataset
+    from dynamorph_amd.train import get_mask, get_relation_tensor
+    rel = sp.dok_matrix((10, 10), dtype=np.float32)
+    rel[1, 2] = rel[2, 1] = 1.
+    rel[2, 7] = rel[7, 2] = 2.
+    ids = [7, 2, 1, 4]
+    out = get_relation_tensor(rel, ids, device=None)
+    assert out.dtype == torch.float32 and out.shape == (4, 4)
+    expect = np.zeros((4, 4), np.float32)
+    expect[0, 1] = expect[1, 0] = 2.
+    expect[1, 2] = expect[2, 1] = 1.
+    assert np.array_equal(out.numpy(), expect)
+    assert get_relation_tensor(None, ids) is None and get_mask(None, ids) is None
+    m = torch.sign(torch.randn(10, 2, 8, 8))
+    bm = get_mask(TensorDataset(m), ids, device="cpu")
+    assert bm.shape == (4, 1, 8, 8)
+    assert torch.equal(bm, (m[ids][:, 1:2] + 1) / 2) and set(bm.unique().tolist()) <= {0., 1.}
