@@ -637,3 +637,37 @@ def test_fused_trainer_time_matching(z16, use_graph):
         if k in BN_FED_BIASES or "tracked" in k:
             continue
         close(v, sd_r[k], 0, 2.5e-4 if "running" not in k else 2e-5, k)
+
+
+@pytest.mark.parametrize("kw,B,with_tm", [({}, 6, True), (dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512), 3, False)])
+def test_graphed_trainer_z32_equals_eager_adam(kw, B, with_tm):
+    """GraphedTrainer (the autograd step of VQ_VAE_z32 replayed as a HIP graph, capturable Adam) against the same module
+    stepped eagerly with torch.optim.Adam: same losses, same parameters, same BatchNorm buffers after 3 steps, and the
+    capture's warm-up leaves no trace."""
+    import copy
+    import dynamorph_amd
+    from dynamorph_amd.train import GraphedTrainer
+    torch.manual_seed(4321)
+    m1 = dynamorph_amd.VQ_VAE_z32(**kw).to(DEV)
+    m2 = copy.deepcopy(m1)
+    opt = torch.optim.Adam(m1.parameters(), lr=1e-3)
+    tr = GraphedTrainer(m2, lr=1e-3)
+    mask = (torch.rand(B, 1, 128, 128, generator=torch.Generator().manual_seed(2)) > 0.4).float().to(DEV)
+    for step in range(3):
+        x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(10 + step)).to(DEV)
+        tm = torch.randint(0, 3, (B, B), generator=torch.Generator().manual_seed(20 + step)).float().to(DEV) if with_tm else None
+        _, ld = m1(x, time_matching_mat=tm, batch_mask=mask)
+        ld["total_loss"].backward()
+        opt.step()
+        m1.zero_grad()
+        vals = tr.step(x, mask, tm).tolist()
+        for i, k in enumerate(("recon_loss", "commitment_loss", "total_loss", "perplexity")):
+            assert abs(vals[i] - float(ld[k])) <= 1e-5 * max(1.0, abs(float(ld[k]))), (step, k, vals[i], float(ld[k]))
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        if "tracked" in k:
+            assert int(sd1[k]) == int(sd2[k]) == 3, k
+        else:
+            # (the LDS float atomics of the codebook gradient are order-dependent; Adam turns a last-bit difference of a
+            #  near-zero gradient into a fraction of lr)
+            assert (sd1[k] - sd2[k]).abs().max().item() <= 2.5e-4 * max(1.0, sd1[k].abs().max().item()), k
