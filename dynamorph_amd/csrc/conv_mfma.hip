@@ -724,7 +724,9 @@ void launch_conv4(const ConvArgs &a)
 #undef DM_L4
 }
 
-int conv3_tw(int W) { return W < 64 ? W : 64; }
+// (32 input channels: 16-wide tiles whatever the width -- the 32-wide instantiation with side inputs spills 296 bytes
+//  per lane, and scratch reloads in the MFMA loop cost more than the narrower tile)
+int conv3_tw(int W, int CIN) { return CIN >= 32 ? (W < 16 ? W : 16) : (W < 64 ? W : 64); }
 // 16-wide tiles take 16 rows (a whole 16x16 latent), except with 32 input channels (staging registers)
 constexpr int conv3_th(int TW, int CIN) { return (TW == 16 && CIN < 32) ? 16 : 8; }
 
@@ -865,7 +867,7 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
 
 static bool conv3_fast_tileable(int CIN, int H, int W)
 {
-    const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
+    const int TW = conv3_tw(W, CIN), TH = conv3_th(TW, CIN);
     return (TW == 16 || TW == 32 || TW == 64) && W % TW == 0 && H % TH == 0 && CIN % 4 == 0 && CIN <= 32;
 }
 
@@ -873,7 +875,7 @@ static bool conv3_fast_tileable(int CIN, int H, int W)
 static bool conv3_has_kernel(int CIN, int NOUT, int H, int W, int taps, bool pix, int per_tile)
 {
     if (!conv3_fast_tileable(CIN, H, W)) return false;
-    const int TW = conv3_tw(W), NTT = (NOUT + 15) / 16;
+    const int TW = conv3_tw(W, CIN), NTT = (NOUT + 15) / 16;
     const bool t13 = TW == 16 || TW == 32;
     if (pix && CIN == 16 && (NOUT == 32 || NOUT == 64) && t13 && !per_tile) return true;
     if (!pix && taps == 9) return t13 && ((CIN == 16 && (NTT == 1 || NTT == 2)) || (CIN == 32 && NTT == 1));
@@ -891,7 +893,7 @@ extern "C" int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int
 {
     if (B <= 0 || H <= 0 || W <= 0) return -1;
     if (conv3_has_kernel(CIN, NOUT, H, W, taps, pixel_shuffle != 0, per_tile)) {
-        const int TW = conv3_tw(W), TH = conv3_th(TW, CIN);
+        const int TW = conv3_tw(W, CIN), TH = conv3_th(TW, CIN);
         return conv_slabs(B * (H / TH) * (W / TW), per_tile);
     }
     const int form = pixel_shuffle ? 2 : 1;
@@ -914,7 +916,7 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
     DM_REQUIRE(taps == 9 || taps == 1, "dm_conv3x3: taps must be 9 or 1");
     DM_REQUIRE(!pixel_shuffle || (taps == 9 && NOUT % 4 == 0), "dm_conv3x3: pixel_shuffle needs taps=9, NOUT%%4==0");
     DM_REQUIRE(!in->ones_channel, "dm_conv3x3: ones_channel not supported");
-    const int TW = conv3_tw(W);
+    const int TW = conv3_tw(W, CIN);
     const bool fast = conv3_has_kernel(CIN, NOUT, H, W, taps, pixel_shuffle != 0, ep ? ep->stats_per_tile : 0);
     ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN, CIN, NOUT, H, W, ep ? ep->stats_per_tile : 0,
                (hipStream_t)stream};
