@@ -724,9 +724,14 @@ void launch_conv4(const ConvArgs &a)
 #undef DM_L4
 }
 
-// (32 input channels: 16-wide tiles whatever the width -- the 32-wide instantiation with side inputs spills 296 bytes
-//  per lane, and scratch reloads in the MFMA loop cost more than the narrower tile)
-int conv3_tw(int W, int CIN) { return CIN >= 32 ? (W < 16 ? W : 16) : (W < 64 ? W : 64); }
+// (32 input channels: 16-wide tiles whatever the width, 16 channels: at most 32 -- the wider instantiations with side
+//  inputs spill ~300 bytes per lane, and scratch reloads in the MFMA loop cost more than the narrower tile; 32-wide
+//  tiles also keep the 16-channel transposed convolutions on the phase-decomposed kernel)
+int conv3_tw(int W, int CIN)
+{
+    const int cap = CIN >= 32 ? 16 : (CIN >= 16 ? 32 : 64);
+    return W < cap ? W : cap;
+}
 // 16-wide tiles take 16 rows (a whole 16x16 latent), except with 32 input channels (staging registers)
 constexpr int conv3_th(int TW, int CIN) { return (TW == 16 && CIN < 32) ? 16 : 8; }
 
