@@ -93,6 +93,24 @@ def allreduce_mean_(t, group=None):
     return t
 
 
+def allreduce_grads_(params, group=None):
+    """Mean over ranks of the .grad of `params` (autograd path: VQ_VAE_z32 with a torch optimizer) -- packed into one
+    flat bucket, ONE collective, scattered back.  No-op in a single process."""
+    w = world_size(group)
+    if w == 1:
+        return
+    gs = [p.grad for p in params if p.grad is not None]
+    if not gs:
+        return
+    flat = torch.cat([g.reshape(-1) for g in gs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / w)
+    off = 0
+    for g in gs:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
 def max_over_ranks(value, device=None, group=None):
     """Scalar max over ranks (bench timing contract)."""
     if world_size(group) == 1:

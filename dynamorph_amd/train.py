@@ -273,6 +273,7 @@ def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, t
         _, loss_dict = model(batch, **model_kwargs)
         if training:
             loss_dict['total_loss'].backward()
+            D.allreduce_grads_(list(model.parameters()))       # data parallel: one flat bucket (no-op in one process)
             optimizer.step()
             model.zero_grad()
     for key, loss in loss_dict.items():
@@ -318,7 +319,9 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     if get_mask is None and mask is not None:
         get_mask = globals()["get_mask"]
     # the fused path is built for the 16x16-latent architecture; other modules (VQ_VAE_z32) train through autograd
-    if fused == "graph":
+    if D.world_size() > 1 and not isinstance(model, VQ_VAE):
+        D.broadcast_(torch.zeros(1, device=device), [p.data for p in model.parameters()] + list(model.buffers()))   # same replica everywhere
+    if fused == "graph" and D.world_size() == 1:
         optimizer = GraphedTrainer(model, lr=lr)          # any module: the autograd step as a replayed HIP graph
     elif fused and isinstance(model, VQ_VAE):
         optimizer = FusedTrainer(model, lr=lr)

@@ -47,8 +47,14 @@ def _worker(rank, world, port, out_dir):
         fp.gview(p).copy_(p.grad)
     local = fp.grad.clone()
     D.allreduce_mean_(fp.grad)
+    # autograd-path helper (VQ_VAE_z32 + torch optimizer): .grad tensors averaged through one bucket
+    plist = [p for p in model.parameters() if p.grad is not None]
+    for p in plist:
+        p.grad = p.grad.clone()
+    D.allreduce_grads_(plist)
+    helper = torch.cat([p.grad.reshape(-1) for p in fp.params])
     t = D.max_over_ranks(1.0 + rank)
-    torch.save({"flat0": flat0, "local": local, "mean": fp.grad.clone(), "tmax": t, "range": (lo, hi)},
+    torch.save({"flat0": flat0, "local": local, "mean": fp.grad.clone(), "helper": helper, "tmax": t, "range": (lo, hi)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -64,5 +70,6 @@ def test_data_parallel_plumbing_world2(tmp_path):
     expect = (res[0]["local"] + res[1]["local"]) / world
     for r in res:
         assert torch.allclose(r["mean"], expect, rtol=0, atol=1e-7)      # ONE collective gives the mean of per-shard grads
+        assert torch.allclose(r["helper"], expect, rtol=0, atol=1e-7)    # allreduce_grads_ (autograd path) gives the same
         assert r["tmax"] == float(world)                                 # max over ranks (bench timing contract)
     assert res[0]["range"] == (0, 4) and res[1]["range"] == (4, 8)
