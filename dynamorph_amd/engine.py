@@ -340,24 +340,28 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
 # The residual stacks are the ResidualBlock module itself (residual_forward/backward); these four functions are the
 # two conv "stems" around them.  Same conventions as above: raw conv outputs + statistics slabs, BatchNorm applied by
 # the consumer's operand load, BatchNorm backward as an AFFINE2 operand.
-def z32_stem_forward(conv0, bn0, conv1, bn1, x):
-    """x (B,NIN,H,W) -> h = BN(conv1(relu(BN(conv0(x))))) (B,nh,H/4,W/4), materialised for the residual stack."""
+def z32_stem_forward(conv0, bn0, conv1, bn1, x, per_sample=False):
+    """x (B,NIN,H,W) -> h = BN(conv1(relu(BN(conv0(x))))) (B,nh,H/4,W/4), materialised for the residual stack.
+    per_sample=True: every BatchNorm uses that sample's own statistics (process_VAE's batch-of-one calls, batched)."""
     B, NIN, H, W = x.shape
+    ps = per_sample
     c1, nh = conv0.weight.shape[0], conv1.weight.shape[0]
     H1, W1, H2, W2 = H // 2, W // 2, H // 4, W // 4
     a1, st = ops.conv4x4s2(Op(x), weight_view(_w(conv0.weight), NIN * 16, 16, 4, 1), B, NIN, c1, H, W,
-                           want_stats=True, bias=_w(conv0.bias))
-    coef1, saved1 = _bn_coef(st, bn0, B * H1 * W1, False, B)
-    a2, st = ops.conv4x4s2(Op(a1, DM_LOAD_AFFINE_RELU, coef1), weight_view(_w(conv1.weight), c1 * 16, 16, 4, 1),
-                           B, c1, nh, H1, W1, want_stats=True, bias=_w(conv1.bias))
-    coef2, saved2 = _bn_coef(st, bn1, B * H2 * W2, False, B)
-    h = ops.apply(Op(a2, DM_LOAD_AFFINE, coef2), B, nh, H2, W2)
-    cx = SimpleNamespace(x=x, a1=a1, a2=a2, coef1=coef1, coef2=coef2, saved1=saved1, saved2=saved2,
+                           want_stats=True, bias=_w(conv0.bias), per_tile=ps)
+    coef1, saved1 = _bn_coef(st, bn0, H1 * W1 * (1 if ps else B), ps, B)
+    a2, st = ops.conv4x4s2(Op(a1, DM_LOAD_AFFINE_RELU, coef1, per_sample=ps), weight_view(_w(conv1.weight), c1 * 16, 16, 4, 1),
+                           B, c1, nh, H1, W1, want_stats=True, bias=_w(conv1.bias), per_tile=ps)
+    coef2, saved2 = _bn_coef(st, bn1, H2 * W2 * (1 if ps else B), ps, B)
+    h = ops.apply(Op(a2, DM_LOAD_AFFINE, coef2, per_sample=ps), B, nh, H2, W2)
+    cx = SimpleNamespace(x=x, a1=a1, a2=a2, coef1=coef1, coef2=coef2, saved1=saved1, saved2=saved2, per_sample=ps,
                          dims=(B, NIN, c1, nh, H1, W1, H2, W2))
     return h, cx
 
 
 def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G):
+    if getattr(cx, "per_sample", False) and cx.dims[0] > 1:
+        raise NotImplementedError("backward through per-sample BatchNorm statistics with B > 1")
     if cx.saved1 is None or cx.saved2 is None:
         raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
     B, NIN, c1, nh, H1, W1, H2, W2 = cx.dims

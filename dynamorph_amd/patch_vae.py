@@ -25,7 +25,25 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
     patches = torch.as_tensor(patches)
     if patches.dim() != 4:
         raise AssertionError("dataset tensor dimension can only be 4, not {}".format(patches.dim()))
-    layers = E.Layers(model)
+    from .vq_vae import VQ_VAE, VQ_VAE_z32
+    if isinstance(model, VQ_VAE):
+        layers = E.Layers(model)
+        codebook = layers.codebook.weight
+
+        def encode(x):
+            return E.encoder_forward(layers, x, per_sample=True)[0]
+    elif isinstance(model, VQ_VAE_z32):
+        enc = model.enc                     # children 0/1/3/4: conv, BatchNorm, conv, BatchNorm; 5: ResidualBlock
+        codebook = model.vq.w.weight
+
+        def encode(x):
+            h, _ = E.z32_stem_forward(enc[0], enc[1], enc[3], enc[4], x, per_sample=True)
+            return E.residual_forward(enc[5]._handles(), h, True)[0]
+    else:
+        codebook = model.vq.w.weight
+
+        def encode(x):                      # any other module: the reference's batch-of-one loop as it is
+            return torch.cat([model.enc(x[j:j + 1]) for j in range(x.shape[0])], 0)
     z_bs, z_as = [], []
     with torch.no_grad():
         for i in range(0, patches.shape[0], batch_size):
@@ -33,8 +51,8 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
                 x = ops.zscore_patch(patches[i:i + batch_size].to(device=device))
             else:
                 x = patches[i:i + batch_size].to(device=device, dtype=torch.float32).contiguous()
-            z_b, _ = E.encoder_forward(layers, x, per_sample=True)
-            z_a, _, _ = E.vq_forward(layers.codebook.weight, z_b, float(model.commitment_cost))
+            z_b = encode(x)
+            z_a, _, _ = E.vq_forward(codebook, z_b, float(model.commitment_cost))
             z_bs.append(z_b.reshape(x.shape[0], -1).cpu())
             z_as.append(z_a.reshape(x.shape[0], -1).cpu())
     if not z_bs:

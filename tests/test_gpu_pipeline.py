@@ -123,3 +123,28 @@ def test_encode_patches_per_sample_shape_sweep(N, nin, hw):
     assert int(m.enc[2].num_batches_tracked) == N
     np.testing.assert_allclose(m.enc[2].running_mean.cpu().numpy(), ref.enc[2].running_mean.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(m.enc[2].running_var.cpu().numpy(), ref.enc[2].running_var.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kw,N", [({}, 5), (dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512), 3)])
+def test_encode_patches_z32_per_sample(kw, N):
+    """process_VAE semantics for VQ_VAE_z32 (the network config_example.yml names), default and example widths: the batched
+    per-sample-statistics encoder against the oracle's batch-of-one loop, BatchNorm running statistics included."""
+    import dynamorph_amd
+    from dynamorph_amd.patch_vae import encode_patches
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(77 + N)
+    ref = O.OracleVQVAEz32(**kw)
+    m = dynamorph_amd.VQ_VAE_z32(**kw).to("cuda:0")
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(N, 2, 128, 128, generator=torch.Generator().manual_seed(N))
+    with torch.no_grad():
+        zb_r = torch.cat([ref.enc(x[i:i + 1]) for i in range(N)], 0)            # patch_VAE.py:445-452, train mode
+        za_r = torch.cat([ref.vq(zb_r[i:i + 1])[0] for i in range(N)], 0)
+    zb, za = encode_patches(m, x, device="cuda:0", batch_size=2)
+    assert zb.shape == (N, zb_r[0].numel())
+    np.testing.assert_allclose(zb, zb_r.reshape(N, -1).numpy(), rtol=3e-4, atol=3e-4)
+    flips = int((np.abs(za - za_r.reshape(N, -1).numpy()) > 1e-3).any(axis=0).sum())
+    assert flips <= za.shape[1] // 200, flips
+    assert int(m.enc[1].num_batches_tracked) == N
+    np.testing.assert_allclose(m.enc[1].running_mean.cpu().numpy(), ref.enc[1].running_mean.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.enc[4].running_var.cpu().numpy(), ref.enc[4].running_var.numpy(), rtol=1e-4, atol=1e-6)
