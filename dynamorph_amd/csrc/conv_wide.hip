@@ -105,7 +105,7 @@ template <int FORM, int TAPS>
 struct WideGeom {
     static constexpr int S = FORM == W_S2 ? 2 : 1;                       // stride
     static constexpr int R = FORM == W_S2 ? 1 : (TAPS == 9 ? 1 : 0);     // halo
-    static constexpr int T = FORM == W_S2 ? 16 : TAPS;                   // taps of the K loop
+    static constexpr int T = FORM == W_S1 ? TAPS : 16;                   // taps of the K loop (transposed: 4 parities x 2 x 2)
     static constexpr int ROWS = FORM == W_S2 ? 18 : 8 + 2 * R;           // input rows of a tile
     static constexpr int QW = FORM == W_S2 ? 8 : 4;                      // aligned float4 per input row (the interior)
     static constexpr bool HALO = R > 0;
@@ -127,7 +127,7 @@ struct WideGeom {
 // conv kernel stages a weight chunk as a straight float4 copy.
 template <int FORM, int TAPS, int NPW>
 struct WideW {
-    static constexpr int T = FORM == W_S2 ? 16 : TAPS;
+    static constexpr int T = FORM == W_S1 ? TAPS : 16;
     static constexpr int NS = NPW == 1 ? 16 : 16 * NPW + 16;
     static constexpr int W_PS = 2 * NS + 9;
     static constexpr int W_TS = ((WKC / 2) * W_PS + 30) / 32 * 32 + 1;
@@ -135,8 +135,11 @@ struct WideW {
     static constexpr int NPASS = 16 * NPW;
 };
 
-// scratch[(pass*nchunks + chunk)*BLK + ...] <- the weight view's values in LDS layout (0 where a transposed-conv tap
-// does not reach an output parity, past CIN / NOUT).  grid (nchunks, passes).
+// scratch[(pass*nchunks + chunk)*BLK + ...] <- the weight view's values in LDS layout (0 past CIN / the channel count).
+// Transposed form: the N dimension is the output channel co (NOUT / 4 of them); the 16 "taps" are (output parity
+// (py, px), a, b): output (2y+py, 2x+px) takes input (y-1+py+a, x-1+px+b) through kernel element (3-py-2a, 3-px-2b) --
+// the 4 taps of the 4x4 kernel that reach that parity, instead of a 3x3 neighbourhood with 5 structural zeros.
+// grid (nchunks, passes).
 template <int FORM, int TAPS, int NPW>
 __global__ __launch_bounds__(256) void wide_pack_kernel(WeightView wv, float *__restrict__ scratch, int CIN, int NOUT)
 {
@@ -147,12 +150,10 @@ __global__ __launch_bounds__(256) void wide_pack_kernel(WeightView wv, float *__
         const int tap = idx % P::T, cl = (idx / P::T) % WKC, nl = idx / (P::T * WKC);
         const int n = n0 + nl, c = c0 + cl;
         float v = 0.f;
-        if (n < NOUT && c < CIN) {
+        if (n < (FORM == W_PIX ? NOUT >> 2 : NOUT) && c < CIN) {
             if (FORM == W_PIX) {
-                const int co = n >> 2, py = (n >> 1) & 1, px = n & 1, tyy = tap / 3, txx = tap - tyy * 3;
-                const int da = tyy - py, db = txx - px;
-                if (da >= 0 && da <= 1 && db >= 0 && db <= 1)
-                    v = wv.w[wv.off + co * wv.sn + c * wv.sc + (py + 3 - 2 * tyy) * wv.sky + (px + 3 - 2 * txx) * wv.skx];
+                const int py = tap >> 3, px = (tap >> 2) & 1, a = (tap >> 1) & 1, b = tap & 1;
+                v = wv.w[wv.off + n * wv.sn + c * wv.sc + (3 - py - 2 * a) * wv.sky + (3 - px - 2 * b) * wv.skx];
             } else {
                 constexpr int KW = FORM == W_S2 ? 4 : (TAPS == 9 ? 3 : 1);
                 const int ky = tap / KW, kx = tap - ky * KW;
@@ -393,11 +394,14 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
         for (int tile = t_begin; tile < t_end; tile += t_step) {
             const int b = tile / tps, r = tile - b * tps;
             const int y0 = (r / tx_n) << 3, x0 = (r - (r / tx_n) * tx_n) << 4;
-            f32x4 acc[2][NPW];
+            constexpr int NPAR = FORM == W_PIX ? 4 : 1;              // transposed form: one accumulator set per output parity
+            f32x4 acc[NPAR][2][NPW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int q = 0; q < NPAR; ++q)
 #pragma unroll
-                for (int t = 0; t < NPW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NPW; ++t) acc[q][i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
             for (int ch = 0; ch < nchunks; ++ch) {
                 __syncthreads();                 // the previous chunk's MFMAs are done with s_in / s_w
@@ -420,6 +424,9 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                     if (FORM == W_S2) {
                         const int ky = tap >> 2, kx = tap & 3;
                         toff = (kx & 1) * G::PLS + ky * G::RS + (kx >> 1) + ((kx & 1) ? 0 : 1);
+                    } else if (FORM == W_PIX) {
+                        const int py = tap >> 3, px = (tap >> 2) & 1, a = (tap >> 1) & 1, b = tap & 1;
+                        toff = (py + a) * G::RS + (px + b) + G::OFFC - 1;
                     } else {
                         toff = TAPS == 9 ? (tap / 3) * G::RS + (tap % 3) + G::OFFC - 1 : 0;
                     }
@@ -430,12 +437,13 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
 #pragma unroll
                     for (int t = 0; t < NPW; ++t) bv[t] = bp[t * 16];
                 };
-                auto mfma_step = [&](const float (&av)[2], const float (&bv)[NPW]) {
+                auto mfma_step = [&](auto parc, const float (&av)[2], const float (&bv)[NPW]) {
+                    constexpr int PAR = decltype(parc)::value;
 #pragma unroll
                     for (int t = 0; t < NPW; ++t)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
+                            acc[PAR][i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[PAR][i][t], 0, 0, 0);
                 };
                 static_assert(WKC == 8, "two channel quads per tap");
                 constexpr int NSTEP = 2 * G::T, NIT = G::T;
@@ -455,12 +463,13 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                             }
                         };
                         slots(slots, std::integral_constant<int, 0>{});
+                        constexpr int PAR = FORM == W_PIX ? IT >> 2 : 0;            // both steps of a tap share its parity
                         __builtin_amdgcn_sched_barrier(0);
-                        mfma_step(a0, b0);
+                        mfma_step(std::integral_constant<int, PAR>{}, a0, b0);
                         __builtin_amdgcn_sched_barrier(0);
                         lds_step(step + 2 < NSTEP ? step + 2 : step, a0, b0);       // last round: a harmless re-read
                         __builtin_amdgcn_sched_barrier(0);
-                        mfma_step(a1, b1);
+                        mfma_step(std::integral_constant<int, PAR>{}, a1, b1);
                         __builtin_amdgcn_sched_barrier(0);
                         self(self, std::integral_constant<int, IT + 1>{});
                     }
@@ -469,33 +478,19 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
             }
 
             // ---- epilogue: lane holds pixels (row 2*wave+i, columns 4*kq .. 4*kq+3) of channel n0 + 16*t + p
+            //      (transposed form: of every output parity, i.e. 2 output rows x 8 consecutive output columns)
 #pragma unroll
             for (int t = 0; t < NPW; ++t) {
-                const int n = n0 + t * 16 + p;
-                const bool live = n < NOUT;
-                const int chn = FORM == W_PIX ? n >> 2 : n;
+                const int chn = n0 + t * 16 + p;
+                const bool live = chn < CO;
                 const float bias = (live && ep.bias) ? ep.bias[chn] : 0.f;
                 float mc0 = 1.f, mc2 = 0.f;
                 if (live && ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) {
                     const float *cf = ep.mask.coef + (long long)b * ep.mask.coef_bstride + chn * 4;
                     mc0 = cf[0]; mc2 = cf[2];
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x4 v = acc[i][t];
-                    int oy, ox;
-                    if (FORM == W_PIX) {
-                        // pair (px = 0, 1) lanes exchange so that each writes 4 consecutive output pixels
-                        const f32x4 o = lane_xor1(v);
-                        const bool odd = n & 1;
-                        v = odd ? (f32x4){o.z, v.z, o.w, v.w} : (f32x4){v.x, o.x, v.y, o.y};
-                        oy = 2 * (y0 + 2 * wave + i) + ((n >> 1) & 1);
-                        ox = 2 * (x0 + 4 * kq) + (odd ? 4 : 0);
-                    } else {
-                        oy = y0 + 2 * wave + i;
-                        ox = x0 + 4 * kq;
-                    }
-                    if (!live) continue;
+                auto emit = [&](f32x4 v, int oy, int ox) {
+                    if (!live) return;
                     if (FORM == W_S2 && ep.bias_border) {
                         const int ry = oy == 0 ? 0 : (oy == OH - 1 ? 2 : 1);
                         const float *tb = ep.bias_border + (ry * 3) * CO + chn;
@@ -525,6 +520,20 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                         st1[t] += (double)((v.x + v.y) + (v.z + v.w));
                         st2[t] += (double)((v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w));
                     }
+                };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (FORM == W_PIX) {
+#pragma unroll
+                        for (int py = 0; py < 2; ++py) {
+                            const f32x4 e = acc[py * 2][i][t], o = acc[py * 2 + 1][i][t];      // px = 0, 1
+                            const int oy = 2 * (y0 + 2 * wave + i) + py, ox = 2 * (x0 + 4 * kq);
+                            emit((f32x4){e.x, o.x, e.y, o.y}, oy, ox);
+                            emit((f32x4){e.z, o.z, e.w, o.w}, oy, ox + 4);
+                        }
+                    } else {
+                        emit(acc[0][i][t], y0 + 2 * wave + i, x0 + 4 * kq);
+                    }
                 }
             }
         }
@@ -544,20 +553,13 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
             }
             __syncthreads();
             const long long slab = per_tile ? (long long)g * spg : blockIdx.x;
-            constexpr int CPP = FORM == W_PIX ? 4 * NPW : 16 * NPW;        // statistics channels of one pass
+            constexpr int CPP = 16 * NPW;                                  // statistics channels of one pass
             for (int i = tid; i < CPP * 2; i += 256) {
                 const int cl = i >> 1, k = i & 1;
-                const int chn = (FORM == W_PIX ? n0 >> 2 : n0) + cl;
+                const int chn = n0 + cl;
                 if (chn >= CO) continue;
                 double s = 0.0;
-                for (int w = 0; w < 4; ++w) {
-                    if (FORM == W_PIX) {
-                        const int t = cl >> 2, pp = (cl & 3) * 4;
-                        for (int j = 0; j < 4; ++j) s += s_red[((w * NPW + t) * 16 + pp + j) * 2 + k];
-                    } else {
-                        s += s_red[((w * NPW + (cl >> 4)) * 16 + (cl & 15)) * 2 + k];
-                    }
-                }
+                for (int w = 0; w < 4; ++w) s += s_red[((w * NPW + (cl >> 4)) * 16 + (cl & 15)) * 2 + k];
                 ep.stats[(slab * CO + chn) * 2 + k] = s;
                 if (per_tile)
                     for (int e = 1; e < spg; ++e) ep.stats[((slab + e) * CO + chn) * 2 + k] = 0.0;
@@ -565,8 +567,8 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
         }
     }
     if (ep.stats && !per_tile) {                                      // slabs no workgroup owns
-        constexpr int CPP = FORM == W_PIX ? 4 * NPW : 16 * NPW;
-        const int cbase = FORM == W_PIX ? n0 >> 2 : n0;
+        constexpr int CPP = 16 * NPW;
+        const int cbase = n0;
         for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
             for (int i = tid; i < CPP * 2; i += 256)
                 if (cbase + (i >> 1) < CO) ep.stats[((long long)sl * CO + cbase + (i >> 1)) * 2 + (i & 1)] = 0.0;
@@ -746,12 +748,17 @@ int dm_wide_conv_slabs(int form, int B, int H, int W, int per_tile)
 // output channels per pass / 16: wider passes put the accumulators plus the prefetch registers past 256
 // (the stride-2 form stages 2.5x as much input per chunk and the transposed form's unrolled loop is register-hungry:
 //  32 channels per pass there)
-static int wide_npw(int form, int NOUT) { return NOUT <= 16 ? 1 : ((NOUT <= 32 || form != W_S1) ? 2 : 4); }
+static int wide_npw(int form, int NOUT)
+{
+    const int n = form == W_PIX ? NOUT / 4 : NOUT;          // transposed form: N = output channels, 4 parities each
+    return n <= 16 ? 1 : ((n <= 32 || form != W_S1) ? 2 : 4);
+}
 
 template <int FORM, int TAPS, int NPW>
 static long long wide_scratch_floats_t(int CIN, int NOUT)
 {
-    const long long passes = (NOUT + 16 * NPW - 1) / (16 * NPW), nchunks = (CIN + WKC - 1) / WKC;
+    const int n = FORM == W_PIX ? NOUT / 4 : NOUT;
+    const long long passes = (n + 16 * NPW - 1) / (16 * NPW), nchunks = (CIN + WKC - 1) / WKC;
     return passes * nchunks * WideW<FORM, TAPS, NPW>::BLK;
 }
 
@@ -759,7 +766,7 @@ static long long wide_scratch_floats_t(int CIN, int NOUT)
     if (form == W_S2) {                                                                                         \
         if (np == 1) CALL(W_S2, 16, 1) else if (np == 2) CALL(W_S2, 16, 2) else CALL(W_S2, 16, 4)              \
     } else if (form == W_PIX) {                                                                                 \
-        if (np == 1) CALL(W_PIX, 9, 1) else if (np == 2) CALL(W_PIX, 9, 2) else CALL(W_PIX, 9, 4)              \
+        if (np == 1) CALL(W_PIX, 9, 1) else CALL(W_PIX, 9, 2)                                                    \
     } else if (taps == 9) {                                                                                     \
         if (np == 1) CALL(W_S1, 9, 1) else if (np == 2) CALL(W_S1, 9, 2) else CALL(W_S1, 9, 4)                 \
     } else {                                                                                                    \
@@ -786,7 +793,8 @@ int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scrat
     if (gx > WIDE_MAX_BLOCKS) gx = WIDE_MAX_BLOCKS;
     if (ep.stats && !per_tile && gx > nslabs) gx = nslabs;
     const int np = wide_npw(form, NOUT);
-    const int passes = (NOUT + 16 * np - 1) / (16 * np), nchunks = (CIN + WKC - 1) / WKC;
+    const int nn = form == W_PIX ? NOUT / 4 : NOUT;
+    const int passes = (nn + 16 * np - 1) / (16 * np), nchunks = (CIN + WKC - 1) / WKC;
     const dim3 grid((unsigned)gx, (unsigned)passes), pgrid((unsigned)nchunks, (unsigned)passes);
     // persistent grid = what is resident at once (workgroups per CU by registers / LDS x 256 CUs): with more, the late
     // starters run on a half-empty machine
