@@ -5,13 +5,16 @@
 // num_hiddens 64, num_residual_hiddens 64, 512 codes) has 64 -> 64 channel 3x3 layers: 147 KB of weights, MFMA bound.
 // These kernels are the classic implicit GEMM for that regime:
 //   convolution     M = 8 x 16 pixels of one sample, N = up to 64 output channels per pass, K = (tap, channel) in chunks of
-//                   8 channels; the input chunk (operand transform, zero padding, ones channel applied) and the weight
-//                   chunk (re-laid as [tap][channel][n]) are staged in LDS, every wave owns 2 pixel rows x all N;
+//                   8 channels; the input chunk (operand transform, zero padding, ones channel applied; rows of aligned
+//                   float4 + halo scalars) and the weight chunk (re-laid once per call into caller scratch, copied as
+//                   float4) are staged in LDS through registers, prefetched one chunk ahead; every wave owns 2 pixel
+//                   rows x all N;
 //   weight gradient M = 64 S channels (one 16-row tile per wave), N = (T channel, tap) flattened, K = the 128 pixels
 //                   of a tile; both operand tiles in LDS, deterministic slabs as everywhere else.
 // Same operands / epilogue / statistics-slab semantics as the thin kernels (dm_operand, dm_weight_view, dm_epilogue);
-// the fp32 MFMA (v_mfma_f32_16x16x4_f32) keeps full precision.  LDS strides are chosen so that the 4 x 16 lane groups
-// of an MFMA operand read fall into distinct banks (channel stride = 16 mod 64 floats for conv, 4 mod 64 for wgrad).
+// the fp32 MFMA (v_mfma_f32_16x16x4_f32) keeps full precision.  ds_read_b32 / ds_write banks are dword address mod 32
+// inside each 32-lane half: strides are chosen so that the two k lanes x 16 column lanes of a half hit 32 banks
+// (DESIGN.md section 3a has the measurements behind each of these choices).
 #include "dm_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -21,75 +24,6 @@ namespace {
 enum { W_S2 = 0, W_S1 = 1, W_PIX = 2 };
 constexpr int WKC = 8;                 // input channels per K chunk
 constexpr int WIDE_MAX_BLOCKS = 768;   // persistent grid cap (x dimension)
-
-// operand value at (b, c, y, x): zero outside the image, ones channel (c >= Cphys) is 1 inside it
-__device__ __forceinline__ float wide_load(const Operand &op, int b, int c, int y, int x, int Cphys, int H, int W)
-{
-    if (y < 0 || y >= H || x < 0 || x >= W) return 0.f;
-    if (c >= Cphys) return 1.f;
-    const long long off = (((long long)b * Cphys + c) * H + y) * W + x;
-    float v = op.p0[off];
-    if (op.mode == DM_LOAD_IDENT) return v;
-    if (op.mode == DM_LOAD_RELU) return v < 0.f ? 0.f : v;
-    const float *cf = op.coef + (long long)b * op.coef_bstride + c * 4;
-    if (op.mode == DM_LOAD_AFFINE2) return cf[0] * v + (cf[1] * op.p1[off] + cf[2]);
-    v = cf[0] * v + cf[2];
-    if (op.mode == DM_LOAD_AFFINE_RELU) v = v < 0.f ? 0.f : v;
-    return v;
-}
-
-// Stage `nch` channels (first channel c_first, channels >= c_limit are zero, channel Cphys is the ones channel) of the
-// ROWS x LCOLS window at (gy0, gx0) of sample b into LDS, operand transform and zero padding applied.  Loads are issued
-// in batches of 8 per thread before any of them is consumed (one exposed latency per batch instead of one per load);
-// AFFINE coefficients come from LDS (s_cf[channel - c_first][4], staged by the caller).
-// PLANES: columns are split into even / odd planes of COLS columns (stride-2 readers then step by 1).
-template <int ROWS, int LCOLS, int COLS, int CHS, bool PLANES>
-__device__ __forceinline__ void stage_window(const Operand &op, const float *s_cf, float *s_dst, int nch, int c_first,
-                                             int c_limit, int Cphys, int b, int gy0, int gx0, int H, int W, int tid)
-{
-    constexpr int PER = ROWS * LCOLS, PLS = ROWS * COLS;
-    const int total = nch * PER;
-    const long long sample = (long long)b * Cphys * H * W;
-    const int mode = op.mode;
-#pragma unroll 1
-    for (int base = 0; base < total; base += 256 * 8) {
-        float v[8], u[8];
-        int la[8], cc[8], off[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = base + j * 256 + tid;
-            const int c = idx / PER, rem = idx - c * PER, iy = rem / LCOLS, ix = rem - iy * LCOLS;
-            const int gy = gy0 + iy, gx = gx0 + ix, chn = c_first + c;
-            const bool ok = idx < total;
-            const bool inimg = ok && gy >= 0 && gy < H && gx >= 0 && gx < W && chn < c_limit;
-            const bool phys = inimg && chn < Cphys;
-            off[j] = phys ? (chn * H + gy) * W + gx : 0;
-            la[j] = ok ? (PLANES ? c * CHS + (ix & 1) * PLS + iy * COLS + (ix >> 1) : c * CHS + iy * COLS + ix) : -1;
-            cc[j] = phys ? c : (inimg ? -1 : -2);            // -1: ones channel, -2: zero
-            v[j] = op.p0[sample + off[j]];
-        }
-        if (mode == DM_LOAD_AFFINE2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = op.p1[sample + off[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (la[j] < 0) continue;
-            float x = v[j];
-            if (cc[j] >= 0) {
-                if (mode == DM_LOAD_RELU) x = x < 0.f ? 0.f : x;
-                else if (mode == DM_LOAD_AFFINE2) x = s_cf[cc[j] * 4] * x + (s_cf[cc[j] * 4 + 1] * u[j] + s_cf[cc[j] * 4 + 2]);
-                else if (mode >= DM_LOAD_AFFINE) {
-                    x = s_cf[cc[j] * 4] * x + s_cf[cc[j] * 4 + 2];
-                    if (mode == DM_LOAD_AFFINE_RELU) x = x < 0.f ? 0.f : x;
-                }
-            } else {
-                x = cc[j] == -1 ? 1.f : 0.f;
-            }
-            s_dst[la[j]] = x;
-        }
-    }
-}
 
 // coefficient rows of channels [c_first, c_first + nch) of sample b -> s_cf[nch][4] (caller synchronises)
 __device__ __forceinline__ void stage_coef(const Operand &op, float *s_cf, int nch, int c_first, int Cphys, int b, int tid)
