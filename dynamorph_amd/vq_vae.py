@@ -437,8 +437,9 @@ class _Z32Decoder(nn.Sequential):
 class VQ_VAE_z32(nn.Module):
     """Vector-Quantized VAE with a 32 x 32 x num_hiddens latent (reference vae.py:348-474): two stride-2 convs and a
     residual stack in the encoder, a residual stack, BatchNorm and two transposed convs in the decoder, the
-    weighted-hinge time-matching loss on z_after.  Built for the default channel family (num_hiddens 16,
-    num_residual_hiddens 32); other sizes raise ValueError("no kernel built ...")."""
+    weighted-hinge time-matching loss on z_after.  The default widths (num_hiddens 16, num_residual_hiddens 32) run on the
+    register-resident kernels, any other width (config_example.yml: 64 / 64 / 512 codes) on the implicit-GEMM kernels of
+    csrc/conv_wide.hip."""
 
     def __init__(self, num_inputs=2, num_hiddens=16, num_residual_hiddens=32, num_residual_layers=2, num_embeddings=64,
                  commitment_cost=0.25, channel_var=np.ones(2), weight_matching=0.005, w_a=1.1, w_t=0.1, w_n=-0.5,
