@@ -381,7 +381,10 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float 
                 };
                 static_assert(WKC == 8, "two channel quads per tap");
                 constexpr int NSTEP = 2 * G::T, NIT = G::T;
-                constexpr int SPI = (NSLOT + NIT - 1) / NIT;          // load slots per iteration
+                // (all requests go out in the first half of the taps: the last one needs a round trip of lead before the
+                //  commit that follows this loop)
+                constexpr int NITL = NIT > 1 ? NIT / 2 : 1;
+                constexpr int SPI = (NSLOT + NITL - 1) / NITL;        // load slots per iteration
                 float a0[2], b0[NPW], a1[2], b1[NPW];
                 lds_step(0, a0, b0);
                 auto round = [&](auto self, auto itc) -> void {
