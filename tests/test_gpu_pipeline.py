@@ -148,3 +148,26 @@ def test_encode_patches_z32_per_sample(kw, N):
     assert int(m.enc[1].num_batches_tracked) == N
     np.testing.assert_allclose(m.enc[1].running_mean.cpu().numpy(), ref.enc[1].running_mean.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(m.enc[4].running_var.cpu().numpy(), ref.enc[4].running_var.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_encode_patches_wide_vq_vae_per_sample():
+    """process_VAE semantics for VQ_VAE at the example widths (64 / 64 / 512): per-sample statistics through the
+    implicit-GEMM kernels (border-bias first conv, statistics slabs grouped by sample)."""
+    import dynamorph_amd
+    from dynamorph_amd.patch_vae import encode_patches
+    from oracle import vqvae_oracle as O
+    kw = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)
+    torch.manual_seed(64)
+    ref = O.OracleVQVAE(**kw)
+    m = dynamorph_amd.VQ_VAE(**kw).to("cuda:0")
+    m.load_state_dict(ref.state_dict())
+    N = 3
+    x = torch.randn(N, 2, 128, 128, generator=torch.Generator().manual_seed(N))
+    with torch.no_grad():
+        zb_r, za_r = O.encode_per_sample(ref, x)
+    zb, za = encode_patches(m, x, device="cuda:0", batch_size=2)
+    np.testing.assert_allclose(zb, zb_r.reshape(N, -1).numpy(), rtol=3e-4, atol=3e-4)
+    flips = int((np.abs(za - za_r.reshape(N, -1).numpy()) > 1e-3).any(axis=0).sum())
+    assert flips <= za.shape[1] // 200, flips
+    assert int(m.enc[2].num_batches_tracked) == N
+    np.testing.assert_allclose(m.enc[2].running_var.cpu().numpy(), ref.enc[2].running_var.numpy(), rtol=1e-4, atol=1e-6)
