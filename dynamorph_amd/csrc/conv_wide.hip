@@ -525,7 +525,10 @@ struct WgGeom {
     static constexpr bool PLANES = KK == 4;
     static constexpr int RS = KK == 4 ? 18 : (R ? 24 : 16);
     static constexpr int OFFC = KK == 3 ? 4 : 0;
-    static constexpr int PLS = ROWS * RS;
+    // 4x4/s2: the 16 lanes of an N tile are the 16 taps of one channel = (plane, row ky, column) with 3 columns in use
+    // per plane; rows step the bank by 18, so a plane stride of 8 (mod 32) puts all 24 addresses of a half on their own
+    // bank (with the planes back to back, 324 = 4 mod 32, SQ_LDS_BANK_CONFLICT was 49 % of the LDS cycles)
+    static constexpr int PLS = ROWS * RS + (KK == 4 ? 4 : 0);
     static constexpr int RAW = KK == 4 ? 2 * PLS : PLS;
     // channel stride: multiple of 4 (aligned float4 / float2 rows); = 4 (mod 32) so that the taps of neighbouring
     // channels inside one 16-lane N tile spread over the banks
