@@ -553,6 +553,10 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
     const int nct = CT - ct0 < G::NCTP ? CT - ct0 : G::NCTP;           // T channels of this pass
     const int ntw = (nct * G::T2 + 15) >> 4;                          // N tiles in use
     const int ncs = CS - cs0 < 64 ? CS - cs0 : 64;
+    // waves -> (M tile of 16 S channels, group of N tiles): with fewer than 64 S channels the spare waves take a share
+    // of the N tiles instead of multiplying zero rows (16 channels: 4 groups, 32: 2)
+    const int MT = ncs <= 16 ? 1 : (ncs <= 32 ? 2 : 4);
+    const int mt = wave & (MT - 1), ng = wave / MT, ngm = 4 / MT - 1;
     const int Ht = Hs * G::S, Wt = Ws * G::S;
     const int tx_n = Ws >> 4, tps = (Hs >> 3) * tx_n;
     const long long E = (long long)CS * CT * G::T2;
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
         }
         __syncthreads();
         // K = the 128 pixels: 8 rows x 4 steps of 4 columns.  Inside a row every LDS address is tb[nt] + constant.
-        const float *sp = s_S + (wave * 16 + p) * WG_CSS + kq;
+        const float *sp = s_S + (mt * 16 + p) * WG_CSS + kq;
 #pragma unroll 1
         for (int row = 0; row < 8; ++row) {
 #pragma unroll
@@ -630,10 +634,10 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
                 float bv[G::NTW];
 #pragma unroll
                 for (int nt = 0; nt < G::NTW; ++nt)
-                    if (nt < ntw) bv[nt] = s_T[tb[nt] + k4 * 4];
+                    if (nt < ntw && (nt & ngm) == ng) bv[nt] = s_T[tb[nt] + k4 * 4];
 #pragma unroll
                 for (int nt = 0; nt < G::NTW; ++nt)
-                    if (nt < ntw) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
+                    if (nt < ntw && (nt & ngm) == ng) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);          // keep the four steps' LDS reads from all moving to the top
             }
 #pragma unroll
@@ -643,15 +647,15 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, f
         for (int nt = 0; nt < G::NTW; ++nt) tb[nt] -= 8 * G::ROWSTEP;
     }
 
-    // lane holds R[cs = cs0 + 16*wave + 4*kq + j][n = 16*nt + p]
+    // lane holds R[cs = cs0 + 16*mt + 4*kq + j][n = 16*nt + p] for the N tiles of its group
     float *row = slabs + (long long)blockIdx.x * E;
 #pragma unroll
     for (int nt = 0; nt < G::NTW; ++nt) {
         const int n = nt * 16 + p, ctl = n / G::T2, tap = n - ctl * G::T2;
-        if (nt >= ntw || ctl >= nct) continue;
+        if (nt >= ntw || ctl >= nct || (nt & ngm) != ng) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int cs = cs0 + wave * 16 + kq * 4 + j;
+            const int cs = cs0 + mt * 16 + kq * 4 + j;
             if (cs < CS) row[((long long)cs * CT + ct0 + ctl) * G::T2 + tap] = acc[nt][j];
         }
     }

@@ -412,7 +412,8 @@ def test_wide_conv_transpose(ops, B, ci, co, h, w):
 @pytest.mark.parametrize("B,cs,ct,k,hs,ws,ones", [(3, 64, 64, 3, 16, 16, False), (3, 64, 64, 1, 16, 16, False),
                                                  (3, 64, 32, 4, 16, 16, False), (2, 32, 3, 4, 64, 64, True),
                                                  (2, 32, 2, 4, 64, 64, False), (2, 128, 20, 3, 8, 32, False),
-                                                 (40, 32, 64, 4, 32, 32, False), (3, 64, 100, 1, 16, 32, False)])
+                                                 (40, 32, 64, 4, 32, 32, False), (3, 64, 100, 1, 16, 32, False),
+                                                 (2, 16, 16, 4, 64, 64, False), (2, 16, 40, 3, 16, 16, False), (3, 48, 24, 4, 16, 16, False)])
 def test_wide_wgrad(ops, B, cs, ct, k, hs, ws, ones):
     s, p = (2, 1) if k == 4 else ((1, 1) if k == 3 else (1, 0))
     ctp = ct - (1 if ones else 0)
