@@ -58,6 +58,12 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_wgrad_num_blocks(1, 8, 3, 64, 64, 5) == -1
     assert lib.dm_head_num_blocks(2048, 128, 128) == 2048
     assert lib.dm_head_supported(4, 2) == 1 and lib.dm_head_supported(16, 4) == 1 and lib.dm_head_supported(12, 2) == 0
+    # scratch for the re-laid weights: none for register-resident shapes, (passes x chunks x block) floats otherwise
+    assert lib.dm_conv3x3_scratch_floats(16, 16, 16, 16, 9, 0, 0) == 0
+    assert lib.dm_conv3x3_scratch_floats(64, 64, 32, 32, 9, 0, 0) == 8 * 6348          # 1 pass x 8 chunks of 8 channels
+    assert lib.dm_conv3x3_scratch_floats(64, 64, 33, 32, 9, 0, 0) == 0                 # not tileable by 8 x 16: generic kernel
+    assert lib.dm_conv4x4s2_scratch_floats(8, 16, 64, 64, 0) == 0 and lib.dm_conv4x4s2_scratch_floats(8, 16, 64, 64, 1) > 0
+    assert lib.dm_conv4x4s2_scratch_floats(32, 64, 64, 64, 0) > 0
     assert lib.dm_channel_stats_num_blocks(20, 16, 16, 16) == 3
 
 

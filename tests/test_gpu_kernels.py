@@ -433,6 +433,87 @@ def test_wide_wgrad(ops, B, cs, ct, k, hs, ws, ones):
     close(dst, w.grad, 5e-5, 5e-5 * scale, "wide wgrad")
 
 
+def _wide_random_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    cases = []
+    for i in range(n):
+        form = ("s2", "s1_9", "s1_1", "pix")[i % 4]
+        cin = rng.choice([1, 3, 7, 8, 9, 17, 24, 40, 65])
+        nout = rng.choice([1, 2, 15, 16, 17, 33, 48, 70])
+        h, w = rng.choice([8, 16, 24]), rng.choice([16, 32, 48])
+        cases.append((form, rng.randint(1, 4), cin, nout, h, w, rng.choice([0, 1, 3, 4]), rng.random() < 0.3, 1000 + i))
+    return cases
+
+
+@pytest.mark.parametrize("form,B,cin,nout,h,w,mode,per_tile,seed", _wide_random_cases(24, 7))
+def test_wide_conv_random_shapes(ops, form, B, cin, nout, h, w, mode, per_tile, seed):
+    """Seeded sweep over channel counts that are not multiples of anything, all three forms, operand modes, ReLU / gate /
+    residual epilogues and both statistics groupings -- against torch on the CPU."""
+    if form == "s2":
+        h, w = 2 * h, 2 * w
+    x, x1 = rnd(B, cin, h, w, seed=seed), rnd(B, cin, h, w, seed=seed + 1)
+    coef = torch.stack([rnd(cin, seed=seed + 2).abs() + 0.5, rnd(cin, seed=seed + 3) * 0.2, rnd(cin, seed=seed + 4) * 0.3,
+                        torch.zeros(cin)], 1)
+    xin = load_ref(x, mode, coef, x1)
+    inp = ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, p1=x1.to(DEV) if mode == 4 else None)
+    bias = rnd(nout, seed=seed + 5)
+    if form == "s2":
+        wt = rnd(nout, cin, 4, 4, seed=seed + 6, scale=0.2)
+        ref = F.conv2d(xin, wt, bias, stride=2, padding=1)
+        call = lambda **kw: ops.conv4x4s2(inp, ops.weight_view(wt.to(DEV), cin * 16, 16, 4, 1), B, cin, nout, h, w, **kw)
+    elif form == "pix":
+        wt = rnd(cin, nout, 4, 4, seed=seed + 6, scale=0.2)
+        ref = F.conv_transpose2d(xin, wt, bias, stride=2, padding=1)
+        call = lambda **kw: ops.conv3x3(inp, ops.weight_view(wt.to(DEV), 16, nout * 16, 4, 1), B, cin, 4 * nout, h, w, taps=9,
+                                        pixel_shuffle=True, **kw)
+    else:
+        k = 3 if form == "s1_9" else 1
+        wt = rnd(nout, cin, k, k, seed=seed + 6, scale=0.2)
+        ref = F.conv2d(xin, wt, bias, padding=k // 2)
+        wv = ops.weight_view(wt.to(DEV), cin * k * k, k * k, k if k == 3 else 0, 1 if k == 3 else 0)
+        call = lambda **kw: ops.conv3x3(inp, wv, B, cin, nout, h, w, taps=k * k, **kw)
+    gate, resid = rnd(*ref.shape, seed=seed + 7), rnd(*ref.shape, seed=seed + 8)
+    ref = F.relu(ref) * (gate > 0) + resid
+    out, st = call(want_stats=True, bias=bias.to(DEV), relu=True, mask=ops.Op(gate.to(DEV)), resid=resid.to(DEV),
+                   stat_q=gate.to(DEV), per_tile=per_tile)
+    close(out, ref, 5e-5, 5e-5, f"{form} output")
+    if per_tile:
+        per = st.reshape(B, -1, nout, 2).sum(1)
+        for b in range(B):
+            close_stats(per[b], ref[b:b + 1], gate[b:b + 1], f"per-sample stats {b}")
+    else:
+        close_stats(st.sum(0), ref, gate)
+
+
+def _wide_wgrad_random_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        k = (4, 3, 1)[i % 3]
+        out.append((rng.randint(1, 5), rng.choice([1, 5, 16, 17, 33, 64, 70]), rng.choice([1, 2, 9, 16, 29, 65]), k,
+                    rng.choice([8, 16, 24]), rng.choice([16, 32]), rng.choice([0, 1, 3, 4]), rng.choice([0, 1, 3]), 2000 + i))
+    return out
+
+
+@pytest.mark.parametrize("B,cs,ct,k,hs,ws,smode,tmode,seed", _wide_wgrad_random_cases(18, 11))
+def test_wide_wgrad_random_shapes(ops, B, cs, ct, k, hs, ws, smode, tmode, seed):
+    """Seeded sweep of the implicit-GEMM weight gradient: channel counts on neither side of any tile size, the three
+    kernel sizes, every operand mode on both operands."""
+    s_, p_ = (2, 1) if k == 4 else ((1, 1) if k == 3 else (1, 0))
+    dy, a = rnd(B, cs, hs, ws, seed=seed), rnd(B, cs, hs, ws, seed=seed + 1)
+    coef = torch.stack([rnd(cs, seed=seed + 2), rnd(cs, seed=seed + 3) * 0.1, rnd(cs, seed=seed + 4) * 0.1, torch.zeros(cs)], 1)
+    t = rnd(B, ct, hs * s_, ws * s_, seed=seed + 5)
+    tcoef = torch.stack([rnd(ct, seed=seed + 6), torch.zeros(ct), rnd(ct, seed=seed + 7) * 0.2, torch.zeros(ct)], 1)
+    w = torch.zeros(cs, ct, k, k, requires_grad=True)
+    F.conv2d(load_ref(t, tmode, tcoef), w, None, stride=s_, padding=p_).backward(load_ref(dy, smode, coef, a))
+    dst = torch.empty(cs, ct, k, k, device=DEV)
+    ops.wgrad(ops.Op(dy.to(DEV), smode, coef.to(DEV) if smode >= 2 else None, p1=a.to(DEV) if smode == 4 else None),
+              ops.Op(t.to(DEV), tmode, tcoef.to(DEV) if tmode >= 2 else None), dst, B, cs, ct, hs, ws, k)
+    close(dst, w.grad, 5e-5, 5e-5 * max(w.grad.abs().max().item(), 1e-6), "wide wgrad")
+
+
 # =============================================================================== wgrad
 @pytest.mark.parametrize("cs,ct,k,hs,ones,B", [
     (8, 3, 4, 64, True, 3), (16, 8, 4, 32, False, 3), (16, 16, 4, 16, False, 5), (16, 16, 3, 16, False, 5),
