@@ -246,7 +246,7 @@ struct RowPrefetch {
 //                  other slabs are zeroed (per-sample BatchNorm sums the slabs of a sample).
 // wpk: the packed weights (wide_pack_kernel, same <FORM, TAPS, NPW>).
 template <int FORM, int TAPS, int NPW>
-__global__ __launch_bounds__(256) void conv_wide_kernel(Operand in, const float *__restrict__ wpk, float *__restrict__ out,
+__global__ __launch_bounds__(256, (FORM == W_S1 && TAPS == 9 && NPW == 4) ? 3 : 2) void conv_wide_kernel(Operand in, const float *__restrict__ wpk, float *__restrict__ out,
                                                         Epilogue ep, int B, int Cphys, int CIN, int NOUT, int H, int W,
                                                         int nslabs, int per_tile)
 {
@@ -541,7 +541,7 @@ constexpr int WG_CSS = 130;            // S channel stride: the 16 channel lanes
 
 // grid (x: persistent over (sample, tile) units -> slab x, y: passes of NCTP T channels, z: passes of 64 S channels)
 template <int KK>
-__global__ __launch_bounds__(256) void wgrad_wide_kernel(Operand S, Operand T, float *__restrict__ slabs, int B, int CS,
+__global__ __launch_bounds__(256, 2) void wgrad_wide_kernel(Operand S, Operand T, float *__restrict__ slabs, int B, int CS,
                                                          int CT, int CTphys, int Hs, int Ws, int nslabs)
 {
     using G = WgGeom<KK>;
