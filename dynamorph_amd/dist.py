@@ -111,6 +111,22 @@ def allreduce_grads_(params, group=None):
         off += g.numel()
 
 
+def gather_shards(local, group=None):
+    """Host arrays of the contiguous per-rank shards (shard_range order) -> the full arrays, on every rank, in rank order
+    = input order.  The data path itself has no collective; this is the final hand-over of results on the host."""
+    if world_size(group) == 1:
+        return local
+    import numpy as np
+    parts = [None] * world_size(group)
+    dist.all_gather_object(parts, local, group=group)
+    def cat(arrs):
+        arrs = [a for a in arrs if a.shape[0] > 0] or [arrs[0]]          # ranks with an empty shard contribute nothing
+        return np.concatenate(arrs, 0)
+    if isinstance(local, (tuple, list)):
+        return type(local)(cat([p[i] for p in parts]) for i in range(len(local)))
+    return cat(parts)
+
+
 def max_over_ranks(value, device=None, group=None):
     """Scalar max over ranks (bench timing contract)."""
     if world_size(group) == 1:

@@ -60,6 +60,21 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
     return torch.cat(z_bs, 0).numpy(), torch.cat(z_as, 0).numpy()
 
 
+def encode_patches_sharded(model, patches, device="cuda:0", batch_size=1024, zscore_on_device=False, group=None):
+    """encode_patches over a torch.distributed group: patches are independent (per-sample BatchNorm statistics), so rank r
+    encodes the contiguous shard dist.shard_range(N, r, world) with no collective on the data path, and the (N, D*h*w)
+    results are handed over on the host in rank order = input order (patch_VAE.py:454,459 stack in file-path order).
+    BatchNorm running statistics advance per rank by that rank's shard only (they are not part of the outputs)."""
+    from . import dist as D
+    import torch.distributed as tdist
+    patches = torch.as_tensor(patches)
+    world = D.world_size(group)
+    rank = tdist.get_rank(group) if world > 1 else 0
+    lo, hi = D.shard_range(patches.shape[0], rank, world)
+    z_b, z_a = encode_patches(model, patches[lo:hi], device=device, batch_size=batch_size, zscore_on_device=zscore_on_device)
+    return D.gather_shards((z_b, z_a), group=group) if world > 1 else (z_b, z_a)
+
+
 def process_VAE(raw_folder, supp_folder, sites, config_, gpu=0, network_module=None, **kwargs):
     """Same contract as the reference: reads <raw>/<well>_file_paths.pkl and <well>_static_patches.pkl,
     loads <weights>/model.pt, writes <raw>/<model_name>/<well>_latent_space[_after].pkl (protocol 4)."""

@@ -53,6 +53,12 @@ def _worker(rank, world, port, out_dir):
         p.grad = p.grad.clone()
     D.allreduce_grads_(plist)
     helper = torch.cat([p.grad.reshape(-1) for p in fp.params])
+    # inference hand-over: contiguous shards gathered on the host in rank order
+    n_items = 7
+    a, b_ = D.shard_range(n_items, rank, world)
+    full = np.arange(n_items * 3, dtype=np.float32).reshape(n_items, 3)
+    got = D.gather_shards((full[a:b_], 2 * full[a:b_]))
+    assert np.array_equal(got[0], full) and np.array_equal(got[1], 2 * full)
     t = D.max_over_ranks(1.0 + rank)
     torch.save({"flat0": flat0, "local": local, "mean": fp.grad.clone(), "helper": helper, "tmax": t, "range": (lo, hi)},
                os.path.join(out_dir, f"rank{rank}.pt"))
