@@ -171,3 +171,16 @@ def test_encode_patches_wide_vq_vae_per_sample():
     assert flips <= za.shape[1] // 200, flips
     assert int(m.enc[2].num_batches_tracked) == N
     np.testing.assert_allclose(m.enc[2].running_var.cpu().numpy(), ref.enc[2].running_var.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_encode_patches_sharded_single_process_is_encode_patches():
+    import copy
+    import dynamorph_amd
+    from dynamorph_amd.patch_vae import encode_patches, encode_patches_sharded
+    torch.manual_seed(5)
+    m1 = dynamorph_amd.VQ_VAE().to("cuda:0")
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(5, 2, 128, 128, generator=torch.Generator().manual_seed(1))
+    a = encode_patches(m1, x, device="cuda:0", batch_size=2)
+    b = encode_patches_sharded(m2, x, device="cuda:0", batch_size=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
