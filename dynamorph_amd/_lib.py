@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdynamorph_hip.so")
 
 DM_LOAD_IDENT, DM_LOAD_RELU, DM_LOAD_AFFINE, DM_LOAD_AFFINE_RELU, DM_LOAD_AFFINE2 = range(5)
+DM_VQ_AUTO, DM_VQ_EXACT, DM_VQ_MFMA = range(3)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -45,6 +46,7 @@ SIGNATURES = {
     "dm_vq_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dm_vq_num_blocks": (C.c_int, [i64]),
     "dm_vq_forward": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, vp]),
+    "dm_vq_forward_variant": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, C.c_int, vp]),
     "dm_vq_decode": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_vq_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp, vp]),
     "dm_vq_backward": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),

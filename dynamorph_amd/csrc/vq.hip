@@ -12,25 +12,82 @@
 // codebook is first re-laid out as [K/2][D][2] so a pair's operands are adjacent, staged in
 // LDS per workgroup and read with wave-uniform (broadcast) ds_read_b128.
 #include "dm_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int VQ_BLOCK = 256;
 constexpr int VQ_MAX_LDS_HIST = 4096;
 
-__global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ cbT, int K, int D,
+// Workspace of dm_vq_forward (float offsets; every region starts on a 16-byte boundary):
+//   header  4 ints: [0] = positions that went through the exact re-check of the MFMA path (statistics)
+//   cbT     [ceil(K/2)][D][2]   pair-interleaved codebook of the exact kernel (v1)
+//   cbA     [K64/64][4 kt][SQ][64 lanes][4]  A operand of v_mfma_f32_16x16x4_f32: -2 * e[64 cc + 16 kt + (lane & 15)]
+//           [4 (4 sq + j) + (lane >> 4)], zero beyond K / D  (K64 = K rounded up to 64, SQ = ceil(D / 16))
+//   nrm     [K64]  ||e_k||^2 summed in double, rounded once; VQ2_PAD_NORM beyond K (such a code never wins)
+//   cbH     [K][4 h][D / 4]  e[k][4 s + h]: the codebook row in the order a lane of the MFMA kernel holds z
+constexpr int VQ2_HDR = 4;
+constexpr float VQ2_PAD_NORM = 3.0e38f;
+struct Vq2Layout { long long cbT, cbA, nrm, cbH, total; };
+
+Vq2Layout vq2_layout(int K, int D)
+{
+    const long long K64 = ((long long)K + 63) / 64 * 64;
+    const int SQ = (D / 4 + 3) / 4;
+    Vq2Layout L;
+    long long o = VQ2_HDR;
+    L.cbT = o; o += (long long)((K + 1) / 2) * 2 * D; o = (o + 3) & ~3LL;
+    L.cbA = o; o += K64 * 16 * SQ;
+    L.nrm = o; o += K64;
+    L.cbH = o; o += (long long)K * D; o = (o + 3) & ~3LL;
+    L.total = o;
+    return L;
+}
+
+__global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ ws, Vq2Layout L, int K, int D,
                                int *__restrict__ hist, double *__restrict__ slabs, int nslabs)
 {
     // also clears the outputs the forward kernel accumulates into (no separate memset launches)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) hist[i] = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nslabs; i += gridDim.x * blockDim.x) slabs[i] = 0.0;
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int i = t0; i < K; i += nt) hist[i] = 0;
+    for (int i = t0; i < nslabs; i += nt) slabs[i] = 0.0;
+    if (t0 < VQ2_HDR) reinterpret_cast<int *>(ws)[t0] = 0;
     // cbT[p][d][j] = cb[2p + j][d]; for odd K the missing partner repeats code K-1 (never selected).
+    float *__restrict__ cbT = ws + L.cbT;
     const int npairs = (K + 1) >> 1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npairs * D * 2; i += gridDim.x * blockDim.x) {
+    for (int i = t0; i < npairs * D * 2; i += nt) {
         const int j = i & 1, d = (i >> 1) % D, p = (i >> 1) / D;
         int k = 2 * p + j;
         if (k >= K) k = K - 1;
         cbT[i] = cb[(long long)k * D + d];
+    }
+    if (D & 3) return;                                     // the MFMA path needs D % 4 == 0
+    const int S = D / 4, SQ = (S + 3) / 4;
+    const long long K64 = ((long long)K + 63) / 64 * 64;
+    float *__restrict__ cbA = ws + L.cbA;
+    for (long long i = t0; i < K64 * 16 * SQ; i += nt) {
+        const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        long long rest = i >> 8;
+        const int sq = (int)(rest % SQ); rest /= SQ;
+        const int kt = (int)(rest & 3);
+        const long long cc = rest >> 2;
+        const long long code = cc * 64 + kt * 16 + (lane & 15);
+        const int d = 4 * (4 * sq + j) + (lane >> 4);
+        cbA[i] = (code < K && d < D) ? -2.f * cb[code * D + d] : 0.f;
+    }
+    float *__restrict__ nrm = ws + L.nrm;
+    for (long long k = t0; k < K64; k += nt) {
+        double acc = 0.0;
+        if (k < K)
+            for (int d = 0; d < D; ++d) { const double e = (double)cb[k * D + d]; acc += e * e; }
+        nrm[k] = k < K ? (float)acc : VQ2_PAD_NORM;
+    }
+    float *__restrict__ cbH = ws + L.cbH;
+    for (long long i = t0; i < (long long)K * D; i += nt) {
+        const int s = (int)(i % S), h = (int)((i / S) & 3);
+        const long long k = i / D;
+        cbH[i] = cb[k * D + 4 * s + h];
     }
 }
 
@@ -193,6 +250,385 @@ __global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : (D <= 64 ? 2 : 1))) void v
     }
 }
 
+// ================================================================================================================
+// v2: MFMA prefilter + exact re-check -- same indices as the kernel above, a third of its instructions.
+//
+// The exact distance costs 3*K*D non-fused VALU operations per position.  argmin_k |z - e_k|^2 = argmin_k S(k) with
+// S(k) = |e_k|^2 - 2 z.e_k, a (positions x D) . (D x K) product: v_mfma_f32_16x16x4_f32 with the codes on the rows
+// (A = -2 e, exact), the positions on the columns (B = z) and |e_k|^2 as the initial accumulator gives
+// s(k) = fl-chain(S(k)) at 2*K*D FLOP on the matrix pipe.  The result is only an approximation of the reference's
+// d_ref(k) = sum_d fl(fl(z_d - e_kd)^2) (summed in ATen's order), so it is used as a FILTER:
+//   * per position the two smallest s' are tracked (s' = s with its low 6 bits replaced by the code's number inside
+//     the 64-code chunk, so the minimum carries its own index: v_and_or, v_med3, v_min per score);
+//   * error bounds, u = 2^-24, A = |z|^2 + 2 max_k |e_k|^2:
+//       |s'(k) - S(k)| <= (D + 1) u A   (rounded |e|^2 + D fused multiply-adds, every partial sum <= A in magnitude)
+//                         + 128 u A     (64 ulp of the index bits)                         =: eta
+//       |d_ref(k) - D(k)| <= (D/16 + 18) u D(k) =: rho D(k),  D(k) = |z|^2 + S(k)  (3 roundings per square, then at
+//                                                              most 15 + D/16 - 1 additions of non-negative terms);
+//     with g' = s'(j) - s'(k*) the reference orders d_ref(k*) < d_ref(j) whenever
+//       g' > [2 eta + 2 rho (|z|^2 + s'(k*)) + 2 rho eta] / (1 - rho);
+//     the kernel tests g' > tol with tol = 2 x (2 eta + 2 rho max(|z|^2 + s'(k*), 0)) (a factor 2 of margin over the
+//     first-order bound, |z|^2 from an fp32 dot product) for the runner-up, which then holds for every other code;
+//   * a position that fails the test (1e-3 of them on N(0,1) data; every position whose z or codebook is not finite,
+//     because tol is then inf or NaN) is re-evaluated EXACTLY over all K codes by the whole wave: lane l takes codes
+//     l, l + 64, ... in the reference's arithmetic and order, first minimum and torch.argmax(-dist) NaN rule included.
+// So the index is the reference's for every position; only the work per position differs.
+//
+// Layout: a wave owns a chunk of 64 consecutive positions of one sample; lane (h = lane >> 4, c = lane & 15) loads
+// z[d = 4 s + h][4 c .. 4 c + 3] as one 16-byte load per s (16 lanes x 16 B = 256 B contiguous per row), which is
+// exactly the B operand of step s for the four position tiles t = 0..3 (column c of tile t = position 4 c + t): no
+// transpose, no LDS.  The 16 x 16 result tile has code 16 kt + 4 h + r in register r, so a position's 64 scores sit in
+// 16 registers of 4 lanes: 16 in-lane updates, then two cross-lane steps (lanes l ^ 16, l ^ 32).
+constexpr int VQ2_BLOCK = 256;
+
+__device__ __forceinline__ float vq2_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vq2_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vq2_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vq2_med3(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vq2_embed(float v, unsigned code)
+{
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & ~63u) | code);
+}
+__device__ __forceinline__ float vq2_or(float v, unsigned bits)
+{
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) | bits);
+}
+
+// Exchange across the lane pairs (l, l ^ 16) resp. (l, l ^ 32) as ONE VALU instruction (v_permlane16_swap /
+// v_permlane32_swap, gfx950) instead of two ds_bpermute round trips through the LDS crossbar: with both operands = x
+// the swap leaves the even rows' (lower half's) value in `lo` and the odd rows' (upper half's) in `hi`, in BOTH lanes of
+// a pair, so a symmetric combine of (lo, hi) gives every lane the pair's result.
+template <int M>
+__device__ __forceinline__ void vq2_pair(unsigned x, unsigned &lo, unsigned &hi)
+{
+    if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        lo = r0; hi = r1;
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        lo = r0; hi = r1;
+    }
+}
+template <int M>
+__device__ __forceinline__ void vq2_pair(float x, float &lo, float &hi)
+{
+    unsigned l, h;
+    vq2_pair<M>(__builtin_bit_cast(unsigned, x), l, h);
+    lo = __builtin_bit_cast(float, l); hi = __builtin_bit_cast(float, h);
+}
+
+// exact distance of the reference (vq_vae.py:65): blocks of 16 consecutive d summed sequentially, block sums sequentially
+template <int D>
+__device__ __forceinline__ float vq_exact_dist(const float (&zv)[D], const float *__restrict__ e)
+{
+    float total = 0.f;
+#pragma unroll
+    for (int d0 = 0; d0 < D; d0 += 16) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = d0; d < d0 + 16 && d < D; ++d) {
+            const float diff = zv[d] - e[d];
+            const float sq = diff * diff;
+            acc = (d == d0) ? sq : acc + sq;
+        }
+        total = (d0 == 0) ? acc : total + acc;
+    }
+    return total;
+}
+
+template <int D, bool SINGLE, bool PREFETCH, int MINW>
+__global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
+    const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbA,
+    const float *__restrict__ nrm, const float *__restrict__ cbH, long long *__restrict__ idx,
+    float *__restrict__ out, double *__restrict__ sse_slabs, int *__restrict__ hist, int *__restrict__ hdr,
+    int K, int HW, long long P)
+{
+    constexpr int S = D / 4, SQ = (S + 3) / 4;
+    constexpr int CHUNK_F4 = 4 * SQ * 64;                          // f32x4 of packed A operand per 64-code chunk
+    constexpr int PIECE = SINGLE ? 1 : (2048 / CHUNK_F4 > 0 ? 2048 / CHUNK_F4 : 1);   // code chunks per 32 KB LDS piece
+    constexpr float U = 5.9604645e-8f;                             // 2^-24
+    constexpr float TOL_A = 4.f * (D + 129) * U, TOL_D = 4.f * (D / 16 + 18) * U;
+    __shared__ f32x4 s_A[SINGLE ? 1 : PIECE * CHUNK_F4];
+    __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];
+    __shared__ f32x4 s_H[SINGLE ? 64 * S : 1];                       // small codebooks: the lane-ordered rows (cbH) for the gather
+    __shared__ int s_hist[SINGLE ? 64 : VQ_MAX_LDS_HIST];
+    __shared__ double s_red[4];
+    __shared__ float s_em[4];
+    const int lane = threadIdx.x & 63, h = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // provably wave-uniform: scalar branches
+    const bool lds_hist = K <= VQ_MAX_LDS_HIST;
+    if (lds_hist)
+        for (int k = threadIdx.x; k < K; k += VQ2_BLOCK) s_hist[k] = 0;
+    if constexpr (SINGLE) {
+        static_assert(S % 4 == 0 || S == 2, "embedding_dim 8, 16, 32 or 64");
+        for (int i = threadIdx.x; i < K * S; i += VQ2_BLOCK) reinterpret_cast<float *>(s_H)[i] = cbH[i];
+    }
+
+    // max_k |e_k|^2 for the tolerance; a non-finite codebook makes it inf: every position takes the exact path
+    float emax;
+    {
+        float em = 0.f;
+        bool bad = false;
+        for (int k = threadIdx.x; k < K; k += VQ2_BLOCK) {
+            const float v = nrm[k];
+            bad |= !(v < __builtin_inff());
+            em = fmaxf(em, v);
+        }
+        em = bad ? __builtin_inff() : em;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) em = fmaxf(em, __shfl_xor(em, o, 64));
+        if (lane == 0) s_em[wave] = em;
+        __syncthreads();
+        emax = fmaxf(fmaxf(s_em[0], s_em[1]), fmaxf(s_em[2], s_em[3]));
+    }
+
+    f32x4 areg[4][SQ], nreg[4];
+    if constexpr (SINGLE) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int sq = 0; sq < SQ; ++sq) areg[kt][sq] = reinterpret_cast<const f32x4 *>(cbA)[(kt * SQ + sq) * 64 + lane];
+            nreg[kt] = *reinterpret_cast<const f32x4 *>(nrm + kt * 16 + h * 4);
+        }
+    }
+
+    // Chunk bookkeeping in 32-bit scalars, advanced incrementally: a 64-bit `pos / HW` per iteration is a ~150-instruction
+    // software division in front of the loads whose address it feeds.
+    const unsigned NC = (unsigned)(P >> 6);                    // chunks of 64 positions (HW % 64 == 0: never across samples)
+    const unsigned cps = (unsigned)HW >> 6;                    // chunks per sample
+    const unsigned qstep = 4u * gridDim.x;
+    const unsigned step_b = qstep / cps, step_c = qstep - step_b * cps;
+    const int ncc = (K + 63) >> 6;                             // 64-code chunks
+    int staged = -1;                                           // first code chunk of the piece held in LDS
+    double sse = 0.0;
+    int nflag = 0;
+
+    // (a wave without a chunk -- the tail of the last quad -- loads the last chunk and computes nothing)
+    auto zptr = [&](unsigned chunk, unsigned b, unsigned cw) {
+        const bool ok = chunk < NC;
+        const unsigned bb = ok ? b : NC / cps - 1, cc = ok ? cw : cps - 1;
+        return ((long long)bb * D + h) * (long long)HW + (long long)(cc * 64u + 4u * c);
+    };
+    unsigned chunk = blockIdx.x * 4u + (unsigned)wave;
+    unsigned cb_ = chunk / cps, cw_ = chunk - cb_ * cps;       // sample and chunk-in-sample of `chunk`
+    f32x4 zr[S];
+    {
+        const long long o = zptr(chunk, cb_, cw_);
+#pragma unroll
+        for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
+    }
+    for (unsigned q = blockIdx.x; q * 4u < NC; q += gridDim.x) {
+        const bool act = chunk < NC;                           // wave-uniform
+        const long long zoff = zptr(chunk, cb_, cw_);
+        unsigned nchunk = chunk + qstep, nb = cb_ + step_b, nw = cw_ + step_c;
+        if (nw >= cps) { nw -= cps; ++nb; }
+        // the next chunk's z is requested now and lands under this chunk's MFMAs
+        f32x4 zn[PREFETCH ? S : 1];
+        if constexpr (PREFETCH) {
+            const long long o = zptr(nchunk, nb, nw);
+#pragma unroll
+            for (int s = 0; s < S; ++s) zn[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
+        }
+
+        float m1[4], m2[4];
+        int c1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { m1[t] = 3.4028235e38f; m2[t] = 3.4028235e38f; c1[t] = 0; }
+
+        // scores of one 64-code chunk against the 4 position tiles; na: the chunk's |e|^2, aq(kt, sq): 4 K-steps of A
+        auto chunk_scores = [&](const f32x4 (&na)[4], auto &&aq, int ccg) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int sq = 0; sq < SQ; ++sq) {
+                    f32x4 a4[4];
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) a4[kt] = aq(kt, sq);
+                    // K-step outer, code tile inner: consecutive MFMAs belong to four independent accumulator chains
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int s = 4 * sq + j;
+                        if (s < S) {
+#pragma unroll
+                            for (int kt = 0; kt < 4; ++kt)
+                                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[kt][j], zr[s][t], s == 0 ? na[kt] : acc[kt], 0, 0, 0);
+                        }
+                    }
+                }
+                const float pm1 = m1[t];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = vq2_embed(acc[kt][r], (unsigned)(kt * 16 + r));
+                        m2[t] = vq2_med3(m1[t], m2[t], v);
+                        m1[t] = vq2_min(m1[t], v);
+                    }
+                }
+                if constexpr (!SINGLE) c1[t] = m1[t] < pm1 ? ccg : c1[t];
+            }
+        };
+
+        if constexpr (SINGLE) {
+            if (act) chunk_scores(nreg, [&](int kt, int sq) { return areg[kt][sq]; }, 0);
+        } else {
+            for (int p0 = 0; p0 < ncc; p0 += PIECE) {
+                const int pn = min(PIECE, ncc - p0);
+                if (staged != p0) {                            // (one piece in all: staged once per workgroup)
+                    __syncthreads();                           // the previous piece has been consumed
+                    const f32x4 *__restrict__ ga = reinterpret_cast<const f32x4 *>(cbA) + (long long)p0 * CHUNK_F4;
+                    for (int i = threadIdx.x; i < pn * CHUNK_F4; i += VQ2_BLOCK) s_A[i] = ga[i];
+                    const f32x4 *__restrict__ gn = reinterpret_cast<const f32x4 *>(nrm) + (long long)p0 * 16;
+                    for (int i = threadIdx.x; i < pn * 16; i += VQ2_BLOCK) s_n[i] = gn[i];
+                    staged = p0;
+                    __syncthreads();
+                }
+                if (act) {
+                    for (int cc = 0; cc < pn; ++cc) {
+                        f32x4 na[4];
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt) na[kt] = s_n[cc * 16 + kt * 4 + h];
+                        const f32x4 *__restrict__ ab = s_A + cc * CHUNK_F4 + lane;
+                        // (conflict-free ds_read_b128: consecutive lanes, consecutive 16-byte slots)
+                        chunk_scores(na, [&](int kt, int sq) { return ab[(kt * SQ + sq) * 64]; }, p0 + cc);
+                    }
+                }
+            }
+        }
+
+        if (act) {
+            const long long pos0 = (long long)chunk << 6;
+            const unsigned hbits = (unsigned)h << 2;
+            int kb[4];
+            // one instantiation per position tile (the tile number is a compile-time constant)
+            auto finish_tile = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                float a1 = vq2_or(m1[t], hbits), a2 = vq2_or(m2[t], hbits);
+                int cc1 = c1[t];
+                float zz = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) zz = fmaf(zr[s][t], zr[s][t], zz);
+                auto merge = [&](auto mc) {
+                    constexpr int M = decltype(mc)::value;
+                    float l1, h1, l2, h2, lz, hz;
+                    vq2_pair<M>(a1, l1, h1);
+                    vq2_pair<M>(a2, l2, h2);
+                    vq2_pair<M>(zz, lz, hz);
+                    if constexpr (!SINGLE) {
+                        unsigned lc, hc;
+                        vq2_pair<M>((unsigned)cc1, lc, hc);
+                        cc1 = (int)(h1 < l1 ? hc : lc);
+                    }
+                    a2 = vq2_min3(l2, h2, vq2_max(l1, h1));
+                    a1 = vq2_min(l1, h1);
+                    zz = lz + hz;
+                };
+                merge(std::integral_constant<int, 16>{});
+                merge(std::integral_constant<int, 32>{});
+                const float tol = TOL_A * (zz + 2.f * emax) + TOL_D * fmaxf(zz + a1, 0.f) + 1e-30f;
+                const bool flagged = !((a2 - a1) > tol);       // also true when anything is NaN / inf
+                kb[t] = (SINGLE ? 0 : cc1 * 64) + (int)(__builtin_bit_cast(unsigned, a1) & 63u);
+                unsigned long long fm = __ballot(flagged) & 0xFFFFull;      // the four h rows agree: take row 0
+                while (fm) {
+                    const int col = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    float zv[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        // (through a scalar temporary: __builtin_bit_cast applied to the vector-element lvalue
+                        // zr[s][t] itself reads element 0 whatever t is -- clang 7.2, seen in the IR)
+                        const float zc = zr[d >> 2][t];
+                        zv[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zc), (d & 3) * 16 + col));
+                    }
+                    float bd = __builtin_inff();
+                    int bk = 0x7fffffff;
+                    if (lane < K) { bd = vq_exact_dist<D>(zv, cb + (long long)lane * D); bk = lane; }
+                    for (int k = lane + 64; k < K; k += 64) {
+                        const float dk = vq_exact_dist<D>(zv, cb + (long long)k * D);
+                        const bool bt = vq_better(dk, bd);
+                        bd = bt ? dk : bd; bk = bt ? k : bk;
+                    }
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) {
+                        const float od = __shfl_xor(bd, m, 64);
+                        const int ok = __shfl_xor(bk, m, 64);
+                        // the other lane's candidate wins: NaN beats numbers, equal distances (and two NaNs) go to the smaller code
+                        const int an = bd != bd, bn = od != od, lk = ok < bk;
+                        const int other = (bn & ((an ^ 1) | lk)) | ((bn ^ 1) & (an ^ 1) & ((od < bd) | ((od == bd) & lk)));
+                        bd = other ? od : bd; bk = other ? ok : bk;
+                    }
+                    kb[t] = (c == col) ? bk : kb[t];
+                    ++nflag;
+                }
+            };
+            finish_tile(std::integral_constant<int, 0>{});
+            finish_tile(std::integral_constant<int, 1>{});
+            finish_tile(std::integral_constant<int, 2>{});
+            finish_tile(std::integral_constant<int, 3>{});
+
+            // gather + straight-through value + squared error, in the layout the lane already holds
+            float ssef = 0.f;
+            const long long obase = zoff;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *__restrict__ eh = (SINGLE ? reinterpret_cast<const float *>(s_H) : cbH) + ((long long)kb[t] * 4 + h) * S;
+                float ev[S];
+                if constexpr (S % 4 == 0) {
+#pragma unroll
+                    for (int s4 = 0; s4 < S / 4; ++s4) {
+                        const f32x4 v = reinterpret_cast<const f32x4 *>(eh)[s4];
+                        ev[4 * s4] = v.x; ev[4 * s4 + 1] = v.y; ev[4 * s4 + 2] = v.z; ev[4 * s4 + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) ev[s] = eh[s];
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float diff = ev[s] - zr[s][t];
+                    zr[s][t] = zr[s][t] + diff;                // z + (q - z), vq_vae.py:71
+                    ssef += diff * diff;
+                }
+            }
+            if (out) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) *reinterpret_cast<f32x4 *>(out + obase + (long long)(4 * s) * HW) = zr[s];
+            }
+            sse += (double)ssef;
+            if (idx && h < 2) {
+                long long pair[2] = {(long long)(h ? kb[2] : kb[0]), (long long)(h ? kb[3] : kb[1])};
+                *reinterpret_cast<f32x4 *>(idx + pos0 + 4 * c + 2 * h) = *reinterpret_cast<const f32x4 *>(pair);
+            }
+            const int kk = h == 0 ? kb[0] : (h == 1 ? kb[1] : (h == 2 ? kb[2] : kb[3]));
+            if (lds_hist) atomicAdd(&s_hist[kk], 1);
+            else atomicAdd(&hist[kk], 1);
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) zr[s] = zn[s];
+        } else if ((q + gridDim.x) * 4u < NC) {
+            const long long o = zptr(nchunk, nb, nw);
+#pragma unroll
+            for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
+        }
+        chunk = nchunk; cb_ = nb; cw_ = nw;
+    }
+
+    const double tot = block_sum(sse, s_red);
+    if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
+    if (lane == 0 && nflag) atomicAdd(hdr, nflag);
+    if (lds_hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += VQ2_BLOCK) {
+            const int cnt = s_hist[k];
+            if (cnt) atomicAdd(&hist[k], cnt);
+        }
+    }
+}
+
 __global__ void vq_decode_kernel(const long long *__restrict__ idx, const float *__restrict__ cb,
                                  float *__restrict__ q, int D, int K, int HW, long long P)
 {
@@ -290,31 +726,78 @@ bool vq_dim_supported(int D) { return D == 8 || D == 16 || D == 32 || D == 64 ||
 
 extern "C" size_t dm_vq_workspace_bytes(int K, int D)
 {
-    return (size_t)((K + 1) / 2) * 2 * (size_t)D * sizeof(float);
+    if (K <= 0 || D <= 0) return 0;
+    return (size_t)vq2_layout(K, D).total * sizeof(float);
 }
 
-constexpr int VQ_PP = 2;      // positions per lane in the forward kernel (1 for embedding_dim 64: registers)
+constexpr int VQ_PP = 2;      // positions per lane in the exact kernel (1 for embedding_dim 64: registers)
 
 extern "C" int dm_vq_num_blocks(int64_t positions)
 {
     return (int)((positions + VQ_BLOCK - 1) / VQ_BLOCK);     // upper bound over all variants; unused slabs are zeroed
 }
 
-extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *out,
-                             double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
-                             void *workspace, size_t workspace_bytes, void *stream)
+namespace {
+bool vq2_applicable(const float *z, const int64_t *idx, const float *out, const void *ws, int D, int HW)
+{
+    const uintptr_t al = (uintptr_t)z | (uintptr_t)idx | (uintptr_t)out | (uintptr_t)ws;
+    return (D == 8 || D == 16 || D == 32 || D == 64) && HW % 64 == 0 && (al & 15) == 0;
+}
+}  // namespace
+
+extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
+                                     double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                                     void *workspace, size_t workspace_bytes, int variant, void *stream)
 {
     DM_REQUIRE(z && codebook && sse_slabs && hist, "dm_vq_forward: NULL pointer");
     DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
     DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d not built (8/16/32/64/128)", D);
     DM_REQUIRE(workspace && workspace_bytes >= dm_vq_workspace_bytes(K, D), "dm_vq_forward: workspace too small");
+    DM_REQUIRE(variant >= DM_VQ_AUTO && variant <= DM_VQ_MFMA, "dm_vq_forward: bad variant %d", variant);
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)B * H * W;
-    float *cbT = (float *)workspace;
-    const int n = ((K + 1) / 2) * 2 * D;
+    const Vq2Layout L = vq2_layout(K, D);
+    float *ws = (float *)workspace;
+    const bool can2 = vq2_applicable(z, idx, out, workspace, D, H * W);
+    DM_REQUIRE(variant != DM_VQ_MFMA || can2,
+               "dm_vq_forward: the MFMA variant needs embedding_dim 8/16/32/64, H*W %% 64 == 0 and 16-byte aligned tensors");
+    const bool use2 = variant == DM_VQ_MFMA || (variant == DM_VQ_AUTO && can2);
+    const long long n = L.total;
     const int nslabs = dm_vq_num_blocks(P);
-    hipLaunchKernelGGL(vq_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, codebook, cbT, K, D, (int *)hist, sse_slabs, nslabs);
-    // (vq_prep_kernel cleared hist and all slabs: with PP positions per lane there are fewer workgroups than slabs)
+    int pgrid = (int)((n + 255) / 256);
+    if (pgrid > 1024) pgrid = 1024;
+    hipLaunchKernelGGL(vq_prep_kernel, dim3(pgrid), dim3(256), 0, s, codebook, ws, L, K, D, (int *)hist, sse_slabs, nslabs);
+    // (vq_prep_kernel cleared hist and all slabs: there are fewer workgroups than slabs)
+    if (use2) {
+        const long long quads = ((P >> 6) + 3) / 4;
+        const char *tune = getenv("DM_VQ2_TUNE");              // experiment switches, removed once measured
+        const int tv = tune ? atoi(tune) : 0;
+        const char *tw = getenv("DM_VQ2_WGS");
+        const int wgs_env = tw ? atoi(tw) : 0;
+#define DM_VQ2(DD, SINGLE_, PF, MINW, WGS)                                                                           \
+    {                                                                                                                \
+        const int wgs = wgs_env > 0 ? wgs_env : (WGS);                                                               \
+        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, PF, MINW>), dim3((unsigned)(quads < 256 * wgs ? quads : 256 * wgs)), \
+                           dim3(VQ2_BLOCK), 0, s, z, codebook, ws + L.cbA, ws + L.nrm, ws + L.cbH, (long long *)idx, out, \
+                           sse_slabs, (int *)hist, (int *)ws, K, H * W, P);                                          \
+    }
+        const bool single = K <= 64;
+        switch (D) {
+        case 8: if (single) DM_VQ2(8, true, true, 4, 4) else DM_VQ2(8, false, false, 3, 3) break;
+        case 16:
+            if (single) {
+                if (tv == 1) DM_VQ2(16, true, false, 4, 4)
+                else if (tv == 2) DM_VQ2(16, true, true, 3, 3)
+                else DM_VQ2(16, true, true, 4, 4)
+            } else DM_VQ2(16, false, false, 3, 3)
+            break;
+        case 32: if (single) DM_VQ2(32, true, false, 2, 2) else DM_VQ2(32, false, false, 2, 2) break;
+        default: if (single) DM_VQ2(64, true, false, 1, 1) else DM_VQ2(64, false, false, 1, 2) break;
+        }
+#undef DM_VQ2
+        return dm_launch_status("dm_vq_forward");
+    }
+    const float *cbT = ws + L.cbT;
 #define DM_VQ_FWD(DD, PP_)                                                                                   \
     hipLaunchKernelGGL((vq_forward_kernel<DD, PP_>), dim3((unsigned)((P + VQ_BLOCK * PP_ - 1) / (VQ_BLOCK * PP_))), \
                        dim3(VQ_BLOCK), 0, s, z, codebook, cbT, (long long *)idx, out, sse_slabs, (int *)hist, K, H * W, P)
@@ -327,6 +810,14 @@ extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx
     }
 #undef DM_VQ_FWD
     return dm_launch_status("dm_vq_forward");
+}
+
+extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *out,
+                             double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    return dm_vq_forward_variant(z, codebook, idx, out, sse_slabs, hist, B, D, K, H, W, workspace, workspace_bytes,
+                                 DM_VQ_AUTO, stream);
 }
 
 extern "C" int dm_vq_decode(const int64_t *idx, const float *codebook, float *q,

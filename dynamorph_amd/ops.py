@@ -78,8 +78,11 @@ def _new(shape, like, dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------- VQ
-def vq_forward(z, codebook, want_idx=True, want_out=True):
-    """Returns (idx int64 (B,H,W), out (B,D,H,W), sse_slabs, hist)."""
+def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, want_rechecked=False):
+    """Returns (idx int64 (B,H,W), out (B,D,H,W), sse_slabs, hist).
+    variant: L.DM_VQ_AUTO (default) / DM_VQ_EXACT / DM_VQ_MFMA -- same results, different kernels (include/dynamorph_hip.h).
+    want_rechecked: a fifth return value, the 1-element int32 device tensor counting the positions the MFMA kernel
+    re-evaluated exactly (0 after the exact kernel)."""
     lib = L.load()
     B, D, H, W = z.shape
     K = codebook.shape[0]
@@ -90,8 +93,11 @@ def vq_forward(z, codebook, want_idx=True, want_out=True):
     hist = _new((K,), z, torch.int32)          # cleared by dm_vq_forward itself
     wsb = lib.dm_vq_workspace_bytes(K, D)
     ws = _new((wsb // 4,), z)
-    L.check(lib.dm_vq_forward(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out), _ptr(slabs, torch.float64),
-                              _ptr(hist, torch.int32), B, D, K, H, W, _ptr(ws), wsb, _stream()), "dm_vq_forward")
+    L.check(lib.dm_vq_forward_variant(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out),
+                                      _ptr(slabs, torch.float64), _ptr(hist, torch.int32), B, D, K, H, W, _ptr(ws), wsb,
+                                      variant, _stream()), "dm_vq_forward")
+    if want_rechecked:
+        return idx, out, slabs, hist, ws[:1].view(torch.int32)
     return idx, out, slabs, hist
 
 

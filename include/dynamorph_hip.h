@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 103
+#define DM_VERSION 104
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -109,6 +109,18 @@ int dm_vq_num_blocks(int64_t positions);
 int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *out,
                   double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same with the kernel chosen by the caller (tests and measurements; dm_vq_forward = DM_VQ_AUTO):
+ *   DM_VQ_EXACT  every distance in the reference's arithmetic (3*K*D non-fused operations per position);
+ *   DM_VQ_MFMA   |e|^2 - 2 z.e on the matrix pipe as a filter, the exact arithmetic only for positions whose two best
+ *                scores are closer than the proven error bound (csrc/vq.hip) -- identical indices; needs
+ *                embedding_dim 8/16/32/64, H*W a multiple of 64 and 16-byte aligned tensors (else a negative return);
+ *   DM_VQ_AUTO   DM_VQ_MFMA where it applies, DM_VQ_EXACT otherwise.
+ * After a DM_VQ_MFMA call the first int32 of `workspace` holds the number of positions that took the exact path. */
+enum { DM_VQ_AUTO = 0, DM_VQ_EXACT = 1, DM_VQ_MFMA = 2 };
+int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
+                          double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                          void *workspace, size_t workspace_bytes, int variant, void *stream);
 
 /* vq_vae.py:105-116 decode_inputs: q[b,d,h,w] = codebook[idx[b,h,w], d]. */
 int dm_vq_decode(const int64_t *idx, const float *codebook, float *q,

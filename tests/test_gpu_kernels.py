@@ -61,11 +61,17 @@ def load_ref(p0, mode, coef=None, p1=None):
 
 
 # =================================================================================== VQ
-def test_vq_forward_bit_exact_golden(ops, golden):
+from dynamorph_amd._lib import DM_VQ_AUTO, DM_VQ_EXACT, DM_VQ_MFMA          # noqa: E402
+
+VQ_VARIANTS = [pytest.param(DM_VQ_EXACT, id="exact"), pytest.param(DM_VQ_MFMA, id="mfma")]
+
+
+@pytest.mark.parametrize("variant", VQ_VARIANTS)
+def test_vq_forward_bit_exact_golden(ops, golden, variant):
     g4, g5 = golden("g4_vq_indices.npz"), golden("g5_vq_forward.npz")
     z = torch.from_numpy(g5["z_before"]).to(DEV)
     cb = torch.from_numpy(g4["codebook"]).to(DEV)
-    idx, out, slabs, hist = ops.vq_forward(z, cb)
+    idx, out, slabs, hist = ops.vq_forward(z, cb, variant=variant)
     sc = ops.vq_finalize(slabs, hist, idx.numel(), 16, 0.25).cpu().numpy()
     assert np.array_equal(idx.cpu().numpy(), g4["idx"])
     assert np.array_equal(out.cpu().numpy().view(np.uint32), g5["quantized"].view(np.uint32))
@@ -76,11 +82,14 @@ def test_vq_forward_bit_exact_golden(ops, golden):
     assert torch.equal(q, torch.from_numpy(g4["codebook"])[torch.from_numpy(g4["idx"])].permute(0, 3, 1, 2))
 
 
+@pytest.mark.parametrize("variant", VQ_VARIANTS)
 @pytest.mark.parametrize("name", ["g9_vq_k4096.npz", "g9_vq_d64.npz", "g9_vq_ties.npz"])
-def test_vq_forward_stress_golden(ops, golden, name):
+def test_vq_forward_stress_golden(ops, golden, name, variant):
     g = golden(name)
     z, cb = torch.from_numpy(g["z"]).to(DEV), torch.from_numpy(g["codebook"]).to(DEV)
-    idx, out, slabs, hist = ops.vq_forward(z, cb)
+    if variant == DM_VQ_MFMA and (z.shape[2] * z.shape[3]) % 64:
+        pytest.skip("the MFMA kernel takes latent grids that are multiples of 64 positions")
+    idx, out, slabs, hist = ops.vq_forward(z, cb, variant=variant)
     assert np.array_equal(idx.cpu().numpy(), g["idx"]), name
     if "loss" in g:
         sc = ops.vq_finalize(slabs, hist, idx.numel(), z.shape[1], 0.25).cpu().numpy()
@@ -88,17 +97,117 @@ def test_vq_forward_stress_golden(ops, golden, name):
         assert abs(sc[1] - g["perplexity"]) <= 2e-5 * abs(g["perplexity"])
 
 
+def _c_oracle_idx(cvq, z, cb):
+    B, D, H, W = z.shape
+    idx_ref = np.empty((B, H, W), np.int64)
+    cvq.oracle_vq_encode(_p(z), _p(cb), _p(idx_ref), B, D, cb.shape[0], H, W)
+    return idx_ref
+
+
 @pytest.mark.parametrize("B,D,K,H,W", [(3, 16, 64, 16, 16), (2, 16, 63, 8, 12), (1, 32, 10, 4, 4), (5, 8, 7, 16, 16),
-                                       (2, 64, 40, 8, 8), (2, 128, 128, 8, 8)])
+                                       (2, 64, 40, 8, 8), (2, 128, 128, 8, 8),
+                                       # shapes of the MFMA kernel: code counts around the 64-code chunks and the 32 KB
+                                       # LDS pieces, every embedding_dim it is built for, chunk counts that are not a
+                                       # multiple of the 4 waves of a workgroup
+                                       (7, 16, 1, 8, 8), (3, 16, 65, 16, 16), (2, 16, 513, 16, 16), (1, 16, 1000, 32, 32),
+                                       (3, 8, 100, 8, 8), (3, 32, 300, 8, 16), (2, 64, 512, 16, 16), (5, 64, 129, 8, 8)])
 def test_vq_forward_vs_c_oracle(ops, cvq, B, D, K, H, W):
     z = rnd(B, D, H, W, seed=B + D + K).numpy()
     cb = rnd(K, D, seed=K).numpy()
-    idx_ref = np.empty((B, H, W), np.int64)
-    cvq.oracle_vq_encode(_p(z), _p(cb), _p(idx_ref), B, D, K, H, W)
-    idx, out, _, _ = ops.vq_forward(torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV))
-    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    idx_ref = _c_oracle_idx(cvq, z, cb)
     q = cb[idx_ref].transpose(0, 3, 1, 2)
-    assert np.array_equal(out.cpu().numpy(), z + (q - z))
+    variants = [DM_VQ_AUTO, DM_VQ_EXACT] + ([DM_VQ_MFMA] if (H * W) % 64 == 0 and D <= 64 else [])
+    for variant in variants:
+        idx, out, slabs, hist = ops.vq_forward(torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV), variant=variant)
+        assert np.array_equal(idx.cpu().numpy(), idx_ref), variant
+        assert np.array_equal(out.cpu().numpy(), z + (q - z)), variant
+        assert np.array_equal(hist.cpu().numpy(), np.bincount(idx_ref.ravel(), minlength=K)), variant
+        sse = float(slabs.sum().cpu())
+        assert abs(sse - float(((q - z).astype(np.float64) ** 2).sum())) <= 1e-6 * sse, variant
+
+
+def test_vq_mfma_rejects_what_it_cannot_tile(ops):
+    with pytest.raises(ValueError):
+        ops.vq_forward(rnd(1, 16, 8, 12).to(DEV), rnd(4, 16).to(DEV), variant=DM_VQ_MFMA)     # 96 positions per sample
+    with pytest.raises(ValueError):
+        ops.vq_forward(rnd(1, 128, 8, 8).to(DEV), rnd(4, 128).to(DEV), variant=DM_VQ_MFMA)    # embedding_dim 128
+
+
+@pytest.mark.parametrize("D,K", [(16, 64), (16, 512), (64, 128)])
+def test_vq_mfma_near_ties_and_non_finite_values(ops, cvq, D, K):
+    """The cases the MFMA filter must hand to the exact path: latents on (and a few ulp off) the bisector of two codes,
+    duplicated codes (exact ties: the FIRST index wins, vq_vae.py:68), NaN / inf latents, and -- second half -- a
+    codebook with a NaN and an inf row (torch.argmax(-dist): the first NaN wins)."""
+    g = np.random.default_rng(D + K)
+    cb = g.standard_normal((K, D)).astype(np.float32)
+    cb[K // 2] = cb[3]                                    # exact duplicates, the earlier one must win
+    cb[K - 1] = cb[1]
+    B, H, W = 4, 16, 16
+    z = g.standard_normal((B, D, H, W)).astype(np.float32)
+    zf = z.transpose(0, 2, 3, 1).reshape(-1, D)           # (P, D) view for editing positions
+    P = zf.shape[0]
+    pick = g.permutation(P)
+    n = P // 8
+    a, b = g.integers(0, K, n), g.integers(0, K, n)
+    mid = 0.5 * (cb[a] + cb[b])
+    zf[pick[:n]] = mid                                                                     # on the bisector
+    zf[pick[n:2 * n]] = np.nextafter(mid, np.float32(np.inf)) + np.float32(0)               # one ulp off, every coordinate
+    zf[pick[2 * n:3 * n]] = mid * (1 + 3e-7 * g.standard_normal((n, 1)).astype(np.float32))  # a few ulp off
+    zf[pick[3 * n:3 * n + 64]] = cb[g.integers(0, K, 64)]                                   # exactly on a code
+    zf[pick[3 * n + 64], 0] = np.nan
+    zf[pick[3 * n + 65], D - 1] = np.inf
+    zf[pick[3 * n + 66], 1] = -np.inf
+    zf[pick[3 * n + 67]] = 1e30                                                            # squares overflow
+    zf[pick[3 * n + 68]] = 0.0
+    z = np.ascontiguousarray(zf.reshape(B, H, W, D).transpose(0, 3, 1, 2))
+    for with_bad_codes in (False, True):
+        if with_bad_codes:
+            cb = cb.copy()
+            cb[7, 2] = np.nan
+            cb[5, 0] = np.inf
+        idx_ref = _c_oracle_idx(cvq, z, cb)
+        zd, cbd = torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV)
+        idx_e = ops.vq_forward(zd, cbd, want_out=False, variant=DM_VQ_EXACT)[0].cpu().numpy()
+        idx_m, _, _, _, nre = ops.vq_forward(zd, cbd, want_out=False, variant=DM_VQ_MFMA, want_rechecked=True)
+        assert np.array_equal(idx_e, idx_ref)
+        assert np.array_equal(idx_m.cpu().numpy(), idx_ref)
+        nre = int(nre.cpu())
+        if with_bad_codes:
+            assert nre == P                                   # a non-finite codebook: every position takes the exact path
+        else:
+            # every position whose two best codes are (nearly) tied in float64 must have taken the exact path
+            zt, ct = torch.from_numpy(z).double().permute(0, 2, 3, 1).reshape(-1, D), torch.from_numpy(cb).double()
+            d2 = torch.cdist(zt, ct).pow(2)
+            fin = torch.isfinite(d2).all(1)
+            top = torch.topk(d2[fin], 2, dim=1, largest=False).values
+            near = int(((top[:, 1] - top[:, 0]) <= 1e-6 * top[:, 1]).sum()) + int((~fin).sum())
+            assert near >= n, near                            # the construction did produce near-ties
+            assert nre >= near, (nre, near, P)
+
+
+def test_vq_mfma_large_sweep(ops, cvq):
+    """4 M random positions at the headline shape (K = 64, D = 16, 16 x 16 latents): the MFMA kernel equals the exact
+    kernel everywhere and the C oracle on the first 0.5 M positions; the share of positions it has to re-evaluate
+    exactly stays small (it is the price of the filter, printed for DESIGN.md)."""
+    B, D, K, H, W = 2048, 16, 64, 16, 16
+    cb = rnd(K, D, seed=5)
+    cbd = cb.to(DEV)
+    total, rechecked = 0, 0
+    for rep in range(8):
+        z = torch.randn(B, D, H, W, generator=torch.Generator().manual_seed(100 + rep)) * (0.5 + 0.25 * rep)
+        zd = z.to(DEV)
+        idx_e, out_e, _, hist_e = ops.vq_forward(zd, cbd, variant=DM_VQ_EXACT)
+        idx_m, out_m, _, hist_m, nre = ops.vq_forward(zd, cbd, variant=DM_VQ_MFMA, want_rechecked=True)
+        assert torch.equal(idx_e, idx_m), rep
+        assert torch.equal(out_e, out_m), rep
+        assert torch.equal(hist_e, hist_m), rep
+        total += idx_m.numel()
+        rechecked += int(nre.cpu())
+        if rep == 0:
+            assert np.array_equal(idx_m.cpu().numpy(), _c_oracle_idx(cvq, z.numpy(), cb.numpy()))
+    frac = rechecked / total
+    print(f"vq mfma sweep: {total} positions, {rechecked} re-evaluated exactly ({frac:.2e})")
+    assert 0 < frac < 1e-2
 
 
 def test_vq_backward_golden(ops, golden):

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""VectorQuantizer forward micro-bench: the exact kernel vs the MFMA filter + exact re-check, per shape.
+
+    gpurun -- python tools/vqbench.py                 # headline (K 64, D 16, B 2048), stress (K 4096), example (K 512, D 64)
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/vqbench.py headline
+
+Times whole dm_vq_forward calls (prep + distance kernel) with events on the launch stream; per-kernel durations come
+from the rocprofv3 kernel trace of the same command.  Algorithmic bytes = P * (2 * D * 4 + 8) (read z, write the
+straight-through value, write int64 indices): SURVEY section 8(d).
+"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamorph_amd import ops
+from dynamorph_amd._lib import DM_VQ_EXACT, DM_VQ_MFMA
+
+
+def t_ms(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+SHAPES = {"headline": (2048, 16, 64, 16, 16), "stress": (256, 16, 4096, 32, 32), "example": (256, 64, 512, 32, 32),
+          "c2": (1024, 16, 64, 16, 16), "big": (8192, 16, 64, 16, 16)}
+want = sys.argv[1:] or ["headline", "stress", "example", "c2"]
+dev = "cuda:0"
+for name in want:
+    B, D, K, H, W = SHAPES[name]
+    z = torch.randn(B, D, H, W, device=dev, generator=torch.Generator(dev).manual_seed(1))
+    cb = torch.randn(K, D, device=dev, generator=torch.Generator(dev).manual_seed(2))
+    P = B * H * W
+    nbytes = P * (2 * D * 4 + 8)
+    ref = None
+    for vname, variant in (("exact", DM_VQ_EXACT), ("mfma", DM_VQ_MFMA)):
+        idx, out, slabs, hist, nre = ops.vq_forward(z, cb, variant=variant, want_rechecked=True)
+        if ref is None:
+            ref = idx
+        same = bool(torch.equal(idx, ref))
+        ms = t_ms(lambda: ops.vq_forward(z, cb, variant=variant))
+        print(f"{name:9s} {vname:6s} B={B} D={D} K={K} P={P}: {ms * 1e3:8.1f} us/call  {nbytes / ms / 1e6:8.1f} GB/s algorithmic "
+              f"({nbytes / ms / 1e6 / 8000:.3f} of HBM peak)  rechecked={int(nre.cpu())} ({int(nre.cpu()) / P:.2e})  same_idx={same}",
+              flush=True)
