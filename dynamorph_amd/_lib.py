@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdynamorph_hip.so")
+# DM_LIB_PATH: a diagnostic twin of the library (make -C csrc stamps) for experiments; the package default is the in-tree .so
+LIB_PATH = os.environ.get("DM_LIB_PATH") or os.path.join(_HERE, "libdynamorph_hip.so")
 
 DM_LOAD_IDENT, DM_LOAD_RELU, DM_LOAD_AFFINE, DM_LOAD_AFFINE_RELU, DM_LOAD_AFFINE2 = range(5)
 DM_VQ_AUTO, DM_VQ_EXACT, DM_VQ_MFMA = range(3)

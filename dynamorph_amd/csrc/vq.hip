@@ -21,15 +21,26 @@ constexpr int VQ_BLOCK = 256;
 constexpr int VQ_MAX_LDS_HIST = 4096;
 
 // Workspace of dm_vq_forward (float offsets; every region starts on a 16-byte boundary):
-//   header  4 ints: [0] = positions that went through the exact re-check of the MFMA path (statistics)
+//   header  32 ints: [0] = positions that went through the exact re-check of the MFMA path (statistics); [4..] = per-phase
+//           cycle sums of the diagnostic build (-DVQ2_STAMPS, never the shipped one)
 //   cbT     [ceil(K/2)][D][2]   pair-interleaved codebook of the exact kernel (v1)
 //   cbA     [K64/64][4 kt][SQ][64 lanes][4]  A operand of v_mfma_f32_16x16x4_f32: -2 * e[64 cc + 16 kt + (lane & 15)]
 //           [4 (4 sq + j) + (lane >> 4)], zero beyond K / D  (K64 = K rounded up to 64, SQ = ceil(D / 16))
 //   nrm     [K64]  ||e_k||^2 summed in double, rounded once; VQ2_PAD_NORM beyond K (such a code never wins)
 //   cbH     [K][4 h][D / 4]  e[k][4 s + h]: the codebook row in the order a lane of the MFMA kernel holds z
-constexpr int VQ2_HDR = 4;
+//   hrep    [R][K] int32  replicated code-usage counters (vq_hist_replicas)
+constexpr int VQ2_HDR = 32;
 constexpr float VQ2_PAD_NORM = 3.0e38f;
-struct Vq2Layout { long long cbT, cbA, nrm, cbH, total; };
+struct Vq2Layout { long long cbT, cbA, nrm, cbH, hrep, total; int R; };
+
+// Code-usage counters: every workgroup flushing its LDS histogram into ONE set of K global counters serialises
+// (workgroups x K atomics on K addresses: 8 us of a 28 us kernel at 512 workgroups, K = 64).  The workgroups add into
+// R replicas (replica = workgroup % R) and a tiny kernel sums the replicas into `hist`.
+int vq_hist_replicas(int K)
+{
+    int r = 65536 / (K > 0 ? K : 1);
+    return r < 1 ? 1 : (r > 64 ? 64 : r);
+}
 
 Vq2Layout vq2_layout(int K, int D)
 {
@@ -41,16 +52,19 @@ Vq2Layout vq2_layout(int K, int D)
     L.cbA = o; o += K64 * 16 * SQ;
     L.nrm = o; o += K64;
     L.cbH = o; o += (long long)K * D; o = (o + 3) & ~3LL;
+    L.R = vq_hist_replicas(K);
+    L.hrep = o; o += (long long)L.R * K; o = (o + 3) & ~3LL;
     L.total = o;
     return L;
 }
 
 __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ ws, Vq2Layout L, int K, int D,
-                               int *__restrict__ hist, double *__restrict__ slabs, int nslabs)
+                               double *__restrict__ slabs, int nslabs)
 {
     // also clears the outputs the forward kernel accumulates into (no separate memset launches)
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    for (int i = t0; i < K; i += nt) hist[i] = 0;
+    int *__restrict__ hrep = reinterpret_cast<int *>(ws + L.hrep);
+    for (int i = t0; i < L.R * K; i += nt) hrep[i] = 0;
     for (int i = t0; i < nslabs; i += nt) slabs[i] = 0.0;
     if (t0 < VQ2_HDR) reinterpret_cast<int *>(ws)[t0] = 0;
     // cbT[p][d][j] = cb[2p + j][d]; for odd K the missing partner repeats code K-1 (never selected).
@@ -109,8 +123,9 @@ template <int D, int PP>
 __global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : (D <= 64 ? 2 : 1))) void vq_forward_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbT,
     long long *__restrict__ idx, float *__restrict__ out, double *__restrict__ sse_slabs,
-    int *__restrict__ hist, int K, int HW, long long P)
+    int *__restrict__ hrep, int R, int K, int HW, long long P)
 {
+    int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;     // this workgroup's replica of the counters
     constexpr int CHUNK_PAIRS = 2048 / D;                 // 16 KB of LDS per chunk
     __shared__ __attribute__((aligned(16))) float s_cb[CHUNK_PAIRS * D * 2];
     __shared__ int s_hist[VQ_MAX_LDS_HIST];
@@ -250,6 +265,20 @@ __global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : (D <= 64 ? 2 : 1))) void v
     }
 }
 
+__global__ void vq_hist_reduce_kernel(const int *__restrict__ hrep, int R, int K, int *__restrict__ hist)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    // (all replicas requested before the first is used: one memory round trip, not R)
+    int v[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) v[r] = r < R ? hrep[(long long)r * K + k] : 0;
+    int s = 0;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) s += v[r];
+    hist[k] = s;
+}
+
 // ================================================================================================================
 // v2: MFMA prefilter + exact re-check -- same indices as the kernel above, a third of its instructions.
 //
@@ -279,7 +308,24 @@ __global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : (D <= 64 ? 2 : 1))) void v
 // exactly the B operand of step s for the four position tiles t = 0..3 (column c of tile t = position 4 c + t): no
 // transpose, no LDS.  The 16 x 16 result tile has code 16 kt + 4 h + r in register r, so a position's 64 scores sit in
 // 16 registers of 4 lanes: 16 in-lane updates, then two cross-lane steps (lanes l ^ 16, l ^ 32).
-constexpr int VQ2_BLOCK = 256;
+
+// Diagnostic build only (make STAMPS=1): s_memtime at the phase boundaries of the chunk loop, per-wave sums added into the
+// workspace header.  The shipped library has no stamp (cdna_hip_programming.md section 7, In-kernel stamps).
+#ifdef VQ2_STAMPS
+#define VQ2_STAMP(i)                                                                                      \
+    {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        unsigned long long t_;                                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        st_sum[i] += t_ - st_prev;                                                                        \
+        st_prev = t_;                                                                                     \
+    }
+#define VQ2_USE(v) asm volatile("; use" ::"v"(v))
+#else
+#define VQ2_STAMP(i)
+#define VQ2_USE(v)
+#endif
 
 __device__ __forceinline__ float vq2_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vq2_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -338,13 +384,16 @@ __device__ __forceinline__ float vq_exact_dist(const float (&zv)[D], const float
     return total;
 }
 
-template <int D, bool SINGLE, bool PREFETCH, int MINW>
-__global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
+template <int D, bool SINGLE, bool PREFETCH, int MINW, int NW>
+__global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbA,
     const float *__restrict__ nrm, const float *__restrict__ cbH, long long *__restrict__ idx,
-    float *__restrict__ out, double *__restrict__ sse_slabs, int *__restrict__ hist, int *__restrict__ hdr,
-    int K, int HW, long long P)
+    float *__restrict__ out, double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int *__restrict__ hdr,
+    int K, int HW, long long P, int ablate, int stagger)
 {
+    constexpr int BLOCK = 64 * NW;                                   // NW waves: 4 (one per SIMD) or 8 (two per SIMD)
+    int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;     // this workgroup's replica of the counters
+    // `ablate` (0 in every product launch) switches phases off for timing experiments only (DM_VQ2_ABLATE, results wrong)
     constexpr int S = D / 4, SQ = (S + 3) / 4;
     constexpr int CHUNK_F4 = 4 * SQ * 64;                          // f32x4 of packed A operand per 64-code chunk
     constexpr int PIECE = SINGLE ? 1 : (2048 / CHUNK_F4 > 0 ? 2048 / CHUNK_F4 : 1);   // code chunks per 32 KB LDS piece
@@ -352,26 +401,92 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
     constexpr float TOL_A = 4.f * (D + 129) * U, TOL_D = 4.f * (D / 16 + 18) * U;
     __shared__ f32x4 s_A[SINGLE ? 1 : PIECE * CHUNK_F4];
     __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];
-    __shared__ f32x4 s_H[SINGLE ? 64 * S : 1];                       // small codebooks: the lane-ordered rows (cbH) for the gather
+    constexpr int HROW = S + 1;                                       // f32x4 per code in s_H: D floats + 16 bytes of padding (banks)
+    __shared__ f32x4 s_H[SINGLE ? 64 * HROW : 1];                    // small codebooks: the lane-ordered rows (cbH) for the gather
     __shared__ int s_hist[SINGLE ? 64 : VQ_MAX_LDS_HIST];
-    __shared__ double s_red[4];
-    __shared__ float s_em[4];
+    __shared__ double s_red[NW];
+    __shared__ float s_em[NW];
     const int lane = threadIdx.x & 63, h = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // provably wave-uniform: scalar branches
     const bool lds_hist = K <= VQ_MAX_LDS_HIST;
-    if (lds_hist)
-        for (int k = threadIdx.x; k < K; k += VQ2_BLOCK) s_hist[k] = 0;
+
+    // Chunk bookkeeping in 32-bit scalars, advanced incrementally: a 64-bit `pos / HW` per iteration is a ~150-instruction
+    // software division in front of the loads whose address it feeds.
+    const unsigned NC = (unsigned)(P >> 6);                    // chunks of 64 positions (HW % 64 == 0: never across samples)
+    const unsigned cps = (unsigned)HW >> 6;                    // chunks per sample
+    const unsigned qstep = (unsigned)NW * gridDim.x;
+    const unsigned step_b = qstep / cps, step_c = qstep - step_b * cps;
+    const int ncc = (K + 63) >> 6;                             // 64-code chunks
+    int staged = -1;                                           // first code chunk of the piece held in LDS
+    double sse = 0.0;
+    int nflag = 0;
+#ifdef VQ2_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+
+    // (a wave without a chunk -- the tail of the last quad -- loads the last chunk and computes nothing)
+    auto zptr = [&](unsigned chunk, unsigned b, unsigned cw) {
+        const bool ok = chunk < NC;
+        const unsigned bb = ok ? b : NC / cps - 1, cc = ok ? cw : cps - 1;
+        return ((long long)bb * D + h) * (long long)HW + (long long)(cc * 64u + 4u * c);
+    };
+    unsigned chunk = blockIdx.x * (unsigned)NW + (unsigned)wave;
+    unsigned cb_ = chunk / cps, cw_ = chunk - cb_ * cps;       // sample and chunk-in-sample of `chunk`
+    f32x4 zr[S];
+    {
+        const long long o = zptr(chunk, cb_, cw_);
+#pragma unroll
+        for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
+    }
+    // every global load of the prologue is issued before the first wait: z of the first chunk, the A operand and the
+    // norms (small codebooks: registers), the rows for the gather -- one memory round trip instead of four
+    f32x4 areg[4][SQ], nreg[4];
+    constexpr int HCOPY = SINGLE ? (64 * S + BLOCK - 1) / BLOCK : 1;
+    f32x4 hreg[HCOPY];
     if constexpr (SINGLE) {
         static_assert(S % 4 == 0 || S == 2, "embedding_dim 8, 16, 32 or 64");
-        for (int i = threadIdx.x; i < K * S; i += VQ2_BLOCK) reinterpret_cast<float *>(s_H)[i] = cbH[i];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int sq = 0; sq < SQ; ++sq) areg[kt][sq] = reinterpret_cast<const f32x4 *>(cbA)[(kt * SQ + sq) * 64 + lane];
+            nreg[kt] = *reinterpret_cast<const f32x4 *>(nrm + kt * 16 + h * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < HCOPY; ++j) {
+            const int i = threadIdx.x + j * BLOCK;
+            hreg[j] = i < K * S ? reinterpret_cast<const f32x4 *>(cbH)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
+    if (lds_hist)
+        for (int k = threadIdx.x; k < K; k += BLOCK) s_hist[k] = 0;
 
     // max_k |e_k|^2 for the tolerance; a non-finite codebook makes it inf: every position takes the exact path
     float emax;
-    {
+    if constexpr (SINGLE) {
+        // the 64 norms are already in the wave's registers (16 per lane): in-lane maximum, two lane-pair steps
+        float em = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = nreg[kt][r];
+                const bool real = kt * 16 + h * 4 + r < K;         // (padding carries VQ2_PAD_NORM)
+                em = real ? (v < __builtin_inff() ? fmaxf(em, v) : __builtin_inff()) : em;
+            }
+        float lo, hi;
+        vq2_pair<16>(em, lo, hi); em = fmaxf(lo, hi);
+        vq2_pair<32>(em, lo, hi); emax = fmaxf(lo, hi);
+#pragma unroll
+        for (int j = 0; j < HCOPY; ++j) {
+            const int i = threadIdx.x + j * BLOCK;
+            if (i < K * S) s_H[(i / S) * HROW + i % S] = hreg[j];
+        }
+        __syncthreads();
+    } else {
         float em = 0.f;
         bool bad = false;
-        for (int k = threadIdx.x; k < K; k += VQ2_BLOCK) {
+        for (int k = threadIdx.x; k < K; k += BLOCK) {
             const float v = nrm[k];
             bad |= !(v < __builtin_inff());
             em = fmaxf(em, v);
@@ -381,46 +496,29 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
         for (int o = 32; o > 0; o >>= 1) em = fmaxf(em, __shfl_xor(em, o, 64));
         if (lane == 0) s_em[wave] = em;
         __syncthreads();
-        emax = fmaxf(fmaxf(s_em[0], s_em[1]), fmaxf(s_em[2], s_em[3]));
+        emax = s_em[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) emax = fmaxf(emax, s_em[w]);
     }
 
-    f32x4 areg[4][SQ], nreg[4];
+    // Two waves per SIMD running this loop in lockstep both want the matrix pipe, then both the VALU: the time of the
+    // phases adds up.  Waves 4..7 (the SIMD partners of 0..3) start half an iteration late so that one wave's MFMAs run
+    // beside the other's top-2 / merge / gather work (MI355X_MICROARCH.md, two waves per SIMD, item 9).
     if constexpr (SINGLE) {
+        // every prologue load is waited for HERE: left pending, hipcc's counted waits for them at the first MFMAs of the
+        // loop body (vmcnt(4)) would also hold every later iteration until its predecessor's stores have completed
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int sq = 0; sq < SQ; ++sq) areg[kt][sq] = reinterpret_cast<const f32x4 *>(cbA)[(kt * SQ + sq) * 64 + lane];
-            nreg[kt] = *reinterpret_cast<const f32x4 *>(nrm + kt * 16 + h * 4);
+            for (int sq = 0; sq < SQ; ++sq) asm volatile("" ::"v"(areg[kt][sq]));
+            asm volatile("" ::"v"(nreg[kt]));
         }
     }
-
-    // Chunk bookkeeping in 32-bit scalars, advanced incrementally: a 64-bit `pos / HW` per iteration is a ~150-instruction
-    // software division in front of the loads whose address it feeds.
-    const unsigned NC = (unsigned)(P >> 6);                    // chunks of 64 positions (HW % 64 == 0: never across samples)
-    const unsigned cps = (unsigned)HW >> 6;                    // chunks per sample
-    const unsigned qstep = 4u * gridDim.x;
-    const unsigned step_b = qstep / cps, step_c = qstep - step_b * cps;
-    const int ncc = (K + 63) >> 6;                             // 64-code chunks
-    int staged = -1;                                           // first code chunk of the piece held in LDS
-    double sse = 0.0;
-    int nflag = 0;
-
-    // (a wave without a chunk -- the tail of the last quad -- loads the last chunk and computes nothing)
-    auto zptr = [&](unsigned chunk, unsigned b, unsigned cw) {
-        const bool ok = chunk < NC;
-        const unsigned bb = ok ? b : NC / cps - 1, cc = ok ? cw : cps - 1;
-        return ((long long)bb * D + h) * (long long)HW + (long long)(cc * 64u + 4u * c);
-    };
-    unsigned chunk = blockIdx.x * 4u + (unsigned)wave;
-    unsigned cb_ = chunk / cps, cw_ = chunk - cb_ * cps;       // sample and chunk-in-sample of `chunk`
-    f32x4 zr[S];
-    {
-        const long long o = zptr(chunk, cb_, cw_);
-#pragma unroll
-        for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
-    }
-    for (unsigned q = blockIdx.x; q * 4u < NC; q += gridDim.x) {
+    if (NW == 8 && wave >= 4 && stagger > 0)
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    for (unsigned q = blockIdx.x; q * (unsigned)NW < NC; q += gridDim.x) {
         const bool act = chunk < NC;                           // wave-uniform
+        if (ablate & 64) __builtin_amdgcn_s_barrier();         // experiment: the workgroup's waves request their rows together
         const long long zoff = zptr(chunk, cb_, cw_);
         unsigned nchunk = chunk + qstep, nb = cb_ + step_b, nw = cw_ + step_c;
         if (nw >= cps) { nw -= cps; ++nb; }
@@ -432,6 +530,9 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
             for (int s = 0; s < S; ++s) zn[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
         }
 
+        VQ2_STAMP(1)                                           // addresses + prefetch issue
+        VQ2_USE(zr[S - 1]);
+        VQ2_STAMP(2)                                           // this chunk's z has arrived
         float m1[4], m2[4];
         int c1[4];
 #pragma unroll
@@ -473,16 +574,20 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
         };
 
         if constexpr (SINGLE) {
-            if (act) chunk_scores(nreg, [&](int kt, int sq) { return areg[kt][sq]; }, 0);
+            if (act && !(ablate & 4)) chunk_scores(nreg, [&](int kt, int sq) { return areg[kt][sq]; }, 0);
+            if (ablate & 4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { m1[t] = zr[0][t]; m2[t] = zr[1][t] + 100.f; }
+            }
         } else {
             for (int p0 = 0; p0 < ncc; p0 += PIECE) {
                 const int pn = min(PIECE, ncc - p0);
                 if (staged != p0) {                            // (one piece in all: staged once per workgroup)
                     __syncthreads();                           // the previous piece has been consumed
                     const f32x4 *__restrict__ ga = reinterpret_cast<const f32x4 *>(cbA) + (long long)p0 * CHUNK_F4;
-                    for (int i = threadIdx.x; i < pn * CHUNK_F4; i += VQ2_BLOCK) s_A[i] = ga[i];
+                    for (int i = threadIdx.x; i < pn * CHUNK_F4; i += BLOCK) s_A[i] = ga[i];
                     const f32x4 *__restrict__ gn = reinterpret_cast<const f32x4 *>(nrm) + (long long)p0 * 16;
-                    for (int i = threadIdx.x; i < pn * 16; i += VQ2_BLOCK) s_n[i] = gn[i];
+                    for (int i = threadIdx.x; i < pn * 16; i += BLOCK) s_n[i] = gn[i];
                     staged = p0;
                     __syncthreads();
                 }
@@ -499,8 +604,16 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
             }
         }
 
+        VQ2_USE(m1[3]); VQ2_USE(m2[3]);
+        VQ2_STAMP(3)                                           // MFMAs + in-lane top-2
+#ifdef VQ2_STAMPS
+        if constexpr (PREFETCH) { VQ2_USE(zn[S - 1]); }
+        VQ2_STAMP(7)                                           // (diagnostic: has the prefetch landed after the MFMA phase?)
+#endif
+        f32x4 o[S];
+        long long kpair[2] = {0, 0};
+        int kk = 0;
         if (act) {
-            const long long pos0 = (long long)chunk << 6;
             const unsigned hbits = (unsigned)h << 2;
             int kb[4];
             // one instantiation per position tile (the tile number is a compile-time constant)
@@ -529,7 +642,7 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
                 merge(std::integral_constant<int, 16>{});
                 merge(std::integral_constant<int, 32>{});
                 const float tol = TOL_A * (zz + 2.f * emax) + TOL_D * fmaxf(zz + a1, 0.f) + 1e-30f;
-                const bool flagged = !((a2 - a1) > tol);       // also true when anything is NaN / inf
+                const bool flagged = !((a2 - a1) > tol) && !(ablate & 32);       // also true when anything is NaN / inf
                 kb[t] = (SINGLE ? 0 : cc1 * 64) + (int)(__builtin_bit_cast(unsigned, a1) & 63u);
                 unsigned long long fm = __ballot(flagged) & 0xFFFFull;      // the four h rows agree: take row 0
                 while (fm) {
@@ -564,17 +677,24 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
                     ++nflag;
                 }
             };
-            finish_tile(std::integral_constant<int, 0>{});
-            finish_tile(std::integral_constant<int, 1>{});
-            finish_tile(std::integral_constant<int, 2>{});
-            finish_tile(std::integral_constant<int, 3>{});
+            if (!(ablate & 2)) {
+                finish_tile(std::integral_constant<int, 0>{});
+                finish_tile(std::integral_constant<int, 1>{});
+                finish_tile(std::integral_constant<int, 2>{});
+                finish_tile(std::integral_constant<int, 3>{});
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) kb[t] = (int)(__builtin_bit_cast(unsigned, m1[t]) & 63u);
+            }
 
+            VQ2_USE(kb[3]);
+            VQ2_STAMP(4)                                       // cross-lane merge, tolerance, exact re-checks
             // gather + straight-through value + squared error, in the layout the lane already holds
             float ssef = 0.f;
-            const long long obase = zoff;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float *__restrict__ eh = (SINGLE ? reinterpret_cast<const float *>(s_H) : cbH) + ((long long)kb[t] * 4 + h) * S;
+                const float *__restrict__ eh = SINGLE ? reinterpret_cast<const float *>(s_H) + kb[t] * (4 * HROW) + h * S
+                                                      : cbH + ((long long)kb[t] * 4 + h) * S;
                 float ev[S];
                 if constexpr (S % 4 == 0) {
 #pragma unroll
@@ -589,40 +709,63 @@ __global__ __launch_bounds__(VQ2_BLOCK, MINW) void vq_forward_mfma_kernel(
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     const float diff = ev[s] - zr[s][t];
-                    zr[s][t] = zr[s][t] + diff;                // z + (q - z), vq_vae.py:71
+                    o[s][t] = zr[s][t] + diff;                 // z + (q - z), vq_vae.py:71
                     ssef += diff * diff;
                 }
             }
-            if (out) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) *reinterpret_cast<f32x4 *>(out + obase + (long long)(4 * s) * HW) = zr[s];
-            }
             sse += (double)ssef;
-            if (idx && h < 2) {
-                long long pair[2] = {(long long)(h ? kb[2] : kb[0]), (long long)(h ? kb[3] : kb[1])};
-                *reinterpret_cast<f32x4 *>(idx + pos0 + 4 * c + 2 * h) = *reinterpret_cast<const f32x4 *>(pair);
-            }
-            const int kk = h == 0 ? kb[0] : (h == 1 ? kb[1] : (h == 2 ? kb[2] : kb[3]));
-            if (lds_hist) atomicAdd(&s_hist[kk], 1);
-            else atomicAdd(&hist[kk], 1);
+            kpair[0] = (long long)(h ? kb[2] : kb[0]); kpair[1] = (long long)(h ? kb[3] : kb[1]);
+            kk = h == 0 ? kb[0] : (h == 1 ? kb[1] : (h == 2 ? kb[2] : kb[3]));
+            VQ2_USE(o[S - 1]); VQ2_USE(ssef);
+            VQ2_STAMP(5)                                       // gather, straight-through value, squared error
         }
+        // The prefetched z replaces this chunk's BEFORE the stores are issued: the wait for the prefetch then counts loads
+        // only.  After the stores (vmcnt counts loads and stores in issue order, and hipcc cannot count across the re-check
+        // branches) it was a vmcnt(0): every wave sat out the completion of its own stores once per chunk.
         if constexpr (PREFETCH) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) zr[s] = zn[s];
-        } else if ((q + gridDim.x) * 4u < NC) {
-            const long long o = zptr(nchunk, nb, nw);
+            for (int s = 0; s < S; ++s) {
+                asm volatile("" : "+v"(zn[s]));                // (an opaque use pins the wait here; a plain copy is only renaming)
+                zr[s] = zn[s];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        VQ2_STAMP(0)                                           // wait for the prefetched z
+        if (act) {
+            if (out && !(ablate & 1)) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
+                for (int s = 0; s < S; ++s) *reinterpret_cast<f32x4 *>(out + zoff + (long long)(4 * s) * HW) = o[s];
+            }
+            if (idx && h < 2 && !(ablate & 1))
+                *reinterpret_cast<f32x4 *>(idx + ((long long)chunk << 6) + 4 * c + 2 * h) = *reinterpret_cast<const f32x4 *>(kpair);
+            if (!(ablate & 8)) {
+                if (lds_hist) atomicAdd(&s_hist[kk], 1);
+                else atomicAdd(&hist[kk], 1);
+            }
+        }
+        VQ2_STAMP(6)                                           // stores issued
+        if constexpr (!PREFETCH) {
+            if ((q + gridDim.x) * (unsigned)NW < NC) {
+                const long long o2 = zptr(nchunk, nb, nw);
+#pragma unroll
+                for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o2 + (long long)(4 * s) * HW);
+            }
         }
         chunk = nchunk; cb_ = nb; cw_ = nw;
     }
 
+    VQ2_STAMP(0)
+    if (ablate & 16) return;
     const double tot = block_sum(sse, s_red);
     if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
     if (lane == 0 && nflag) atomicAdd(hdr, nflag);
-    if (lds_hist) {
+#ifdef VQ2_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4) + i, st_sum[i]);
+#endif
+    if (lds_hist && !(ablate & 8)) {
         __syncthreads();
-        for (int k = threadIdx.x; k < K; k += VQ2_BLOCK) {
+        for (int k = threadIdx.x; k < K; k += BLOCK) {
             const int cnt = s_hist[k];
             if (cnt) atomicAdd(&hist[k], cnt);
         }
@@ -766,41 +909,48 @@ extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int6
     const int nslabs = dm_vq_num_blocks(P);
     int pgrid = (int)((n + 255) / 256);
     if (pgrid > 1024) pgrid = 1024;
-    hipLaunchKernelGGL(vq_prep_kernel, dim3(pgrid), dim3(256), 0, s, codebook, ws, L, K, D, (int *)hist, sse_slabs, nslabs);
-    // (vq_prep_kernel cleared hist and all slabs: there are fewer workgroups than slabs)
+    hipLaunchKernelGGL(vq_prep_kernel, dim3(pgrid), dim3(256), 0, s, codebook, ws, L, K, D, sse_slabs, nslabs);
+    // (vq_prep_kernel cleared the counter replicas and all slabs: there are fewer workgroups than slabs)
+    int *hrep = reinterpret_cast<int *>(ws + L.hrep);
     if (use2) {
-        const long long quads = ((P >> 6) + 3) / 4;
         const char *tune = getenv("DM_VQ2_TUNE");              // experiment switches, removed once measured
         const int tv = tune ? atoi(tune) : 0;
         const char *tw = getenv("DM_VQ2_WGS");
         const int wgs_env = tw ? atoi(tw) : 0;
-#define DM_VQ2(DD, SINGLE_, PF, MINW, WGS)                                                                           \
+        const char *ta = getenv("DM_VQ2_ABLATE");
+        const int ablate = ta ? atoi(ta) : 0;
+        const char *ts = getenv("DM_VQ2_STAGGER");
+        const int stagger = ts ? atoi(ts) : 0;
+#define DM_VQ2(DD, SINGLE_, PF, MINW, WGS, NW)                                                                       \
     {                                                                                                                \
         const int wgs = wgs_env > 0 ? wgs_env : (WGS);                                                               \
-        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, PF, MINW>), dim3((unsigned)(quads < 256 * wgs ? quads : 256 * wgs)), \
-                           dim3(VQ2_BLOCK), 0, s, z, codebook, ws + L.cbA, ws + L.nrm, ws + L.cbH, (long long *)idx, out, \
-                           sse_slabs, (int *)hist, (int *)ws, K, H * W, P);                                          \
+        const long long groups = ((P >> 6) + (NW) - 1) / (NW);                                                       \
+        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, PF, MINW, NW>), dim3((unsigned)(groups < 256 * wgs ? groups : 256 * wgs)), \
+                           dim3(64 * (NW)), 0, s, z, codebook, ws + L.cbA, ws + L.nrm, ws + L.cbH, (long long *)idx, out, \
+                           sse_slabs, hrep, L.R, (int *)ws, K, H * W, P, ablate, stagger);                           \
     }
         const bool single = K <= 64;
         switch (D) {
-        case 8: if (single) DM_VQ2(8, true, true, 4, 4) else DM_VQ2(8, false, false, 3, 3) break;
+        case 8: if (single) DM_VQ2(8, true, true, 4, 4, 4) else DM_VQ2(8, false, false, 3, 3, 4) break;
         case 16:
             if (single) {
-                if (tv == 1) DM_VQ2(16, true, false, 4, 4)
-                else if (tv == 2) DM_VQ2(16, true, true, 3, 3)
-                else DM_VQ2(16, true, true, 4, 4)
-            } else DM_VQ2(16, false, false, 3, 3)
+                if (tv == 1) DM_VQ2(16, true, false, 4, 4, 4)
+                else if (tv == 2) DM_VQ2(16, true, true, 3, 3, 4)
+                else if (tv == 3) DM_VQ2(16, true, true, 2, 1, 8)
+                else DM_VQ2(16, true, true, 4, 4, 4)
+            } else DM_VQ2(16, false, false, 3, 3, 4)
             break;
-        case 32: if (single) DM_VQ2(32, true, false, 2, 2) else DM_VQ2(32, false, false, 2, 2) break;
-        default: if (single) DM_VQ2(64, true, false, 1, 1) else DM_VQ2(64, false, false, 1, 2) break;
+        case 32: if (single) DM_VQ2(32, true, false, 2, 2, 4) else DM_VQ2(32, false, false, 2, 2, 4) break;
+        default: if (single) DM_VQ2(64, true, false, 1, 1, 4) else DM_VQ2(64, false, false, 1, 2, 4) break;
         }
 #undef DM_VQ2
+        hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
         return dm_launch_status("dm_vq_forward");
     }
     const float *cbT = ws + L.cbT;
 #define DM_VQ_FWD(DD, PP_)                                                                                   \
     hipLaunchKernelGGL((vq_forward_kernel<DD, PP_>), dim3((unsigned)((P + VQ_BLOCK * PP_ - 1) / (VQ_BLOCK * PP_))), \
-                       dim3(VQ_BLOCK), 0, s, z, codebook, cbT, (long long *)idx, out, sse_slabs, (int *)hist, K, H * W, P)
+                       dim3(VQ_BLOCK), 0, s, z, codebook, cbT, (long long *)idx, out, sse_slabs, hrep, L.R, K, H * W, P)
     switch (D) {
     case 8: DM_VQ_FWD(8, VQ_PP); break;
     case 16: DM_VQ_FWD(16, VQ_PP); break;
@@ -809,6 +959,7 @@ extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int6
     default: DM_VQ_FWD(128, 1); break;        // VectorQuantizer's own default embedding_dim (vq_vae.py:35)
     }
 #undef DM_VQ_FWD
+    hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
     return dm_launch_status("dm_vq_forward");
 }
 

@@ -46,8 +46,9 @@ def test_struct_layouts_match_the_header():
 def test_version_and_host_only_queries(lib):
     assert lib.dm_version() == 104          # 104: dm_vq_forward_variant (MFMA filter + exact re-check), larger VQ workspace
     # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows (csrc/vq.hip)
-    assert lib.dm_vq_workspace_bytes(64, 16) == (4 + 64 * 16 + 64 * 16 + 64 + 64 * 16) * 4
-    assert lib.dm_vq_workspace_bytes(65, 16) == (4 + 66 * 16 + 128 * 16 + 128 + 65 * 16) * 4
+    # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows + counter replicas
+    assert lib.dm_vq_workspace_bytes(64, 16) == (32 + 64 * 16 + 64 * 16 + 64 + 64 * 16 + 64 * 64) * 4
+    assert lib.dm_vq_workspace_bytes(4096, 16) == (32 + 4096 * 16 * 3 + 4096 + 16 * 4096) * 4
     assert lib.dm_vq_num_blocks(524288) == 2048
     assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128, 1) == 2048 * 8   # one slab per tile (per-sample stats)
     assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128, 0) == 768        # persistent grid

@@ -26,7 +26,7 @@ def t_ms(fn, iters=20, warm=3):
 
 
 SHAPES = {"headline": (2048, 16, 64, 16, 16), "stress": (256, 16, 4096, 32, 32), "example": (256, 64, 512, 32, 32),
-          "c2": (1024, 16, 64, 16, 16), "big": (8192, 16, 64, 16, 16)}
+          "c2": (1024, 16, 64, 16, 16), "big": (8192, 16, 64, 16, 16), "tiny": (1, 16, 64, 16, 16), "small": (256, 16, 64, 16, 16)}
 want = sys.argv[1:] or ["headline", "stress", "example", "c2"]
 dev = "cuda:0"
 for name in want:
