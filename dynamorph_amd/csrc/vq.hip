@@ -384,21 +384,68 @@ __device__ __forceinline__ float vq_exact_dist(const float (&zv)[D], const float
     return total;
 }
 
-template <int D, bool SINGLE, bool PREFETCH, int MINW, int NW>
-__global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
+// Smallest and second smallest of 16 values in 20 instructions (a chain of v_med3 / v_min updates takes 32): triples give
+// (min3, med3); the overall minimum is the minimum of the triple minima, the runner-up is either the second smallest of
+// the triple minima (it sits in another triple) or the median of the winner's triple -- and every other triple median or
+// triple minimum is some element other than the winner, hence no smaller than the runner-up: m2 = min of both kinds.
+__device__ __forceinline__ void vq2_top2_16(const float (&v)[16], float &m1, float &m2)
+{
+    float n[5], d[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        n[g] = vq2_min3(v[3 * g], v[3 * g + 1], v[3 * g + 2]);
+        d[g] = vq2_med3(v[3 * g], v[3 * g + 1], v[3 * g + 2]);
+    }
+    const float p0 = vq2_min3(n[0], n[1], n[2]), q0 = vq2_med3(n[0], n[1], n[2]);
+    const float p1 = vq2_min3(n[3], n[4], v[15]), q1 = vq2_med3(n[3], n[4], v[15]);
+    m1 = vq2_min(p0, p1);
+    const float second_of_minima = vq2_min3(vq2_max(p0, p1), q0, q1);
+    const float least_median = vq2_min3(vq2_min3(d[0], d[1], d[2]), d[3], d[4]);
+    m2 = vq2_min(second_of_minima, least_median);
+}
+
+// lane-pair exchange of TWO values in one instruction: after vq2_swap<16>(x, y) the even 16-lane rows hold (own x,
+// partner's x) and the odd rows (partner's y, own y); in both, x is the even row's value and y the odd row's.  <32>: the
+// same for the 32-lane halves.
+template <int M>
+__device__ __forceinline__ void vq2_swap(float &x, float &y)
+{
+    unsigned lo, hi;
+    if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        lo = r0; hi = r1;
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        lo = r0; hi = r1;
+    }
+    x = __builtin_bit_cast(float, lo); y = __builtin_bit_cast(float, hi);
+}
+
+// The kernel.  One 256-thread workgroup = 4 waves = 4 chunks of 64 positions per iteration, persistent over the chunks.
+// Per chunk and wave: 64 MFMAs (the scores of 64 codes x 64 positions), the in-lane top 2 of every lane's 16 scores per
+// position tile, a reduce-scatter over the four lanes that share a position (afterwards lane (h, c) OWNS position tile
+// T(h) = {0, 2, 1, 3}[h], column c: its two best scores, |z|^2, the tolerance test, the re-check request), the exact
+// re-checks, an all-gather of the four chosen codes, the gather / straight-through value / squared error, the stores.
+// On gfx950 the f32 MFMA and the VALU do not overlap (SQ_VALU_MFMA_COEXEC_CYCLES = 0: the kernel's time is the SUM of its
+// matrix and vector instructions), so what is left to optimise is the instruction count of everything around the MFMAs.
+template <int D, bool SINGLE, int MINW>
+__global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbA,
     const float *__restrict__ nrm, const float *__restrict__ cbH, long long *__restrict__ idx,
     float *__restrict__ out, double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int *__restrict__ hdr,
-    int K, int HW, long long P, int ablate, int stagger)
+    int K, int HW, long long P, int ablate)
 {
-    constexpr int BLOCK = 64 * NW;                                   // NW waves: 4 (one per SIMD) or 8 (two per SIMD)
-    int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;     // this workgroup's replica of the counters
     // `ablate` (0 in every product launch) switches phases off for timing experiments only (DM_VQ2_ABLATE, results wrong)
+    constexpr int BLOCK = 256, NW = 4;
+    int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;     // this workgroup's replica of the counters
     constexpr int S = D / 4, SQ = (S + 3) / 4;
     constexpr int CHUNK_F4 = 4 * SQ * 64;                          // f32x4 of packed A operand per 64-code chunk
     constexpr int PIECE = SINGLE ? 1 : (2048 / CHUNK_F4 > 0 ? 2048 / CHUNK_F4 : 1);   // code chunks per 32 KB LDS piece
     constexpr float U = 5.9604645e-8f;                             // 2^-24
-    constexpr float TOL_A = 4.f * (D + 129) * U, TOL_D = 4.f * (D / 16 + 18) * U;
+    // 32 ulp of index bits (4 in the lane, 1 in the first merge step) instead of the 64 of the header comment's bound
+    constexpr float TOL_A = 4.f * (D + 65) * U, TOL_D = 4.f * (D / 16 + 18) * U;
     __shared__ f32x4 s_A[SINGLE ? 1 : PIECE * CHUNK_F4];
     __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];
     constexpr int HROW = S + 1;                                       // f32x4 per code in s_H: D floats + 16 bytes of padding (banks)
@@ -410,8 +457,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // provably wave-uniform: scalar branches
     const bool lds_hist = K <= VQ_MAX_LDS_HIST;
 
-    // Chunk bookkeeping in 32-bit scalars, advanced incrementally: a 64-bit `pos / HW` per iteration is a ~150-instruction
-    // software division in front of the loads whose address it feeds.
+    // Chunk bookkeeping in 32-bit scalars, advanced incrementally (a 64-bit `pos / HW` per iteration is a ~150-instruction
+    // software division in front of the loads whose address it feeds).  All global traffic of the loop goes through
+    // buffer descriptors rebased per sample: the per-lane offset is a constant, the per-chunk part a scalar offset.
     const unsigned NC = (unsigned)(P >> 6);                    // chunks of 64 positions (HW % 64 == 0: never across samples)
     const unsigned cps = (unsigned)HW >> 6;                    // chunks per sample
     const unsigned qstep = (unsigned)NW * gridDim.x;
@@ -424,21 +472,25 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-
+    const unsigned sample_bytes = (unsigned)D * (unsigned)HW * 4u;
+    const unsigned zvoff = ((unsigned)h * (unsigned)HW + 4u * (unsigned)c) * 4u;     // this lane's bytes inside a chunk's rows
     // (a wave without a chunk -- the tail of the last quad -- loads the last chunk and computes nothing)
-    auto zptr = [&](unsigned chunk, unsigned b, unsigned cw) {
-        const bool ok = chunk < NC;
-        const unsigned bb = ok ? b : NC / cps - 1, cc = ok ? cw : cps - 1;
-        return ((long long)bb * D + h) * (long long)HW + (long long)(cc * 64u + 4u * c);
+    auto z_rsrc = [&](unsigned chunk, unsigned b) {
+        const unsigned bb = chunk < NC ? b : NC / cps - 1;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(z) + (long long)bb * D * HW, 0, sample_bytes, 0x00020000);
+    };
+    auto z_soff = [&](unsigned chunk, unsigned cw) { return (chunk < NC ? cw : cps - 1) * 256u; };
+    auto z_load = [&](f32x4 (&dst)[S], unsigned chunk, unsigned b, unsigned cw) {
+        const __amdgpu_buffer_rsrc_t r = z_rsrc(chunk, b);
+        const unsigned so = z_soff(chunk, cw);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            dst[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, zvoff, so + (unsigned)(4 * s) * (unsigned)HW * 4u, 0));
     };
     unsigned chunk = blockIdx.x * (unsigned)NW + (unsigned)wave;
     unsigned cb_ = chunk / cps, cw_ = chunk - cb_ * cps;       // sample and chunk-in-sample of `chunk`
     f32x4 zr[S];
-    {
-        const long long o = zptr(chunk, cb_, cw_);
-#pragma unroll
-        for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
-    }
+    z_load(zr, chunk, cb_, cw_);
     // every global load of the prologue is issued before the first wait: z of the first chunk, the A operand and the
     // norms (small codebooks: registers), the rows for the gather -- one memory round trip instead of four
     f32x4 areg[4][SQ], nreg[4];
@@ -472,7 +524,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
             for (int r = 0; r < 4; ++r) {
                 const float v = nreg[kt][r];
                 const bool real = kt * 16 + h * 4 + r < K;         // (padding carries VQ2_PAD_NORM)
-                em = real ? (v < __builtin_inff() ? fmaxf(em, v) : __builtin_inff()) : em;
+                const float vv = v < __builtin_inff() ? v : __builtin_inff();    // NaN -> inf
+                em = real ? fmaxf(em, vv) : em;
             }
         float lo, hi;
         vq2_pair<16>(em, lo, hi); em = fmaxf(lo, hi);
@@ -483,6 +536,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
             if (i < K * S) s_H[(i / S) * HROW + i % S] = hreg[j];
         }
         __syncthreads();
+        // every prologue load is waited for HERE: left pending, hipcc's counted waits for them at the first MFMAs of the
+        // loop body would also hold every later iteration until its predecessor's stores have completed
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int sq = 0; sq < SQ; ++sq) asm volatile("" ::"v"(areg[kt][sq]));
+            asm volatile("" ::"v"(nreg[kt]));
+        }
     } else {
         float em = 0.f;
         bool bad = false;
@@ -501,38 +562,19 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
         for (int w = 1; w < NW; ++w) emax = fmaxf(emax, s_em[w]);
     }
 
-    // Two waves per SIMD running this loop in lockstep both want the matrix pipe, then both the VALU: the time of the
-    // phases adds up.  Waves 4..7 (the SIMD partners of 0..3) start half an iteration late so that one wave's MFMAs run
-    // beside the other's top-2 / merge / gather work (MI355X_MICROARCH.md, two waves per SIMD, item 9).
-    if constexpr (SINGLE) {
-        // every prologue load is waited for HERE: left pending, hipcc's counted waits for them at the first MFMAs of the
-        // loop body (vmcnt(4)) would also hold every later iteration until its predecessor's stores have completed
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int sq = 0; sq < SQ; ++sq) asm volatile("" ::"v"(areg[kt][sq]));
-            asm volatile("" ::"v"(nreg[kt]));
-        }
-    }
-    if (NW == 8 && wave >= 4 && stagger > 0)
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    // the position tile this lane owns after the reduce-scatter, and constants of the stores
+    const unsigned ovoff = zvoff;                                  // `out` has z's layout
+    const unsigned ivoff = (4u * (unsigned)c + 2u * (unsigned)h) * 8u;      // int64 indices of positions 4c + 2h, + 1 (lanes h < 2)
+
     for (unsigned q = blockIdx.x; q * (unsigned)NW < NC; q += gridDim.x) {
         const bool act = chunk < NC;                           // wave-uniform
-        if (ablate & 64) __builtin_amdgcn_s_barrier();         // experiment: the workgroup's waves request their rows together
-        const long long zoff = zptr(chunk, cb_, cw_);
         unsigned nchunk = chunk + qstep, nb = cb_ + step_b, nw = cw_ + step_c;
         if (nw >= cps) { nw -= cps; ++nb; }
         // the next chunk's z is requested now and lands under this chunk's MFMAs
-        f32x4 zn[PREFETCH ? S : 1];
-        if constexpr (PREFETCH) {
-            const long long o = zptr(nchunk, nb, nw);
-#pragma unroll
-            for (int s = 0; s < S; ++s) zn[s] = *reinterpret_cast<const f32x4 *>(z + o + (long long)(4 * s) * HW);
-        }
+        f32x4 zn[S];
+        z_load(zn, nchunk, nb, nw);
 
-        VQ2_STAMP(1)                                           // addresses + prefetch issue
-        VQ2_USE(zr[S - 1]);
-        VQ2_STAMP(2)                                           // this chunk's z has arrived
+        VQ2_STAMP(1)                                           // prefetch issue
         float m1[4], m2[4];
         int c1[4];
 #pragma unroll
@@ -559,17 +601,21 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
                         }
                     }
                 }
-                const float pm1 = m1[t];
+                // the score's low 4 bits become its number inside the lane (code = 16 kt + 4 h + r): the minimum carries it
+                float v[16];
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = vq2_embed(acc[kt][r], (unsigned)(kt * 16 + r));
-                        m2[t] = vq2_med3(m1[t], m2[t], v);
-                        m1[t] = vq2_min(m1[t], v);
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        v[kt * 4 + r] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, (float)acc[kt][r]) & ~15u) | (unsigned)(kt * 4 + r));
+                float t1, t2;
+                vq2_top2_16(v, t1, t2);
+                if constexpr (SINGLE) { m1[t] = t1; m2[t] = t2; }
+                else {
+                    m2[t] = vq2_min3(m2[t], t2, vq2_max(m1[t], t1));
+                    c1[t] = t1 < m1[t] ? ccg : c1[t];
+                    m1[t] = vq2_min(m1[t], t1);
                 }
-                if constexpr (!SINGLE) c1[t] = m1[t] < pm1 ? ccg : c1[t];
             }
         };
 
@@ -606,90 +652,135 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
 
         VQ2_USE(m1[3]); VQ2_USE(m2[3]);
         VQ2_STAMP(3)                                           // MFMAs + in-lane top-2
-#ifdef VQ2_STAMPS
-        if constexpr (PREFETCH) { VQ2_USE(zn[S - 1]); }
-        VQ2_STAMP(7)                                           // (diagnostic: has the prefetch landed after the MFMA phase?)
-#endif
         f32x4 o[S];
         long long kpair[2] = {0, 0};
-        int kk = 0;
+        int kown = 0;
         if (act) {
-            const unsigned hbits = (unsigned)h << 2;
-            int kb[4];
-            // one instantiation per position tile (the tile number is a compile-time constant)
-            auto finish_tile = [&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                float a1 = vq2_or(m1[t], hbits), a2 = vq2_or(m2[t], hbits);
-                int cc1 = c1[t];
-                float zz = 0.f;
+            // ---- reduce-scatter over the 4 lanes of a column: 9 lane-pair swaps, then this lane owns tile own_tile ----
+            float zp[4];
 #pragma unroll
-                for (int s = 0; s < S; ++s) zz = fmaf(zr[s][t], zr[s][t], zz);
-                auto merge = [&](auto mc) {
-                    constexpr int M = decltype(mc)::value;
-                    float l1, h1, l2, h2, lz, hz;
-                    vq2_pair<M>(a1, l1, h1);
-                    vq2_pair<M>(a2, l2, h2);
-                    vq2_pair<M>(zz, lz, hz);
-                    if constexpr (!SINGLE) {
-                        unsigned lc, hc;
-                        vq2_pair<M>((unsigned)cc1, lc, hc);
-                        cc1 = (int)(h1 < l1 ? hc : lc);
-                    }
-                    a2 = vq2_min3(l2, h2, vq2_max(l1, h1));
-                    a1 = vq2_min(l1, h1);
-                    zz = lz + hz;
-                };
-                merge(std::integral_constant<int, 16>{});
-                merge(std::integral_constant<int, 32>{});
-                const float tol = TOL_A * (zz + 2.f * emax) + TOL_D * fmaxf(zz + a1, 0.f) + 1e-30f;
-                const bool flagged = !((a2 - a1) > tol) && !(ablate & 32);       // also true when anything is NaN / inf
-                kb[t] = (SINGLE ? 0 : cc1 * 64) + (int)(__builtin_bit_cast(unsigned, a1) & 63u);
-                unsigned long long fm = __ballot(flagged) & 0xFFFFull;      // the four h rows agree: take row 0
-                while (fm) {
-                    const int col = __builtin_ctzll(fm);
-                    fm &= fm - 1;
-                    float zv[D];
+            for (int t = 0; t < 4; ++t) {
+                zp[t] = 0.f;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        // (through a scalar temporary: __builtin_bit_cast applied to the vector-element lvalue
-                        // zr[s][t] itself reads element 0 whatever t is -- clang 7.2, seen in the IR)
-                        const float zc = zr[d >> 2][t];
-                        zv[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zc), (d & 3) * 16 + col));
+                for (int s = 0; s < S; ++s) zp[t] = fmaf(zr[s][t], zr[s][t], zp[t]);
+            }
+            float A1[2], A2[2], ZZ[2];
+            int CC[2];
+            // step 1, lanes h ^ 1: even rows keep tiles {0, 1}, odd rows tiles {2, 3}; the low embedded bit 4 of the
+            // minimum records which row it came from (bit 0 of the winner's h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float x1 = m1[j], y1 = m1[j + 2], x2 = m2[j], y2 = m2[j + 2], xz = zp[j], yz = zp[j + 2];
+                vq2_swap<16>(x1, y1);
+                vq2_swap<16>(x2, y2);
+                vq2_swap<16>(xz, yz);
+                const bool odd_wins = y1 < x1;
+                if constexpr (!SINGLE) {
+                    float xc = __builtin_bit_cast(float, c1[j]), yc = __builtin_bit_cast(float, c1[j + 2]);
+                    vq2_swap<16>(xc, yc);
+                    CC[j] = __builtin_bit_cast(int, odd_wins ? yc : xc);
+                }
+                A2[j] = vq2_min3(x2, y2, vq2_max(x1, y1));
+                const float w = vq2_min(x1, y1);
+                A1[j] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, w) & ~16u) | (odd_wins ? 16u : 0u));
+                ZZ[j] = xz + yz;
+            }
+            // step 2, lanes h ^ 2: the lower half keeps its first tile, the upper half its second
+            float a1, a2, zz;
+            int cc1 = 0, hb1;
+            {
+                float x1 = A1[0], y1 = A1[1], x2 = A2[0], y2 = A2[1], xz = ZZ[0], yz = ZZ[1];
+                vq2_swap<32>(x1, y1);
+                vq2_swap<32>(x2, y2);
+                vq2_swap<32>(xz, yz);
+                const bool hi_wins = y1 < x1;
+                if constexpr (!SINGLE) {
+                    float xc = __builtin_bit_cast(float, CC[0]), yc = __builtin_bit_cast(float, CC[1]);
+                    vq2_swap<32>(xc, yc);
+                    cc1 = __builtin_bit_cast(int, hi_wins ? yc : xc);
+                }
+                a2 = vq2_min3(x2, y2, vq2_max(x1, y1));
+                a1 = vq2_min(x1, y1);
+                zz = xz + yz;
+                hb1 = hi_wins ? 2 : 0;
+            }
+            const float tol = TOL_A * (zz + 2.f * emax) + TOL_D * fmaxf(zz + a1, 0.f) + 1e-30f;
+            const bool flagged = !((a2 - a1) > tol) && !(ablate & 32);     // also true when anything is NaN / inf
+            {
+                const unsigned bits = __builtin_bit_cast(unsigned, a1);
+                const int kt = (bits >> 2) & 3, r = bits & 3, hw = hb1 | ((bits >> 4) & 1);
+                kown = (SINGLE ? 0 : cc1 * 64) + kt * 16 + hw * 4 + r;
+            }
+            VQ2_USE(kown);
+            VQ2_STAMP(4)                                       // reduce-scatter, tolerance
+            // ---- exact re-check of the positions that failed the test: the whole wave, one position at a time ----
+            unsigned long long fm = __ballot(flagged);
+            while (fm) {
+                const int fl = __builtin_ctzll(fm);
+                fm &= fm - 1;
+                const int col = fl & 15, fh = fl >> 4, ft = ((fh & 1) << 1) | (fh >> 1);      // the lane's column and tile
+                float zv[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    // (scalar temporaries: __builtin_bit_cast applied to a vector-element lvalue reads element 0 -- clang 7.2)
+                    const float z0 = zr[d >> 2][0], z1 = zr[d >> 2][1], z2 = zr[d >> 2][2], z3 = zr[d >> 2][3];
+                    const float zc = ft == 0 ? z0 : (ft == 1 ? z1 : (ft == 2 ? z2 : z3));
+                    zv[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zc), (d & 3) * 16 + col));
+                }
+                float bd = __builtin_inff();
+                int bk = 0x7fffffff;
+                if constexpr (SINGLE) {
+                    // the codebook row of code `lane` from the LDS copy (no vector-memory operation in this loop)
+                    float er[D];
+                    const f32x4 *__restrict__ hr = s_H + lane * HROW;
+                    if constexpr (S % 4 == 0) {
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+                            for (int s4 = 0; s4 < S / 4; ++s4) {
+                                const f32x4 v = hr[hh * (S / 4) + s4];
+                                er[4 * (4 * s4) + hh] = v.x; er[4 * (4 * s4 + 1) + hh] = v.y;
+                                er[4 * (4 * s4 + 2) + hh] = v.z; er[4 * (4 * s4 + 3) + hh] = v.w;
+                            }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) er[d] = reinterpret_cast<const float *>(hr)[(d & 3) * S + (d >> 2)];
                     }
-                    float bd = __builtin_inff();
-                    int bk = 0x7fffffff;
+                    if (lane < K) { bd = vq_exact_dist<D>(zv, er); bk = lane; }
+                } else {
                     if (lane < K) { bd = vq_exact_dist<D>(zv, cb + (long long)lane * D); bk = lane; }
                     for (int k = lane + 64; k < K; k += 64) {
                         const float dk = vq_exact_dist<D>(zv, cb + (long long)k * D);
                         const bool bt = vq_better(dk, bd);
                         bd = bt ? dk : bd; bk = bt ? k : bk;
                     }
-#pragma unroll
-                    for (int m = 1; m < 64; m <<= 1) {
-                        const float od = __shfl_xor(bd, m, 64);
-                        const int ok = __shfl_xor(bk, m, 64);
-                        // the other lane's candidate wins: NaN beats numbers, equal distances (and two NaNs) go to the smaller code
-                        const int an = bd != bd, bn = od != od, lk = ok < bk;
-                        const int other = (bn & ((an ^ 1) | lk)) | ((bn ^ 1) & (an ^ 1) & ((od < bd) | ((od == bd) & lk)));
-                        bd = other ? od : bd; bk = other ? ok : bk;
-                    }
-                    kb[t] = (c == col) ? bk : kb[t];
-                    ++nflag;
                 }
-            };
-            if (!(ablate & 2)) {
-                finish_tile(std::integral_constant<int, 0>{});
-                finish_tile(std::integral_constant<int, 1>{});
-                finish_tile(std::integral_constant<int, 2>{});
-                finish_tile(std::integral_constant<int, 3>{});
-            } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) kb[t] = (int)(__builtin_bit_cast(unsigned, m1[t]) & 63u);
+                for (int m = 1; m < 64; m <<= 1) {
+                    const float od = __shfl_xor(bd, m, 64);
+                    const int ok = __shfl_xor(bk, m, 64);
+                    // the other lane's candidate wins: NaN beats numbers, equal distances (and two NaNs) go to the smaller code
+                    const int an = bd != bd, bn = od != od, lk = ok < bk;
+                    const int other = (bn & ((an ^ 1) | lk)) | ((bn ^ 1) & (an ^ 1) & ((od < bd) | ((od == bd) & lk)));
+                    bd = other ? od : bd; bk = other ? ok : bk;
+                }
+                kown = lane == fl ? bk : kown;
+                ++nflag;
             }
-
+            // ---- all-gather of the four codes of the column (3 swaps) ----
+            int kb[4];
+            {
+                float lo = __builtin_bit_cast(float, kown), hi = lo;
+                vq2_swap<32>(lo, hi);                          // lo: the lower half's code (tile 0 or 2), hi: the upper half's (1 or 3)
+                float e0 = lo, o0 = lo, e1 = hi, o1 = hi;
+                vq2_swap<16>(e0, o0);                          // even row's: tile 0, odd row's: tile 2
+                vq2_swap<16>(e1, o1);                          // tile 1, tile 3
+                kb[0] = __builtin_bit_cast(int, e0); kb[2] = __builtin_bit_cast(int, o0);
+                kb[1] = __builtin_bit_cast(int, e1); kb[3] = __builtin_bit_cast(int, o1);
+            }
             VQ2_USE(kb[3]);
-            VQ2_STAMP(4)                                       // cross-lane merge, tolerance, exact re-checks
-            // gather + straight-through value + squared error, in the layout the lane already holds
+            VQ2_STAMP(5)                                       // exact re-checks, all-gather
+            // ---- gather + straight-through value + squared error, in the layout the lane already holds ----
             float ssef = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -715,46 +806,40 @@ __global__ __launch_bounds__(64 * NW, MINW) void vq_forward_mfma_kernel(
             }
             sse += (double)ssef;
             kpair[0] = (long long)(h ? kb[2] : kb[0]); kpair[1] = (long long)(h ? kb[3] : kb[1]);
-            kk = h == 0 ? kb[0] : (h == 1 ? kb[1] : (h == 2 ? kb[2] : kb[3]));
             VQ2_USE(o[S - 1]); VQ2_USE(ssef);
-            VQ2_STAMP(5)                                       // gather, straight-through value, squared error
+            VQ2_STAMP(6)                                       // gather, straight-through value, squared error
         }
         // The prefetched z replaces this chunk's BEFORE the stores are issued: the wait for the prefetch then counts loads
-        // only.  After the stores (vmcnt counts loads and stores in issue order, and hipcc cannot count across the re-check
-        // branches) it was a vmcnt(0): every wave sat out the completion of its own stores once per chunk.
-        if constexpr (PREFETCH) {
+        // only (vmcnt retires loads and stores in issue order; after the stores it would be a wait for them too).
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                asm volatile("" : "+v"(zn[s]));                // (an opaque use pins the wait here; a plain copy is only renaming)
-                zr[s] = zn[s];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < S; ++s) {
+            asm volatile("" : "+v"(zn[s]));                    // (an opaque use pins the wait here; a plain copy is only renaming)
+            zr[s] = zn[s];
         }
+        __builtin_amdgcn_sched_barrier(0);
         VQ2_STAMP(0)                                           // wait for the prefetched z
         if (act) {
             if (out && !(ablate & 1)) {
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long long)cb_ * D * HW, 0, sample_bytes, 0x00020000);
 #pragma unroll
-                for (int s = 0; s < S; ++s) *reinterpret_cast<f32x4 *>(out + zoff + (long long)(4 * s) * HW) = o[s];
+                for (int s = 0; s < S; ++s)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o[s]),
+                                                           ro, ovoff, cw_ * 256u + (unsigned)(4 * s) * (unsigned)HW * 4u, 0);
             }
-            if (idx && h < 2 && !(ablate & 1))
-                *reinterpret_cast<f32x4 *>(idx + ((long long)chunk << 6) + 4 * c + 2 * h) = *reinterpret_cast<const f32x4 *>(kpair);
+            if (idx && h < 2 && !(ablate & 1)) {
+                const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(idx + (long long)cb_ * HW, 0, (unsigned)HW * 8u, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(kpair),
+                                                       ri, ivoff, cw_ * 512u, 0);
+            }
             if (!(ablate & 8)) {
-                if (lds_hist) atomicAdd(&s_hist[kk], 1);
-                else atomicAdd(&hist[kk], 1);
+                if (lds_hist) atomicAdd(&s_hist[kown], 1);
+                else atomicAdd(&hist[kown], 1);
             }
         }
-        VQ2_STAMP(6)                                           // stores issued
-        if constexpr (!PREFETCH) {
-            if ((q + gridDim.x) * (unsigned)NW < NC) {
-                const long long o2 = zptr(nchunk, nb, nw);
-#pragma unroll
-                for (int s = 0; s < S; ++s) zr[s] = *reinterpret_cast<const f32x4 *>(z + o2 + (long long)(4 * s) * HW);
-            }
-        }
+        VQ2_STAMP(7)                                           // stores issued
         chunk = nchunk; cb_ = nb; cw_ = nw;
     }
 
-    VQ2_STAMP(0)
     if (ablate & 16) return;
     const double tot = block_sum(sse, s_red);
     if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
@@ -913,35 +998,24 @@ extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int6
     // (vq_prep_kernel cleared the counter replicas and all slabs: there are fewer workgroups than slabs)
     int *hrep = reinterpret_cast<int *>(ws + L.hrep);
     if (use2) {
-        const char *tune = getenv("DM_VQ2_TUNE");              // experiment switches, removed once measured
-        const int tv = tune ? atoi(tune) : 0;
-        const char *tw = getenv("DM_VQ2_WGS");
+        const char *tw = getenv("DM_VQ2_WGS");                 // experiment switches (unset in every product run)
         const int wgs_env = tw ? atoi(tw) : 0;
         const char *ta = getenv("DM_VQ2_ABLATE");
         const int ablate = ta ? atoi(ta) : 0;
-        const char *ts = getenv("DM_VQ2_STAGGER");
-        const int stagger = ts ? atoi(ts) : 0;
-#define DM_VQ2(DD, SINGLE_, PF, MINW, WGS, NW)                                                                       \
+        const long long groups = ((P >> 6) + 3) / 4;
+#define DM_VQ2(DD, SINGLE_, MINW, WGS)                                                                               \
     {                                                                                                                \
         const int wgs = wgs_env > 0 ? wgs_env : (WGS);                                                               \
-        const long long groups = ((P >> 6) + (NW) - 1) / (NW);                                                       \
-        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, PF, MINW, NW>), dim3((unsigned)(groups < 256 * wgs ? groups : 256 * wgs)), \
-                           dim3(64 * (NW)), 0, s, z, codebook, ws + L.cbA, ws + L.nrm, ws + L.cbH, (long long *)idx, out, \
-                           sse_slabs, hrep, L.R, (int *)ws, K, H * W, P, ablate, stagger);                           \
+        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW>), dim3((unsigned)(groups < 256 * wgs ? groups : 256 * wgs)), \
+                           dim3(256), 0, s, z, codebook, ws + L.cbA, ws + L.nrm, ws + L.cbH, (long long *)idx, out,    \
+                           sse_slabs, hrep, L.R, (int *)ws, K, H * W, P, ablate);                                    \
     }
         const bool single = K <= 64;
         switch (D) {
-        case 8: if (single) DM_VQ2(8, true, true, 4, 4, 4) else DM_VQ2(8, false, false, 3, 3, 4) break;
-        case 16:
-            if (single) {
-                if (tv == 1) DM_VQ2(16, true, false, 4, 4, 4)
-                else if (tv == 2) DM_VQ2(16, true, true, 3, 3, 4)
-                else if (tv == 3) DM_VQ2(16, true, true, 2, 1, 8)
-                else DM_VQ2(16, true, true, 4, 4, 4)
-            } else DM_VQ2(16, false, false, 3, 3, 4)
-            break;
-        case 32: if (single) DM_VQ2(32, true, false, 2, 2, 4) else DM_VQ2(32, false, false, 2, 2, 4) break;
-        default: if (single) DM_VQ2(64, true, false, 1, 1, 4) else DM_VQ2(64, false, false, 1, 2, 4) break;
+        case 8: if (single) DM_VQ2(8, true, 3, 3) else DM_VQ2(8, false, 3, 3) break;
+        case 16: if (single) DM_VQ2(16, true, 3, 3) else DM_VQ2(16, false, 3, 3) break;
+        case 32: if (single) DM_VQ2(32, true, 2, 2) else DM_VQ2(32, false, 2, 2) break;
+        default: if (single) DM_VQ2(64, true, 1, 1) else DM_VQ2(64, false, 1, 2) break;
         }
 #undef DM_VQ2
         hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);

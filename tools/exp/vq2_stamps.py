@@ -9,8 +9,8 @@ dev = "cuda:0"
 z = torch.randn(B, D, H, W, device=dev); cb = torch.randn(K, D, device=dev)
 lib = L.load()
 wsb = lib.dm_vq_workspace_bytes(K, D)
-names = ["back edge/prologue", "addresses + prefetch issue", "wait for z", "MFMA + in-lane top-2", "merge/tol/re-check",
-         "gather + out", "stores issue", "prefetch wait after MFMA phase"]
+names = ["wait for prefetched z (before stores)", "prefetch issue", "-", "MFMA + in-lane top-2", "reduce-scatter + tolerance",
+         "re-checks + all-gather", "gather + out", "stores issue"]
 for rep in range(3):
     idx = torch.empty(B, H, W, device=dev, dtype=torch.int64); out = torch.empty_like(z)
     slabs = torch.empty(lib.dm_vq_num_blocks(B * H * W), device=dev, dtype=torch.float64)
