@@ -12,7 +12,6 @@
 // codebook is first re-laid out as [K/2][D][2] so a pair's operands are adjacent, staged in
 // LDS per workgroup and read with wave-uniform (broadcast) ds_read_b128.
 #include "dm_common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -435,9 +434,8 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbA,
     const float *__restrict__ nrm, const float *__restrict__ cbH, long long *__restrict__ idx,
     float *__restrict__ out, double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int *__restrict__ hdr,
-    int K, int HW, long long P, int ablate)
+    int K, int HW, long long P)
 {
-    // `ablate` (0 in every product launch) switches phases off for timing experiments only (DM_VQ2_ABLATE, results wrong)
     constexpr int BLOCK = 256, NW = 4;
     int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;     // this workgroup's replica of the counters
     constexpr int S = D / 4, SQ = (S + 3) / 4;
@@ -445,7 +443,8 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     constexpr int PIECE = SINGLE ? 1 : (2048 / CHUNK_F4 > 0 ? 2048 / CHUNK_F4 : 1);   // code chunks per 32 KB LDS piece
     constexpr float U = 5.9604645e-8f;                             // 2^-24
     // 32 ulp of index bits (4 in the lane, 1 in the first merge step) instead of the 64 of the header comment's bound
-    constexpr float TOL_A = 4.f * (D + 65) * U, TOL_D = 4.f * (D / 16 + 18) * U;
+    // (margin 1.25 over the first-order bound: the neglected terms are O(u) relative to it)
+    constexpr float TOL_A = 2.5f * (D + 65) * U, TOL_D = 2.5f * (D / 16 + 18) * U;
     __shared__ f32x4 s_A[SINGLE ? 1 : PIECE * CHUNK_F4];
     __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];
     constexpr int HROW = S + 1;                                       // f32x4 per code in s_H: D floats + 16 bytes of padding (banks)
@@ -620,11 +619,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
         };
 
         if constexpr (SINGLE) {
-            if (act && !(ablate & 4)) chunk_scores(nreg, [&](int kt, int sq) { return areg[kt][sq]; }, 0);
-            if (ablate & 4) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { m1[t] = zr[0][t]; m2[t] = zr[1][t] + 100.f; }
-            }
+            if (act) chunk_scores(nreg, [&](int kt, int sq) { return areg[kt][sq]; }, 0);
         } else {
             for (int p0 = 0; p0 < ncc; p0 += PIECE) {
                 const int pn = min(PIECE, ncc - p0);
@@ -705,7 +700,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                 hb1 = hi_wins ? 2 : 0;
             }
             const float tol = TOL_A * (zz + 2.f * emax) + TOL_D * fmaxf(zz + a1, 0.f) + 1e-30f;
-            const bool flagged = !((a2 - a1) > tol) && !(ablate & 32);     // also true when anything is NaN / inf
+            const bool flagged = !((a2 - a1) > tol);           // also true when anything is NaN / inf
             {
                 const unsigned bits = __builtin_bit_cast(unsigned, a1);
                 const int kt = (bits >> 2) & 3, r = bits & 3, hw = hb1 | ((bits >> 4) & 1);
@@ -755,14 +750,23 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                         bd = bt ? dk : bd; bk = bt ? k : bk;
                     }
                 }
-#pragma unroll
-                for (int m = 1; m < 64; m <<= 1) {
-                    const float od = __shfl_xor(bd, m, 64);
-                    const int ok = __shfl_xor(bk, m, 64);
+                // wave-wide first minimum: DPP moves inside the 16-lane rows, lane-pair swaps across them (no LDS round trips)
+                auto combine = [&](float od, int ok) {
                     // the other lane's candidate wins: NaN beats numbers, equal distances (and two NaNs) go to the smaller code
                     const int an = bd != bd, bn = od != od, lk = ok < bk;
                     const int other = (bn & ((an ^ 1) | lk)) | ((bn ^ 1) & (an ^ 1) & ((od < bd) | ((od == bd) & lk)));
                     bd = other ? od : bd; bk = other ? ok : bk;
+                };
+                combine(lane_xor1(bd), __builtin_bit_cast(int, lane_xor1(__builtin_bit_cast(float, bk))));
+                combine(lane_xor2(bd), __builtin_bit_cast(int, lane_xor2(__builtin_bit_cast(float, bk))));
+                combine(lane_xor4(bd), __builtin_bit_cast(int, lane_xor4(__builtin_bit_cast(float, bk))));
+                combine(lane_xor8(bd), __builtin_bit_cast(int, lane_xor8(__builtin_bit_cast(float, bk))));
+                {
+                    float dl, dh; unsigned kl, kh;
+                    vq2_pair<16>(bd, dl, dh); vq2_pair<16>((unsigned)bk, kl, kh);
+                    bd = dl; bk = (int)kl; combine(dh, (int)kh);
+                    vq2_pair<32>(bd, dl, dh); vq2_pair<32>((unsigned)bk, kl, kh);
+                    bd = dl; bk = (int)kl; combine(dh, (int)kh);
                 }
                 kown = lane == fl ? bk : kown;
                 ++nflag;
@@ -819,28 +823,25 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
         __builtin_amdgcn_sched_barrier(0);
         VQ2_STAMP(0)                                           // wait for the prefetched z
         if (act) {
-            if (out && !(ablate & 1)) {
+            if (out) {
                 const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long long)cb_ * D * HW, 0, sample_bytes, 0x00020000);
 #pragma unroll
                 for (int s = 0; s < S; ++s)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o[s]),
                                                            ro, ovoff, cw_ * 256u + (unsigned)(4 * s) * (unsigned)HW * 4u, 0);
             }
-            if (idx && h < 2 && !(ablate & 1)) {
+            if (idx && h < 2) {
                 const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(idx + (long long)cb_ * HW, 0, (unsigned)HW * 8u, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned *>(kpair),
                                                        ri, ivoff, cw_ * 512u, 0);
             }
-            if (!(ablate & 8)) {
-                if (lds_hist) atomicAdd(&s_hist[kown], 1);
-                else atomicAdd(&hist[kown], 1);
-            }
+            if (lds_hist) atomicAdd(&s_hist[kown], 1);
+            else atomicAdd(&hist[kown], 1);
         }
         VQ2_STAMP(7)                                           // stores issued
         chunk = nchunk; cb_ = nb; cw_ = nw;
     }
 
-    if (ablate & 16) return;
     const double tot = block_sum(sse, s_red);
     if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
     if (lane == 0 && nflag) atomicAdd(hdr, nflag);
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4) + i, st_sum[i]);
 #endif
-    if (lds_hist && !(ablate & 8)) {
+    if (lds_hist) {
         __syncthreads();
         for (int k = threadIdx.x; k < K; k += BLOCK) {
             const int cnt = s_hist[k];
@@ -998,17 +999,13 @@ extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int6
     // (vq_prep_kernel cleared the counter replicas and all slabs: there are fewer workgroups than slabs)
     int *hrep = reinterpret_cast<int *>(ws + L.hrep);
     if (use2) {
-        const char *tw = getenv("DM_VQ2_WGS");                 // experiment switches (unset in every product run)
-        const int wgs_env = tw ? atoi(tw) : 0;
-        const char *ta = getenv("DM_VQ2_ABLATE");
-        const int ablate = ta ? atoi(ta) : 0;
         const long long groups = ((P >> 6) + 3) / 4;
 #define DM_VQ2(DD, SINGLE_, MINW, WGS)                                                                               \
     {                                                                                                                \
-        const int wgs = wgs_env > 0 ? wgs_env : (WGS);                                                               \
+        const int wgs = (WGS);                                                                                       \
         hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW>), dim3((unsigned)(groups < 256 * wgs ? groups : 256 * wgs)), \
                            dim3(256), 0, s, z, codebook, ws + L.cbA, ws + L.nrm, ws + L.cbH, (long long *)idx, out,    \
-                           sse_slabs, hrep, L.R, (int *)ws, K, H * W, P, ablate);                                    \
+                           sse_slabs, hrep, L.R, (int *)ws, K, H * W, P);                                            \
     }
         const bool single = K <= 64;
         switch (D) {
