@@ -5,6 +5,7 @@ raises, so a GPU box can never silently run something else than the HIP kernels.
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DM_LIB_PATH: a diagnostic twin of the library (make -C csrc stamps) for experiments; the package default is the in-tree .so
@@ -101,6 +102,40 @@ class DynamorphHipError(RuntimeError):
     pass
 
 
+class _CallDevice(threading.local):
+    """Device of the tensors handed to the call being assembled (dynamorph_amd.ops._ptr records it)."""
+    index = None
+
+
+call_device = _CallDevice()
+
+
+def _guarded(fn):
+    """The entry points take raw pointers and enqueue on whatever device is current, so the tensors' device is made
+    current around the call (the reference hands non-zero gpu ids to its workers, run_VAE.py:78-85): a kernel launched on
+    device 0's stream against device-N memory is a fault or a silent race."""
+    def call(*args):
+        dev, call_device.index = call_device.index, None
+        if dev is None:
+            return fn(*args)
+        import torch
+        if dev == torch.cuda.current_device():
+            return fn(*args)
+        with torch.cuda.device(dev):
+            return fn(*args)
+    call.__name__ = getattr(fn, "__name__", "dm_call")
+    return call
+
+
+class _Library:
+    """Attribute access to the C entry points, each behind the device guard."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name in SIGNATURES:
+            setattr(self, name, _guarded(getattr(cdll, name)))
+
+
 def load():
     """Load the library once; raise (never fall back) when it is not built."""
     global _lib
@@ -115,8 +150,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _Library(lib)
+    return _lib
 
 
 def check(rc, what):

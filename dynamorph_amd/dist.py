@@ -38,6 +38,33 @@ def world_size(group=None):
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def get_rank(group=None):
+    return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def barrier(group=None):
+    if world_size(group) > 1:
+        dist.barrier(group=group)
+
+
+def broadcast_object(obj, src=0, group=None):
+    """A small picklable object from `src` to every rank (seeds, split points); the identity in a single process."""
+    if world_size(group) == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
+def allreduce_sum_host(values, device=None, group=None):
+    """Element-wise sum over ranks of a short list of Python floats (epoch loss sums: one collective per epoch)."""
+    if world_size(group) == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.tolist()
+
+
 def shard_range(n, rank, world):
     """Contiguous shard [lo, hi) of n independent units for `rank`; sizes differ by at most one and the
     shards tile [0, n) in rank order (so gathering in rank order restores file-path order)."""

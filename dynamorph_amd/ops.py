@@ -13,7 +13,10 @@ from ._lib import DM_LOAD_AFFINE, DM_LOAD_AFFINE2, DM_LOAD_AFFINE_RELU, DM_LOAD_
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """The stream of the device the call's tensors live on (recorded by _ptr), not of whatever device is current; the
+    launch itself runs under a device guard (_lib._guarded)."""
+    dev = L.call_device.index
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _ptr(t, dtype=torch.float32):
@@ -25,6 +28,12 @@ def _ptr(t, dtype=torch.float32):
         raise ValueError(f"dynamorph_amd: expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError("dynamorph_amd: tensor must be contiguous")
+    dev = t.device.index
+    if L.call_device.index is None:
+        L.call_device.index = dev
+    elif L.call_device.index != dev:
+        first, L.call_device.index = L.call_device.index, None
+        raise ValueError(f"dynamorph_amd: operands of one call live on different devices (cuda:{first} and cuda:{dev})")
     return t.data_ptr()
 
 
@@ -34,7 +43,8 @@ class Op:
 
     def __init__(self, p0, mode=DM_LOAD_IDENT, coef=None, p1=None, ones=False, per_sample=False):
         self.p0, self.p1, self.coef, self.mode, self.ones = p0, p1, coef, mode, ones
-        self.bstride = coef.shape[-2] * 4 if (per_sample and coef is not None) else 0
+        # per-sample coefficients are (B, C, 4); eval-mode BatchNorm hands the shared (C, 4) table to the per-sample path too
+        self.bstride = coef.shape[-2] * 4 if (per_sample and coef is not None and coef.dim() == 3) else 0
 
     def struct(self):
         return L.Operand(_ptr(self.p0), _ptr(self.p1), _ptr(self.coef), self.bstride, self.mode, 1 if self.ones else 0)
@@ -478,6 +488,7 @@ def zscore_patch(x):
     x = x.contiguous()
     N, Cn, H, W = x.shape
     out = torch.empty((N, Cn, H, W), device=x.device, dtype=torch.float32)
+    L.call_device.index = x.device.index
     L.check(lib.dm_zscore_patch(C.c_void_p(x.data_ptr()), 1 if x.dtype == torch.float64 else 0, _ptr(out), N * Cn, H * W,
                                 _stream()), "dm_zscore_patch")
     return out

@@ -45,7 +45,8 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
         def encode(x):                      # any other module: the reference's batch-of-one loop as it is
             return torch.cat([model.enc(x[j:j + 1]) for j in range(x.shape[0])], 0)
     z_bs, z_as = [], []
-    with torch.no_grad():
+    device = torch.device(device)
+    with torch.no_grad(), torch.cuda.device(device):           # (the reference hands non-zero gpu ids to its workers)
         for i in range(0, patches.shape[0], batch_size):
             if zscore_on_device:
                 x = ops.zscore_patch(patches[i:i + batch_size].to(device=device))

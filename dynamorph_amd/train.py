@@ -53,11 +53,8 @@ class FusedTrainer:
         self.w_recon = torch.tensor([float(model.weight_recon)], device=dev)
         self.w_commit = torch.tensor([float(model.weight_commitment)], device=dev)
         self.use_graph = use_graph
-        self._graph = None
-        self._static_x = None
-        self._static_mask = None
-        self._static_tm = None
-        self._static_out = None
+        self._graphs = {}            # input shapes -> (graph, static x, static mask, static matrix, static output)
+        self._static_x = None        # input tensor of the graph replayed last
         D.broadcast_(self.flat, list(model.buffers()), group=self.group)    # same replica everywhere
 
     # ------------------------------------------------------------------------------------------
@@ -113,8 +110,15 @@ class FusedTrainer:
         E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False, pending_extra=extra)
         return scalars
 
-    def _allreduce(self):
-        D.allreduce_mean_(self.grad, self.group)     # every loss is a mean over the local batch
+    def _allreduce(self, weight=1.0):
+        """Mean over ranks of the flat gradient bucket: ONE collective.  Every loss is a mean over the LOCAL batch, so with
+        equal shards the mean of the per-rank gradients is the gradient of the global-batch mean loss; a rank whose shard
+        of a ragged batch is smaller passes weight = n_local * world / n_global (0 for an empty shard)."""
+        if self.world == 1:
+            return
+        if weight != 1.0:
+            self.grad.mul_(float(weight))
+        D.allreduce_mean_(self.grad, self.group)
 
     def _adam(self):
         a, b = self._step_slot, 1 - self._step_slot
@@ -122,31 +126,44 @@ class FusedTrainer:
                          self.step_dev[a:a + 1], self.step_dev[b:b + 1])
         self._step_slot = b
 
-    def step(self, x, mask=None, time_matching_mat=None):
+    def step_without_data(self):
+        """This rank's shard of a ragged global batch is empty: it contributes a zero gradient to the exchange and takes
+        the same Adam step as the others."""
+        with torch.cuda.device(self.flat.device):
+            self.grad.zero_()
+            self._allreduce()
+            self._adam()
+
+    def step(self, x, mask=None, time_matching_mat=None, grad_weight=1.0):
         """One optimisation step on a device batch; returns the device tensor of LOSS_KEYS values (+ the time-matching
-        loss as a fifth entry when a matrix is given)."""
+        loss as a fifth entry when a matrix is given).  grad_weight: see _allreduce."""
         if not x.is_cuda:
             raise RuntimeError("FusedTrainer.step: batch must be on the GPU")
+        if x.device != self.flat.device:
+            raise RuntimeError(f"FusedTrainer.step: batch on {x.device}, model on {self.flat.device}")
         x = x.contiguous()
-        if not self.use_graph:
-            out = self.forward_backward(x, mask, time_matching_mat)
-        else:
-            out = self._graph_step(x, mask, time_matching_mat)
-        self._allreduce()
-        self._adam()
+        with torch.cuda.device(self.flat.device):       # graph capture / replay and the streams are the model's device's
+            if not self.use_graph:
+                out = self.forward_backward(x, mask, time_matching_mat)
+            else:
+                out = self._graph_step(x, mask, time_matching_mat)
+            self._allreduce(grad_weight)
+            self._adam()
         return out
 
     def _graph_step(self, x, mask, tm=None):
+        """Graphs are cached per input shape (a ragged last batch gets its own, captured once, not once per epoch)."""
         key = (tuple(x.shape), None if mask is None else tuple(mask.shape), None if tm is None else tuple(tm.shape))
-        if self._graph is None or self._graph_key != key:
-            self._static_x = torch.empty_like(x)
-            self._static_mask = torch.empty_like(mask) if mask is not None else None
-            self._static_tm = torch.empty_like(tm, dtype=torch.float32) if tm is not None else None
-            self._static_x.copy_(x)
+        entry = self._graphs.get(key)
+        if entry is None:
+            sx = torch.empty_like(x)
+            smask = torch.empty_like(mask) if mask is not None else None
+            stm = torch.empty_like(tm, dtype=torch.float32) if tm is not None else None
+            sx.copy_(x)
             if mask is not None:
-                self._static_mask.copy_(mask)
+                smask.copy_(mask)
             if tm is not None:
-                self._static_tm.copy_(tm)
+                stm.copy_(tm)
             # warm-up on a side stream (allocator + lazy init), then capture.  The warm-up really executes,
             # so the BatchNorm running statistics it advanced are put back: only replays count as steps.
             bufs = list(self.model.buffers())
@@ -154,26 +171,28 @@ class FusedTrainer:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.forward_backward(self._static_x, self._static_mask, self._static_tm)
+                self.forward_backward(sx, smask, stm)
             torch.cuda.current_stream().wait_stream(s)
             for b, sv in zip(bufs, saved):
                 b.copy_(sv)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._static_out = self.forward_backward(self._static_x, self._static_mask, self._static_tm)
-            self._graph, self._graph_key = g, key
+                sout = self.forward_backward(sx, smask, stm)
+            entry = self._graphs[key] = (g, sx, smask, stm, sout)
         else:
-            if x.data_ptr() != self._static_x.data_ptr():      # a loader may write straight into input_buffer()
-                self._static_x.copy_(x)
-            if mask is not None and mask.data_ptr() != self._static_mask.data_ptr():
-                self._static_mask.copy_(mask)
+            _, sx, smask, stm, _ = entry
+            if x.data_ptr() != sx.data_ptr():      # a loader may write straight into input_buffer()
+                sx.copy_(x)
+            if mask is not None and mask.data_ptr() != smask.data_ptr():
+                smask.copy_(mask)
             if tm is not None:
-                self._static_tm.copy_(tm)
-        self._graph.replay()
-        return self._static_out
+                stm.copy_(tm)
+        self._static_x = entry[1]
+        entry[0].replay()
+        return entry[4]
 
     def input_buffer(self):
-        """The captured graph's input tensor (None before the first step): fill it in place to skip the copy."""
+        """Input tensor of the graph replayed last (None before the first step): fill it in place to skip the copy."""
         return self._static_x
 
 
@@ -241,31 +260,41 @@ class GraphedTrainer:
             raise RuntimeError("GraphedTrainer.step: batch must be on the GPU")
         tm = time_matching_mat
         key = (tuple(x.shape), None if mask is None else tuple(mask.shape), None if tm is None else tuple(tm.shape))
-        if key not in self._graphs:
-            self._graphs[key] = self._capture(x.contiguous(), mask, tm)       # (a ragged last batch gets its own graph)
-        else:
-            _, sx, smask, stm, _ = self._graphs[key]
-            sx.copy_(x)
-            if mask is not None:
-                smask.copy_(mask)
-            if tm is not None:
-                stm.copy_(tm)
-        g, _, _, _, out = self._graphs[key]
-        g.replay()
+        with torch.cuda.device(x.device):
+            if key not in self._graphs:
+                self._graphs[key] = self._capture(x.contiguous(), mask, tm)       # (a ragged last batch gets its own graph)
+            else:
+                _, sx, smask, stm, _ = self._graphs[key]
+                sx.copy_(x)
+                if mask is not None:
+                    smask.copy_(mask)
+                if tm is not None:
+                    stm.copy_(tm)
+            g, _, _, _, out = self._graphs[key]
+            g.replay()
         return out
 
 
 # ================================================================ reference-style loop mirrors
-def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, transform=None, training=True):
-    """run_training.py:377-417.  `optimizer` may be a torch optimizer (autograd path), a FusedTrainer or a GraphedTrainer."""
+def _augment(batch):
+    """run_training.py:396-403: a random flip (none / up-down / left-right) and a random multiple of 90 degrees per
+    sample, drawn from numpy's global generator like the reference -- applied by ONE kernel instead of the O(B) loop."""
+    n = len(batch)
+    flips = torch.from_numpy(np.random.choice([0, 1, 2], size=n)).to(device=batch.device, dtype=torch.int32)
+    rots = torch.from_numpy(np.random.choice([0, 1, 2, 3], size=n)).to(device=batch.device, dtype=torch.int32)
+    return ops.augment(batch.contiguous(), flips, rots)
+
+
+def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, transform=None, training=True,
+                  grad_weight=1.0):
+    """run_training.py:377-417.  `optimizer` may be a torch optimizer (autograd path), a FusedTrainer or a GraphedTrainer.
+    grad_weight scales this rank's gradient before the data-parallel mean (FusedTrainer._allreduce); 1 in one process."""
     model_kwargs = model_kwargs or {}
     if transform is not None:
-        flips = torch.from_numpy(np.random.choice([0, 1, 2], size=len(batch))).to(device=batch.device, dtype=torch.int32)
-        rots = torch.from_numpy(np.random.choice([0, 1, 2, 3], size=len(batch))).to(device=batch.device, dtype=torch.int32)
-        batch = ops.augment(batch.contiguous(), flips, rots)       # one kernel instead of the O(B) python loop
-    fused = isinstance(optimizer, (FusedTrainer, GraphedTrainer))
-    if fused and training:
-        vals = optimizer.step(batch, model_kwargs.get("batch_mask"), model_kwargs.get("time_matching_mat"))
+        batch = _augment(batch)
+    if isinstance(optimizer, (FusedTrainer, GraphedTrainer)) and training:
+        kw = {"grad_weight": grad_weight} if isinstance(optimizer, FusedTrainer) else {}
+        vals = optimizer.step(batch, model_kwargs.get("batch_mask"), model_kwargs.get("time_matching_mat"), **kw)
         vals = vals.tolist()                                           # one device sync per step (reference: five)
         loss_dict = dict(zip(LOSS_KEYS, vals))
         loss_dict["time_matching_loss"] = vals[4] if len(vals) > 4 else 0.
@@ -273,12 +302,30 @@ def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, t
         _, loss_dict = model(batch, **model_kwargs)
         if training:
             loss_dict['total_loss'].backward()
-            D.allreduce_grads_(list(model.parameters()))       # data parallel: one flat bucket (no-op in one process)
+            params = [p for p in model.parameters() if p.requires_grad]
+            if grad_weight != 1.0:
+                for p in params:
+                    if p.grad is not None:
+                        p.grad.mul_(float(grad_weight))
+            D.allreduce_grads_(params)                          # data parallel: one flat bucket (no-op in one process)
             optimizer.step()
             model.zero_grad()
     for key, loss in loss_dict.items():
         train_loss.setdefault(key, []).append(float(loss))
     return model, train_loss
+
+
+def _step_without_data(model, optimizer):
+    """A rank whose shard of a ragged global batch is empty still joins the gradient exchange (with zeros) and the step."""
+    if isinstance(optimizer, FusedTrainer):
+        optimizer.step_without_data()
+        return
+    params = [p for p in model.parameters() if p.requires_grad]
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    D.allreduce_grads_(params)
+    optimizer.step()
+    model.zero_grad()
 
 
 def get_relation_tensor(relation_mat, sample_ids, device='cuda:0'):
@@ -304,72 +351,119 @@ def get_mask(mask, sample_ids, device='cuda:0'):
     return m.to(device)
 
 
+class _EpochLosses:
+    """Per-key sums of (local loss x local samples) over an epoch; `means()` exchanges them once so every rank holds the
+    global-batch means (and takes the same early-stopping decision)."""
+
+    def __init__(self, device):
+        self.sums, self.count, self.device = {}, 0.0, device
+
+    def add(self, batch_losses, n):
+        for key, values in batch_losses.items():
+            self.sums[key] = self.sums.get(key, 0.0) + float(values[-1]) * n
+        self.count += n
+
+    def means(self):
+        keys = sorted(self.sums)
+        tot = D.allreduce_sum_host([self.sums[k] for k in keys] + [self.count], device=self.device)
+        return {k: v / max(tot[-1], 1.0) for k, v in zip(keys, tot[:-1])}
+
+
+def _make_optimizer(model, lr, fused):
+    from .vq_vae import VQ_VAE
+    if D.world_size() > 1 and not (fused and isinstance(model, VQ_VAE)):
+        # FusedTrainer broadcasts its flat buffer itself; any other module: same replica everywhere before the first step
+        for t in list(model.parameters()) + list(model.buffers()):
+            torch.distributed.broadcast(t.data, src=0)
+    if fused == "graph" and D.world_size() == 1:
+        return GraphedTrainer(model, lr=lr)               # any module: the autograd step as a replayed HIP graph
+    if fused and isinstance(model, VQ_VAE):
+        return FusedTrainer(model, lr=lr)
+    # VQ_VAE_z32 is GPU bound through autograd at every batch size measured (8.2 ms eager vs 8.5 ms replayed at
+    # B = 2048), so the plain loop stays the default there
+    return torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
+
+
 def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10, lr=0.001, batch_size=16,
           device='cuda:0', shuffle_data=False, transform=None, val_split_ratio=0.15, patience=20,
           get_relation_tensor=None, get_mask=None, writer=None, fused=True):
-    """run_training.py:455-551: Adam, contiguous validation block, epoch/batch loops, EarlyStopping
-    checkpoint of the state_dict to <output_dir>/model.pt.  `dataset` is a TensorDataset-like object
-    indexable with a list of ids (dataset[ids][0] -> host tensor)."""
+    """The training loop of run_training.py:455-551 -- Adam, a contiguous validation block at a random start, epoch and
+    batch loops, TensorBoard-style scalars, EarlyStopping checkpoint of the state_dict to <output_dir>/model.pt -- made
+    data parallel (one process per GPU, torch.distributed initialised by the launcher):
+
+      * the validation split and every shuffle come from ONE seed drawn on rank 0, so all ranks walk the same batches;
+      * each global batch of `batch_size` samples is cut into contiguous per-rank shards (dist.shard_range); a rank
+        weights its gradient by n_local * world / n_global before the single all-reduce, so the averaged gradient is the
+        global-batch mean loss's (BatchNorm statistics and the pairwise time-matching term stay rank-local: standard
+        data-parallel semantics, the reference has no multi-device behaviour to match);
+      * epoch losses are exchanged once per epoch, the early-stopping decision is therefore the same everywhere;
+      * rank 0 alone writes model.pt (atomically), the others wait at a barrier.
+
+    `dataset` is a TensorDataset-like object indexable with a list of ids (dataset[ids][0] -> host tensor)."""
     assert val_split_ratio is None or 0 < val_split_ratio < 1
     if patience is not None:
         assert val_split_ratio is not None
-    from .vq_vae import VQ_VAE
     if get_relation_tensor is None and relation_mat is not None:
         get_relation_tensor = globals()["get_relation_tensor"]
     if get_mask is None and mask is not None:
         get_mask = globals()["get_mask"]
-    # the fused path is built for the 16x16-latent architecture; other modules (VQ_VAE_z32) train through autograd
-    if D.world_size() > 1 and not isinstance(model, VQ_VAE):
-        D.broadcast_(torch.zeros(1, device=device), [p.data for p in model.parameters()] + list(model.buffers()))   # same replica everywhere
-    if fused == "graph" and D.world_size() == 1:
-        optimizer = GraphedTrainer(model, lr=lr)          # any module: the autograd step as a replayed HIP graph
-    elif fused and isinstance(model, VQ_VAE):
-        optimizer = FusedTrainer(model, lr=lr)
-    else:
-        # VQ_VAE_z32 is GPU bound through autograd at every batch size measured (8.2 ms eager vs 8.5 ms replayed at
-        # B = 2048), so the plain loop stays the default there
-        optimizer = torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    rank, world = D.get_rank(), D.world_size()
+    optimizer = _make_optimizer(model, lr, fused)
     model.zero_grad()
+
+    seed = D.broadcast_object(int(np.random.randint(0, 2 ** 31 - 1)))
+    order = np.random.RandomState(seed)                     # split and shuffles: the same stream on every rank
+    if world > 1:
+        np.random.seed((seed + 7919 * rank) % (2 ** 32))    # augmentation draws: a stream of its own per rank
     n_samples = len(dataset)
     sample_ids = list(range(n_samples))
     split = int(np.floor(val_split_ratio * n_samples))
-    split_start = np.random.randint(0, n_samples - split)
+    split_start = int(order.randint(0, n_samples - split))
     if shuffle_data:
-        np.random.shuffle(sample_ids)
-    val_ids = sample_ids[split_start: split_start + split]
-    train_ids = sample_ids[:split_start] + sample_ids[split_start + split:]
-    n_train, n_val = len(train_ids), len(val_ids)
-    n_batches = int(np.ceil(n_train / batch_size))
-    n_val_batches = int(np.ceil(n_val / batch_size))
+        order.shuffle(sample_ids)
+    phases = {"train": sample_ids[:split_start] + sample_ids[split_start + split:],
+              "val": sample_ids[split_start: split_start + split]}
+
     os.makedirs(output_dir, exist_ok=True)
-    model_path = os.path.join(output_dir, 'model.pt')
-    early_stopping = EarlyStopping(patience=patience, verbose=True, path=model_path)
+    early_stopping = EarlyStopping(patience=patience, verbose=(rank == 0), path=os.path.join(output_dir, 'model.pt'))
+    early_stopping.writes = rank == 0
+    say = print if rank == 0 else (lambda *a, **k: None)
     for epoch in range(n_epochs):
-        train_loss, val_loss = {}, {}
-        print('start epoch %d' % epoch)
-        for phase, ids, nb, losses in (("train", train_ids, n_batches, train_loss), ("val", val_ids, n_val_batches, val_loss)):
-            for i in range(nb):
-                ids_batch = ids[i * batch_size:min((i + 1) * batch_size, len(ids))]
-                batch = dataset[ids_batch][0].to(device)
-                kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_batch, device=device) if get_relation_tensor else None,
-                      'batch_mask': get_mask(mask, ids_batch, device=device) if get_mask else None}
-                model, losses = run_one_batch(model, batch, losses, optimizer=optimizer, model_kwargs=kw,
-                                              transform=transform, training=(phase == "train"))
+        say('start epoch %d' % epoch)
+        epoch_means = {}
+        for phase, ids in phases.items():
+            losses = _EpochLosses(dev if dev.type == "cuda" else None)
+            for start in range(0, len(ids), batch_size):
+                ids_batch = ids[start:start + batch_size]
+                lo, hi = D.shard_range(len(ids_batch), rank, world)
+                ids_local = ids_batch[lo:hi]
+                if not ids_local:
+                    if phase == "train":
+                        _step_without_data(model, optimizer)
+                    continue
+                batch = dataset[ids_local][0].to(dev)
+                kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_local, device=dev) if get_relation_tensor else None,
+                      'batch_mask': get_mask(mask, ids_local, device=dev) if get_mask else None}
+                last = {}
+                run_one_batch(model, batch, last, optimizer=optimizer, model_kwargs=kw, transform=transform,
+                              training=(phase == "train"), grad_weight=len(ids_local) * world / len(ids_batch))
+                losses.add(last, len(ids_local))
+            epoch_means[phase] = losses.means()
         if shuffle_data:
-            np.random.shuffle(train_ids)
-        for key, loss in train_loss.items():
-            train_loss[key] = sum(loss) / len(loss)
-            if writer is not None:
-                writer.add_scalar('Loss/' + key, train_loss[key], epoch)
-        for key, loss in val_loss.items():
-            val_loss[key] = sum(loss) / len(loss)
-            if writer is not None:
-                writer.add_scalar('Val loss/' + key, val_loss[key], epoch)
-        early_stopping(val_loss['total_loss'], model)
+            order.shuffle(phases["train"])
+        if writer is not None and rank == 0:
+            for phase, prefix in (("train", 'Loss/'), ("val", 'Val loss/')):
+                for key, value in epoch_means[phase].items():
+                    writer.add_scalar(prefix + key, value, epoch)
+        early_stopping(epoch_means["val"]['total_loss'], model)
+        D.barrier()                                          # model.pt is complete before any rank moves on
         if early_stopping.early_stop:
-            print("Early stopping")
+            say("Early stopping")
             break
-        print('epoch %d' % epoch)
-        print('train: ', ''.join(['{}:{:0.4f}  '.format(key, loss) for key, loss in train_loss.items()]))
-        print('validation: ', ''.join(['{}:{:0.4f}  '.format(key, loss) for key, loss in val_loss.items()]))
+        say('epoch %d' % epoch)
+        for phase, label in (("train", 'train: '), ("val", 'validation: ')):
+            say(label, ''.join(['{}:{:0.4f}  '.format(key, loss) for key, loss in epoch_means[phase].items()]))
     return model

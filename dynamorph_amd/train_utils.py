@@ -4,6 +4,8 @@
   zscore         pipeline/train_utils.py:228-250
   zscore_patch   pipeline/train_utils.py:252-274
 """
+import os
+
 import numpy as np
 import torch
 
@@ -21,6 +23,7 @@ class EarlyStopping:
         self.delta = delta
         self.path = path
         self.trace_func = trace_func
+        self.writes = True
 
     def __call__(self, val_loss, model):
         score = -val_loss
@@ -36,10 +39,15 @@ class EarlyStopping:
             self.early_stop = True
 
     def save_checkpoint(self, val_loss, model):
-        """Weights only (state_dict), exactly what process_VAE later loads as <weights>/model.pt."""
+        """Weights only (state_dict), exactly what process_VAE later loads as <weights>/model.pt.  `writes` (set False on
+        the non-zero ranks of a data-parallel run) keeps the bookkeeping and skips the file; the file appears atomically
+        (temporary name + os.replace), so a reader never sees a torn checkpoint."""
         if self.verbose:
             self.trace_func(f'Validation loss decreased ({self.val_loss_min:.6f} --> {val_loss:.6f}).  Saving model ...')
-        torch.save(model.state_dict(), self.path)
+        if self.writes:
+            tmp = str(self.path) + '.tmp'
+            torch.save(model.state_dict(), tmp)
+            os.replace(tmp, self.path)
         self.val_loss_min = val_loss
 
 

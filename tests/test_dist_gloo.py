@@ -79,3 +79,90 @@ def test_data_parallel_plumbing_world2(tmp_path):
         assert torch.allclose(r["helper"], expect, rtol=0, atol=1e-7)    # allreduce_grads_ (autograd path) gives the same
         assert r["tmax"] == float(world)                                 # max over ranks (bench timing contract)
     assert res[0]["range"] == (0, 4) and res[1]["range"] == (4, 8)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# train() itself at world size 2.  The product modules have no CPU path, so the module that stands in here is the CPU
+# oracle (same constructor / forward contract); what is under test is the LOOP: one seed for split and shuffles, contiguous
+# per-rank shards of every global batch, the weighted single gradient exchange, the collective early-stopping decision
+# and the rank-0 checkpoint.
+N_SAMPLES, BATCH, EPOCHS, LR = 22, 6, 2, 1e-3
+
+
+def _train_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from dynamorph_amd import dist as D
+    from dynamorph_amd.train import train
+    from oracle import vqvae_oracle as O
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(500 + rank)                       # different replicas: train() must broadcast rank 0's
+    np.random.seed(11 + rank)                           # different host generators: the split must still agree
+    model = O.OracleVQVAE()
+    data = torch.utils.data.TensorDataset(torch.randn(N_SAMPLES, 2, 128, 128, generator=torch.Generator().manual_seed(3)))
+    rows = {}
+
+    class Scalars:
+        def add_scalar(self, key, value, epoch):
+            rows.setdefault(key, []).append(float(value))
+    train(model, data, os.path.join(out_dir, "run"), n_epochs=EPOCHS, lr=LR, batch_size=BATCH, device="cpu",
+          transform=None, val_split_ratio=0.2, patience=5, writer=Scalars(), fused=False)
+    torch.save({"params": [p.detach().clone() for p in model.parameters()], "rows": rows},
+               os.path.join(out_dir, f"train_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_train_loop_world2_shards_batches_and_checkpoints_on_rank0(tmp_path):
+    from dynamorph_amd import dist as D
+    from oracle import vqvae_oracle as O
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"train_rank{r}.pt")) for r in range(world)]
+    # identical replicas after training, and rank 0 alone reported the epoch scalars
+    for a, b in zip(res[0]["params"], res[1]["params"]):
+        assert torch.equal(a, b)
+    assert len(res[0]["rows"]["Loss/total_loss"]) == EPOCHS and not res[1]["rows"]
+    ck = torch.load(os.path.join(tmp_path, "run", "model.pt"))
+    assert not os.path.exists(os.path.join(tmp_path, "run", "model.pt.tmp"))
+
+    # single-process emulation of the same schedule: per global batch, the shards' gradients weighted by their sizes
+    torch.manual_seed(500)                              # rank 0's replica is the one that was broadcast
+    np.random.seed(11)
+    model = O.OracleVQVAE()
+    opt = O.make_adam(model, LR)
+    data = torch.randn(N_SAMPLES, 2, 128, 128, generator=torch.Generator().manual_seed(3))
+    seed = int(np.random.randint(0, 2 ** 31 - 1))       # what train() drew on rank 0
+    order = np.random.RandomState(seed)
+    split = int(np.floor(0.2 * N_SAMPLES))
+    start = int(order.randint(0, N_SAMPLES - split))
+    ids = list(range(N_SAMPLES))
+    train_ids = ids[:start] + ids[start + split:]
+    params = [p for p in model.parameters() if p.requires_grad]
+    for _ in range(EPOCHS):
+        for s0 in range(0, len(train_ids), BATCH):
+            gb = train_ids[s0:s0 + BATCH]
+            acc = [torch.zeros_like(p) for p in params]
+            for r in range(world):
+                lo, hi = D.shard_range(len(gb), r, world)
+                if hi > lo:
+                    model.zero_grad()
+                    model(data[gb[lo:hi]])[1]["total_loss"].backward()
+                    for a, p in zip(acc, params):
+                        a += p.grad * ((hi - lo) / len(gb))
+            for a, p in zip(acc, params):
+                p.grad = a
+            opt.step()
+    # (biases of convolutions that feed a train-mode BatchNorm have an identically zero gradient; autograd returns
+    # +-1e-9 of rounding noise there, which Adam turns into +-lr steps whose signs depend on the summation order)
+    noise = ("enc.1.bias", "enc.4.bias", "enc.7.bias", "enc.10.bias", ".1.bias", ".4.bias")
+    for (name, w_), g in zip(model.named_parameters(), res[0]["params"]):
+        if name.endswith(noise) and "enc" in name:
+            assert (g - w_).abs().max() <= 2.5 * LR * EPOCHS * 4
+            continue
+        assert torch.allclose(g, w_.detach(), rtol=0, atol=2e-6), (name, float((g - w_).abs().max()))
+    # the checkpoint holds one of the epochs' weights (the best validation loss), written by rank 0
+    assert set(ck.keys()) == set(model.state_dict().keys())

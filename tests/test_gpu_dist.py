@@ -1,0 +1,85 @@
+"""GPU: the data-parallel training loop with the HIP path underneath, rehearsed as 2 ranks that share the one GPU of the
+box over gloo (RCCL needs one GPU per rank; the 8-GPU run is the driver's).  What runs per rank is exactly the N > 1 path
+of train(): broadcast of rank 0's replica, contiguous shards of every global batch, graph replay, ONE all-reduce of the
+flat gradient bucket, fused Adam, rank-0 checkpoint."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SAMPLES, BATCH, EPOCHS, LR = 40, 16, 2, 1e-3
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", DM_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    import dynamorph_amd
+    from dynamorph_amd import dist as D
+    from dynamorph_amd.train import train
+    D.init_from_env()
+    torch.cuda.set_device(0)
+    torch.manual_seed(900 + rank)                       # different replicas: rank 0's must win
+    np.random.seed(21 + rank)
+    model = dynamorph_amd.VQ_VAE().to("cuda:0")
+    data = torch.utils.data.TensorDataset(torch.randn(N_SAMPLES, 2, 128, 128, generator=torch.Generator().manual_seed(5)))
+    train(model, data, os.path.join(out_dir, "run"), n_epochs=EPOCHS, lr=LR, batch_size=BATCH, device="cuda:0",
+          transform=None, val_split_ratio=0.2, patience=5)
+    torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_fused_training_loop_two_ranks_on_one_gpu(tmp_path):
+    import dynamorph_amd
+    from dynamorph_amd import dist as D
+    from dynamorph_amd.train import FusedTrainer
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sd = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    trainable = [k for k in sd[0] if "running" not in k and "num_batches" not in k]
+    for k in trainable:
+        assert torch.equal(sd[0][k], sd[1][k]), k       # identical replicas after training
+    assert os.path.exists(os.path.join(tmp_path, "run", "model.pt"))
+
+    # the same schedule in one process: per global batch the two shards' gradients, weighted by shard size, one Adam step
+    torch.manual_seed(900)
+    np.random.seed(21)
+    model = dynamorph_amd.VQ_VAE().to("cuda:0")
+    tr = FusedTrainer(model, lr=LR, use_graph=False)
+    data = torch.randn(N_SAMPLES, 2, 128, 128, generator=torch.Generator().manual_seed(5))
+    seed = int(np.random.randint(0, 2 ** 31 - 1))
+    order = np.random.RandomState(seed)
+    split = int(np.floor(0.2 * N_SAMPLES))
+    start = int(order.randint(0, N_SAMPLES - split))
+    ids = list(range(N_SAMPLES))
+    train_ids = ids[:start] + ids[start + split:]
+    for _ in range(EPOCHS):
+        for s0 in range(0, len(train_ids), BATCH):
+            gb = train_ids[s0:s0 + BATCH]
+            acc = torch.zeros_like(tr.grad)
+            for r in range(world):
+                lo, hi = D.shard_range(len(gb), r, world)
+                if hi > lo:
+                    tr.forward_backward(data[gb[lo:hi]].to("cuda:0"))
+                    acc += tr.grad * ((hi - lo) / len(gb))
+            tr.grad.copy_(acc)
+            tr._adam()
+    want = {k: v.cpu() for k, v in model.state_dict().items()}
+    for k in trainable:
+        d = float((sd[0][k] - want[k]).abs().max())
+        assert d <= 5e-6 + 1e-4 * float(want[k].abs().max()), (k, d)

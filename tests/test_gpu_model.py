@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import codes_gate
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -131,7 +133,7 @@ def test_forward_losses_and_reconstruction(golden, masked):
     idx_ref = golden("g4_vq_indices.npz")["idx"]
     idx = m.vq.encode_inputs(m.enc(x)).cpu().numpy()      # (running stats mutate: irrelevant here)
     same = (idx == idx_ref).reshape(4, -1).all(1)
-    assert (idx != idx_ref).mean() < 1e-3
+    codes_gate(idx != idx_ref, golden("g5_vq_forward.npz")["z_before"], golden("g4_vq_indices.npz")["codebook"], "VQ_VAE.forward")
     for b in range(4):
         if same[b]:
             close(dec[b], g["decoded"][b], 5e-4, 5e-4, f"decoded[{b}]")
@@ -235,8 +237,8 @@ def test_oracle_parity_fresh_seed_larger_batch():
     ref2.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
     idx_ref = ref2.vq.encode_inputs(ref2.enc(x))
     idx = m.vq.encode_inputs(m.enc(x.to(DEV))).cpu()
+    codes_gate(idx != idx_ref, ref2.enc(x).detach(), ref2.vq.w.weight.detach(), "fresh-seed model")
     flips = int((idx != idx_ref).sum())
-    assert flips <= 4, flips
     # The reference's fp32 gradients carry ~3e-3 relative accumulation noise of their own (measured against
     # an fp64 run of the same graph).  Gate: the HIP gradients are as close to the fp64 truth as the
     # reference's fp32 CPU path is (x1.5), or within 2e-4 of the tensor's scale.
