@@ -49,6 +49,7 @@ SIGNATURES = {
     "dm_vq_num_blocks": (C.c_int, [i64]),
     "dm_vq_forward": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, vp]),
     "dm_vq_forward_variant": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, C.c_int, vp]),
+    "dm_vq_forward_repeat": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, C.c_int, C.c_int, vp]),
     "dm_vq_decode": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_vq_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp, vp]),
     "dm_vq_backward": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),

@@ -974,9 +974,33 @@ bool vq2_applicable(const float *z, const int64_t *idx, const float *out, const 
 }
 }  // namespace
 
+namespace {
+int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float *out, double *sse_slabs, int32_t *hist,
+                      int B, int D, int K, int H, int W, void *workspace, size_t workspace_bytes, int variant, int repeats,
+                      void *stream);
+}
+
 extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
                                      double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
                                      void *workspace, size_t workspace_bytes, int variant, void *stream)
+{
+    return vq_forward_launch(z, codebook, idx, out, sse_slabs, hist, B, D, K, H, W, workspace, workspace_bytes, variant, 1,
+                             stream);
+}
+
+extern "C" int dm_vq_forward_repeat(const float *z, const float *codebook, int64_t *idx, float *out,
+                                    double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                                    void *workspace, size_t workspace_bytes, int variant, int repeats, void *stream)
+{
+    DM_REQUIRE(repeats >= 1 && repeats <= 1000, "dm_vq_forward_repeat: repeats %d", repeats);
+    return vq_forward_launch(z, codebook, idx, out, sse_slabs, hist, B, D, K, H, W, workspace, workspace_bytes, variant,
+                             repeats, stream);
+}
+
+namespace {
+int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float *out, double *sse_slabs, int32_t *hist,
+                      int B, int D, int K, int H, int W, void *workspace, size_t workspace_bytes, int variant, int repeats,
+                      void *stream)
 {
     DM_REQUIRE(z && codebook && sse_slabs && hist, "dm_vq_forward: NULL pointer");
     DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
@@ -1008,11 +1032,13 @@ extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int6
                            sse_slabs, hrep, L.R, (int *)ws, K, H * W, P);                                            \
     }
         const bool single = K <= 64;
-        switch (D) {
-        case 8: if (single) DM_VQ2(8, true, 3, 3) else DM_VQ2(8, false, 3, 3) break;
-        case 16: if (single) DM_VQ2(16, true, 3, 3) else DM_VQ2(16, false, 3, 3) break;
-        case 32: if (single) DM_VQ2(32, true, 2, 2) else DM_VQ2(32, false, 2, 2) break;
-        default: if (single) DM_VQ2(64, true, 1, 1) else DM_VQ2(64, false, 1, 2) break;
+        for (int rep = 0; rep < repeats; ++rep) {
+            switch (D) {
+            case 8: if (single) DM_VQ2(8, true, 3, 3) else DM_VQ2(8, false, 3, 3) break;
+            case 16: if (single) DM_VQ2(16, true, 3, 3) else DM_VQ2(16, false, 3, 3) break;
+            case 32: if (single) DM_VQ2(32, true, 2, 2) else DM_VQ2(32, false, 2, 2) break;
+            default: if (single) DM_VQ2(64, true, 1, 1) else DM_VQ2(64, false, 1, 2) break;
+            }
         }
 #undef DM_VQ2
         hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
@@ -1022,17 +1048,20 @@ extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int6
 #define DM_VQ_FWD(DD, PP_)                                                                                   \
     hipLaunchKernelGGL((vq_forward_kernel<DD, PP_>), dim3((unsigned)((P + VQ_BLOCK * PP_ - 1) / (VQ_BLOCK * PP_))), \
                        dim3(VQ_BLOCK), 0, s, z, codebook, cbT, (long long *)idx, out, sse_slabs, hrep, L.R, K, H * W, P)
-    switch (D) {
-    case 8: DM_VQ_FWD(8, VQ_PP); break;
-    case 16: DM_VQ_FWD(16, VQ_PP); break;
-    case 32: DM_VQ_FWD(32, VQ_PP); break;
-    case 64: DM_VQ_FWD(64, 1); break;
-    default: DM_VQ_FWD(128, 1); break;        // VectorQuantizer's own default embedding_dim (vq_vae.py:35)
+    for (int rep = 0; rep < repeats; ++rep) {
+        switch (D) {
+        case 8: DM_VQ_FWD(8, VQ_PP); break;
+        case 16: DM_VQ_FWD(16, VQ_PP); break;
+        case 32: DM_VQ_FWD(32, VQ_PP); break;
+        case 64: DM_VQ_FWD(64, 1); break;
+        default: DM_VQ_FWD(128, 1); break;        // VectorQuantizer's own default embedding_dim (vq_vae.py:35)
+        }
     }
 #undef DM_VQ_FWD
     hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
     return dm_launch_status("dm_vq_forward");
 }
+}  // namespace
 
 extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *out,
                              double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,

@@ -111,6 +111,24 @@ def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, 
     return idx, out, slabs, hist
 
 
+def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None):
+    """Measurement helper (include/dynamorph_hip.h, dm_vq_forward_repeat): one preparation, `repeats` launches of the
+    distance / argmin kernel, one counter reduction, on preallocated buffers `bufs` (from a first call) so that nothing is
+    allocated inside a timed region.  Returns bufs."""
+    lib = L.load()
+    B, D, H, W = z.shape
+    K = codebook.shape[0]
+    if bufs is None:
+        wsb = lib.dm_vq_workspace_bytes(K, D)
+        bufs = (_new((B, H, W), z, torch.int64), torch.empty_like(z), _new((lib.dm_vq_num_blocks(B * H * W),), z, torch.float64),
+                _new((K,), z, torch.int32), _new((wsb // 4,), z), wsb)
+    idx, out, slabs, hist, ws, wsb = bufs
+    L.check(lib.dm_vq_forward_repeat(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out), _ptr(slabs, torch.float64),
+                                     _ptr(hist, torch.int32), B, D, K, H, W, _ptr(ws), wsb, variant, repeats, _stream()),
+            "dm_vq_forward_repeat")
+    return bufs
+
+
 def vq_finalize(slabs, hist, positions, D, commitment_cost):
     lib = L.load()
     scalars = _new((3,), slabs)

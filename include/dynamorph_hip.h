@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 104
+#define DM_VERSION 105
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -121,6 +121,14 @@ enum { DM_VQ_AUTO = 0, DM_VQ_EXACT = 1, DM_VQ_MFMA = 2 };
 int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
                           double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
                           void *workspace, size_t workspace_bytes, int variant, void *stream);
+
+/* Measurement entry (bench.py, tools/vqbench.py): the same launches, the distance / argmin kernel `repeats` times in a row
+ * between ONE preparation and ONE counter reduction, so that T(repeats = n + 1) - T(repeats = 1) times n launches of that
+ * kernel alone, with events on the caller's stream and no synchronisation inside the library.  idx / out / sse_slabs are the
+ * single call's (the kernel overwrites them); hist and the re-check counter accumulate over the repeats. */
+int dm_vq_forward_repeat(const float *z, const float *codebook, int64_t *idx, float *out,
+                         double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                         void *workspace, size_t workspace_bytes, int variant, int repeats, void *stream);
 
 /* vq_vae.py:105-116 decode_inputs: q[b,d,h,w] = codebook[idx[b,h,w], d]. */
 int dm_vq_decode(const int64_t *idx, const float *codebook, float *q,

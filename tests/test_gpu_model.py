@@ -375,6 +375,28 @@ def test_z32_forward_against_reference(golden):
     assert abs(float(ld["perplexity"]) - float(g["perplexity"])) <= 1e-3 * float(g["perplexity"])
 
 
+def test_z32_time_matching_mask_and_gradients_against_reference(golden):
+    """VQ_VAE_z32 forward + backward with a time-matching matrix and a batch mask against the vectors captured from the
+    reference (g8_z32_tm.npz): losses within the north star's 1e-5, every gradient within the accumulation noise of fp32."""
+    import dynamorph_amd
+    g = golden("g8_z32_tm.npz")
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    m = dynamorph_amd.VQ_VAE_z32().to(DEV)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd/")})
+    dec, ld = m(x, time_matching_mat=torch.from_numpy(g["tm"]).to(DEV), batch_mask=torch.from_numpy(g["mask"]).to(DEV))
+    close(dec, g["decoded"], 1e-4, 1e-4, "z32 decoded (masked, time matching)")
+    for k in ("recon_loss", "commitment_loss", "time_matching_loss", "total_loss"):
+        assert abs(float(ld[k]) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), (k, float(ld[k]), float(g[k]))
+    ld["total_loss"].backward()
+    for k, p in m.named_parameters():
+        if not p.requires_grad or k in Z32_BN_FED_BIASES:
+            continue
+        ref = g["grad/" + k]
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = float((p.grad.cpu() - torch.from_numpy(ref)).abs().max())
+        assert err <= 4e-3 * scale + 1e-8, (k, err, scale)
+
+
 def test_z32_gradients_against_oracle():
     """Fresh weights and inputs, masked loss + time matching: every gradient vs the fp64 oracle (same gate as the
     16x16 model: as close to the truth as the reference's own fp32 path, x1.5)."""

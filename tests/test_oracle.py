@@ -192,6 +192,25 @@ def test_z32(golden):
         assert abs(float(ld[k]) - float(g[k])) <= 1e-6 * abs(float(g[k])), k
 
 
+def test_z32_time_matching_mask_and_gradients(golden):
+    """VQ_VAE_z32 with a time-matching matrix and a batch mask (vae.py:441-455): the oracle against the vectors captured
+    from the reference -- losses, reconstruction and every parameter gradient (tests/golden/make_golden_z32_tm.py)."""
+    g = golden("g8_z32_tm.npz")
+    x = torch.from_numpy(golden("g2_input.npz")["x"])
+    m = O.load_numpy_state(O.OracleVQVAEz32(), g, prefix="sd/")
+    dec, ld = m(x, time_matching_mat=torch.from_numpy(g["tm"]), batch_mask=torch.from_numpy(g["mask"]))
+    assert np.array_equal(dec.detach().numpy(), g["decoded"])
+    for k in ("recon_loss", "commitment_loss", "time_matching_loss", "total_loss", "perplexity"):
+        assert abs(float(ld[k]) - float(g[k])) <= 2e-6 * max(1.0, abs(float(g[k]))), k
+    ld["total_loss"].backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(p.grad.numpy(), g["grad/" + k], rtol=2e-5, atol=2e-7, err_msg=k)
+            n += 1
+    assert n == sum(1 for k in g if k.startswith("grad/"))
+
+
 def test_stress_codebooks(golden):
     for name, D, K in (("g9_vq_k4096.npz", 16, 4096), ("g9_vq_d64.npz", 64, 512)):
         g = golden(name)
