@@ -87,6 +87,11 @@ SIGNATURES = {
     "dm_recon_loss_backward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp] + [C.c_int] * 4 + [vp]),
     "dm_pair_msd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "dm_pair_msd_backward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "dm_time_matching_supported": (C.c_int, [C.c_int, C.c_int]),
+    "dm_time_matching_workspace_floats": (i64, [C.c_int, C.c_int]),
+    "dm_time_matching_num_slabs": (C.c_int, [C.c_int]),
+    "dm_time_matching_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, i64, vp, vp, vp]),
+    "dm_time_matching_backward": (C.c_int, [vp, vp, vp, f32, vp, C.c_int, C.c_int, vp]),
     "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_compose_border": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -101,3 +101,242 @@ extern "C" int dm_pair_msd_backward(const float *z, const float *g_sim, float *d
                        (hipStream_t)stream, z, g_sim, dz, B, n);
     return dm_launch_status("dm_pair_msd_backward");
 }
+
+// ================================================================================================================
+// The whole time-matching term on the matrix pipe (vq_vae.py:324-332, vae.py:322-336).
+//
+//   sim_ij = mean_d (z_i - z_j)^2 = (G_ii + G_jj - 2 G_ij) / n,   G = Z Z^T        (B x B x n GEMM, f32 MFMA)
+//   loss   = sum_ij sim_ij tm_ij                                                   (mode 0, vq_vae.py:331)
+//          = mean_ij v_ij, v = sim * w(tm), tm == 0: v = max(v + margin, 0)        (mode 1, vae.py:327-336)
+//   S_ij   = dloss/dsim_ij + dloss/dsim_ji          (formed by the epilogue: the backward needs nothing else)
+//   dz_i   = (2/n) (rowsum(S)_i z_i - sum_j S_ij z_j)                              (B x n x B GEMM, f32 MFMA)
+//
+// The reference materialises a (B, B, n) tensor for this (9.7 GB at its example batch of 768); the first version here
+// formed the differences on the VALU (3 B^2 n operations, two LDS reads per multiply).  The Gram form costs 2 B^2 n on
+// v_mfma_f32_16x16x4_f32; its cancellation error is ~ sqrt(n) u |z|^2 / n absolute on sim (1e-6 for N(0,1) latents of
+// length 4096, K split into chunks whose partial sums are added in double), inside the north star's 1e-5 on the loss.
+namespace {
+
+constexpr int TM_T = 64;          // 64 x 64 output tile per workgroup: 4 waves, 32 x 32 each (2 x 2 MFMA tiles)
+constexpr int TM_KC = 32;         // K staged per step
+constexpr int TM_LDA = TM_KC + 2; // LDS row stride of a K-major tile: == 2 (mod 32) banks, conflict-free operand reads
+
+// P[ks][i][j] = sum_{d in split ks} z[i][d] z[j][d]
+__global__ __launch_bounds__(256) void tm_gram_kernel(const float *__restrict__ z, float *__restrict__ P, int B, int n, int klen)
+{
+    __shared__ float sA[TM_T * TM_LDA], sB[TM_T * TM_LDA];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    const int i0 = blockIdx.y * TM_T, j0 = blockIdx.x * TM_T;
+    const int k_lo = blockIdx.z * klen, k_hi = min(n, k_lo + klen);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lr = threadIdx.x >> 3, lq = threadIdx.x & 7;     // staging: 8 threads per row, 32 rows per pass
+    for (int k0 = k_lo; k0 < k_hi; k0 += TM_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = lr + 32 * pass;
+            f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
+            if (i0 + r < B) va = *reinterpret_cast<const f32x4 *>(z + (long long)(i0 + r) * n + k0 + 4 * lq);
+            if (j0 + r < B) vb = *reinterpret_cast<const f32x4 *>(z + (long long)(j0 + r) * n + k0 + 4 * lq);
+            *reinterpret_cast<f32x2 *>(sA + r * TM_LDA + 4 * lq) = (f32x2){va.x, va.y};
+            *reinterpret_cast<f32x2 *>(sA + r * TM_LDA + 4 * lq + 2) = (f32x2){va.z, va.w};
+            *reinterpret_cast<f32x2 *>(sB + r * TM_LDA + 4 * lq) = (f32x2){vb.x, vb.y};
+            *reinterpret_cast<f32x2 *>(sB + r * TM_LDA + 4 * lq + 2) = (f32x2){vb.z, vb.w};
+        }
+        __syncthreads();
+        const float *pa = sA + (wr * 32 + (lane & 15)) * TM_LDA + (lane >> 4);
+        const float *pb = sB + (wc * 32 + (lane & 15)) * TM_LDA + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < TM_KC; ks += 4) {
+            const float a0 = pa[ks], a1 = pa[16 * TM_LDA + ks], b0 = pb[ks], b1 = pb[16 * TM_LDA + ks];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float *__restrict__ Pk = P + (long long)blockIdx.z * B * B;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wr * 32 + a * 16 + (lane >> 4) * 4 + r, j = j0 + wc * 32 + b * 16 + (lane & 15);
+                if (i < B && j < B) Pk[(long long)i * B + j] = acc[a][b][r];
+            }
+}
+
+struct TmParams { int mode; float w_a, w_t, w_n, margin; };
+
+__device__ __forceinline__ void tm_value(const TmParams &p, float sim, float tm, float inv_count, double &val, float &dsim)
+{
+    if (p.mode == 0) { val = (double)(sim * tm); dsim = tm; return; }
+    const float w = tm == 2.f ? p.w_a : (tm == 1.f ? p.w_t : (tm == 0.f ? p.w_n : tm));
+    float v = sim * w, live = 1.f;
+    if (tm == 0.f) {                                      // hinge on the non-related pairs (vae.py:333-335)
+        v = v + p.margin;
+        live = v >= 0.f ? 1.f : 0.f;
+        v = v > 0.f ? v : 0.f;
+    }
+    val = (double)v * (double)inv_count;
+    dsim = w * live * inv_count;
+}
+
+// one thread per (i, j): sim from the Gram slabs, both orientations of the loss term, S_ij, loss partials per workgroup
+__global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restrict__ P, int ksplit, const float *__restrict__ tm,
+                                                          int B, int n, TmParams p, float *__restrict__ S,
+                                                          double *__restrict__ loss_slabs)
+{
+    __shared__ double s_red[4];
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x, BB = (long long)B * B;
+    double val = 0.0;
+    if (e < BB) {
+        const int i = (int)(e / B), j = (int)(e - (long long)i * B);
+        double gij = 0.0, gii = 0.0, gjj = 0.0;
+        for (int ks = 0; ks < ksplit; ++ks) {             // chunk sums added in double, in a fixed order
+            const float *__restrict__ Pk = P + ks * BB;
+            gij += (double)Pk[(long long)i * B + j];
+            gii += (double)Pk[(long long)i * B + i];
+            gjj += (double)Pk[(long long)j * B + j];
+        }
+        const float sim = i == j ? 0.f : (float)((gii + gjj - 2.0 * gij) / (double)n);
+        const float inv_count = p.mode == 0 ? 1.f : 1.f / (float)BB;
+        float d_ij, d_ji;
+        double v_ji;
+        tm_value(p, sim, tm[(long long)i * B + j], inv_count, val, d_ij);
+        tm_value(p, sim, tm[(long long)j * B + i], inv_count, v_ji, d_ji);
+        S[e] = d_ij + d_ji;
+    }
+    const double tot = block_sum(val, s_red);
+    if (threadIdx.x == 0) { loss_slabs[2 * blockIdx.x] = tot; loss_slabs[2 * blockIdx.x + 1] = 0.0; }
+}
+
+// dz[i][d] = scale * g * (rowsum(S)_i z[i][d] - sum_j S_ij z[j][d]);  64 rows x 64 columns per workgroup, K = B
+constexpr int TM_LDZ = TM_T + 16;  // LDS row stride of the [j][d] tile: == 16 (mod 32), conflict-free B-operand reads
+__global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restrict__ z, const float *__restrict__ S,
+                                                          const float *__restrict__ g_dev, float scale,
+                                                          float *__restrict__ dz, int B, int n)
+{
+    __shared__ float sS[TM_T * TM_LDA], sZ[TM_KC * TM_LDZ], s_rs[TM_T], s_part[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    const int i0 = blockIdx.y * TM_T, d0 = blockIdx.x * TM_T;
+    {   // row sums of S for the tile's 64 rows: 4 threads per row, fixed order
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+        float a = 0.f;
+        if (i0 + r < B)
+            for (int j = q; j < B; j += 4) a += S[(long long)(i0 + r) * B + j];
+        s_part[threadIdx.x] = a;
+        __syncthreads();
+        if (q == 0) s_rs[r] = (s_part[threadIdx.x] + s_part[threadIdx.x + 1]) + (s_part[threadIdx.x + 2] + s_part[threadIdx.x + 3]);
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lr = threadIdx.x >> 3, lq = threadIdx.x & 7;     // S tile staging: 8 threads per row (32 columns j)
+    const int zr = threadIdx.x >> 4, zq = threadIdx.x & 15;    // Z tile staging: 16 threads per row (64 columns d)
+    for (int k0 = 0; k0 < B; k0 += TM_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = lr + 32 * pass;
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = k0 + 4 * lq + u;
+                v[u] = (i0 + r < B && j < B) ? S[(long long)(i0 + r) * B + j] : 0.f;
+            }
+            *reinterpret_cast<f32x2 *>(sS + r * TM_LDA + 4 * lq) = (f32x2){v[0], v[1]};
+            *reinterpret_cast<f32x2 *>(sS + r * TM_LDA + 4 * lq + 2) = (f32x2){v[2], v[3]};
+            const int jr = zr + 16 * pass;
+            f32x4 vz = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k0 + jr < B && d0 + 4 * zq < n) vz = *reinterpret_cast<const f32x4 *>(z + (long long)(k0 + jr) * n + d0 + 4 * zq);
+            *reinterpret_cast<f32x4 *>(sZ + jr * TM_LDZ + 4 * zq) = vz;
+        }
+        __syncthreads();
+        const float *pa = sS + (wr * 32 + (lane & 15)) * TM_LDA + (lane >> 4);
+        const float *pb = sZ + (lane >> 4) * TM_LDZ + wc * 32 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < TM_KC; ks += 4) {
+            const float a0 = pa[ks], a1 = pa[16 * TM_LDA + ks], b0 = pb[ks * TM_LDZ], b1 = pb[ks * TM_LDZ + 16];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    const float sc = scale * (g_dev ? g_dev[0] : 1.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = wr * 32 + a * 16 + (lane >> 4) * 4 + r, i = i0 + il, d = d0 + wc * 32 + b * 16 + (lane & 15);
+                if (i < B && d < n) {
+                    const long long o = (long long)i * n + d;
+                    dz[o] = sc * (s_rs[il] * z[o] - acc[a][b][r]);
+                }
+            }
+}
+
+int tm_ksplit(int B, int n)
+{
+    const int tiles = ((B + TM_T - 1) / TM_T) * ((B + TM_T - 1) / TM_T);
+    int ks = 1024 / tiles;
+    const int maxks = n / 256 > 0 ? n / 256 : 1;
+    if (ks > maxks) ks = maxks;
+    if (ks > 64) ks = 64;
+    if (ks < 1) ks = 1;
+    return ks;
+}
+
+}  // namespace
+
+extern "C" int dm_time_matching_supported(int B, int n) { return (B > 0 && n > 0 && n % TM_KC == 0) ? 1 : 0; }
+
+extern "C" int64_t dm_time_matching_workspace_floats(int B, int n)
+{
+    // Gram slabs + (double) loss partials of the epilogue
+    const long long blocks = ((long long)B * B + 255) / 256;
+    return (long long)tm_ksplit(B, n) * B * B + 4 * blocks + 4;
+}
+
+extern "C" int dm_time_matching_num_slabs(int B) { return (int)(((long long)B * B + 255) / 256); }
+
+extern "C" int dm_time_matching_forward(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t,
+                                        float w_n, float margin, float *workspace, int64_t workspace_floats, float *S,
+                                        double *loss_slabs, void *stream)
+{
+    DM_REQUIRE(z && tm && workspace && S && loss_slabs, "dm_time_matching_forward: NULL pointer");
+    DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_forward: latent length %d is not a multiple of %d", n, TM_KC);
+    DM_REQUIRE(mode == 0 || mode == 1, "dm_time_matching_forward: mode %d", mode);
+    DM_REQUIRE((long long)B * n < (1LL << 31) && (long long)B * B < (1LL << 31), "dm_time_matching_forward: tensor too large");
+    DM_REQUIRE(workspace_floats >= dm_time_matching_workspace_floats(B, n), "dm_time_matching_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int ks = tm_ksplit(B, n), nt = (B + TM_T - 1) / TM_T;
+    int klen = (n + ks - 1) / ks;
+    klen = (klen + TM_KC - 1) / TM_KC * TM_KC;
+    hipLaunchKernelGGL(tm_gram_kernel, dim3(nt, nt, ks), dim3(256), 0, s, z, workspace, B, n, klen);
+    const TmParams p{mode, w_a, w_t, w_n, margin};
+    hipLaunchKernelGGL(tm_epilogue_kernel, dim3((unsigned)dm_time_matching_num_slabs(B)), dim3(256), 0, s, workspace, ks, tm, B, n,
+                       p, S, loss_slabs);
+    return dm_launch_status("dm_time_matching_forward");
+}
+
+extern "C" int dm_time_matching_backward(const float *z, const float *S, const float *g_loss_dev, float scale, float *dz,
+                                         int B, int n, void *stream)
+{
+    DM_REQUIRE(z && S && dz, "dm_time_matching_backward: NULL pointer");
+    DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_backward: latent length %d is not a multiple of %d", n, TM_KC);
+    DM_REQUIRE((long long)B * n < (1LL << 31), "dm_time_matching_backward: tensor too large");
+    hipLaunchKernelGGL(tm_backward_kernel, dim3((n + TM_T - 1) / TM_T, (B + TM_T - 1) / TM_T), dim3(256), 0, (hipStream_t)stream,
+                       z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n);
+    return dm_launch_status("dm_time_matching_backward");
+}

@@ -456,6 +456,36 @@ def pair_msd_backward(z, g_sim):
     return dz
 
 
+def time_matching_supported(B, n):
+    return bool(L.load().dm_time_matching_supported(B, n))
+
+
+def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0):
+    """The whole pairwise term on the MFMA (include/dynamorph_hip.h, dm_time_matching_forward).  z (B, n), tm (B, B) float32.
+    Returns (loss: 1-element device tensor, S (B, B) = dloss/dsim + its transpose, for time_matching_backward)."""
+    lib = L.load()
+    B, n = z.shape
+    wsf = lib.dm_time_matching_workspace_floats(B, n)
+    ws = _new((wsf,), z)
+    S = _new((B, B), z)
+    nsl = lib.dm_time_matching_num_slabs(B)
+    slabs = _new((nsl, 1, 2), z, torch.float64)
+    L.check(lib.dm_time_matching_forward(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),
+                                         _ptr(slabs, torch.float64), _stream()), "dm_time_matching_forward")
+    loss = sum_slabs(slabs, _new((1,), z))
+    return loss, S
+
+
+def time_matching_backward(z, S, g_loss=None, scale=1.0):
+    """dz = scale * g_loss[0] * d loss / d z  (g_loss: 1-element device tensor or None = 1)."""
+    lib = L.load()
+    B, n = z.shape
+    dz = torch.empty_like(z)
+    L.check(lib.dm_time_matching_backward(_ptr(z), _ptr(S), _ptr(g_loss), scale, _ptr(dz), B, n, _stream()),
+            "dm_time_matching_backward")
+    return dz
+
+
 # ------------------------------------------------------------- composition / optimizer
 def e1_compose(w0, b0, w1):
     lib = L.load()

@@ -101,10 +101,19 @@ class FusedTrainer:
             # pairwise term on z_before (vq_vae.py:324-332): HIP kernels for the (B, B) distances and their gradient,
             # the B*B weighting in torch
             zf = z.reshape(B, -1)
-            sim = ops.pair_msd(zf)
-            tml, g_sim = self._time_matching(sim, time_matching_mat.to(sim.dtype))
             wm = float(model.weight_matching)
-            dz = dz + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(z.shape)
+            tm = time_matching_mat.to(torch.float32).contiguous()
+            if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
+                z16 = getattr(model, "_z16_loss", False)
+                tml, S = ops.time_matching_forward(zf, tm, 1 if z16 else 0, float(getattr(model, "w_a", 0.0)),
+                                                   float(getattr(model, "w_t", 0.0)), float(getattr(model, "w_n", 0.0)),
+                                                   float(getattr(model, "margin", 0.0)))
+                dz = dz + ops.time_matching_backward(zf, S, None, wm).reshape(z.shape)
+                tml = tml.reshape(())
+            else:
+                sim = ops.pair_msd(zf)
+                tml, g_sim = self._time_matching(sim, tm)
+                dz = dz + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(z.shape)
             scalars = torch.cat([scalars[:2], (scalars[2] + wm * tml).reshape(1), scalars[3:4], tml.reshape(1)])
         # the flat gradient buffer starts at zero and nothing ever writes the BatchNorm-fed conv biases' slots
         E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False, pending_extra=extra)

@@ -156,6 +156,44 @@ class _PairMSDFn(torch.autograd.Function):
         return ops.pair_msd_backward(z, g_sim.contiguous().float())
 
 
+class _TimeMatchingFn(torch.autograd.Function):
+    """The time-matching loss as ONE op: Gram matrix on the MFMA, the loss form of the model family (mode 0:
+    vq_vae.py:330-331; mode 1: vae.py:327-336) in the kernel's epilogue, the backward a second MFMA product
+    (dm_time_matching_forward / _backward).  Returns the scalar loss."""
+
+    @staticmethod
+    def forward(ctx, zf, tm, mode, w_a, w_t, w_n, margin):
+        _require_gpu(zf, "time-matching loss")
+        z = zf.detach().contiguous().float()
+        loss, S = ops.time_matching_forward(z, tm.detach().contiguous().float(), mode, w_a, w_t, w_n, margin)
+        ctx.save_for_backward(z, S)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        z, S = ctx.saved_tensors
+        return (ops.time_matching_backward(z, S, g.reshape(1).contiguous().float()),) + (None,) * 6
+
+
+def time_matching_loss(latents, time_matching_mat, z16_form, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0):
+    """latents (B, ...) -> scalar loss of the pairwise term; the reference's expressions when the MFMA kernels do not tile
+    the latent length (n % 32 != 0): distances from dm_pair_msd, weights / hinge / reduction in torch."""
+    zf = latents.reshape((latents.shape[0], -1))
+    assert (zf.shape[0], zf.shape[0]) == tuple(time_matching_mat.shape)
+    if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
+        return _TimeMatchingFn.apply(zf, time_matching_mat, 1 if z16_form else 0, float(w_a), float(w_t), float(w_n), float(margin))
+    sim_mat = _PairMSDFn.apply(zf)
+    if not z16_form:
+        return (sim_mat * time_matching_mat).sum()                          # vq_vae.py:331
+    wts = time_matching_mat.clone()                                          # vae.py:327-335
+    wts[time_matching_mat == 2] = w_a
+    wts[time_matching_mat == 1] = w_t
+    wts[time_matching_mat == 0] = w_n
+    val = sim_mat * wts
+    val = torch.where(time_matching_mat == 0, torch.clamp(val + margin, min=0), val)
+    return val.mean()
+
+
 class VectorQuantizer(nn.Module):
     """Vector quantizer of "Neural Discrete Representation Learning" (reference vq_vae.py:25-116)."""
 
@@ -313,21 +351,10 @@ class VQ_VAE(nn.Module):
         object.__setattr__(self.enc, "_owner", ref)
         object.__setattr__(self.dec, "_owner", ref)
 
-    # ---- the pairwise term: the (B, B) mean-squared latent distances come from the HIP kernel (no (B, B, n)
-    #      intermediate); weights / hinge / reduction over the B*B matrix are the reference's torch expressions ----
+    # ---- the pairwise term (vq_vae.py:324-332; weighted / hinge form of VQ_VAE_z16, vae.py:322-336): one fused op ----
     def _time_matching(self, z_before, time_matching_mat):
-        zf = z_before.reshape((z_before.shape[0], -1))
-        sim_mat = _PairMSDFn.apply(zf)
-        assert sim_mat.shape == time_matching_mat.shape
-        if not self._z16_loss:
-            return (sim_mat * time_matching_mat).sum()                      # vq_vae.py:331
-        wts = time_matching_mat.clone()                                      # vae.py:327-335
-        wts[time_matching_mat == 2] = self.w_a
-        wts[time_matching_mat == 1] = self.w_t
-        wts[time_matching_mat == 0] = self.w_n
-        val = sim_mat * wts
-        val = torch.where(time_matching_mat == 0, torch.clamp(val + self.margin, min=0), val)
-        return val.mean()
+        return time_matching_loss(z_before, time_matching_mat, self._z16_loss, getattr(self, "w_a", 0.0),
+                                  getattr(self, "w_t", 0.0), getattr(self, "w_n", 0.0), getattr(self, "margin", 0.0))
 
     def forward(self, inputs, time_matching_mat=None, batch_mask=None):
         """inputs (B, C, H, W) -> (decoded, loss dict)   [vq_vae.py:300-338]"""
@@ -488,20 +515,13 @@ class VQ_VAE_z32(nn.Module):
         mask = _prep(batch_mask) if batch_mask is not None else None
         decoded, recon_loss = self.dec._tail(self.dec[0](z_after), x, mask, self.channel_var)
         total_loss = recon_loss + c_loss
-        time_matching_loss = 0
         if time_matching_mat is not None:
-            sim_mat = _PairMSDFn.apply(z_after.reshape((z_after.shape[0], -1)))
-            assert sim_mat.shape == time_matching_mat.shape
-            wts = time_matching_mat.clone()
-            wts[time_matching_mat == 2] = self.w_a
-            wts[time_matching_mat == 1] = self.w_t
-            wts[time_matching_mat == 0] = self.w_n
-            val = sim_mat * wts
-            val = torch.where(time_matching_mat == 0, torch.clamp(val + self.margin, min=0), val)
-            time_matching_loss = val.mean()
-            total_loss = total_loss + time_matching_loss * self.weight_matching
+            tml = time_matching_loss(z_after, time_matching_mat, True, self.w_a, self.w_t, self.w_n, self.margin)   # vae.py:441-455
+            total_loss = total_loss + tml * self.weight_matching
+        else:
+            tml = 0
         return decoded, {'recon_loss': recon_loss, 'commitment_loss': c_loss,
-                         'time_matching_loss': time_matching_loss, 'perplexity': perplexity,
+                         'time_matching_loss': tml, 'perplexity': perplexity,
                          'total_loss': total_loss}
 
     def predict(self, inputs):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 105
+#define DM_VERSION 106
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -317,6 +317,24 @@ int dm_recon_loss_backward(const float *decoded, const float *x, const float *ma
 int dm_pair_msd(const float *z, float *sim, int B, int n, void *stream);
 /* Its backward: dz[i] = (2/n) * sum_j (g_sim[i][j] + g_sim[j][i]) * (z[i] - z[j]). */
 int dm_pair_msd_backward(const float *z, const float *g_sim, float *dz, int B, int n, void *stream);
+
+/* The whole term on the matrix pipe (csrc/pairwise.hip): sim from the Gram matrix Z Z^T (f32 MFMA, K split into chunks added
+ * in double), the loss form of either model family, and S_ij = dloss/dsim_ij + dloss/dsim_ji for the backward, which is a
+ * second MFMA GEMM: dz_i = (2/n) (rowsum(S)_i z_i - sum_j S_ij z_j).
+ *   mode 0  vq_vae.py:330-331   loss = sum_ij sim_ij * tm_ij
+ *   mode 1  vae.py:327-336      w = {2: w_a, 1: w_t, 0: w_n}[tm]; v = sim * w; tm == 0: v = max(v + margin, 0); loss = mean v
+ * z (B, n) contiguous with n % 32 == 0 (dm_time_matching_supported; other lengths: dm_pair_msd); tm (B, B) float32;
+ * workspace: dm_time_matching_workspace_floats(B, n) floats of scratch; S (B, B) out; loss_slabs: dm_time_matching_num_slabs(B)
+ * pairs of doubles, (partial loss, 0) each -- dm_sum_slabs(loss_slabs, nslabs, 1, 1, loss) gives the scalar.
+ * dm_time_matching_backward: dz = scale * g_loss_dev[0] * d loss / d z  (g_loss_dev NULL: 1). */
+int dm_time_matching_supported(int B, int n);
+int64_t dm_time_matching_workspace_floats(int B, int n);
+int dm_time_matching_num_slabs(int B);
+int dm_time_matching_forward(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t, float w_n,
+                             float margin, float *workspace, int64_t workspace_floats, float *S, double *loss_slabs,
+                             void *stream);
+int dm_time_matching_backward(const float *z, const float *S, const float *g_loss_dev, float scale, float *dz, int B, int n,
+                              void *stream);
 
 /* ===== enc.0 o enc.1 composition (vq_vae.py:277-278) ========================== */
 
