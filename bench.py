@@ -59,14 +59,17 @@ def event_time_ms(fn, iters=20, warmup=3):
 
 def pmc_traffic(kernel_key, batch):
     """HBM bytes per launch of the roofline kernel, from the separate `rocprofv3 --pmc` passes summarised in
-    profiles/r01_pmc_traffic.json (tools/pmc_traffic.py writes it; bench.py cannot run under the profiler
+    profiles/r0N_pmc_traffic.json (tools/pmc_traffic.py writes it; bench.py cannot run under the profiler
     itself).  None when no measurement for this kernel and batch has been committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f).get(kernel_key)
-    except (OSError, ValueError):
-        return None
+    rec = None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):       # the newest measurement that has this kernel
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f).get(kernel_key)
+        except (OSError, ValueError):
+            rec = None
+        if rec:
+            break
     if not rec or rec.get("batch") != batch:
         return None
     return rec.get("hbm_bytes_per_launch")

@@ -42,6 +42,10 @@ cases["tail_fwd"] = (lambda: ops.dec_tail_forward(d2, w4, b4, w6, b6, x, None, v
 cases["tail_bwd"] = (lambda: ops.dec_tail_backward(d2, w4, b4, w6, dec, x, None, var, gs), B * 393216)
 cases["tail_train"] = (lambda: ops.dec_tail_train(d2, w4, b4, w6, b6, x, None, var, gs), B * 262144)
 
+zq = torch.randn(B, 16, 16, 16, device=dev); cbk = torch.randn(64, 16, device=dev)
+vq_bufs = ops.vq_forward_repeat(zq, cbk, 1)
+cases["vq_fwd"] = (lambda: ops.vq_forward_repeat(zq, cbk, 1, bufs=vq_bufs), B * 34816)      # prep + distance kernel + counter reduction
+
 src = torch.randn(64 << 20, device=dev); dst = torch.empty_like(src)          # 256 MiB each: past the Infinity Cache
 cases["copy_calib"] = (lambda: torch.add(src, 1.0, out=dst), 2 * src.numel() * 4)            # known bytes: calibrates the PMC counters
 
