@@ -413,7 +413,7 @@ def main():
     else:
         roof = roofline_dominant_kernel(model, x, args.workload)
     targets = c2 = None
-    if rank == 0 and args.workload == "c3" and not args.no_targets:
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_targets:
         targets = north_star_targets(model, x)
         c2 = c2_record(model)
     cpu = None

@@ -949,6 +949,188 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
     }
 }
 
+// ---- codebooks of at most 64 codes (every configuration of the reference): the codebook gradient as a one-hot product
+// on the matrix cores.  dW[k][d] = sw * sum_p [idx[p] == k] (e_k[d] - z[p][d]) is (codes x positions) . (positions x D):
+// v_mfma_f32_16x16x4_f32 with A[i = code][kk = position] = 1.0 or 0.0 built from the indices and
+// B[kk = position][j = d] = sw * (e - z) -- the value the lane has just formed for dz.  The accumulators live in
+// registers over all of a wave's positions, the waves of a workgroup are combined in wave order and the workgroup
+// writes ONE slab, so the sum over positions has a fixed order: no float atomics anywhere (the LDS-atomic kernel
+// above stays for larger codebooks, where a one-hot product would cost K/16 matrix instructions per four positions).
+// Lane (i = lane & 15, g = lane >> 4) holds row d = 16 dt + i of four position quads: z[d][16 u + 4 g .. + 3].
+constexpr int VQ_BWD2_BLOCK = 512;
+template <int D, int WGS>
+__global__ __launch_bounds__(VQ_BWD2_BLOCK, WGS) void vq_backward_mfma_kernel(
+    const float *__restrict__ z, const float *__restrict__ cb, const long long *__restrict__ idx,
+    const float *__restrict__ g_out, const float *__restrict__ g_loss_dev, float cc,
+    float *__restrict__ dz, float *__restrict__ dw_slabs, int K, int HW, unsigned NC)
+{
+    constexpr int DT = D / 16, HROW = D + 1, NW = VQ_BWD2_BLOCK / 64;
+    __shared__ float s_cb[64 * HROW];                        // codes as rows, one pad word: the gather is conflict-free
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float g_loss = g_loss_dev ? g_loss_dev[0] : 1.f;
+    const double N = (double)NC * 64.0 * (double)D;
+    const float sz = (float)(2.0 * (double)cc / N) * g_loss;   // d/dz of cc * mse(q.detach(), z)
+    const float sw = (float)(2.0 / N) * g_loss;                // d/dq of mse(q, z.detach())
+    const unsigned cps = (unsigned)HW >> 6;                    // chunks of 64 positions per sample
+    f32x4 acc[4][DT];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned sample_bytes = (unsigned)D * (unsigned)HW * 4u;
+    const unsigned voff = ((unsigned)i * (unsigned)HW + 4u * (unsigned)g) * 4u;      // this lane's bytes inside a row group
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+    auto rsrc = [&](const float *p, unsigned b) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p) + (long long)b * D * HW, 0, sample_bytes, 0x00020000);
+    };
+    // (row group dt, position quad u) of chunk cw: scalar byte offset inside the sample
+    auto soff = [&](unsigned cw, int dt, int u) { return cw * 256u + (unsigned)(16 * dt) * (unsigned)HW * 4u + 64u * u; };
+    auto load = [&](f32x4 (&dst)[DT][4], const float *p, unsigned b, unsigned cw) {
+        const __amdgpu_buffer_rsrc_t r = rsrc(p, b);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                dst[dt][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff(cw, dt, u), 0));
+    };
+    // (the low word of the int64 index: a 64-bit load leaves a dead high register whose reuse stalls on the load)
+    const int *__restrict__ idx32 = reinterpret_cast<const int *>(idx);
+    const unsigned step = gridDim.x * NW;
+    unsigned chunk = blockIdx.x * NW + wave;
+    f32x4 zr[DT][4], gr[DT][4], zn[DT][4], gn[DT][4];
+    int kv = 0, kn = 0;
+    constexpr bool PF = D <= 32;                               // (embedding_dim 64: the second set of rows would spill)
+    if (PF && chunk < NC) {
+        const unsigned b = chunk / cps, cw = chunk - b * cps;
+        load(zr, z, b, cw);
+        if (g_out) load(gr, g_out, b, cw);
+        kv = idx32[2 * ((long long)chunk * 64 + lane)];
+    }
+    // (the codebook after the first rows have been requested: one memory round trip for both)
+    for (int e = threadIdx.x; e < 64 * D; e += VQ_BWD2_BLOCK) {
+        const int k = e / D, d = e - k * D;
+        s_cb[k * HROW + d] = k < K ? cb[e] : 0.f;
+    }
+    __syncthreads();
+    for (; chunk < NC; chunk += step) {
+        const unsigned b = chunk / cps, cw = chunk - b * cps;
+        const unsigned nxt = chunk + step;
+        if constexpr (!PF) {
+            load(zr, z, b, cw);
+            if (g_out) load(gr, g_out, b, cw);
+            kv = idx32[2 * ((long long)chunk * 64 + lane)];
+        }
+        if constexpr (PF) {
+            // the next chunk's rows are in flight during this one's products (past the end: the last chunk again, from L2 --
+            // an unconditional load keeps the wait counts exact)
+            const unsigned nc = nxt < NC ? nxt : NC - 1;
+            const unsigned nb = nc / cps, ncw = nc - nb * cps;
+            load(zn, z, nb, ncw);
+            if (g_out) load(gn, g_out, nb, ncw);
+            kn = idx32[2 * ((long long)nc * 64 + lane)];
+            __builtin_amdgcn_sched_barrier(0);                 // (the scheduler otherwise sinks the index load below the products)
+        }
+        if (!g_out) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gr[dt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // the sixteen codes of this lane's positions, then their rows of the codebook: two batched LDS round trips
+        int kj[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = __builtin_amdgcn_ds_bpermute(4 * (16 * u + 4 * g + t), kv);
+                kj[u][t] = (unsigned)k < 64u ? k : 63;         // (indices come from dm_vq_forward: always in range)
+            }
+        float ev[DT][4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) ev[dt][u][t] = s_cb[kj[u][t] * HROW + 16 * dt + i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rel = kj[u][t] - i;
+                float bv[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const float zc = zr[dt][u][t], gc = gr[dt][u][t];
+                    const float diff = ev[dt][u][t] - zc;
+                    bv[dt] = sw * diff;
+                    gr[dt][u][t] = gc - sz * diff;            // g + sz * (z - e), the bits of the kernel above
+                }
+                // (all four code tiles: a tile past K holds no index, its products are zeros)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const float a = rel == 16 * kt ? 1.f : 0.f;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        acc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[dt], acc[kt][dt], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (PF) {
+            // pin the wait for the prefetched rows here, ahead of the stores (else it lands after them as vmcnt(0))
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" : "+v"(zn[dt][u]));
+                    if (g_out) asm volatile("" : "+v"(gn[dt][u]));
+                }
+            asm volatile("" : "+v"(kn));
+        }
+        if (dz) {
+            const __amdgpu_buffer_rsrc_t r = rsrc(dz, b);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gr[dt][u]), r, voff, soff(cw, dt, u), 0);
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    zr[dt][u] = zn[dt][u];
+                    if (g_out) gr[dt][u] = gn[dt][u];
+                }
+            kv = kn;
+        }
+    }
+    // ---- the waves of the workgroup in wave order, then one slab [K][D].  acc[kt][dt][r] is code 16 kt + 4 g + r, d 16 dt + i
+    __syncthreads();                                           // every gather from s_cb is done: reuse it as the sum
+    float *s_sum = s_cb;
+    for (unsigned w = 0; w < NW; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *dst = s_sum + (16 * kt + 4 * g + r) * HROW + 16 * dt + i;
+                        *dst = w == 0 ? acc[kt][dt][r] : *dst + acc[kt][dt][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *slab = dw_slabs + (long long)blockIdx.x * K * D;
+    for (int e = threadIdx.x; e < K * D; e += VQ_BWD2_BLOCK) {
+        const int k = e / D, d = e - k * D;
+        slab[e] = s_sum[k * HROW + d];
+    }
+}
+
 bool vq_dim_supported(int D) { return D == 8 || D == 16 || D == 32 || D == 64 || D == 128; }
 
 }  // namespace
@@ -1111,6 +1293,20 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
     const int grid = vq_backward_grid(P);
     const dim3 g3((unsigned)grid, (unsigned)((K + Kc - 1) / Kc));
     hipStream_t s = (hipStream_t)stream;
+    const uintptr_t al = (uintptr_t)z | (uintptr_t)g_out | (uintptr_t)dz;
+    if (dw_slabs && K <= 64 && (D == 16 || D == 32 || D == 64) && (H * W) % 64 == 0 && (al & 15) == 0) {
+        const unsigned NC = (unsigned)(P >> 6);
+#define DM_VQ_BWD2(DD, WGS)                                                                                    \
+    hipLaunchKernelGGL((vq_backward_mfma_kernel<DD, WGS>), dim3((unsigned)grid), dim3(VQ_BWD2_BLOCK), 0, s, z, codebook, \
+                       (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw_slabs, K, H * W, NC)
+        switch (D) {
+        case 16: DM_VQ_BWD2(16, 4); break;
+        case 32: DM_VQ_BWD2(32, 2); break;
+        default: DM_VQ_BWD2(64, 2); break;
+        }
+#undef DM_VQ_BWD2
+        return dm_launch_status(who);
+    }
 #define DM_VQ_BWD(DD)                                                                                          \
     if (lds > 48 * 1024)                                                                                       \
         (void)hipFuncSetAttribute((const void *)vq_backward_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize,  \

@@ -148,7 +148,7 @@ def vq_decode(idx, codebook):
 
 def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_dz=True):
     """g_loss: 1-element device tensor (or None = 1).  dw given: accumulated into with float atomics (zero it first);
-    dw None: a fresh tensor from the deterministic slab form."""
+    dw None: a fresh tensor from the slab form (see vq_backward_slabs for when that form is ordered)."""
     lib = L.load()
     B, D, H, W = z.shape
     K = codebook.shape[0]
@@ -163,7 +163,10 @@ def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_
 
 def vq_backward_slabs(z, codebook, idx, g_out, g_loss, commitment_cost, want_dz=True):
     """Like vq_backward, but the codebook gradient comes back as per-workgroup slabs (nslabs, K*D) for
-    reduce_slabs / reduce_slabs_multi: no global float atomics, nothing to zero."""
+    reduce_slabs / reduce_slabs_multi: no global float atomics, nothing to zero.  Codebooks of at most 64 codes with
+    embedding_dim 16/32/64 and H*W % 64 == 0 (every reference configuration) accumulate as a one-hot product on the
+    matrix cores in a fixed order: bit-reproducible.  Larger codebooks add inside a workgroup with LDS float atomics in
+    arrival order, so the low bits of THEIR gradient may differ from run to run."""
     lib = L.load()
     B, D, H, W = z.shape
     K = codebook.shape[0]

@@ -94,7 +94,8 @@ class FusedTrainer:
         scalars = ops.loss_finalize(dcx.loss_slabs, B * NIN * H * W, vsc, float(model.weight_recon),
                                     float(model.weight_commitment))
         gcb = self.G(L.codebook.weight)
-        # codebook gradient as slabs, added in the encoder's single slab reduction: no atomics, nothing to zero
+        # codebook gradient as slabs, added in the encoder's single slab reduction: nothing to zero, no global atomics
+        # (K <= 64: an ordered one-hot product on the matrix cores, bit-reproducible; larger K: LDS adds in arrival order)
         dz, cb_slabs = ops.vq_backward_slabs(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc)
         extra = [(cb_slabs, gcb)]
         if time_matching_mat is not None:

@@ -149,8 +149,11 @@ int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
 
 /* The same with the codebook gradient as per-workgroup slabs [dm_vq_backward_num_slabs(P)][K*D] instead of global
  * float atomics: dm_reduce_slabs / dm_reduce_slabs_multi adds them in a fixed order and nothing has to be zeroed
- * first (inside a workgroup the LDS adds still arrive in hardware order).  Codebooks above the 128 KB LDS window
- * (512 x 64, 4096 x 16) are processed in windows of codes over grid.y. */
+ * first.  K <= 64 with D in {16, 32, 64}, H*W % 64 == 0 and 16-byte aligned tensors: the gradient is a one-hot
+ * (codes x positions) . (positions x D) product on the matrix cores, accumulated in registers and combined in wave
+ * order -- bit-reproducible.  Otherwise positions are added into an LDS window with float atomics (hardware order
+ * inside a workgroup: low bits may vary); codebooks above the 128 KB window (512 x 64, 4096 x 16) are processed in
+ * windows of codes over grid.y. */
 int dm_vq_backward_num_slabs(int64_t positions);
 int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *idx,
                          const float *g_out, const float *g_loss_dev, float commitment_cost,

@@ -814,6 +814,39 @@ def test_vq_backward_slabs_equal_the_atomic_form(ops):
     close(dw_s.reshape(K, D), dw_a, 1e-5, 1e-7 * float(dw_a.abs().max()) + 1e-9, "codebook gradient (slabs)")
 
 
+@pytest.mark.parametrize("B,K,D,H", [(70, 64, 16, 16), (9, 64, 32, 8), (5, 64, 64, 16), (3, 10, 16, 8), (37, 33, 32, 16),
+                                     (2048, 64, 16, 16)])
+def test_vq_backward_one_hot_product_is_ordered(ops, B, K, D, H):
+    """Codebooks of at most 64 codes: the slab form accumulates the codebook gradient on the matrix cores in a fixed
+    order (no float atomics, LDS or global), so two runs agree to the bit; values against embedding_dense_backward /
+    mse_loss_backward restated with index_add in double."""
+    z = rnd(B, D, H, H, seed=61)
+    cb = rnd(K, D, seed=62)
+    g = rnd(B, D, H, H, seed=63)
+    zd, cbd, gd = z.to(DEV), cb.to(DEV), g.to(DEV)
+    idx, _, _, _ = ops.vq_forward(zd, cbd, want_out=False)
+    gl = torch.tensor([1.3], device=DEV)
+    q = cb[idx.cpu()].permute(0, 3, 1, 2)
+    N = z.numel()
+    dz_ref = g + 1.3 * 2 * 0.25 * (z - q) / N
+    dw_ref = torch.zeros(K, D, dtype=torch.float64).index_add_(
+        0, idx.cpu().reshape(-1), (1.3 * 2 * (q.double() - z.double()) / N).permute(0, 2, 3, 1).reshape(-1, D))
+    dz_1, slabs_1 = ops.vq_backward_slabs(zd, cbd, idx, gd, gl, 0.25)
+    dz_2, slabs_2 = ops.vq_backward_slabs(zd, cbd, idx, gd, gl, 0.25)
+    assert torch.equal(slabs_1, slabs_2) and torch.equal(dz_1, dz_2)
+    dw = ops.reduce_slabs(slabs_1, torch.empty_like(cbd))
+    close(dz_1, dz_ref, 1e-6, 1e-9, "dz")
+    close(dw, dw_ref.float(), 1e-5, 1e-6 * float(dw_ref.abs().max()), "codebook gradient (one-hot product)")
+    dz_a, dw_a = ops.vq_backward(zd, cbd, idx, gd, gl, 0.25, dw=torch.zeros(K, D, device=DEV))
+    assert torch.equal(dz_a, dz_1)                             # same expression as the windowed kernel
+    # no upstream gradient / no dz wanted
+    dz_0, slabs_0 = ops.vq_backward_slabs(zd, cbd, idx, None, gl, 0.25)
+    close(dz_0, 1.3 * 2 * 0.25 * (z - q) / N, 1e-5, 1e-12, "dz without g_out")
+    none, slabs_n = ops.vq_backward_slabs(zd, cbd, idx, gd, None, 0.25, want_dz=False)
+    assert none is None
+    close(ops.reduce_slabs(slabs_n, torch.empty_like(cbd)), (dw_ref / 1.3).float(), 1e-5, 1e-6 * float(dw_ref.abs().max()), "dw, g_loss 1")
+
+
 @pytest.mark.parametrize("K,D,H", [(512, 64, 32), (4096, 16, 32), (300, 128, 8)])
 def test_vq_backward_large_codebooks(ops, K, D, H):
     """Codebooks above the LDS window (config_example.yml: 512 x 64; the stress case: 4096 x 16) go through windows

@@ -46,6 +46,11 @@ zq = torch.randn(B, 16, 16, 16, device=dev); cbk = torch.randn(64, 16, device=de
 vq_bufs = ops.vq_forward_repeat(zq, cbk, 1)
 cases["vq_fwd"] = (lambda: ops.vq_forward_repeat(zq, cbk, 1, bufs=vq_bufs), B * 34816)      # prep + distance kernel + counter reduction
 
+vq_idx = ops.vq_forward(zq, cbk, want_out=False)[0]
+gq = torch.randn_like(zq)
+cases["vq_bwd"] = (lambda: ops.vq_backward_slabs(zq, cbk, vq_idx, gq, None, 0.25), B * 256 * (3 * 64 + 8))  # z, g_out, dz, idx
+cases["vq_bwd_atomic"] = (lambda: ops.vq_backward(zq, cbk, vq_idx, gq, None, 0.25, dw=torch.zeros_like(cbk)), B * 256 * (3 * 64 + 8))
+
 src = torch.randn(64 << 20, device=dev); dst = torch.empty_like(src)          # 256 MiB each: past the Infinity Cache
 cases["copy_calib"] = (lambda: torch.add(src, 1.0, out=dst), 2 * src.numel() * 4)            # known bytes: calibrates the PMC counters
 
