@@ -44,21 +44,77 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
 
         def encode(x):                      # any other module: the reference's batch-of-one loop as it is
             return torch.cat([model.enc(x[j:j + 1]) for j in range(x.shape[0])], 0)
-    z_bs, z_as = [], []
     device = torch.device(device)
-    with torch.no_grad(), torch.cuda.device(device):           # (the reference hands non-zero gpu ids to its workers)
-        for i in range(0, patches.shape[0], batch_size):
+    N = patches.shape[0]
+    if N == 0:
+        return np.zeros((0, 0), np.float32), np.zeros((0, 0), np.float32)
+    # Three stages in flight: batch i+1 crosses PCIe on a copy stream while batch i is encoded, and the latents of batch
+    # i-1 go back on a second copy stream straight into the result arrays (a synchronous .cpu() per batch would leave the
+    # GPU idle for both transfers: at 2 M patches/s one batch of 1024 is 0.5 ms of kernels against 134 MB in and 33 MB
+    # out).  Measured on the MI355X host (tools/exp/host_alloc_probe.py): DMA from / to pinned memory 53-56 GB/s, from
+    # pageable memory 10 GB/s, into freshly allocated pageable memory 5 GB/s (first-touch page faults).  Hence: hand
+    # over PINNED patches for the full rate (process_VAE does: 365 k patches/s host to host, the PCIe limit); pageable
+    # patches of the right dtype are copied by the runtime's own staging (this thread blocks, the queued kernels do
+    # not: 120 k patches/s); patches that need a dtype conversion go through two pinned staging buffers.  The result
+    # arrays are allocated pinned (25 GB/s to allocate) unless they exceed DM_PINNED_RESULT_BYTES (default 16 GiB; then
+    # pageable, pre-faulted by a parallel fill, and written by blocking copies on a helper thread).
+    from concurrent.futures import ThreadPoolExecutor
+    bs = int(min(batch_size, N))
+    in_dtype = patches.dtype if zscore_on_device else torch.float32
+    pin_cap = int(os.environ.get("DM_PINNED_RESULT_BYTES", str(16 << 30)))
+    res = [None, None]
+    with torch.no_grad(), torch.cuda.device(device), ThreadPoolExecutor(1) as helper:   # (non-zero gpu ids: patch_VAE.py:422)
+        compute = torch.cuda.current_stream()
+        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+        shape = (bs,) + tuple(patches.shape[1:])
+        x_dev = [torch.empty(shape, dtype=in_dtype, device=device) for _ in range(2)]
+        convert = patches.dtype != in_dtype
+        in_pin = [torch.empty(shape, dtype=in_dtype, pin_memory=True) for _ in range(2)] if convert else None
+        ev_in = [torch.cuda.Event() for _ in range(2)]          # the batch has reached x_dev[k]
+        ev_done = [torch.cuda.Event() for _ in range(2)]        # the kernels reading x_dev[k] have finished
+        sent = [None, None]                                     # helper's future for the batch that last used slot k
+
+        def hand_back(lo, n, z_b, z_a, ev):
+            with torch.cuda.device(device), torch.cuda.stream(s_out):
+                s_out.wait_event(ev)
+                res[0][lo:lo + n].copy_(z_b, non_blocking=True)     # asynchronous into pinned results; into pageable ones
+                res[1][lo:lo + n].copy_(z_a, non_blocking=True)     # it blocks, but only this helper thread
+
+        for it, lo in enumerate(range(0, N, bs)):
+            k = it & 1
+            n = min(bs, N - lo)
+            if sent[k] is not None:
+                sent[k].result()                                # at most two batches of latents wait on the device
+            src = patches[lo:lo + n]
+            if convert:
+                ev_in[k].synchronize()                          # staging buffer k has left for the device
+                in_pin[k][:n].copy_(src)                        # host: the reference's .float() (patch_VAE.py:419)
+                src = in_pin[k][:n]
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(ev_done[k])                     # x_dev[k] is no longer being read (no-op the first time)
+                x_dev[k][:n].copy_(src, non_blocking=True)      # (pageable source: blocks this thread until it has left)
+                ev_in[k].record(s_in)
+            compute.wait_event(ev_in[k])
+            x = x_dev[k][:n]
             if zscore_on_device:
-                x = ops.zscore_patch(patches[i:i + batch_size].to(device=device))
-            else:
-                x = patches[i:i + batch_size].to(device=device, dtype=torch.float32).contiguous()
+                x = ops.zscore_patch(x)
             z_b = encode(x)
             z_a, _, _ = E.vq_forward(codebook, z_b, float(model.commitment_cost))
-            z_bs.append(z_b.reshape(x.shape[0], -1).cpu())
-            z_as.append(z_a.reshape(x.shape[0], -1).cpu())
-    if not z_bs:
-        return np.zeros((0, 0), np.float32), np.zeros((0, 0), np.float32)
-    return torch.cat(z_bs, 0).numpy(), torch.cat(z_as, 0).numpy()
+            ev_done[k].record(compute)
+            z_b, z_a = z_b.reshape(n, -1), z_a.reshape(n, -1)
+            if res[0] is None:
+                pinned = 4 * N * (z_b.shape[1] + z_a.shape[1]) <= pin_cap
+                for q, zq in enumerate((z_b, z_a)):
+                    res[q] = (torch.empty((N, zq.shape[1]), dtype=torch.float32, pin_memory=True) if pinned
+                              else torch.empty((N, zq.shape[1]), dtype=torch.float32).fill_(0))
+            z_b.record_stream(s_out)
+            z_a.record_stream(s_out)
+            sent[k] = helper.submit(hand_back, lo, n, z_b, z_a, ev_done[k])
+        for f in sent:
+            if f is not None:
+                f.result()
+        s_out.synchronize()
+    return res[0].numpy(), res[1].numpy()
 
 
 def encode_patches_sharded(model, patches, device="cuda:0", batch_size=1024, zscore_on_device=False, group=None):
@@ -99,8 +155,11 @@ def process_VAE(raw_folder, supp_folder, sites, config_, gpu=0, network_module=N
     if on_dev:
         dataset = torch.from_numpy(np.ascontiguousarray(np.squeeze(dataset)))       # raw float64; z-scored per batch on the GPU
     else:
-        dataset = zscore_patch(np.squeeze(dataset))
-        dataset = torch.from_numpy(dataset).float()
+        dataset = torch.from_numpy(zscore_patch(np.squeeze(dataset)))
+        try:                                        # the .float() of patch_VAE.py:419, into pinned memory: encode_patches
+            dataset = torch.empty(dataset.shape, dtype=torch.float32, pin_memory=True).copy_(dataset)   # then runs at the PCIe rate
+        except RuntimeError:
+            dataset = dataset.float()
     assert dataset.dim() == 4, "dataset tensor dimension can only be 4, not {}".format(dataset.dim())
     assert len(fs) == dataset.shape[0]
     device = torch.device('cuda:%d' % gpu)

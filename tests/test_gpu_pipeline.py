@@ -198,6 +198,35 @@ def test_encode_patches_sharded_single_process_is_encode_patches():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("on_device", [False, True])
+def test_encode_patches_pipeline_is_independent_of_the_batching(on_device):
+    """The copy-in / encode / copy-out pipeline (two pinned staging buffers per direction, three streams): many ragged
+    batches give bit for bit what one batch gives, in input order -- per-sample BatchNorm statistics keep patches
+    independent; also with the z-score on the device (float64 staging)."""
+    import dynamorph_amd
+    from dynamorph_amd.patch_vae import encode_patches
+    torch.manual_seed(9)
+    m = dynamorph_amd.VQ_VAE().to("cuda:0")
+    x = torch.randn(23, 2, 128, 128, generator=torch.Generator().manual_seed(4))
+    x = (x.double() * 300 + 1000) if on_device else x
+    one = encode_patches(m, x, device="cuda:0", batch_size=64, zscore_on_device=on_device)
+    for bs in (5, 1, 23, 11):
+        many = encode_patches(m, x.numpy() if bs == 11 else x, device="cuda:0", batch_size=bs, zscore_on_device=on_device)
+        assert many[0].shape == (23, 16 * 16 * 16) and many[0].dtype == np.float32
+        assert np.array_equal(one[0], many[0]) and np.array_equal(one[1], many[1]), bs
+    empty = encode_patches(m, x[:0], device="cuda:0")
+    assert empty[0].shape[0] == 0
+    # pinned input is sent without staging; results above DM_PINNED_RESULT_BYTES come back into pageable memory
+    pinned_in = encode_patches(m, x.pin_memory(), device="cuda:0", batch_size=6, zscore_on_device=on_device)
+    os.environ["DM_PINNED_RESULT_BYTES"] = "0"
+    try:
+        pageable_out = encode_patches(m, x, device="cuda:0", batch_size=6, zscore_on_device=on_device)
+    finally:
+        del os.environ["DM_PINNED_RESULT_BYTES"]
+    for got in (pinned_in, pageable_out):
+        assert np.array_equal(one[0], got[0]) and np.array_equal(one[1], got[1])
+
+
 def test_encode_patches_in_eval_mode_uses_running_statistics():
     """model.eval() before encode_patches (never done by the reference path, but a caller may): BatchNorm takes its
     running statistics for every sample -- the coefficients are shared, not per sample."""
