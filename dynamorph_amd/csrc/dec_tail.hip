@@ -124,7 +124,7 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
     in.p0 = d2; in.p1 = nullptr; in.coef = nullptr; in.coef_bstride = 0; in.mode = DM_LOAD_IDENT; in.ones = 0;
 
     TileStage<TT_C, AROWS, TT_W / 4, TT_W, APS, false> stage;
-    stage.init();
+    stage.init(H2, TT_W);
     int tidx = blockIdx.x, b = 0, y0 = 0;
     if (tidx < ntiles) {
         y0 = (tidx % tiles_y) * TT_TH; b = tidx / tiles_y;
@@ -276,7 +276,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     in.p0 = d2; in.p1 = nullptr; in.coef = nullptr; in.coef_bstride = 0; in.mode = DM_LOAD_IDENT; in.ones = 0;
 
     TileStage<TT_C, AROWS, TT_W / 4, TT_W, APS, false> stage;
-    stage.init();
+    stage.init(H2, TT_W);
     int tidx = blockIdx.x, b = 0, y0 = 0;
     if (tidx < ntiles) {
         y0 = (tidx % tiles_y) * TT_TH; b = tidx / tiles_y;

@@ -2,14 +2,23 @@
 //
 // Register-staged, two-phase, so a persistent workgroup can keep the NEXT tile's loads in flight while
 // it runs the MFMAs and stores of the current one (the LDS buffer is single, the registers are the
-// second buffer):
-//   init():   per-thread constants of its N tile elements (LDS offset, row, column, channel packed in one
-//             register each) -- tile independent, computed once per workgroup.
-//   issue():  all of a thread's 16-byte loads (both tensors for AFFINE2) go out back to back, predicated
-//             only on "inside the image"; no branch depends on the operand mode.
-//   commit(): v = c0*p0 + c1*p1 + c2, optional ReLU, zero in the padding, 1 in the synthetic ones channel;
-//             one ds_write_b128 per element.  The per-channel coefficients come from a small LDS table
-//             (stage_coef) so commit issues no global loads.
+// second buffer).
+//
+// Element mapping (round 2): a thread owns the SAME position (row r, 16-byte column j4) of the tile in every channel
+// step, so everything that depends on the position -- inside-the-image test, global offset, LDS offset -- is worked
+// out once per tile (a handful of vector instructions), and an element costs its load, its transform and its
+// ds_write_b128 only.  (Round 1 spread consecutive elements over the threads regardless of channel: ~30 vector
+// instructions of decoding and bounds tests per element, in a dozen small basic blocks each with its own wait.)
+// A channel plane of PER_C = ROWS * COLS4 elements is covered by P = ceil(PER_C / 256) passes of the workgroup; planes
+// smaller than half a workgroup put G = 256 / PER_C channels side by side.  Element k = (channel step k / P, pass
+// k % P) is channel G * (k / P) + cs of this thread's pass-p position.
+//   init(H, W): per-thread constants of its P positions -- tile independent, computed once per workgroup.
+//   begin():    the tile's buffer descriptors and, per position, the byte offset or an out-of-range marker.
+//   issue_one(k): ONE 16-byte load per tensor; elements outside the image, channels past the physical ones and every
+//               element when there is no next tile (empty descriptor) fail the range check and read as 0 = the padding.
+//   commit():   v = c0*p0 + c1*p1 + c2, optional ReLU, zero in the padding, 1 in the synthetic ones channel;
+//               one ds_write_b128 per element.  The per-channel coefficients come from a small LDS table
+//               (stage_coef) so commit issues no global loads.
 // IDENT/RELU use c0 = 1, c1 = c2 = 0, which leaves the value bit-identical.
 #pragma once
 #include "dm_common.h"
@@ -32,27 +41,51 @@ __device__ __forceinline__ void stage_coef(float *__restrict__ s_coef, const Ope
     }
 }
 
+typedef unsigned short dm_u16x2 __attribute__((ext_vector_type(2)));
+
 template <int CIN, int ROWS, int COLS4, int RS, int PS, bool TWO>
 struct TileStage {
     static constexpr int PER_C = ROWS * COLS4;
-    static constexpr int TOTAL = CIN * PER_C;
-    static constexpr int N = (TOTAL + DM_BLOCK - 1) / DM_BLOCK;
-    static_assert(CIN * PS < (1 << 14) && ROWS < 64 && COLS4 < 64 && CIN <= 64, "metadata packing");
+    static constexpr int G = PER_C < DM_BLOCK ? DM_BLOCK / PER_C : 1;       // channels side by side across the workgroup
+    static constexpr int P = (PER_C + DM_BLOCK - 1) / DM_BLOCK;             // passes over one channel plane
+    static constexpr int NC = (CIN + G - 1) / G;                            // channel steps
+    static constexpr int N = NC * P;
+    static constexpr unsigned OOB = 0x80000000u;   // + any channel offset (< 2^31) stays past every sample, never wraps
+    static_assert(CIN * PS < (1 << 14) && ROWS < 0x4000 && COLS4 < 0x4000 && CIN <= 64, "LDS offsets fit ds immediates");
     f32x4 v[N];
     f32x4 u[TWO ? N : 1];
-    int meta[N];     // lds offset | r << 14 | j4 << 20 | c << 26 ; -1 = no element
+    int rj[P];       // r | j4 << 16 of this thread's pass-p position; r = 0x7fff: no such position (never inside)
+    int loff[P];     // LDS float offset of (channel cs, r, j4)
+    int goff[P];     // byte offset of (channel cs, row r, column 4*j4) from the sample's (channel 0, row 0, column 0)
+    int cs;          // channel sub-index of this thread (< G)
+    int HW4;         // bytes of one channel plane (uniform)
 
-    __device__ __forceinline__ void init()
+    __device__ __forceinline__ void init(int H, int W)
     {
+        const int t = threadIdx.x;
+        cs = G > 1 ? t / PER_C : 0;
+        const int e0 = G > 1 ? t - cs * PER_C : t;
+        HW4 = H * W * 4;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int i = threadIdx.x + k * DM_BLOCK;
-            const int c = i / PER_C;
-            const int rem = i - c * PER_C;
-            const int r = rem / COLS4;
-            const int j4 = rem - r * COLS4;
-            meta[k] = i < TOTAL ? ((c * PS + r * RS + 4 * j4) | (r << 14) | (j4 << 20) | (c << 26)) : -1;
+        for (int p = 0; p < P; ++p) {
+            const int e = e0 + p * DM_BLOCK;
+            const bool have = e < PER_C && cs < G;
+            const int r = e / COLS4, j4 = e - r * COLS4;
+            rj[p] = have ? (r | (j4 << 16)) : 0x7fff;
+            loff[p] = cs * PS + r * RS + 4 * j4;
+            goff[p] = ((cs * H + r) * W + 4 * j4) * 4;
         }
+    }
+
+    // inside the image?  (gy, gx / 4) = (r, j4) + (gy0, gx0 / 4) as two 16-bit lanes; inside iff both are below
+    // (H, W / 4) as UNSIGNED numbers (a negative coordinate wraps to a large one).  Three vector instructions.
+    __device__ __forceinline__ bool inside(int p, int H, int W, int gy0, int gx0) const
+    {
+        const dm_u16x2 org = {(unsigned short)gy0, (unsigned short)(gx0 >> 2)};
+        const dm_u16x2 lim = {(unsigned short)(H - 1), (unsigned short)((W >> 2) - 1)};
+        const dm_u16x2 pos = __builtin_bit_cast(dm_u16x2, rj[p]) + org;
+        const dm_u16x2 cl = __builtin_elementwise_min(pos, lim);
+        return __builtin_bit_cast(int, cl) == __builtin_bit_cast(int, pos);
     }
 
     // ---- one element at a time, through buffer descriptors -------------------------------------------------
@@ -60,11 +93,10 @@ struct TileStage {
     // at the issue point until earlier requests return (measured: 24-38 % of a wave's time in the conv and
     // weight-gradient kernels).  begin() prepares the tile's descriptors, issue_one(k) requests element k; the
     // kernels call it between the MFMA steps of the current tile so the requests trickle out under the matrix
-    // work.  Elements outside the image (and every element when there is no next tile: empty descriptor) carry
-    // an out-of-range offset -> the load returns 0 without a branch, which is exactly the zero padding.
+    // work.
     struct Ctx {
         __amdgpu_buffer_rsrc_t r0, r1;
-        int H, W, Cphys, gy0, gx0;
+        unsigned voff[P];
     };
     __device__ __forceinline__ Ctx begin(const Operand &op, bool live, int b, int Cphys, int H, int W, int gy0, int gx0) const
     {
@@ -74,89 +106,96 @@ struct TileStage {
         cx.r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(op.p0 + se * b), 0, bytes, 0x00020000);
         cx.r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((TWO && op.p1 ? op.p1 : op.p0) + se * b), 0,
                                                   (TWO && op.p1) ? bytes : 0, 0x00020000);
-        cx.H = H; cx.W = W; cx.Cphys = Cphys; cx.gy0 = gy0; cx.gx0 = gx0;
+        const int org = (gy0 * W + gx0) * 4;               // (uniform; may be negative: only used where inside)
+#pragma unroll
+        for (int p = 0; p < P; ++p) cx.voff[p] = inside(p, H, W, gy0, gx0) ? (unsigned)(goff[p] + org) : OOB;
         return cx;
     }
     __device__ __forceinline__ void issue_one(int k, const Ctx &cx)
     {
-        const int mt = meta[k];
-        const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63, c = (mt >> 26) & 63;
-        const int gy = cx.gy0 + r, gx = cx.gx0 + 4 * j4;
-        const bool ok = mt >= 0 && c < cx.Cphys && (unsigned)gy < (unsigned)cx.H && (unsigned)gx < (unsigned)cx.W;
-        const int voff = ok ? ((c * cx.H + gy) * cx.W + gx) * 4 : 0x7ffffff0;
-        v[k] = __builtin_amdgcn_raw_buffer_load_b128(cx.r0, voff, 0, 0);
-        if (TWO) u[k] = __builtin_amdgcn_raw_buffer_load_b128(cx.r1, voff, 0, 0);
+        const int p = k % P, step = k / P;
+        // channels past Cphys (the synthetic ones channel, the unused tail of the last channel step) land past the
+        // descriptor's range like everything else that must read as 0
+        const unsigned vo = cx.voff[p] + (unsigned)(step * G) * (unsigned)HW4;
+        v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cx.r0, (int)vo, 0, 0));
+        if (TWO) u[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cx.r1, (int)vo, 0, 0));
     }
 
+    // all of a tile's loads back to back (the first tile of a workgroup: nothing to hide them under)
     __device__ __forceinline__ void issue(const Operand &op, int b, int Cphys, int H, int W, int gy0, int gx0)
     {
-        // tensors stay below 2^31 elements (checked on the host): 32-bit element offsets
-        const int base = ((b * Cphys) * H + gy0) * W + gx0;
+        const Ctx cx = begin(op, true, b, Cphys, H, W, gy0, gx0);
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int mt = meta[k];
-            const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63, c = (mt >> 26) & 63;
-            const int gy = gy0 + r, gx = gx0 + 4 * j4;
-            const bool ok = mt >= 0 && c < Cphys && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const int off = base + (c * H + r) * W + 4 * j4;
-            v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ok) v[k] = *reinterpret_cast<const f32x4 *>(op.p0 + off);
-            if (TWO) {
-                u[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok && op.p1) u[k] = *reinterpret_cast<const f32x4 *>(op.p1 + off);   // p1 == NULL: not AFFINE2
+        for (int k = 0; k < N; ++k) issue_one(k, cx);
+    }
+
+    // mode: the operand's load mode (workgroup uniform).  IDENT tiles skip the transform altogether (their padding is
+    // already zero: elements outside the image were read as 0); RELU tiles only clamp; the AFFINE family takes the
+    // per-channel coefficients from the LDS table.
+    // KIND 0: identity, 1: ReLU, 2: the affine family.  ONES: a synthetic ones channel follows the physical channels.
+    // One straight-line body per (KIND, ONES): the mode tests stay out of the element loop, so the coefficient reads
+    // of a pass are requested together and the loop is a single basic block.
+    template <int KIND, bool ONES>
+    __device__ __forceinline__ void commit_as(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
+                                              int H, int W, int gy0, int gx0)
+    {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if ((rj[p] & 0xffff) == 0x7fff) continue;      // no position in this pass (at most the tail of the workgroup)
+            const bool in = inside(p, H, W, gy0, gx0);
+            float *__restrict__ dst = lds + loff[p];
+            const f32x4 *__restrict__ ctab = reinterpret_cast<const f32x4 *>(s_coef) + cs;
+            f32x4 cf[KIND == 2 ? NC : 1];
+            if constexpr (KIND == 2) {
+#pragma unroll
+                for (int step = 0; step < NC; ++step) cf[step] = ctab[step * G];
+            }
+#pragma unroll
+            for (int step = 0; step < NC; ++step) {
+                const int k = step * P + p;
+                f32x4 val = v[k];
+                if constexpr (KIND == 1) {
+                    // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
+                    val.x = val.x < 0.f ? 0.f : val.x; val.y = val.y < 0.f ? 0.f : val.y;
+                    val.z = val.z < 0.f ? 0.f : val.z; val.w = val.w < 0.f ? 0.f : val.w;
+                } else if constexpr (KIND == 2) {
+                    const f32x4 c = cf[step];
+                    // padding: v (and u) are 0 there, so only the shift has to go; relu_floor <= 0 leaves the 0 alone
+                    const float cz = in ? c.z : 0.f;
+                    val = c.x * val + cz;
+                    if (TWO) val += c.y * u[k];
+                    val.x = val.x < c.w ? c.w : val.x; val.y = val.y < c.w ? c.w : val.y;
+                    val.z = val.z < c.w ? c.w : val.z; val.w = val.w < c.w ? c.w : val.w;
+                }
+                if constexpr (ONES) {                      // 1 inside the image, 0 in the padding
+                    const float one = in ? 1.f : 0.f;
+                    if (step * G + cs >= Cphys) val = (f32x4){one, one, one, one};
+                }
+                if (CIN % G != 0 && step == NC - 1) {      // tail of the last channel step
+                    if (cs < CIN - step * G) *reinterpret_cast<f32x4 *>(dst + step * G * PS) = val;
+                } else {
+                    *reinterpret_cast<f32x4 *>(dst + step * G * PS) = val;
+                }
             }
         }
     }
 
     // mode: the operand's load mode (workgroup uniform).  IDENT tiles skip the transform altogether (their padding is
-    // already zero: issue() leaves unloaded elements at 0); RELU tiles only clamp; the AFFINE family takes the
+    // already zero: elements outside the image were read as 0); RELU tiles only clamp; the AFFINE family takes the
     // per-channel coefficients from the LDS table.
     __device__ __forceinline__ void commit(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
                                            int H, int W, int gy0, int gx0, int mode)
     {
-        if (mode == DM_LOAD_IDENT || mode == DM_LOAD_RELU) {
-            const float fl = mode == DM_LOAD_RELU ? 0.f : -__builtin_inff();
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const int mt = meta[k];
-                f32x4 val = v[k];
-                if (mode == DM_LOAD_RELU) {
-                    // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
-                    val.x = val.x < fl ? fl : val.x; val.y = val.y < fl ? fl : val.y;
-                    val.z = val.z < fl ? fl : val.z; val.w = val.w < fl ? fl : val.w;
-                }
-                const int c = (mt >> 26) & 63;
-                if (c >= Cphys) {                          // synthetic ones channel: 1 inside the image, 0 in the padding
-                    const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63;
-                    const int gy = gy0 + r, gx = gx0 + 4 * j4;
-                    const float one = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1.f : 0.f;
-                    val = (f32x4){one, one, one, one};
-                }
-                if (mt >= 0) *reinterpret_cast<f32x4 *>(lds + (mt & 0x3fff)) = val;
-            }
-            return;
-        }
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int mt = meta[k];
-            const int r = (mt >> 14) & 63, j4 = (mt >> 20) & 63, c = (mt >> 26) & 63;
-            const int gy = gy0 + r, gx = gx0 + 4 * j4;
-            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            f32x4 val;
-            if (c < Cphys) {
-                const f32x4 cf = *reinterpret_cast<const f32x4 *>(s_coef + c * 4);
-                // padding: v (and u) are 0 there, so only the shift has to go; relu_floor <= 0 leaves the 0 alone
-                const float cz = inside ? cf.z : 0.f;
-                val = cf.x * v[k] + cz;
-                if (TWO) val += cf.y * u[k];
-                // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
-                val.x = val.x < cf.w ? cf.w : val.x; val.y = val.y < cf.w ? cf.w : val.y;
-                val.z = val.z < cf.w ? cf.w : val.z; val.w = val.w < cf.w ? cf.w : val.w;
-            } else {
-                const float one = inside ? 1.f : 0.f;
-                val = (f32x4){one, one, one, one};
-            }
-            if (mt >= 0) *reinterpret_cast<f32x4 *>(lds + (mt & 0x3fff)) = val;
+        if (CIN > 1 && Cphys < CIN) {                      // (uniform) with a synthetic ones channel: rare, one body
+            if (mode == DM_LOAD_IDENT) commit_as<0, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else if (mode == DM_LOAD_RELU) commit_as<1, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else commit_as<2, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
+        } else if (mode == DM_LOAD_IDENT) {
+            commit_as<0, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
+        } else if (mode == DM_LOAD_RELU) {
+            commit_as<1, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
+        } else {
+            commit_as<2, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
         }
     }
 };

@@ -82,8 +82,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
     // of tile i and written to LDS after it (register staging, single LDS buffer).
     TileStage<CS, TH, TW / 4, RSS, PSS, STWO> stS;
     TileStage<CT, TROWS, TCOLS4, RST, PST, false> stT;
-    stS.init();
-    stT.init();
+    stS.init(Hs, Ws);
+    stT.init(Ht, Wt);
     int tile = blockIdx.x;
     int cb = 0, cy0 = 0, cx0 = 0;
     if (tile < ntiles) {
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_ys_kernel(Operand S, Operand T
 
     TileStage<CS, TH, TW / 4, RSS, PSS, STWO> stS;
     TileStage<CT, TROWS, TCOLS4, RST, PST, false> stT;
-    stS.init();
-    stT.init();
+    stS.init(Hs, Ws);
+    stT.init(Ht, Wt);
     int tile = blockIdx.x;
     int cb = 0, cy0 = 0, cx0 = 0;
     if (tile < ntiles) {
