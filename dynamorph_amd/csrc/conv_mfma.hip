@@ -289,7 +289,9 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
         }
         // the next tile's loads are requested element by element between the M tiles below (tile.h: issue_one)
         const auto scx = stage.begin(in, next < ntiles, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
-        if (next < ntiles) stage_coef(s_coef, in, b, Cphys);
+        const bool recoef = next < ntiles && coef_changes(in, cb, b);       // (uniform) the next tile is another sample's
+        f32x4 cfn = {1.f, 0.f, 0.f, 0.f};
+        if (recoef) cfn = coef_fetch(in, b, Cphys);
         if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) mask_coef(ep, cb, 16 * t + m < NOUT ? 16 * t + m : 0, mc0[t], mc2[t]);
@@ -351,6 +353,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
 #pragma unroll
             for (int t = 0; t < NT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
         }
+        if (recoef) coef_put(s_coef, in, cfn, Cphys);   // visible after the barrier at the loop top
         tidx = next;
     }
     CS_FLUSH
@@ -464,7 +467,9 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
             }
             // the next tile's loads are requested element by element between the M tiles below (tile.h: issue_one)
             const auto scx = stage.begin(in, next < ntiles, b, Cphys, H, W, y0 - PADR, x0 - 4 * PADR);
-            if (next < ntiles) stage_coef(s_coef, in, b, Cphys);
+            const bool recoef = next < ntiles && coef_changes(in, cb, b);   // (uniform) the next tile is another sample's
+            f32x4 cfn = {1.f, 0.f, 0.f, 0.f};
+            if (recoef) cfn = coef_fetch(in, b, Cphys);
             if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -520,6 +525,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
 #pragma unroll
                 for (int t = 0; t < NTT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
             }
+            if (recoef) coef_put(s_coef, in, cfn, Cphys);   // visible after the barrier at the loop top
             tidx = next;
         }
     }
@@ -614,7 +620,9 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
             y0 = (t % tiles_y) * TH; b = t / tiles_y;
         }
         const auto scx = stage.begin(in, next < ntiles, b, Cphys, H, W, y0 - 1, x0 - 4);
-        if (next < ntiles) stage_coef(s_coef, in, b, Cphys);
+        const bool recoef = next < ntiles && coef_changes(in, cb, b);       // (uniform) the next tile is another sample's
+        f32x4 cfn = {1.f, 0.f, 0.f, 0.f};
+        if (recoef) cfn = coef_fetch(in, b, Cphys);
         if (SIDE != SIDE_NONE && ep.mask.p0 && ep.mask.coef_bstride) mask_coef(ep, cb, co, mc0, mc2);
         cx.rebase(ep, out, sample_elems, cb);
         constexpr int NP = MTW / MP, NE = decltype(stage)::N;
@@ -667,6 +675,7 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
                 }
             }
         }
+        if (recoef) coef_put(s_coef, in, cfn, Cphys);   // visible after the barrier at the loop top
         tidx = next;
     }
     if (ep.stats) {

@@ -26,19 +26,35 @@
 constexpr int DM_COEF_MAX_C = 64;
 
 // LDS coefficient table [C][4] = (c0, c1, c2, relu_floor) for sample b.  relu_floor = 0 (ReLU) or -inf.
-__device__ __forceinline__ void stage_coef(float *__restrict__ s_coef, const Operand &op, int b, int C)
+// Two halves, so a persistent kernel can request the next sample's row right after a tile is committed and write it
+// into LDS at the end of the tile (the load's latency would otherwise sit between two barriers, once per tile):
+//   coef_fetch: the global load of this thread's row (threads < C), nothing waits on it;
+//   coef_put:   the row into the table.
+// coef_changes: whether the table staged for sample cb is stale for sample nb (per-sample coefficients only: batch
+// statistics, the training case, are staged once per workgroup).
+__device__ __forceinline__ bool coef_changes(const Operand &op, int cb, int nb)
+{
+    return op.mode >= DM_LOAD_AFFINE && op.coef_bstride != 0 && nb != cb;
+}
+__device__ __forceinline__ f32x4 coef_fetch(const Operand &op, int b, int C)
+{
+    f32x4 raw = {1.f, 0.f, 0.f, 0.f};
+    if ((int)threadIdx.x < C && op.mode >= DM_LOAD_AFFINE)
+        raw = *reinterpret_cast<const f32x4 *>(op.coef + (long long)b * op.coef_bstride + threadIdx.x * 4);
+    return raw;
+}
+__device__ __forceinline__ void coef_put(float *__restrict__ s_coef, const Operand &op, f32x4 raw, int C)
 {
     const int c = threadIdx.x;
     if (c < C) {
-        float c0 = 1.f, c1 = 0.f, c2 = 0.f;
-        if (op.mode >= DM_LOAD_AFFINE) {
-            const float *cf = op.coef + (long long)b * op.coef_bstride + c * 4;
-            c0 = cf[0]; c2 = cf[2];
-            if (op.mode == DM_LOAD_AFFINE2) c1 = cf[1];
-        }
+        const float c1 = op.mode == DM_LOAD_AFFINE2 ? raw.y : 0.f;
         const bool relu = op.mode == DM_LOAD_RELU || op.mode == DM_LOAD_AFFINE_RELU;
-        *reinterpret_cast<f32x4 *>(s_coef + c * 4) = (f32x4){c0, c1, c2, relu ? 0.f : -__builtin_inff()};
+        *reinterpret_cast<f32x4 *>(s_coef + c * 4) = (f32x4){raw.x, c1, raw.z, relu ? 0.f : -__builtin_inff()};
     }
+}
+__device__ __forceinline__ void stage_coef(float *__restrict__ s_coef, const Operand &op, int b, int C)
+{
+    coef_put(s_coef, op, coef_fetch(op, b, C), C);
 }
 
 typedef unsigned short dm_u16x2 __attribute__((ext_vector_type(2)));

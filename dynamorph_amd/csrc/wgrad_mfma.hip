@@ -101,6 +101,7 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
         stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD, T.mode);
         __syncthreads();
         const int next = tile + gridDim.x;
+        const int pb = cb;                               // sample of the tile now in LDS
         {
             int tid = next < ntiles ? next : tile;       // (no next tile: empty descriptors, every load returns 0)
             const int tx = tid % tiles_x; tid /= tiles_x;
@@ -109,10 +110,11 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
         // the next tile's loads are requested element by element between the MFMA steps below (tile.h: issue_one)
         const auto cxS = stS.begin(S, next < ntiles, cb, CS, Hs, Ws, cy0, cx0);
         const auto cxT = stT.begin(T, next < ntiles, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
-        if (next < ntiles) {
-            stage_coef(s_coefS, S, cb, CS);
-            stage_coef(s_coefT, T, cb, CTphys);
-        }
+        // per-sample coefficient tables: the next sample's rows are requested now and written at the end of the tile
+        const bool recoefS = next < ntiles && coef_changes(S, pb, cb), recoefT = next < ntiles && coef_changes(T, pb, cb);
+        f32x4 cfS = {1.f, 0.f, 0.f, 0.f}, cfT = {1.f, 0.f, 0.f, 0.f};
+        if (recoefS) cfS = coef_fetch(S, cb, CS);
+        if (recoefT) cfT = coef_fetch(T, cb, CTphys);
         constexpr int NES = decltype(stS)::N, NET = decltype(stT)::N, NE = NES + NET;
         constexpr int ROWS_W = TH / 4, NSTEPS = ROWS_W * (TW / 4);
 #pragma unroll
@@ -153,6 +155,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (recoefS) coef_put(s_coefS, S, cfS, CS);
+        if (recoefT) coef_put(s_coefT, T, cfT, CTphys);
         tile = next;
     }
 
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_ys_kernel(Operand S, Operand T
         stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD, T.mode);
         __syncthreads();
         const int next = tile + gridDim.x;
+        const int pb = cb;                               // sample of the tile now in LDS
         {
             int tid = next < ntiles ? next : tile;       // (no next tile: empty descriptors, every load returns 0)
             const int tx = tid % tiles_x; tid /= tiles_x;
@@ -252,10 +257,11 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_ys_kernel(Operand S, Operand T
         }
         const auto cxS = stS.begin(S, next < ntiles, cb, CS, Hs, Ws, cy0, cx0);
         const auto cxT = stT.begin(T, next < ntiles, cb, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD);
-        if (next < ntiles) {
-            stage_coef(s_coefS, S, cb, CS);
-            stage_coef(s_coefT, T, cb, CTphys);
-        }
+        // per-sample coefficient tables: the next sample's rows are requested now and written at the end of the tile
+        const bool recoefS = next < ntiles && coef_changes(S, pb, cb), recoefT = next < ntiles && coef_changes(T, pb, cb);
+        f32x4 cfS = {1.f, 0.f, 0.f, 0.f}, cfT = {1.f, 0.f, 0.f, 0.f};
+        if (recoefS) cfS = coef_fetch(S, cb, CS);
+        if (recoefT) cfT = coef_fetch(T, cb, CTphys);
         constexpr int NES = decltype(stS)::N, NET = decltype(stT)::N, NE = NES + NET;
         constexpr int NSTEPS = (TH + 1) * XW;
         // position rows Y = 0 .. TH; operands of step s+1 are requested before the MFMAs of step s
@@ -287,6 +293,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_ys_kernel(Operand S, Operand T
             for (int t = 0; t < NTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s & 1][t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (recoefS) coef_put(s_coefS, S, cfS, CS);
+        if (recoefT) coef_put(s_coefT, T, cfT, CTphys);
         tile = next;
     }
 
