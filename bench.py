@@ -156,8 +156,8 @@ def north_star_targets(model, x):
                    34 816 algorithmic bytes per patch / average launch of the distance kernel alone
                    (dm_vq_forward_repeat: T(21 launches) - T(1 launch), prepared codebook); `call_ms` is the whole
                    dm_vq_forward (codebook preparation + that kernel + counter reduction) as the step pays it;
-      enc_convs -- every forward convolution of the encoder: useful FLOPs (2 x MACs of SURVEY 2.2) / average launch,
-                   against the f32 MFMA peak."""
+      enc_convs -- every forward convolution of the encoder: useful FLOPs (2 x MACs of SURVEY 2.2) / average launch
+                   (inside a HIP graph of 10 launches, as the step replays them), against the f32 MFMA peak."""
     from dynamorph_amd import engine as E
     from dynamorph_amd import ops
     from dynamorph_amd.ops import DM_LOAD_AFFINE_RELU, DM_LOAD_RELU, Op, weight_view
@@ -196,8 +196,23 @@ def north_star_targets(model, x):
     weff, border = ops.e1_compose_border(w(L.enc0.weight), w(L.enc0.bias), w(L.enc1.weight), w(L.enc1.bias))
     convs = []
 
+    def graph_time_ms(fn, launches=10):
+        """Average duration of one launch inside a HIP graph of `launches` back-to-back launches -- how the step runs
+        them (host launch gaps of eager back-to-back calls are not part of the step)."""
+        fn()
+        gg = torch.cuda.CUDAGraph()
+        sd = torch.cuda.Stream()
+        sd.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sd):
+            fn()
+        torch.cuda.current_stream().wait_stream(sd)
+        with torch.cuda.graph(gg):
+            for _ in range(launches):
+                fn()
+        return event_time_ms(gg.replay, iters=10, warmup=2) / launches
+
     def add(name, macs_per_patch, fn, note=None):
-        ms = event_time_ms(fn, iters=20, warmup=3)
+        ms = graph_time_ms(fn)
         fl = 2.0 * macs_per_patch * B
         rec = {"layer": name, "flops": fl, "avg_launch_ms": round(ms, 5),
                "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}

@@ -148,7 +148,8 @@ struct TileStage {
     // mode: the operand's load mode (workgroup uniform).  IDENT tiles skip the transform altogether (their padding is
     // already zero: elements outside the image were read as 0); RELU tiles only clamp; the AFFINE family takes the
     // per-channel coefficients from the LDS table.
-    // KIND 0: identity, 1: ReLU, 2: the affine family.  ONES: a synthetic ones channel follows the physical channels.
+    // KIND 0: identity, 1: ReLU, 2: affine (AFFINE, AFFINE2), 3: affine + ReLU.  ONES: a synthetic ones channel follows
+    // the physical channels.
     // One straight-line body per (KIND, ONES): the mode tests stay out of the element loop, so the coefficient reads
     // of a pass are requested together and the loop is a single basic block.
     template <int KIND, bool ONES>
@@ -161,8 +162,8 @@ struct TileStage {
             const bool in = inside(p, H, W, gy0, gx0);
             float *__restrict__ dst = lds + loff[p];
             const f32x4 *__restrict__ ctab = reinterpret_cast<const f32x4 *>(s_coef) + cs;
-            f32x4 cf[KIND == 2 ? NC : 1];
-            if constexpr (KIND == 2) {
+            f32x4 cf[KIND >= 2 ? NC : 1];
+            if constexpr (KIND >= 2) {
 #pragma unroll
                 for (int step = 0; step < NC; ++step) cf[step] = ctab[step * G];
             }
@@ -174,14 +175,16 @@ struct TileStage {
                     // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
                     val.x = val.x < 0.f ? 0.f : val.x; val.y = val.y < 0.f ? 0.f : val.y;
                     val.z = val.z < 0.f ? 0.f : val.z; val.w = val.w < 0.f ? 0.f : val.w;
-                } else if constexpr (KIND == 2) {
+                } else if constexpr (KIND >= 2) {
                     const f32x4 c = cf[step];
-                    // padding: v (and u) are 0 there, so only the shift has to go; relu_floor <= 0 leaves the 0 alone
+                    // padding: v (and u) are 0 there, so only the shift has to go; the ReLU leaves that 0 alone
                     const float cz = in ? c.z : 0.f;
                     val = c.x * val + cz;
                     if (TWO) val += c.y * u[k];
-                    val.x = val.x < c.w ? c.w : val.x; val.y = val.y < c.w ? c.w : val.y;
-                    val.z = val.z < c.w ? c.w : val.z; val.w = val.w < c.w ? c.w : val.w;
+                    if constexpr (KIND == 3) {
+                        val.x = val.x < 0.f ? 0.f : val.x; val.y = val.y < 0.f ? 0.f : val.y;
+                        val.z = val.z < 0.f ? 0.f : val.z; val.w = val.w < 0.f ? 0.f : val.w;
+                    }
                 }
                 if constexpr (ONES) {                      // 1 inside the image, 0 in the padding
                     const float one = in ? 1.f : 0.f;
@@ -205,11 +208,14 @@ struct TileStage {
         if (CIN > 1 && Cphys < CIN) {                      // (uniform) with a synthetic ones channel: rare, one body
             if (mode == DM_LOAD_IDENT) commit_as<0, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
             else if (mode == DM_LOAD_RELU) commit_as<1, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else if (mode == DM_LOAD_AFFINE_RELU) commit_as<3, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
             else commit_as<2, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_IDENT) {
             commit_as<0, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_RELU) {
             commit_as<1, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
+        } else if (mode == DM_LOAD_AFFINE_RELU) {
+            commit_as<3, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else {
             commit_as<2, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
         }
