@@ -180,33 +180,6 @@ __device__ __forceinline__ void zero_unowned_slabs(const Epilogue &ep, int NCH, 
         for (int i = threadIdx.x; i < NCH * 2; i += DM_BLOCK) ep.stats[(long long)t2 * NCH * 2 + i] = 0.0;
 }
 
-// Diagnostic build only (make stamps): s_memtime at the phase boundaries of the persistent tile loop, per-wave sums
-// added into a device array read back by dm_conv_stamps_read (tools/exp/conv_stamps.py).  The shipped library has none.
-#ifdef DM_CONV_STAMPS
-__device__ unsigned long long dm_conv_stamp_acc[8];
-#define CS_INIT                                                                                           \
-    unsigned long long cs_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs_prev;                                     \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cs_prev)::"memory");
-#define CS(i)                                                                                             \
-    {                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        unsigned long long t_;                                                                            \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        cs_sum[i] += t_ - cs_prev;                                                                        \
-        cs_prev = t_;                                                                                     \
-    }
-#define CS_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#define CS_FLUSH                                                                                          \
-    if ((threadIdx.x & 63) == 0)                                                                          \
-        for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&dm_conv_stamp_acc[i_], cs_sum[i_]);
-#else
-#define CS_INIT
-#define CS(i)
-#define CS_WAIT_VM
-#define CS_FLUSH
-#endif
-
 // ============================================================================ kernel A
 // BB: per-position bias from ep.bias_border[3][3][NOUT] (first / interior / last output row x column) instead of
 // ep.bias -- the enc.0 bias seen through enc.1's zero padding, so the first conv needs no ones channel (K = 32, not 48).
@@ -268,18 +241,10 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
     int chan_off[NT];                                      // byte offset of the lane's channel plane (+ its x quad)
 #pragma unroll
     for (int t = 0; t < NT; ++t) chan_off[t] = 16 * t + m < NOUT ? ((16 * t + m) * Ho * Wo + 4 * kq) * 4 : DM_VOFF_NONE;
-
-    CS_INIT
     while (tidx < ntiles) {
-        CS(7)
         __syncthreads();                                   // previous tile consumed; coefficient table visible
-        CS(0)
-        CS_WAIT_VM
-        CS(1)
         stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4, in.mode);
-        CS(2)
         __syncthreads();
-        CS(3)
         const int cb = b, cy0 = oy0, cx0 = ox0;            // the tile now in LDS
         const int next = tidx + gridDim.x;
         {                                                  // (no next tile: empty descriptor, every load returns 0)
@@ -322,9 +287,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
             for (int i = 0; i < MP; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            CS(4)
             mfma_tiles<MP, NT, KS, 4>(ap, wreg, acc, off);
-            CS(5)
 #pragma unroll
             for (int i = 0; i < MP; ++i)
 #pragma unroll
@@ -346,7 +309,6 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
                     }
                     epilogue_tail<SIDE>(v, ep, cx, e[i][t], mc0[t], mc2[t], o[i][t], s1[t], s2[t]);
                 }
-            CS(6)
         }
         if (per_tile && ep.stats) {                         // per-sample BatchNorm statistics: one slab per TILE
             stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT, tidx);
@@ -356,7 +318,6 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
         if (recoef) coef_put(s_coef, in, cfn, Cphys);   // visible after the barrier at the loop top
         tidx = next;
     }
-    CS_FLUSH
     if (ep.stats && !per_tile) {
         stats_reduce<NT, false>(s1, s2, s_stat, ep, NOUT, blockIdx.x);
         zero_unowned_slabs(ep, NOUT, nslabs);
@@ -1017,15 +978,3 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
         dm_generic_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps, nslabs, a.per_tile, a.stream);
     return dm_launch_status("dm_conv3x3");
 }
-
-#ifdef DM_CONV_STAMPS
-extern "C" int dm_conv_stamps_read(unsigned long long *out8, int reset)
-{
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(dm_conv_stamp_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(dm_conv_stamp_acc), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
