@@ -34,7 +34,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["c3", "c2", "z32ex"], default="c3")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 2048 for c3, 1024 for c2, 256 for z32ex)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
