@@ -211,11 +211,23 @@ def north_star_targets(model, x):
                 fn()
         return event_time_ms(gg.replay, iters=10, warmup=2) / launches
 
-    def add(name, macs_per_patch, fn, note=None):
+    # rocprof's own MFMA-busy share of the same kernels inside the step (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles a wave
+    # is resident; separate --pmc passes summarised in profiles/ by tools/sqprof.sh -- bench.py cannot run under the profiler)
+    sq = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_c3_b2048_sq_counters.json")) as f:
+            sq = json.load(f).get("kernels", {}) if B == 2048 else {}
+    except (OSError, ValueError):
+        sq = {}
+
+    def add(name, macs_per_patch, fn, note=None, kernel=None):
         ms = graph_time_ms(fn)
         fl = 2.0 * macs_per_patch * B
         rec = {"layer": name, "flops": fl, "avg_launch_ms": round(ms, 5),
                "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+        if kernel and kernel in sq:
+            rec["kernel"] = kernel
+            rec["mfma_busy_pmc"] = round(sq[kernel]["mfma_busy_pct_of_wave_cycles"] / 100.0, 3)
         if note:
             rec["note"] = note
         convs.append(rec)
@@ -225,30 +237,42 @@ def north_star_targets(model, x):
     add("enc.0+enc.1 (composite 4x4/s2, 2->8)", H1 * W1 * 16 * NIN * c1,
         lambda: ops.conv4x4s2(Op(x), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN, c1, H, W, out=a1, want_stats=True,
                               bias_border=border),
-        note="HBM bound: reads x and writes a1, 262 144 B per patch; the reference's two layers would be 4 456 448 MACs per patch")
+        note="HBM bound: reads x and writes a1, 262 144 B per patch; the reference's two layers would be 4 456 448 MACs per patch",
+        kernel="conv4x4s2_kernel<2, 1, 8, 64, 0, 3, true>")
     add("enc.4 (4x4/s2, 8->16)", 2097152,
         lambda: ops.conv4x4s2(Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), weight_view(w(L.enc4.weight), c1 * 16, 16, 4, 1), B, c1, nh,
-                              H1, W1, out=a2, want_stats=True, bias=w(L.enc4.bias)))
+                              H1, W1, out=a2, want_stats=True, bias=w(L.enc4.bias)),
+        kernel="conv4x4s2_kernel<8, 1, 8, 32, 0, 2, false>")
     add("enc.7 (4x4/s2, 16->16)", 1048576,
         lambda: ops.conv4x4s2(Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), weight_view(w(L.enc7.weight), nh * 16, 16, 4, 1), B, nh, nh,
-                              H2, W2, out=a3, want_stats=True, bias=w(L.enc7.bias)))
+                              H2, W2, out=a3, want_stats=True, bias=w(L.enc7.bias)),
+        kernel="conv4x4s2_kernel<16, 1, 8, 16, 0, 2, false>")
     add("enc.10 (3x3, 16->16)", 589824,
         lambda: ops.conv3x3(Op(cx.a3, DM_LOAD_AFFINE_RELU, cx.coef3), weight_view(w(L.enc10.weight), nh * 9, 9, 3, 1), B, nh, nh,
-                            H3, W3, taps=9, out=a4, want_stats=True, bias=w(L.enc10.bias)))
+                            H3, W3, taps=9, out=a4, want_stats=True, bias=w(L.enc10.bias)),
+        kernel="conv3x3_kernel<16, 1, 1, 9, false, 16, 16, false, 0, 3>")
     sv = cx.res[0]
     ca, bna, cb2, bnb = L.res[0]
     ra = torch.empty_like(sv.ra); rb = torch.empty_like(sv.rb)
     add("enc.12 residual 3x3 (16->32), each of 2", 1179648,
         lambda: ops.conv3x3(Op(sv.h_in, DM_LOAD_RELU), weight_view(w(ca.weight), nh * 9, 9, 3, 1), B, nh, nrh, H3, W3, taps=9,
-                            out=ra, want_stats=True, bias=w(ca.bias)))
+                            out=ra, want_stats=True, bias=w(ca.bias)),
+        kernel="conv3x3_kernel<16, 2, 1, 9, false, 16, 16, false, 0, 2>")
     add("enc.12 residual 1x1 (32->16), each of 2", 131072,
         lambda: ops.conv3x3(Op(sv.ra, DM_LOAD_AFFINE_RELU, sv.coefa), weight_view(w(cb2.weight), nrh, 1, 0, 0), B, nrh, nh, H3, W3,
-                            taps=1, out=rb, want_stats=True, bias=w(cb2.bias)))
+                            taps=1, out=rb, want_stats=True, bias=w(cb2.bias)),
+        kernel="conv3x3_kernel<32, 1, 1, 1, false, 8, 16, false, 0, 3>", note="HBM bound: 49 152 B per patch")
     tot_fl = sum(c["flops"] * (2 if "each of 2" in c["layer"] else 1) for c in convs)
     tot_ms = sum(c["avg_launch_ms"] * (2 if "each of 2" in c["layer"] else 1) for c in convs)
-    return {"vq": vq, "enc_convs": convs,
-            "enc_convs_total": {"flops": tot_fl, "ms": round(tot_ms, 5),
-                                "frac_mfma": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}}
+    total = {"flops": tot_fl, "ms": round(tot_ms, 5),
+             "frac_mfma": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+    if all("mfma_busy_pmc" in c for c in convs):
+        wsum = sum(c["mfma_busy_pmc"] * c["avg_launch_ms"] * (2 if "each of 2" in c["layer"] else 1) for c in convs)
+        total["mfma_busy_pmc"] = round(wsum / tot_ms, 3)       # time-weighted
+        total["note"] = ("frac_mfma = executed FLOPs / launch time / 157.3 TFLOP/s (clock- and prologue-inclusive); mfma_busy_pmc = "
+                         "rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / resident wave cycles of the same kernels in the step "
+                         "(profiles/r02_c3_b2048_sq_counters.txt)")
+    return {"vq": vq, "enc_convs": convs, "enc_convs_total": total}
 
 
 def c2_record(model, steps=20, warmup=3, B=1024):

@@ -10,4 +10,4 @@ cd /tmp
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $root/gpurun_out/${tag}_sqA -- "$@" > $root/gpurun_out/${tag}_sqA.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $root/gpurun_out/${tag}_sqB -- "$@" > $root/gpurun_out/${tag}_sqB.log 2>&1
 cd $root
-python3 tools/sq_summary.py gpurun_out/${tag}_sqA gpurun_out/${tag}_sqB | tee gpurun_out/${tag}_sq.txt
+python3 tools/sq_summary.py gpurun_out/${tag}_sqA gpurun_out/${tag}_sqB gpurun_out/${tag}_sq.json | tee gpurun_out/${tag}_sq.txt
