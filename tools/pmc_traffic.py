@@ -20,6 +20,7 @@ KEYS = {                       # key in the JSON -> substring of the kernel name
     "dec_tail_forward": "dec_tail_forward_kernel",
     "conv4x4s2_e1": "conv4x4s2_kernel",
     "vq_forward_mfma": "vq_forward_mfma_kernel",
+    "vq_backward_mfma": "vq_backward_mfma_kernel",
     "copy_calib": "elementwise_kernel",
 }
 
