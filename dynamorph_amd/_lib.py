@@ -39,6 +39,11 @@ class ReduceSeg(C.Structure):
     _fields_ = [("slabs", vp), ("dst", vp), ("nslabs", i32), ("E", i32)]
 
 
+class ReplaySeg(C.Structure):
+    _fields_ = [("stats", vp), ("nslabs", i32), ("slabs_per_group", i32), ("C", i32), ("count_per_group", i64),
+                ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp), ("momentum", f32)]
+
+
 OP, WV, EP = C.POINTER(Operand), C.POINTER(WeightView), C.POINTER(Epilogue)
 
 # name -> (restype, argtypes); every symbol include/dynamorph_hip.h declares
@@ -71,6 +76,7 @@ SIGNATURES = {
     "dm_sum_slabs": (C.c_int, [vp, C.c_int, C.c_int, f32, vp, vp]),
     "dm_sum_slabs_scatter": (C.c_int, [vp, C.c_int, C.c_int, f32, C.POINTER(Scatter), vp]),
     "dm_reduce_slabs_multi": (C.c_int, [C.POINTER(ReduceSeg), C.c_int, vp]),
+    "dm_bn_running_replay": (C.c_int, [C.POINTER(ReplaySeg), C.c_int, vp]),
     "dm_head_supported": (C.c_int, [C.c_int] * 2),
     "dm_head_num_blocks": (C.c_int, [C.c_int] * 3),
     "dm_head_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),

@@ -69,6 +69,64 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     }
 }
 
+// Running statistics of channel c after B successive batch-of-one calls (one workgroup; see the closed form below).
+__device__ __forceinline__ void running_replay_channel(const double *__restrict__ stats, int B, int spg, int C, long long count, int c,
+                                                       float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                       long long *__restrict__ nbt, float momentum, double *s_red)
+{
+    const double n = (double)count;
+    const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
+    const bool track = running_mean && running_var;
+    const double m = (double)momentum, keep = 1.0 - m;
+    double sm = 0.0, sv = 0.0;
+    if (track) {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = 0; i < spg; ++i) {
+                s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
+                s2 += stats[((long long)(b * spg + i) * C + c) * 2 + 1];
+            }
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double w = m * pow(keep, (double)(B - 1 - b));
+            sm += w * (double)(float)mean;                       // the fp32 values a batch-of-one call would feed
+            sv += w * (double)(float)(var * unbias);
+        }
+    }
+    const double tm = block_sum(sm, s_red);
+    const double tv = block_sum(sv, s_red);
+    if (threadIdx.x == 0) {
+        if (track) {
+            const double k = pow(keep, (double)B);
+            running_mean[c] = (float)(k * (double)running_mean[c] + tm);
+            running_var[c] = (float)(k * (double)running_var[c] + tv);
+        }
+        if (nbt && c == 0) nbt[0] += B;
+    }
+}
+
+// The same replay for several BatchNorm layers in ONE launch (dm_bn_running_replay): the per-sample inference path
+// (process_VAE) needs the coefficients of a layer before the next convolution, but its running statistics only as
+// state -- they are taken off the critical path and brought up to date together at the end of the encoder.
+struct ReplaySegs {
+    const double *stats[16];
+    float *running_mean[16], *running_var[16];
+    long long *nbt[16];
+    long long count[16];
+    int B[16], spg[16], C[16], first_block[17];
+    float momentum[16];
+    int nseg;
+};
+__global__ __launch_bounds__(256) void bn_running_replay_kernel(ReplaySegs rs)
+{
+    __shared__ double s_red[4];
+    int k = 0;
+    while (k + 1 < rs.nseg && (int)blockIdx.x >= rs.first_block[k + 1]) ++k;
+    running_replay_channel(rs.stats[k], rs.B[k], rs.spg[k], rs.C[k], rs.count[k], blockIdx.x - rs.first_block[k],
+                           rs.running_mean[k], rs.running_var[k], rs.nbt[k], rs.momentum[k], s_red);
+}
+
 // Per-sample mode (process_VAE: every patch is its own batch), ONE launch:
 //   blocks [0, nb): one thread per (sample, channel) sums that sample's slabs_per_group slabs and writes its coefficients;
 //   blocks [nb, nb + C): channel c = blockIdx - nb replays the running statistics of B successive batch-of-one calls.
@@ -81,38 +139,9 @@ __global__ __launch_bounds__(256) void bn_finalize_per_sample_kernel(
     float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt, float momentum)
 {
     const double n = (double)count;
-    const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
     if ((int)blockIdx.x >= nb) {
         __shared__ double s_red[4];
-        const int c = blockIdx.x - nb;
-        const bool track = running_mean && running_var;
-        const double m = (double)momentum, keep = 1.0 - m;
-        double sm = 0.0, sv = 0.0;
-        if (track) {
-            for (int b = threadIdx.x; b < B; b += blockDim.x) {
-                double s1 = 0.0, s2 = 0.0;
-                for (int i = 0; i < spg; ++i) {
-                    s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
-                    s2 += stats[((long long)(b * spg + i) * C + c) * 2 + 1];
-                }
-                const double mean = s1 / n;
-                double var = s2 / n - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const double w = m * pow(keep, (double)(B - 1 - b));
-                sm += w * (double)(float)mean;                       // the fp32 values a batch-of-one call would feed
-                sv += w * (double)(float)(var * unbias);
-            }
-        }
-        const double tm = block_sum(sm, s_red);
-        const double tv = block_sum(sv, s_red);
-        if (threadIdx.x == 0) {
-            if (track) {
-                const double k = pow(keep, (double)B);
-                running_mean[c] = (float)(k * (double)running_mean[c] + tm);
-                running_var[c] = (float)(k * (double)running_var[c] + tv);
-            }
-            if (nbt && c == 0) nbt[0] += B;
-        }
+        running_replay_channel(stats, B, spg, C, count, blockIdx.x - nb, running_mean, running_var, nbt, momentum, s_red);
         return;
     }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,7 +288,9 @@ extern "C" int dm_bn_finalize(const double *stats, int nslabs, int slabs_per_gro
         const int B = nslabs / slabs_per_group;
         DM_REQUIRE((long long)B * C < (1LL << 30), "dm_bn_finalize: too many (sample, channel) pairs");
         const int nb = (B * C + 255) / 256;
-        hipLaunchKernelGGL(bn_finalize_per_sample_kernel, dim3(nb + C), dim3(256), 0, (hipStream_t)stream, stats, B,
+        // (no running statistics and no counter given: the caller replays them later, dm_bn_running_replay)
+        const int rb = (running_mean && running_var) || num_batches_tracked ? C : 0;
+        hipLaunchKernelGGL(bn_finalize_per_sample_kernel, dim3(nb + rb), dim3(256), 0, (hipStream_t)stream, stats, B,
                            slabs_per_group, C, (long long)count_per_group, gamma, beta, eps, coef, saved, nb, running_mean,
                            running_var, (long long *)num_batches_tracked, momentum);
         return dm_launch_status("dm_bn_finalize");
@@ -268,6 +299,32 @@ extern "C" int dm_bn_finalize(const double *stats, int nslabs, int slabs_per_gro
                        (long long)count_per_group, gamma, beta, running_mean, running_var,
                        (long long *)num_batches_tracked, momentum, eps, coef, saved);
     return dm_launch_status("dm_bn_finalize");
+}
+
+extern "C" int dm_bn_running_replay(const dm_bn_replay_seg *segs, int nseg, void *stream)
+{
+    DM_REQUIRE(segs && nseg >= 1 && nseg <= 16, "dm_bn_running_replay: 1..16 segments");
+    ReplaySegs rs;
+    rs.nseg = nseg;
+    int blocks = 0;
+    for (int k = 0; k < 16; ++k) {
+        const bool on = k < nseg;
+        if (on)
+            DM_REQUIRE(segs[k].stats && segs[k].nslabs > 0 && segs[k].slabs_per_group > 0 && segs[k].C > 0 &&
+                           segs[k].count_per_group > 0 && segs[k].nslabs % segs[k].slabs_per_group == 0,
+                       "dm_bn_running_replay: bad segment %d", k);
+        rs.stats[k] = on ? segs[k].stats : nullptr;
+        rs.running_mean[k] = on ? segs[k].running_mean : nullptr; rs.running_var[k] = on ? segs[k].running_var : nullptr;
+        rs.nbt[k] = on ? (long long *)segs[k].num_batches_tracked : nullptr;
+        rs.count[k] = on ? (long long)segs[k].count_per_group : 1;
+        rs.B[k] = on ? segs[k].nslabs / segs[k].slabs_per_group : 0; rs.spg[k] = on ? segs[k].slabs_per_group : 1;
+        rs.C[k] = on ? segs[k].C : 0; rs.momentum[k] = on ? segs[k].momentum : 0.f;
+        rs.first_block[k] = blocks;
+        if (on) blocks += segs[k].C;
+    }
+    rs.first_block[16] = blocks;
+    hipLaunchKernelGGL(bn_running_replay_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rs);
+    return dm_launch_status("dm_bn_running_replay");
 }
 
 extern "C" int dm_bn_backward_finalize(const double *stats, int nslabs, int C, int64_t count,

@@ -61,9 +61,10 @@ class Layers:
 
 
 # ------------------------------------------------------------------------- BatchNorm glue
-def _bn_coef(stats, bn, count, per_sample, nbatch):
+def _bn_coef(stats, bn, count, per_sample, nbatch, defer=None):
     """Batch statistics -> (coef, saved).  eval() mode (never used by the reference path) takes the
-    running statistics instead; its coefficients are three tiny device ops, no HIP kernel needed."""
+    running statistics instead; its coefficients are three tiny device ops, no HIP kernel needed.
+    defer: list collecting the running-statistics updates of the per-sample path (ops.bn_running_replay)."""
     if not bn.training:
         scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         coef = torch.stack([scale, torch.zeros_like(scale), bn.bias.detach() - bn.running_mean * scale,
@@ -72,7 +73,8 @@ def _bn_coef(stats, bn, count, per_sample, nbatch):
     momentum = 0.1 if bn.momentum is None else bn.momentum
     spg = stats.shape[0] // nbatch if per_sample else 1
     return ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                           bn.num_batches_tracked, momentum, bn.eps, per_sample=per_sample, slabs_per_group=spg)
+                           bn.num_batches_tracked, momentum, bn.eps, per_sample=per_sample, slabs_per_group=spg,
+                           defer=defer if per_sample else None)
 
 
 def _w(p):
@@ -87,52 +89,61 @@ def encoder_forward(L, x, per_sample=False):
     nh, nrh, c1 = L.nh, L.nrh, L.nh // 2
     ps = per_sample
     cx = SimpleNamespace(x=x, per_sample=ps, B=B, H=H, W=W, res=[])
+    defer = [] if ps else None       # per-sample path: running statistics of all eight layers in one launch at the end
 
     # forward: K = 16*NIN; the ones channel of the composite is folded into a per-position bias table (bias_border)
     weff, border = ops.e1_compose_border(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight), _w(L.enc1.bias))
     H1, W1 = H // 2, W // 2
     a1, st = ops.conv4x4s2(Op(x), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN, c1, H, W,
                            want_stats=True, bias_border=border, per_tile=ps)
-    coef1, saved1 = _bn_coef(st, L.bn1, H1 * W1 * (1 if ps else B), ps, B)
+    coef1, saved1 = _bn_coef(st, L.bn1, H1 * W1 * (1 if ps else B), ps, B, defer)
 
     H2, W2 = H1 // 2, W1 // 2
     a2, st = ops.conv4x4s2(Op(a1, DM_LOAD_AFFINE_RELU, coef1, per_sample=ps), weight_view(_w(L.enc4.weight), c1 * 16, 16, 4, 1),
                            B, c1, nh, H1, W1, want_stats=True, bias=_w(L.enc4.bias), per_tile=ps)
-    coef2, saved2 = _bn_coef(st, L.bn2, H2 * W2 * (1 if ps else B), ps, B)
+    coef2, saved2 = _bn_coef(st, L.bn2, H2 * W2 * (1 if ps else B), ps, B, defer)
 
     H3, W3 = H2 // 2, W2 // 2
     a3, st = ops.conv4x4s2(Op(a2, DM_LOAD_AFFINE_RELU, coef2, per_sample=ps), weight_view(_w(L.enc7.weight), nh * 16, 16, 4, 1),
                            B, nh, nh, H2, W2, want_stats=True, bias=_w(L.enc7.bias), per_tile=ps)
     n3 = H3 * W3 * (1 if ps else B)
-    coef3, saved3 = _bn_coef(st, L.bn3, n3, ps, B)
+    coef3, saved3 = _bn_coef(st, L.bn3, n3, ps, B, defer)
 
     a4, st = ops.conv3x3(Op(a3, DM_LOAD_AFFINE_RELU, coef3, per_sample=ps), weight_view(_w(L.enc10.weight), nh * 9, 9, 3, 1),
                          B, nh, nh, H3, W3, taps=9, want_stats=True, bias=_w(L.enc10.bias), per_tile=ps)
-    coef4, saved4 = _bn_coef(st, L.bn4, n3, ps, B)
+    coef4, saved4 = _bn_coef(st, L.bn4, n3, ps, B, defer)
     h = ops.apply(Op(a4, DM_LOAD_AFFINE, coef4, per_sample=ps), B, nh, H3, W3)
 
     cx.__dict__.update(a1=a1, a2=a2, a3=a3, a4=a4, coef1=coef1, coef2=coef2, coef3=coef3, coef4=coef4,
                        saved1=saved1, saved2=saved2, saved3=saved3, saved4=saved4, dims=(H1, W1, H2, W2, H3, W3))
-    z, cx.res = residual_forward(L.res, h, ps)
+    z, cx.res = residual_forward(L.res, h, ps, defer)
+    if defer:
+        ops.bn_running_replay(defer)
     return z, cx
 
 
-def residual_forward(res_layers, h, per_sample=False):
-    """ResidualBlock.forward (vq_vae.py:212-225) on a materialised h (B,nh,H,W)."""
+def residual_forward(res_layers, h, per_sample=False, defer=None):
+    """ResidualBlock.forward (vq_vae.py:212-225) on a materialised h (B,nh,H,W).
+    defer: the caller's list of postponed running-statistics updates (per-sample path); None: flushed here."""
     B, nh, H, W = h.shape
     n = H * W * (1 if per_sample else B)
     saved = []
+    own = defer is None and per_sample
+    if own:
+        defer = []
     for ca, bna, cb, bnb in res_layers:
         nrh = ca.weight.shape[0]
         ra, st = ops.conv3x3(Op(h, DM_LOAD_RELU), weight_view(_w(ca.weight), nh * 9, 9, 3, 1), B, nh, nrh, H, W, taps=9,
                              want_stats=True, bias=_w(ca.bias), per_tile=per_sample)
-        coefa, saveda = _bn_coef(st, bna, n, per_sample, B)
+        coefa, saveda = _bn_coef(st, bna, n, per_sample, B, defer)
         rb, st = ops.conv3x3(Op(ra, DM_LOAD_AFFINE_RELU, coefa, per_sample=per_sample), weight_view(_w(cb.weight), nrh, 1, 0, 0),
                              B, nrh, nh, H, W, taps=1, want_stats=True, bias=_w(cb.bias), per_tile=per_sample)
-        coefb, savedb = _bn_coef(st, bnb, n, per_sample, B)
+        coefb, savedb = _bn_coef(st, bnb, n, per_sample, B, defer)
         hn = ops.apply(Op(rb, DM_LOAD_AFFINE, coefb, per_sample=per_sample), B, nh, H, W, resid=h)
         saved.append(SimpleNamespace(h_in=h, ra=ra, rb=rb, coefa=coefa, saveda=saveda, coefb=coefb, savedb=savedb))
         h = hn
+    if own and defer:
+        ops.bn_running_replay(defer)
     return h, saved
 
 

@@ -267,9 +267,14 @@ def sum_slabs_scatter(stats, dsts, scale=1.0):
 
 # ------------------------------------------------------------------------ BatchNorm
 def bn_finalize(stats, count_per_group, gamma, beta, running_mean, running_var, nbt, momentum, eps,
-                per_sample=False, slabs_per_group=1):
+                per_sample=False, slabs_per_group=1, defer=None):
+    """defer (per_sample only): a list -> the running statistics are NOT touched by this launch; their update is appended
+    to the list for bn_running_replay, which brings every deferred layer up to date in one launch."""
     lib = L.load()
     nslabs, Cn = stats.shape[0], stats.shape[1]
+    if per_sample and defer is not None:
+        defer.append((stats, slabs_per_group, count_per_group, running_mean, running_var, nbt, momentum))
+        running_mean = running_var = nbt = None
     if per_sample:
         Bn = nslabs // slabs_per_group
         coef = _new((Bn, Cn, 4), gamma)
@@ -281,6 +286,18 @@ def bn_finalize(stats, count_per_group, gamma, beta, running_mean, running_var, 
                                _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(nbt, torch.int64), momentum,
                                eps, _ptr(coef), _ptr(saved), 1 if per_sample else 0, _stream()), "dm_bn_finalize")
     return coef, saved
+
+
+def bn_running_replay(deferred):
+    """One launch for the running statistics of every layer bn_finalize(..., defer=deferred) skipped."""
+    lib = L.load()
+    while deferred:
+        chunk, deferred[:] = deferred[:16], deferred[16:]
+        segs = (L.ReplaySeg * len(chunk))()
+        for i, (stats, spg, cnt, rm, rv, nbt, mom) in enumerate(chunk):
+            segs[i] = L.ReplaySeg(_ptr(stats, torch.float64), stats.shape[0], spg, stats.shape[1], cnt, _ptr(rm), _ptr(rv),
+                                  _ptr(nbt, torch.int64), mom)
+        L.check(lib.dm_bn_running_replay(segs, len(chunk), _stream()), "dm_bn_running_replay")
 
 
 def bn_backward_finalize(stats, count, gamma, saved, dgamma, dbeta):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 106
+#define DM_VERSION 107
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -209,6 +209,20 @@ int dm_bn_finalize(const double *stats, int nslabs, int slabs_per_group, int C, 
                    const float *gamma, const float *beta, float *running_mean, float *running_var,
                    int64_t *num_batches_tracked, float momentum, float eps,
                    float *coef, float *saved, int per_sample, void *stream);
+
+/* Per-sample mode only: running_mean = running_var = num_batches_tracked = NULL leaves the module state alone;
+ * dm_bn_running_replay then brings the running statistics of up to 16 layers up to date in ONE launch from the same
+ * slabs (the inference path needs a layer's coefficients before the next convolution, its running statistics never:
+ * patch_VAE.py:445-452 only reads the latents). */
+typedef struct dm_bn_replay_seg {
+    const double *stats;        /* the slabs handed to dm_bn_finalize(per_sample = 1) */
+    int32_t nslabs, slabs_per_group, C;
+    int64_t count_per_group;
+    float *running_mean, *running_var;      /* (C) each, or both NULL */
+    int64_t *num_batches_tracked;           /* or NULL */
+    float momentum;
+} dm_bn_replay_seg;
+int dm_bn_running_replay(const dm_bn_replay_seg *segs, int nseg, void *stream);
 
 /* Backward finalize: slabs hold (sum dy, sum dy*a).  Writes dgamma, dbeta and the
  * AFFINE2 coefficients (A,B,C) with da = A*dy + B*a + C. */

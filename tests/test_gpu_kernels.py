@@ -706,6 +706,20 @@ def test_bn_per_sample_statistics(ops):
     close(rm, bn.running_mean, 1e-5, 1e-7, "running_mean")
     close(rv, bn.running_var, 1e-5, 1e-7, "running_var")
     assert int(nbt) == B
+    # the same with the running statistics deferred: two layers brought up to date by ONE later launch, bit for bit
+    rm2, rv2 = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+    rm3, rv3 = torch.full((Cn,), 0.5, device=DEV), torch.full((Cn,), 2.0, device=DEV)
+    nbt2, nbt3 = torch.zeros((), dtype=torch.int64, device=DEV), torch.full((), 7, dtype=torch.int64, device=DEV)
+    rm3_ref, rv3_ref, nbt3_ref = rm3.clone(), rv3.clone(), nbt3.clone()
+    ops.bn_finalize(stats, h * h, g, b, rm3_ref, rv3_ref, nbt3_ref, 0.25, 1e-5, per_sample=True, slabs_per_group=1)
+    deferred = []
+    coef2, saved2 = ops.bn_finalize(stats, h * h, g, b, rm2, rv2, nbt2, 0.1, 1e-5, per_sample=True, slabs_per_group=1, defer=deferred)
+    ops.bn_finalize(stats, h * h, g, b, rm3, rv3, nbt3, 0.25, 1e-5, per_sample=True, slabs_per_group=1, defer=deferred)
+    assert torch.equal(coef2, coef) and torch.equal(saved2, saved)
+    assert float(rm2.abs().sum()) == 0.0 and int(nbt2) == 0 and len(deferred) == 2         # untouched so far
+    ops.bn_running_replay(deferred)
+    assert torch.equal(rm2, rm) and torch.equal(rv2, rv) and int(nbt2) == B
+    assert torch.equal(rm3, rm3_ref) and torch.equal(rv3, rv3_ref) and int(nbt3) == 7 + B and not deferred
 
 
 # ================================================================================= head
