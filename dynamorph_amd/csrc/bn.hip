@@ -69,6 +69,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     }
 }
 
+// base^e for a small non-negative integer exponent: ~2 log2(e) multiplications (pow() in double costs an order more)
+__device__ __forceinline__ double int_pow(double base, int e)
+{
+    double r = 1.0;
+    while (e > 0) {
+        if (e & 1) r *= base;
+        base *= base;
+        e >>= 1;
+    }
+    return r;
+}
+
 // Running statistics of channel c after B successive batch-of-one calls (one workgroup; see the closed form below).
 __device__ __forceinline__ void running_replay_channel(const double *__restrict__ stats, int B, int spg, int C, long long count, int c,
                                                        float *__restrict__ running_mean, float *__restrict__ running_var,
@@ -79,28 +91,51 @@ __device__ __forceinline__ void running_replay_channel(const double *__restrict_
     const bool track = running_mean && running_var;
     const double m = (double)momentum, keep = 1.0 - m;
     double sm = 0.0, sv = 0.0;
+    // (the old values are requested now, next to the slabs: they are only needed after the two block sums)
+    float rm0 = 0.f, rv0 = 0.f;
+    if (track && threadIdx.x == 0) { rm0 = running_mean[c]; rv0 = running_var[c]; }
+    const double kB = int_pow(keep, B);
     if (track) {
-        for (int b = threadIdx.x; b < B; b += blockDim.x) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int i = 0; i < spg; ++i) {
-                s1 += stats[((long long)(b * spg + i) * C + c) * 2 + 0];
-                s2 += stats[((long long)(b * spg + i) * C + c) * 2 + 1];
+        // four samples per thread and eight slabs per sample requested together (one memory round trip for B <= 1024,
+        // <= 8 slabs per sample); each sample's slabs are still added in slab order
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2 *__restrict__ st2 = reinterpret_cast<const f64x2 *>(stats);
+        for (int b0 = threadIdx.x; b0 < B; b0 += 4 * (int)blockDim.x) {
+            double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i0 = 0; i0 < spg; i0 += 8) {
+                f64x2 v[4][8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int b = b0 + j * (int)blockDim.x, i = i0 + k;
+                        v[j][k] = (f64x2){0.0, 0.0};
+                        if (b < B && i < spg) v[j][k] = st2[(long long)(b * spg + i) * C + c];
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { s1[j] += v[j][k].x; s2[j] += v[j][k].y; }
             }
-            const double mean = s1 / n;
-            double var = s2 / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const double w = m * pow(keep, (double)(B - 1 - b));
-            sm += w * (double)(float)mean;                       // the fp32 values a batch-of-one call would feed
-            sv += w * (double)(float)(var * unbias);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = b0 + j * (int)blockDim.x;
+                if (b >= B) continue;
+                const double mean = s1[j] / n;
+                double var = s2[j] / n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const double w = m * int_pow(keep, B - 1 - b);
+                sm += w * (double)(float)mean;                   // the fp32 values a batch-of-one call would feed
+                sv += w * (double)(float)(var * unbias);
+            }
         }
     }
     const double tm = block_sum(sm, s_red);
     const double tv = block_sum(sv, s_red);
     if (threadIdx.x == 0) {
         if (track) {
-            const double k = pow(keep, (double)B);
-            running_mean[c] = (float)(k * (double)running_mean[c] + tm);
-            running_var[c] = (float)(k * (double)running_var[c] + tv);
+            running_mean[c] = (float)(kB * (double)rm0 + tm);
+            running_var[c] = (float)(kB * (double)rv0 + tv);
         }
         if (nbt && c == 0) nbt[0] += B;
     }
@@ -121,9 +156,9 @@ struct ReplaySegs {
 __global__ __launch_bounds__(256) void bn_running_replay_kernel(ReplaySegs rs)
 {
     __shared__ double s_red[4];
-    int k = 0;
-    while (k + 1 < rs.nseg && (int)blockIdx.x >= rs.first_block[k + 1]) ++k;
-    running_replay_channel(rs.stats[k], rs.B[k], rs.spg[k], rs.C[k], rs.count[k], blockIdx.x - rs.first_block[k],
+    const int k = blockIdx.y;                      // grid (widest layer, layers): no search through the segment table
+    if ((int)blockIdx.x >= rs.C[k]) return;
+    running_replay_channel(rs.stats[k], rs.B[k], rs.spg[k], rs.C[k], rs.count[k], blockIdx.x,
                            rs.running_mean[k], rs.running_var[k], rs.nbt[k], rs.momentum[k], s_red);
 }
 
@@ -323,7 +358,9 @@ extern "C" int dm_bn_running_replay(const dm_bn_replay_seg *segs, int nseg, void
         if (on) blocks += segs[k].C;
     }
     rs.first_block[16] = blocks;
-    hipLaunchKernelGGL(bn_running_replay_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rs);
+    int widest = 1;
+    for (int k = 0; k < nseg; ++k) widest = segs[k].C > widest ? segs[k].C : widest;
+    hipLaunchKernelGGL(bn_running_replay_kernel, dim3(widest, nseg), dim3(256), 0, (hipStream_t)stream, rs);
     return dm_launch_status("dm_bn_running_replay");
 }
 
