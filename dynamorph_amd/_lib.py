@@ -58,7 +58,7 @@ SIGNATURES = {
     "dm_vq_decode": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_vq_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp, vp]),
     "dm_vq_backward": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),
-    "dm_vq_backward_num_slabs": (C.c_int, [i64]),
+    "dm_vq_backward_num_slabs": (C.c_int, [i64, C.c_int, C.c_int]),
     "dm_vq_backward_slabs": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_conv4x4s2": (C.c_int, [OP, WV, vp, EP] + [C.c_int] * 5 + [vp]),
     "dm_conv4x4s2_num_blocks": (C.c_int, [C.c_int] * 6),

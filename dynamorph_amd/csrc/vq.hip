@@ -1274,10 +1274,14 @@ extern "C" int dm_vq_finalize(const double *sse_slabs, int nslabs, const int32_t
 }
 
 namespace {
-int vq_backward_grid(long long P)
+// workgroups = slabs of K*D floats each: two 1024-thread workgroups per CU, fewer for large codebooks so that the slab
+// tensor stays below 32 MB (4096 x 16: 128 slabs instead of 512 = 128 MB written and read back per step)
+int vq_backward_grid(long long P, int K, int D)
 {
     const long long want = (P + VQ_BWD_BLOCK - 1) / VQ_BWD_BLOCK;
-    return (int)(want < 512 ? want : 512);                 // two 1024-thread workgroups per CU
+    long long cap = (8LL << 20) / ((long long)K * D);
+    cap = cap > 512 ? 512 : (cap < 32 ? 32 : cap);
+    return (int)(want < cap ? want : cap);
 }
 
 int vq_backward_launch(const char *who, const float *z, const float *codebook, const int64_t *idx, const float *g_out,
@@ -1290,7 +1294,7 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
     int Kc = VQ_BWD_LDS / (D * (int)sizeof(float));
     if (Kc > K) Kc = K;
     const size_t lds = (size_t)Kc * D * sizeof(float);
-    const int grid = vq_backward_grid(P);
+    const int grid = vq_backward_grid(P, K, D);
     const dim3 g3((unsigned)grid, (unsigned)((K + Kc - 1) / Kc));
     hipStream_t s = (hipStream_t)stream;
     const uintptr_t al = (uintptr_t)z | (uintptr_t)g_out | (uintptr_t)dz;
@@ -1333,7 +1337,11 @@ extern "C" int dm_vq_backward(const float *z, const float *codebook, const int64
                               B, D, K, H, W, stream);
 }
 
-extern "C" int dm_vq_backward_num_slabs(int64_t positions) { return vq_backward_grid(positions); }
+extern "C" int dm_vq_backward_num_slabs(int64_t positions, int K, int D)
+{
+    DM_REQUIRE(positions > 0 && K > 0 && D > 0, "dm_vq_backward_num_slabs: bad argument");
+    return vq_backward_grid(positions, K, D);
+}
 
 extern "C" int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *idx,
                                     const float *g_out, const float *g_loss_dev, float commitment_cost,

@@ -171,7 +171,7 @@ def vq_backward_slabs(z, codebook, idx, g_out, g_loss, commitment_cost, want_dz=
     B, D, H, W = z.shape
     K = codebook.shape[0]
     dz = torch.empty_like(z) if want_dz else None
-    slabs = _new((lib.dm_vq_backward_num_slabs(B * H * W), K * D), z)
+    slabs = _new((lib.dm_vq_backward_num_slabs(B * H * W, K, D), K * D), z)
     L.check(lib.dm_vq_backward_slabs(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(g_out), _ptr(g_loss),
                                      commitment_cost, _ptr(dz), _ptr(slabs), B, D, K, H, W, _stream()),
             "dm_vq_backward_slabs")

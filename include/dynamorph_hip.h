@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 107
+#define DM_VERSION 108
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -147,14 +147,14 @@ int dm_vq_backward(const float *z, const float *codebook, const int64_t *idx,
                    const float *g_out, const float *g_loss_dev, float commitment_cost,
                    float *dz, float *dw, int B, int D, int K, int H, int W, void *stream);
 
-/* The same with the codebook gradient as per-workgroup slabs [dm_vq_backward_num_slabs(P)][K*D] instead of global
+/* The same with the codebook gradient as per-workgroup slabs [dm_vq_backward_num_slabs(P, K, D)][K*D] instead of global
  * float atomics: dm_reduce_slabs / dm_reduce_slabs_multi adds them in a fixed order and nothing has to be zeroed
  * first.  K <= 64 with D in {16, 32, 64}, H*W % 64 == 0 and 16-byte aligned tensors: the gradient is a one-hot
  * (codes x positions) . (positions x D) product on the matrix cores, accumulated in registers and combined in wave
  * order -- bit-reproducible.  Otherwise positions are added into an LDS window with float atomics (hardware order
  * inside a workgroup: low bits may vary); codebooks above the 128 KB window (512 x 64, 4096 x 16) are processed in
  * windows of codes over grid.y. */
-int dm_vq_backward_num_slabs(int64_t positions);
+int dm_vq_backward_num_slabs(int64_t positions, int K, int D);   /* <= 512, fewer for large codebooks (slab tensor <= 32 MB) */
 int dm_vq_backward_slabs(const float *z, const float *codebook, const int64_t *idx,
                          const float *g_out, const float *g_loss_dev, float commitment_cost,
                          float *dz, float *dw_slabs, int B, int D, int K, int H, int W, void *stream);
