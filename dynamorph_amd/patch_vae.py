@@ -105,8 +105,13 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
             if res[0] is None:
                 pinned = 4 * N * (z_b.shape[1] + z_a.shape[1]) <= pin_cap
                 for q, zq in enumerate((z_b, z_a)):
-                    res[q] = (torch.empty((N, zq.shape[1]), dtype=torch.float32, pin_memory=True) if pinned
-                              else torch.empty((N, zq.shape[1]), dtype=torch.float32).fill_(0))
+                    if pinned:
+                        try:
+                            res[q] = torch.empty((N, zq.shape[1]), dtype=torch.float32, pin_memory=True)
+                            continue
+                        except RuntimeError:                    # the host refuses to pin that much: pageable results
+                            pinned = False
+                    res[q] = torch.empty((N, zq.shape[1]), dtype=torch.float32).fill_(0)
             z_b.record_stream(s_out)
             z_a.record_stream(s_out)
             sent[k] = helper.submit(hand_back, lo, n, z_b, z_a, ev_done[k])
