@@ -255,14 +255,16 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restr
     const int c = blockIdx.x % C, chunk = blockIdx.x / C;
     const int b0 = chunk * bchunk, b1 = min(B, b0 + bchunk);
     double s1 = 0.0, s2 = 0.0;
-    for (int b = b0; b < b1; ++b) {
-        const long long base = ((long long)b * C + c) * HW4;
-        for (int i = threadIdx.x; i < HW4; i += blockDim.x) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (base + i) * 4);
-            const f32x4 w = q ? *reinterpret_cast<const f32x4 *>(q + (base + i) * 4) : a;
-            s1 += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
-            s2 += (double)(a.x * w.x) + (double)(a.y * w.y) + (double)(a.z * w.z) + (double)(a.w * w.w);
-        }
+    // the chunk's (sample, position) pairs spread over all threads (a 16 x 16 latent has 64 float4 per plane: a loop over
+    // the plane alone would leave three waves idle); four elements in fp32, then one promotion, as in the conv epilogues
+    const int total = (b1 - b0) * HW4;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int bb = e / HW4, i = e - bb * HW4;
+        const long long off = ((((long long)(b0 + bb)) * C + c) * HW4 + i) * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p + off);
+        const f32x4 w = q ? *reinterpret_cast<const f32x4 *>(q + off) : a;
+        s1 += (double)((a.x + a.y) + (a.z + a.w));
+        s2 += (double)((a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w));
     }
     const double t1 = block_sum(s1, s_red);
     const double t2 = block_sum(s2, s_red);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void sum_slabs_scatter_kernel(const double *__
     }
 }
 
-constexpr int STATS_BCHUNK = 8;
+constexpr int STATS_BCHUNK = 32;
 
 }  // namespace
 
