@@ -26,6 +26,26 @@ extern "C" int dm_version(void) { return DM_VERSION; }
 
 namespace {
 
+// This thread's share of the (sum, sum of products) slabs of channel c: slabs tid, tid + 256, ... -- four 16-byte loads in
+// flight per round (one round for up to 1024 slabs) instead of one dependent load pair per slab.
+__device__ __forceinline__ void slab_partial(const double *__restrict__ stats, int nslabs, int C, int c, double &s1, double &s2)
+{
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const f64x2 *__restrict__ st2 = reinterpret_cast<const f64x2 *>(stats);
+    s1 = 0.0; s2 = 0.0;
+    for (int i0 = threadIdx.x; i0 < nslabs; i0 += 4 * (int)blockDim.x) {
+        f64x2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j * (int)blockDim.x;
+            v[j] = (f64x2){0.0, 0.0};
+            if (i < nslabs) v[j] = st2[(long long)i * C + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1 += v[j].x; s2 += v[j].y; }
+    }
+}
+
 // Batch mode: one block per channel, all slabs form one group.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const double *__restrict__ stats, int nslabs, int C, long long count,
@@ -38,12 +58,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
     const double n = (double)count;
     const double unbias = count > 1 ? n / (n - 1.0) : 1.0;
+    // (the old running statistics are requested with the slabs: they are only needed after the two block sums)
+    float rm0 = 0.f, rv0 = 0.f;
+    if (threadIdx.x == 0) { if (running_mean) rm0 = running_mean[c]; if (running_var) rv0 = running_var[c]; }
     {
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = threadIdx.x; i < nslabs; i += blockDim.x) {
-            s1 += stats[((long long)i * C + c) * 2 + 0];
-            s2 += stats[((long long)i * C + c) * 2 + 1];
-        }
+        double s1, s2;
+        slab_partial(stats, nslabs, C, c, s1, s2);
         const double t1 = block_sum(s1, s_red);
         const double t2 = block_sum(s2, s_red);
         if (threadIdx.x == 0) {
@@ -61,8 +81,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
             saved[c * 2 + 1] = invstd;
             // ATen's CPU kernel evaluates these two updates in double (acc type) before the fp32 store
             const double mom = (double)momentum;
-            if (running_mean) running_mean[c] = (float)(mom * mean + (1.0 - mom) * (double)running_mean[c]);
-            if (running_var) running_var[c] = (float)(mom * (var * unbias) + (1.0 - mom) * (double)running_var[c]);
+            if (running_mean) running_mean[c] = (float)(mom * mean + (1.0 - mom) * (double)rm0);
+            if (running_var) running_var[c] = (float)(mom * (var * unbias) + (1.0 - mom) * (double)rv0);
             if (nbt && c == 0) nbt[0] += 1;
         }
         return;
@@ -210,17 +230,17 @@ __global__ __launch_bounds__(256) void bn_backward_finalize_kernel(
 {
     __shared__ double s_red[4];
     const int c = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < nslabs; i += blockDim.x) {
-        s1 += stats[((long long)i * C + c) * 2 + 0];
-        s2 += stats[((long long)i * C + c) * 2 + 1];
-    }
+    // (requested with the slabs, used after the block sums)
+    float mean_f = 0.f, invstd_f = 0.f, g_f = 1.f;
+    if (threadIdx.x == 0) { mean_f = saved[c * 2 + 0]; invstd_f = saved[c * 2 + 1]; if (gamma) g_f = gamma[c]; }
+    double s1, s2;
+    slab_partial(stats, nslabs, C, c, s1, s2);
     const double sum_dy = block_sum(s1, s_red);
     const double sum_dya = block_sum(s2, s_red);
     if (threadIdx.x == 0) {
         const double n = (double)count;
-        const double mean = (double)saved[c * 2 + 0], invstd = (double)saved[c * 2 + 1];
-        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double mean = (double)mean_f, invstd = (double)invstd_f;
+        const double g = (double)g_f;
         const double sum_dyxh = invstd * (sum_dya - mean * sum_dy);
         if (dgamma) dgamma[c] = (float)sum_dyxh;
         if (dbeta) dbeta[c] = (float)sum_dy;
