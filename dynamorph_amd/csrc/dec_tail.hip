@@ -56,26 +56,21 @@ __device__ __forceinline__ float lane_from_right(float v)   // value of lane + 1
 // kernel is VALU-issue bound).  A lane owns column x and produces the output pair (ox = 2x, 2x+1):
 //   out[oy][2x]   = sum_ci,d  in[d][x-1] * w[ky][3] + in[d][x]   * w[ky][1]
 //   out[oy][2x+1] = sum_ci,d  in[d][x]   * w[ky][2] + in[d][x+1] * w[ky][0]
-// so with L = (in[x-1], in[x]) and R = (in[x], in[x+1]) the pair is  L * (w3, w2) + R * (w1, w0).
+// The lane multiplies ITS value in[x] four ways: (w1, w2) into its own pair, (w3, w0) into a "side" pair whose halves
+// belong to the right neighbour's out[2x'] and the left neighbour's out[2x'+1]; the side sums cross the lanes ONCE per
+// output row (two wave-shift DPP moves whose out-of-range reads return 0 = the zero padding at the image border: the
+// tile spans the whole row) instead of every input value crossing them first.
 // Output rows 2y-1 and 2y both read exactly the input rows y-1 ("P") and y ("C"):
 //   row 2y-1: P with ky = 2, C with ky = 0        row 2y: P with ky = 3, C with ky = 1
-struct RowPairs {
-    f32x2 L[TT_C], R[TT_C];
+struct RowVals {
+    float v[TT_C];
 };
-__device__ __forceinline__ void load_row(const float *__restrict__ sA, int APS, int row, int lane, float (&v)[TT_C])
+__device__ __forceinline__ void load_row(const float *__restrict__ sA, int APS, int row, int lane, RowVals &r)
 {
 #pragma unroll
-    for (int ci = 0; ci < TT_C; ++ci) v[ci] = sA[ci * APS + row * TT_W + lane];
+    for (int ci = 0; ci < TT_C; ++ci) r.v[ci] = sA[ci * APS + row * TT_W + lane];
 }
-__device__ __forceinline__ void make_row_pairs(const float (&v)[TT_C], RowPairs &p)
-{
-#pragma unroll
-    for (int ci = 0; ci < TT_C; ++ci) {
-        p.L[ci] = (f32x2){lane_from_left(v[ci]), v[ci]};
-        p.R[ci] = (f32x2){v[ci], lane_from_right(v[ci])};
-    }
-}
-// wp[ci][ky][0] = (w[ky][3], w[ky][2]), wp[ci][ky][1] = (w[ky][1], w[ky][0]) of W4[ci][co] for this wave's co
+// wp[ci][ky][0] = (w[ky][1], w[ky][2]) (own pair), wp[ci][ky][1] = (w[ky][3], w[ky][0]) (side pair) of W4[ci][co] for this wave's co
 __device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, int wv, f32x2 (&wp)[TT_C][4][2])
 {
 #pragma unroll
@@ -83,22 +78,26 @@ __device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, 
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(w + (ci * TT_C + wv) * 16 + 4 * ky);
-            wp[ci][ky][0] = (f32x2){q.w, q.z};
-            wp[ci][ky][1] = (f32x2){q.y, q.x};
+            wp[ci][ky][0] = (f32x2){q.y, q.z};
+            wp[ci][ky][1] = (f32x2){q.w, q.x};
         }
 }
-__device__ __forceinline__ void convT_pair(const RowPairs &P, const RowPairs &C, const f32x2 (&wp)[TT_C][4][2], float bias,
+__device__ __forceinline__ void convT_pair(const RowVals &P, const RowVals &C, const f32x2 (&wp)[TT_C][4][2], float bias,
                                            f32x2 &lo, f32x2 &hi)
 {
     lo = (f32x2){bias, bias}; hi = (f32x2){bias, bias};
+    f32x2 slo = {0.f, 0.f}, shi = {0.f, 0.f};
 #pragma unroll
     for (int ci = 0; ci < TT_C; ++ci) {
-        // one statement per product: each contracts to a single v_pk_fma_f32 on the accumulator
-        lo += P.L[ci] * wp[ci][2][0]; hi += P.L[ci] * wp[ci][3][0];
-        lo += P.R[ci] * wp[ci][2][1]; hi += P.R[ci] * wp[ci][3][1];
-        lo += C.L[ci] * wp[ci][0][0]; hi += C.L[ci] * wp[ci][1][0];
-        lo += C.R[ci] * wp[ci][0][1]; hi += C.R[ci] * wp[ci][1][1];
+        const f32x2 p = {P.v[ci], P.v[ci]}, c = {C.v[ci], C.v[ci]};
+        // one statement per product: each contracts to a single v_pk_fma_f32 on its accumulator
+        lo += p * wp[ci][2][0]; hi += p * wp[ci][3][0];
+        slo += p * wp[ci][2][1]; shi += p * wp[ci][3][1];
+        lo += c * wp[ci][0][0]; hi += c * wp[ci][1][0];
+        slo += c * wp[ci][0][1]; shi += c * wp[ci][1][1];
     }
+    lo.x += lane_from_left(slo.x); lo.y += lane_from_right(slo.y);
+    hi.x += lane_from_left(shi.x); hi.y += lane_from_right(shi.y);
 }
 __device__ __forceinline__ f32x2 relu2(f32x2 v) { return (f32x2){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}; }
 
@@ -168,15 +167,13 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
         }
         // ---- phase A: d4[co = wave] = relu(dec.4(d2)) for the 16 output rows of this tile -> LDS ---------------
         {
-            RowPairs P, C;                               // d2 rows y-1 and y; sA row 0 <-> d2 row y0-1
-            float nv[TT_C];                              // the next row's values: LDS reads one row ahead of their use
-            load_row(sA, APS, 0, lane, nv);
-            make_row_pairs(nv, P);
-            load_row(sA, APS, 1, lane, nv);
+            RowVals P, C, N;                             // d2 rows y-1, y and (read one row ahead of its use) y+1; sA row 0 <-> d2 row y0-1
+            load_row(sA, APS, 0, lane, P);
+            load_row(sA, APS, 1, lane, N);
 #pragma unroll
             for (int pr = 0; pr <= TT_TH; ++pr) {        // y = y0 + pr -> d4 rows 2y-1 (lo) and 2y (hi)
-                make_row_pairs(nv, C);
-                if (pr < TT_TH) load_row(sA, APS, pr + 2, lane, nv);
+                C = N;
+                if (pr < TT_TH) load_row(sA, APS, pr + 2, lane, N);
                 __builtin_amdgcn_sched_barrier(0);
                 f32x2 lo, hi;
                 convT_pair(P, C, wp, bias4, lo, hi);
@@ -370,11 +367,9 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         {
         f32x2 wp[TT_C][4][2];                         // W4[ci][co = wave] as packed pairs, live in this phase only
         load_convT_weights(s_w4, wv, wp);
-        RowPairs P, C;                                // sA row 0 <-> d2 row y0-2
-        float nv[TT_C];                               // the next row's values: LDS reads one row ahead of their use
-        load_row(sA, APS, 1, lane, nv);
-        make_row_pairs(nv, P);
-        load_row(sA, APS, 2, lane, nv);
+        RowVals P, C, N;                              // rows y-1, y and (read one row ahead of its use) y+1; sA row 0 <-> d2 row y0-2
+        load_row(sA, APS, 1, lane, P);
+        load_row(sA, APS, 2, lane, N);
 #pragma unroll
         for (int pr = 0; pr <= TT_TH; ++pr) {         // y = y0 + pr -> g4-tile rows 2pr (d4 row 2y-1) and 2pr+1 (row 2y)
             {
@@ -383,8 +378,8 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 for (int e = 0; e < NE; ++e)
                     if (e >= pr * NE / (TT_TH + 1) && e < (pr + 1) * NE / (TT_TH + 1)) stage.issue_one(e, scx);
             }
-            make_row_pairs(nv, C);
-            if (pr < TT_TH) load_row(sA, APS, pr + 3, lane, nv);
+            C = N;
+            if (pr < TT_TH) load_row(sA, APS, pr + 3, lane, N);
             __builtin_amdgcn_sched_barrier(0);
             f32x2 lo, hi;
             convT_pair(P, C, wp, bias4, lo, hi);
@@ -457,19 +452,22 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         //      g4[co][2y-1+ky][2x-1+kx] * W4[ci][co][ky][kx], masked by d2 > 0 ------------------------------------------
         {
         // per g4 value pair mid = (col 2x, 2x+1), left = col 2x-1, right = col 2x+2:
-        //   left*w[ky][0] + mid.x*w[ky][1] + mid.y*w[ky][2] + right*w[ky][3] = mid * (w1, w2) + (left, right) * (w0, w3)
-        f32x2 wm[TT_C][4], wo[TT_C][4];               // W4[ci = wave][co][ky] as (w1, w2) and (w0, w3)
+        //   g2[x] += left*w[ky][0] + mid.x*w[ky][1] + mid.y*w[ky][2] + right*w[ky][3]
+        // left / right are the neighbours' mid.y / mid.x: instead of fetching them per value, every lane also accumulates
+        // side = mid * (w3, w0) -- what ITS pair contributes to the left (x) and right (y) neighbour -- and the side sums
+        // cross the lanes once per output row
+        f32x2 wm[TT_C][4], wo[TT_C][4];               // W4[ci = wave][co][ky] as (w1, w2) and (w3, w0)
 #pragma unroll
         for (int co = 0; co < TT_C; ++co)
 #pragma unroll
             for (int ky = 0; ky < 4; ++ky) {
                 const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + (wv * TT_C + co) * 16 + 4 * ky);
                 wm[co][ky] = (f32x2){q.y, q.z};
-                wo[co][ky] = (f32x2){q.x, q.w};
+                wo[co][ky] = (f32x2){q.w, q.x};
             }
-        f32x2 acc[TT_TH];
+        f32x2 acc[TT_TH], side[TT_TH];
 #pragma unroll
-        for (int r = 0; r < TT_TH; ++r) acc[r] = (f32x2){0.f, 0.f};
+        for (int r = 0; r < TT_TH; ++r) { acc[r] = (f32x2){0.f, 0.f}; side[r] = (f32x2){0.f, 0.f}; }
         f32x2 nm[TT_C];                               // the next g4 row: LDS reads one row ahead of their use
 #pragma unroll
         for (int co = 0; co < TT_C; ++co) nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + 2 * lane + 4);
@@ -486,15 +484,15 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int co = 0; co < TT_C; ++co) {
-                const f32x2 lr = {lane_from_left(mid[co].y), lane_from_right(mid[co].x)};
                 const int r1 = gr >> 1, k1 = gr & 1;               // ky = k1 for row r1, ky = k1 + 2 for row r1 - 1
-                if (r1 < TT_TH) { acc[r1] += mid[co] * wm[co][k1]; acc[r1] += lr * wo[co][k1]; }
-                if (r1 >= 1) { acc[r1 - 1] += mid[co] * wm[co][k1 + 2]; acc[r1 - 1] += lr * wo[co][k1 + 2]; }
+                if (r1 < TT_TH) { acc[r1] += mid[co] * wm[co][k1]; side[r1] += mid[co] * wo[co][k1]; }
+                if (r1 >= 1) { acc[r1 - 1] += mid[co] * wm[co][k1 + 2]; side[r1 - 1] += mid[co] * wo[co][k1 + 2]; }
             }
             if ((gr & 1) && gr >= 3) {                             // row r = (gr - 3) / 2 is complete
                 const int r = (gr - 3) >> 1;
                 const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
-                const float v = dd > 0.f ? acc[r].x + acc[r].y : 0.f;
+                const float sum = (acc[r].x + acc[r].y) + (lane_from_right(side[r].x) + lane_from_left(side[r].y));
+                const float v = dd > 0.f ? sum : 0.f;
                 g2[((cb * TT_C + wave) * H2 + cy0 + r) * TT_W + lane] = v;
                 pb2 += v;
             }
