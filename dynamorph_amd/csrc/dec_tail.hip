@@ -85,14 +85,20 @@ __device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, 
 __device__ __forceinline__ void convT_pair(const RowVals &P, const RowVals &C, const f32x2 (&wp)[TT_C][4][2], float bias,
                                            f32x2 &lo, f32x2 &hi)
 {
-    lo = (f32x2){bias, bias}; hi = (f32x2){bias, bias};
-    f32x2 slo = {0.f, 0.f}, shi = {0.f, 0.f};
+    const f32x2 b2 = {bias, bias};
+    f32x2 slo, shi;
 #pragma unroll
     for (int ci = 0; ci < TT_C; ++ci) {
         const f32x2 p = {P.v[ci], P.v[ci]}, c = {C.v[ci], C.v[ci]};
-        // one statement per product: each contracts to a single v_pk_fma_f32 on its accumulator
-        lo += p * wp[ci][2][0]; hi += p * wp[ci][3][0];
-        slo += p * wp[ci][2][1]; shi += p * wp[ci][3][1];
+        // one statement per product: each contracts to a single v_pk_fma_f32 on its accumulator; the first channel
+        // starts the four sums (no registers zeroed first)
+        if (ci == 0) {
+            lo = p * wp[ci][2][0] + b2; hi = p * wp[ci][3][0] + b2;
+            slo = p * wp[ci][2][1]; shi = p * wp[ci][3][1];
+        } else {
+            lo += p * wp[ci][2][0]; hi += p * wp[ci][3][0];
+            slo += p * wp[ci][2][1]; shi += p * wp[ci][3][1];
+        }
         lo += c * wp[ci][0][0]; hi += c * wp[ci][1][0];
         slo += c * wp[ci][0][1]; shi += c * wp[ci][1][1];
     }
@@ -465,9 +471,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 wm[co][ky] = (f32x2){q.y, q.z};
                 wo[co][ky] = (f32x2){q.w, q.x};
             }
-        f32x2 acc[TT_TH], side[TT_TH];
-#pragma unroll
-        for (int r = 0; r < TT_TH; ++r) { acc[r] = (f32x2){0.f, 0.f}; side[r] = (f32x2){0.f, 0.f}; }
+        f32x2 acc[TT_TH], side[TT_TH];                 // (started by their first product below, not zeroed)
         f32x2 nm[TT_C];                               // the next g4 row: LDS reads one row ahead of their use
 #pragma unroll
         for (int co = 0; co < TT_C; ++co) nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + 2 * lane + 4);
@@ -485,7 +489,10 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 #pragma unroll
             for (int co = 0; co < TT_C; ++co) {
                 const int r1 = gr >> 1, k1 = gr & 1;               // ky = k1 for row r1, ky = k1 + 2 for row r1 - 1
-                if (r1 < TT_TH) { acc[r1] += mid[co] * wm[co][k1]; side[r1] += mid[co] * wo[co][k1]; }
+                if (r1 < TT_TH) {
+                    if (k1 == 0 && co == 0) { acc[r1] = mid[co] * wm[co][k1]; side[r1] = mid[co] * wo[co][k1]; }
+                    else { acc[r1] += mid[co] * wm[co][k1]; side[r1] += mid[co] * wo[co][k1]; }
+                }
                 if (r1 >= 1) { acc[r1 - 1] += mid[co] * wm[co][k1 + 2]; side[r1 - 1] += mid[co] * wo[co][k1 + 2]; }
             }
             if ((gr & 1) && gr >= 3) {                             // row r = (gr - 3) / 2 is complete
