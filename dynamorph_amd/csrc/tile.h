@@ -59,6 +59,17 @@ __device__ __forceinline__ void stage_coef(float *__restrict__ s_coef, const Ope
 
 typedef unsigned short dm_u16x2 __attribute__((ext_vector_type(2)));
 
+// ReLU as ONE integer instruction per value: max(bits, 0) on the sign-magnitude float keeps every non-negative number
+// and the (positive, as the hardware generates them) NaNs, and sends every negative number and -0 to +0 --
+// v_max_f32 would return 0 for a NaN (torch.relu keeps it), a compare + select costs two instructions.
+__device__ __forceinline__ f32x4 relu_keep_nan(f32x4 v)
+{
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 b = __builtin_bit_cast(i32x4, v);
+    b.x = b.x > 0 ? b.x : 0; b.y = b.y > 0 ? b.y : 0; b.z = b.z > 0 ? b.z : 0; b.w = b.w > 0 ? b.w : 0;
+    return __builtin_bit_cast(f32x4, b);
+}
+
 template <int CIN, int ROWS, int COLS4, int RS, int PS, bool TWO>
 struct TileStage {
     static constexpr int PER_C = ROWS * COLS4;
@@ -171,20 +182,13 @@ struct TileStage {
             for (int step = 0; step < NC; ++step) {
                 const int k = step * P + p;
                 f32x4 val = v[k];
-                if constexpr (KIND == 1) {
-                    // select instead of fmaxf: a NaN activation stays NaN (torch.relu semantics)
-                    val.x = val.x < 0.f ? 0.f : val.x; val.y = val.y < 0.f ? 0.f : val.y;
-                    val.z = val.z < 0.f ? 0.f : val.z; val.w = val.w < 0.f ? 0.f : val.w;
-                } else if constexpr (KIND >= 2) {
+                if constexpr (KIND == 1) val = relu_keep_nan(val); else if constexpr (KIND >= 2) {
                     const f32x4 c = cf[step];
                     // padding: v (and u) are 0 there, so only the shift has to go; the ReLU leaves that 0 alone
                     const float cz = in ? c.z : 0.f;
                     val = c.x * val + cz;
                     if (TWO) val += c.y * u[k];
-                    if constexpr (KIND == 3) {
-                        val.x = val.x < 0.f ? 0.f : val.x; val.y = val.y < 0.f ? 0.f : val.y;
-                        val.z = val.z < 0.f ? 0.f : val.z; val.w = val.w < 0.f ? 0.f : val.w;
-                    }
+                    if constexpr (KIND == 3) val = relu_keep_nan(val);
                 }
                 if constexpr (ONES) {                      // 1 inside the image, 0 in the padding
                     const float one = in ? 1.f : 0.f;
