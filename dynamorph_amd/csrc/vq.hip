@@ -892,6 +892,55 @@ __global__ void vq_finalize_kernel(const double *__restrict__ sse_slabs, int nsl
     }
 }
 
+// The training step's last scalar launch: vq_finalize_kernel + the reconstruction-loss finaliser in one, reading the
+// code counters straight from their replicas (no vq_hist_reduce launch before it).  out = (recon, commitment, total,
+// perplexity), same arithmetic as dm_vq_finalize followed by dm_loss_finalize.
+__global__ void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, int nslabs, const int *__restrict__ hrep, int R,
+                                        int K, long long P, int D, float cc, const double *__restrict__ loss_slabs, int nloss,
+                                        long long count, float w_recon, float w_commit, float *__restrict__ out)
+{
+    __shared__ double s_red[4];
+    double s = 0.0, l = 0.0, e = 0.0;
+    // (eight slabs per thread requested together: one memory round trip for up to 2048 slabs)
+    for (int i0 = threadIdx.x; i0 < nslabs; i0 += 8 * (int)blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int i = i0 + j * (int)blockDim.x; v[j] = i < nslabs ? sse_slabs[i] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (int i0 = threadIdx.x; i0 < nloss; i0 += 8 * (int)blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int i = i0 + j * (int)blockDim.x; v[j] = i < nloss ? loss_slabs[i] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l += v[j];
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        // (all replicas requested before the first is used: one memory round trip, not R)
+        int v[64];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) v[r] = r < R ? hrep[(long long)r * K + k] : 0;
+        int h = 0;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) h += v[r];
+        const float pk = (float)h / (float)P;
+        e += (double)(pk * logf(pk + 1e-10f));
+    }
+    const double sse = block_sum(s, s_red);
+    const double tot = block_sum(l, s_red);
+    const double ent = block_sum(e, s_red);
+    if (threadIdx.x == 0) {
+        const float mse = (float)(sse / ((double)P * (double)D));
+        const float commit = mse + cc * mse;
+        const float recon = (float)(tot / (double)count);
+        out[0] = recon;
+        out[1] = commit;
+        out[2] = w_recon * recon + w_commit * commit;
+        out[3] = expf(-(float)ent);
+    }
+}
+
 // 1024-thread workgroups walking the positions with a grid stride: the codebook gradient is accumulated in LDS
 // over ALL of a workgroup's positions and flushed once, so the global float atomics (K*D addresses that every
 // workgroup hits) number grid*K*D instead of (P/256)*K*D -- at B = 2048 that flush, not the streaming, was the cost.
@@ -1184,7 +1233,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
                       int B, int D, int K, int H, int W, void *workspace, size_t workspace_bytes, int variant, int repeats,
                       void *stream)
 {
-    DM_REQUIRE(z && codebook && sse_slabs && hist, "dm_vq_forward: NULL pointer");
+    DM_REQUIRE(z && codebook && sse_slabs, "dm_vq_forward: NULL pointer");     // hist == NULL: the counters stay in their replicas
     DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
     DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d not built (8/16/32/64/128)", D);
     DM_REQUIRE(workspace && workspace_bytes >= dm_vq_workspace_bytes(K, D), "dm_vq_forward: workspace too small");
@@ -1223,7 +1272,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
             }
         }
 #undef DM_VQ2
-        hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
+        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
         return dm_launch_status("dm_vq_forward");
     }
     const float *cbT = ws + L.cbT;
@@ -1240,7 +1289,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
     }
 #undef DM_VQ_FWD
-    hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
+    if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
     return dm_launch_status("dm_vq_forward");
 }
 }  // namespace
@@ -1271,6 +1320,21 @@ extern "C" int dm_vq_finalize(const double *sse_slabs, int nslabs, const int32_t
     hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                        sse_slabs, nslabs, (const int *)hist, K, (long long)positions, D, commitment_cost, scalars);
     return dm_launch_status("dm_vq_finalize");
+}
+
+extern "C" int dm_vq_loss_finalize(const double *sse_slabs, int nslabs, const void *workspace, int K, int D,
+                                   int64_t positions, float commitment_cost, const double *loss_slabs, int nloss,
+                                   int64_t count, float weight_recon, float weight_commitment, float *scalars_out,
+                                   void *stream)
+{
+    DM_REQUIRE(sse_slabs && workspace && loss_slabs && scalars_out && nslabs > 0 && nloss > 0 && K > 0 && D > 0 &&
+                   positions > 0 && count > 0, "dm_vq_loss_finalize: bad argument");
+    const Vq2Layout L = vq2_layout(K, D);
+    const int *hrep = reinterpret_cast<const int *>(reinterpret_cast<const float *>(workspace) + L.hrep);
+    hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sse_slabs, nslabs, hrep, L.R, K,
+                       (long long)positions, D, commitment_cost, loss_slabs, nloss, (long long)count, weight_recon,
+                       weight_commitment, scalars_out);
+    return dm_launch_status("dm_vq_loss_finalize");
 }
 
 namespace {

@@ -233,8 +233,13 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
 
 
 # ------------------------------------------------------------------------------------ VQ
-def vq_forward(codebook, z, commitment_cost, want_out=True):
+def vq_forward(codebook, z, commitment_cost, want_out=True, defer_scalars=False):
+    """defer_scalars (training pass): no scalar launches here; the third return value is the state
+    ops.vq_loss_finalize needs to produce them together with the reconstruction loss at the end of the step."""
     B, D, H, W = z.shape
+    if defer_scalars:
+        idx, out, slabs, ws = ops.vq_forward(z, _w(codebook), want_out=want_out, want_hist=False)
+        return out, idx, SimpleNamespace(slabs=slabs, ws=ws, K=codebook.shape[0], D=D, positions=B * H * W, cc=commitment_cost)
     idx, out, slabs, hist = ops.vq_forward(z, _w(codebook), want_out=want_out)
     scalars = ops.vq_finalize(slabs, hist, B * H * W, D, commitment_cost)     # (loss, perplexity, mse)
     return out, idx, scalars

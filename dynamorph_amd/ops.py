@@ -88,8 +88,10 @@ def _new(shape, like, dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------- VQ
-def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, want_rechecked=False):
+def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, want_rechecked=False, want_hist=True):
     """Returns (idx int64 (B,H,W), out (B,D,H,W), sse_slabs, hist).
+    want_hist=False: no counter reduction is launched; the fourth return value is then the WORKSPACE holding the counter
+    replicas, for vq_loss_finalize.
     variant: L.DM_VQ_AUTO (default) / DM_VQ_EXACT / DM_VQ_MFMA -- same results, different kernels (include/dynamorph_hip.h).
     want_rechecked: a fifth return value, the 1-element int32 device tensor counting the positions the MFMA kernel
     re-evaluated exactly (0 after the exact kernel)."""
@@ -100,7 +102,7 @@ def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, 
     idx = _new((B, H, W), z, torch.int64) if want_idx else None
     out = torch.empty_like(z) if want_out else None
     slabs = _new((nb,), z, torch.float64)
-    hist = _new((K,), z, torch.int32)          # cleared by dm_vq_forward itself
+    hist = _new((K,), z, torch.int32) if want_hist else None         # cleared by dm_vq_forward itself
     wsb = lib.dm_vq_workspace_bytes(K, D)
     ws = _new((wsb // 4,), z)
     L.check(lib.dm_vq_forward_variant(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out),
@@ -108,7 +110,7 @@ def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, 
                                       variant, _stream()), "dm_vq_forward")
     if want_rechecked:
         return idx, out, slabs, hist, ws[:1].view(torch.int32)
-    return idx, out, slabs, hist
+    return idx, out, slabs, (hist if want_hist else ws)
 
 
 def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None):
@@ -135,6 +137,17 @@ def vq_finalize(slabs, hist, positions, D, commitment_cost):
     L.check(lib.dm_vq_finalize(_ptr(slabs, torch.float64), slabs.numel(), _ptr(hist, torch.int32), hist.numel(),
                                positions, D, commitment_cost, _ptr(scalars), _stream()), "dm_vq_finalize")
     return scalars
+
+
+def vq_loss_finalize(sse_slabs, ws, K, D, positions, commitment_cost, loss_slabs, count, weight_recon, weight_commitment):
+    """(recon, commitment, total, perplexity) in one launch: vq_finalize + loss_finalize on the counter replicas that
+    vq_forward(..., want_hist=False) left in its workspace `ws`."""
+    lib = L.load()
+    out = _new((4,), sse_slabs)
+    L.check(lib.dm_vq_loss_finalize(_ptr(sse_slabs, torch.float64), sse_slabs.numel(), _ptr(ws), K, D, positions,
+                                    commitment_cost, _ptr(loss_slabs, torch.float64), loss_slabs.numel(), count,
+                                    weight_recon, weight_commitment, _ptr(out), _stream()), "dm_vq_loss_finalize")
+    return out
 
 
 def vq_decode(idx, codebook):

@@ -86,13 +86,14 @@ class FusedTrainer:
         L = E.Layers(model)
         cc = float(model.commitment_cost)
         z, ecx = E.encoder_forward(L, x)
-        zq, idx, vsc = E.vq_forward(L.codebook.weight, z, cc)
+        zq, idx, vqs = E.vq_forward(L.codebook.weight, z, cc, defer_scalars=True)
         # the tail of the decoder (dec.4, dec.6, loss) runs inside decoder_backward, fused with its own backward
         dec, dcx = E.decoder_forward(L, zq, x, mask, defer_tail=True)
         B, NIN, H, W = x.shape
         g_zq = E.decoder_backward(L, dcx, self.w_recon, None, self.G)
-        scalars = ops.loss_finalize(dcx.loss_slabs, B * NIN * H * W, vsc, float(model.weight_recon),
-                                    float(model.weight_commitment))
+        # (recon, commitment, total, perplexity): the VectorQuantizer's scalars and the reconstruction loss in one launch
+        scalars = ops.vq_loss_finalize(vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, dcx.loss_slabs,
+                                       B * NIN * H * W, float(model.weight_recon), float(model.weight_commitment))
         gcb = self.G(L.codebook.weight)
         # codebook gradient as slabs, added in the encoder's single slab reduction: nothing to zero, no global atomics
         # (K <= 64: an ordered one-hot product on the matrix cores, bit-reproducible; larger K: LDS adds in arrival order)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 108
+#define DM_VERSION 109
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -138,6 +138,14 @@ int dm_vq_decode(const int64_t *idx, const float *codebook, float *q,
  * (vq_vae.py:74-82): scalars[0] = loss = mse + cc*mse, [1] = perplexity, [2] = mse. */
 int dm_vq_finalize(const double *sse_slabs, int nslabs, const int32_t *hist, int K,
                    int64_t positions, int D, float commitment_cost, float *scalars, void *stream);
+
+/* dm_vq_forward with hist = NULL leaves the code counters in the workspace's replicas (no reduction launch); this entry
+ * then produces the training step's four scalars -- (recon, commitment, total, perplexity), the arithmetic of
+ * dm_vq_finalize followed by dm_loss_finalize -- in ONE launch from the sse slabs, the workspace of that very
+ * dm_vq_forward call and the reconstruction-loss slabs (vq_vae.py:74-82, 320-323, 333-336). */
+int dm_vq_loss_finalize(const double *sse_slabs, int nslabs, const void *workspace, int K, int D,
+                        int64_t positions, float commitment_cost, const double *loss_slabs, int nloss,
+                        int64_t count, float weight_recon, float weight_commitment, float *scalars_out, void *stream);
 
 /* Autograd of vq_vae.py:71-76 for upstream (g_out, g_loss):
  *   dz = g_out + g_loss*2*cc*(z-q)/N   [g_out may be NULL = 0]

@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header():
 def test_version_and_host_only_queries(lib):
     assert lib.dm_vq_backward_num_slabs(524288, 64, 16) == 512 and lib.dm_vq_backward_num_slabs(262144, 4096, 16) == 128
     assert lib.dm_vq_backward_num_slabs(3000, 64, 16) == 3 and lib.dm_vq_backward_num_slabs(1 << 22, 65536, 16) == 32
-    assert lib.dm_version() == 108          # 104: dm_vq_forward_variant (MFMA filter + exact re-check); 105: dm_vq_forward_repeat
+    assert lib.dm_version() == 109          # 104: dm_vq_forward_variant (MFMA filter + exact re-check); 105: dm_vq_forward_repeat
     # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows (csrc/vq.hip)
     # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows + counter replicas
     assert lib.dm_vq_workspace_bytes(64, 16) == (32 + 64 * 16 + 64 * 16 + 64 + 64 * 16 + 64 * 64) * 4
@@ -68,7 +68,7 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_conv3x3_scratch_floats(64, 64, 33, 32, 9, 0, 0) == 0                 # not tileable by 8 x 16: generic kernel
     assert lib.dm_conv4x4s2_scratch_floats(8, 16, 64, 64, 0) == 0 and lib.dm_conv4x4s2_scratch_floats(8, 16, 64, 64, 1) > 0
     assert lib.dm_conv4x4s2_scratch_floats(32, 64, 64, 64, 0) > 0
-    assert lib.dm_channel_stats_num_blocks(20, 16, 16, 16) == 3
+    assert lib.dm_channel_stats_num_blocks(20, 16, 16, 16) == 1 and lib.dm_channel_stats_num_blocks(2048, 16, 16, 16) == 64   # 32 samples per workgroup
 
 
 def test_argument_errors_are_reported_before_any_launch(lib):
