@@ -36,7 +36,7 @@ class Scatter(C.Structure):
 
 
 class ReduceSeg(C.Structure):
-    _fields_ = [("slabs", vp), ("dst", vp), ("nslabs", i32), ("E", i32)]
+    _fields_ = [("slabs", vp), ("dst", vp), ("nslabs", i32), ("E", i32), ("stride", i32), ("pairs_of_doubles", i32)]
 
 
 class ReplaySeg(C.Structure):

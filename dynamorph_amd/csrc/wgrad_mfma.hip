@@ -353,6 +353,8 @@ struct ReduceSegs {
     float *dst[16];
     int nslabs[16];
     int E[16];
+    int stride[16];           // elements from one slab to the next (float slabs: E)
+    int dbl[16];              // 1: the slabs are (value, second value) double pairs of a statistics epilogue; the first is summed
     int first_block[17];      // prefix sums of ceil(E/16)
     int nseg;
 };
@@ -367,6 +369,31 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceSegs rs)
     const int E = rs.E[k], nslabs = rs.nslabs[k];
     const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int e = ((int)blockIdx.x - rs.first_block[k]) * 16 + el;
+    if (rs.dbl[k]) {
+        // bias gradients and the like: (sum, -) double pairs written by a statistics epilogue, summed in double as
+        // dm_sum_slabs does (they ride in this launch instead of taking one of their own)
+        __shared__ double dpart[16][17];
+        const double *__restrict__ ds = reinterpret_cast<const double *>(slabs);
+        const long long st = rs.stride[k];
+        double a0 = 0.0, a1 = 0.0;
+        if (e < E) {
+            int i = g;
+            for (; i + 16 < nslabs; i += 32) {
+                const double a = ds[((long long)i * st + e) * 2], b = ds[((long long)(i + 16) * st + e) * 2];
+                a0 += a; a1 += b;
+            }
+            for (; i < nslabs; i += 16) a0 += ds[((long long)i * st + e) * 2];
+        }
+        dpart[g][el] = a0 + a1;
+        __syncthreads();
+        if (g == 0 && e < E) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += dpart[j][el];
+            rs.dst[k][e] = (float)t;
+        }
+        return;
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < E) {
         int i = g;
@@ -437,6 +464,8 @@ extern "C" int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *
         if (on) DM_REQUIRE(segs[k].slabs && segs[k].dst && segs[k].nslabs > 0 && segs[k].E > 0, "dm_reduce_slabs_multi: bad segment %d", k);
         rs.slabs[k] = on ? segs[k].slabs : nullptr; rs.dst[k] = on ? segs[k].dst : nullptr;
         rs.nslabs[k] = on ? segs[k].nslabs : 0; rs.E[k] = on ? segs[k].E : 0;
+        rs.dbl[k] = on ? (segs[k].pairs_of_doubles ? 1 : 0) : 0;
+        rs.stride[k] = on ? (segs[k].stride > 0 ? segs[k].stride : segs[k].E) : 0;
         rs.first_block[k] = blocks;
         if (on) blocks += (segs[k].E + 15) / 16;
     }

@@ -320,29 +320,29 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
             raise ValueError("decoder_backward: a deferred tail takes the reconstruction-loss gradient only")
         g2, part, wsl, cx.loss_slabs = ops.dec_tail_train(cx.d2, _w(L.dec4.weight), _w(L.dec4.bias), _w(L.dec6.weight),
                                                           _w(L.dec6.bias), cx.x, cx.mask, var, gscale)
-        ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias), G(L.dec2.bias)])
+        ops.pend_stats(pending, part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias), G(L.dec2.bias)])
         pending.append((wsl, G(L.dec4.weight)))
     elif cx.d4 is None and gdec_ext is None and gscale is not None:
         # fused tail: recompute d4 from d2, g4 lives only in LDS
         g2, part, wsl = ops.dec_tail_backward(cx.d2, _w(L.dec4.weight), _w(L.dec4.bias), _w(L.dec6.weight), cx.dec, cx.x,
                                               cx.mask, var, gscale)
-        ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias), G(L.dec2.bias)])
+        ops.pend_stats(pending, part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias), G(L.dec2.bias)])
         pending.append((wsl, G(L.dec4.weight)))
     else:
         d4 = cx.d4 if cx.d4 is not None else _dec4_forward(L, cx.d2)
         if ops.head_supported(c2, NIN):
             g4, part = ops.head_backward(cx.dec, cx.x, cx.mask, var, d4, _w(L.dec6.weight), gscale, gdec_ext)
-            ops.sum_slabs_scatter(part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias)])
+            ops.pend_stats(pending, part, [G(L.dec6.weight), G(L.dec6.bias), G(L.dec4.bias)])
         else:
             g4 = _head_backward_unfused(L, cx, d4, var, gscale, gdec_ext, G, pending)
         ops.wgrad(Op(cx.d2), Op(g4), G(L.dec4.weight), B, c2, c2, 4 * H3, 4 * W3, 4, pending=pending)
         g2, st = ops.conv4x4s2(Op(g4), weight_view(_w(L.dec4.weight), c2 * 16, 16, 4, 1), B, c2, c2, 8 * H3, 8 * W3,
                                want_stats=True, mask=Op(cx.d2))
-        ops.sum_slabs(st, G(L.dec2.bias))
+        ops.pend_stats(pending, st, [G(L.dec2.bias)])
     ops.wgrad(Op(cx.d0), Op(g2), G(L.dec2.weight), B, c1, c2, 2 * H3, 2 * W3, 4, pending=pending)
     g0, st = ops.conv4x4s2(Op(g2), weight_view(_w(L.dec2.weight), c2 * 16, 16, 4, 1), B, c2, c1, 4 * H3, 4 * W3,
                            want_stats=True, mask=Op(cx.d0))
-    ops.sum_slabs(st, G(L.dec0.bias))
+    ops.pend_stats(pending, st, [G(L.dec0.bias)])         # bias gradients ride in the one slab reduction below
     ops.wgrad(Op(zq), Op(g0), G(L.dec0.weight), B, nh, c1, H3, W3, 4, pending=pending)
     ops.reduce_slabs_multi(pending)                  # all decoder weight gradients in one launch
     if not want_gz:

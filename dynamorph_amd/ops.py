@@ -250,14 +250,34 @@ def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
     return dst
 
 
+def pend_stats(pending, stats, dsts):
+    """Queue the column sums of a statistics slab tensor (nslabs, N, 2) for reduce_slabs_multi: consecutive runs of
+    columns go to the tensors `dsts` (what sum_slabs / sum_slabs_scatter would do in a launch of their own)."""
+    col = 0
+    for d in dsts:
+        pending.append((stats, d, col))
+        col += d.numel()
+    if col != stats.shape[1]:
+        raise ValueError("pend_stats: destinations must cover the slab's columns")
+
+
 def reduce_slabs_multi(pending):
-    """One launch for every (slabs, dst) pair collected by wgrad(..., pending=...)."""
+    """One launch for every (slabs, dst) pair collected by wgrad(..., pending=...) and every (stats, dst, column) run
+    queued by pend_stats."""
     lib = L.load()
     while pending:
         chunk, pending[:] = pending[:16], pending[16:]
         segs = (L.ReduceSeg * len(chunk))()
-        for i, (slabs, dst) in enumerate(chunk):
-            segs[i] = L.ReduceSeg(_ptr(slabs), _ptr(dst), slabs.shape[0], slabs.shape[1])
+        for i, item in enumerate(chunk):
+            if len(item) == 3:      # (stats (nslabs, N, 2) float64, dst, first column): a run of columns of a statistics slab
+                stats, dst, col = item
+                if stats.dtype != torch.float64 or stats.dim() != 3 or col + dst.numel() > stats.shape[1]:
+                    raise ValueError("reduce_slabs_multi: bad statistics segment")
+                _ptr(stats, torch.float64)
+                segs[i] = L.ReduceSeg(stats.data_ptr() + 16 * col, _ptr(dst), stats.shape[0], dst.numel(), stats.shape[1], 1)
+            else:
+                slabs, dst = item
+                segs[i] = L.ReduceSeg(_ptr(slabs), _ptr(dst), slabs.shape[0], slabs.shape[1], 0, 0)
         L.check(lib.dm_reduce_slabs_multi(segs, len(chunk), _stream()), "dm_reduce_slabs_multi")
 
 

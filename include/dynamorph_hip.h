@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 109
+#define DM_VERSION 110
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -315,6 +315,9 @@ typedef struct dm_reduce_seg {
     float *dst;
     int32_t nslabs;
     int32_t E;
+    int32_t stride;             /* elements from one slab to the next; 0 = E (dense float slabs) */
+    int32_t pairs_of_doubles;   /* 1: `slabs` points at (value, -) double pairs of a statistics epilogue (bias gradients,
+                                   dm_sum_slabs' input): the first of each pair is summed in double; stride counts pairs */
 } dm_reduce_seg;
 int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *stream);
 
