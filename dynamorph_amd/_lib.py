@@ -116,19 +116,32 @@ class DynamorphHipError(RuntimeError):
 
 
 class _CallDevice(threading.local):
-    """Device of the tensors handed to the call being assembled (dynamorph_amd.ops._ptr records it)."""
+    """Device of the tensors handed to the call being assembled (dynamorph_amd.ops._ptr records it; ops._op clears it at
+    the start and at the end of every tensor-level wrapper, so an exception half-way through assembling a launch cannot
+    leave a stale index behind)."""
     index = None
 
 
 call_device = _CallDevice()
 
+# entry points that only compute on the host (grid sizes, scratch sizes, capability queries): they touch no device, so
+# they are bound without the device guard and do NOT consume the device recorded for the launch being assembled
+HOST_ONLY_SUFFIXES = ("_num_blocks", "_num_slabs", "_scratch_floats", "_workspace_bytes", "_workspace_floats", "_supported")
+HOST_ONLY = ("dm_last_error", "dm_version")
+
+
+def is_host_only(name):
+    return name in HOST_ONLY or name.endswith(HOST_ONLY_SUFFIXES)
+
 
 def _guarded(fn):
-    """The entry points take raw pointers and enqueue on whatever device is current, so the tensors' device is made
-    current around the call (the reference hands non-zero gpu ids to its workers, run_VAE.py:78-85): a kernel launched on
-    device 0's stream against device-N memory is a fault or a silent race."""
+    """The launching entry points take raw pointers and enqueue on whatever device is current, so the tensors' device is
+    made current around the call (the reference hands non-zero gpu ids to its workers, run_VAE.py:78-85): a kernel
+    launched on device 0's stream against device-N memory is a fault or a silent race.  The device is the one ops._ptr
+    recorded for this call; it stays recorded until the wrapper returns (ops._op), so every pointer of a call is checked
+    against it, whatever host-only queries run in between."""
     def call(*args):
-        dev, call_device.index = call_device.index, None
+        dev = call_device.index
         if dev is None:
             return fn(*args)
         import torch
@@ -141,12 +154,13 @@ def _guarded(fn):
 
 
 class _Library:
-    """Attribute access to the C entry points, each behind the device guard."""
+    """Attribute access to the C entry points; the launching ones sit behind the device guard."""
 
     def __init__(self, cdll):
         self._cdll = cdll
         for name in SIGNATURES:
-            setattr(self, name, _guarded(getattr(cdll, name)))
+            fn = getattr(cdll, name)
+            setattr(self, name, fn if is_host_only(name) else _guarded(fn))
 
 
 def load():

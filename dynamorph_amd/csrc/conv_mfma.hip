@@ -131,7 +131,7 @@ __device__ __forceinline__ void epilogue_tail(f32x4 v, const Epilogue &ep, const
 __device__ __forceinline__ f32x4 bias_relu(f32x4 v, const Epilogue &ep, float bias)
 {
     v += bias;
-    if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (ep.relu) v = dm_relu4(v);
     return v;
 }
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ void convT_pair(const RowVals &P, const RowVals &C, c
     lo.x += lane_from_left(slo.x); lo.y += lane_from_right(slo.y);
     hi.x += lane_from_left(shi.x); hi.y += lane_from_right(shi.y);
 }
-__device__ __forceinline__ f32x2 relu2(f32x2 v) { return (f32x2){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}; }
+__device__ __forceinline__ f32x2 relu2(f32x2 v) { return (f32x2){dm_relu(v.x), dm_relu(v.y)}; }
 
 // =================================================================================== forward
 template <int NIN>

@@ -105,15 +105,17 @@ static inline int dm_check_operand(const dm_operand *o, const char *who)
 }
 
 #ifdef __HIPCC__
+// ReLU as torch.relu defines it: negative numbers to 0, every NaN (either sign) kept -- fmaxf / v_max_f32 would return 0
+// for a NaN and hide it from everything downstream.
+__device__ __forceinline__ float dm_relu(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ f32x4 dm_relu4(f32x4 v) { return (f32x4){dm_relu(v.x), dm_relu(v.y), dm_relu(v.z), dm_relu(v.w)}; }
+
 // Load 4 contiguous elements of channel c / sample b through the operand's transform.
 __device__ __forceinline__ f32x4 operand_load4(const Operand &op, long long off, int b, int c)
 {
     f32x4 v = *reinterpret_cast<const f32x4 *>(op.p0 + off);
     if (op.mode == DM_LOAD_IDENT) return v;
-    if (op.mode == DM_LOAD_RELU) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        return v;
-    }
+    if (op.mode == DM_LOAD_RELU) return dm_relu4(v);
     const float *cf = op.coef + (long long)b * op.coef_bstride + c * 4;
     const float c0 = cf[0], c2 = cf[2];
     if (op.mode == DM_LOAD_AFFINE2) {
@@ -123,9 +125,7 @@ __device__ __forceinline__ f32x4 operand_load4(const Operand &op, long long off,
         return v;
     }
     v = c0 * v + c2;
-    if (op.mode == DM_LOAD_AFFINE_RELU) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
+    if (op.mode == DM_LOAD_AFFINE_RELU) v = dm_relu4(v);
     return v;
 }
 

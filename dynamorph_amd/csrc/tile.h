@@ -59,16 +59,12 @@ __device__ __forceinline__ void stage_coef(float *__restrict__ s_coef, const Ope
 
 typedef unsigned short dm_u16x2 __attribute__((ext_vector_type(2)));
 
-// ReLU as ONE integer instruction per value: max(bits, 0) on the sign-magnitude float keeps every non-negative number
-// and the (positive, as the hardware generates them) NaNs, and sends every negative number and -0 to +0 --
-// v_max_f32 would return 0 for a NaN (torch.relu keeps it), a compare + select costs two instructions.
-__device__ __forceinline__ f32x4 relu_keep_nan(f32x4 v)
-{
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 b = __builtin_bit_cast(i32x4, v);
-    b.x = b.x > 0 ? b.x : 0; b.y = b.y > 0 ? b.y : 0; b.z = b.z > 0 ? b.z : 0; b.w = b.w > 0 ? b.w : 0;
-    return __builtin_bit_cast(f32x4, b);
-}
+// ReLU that keeps EVERY NaN, as torch.relu does: (v < 0) ? 0 : v -- the ordered compare is false for a NaN of either
+// sign, so it passes through; -0 < 0 is false as well, so -0 stays -0 (as it does through ATen's clamp_min).
+// v_max_f32 would return 0 for a NaN; the one-instruction integer form max(bits, 0) used until round 2 kept only the
+// positive NaNs and turned a NaN with the sign bit set (x86's default 0/0 = 0xFFC00000 arriving in the data, and
+// whatever FMAs propagate from it) into +0.  Costs a compare + a select per value.
+__device__ __forceinline__ f32x4 relu_keep_nan(f32x4 v) { return dm_relu4(v); }
 
 template <int CIN, int ROWS, int COLS4, int RS, int PS, bool TWO>
 struct TileStage {

@@ -5,6 +5,7 @@ Nothing here computes on the host and nothing falls back to ATen: a tensor that 
 contiguous fp32 device tensor is an error.
 """
 import ctypes as C
+import functools
 
 import torch
 
@@ -19,6 +20,20 @@ def _stream():
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+def _op(fn):
+    """Every tensor-level wrapper below is one "call": the device recorded by _ptr is cleared when it starts and when it
+    ends (also on an exception), so a half-assembled launch can never leak its device into the next call, and every pointer
+    marshalled for the launch -- before or after host-only queries -- is checked against the same device."""
+    @functools.wraps(fn)
+    def call(*args, **kw):
+        L.call_device.index = None
+        try:
+            return fn(*args, **kw)
+        finally:
+            L.call_device.index = None
+    return call
+
+
 def _ptr(t, dtype=torch.float32):
     if t is None:
         return None
@@ -28,13 +43,17 @@ def _ptr(t, dtype=torch.float32):
         raise ValueError(f"dynamorph_amd: expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError("dynamorph_amd: tensor must be contiguous")
-    dev = t.device.index
+    _note_device(t.device.index)
+    return t.data_ptr()
+
+
+def _note_device(dev):
+    """First operand of a call: its device becomes the call's; every later one must live there too."""
     if L.call_device.index is None:
         L.call_device.index = dev
     elif L.call_device.index != dev:
-        first, L.call_device.index = L.call_device.index, None
-        raise ValueError(f"dynamorph_amd: operands of one call live on different devices (cuda:{first} and cuda:{dev})")
-    return t.data_ptr()
+        raise ValueError(f"dynamorph_amd: operands of one call live on different devices "
+                         f"(cuda:{L.call_device.index} and cuda:{dev})")
 
 
 class Op:
@@ -60,9 +79,16 @@ class WView:
     __slots__ = ("struct", "_keep", "_scratch")
 
     def __init__(self, w, sn, sc, sky, skx, off=0):
+        if not (w.is_cuda and w.dtype == torch.float32):
+            raise ValueError("dynamorph_amd: weights must be fp32 device tensors (the HIP path has no CPU fallback)")
         self._keep = w
         self._scratch = None
-        self.struct = L.WeightView(_ptr(w), off, sn, sc, sky, skx, None, 0)
+        self.struct = L.WeightView(w.data_ptr(), off, sn, sc, sky, skx, None, 0)
+
+    def ref(self):
+        """The struct for a launch; records / checks the weights' device like every other operand of the call."""
+        _note_device(self._keep.device.index)
+        return C.byref(self.struct)
 
     def with_scratch(self, nfloats):
         """Attach `nfloats` of device scratch (dm_weight_view.scratch; what dm_conv*_scratch_floats asked for)."""
@@ -88,6 +114,7 @@ def _new(shape, like, dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------- VQ
+@_op
 def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, want_rechecked=False, want_hist=True):
     """Returns (idx int64 (B,H,W), out (B,D,H,W), sse_slabs, hist).
     want_hist=False: no counter reduction is launched; the fourth return value is then the WORKSPACE holding the counter
@@ -113,6 +140,7 @@ def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, 
     return idx, out, slabs, (hist if want_hist else ws)
 
 
+@_op
 def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None):
     """Measurement helper (include/dynamorph_hip.h, dm_vq_forward_repeat): one preparation, `repeats` launches of the
     distance / argmin kernel, one counter reduction, on preallocated buffers `bufs` (from a first call) so that nothing is
@@ -131,6 +159,7 @@ def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None):
     return bufs
 
 
+@_op
 def vq_finalize(slabs, hist, positions, D, commitment_cost):
     lib = L.load()
     scalars = _new((3,), slabs)
@@ -139,6 +168,7 @@ def vq_finalize(slabs, hist, positions, D, commitment_cost):
     return scalars
 
 
+@_op
 def vq_loss_finalize(sse_slabs, ws, K, D, positions, commitment_cost, loss_slabs, count, weight_recon, weight_commitment):
     """(recon, commitment, total, perplexity) in one launch: vq_finalize + loss_finalize on the counter replicas that
     vq_forward(..., want_hist=False) left in its workspace `ws`."""
@@ -150,6 +180,7 @@ def vq_loss_finalize(sse_slabs, ws, K, D, positions, commitment_cost, loss_slabs
     return out
 
 
+@_op
 def vq_decode(idx, codebook):
     lib = L.load()
     B, H, W = idx.shape
@@ -159,6 +190,7 @@ def vq_decode(idx, codebook):
     return q
 
 
+@_op
 def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_dz=True):
     """g_loss: 1-element device tensor (or None = 1).  dw given: accumulated into with float atomics (zero it first);
     dw None: a fresh tensor from the slab form (see vq_backward_slabs for when that form is ordered)."""
@@ -174,6 +206,7 @@ def vq_backward(z, codebook, idx, g_out, g_loss, commitment_cost, dw=None, want_
     return dz, dw
 
 
+@_op
 def vq_backward_slabs(z, codebook, idx, g_out, g_loss, commitment_cost, want_dz=True):
     """Like vq_backward, but the codebook gradient comes back as per-workgroup slabs (nslabs, K*D) for
     reduce_slabs / reduce_slabs_multi: no global float atomics, nothing to zero.  Codebooks of at most 64 codes with
@@ -192,6 +225,7 @@ def vq_backward_slabs(z, codebook, idx, g_out, g_loss, commitment_cost, want_dz=
 
 
 # ---------------------------------------------------------------------- convolutions
+@_op
 def conv4x4s2(inp, wv, B, CIN, NOUT, H, W, ep=None, out=None, want_stats=False, like=None, **epkw):
     lib = L.load()
     like = like if like is not None else inp.p0
@@ -208,11 +242,12 @@ def conv4x4s2(inp, wv, B, CIN, NOUT, H, W, ep=None, out=None, want_stats=False, 
     fallback = inp.mode == L.DM_LOAD_AFFINE2 or (epkw.get("bias_border") is not None and
                                                   any(epkw.get(k) is not None for k in ("mask", "resid", "stat_q")))
     wv.with_scratch(lib.dm_conv4x4s2_scratch_floats(CIN, NOUT, H, W, 1 if fallback else 0))
-    L.check(lib.dm_conv4x4s2(C.byref(o), C.byref(wv.struct), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, _stream()),
+    L.check(lib.dm_conv4x4s2(C.byref(o), wv.ref(), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, _stream()),
             "dm_conv4x4s2")
     return out, stats
 
 
+@_op
 def conv3x3(inp, wv, B, CIN, NOUT, H, W, taps=9, pixel_shuffle=False, out=None, want_stats=False, like=None, **epkw):
     lib = L.load()
     like = like if like is not None else inp.p0
@@ -229,11 +264,12 @@ def conv3x3(inp, wv, B, CIN, NOUT, H, W, taps=9, pixel_shuffle=False, out=None, 
     o = inp.struct()
     wv.with_scratch(lib.dm_conv3x3_scratch_floats(CIN, NOUT, H, W, taps, 1 if pixel_shuffle else 0,
                                                   1 if epkw.get("per_tile") else 0))
-    L.check(lib.dm_conv3x3(C.byref(o), C.byref(wv.struct), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, taps,
+    L.check(lib.dm_conv3x3(C.byref(o), wv.ref(), _ptr(out), C.byref(e), B, CIN, NOUT, H, W, taps,
                            1 if pixel_shuffle else 0, _stream()), "dm_conv3x3")
     return out, stats
 
 
+@_op
 def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
     """dst (CS*CT*k*k floats, any shape) <- sum over batch/positions; deterministic slab reduction.
     pending: a list -> the slabs are left unreduced and (slabs, dst) is appended for reduce_slabs_multi."""
@@ -261,6 +297,7 @@ def pend_stats(pending, stats, dsts):
         raise ValueError("pend_stats: destinations must cover the slab's columns")
 
 
+@_op
 def reduce_slabs_multi(pending):
     """One launch for every (slabs, dst) pair collected by wgrad(..., pending=...) and every (stats, dst, column) run
     queued by pend_stats."""
@@ -281,6 +318,7 @@ def reduce_slabs_multi(pending):
         L.check(lib.dm_reduce_slabs_multi(segs, len(chunk), _stream()), "dm_reduce_slabs_multi")
 
 
+@_op
 def sum_slabs_scatter(stats, dsts, scale=1.0):
     """stats (nslabs, N, 2) float64 -> consecutive runs of the N sums written straight into the tensors `dsts`."""
     lib = L.load()
@@ -299,6 +337,7 @@ def sum_slabs_scatter(stats, dsts, scale=1.0):
 
 
 # ------------------------------------------------------------------------ BatchNorm
+@_op
 def bn_finalize(stats, count_per_group, gamma, beta, running_mean, running_var, nbt, momentum, eps,
                 per_sample=False, slabs_per_group=1, defer=None):
     """defer (per_sample only): a list -> the running statistics are NOT touched by this launch; their update is appended
@@ -321,6 +360,7 @@ def bn_finalize(stats, count_per_group, gamma, beta, running_mean, running_var, 
     return coef, saved
 
 
+@_op
 def bn_running_replay(deferred):
     """One launch for the running statistics of every layer bn_finalize(..., defer=deferred) skipped."""
     lib = L.load()
@@ -333,6 +373,7 @@ def bn_running_replay(deferred):
         L.check(lib.dm_bn_running_replay(segs, len(chunk), _stream()), "dm_bn_running_replay")
 
 
+@_op
 def bn_backward_finalize(stats, count, gamma, saved, dgamma, dbeta):
     lib = L.load()
     nslabs, Cn = stats.shape[0], stats.shape[1]
@@ -342,6 +383,7 @@ def bn_backward_finalize(stats, count, gamma, saved, dgamma, dbeta):
     return coef_bwd
 
 
+@_op
 def apply(inp, B, Cn, H, W, resid=None, out=None):
     lib = L.load()
     if out is None:
@@ -351,6 +393,7 @@ def apply(inp, B, Cn, H, W, resid=None, out=None):
     return out
 
 
+@_op
 def channel_stats(p, q=None):
     lib = L.load()
     B, Cn, H, W = p.shape
@@ -360,6 +403,7 @@ def channel_stats(p, q=None):
     return stats
 
 
+@_op
 def sum_slabs(stats, dst, scale=1.0, n=None):
     """dst[i] = scale * sum_slabs stats[slab][i][0] for the first n = dst.numel() entries of the slab rows."""
     lib = L.load()
@@ -369,6 +413,7 @@ def sum_slabs(stats, dst, scale=1.0, n=None):
 
 
 # ------------------------------------------------------------------------------ head
+@_op
 def head_forward(d4, w6, b6, x, mask, channel_var):
     lib = L.load()
     B, C4, H, W = d4.shape
@@ -383,6 +428,7 @@ def head_forward(d4, w6, b6, x, mask, channel_var):
     return dec, slabs
 
 
+@_op
 def head_backward(dec, x, mask, channel_var, d4, w6, gscale, gdec_ext=None):
     """Returns (g4, part) with part: (nblocks, NIN*C4 + NIN + C4, 2) float64 slabs."""
     lib = L.load()
@@ -405,6 +451,7 @@ def dec_tail_supported(c2, nin, h2, w2):
     return bool(L.load().dm_dec_tail_supported(c2, nin, h2, w2))
 
 
+@_op
 def dec_tail_forward(d2, w4, b4, w6, b6, x, mask, channel_var):
     """Fused dec.4 + ReLU + dec.6 (+ masked reconstruction loss partials when x is given)."""
     lib = L.load()
@@ -419,6 +466,7 @@ def dec_tail_forward(d2, w4, b4, w6, b6, x, mask, channel_var):
     return dec, slabs
 
 
+@_op
 def dec_tail_backward(d2, w4, b4, w6, dec, x, mask, channel_var, gscale):
     """Returns (g2, part (nb, NIN*4+NIN+8, 2) float64, w_slabs (nb, 256) float32)."""
     lib = L.load()
@@ -435,6 +483,7 @@ def dec_tail_backward(d2, w4, b4, w6, dec, x, mask, channel_var, gscale):
     return g2, part, wsl
 
 
+@_op
 def dec_tail_train(d2, w4, b4, w6, b6, x, mask, channel_var, gscale):
     """Forward loss + backward of the decoder tail in one kernel (no `decoded`).
     Returns (g2, part, w_slabs, loss_slabs)."""
@@ -453,12 +502,14 @@ def dec_tail_train(d2, w4, b4, w6, b6, x, mask, channel_var, gscale):
     return g2, part, wsl, loss
 
 
+@_op
 def reduce_slabs(slabs, dst):
     lib = L.load()
     L.check(lib.dm_reduce_slabs(_ptr(slabs), slabs.shape[0], slabs.shape[1], _ptr(dst), _stream()), "dm_reduce_slabs")
     return dst
 
 
+@_op
 def loss_finalize(loss_slabs, count, vq_scalars, weight_recon, weight_commitment):
     lib = L.load()
     out = _new((4,), vq_scalars)
@@ -468,6 +519,7 @@ def loss_finalize(loss_slabs, count, vq_scalars, weight_recon, weight_commitment
 
 
 # ------------------------------------------------------------------ plain reconstruction loss
+@_op
 def recon_loss(dec, x, mask, channel_var):
     """Partial sums (nblocks,) float64 of (dec*m - x*m)^2 / var for loss_finalize."""
     lib = L.load()
@@ -479,6 +531,7 @@ def recon_loss(dec, x, mask, channel_var):
     return slabs
 
 
+@_op
 def recon_loss_backward(dec, x, mask, channel_var, gscale):
     """(g_decoded, bias_slabs (nblocks, NIN, 2) float64)."""
     lib = L.load()
@@ -492,6 +545,7 @@ def recon_loss_backward(dec, x, mask, channel_var, gscale):
 
 
 # ------------------------------------------------------------------ time-matching loss
+@_op
 def pair_msd(z):
     """z (B, n) contiguous -> sim (B, B), sim[i][j] = mean((z[i] - z[j])**2)."""
     lib = L.load()
@@ -501,6 +555,7 @@ def pair_msd(z):
     return sim
 
 
+@_op
 def pair_msd_backward(z, g_sim):
     lib = L.load()
     B, n = z.shape
@@ -513,6 +568,7 @@ def time_matching_supported(B, n):
     return bool(L.load().dm_time_matching_supported(B, n))
 
 
+@_op
 def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0):
     """The whole pairwise term on the MFMA (include/dynamorph_hip.h, dm_time_matching_forward).  z (B, n), tm (B, B) float32.
     Returns (loss: 1-element device tensor, S (B, B) = dloss/dsim + its transpose, for time_matching_backward)."""
@@ -529,6 +585,7 @@ def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0):
     return loss, S
 
 
+@_op
 def time_matching_backward(z, S, g_loss=None, scale=1.0):
     """dz = scale * g_loss[0] * d loss / d z  (g_loss: 1-element device tensor or None = 1)."""
     lib = L.load()
@@ -540,6 +597,7 @@ def time_matching_backward(z, S, g_loss=None, scale=1.0):
 
 
 # ------------------------------------------------------------- composition / optimizer
+@_op
 def e1_compose(w0, b0, w1):
     lib = L.load()
     C0, NIN = w0.shape[0], w0.shape[1]
@@ -549,6 +607,7 @@ def e1_compose(w0, b0, w1):
     return weff
 
 
+@_op
 def e1_compose_border(w0, b0, w1, b1):
     """(weff, bias_border): bias_border (3, 3, C1) replaces the ones channel in the forward conv."""
     lib = L.load()
@@ -561,6 +620,7 @@ def e1_compose_border(w0, b0, w1, b1):
     return weff, table
 
 
+@_op
 def e1_chain(dweff, w0, b0, w1, dw0, db0, dw1):
     lib = L.load()
     C0, NIN = w0.shape[0], w0.shape[1]
@@ -569,18 +629,21 @@ def e1_chain(dweff, w0, b0, w1, dw0, db0, dw1):
                             _stream()), "dm_e1_chain")
 
 
+@_op
 def adam(param, grad, m, v, lr, beta1, beta2, eps, step_dev):
     lib = L.load()
     L.check(lib.dm_adam(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
                         _ptr(step_dev), _stream()), "dm_adam")
 
 
+@_op
 def adam_counted(param, grad, m, v, lr, beta1, beta2, eps, steps_done, steps_done_next):
     lib = L.load()
     L.check(lib.dm_adam_counted(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
                                 _ptr(steps_done), _ptr(steps_done_next), _stream()), "dm_adam_counted")
 
 
+@_op
 def zscore_patch(x):
     """x (N, C, H, W) float64 or float32 device tensor -> float32 z-scored patches (per patch and channel)."""
     lib = L.load()
@@ -595,6 +658,7 @@ def zscore_patch(x):
     return out
 
 
+@_op
 def augment(x, flip_code, rot_code):
     lib = L.load()
     B, Cn, H, W = x.shape

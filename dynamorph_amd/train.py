@@ -363,20 +363,33 @@ def get_mask(mask, sample_ids, device='cuda:0'):
 
 
 class _EpochLosses:
-    """Per-key sums of (local loss x local samples) over an epoch; `means()` exchanges them once so every rank holds the
-    global-batch means (and takes the same early-stopping decision)."""
+    """Epoch value of every entry of the loss dict.
 
-    def __init__(self, device):
-        self.sums, self.count, self.device = {}, 0.0, device
+    One process: the reference's aggregation, run_training.py:538-543 -- sum(per-batch values) / number of batches.
+    Data parallel (world > 1): every rank sees only its shard of a batch, so the per-key sums of (local loss x local
+    samples) and the sample count are exchanged ONCE per phase and every rank holds the same sample-weighted means (and
+    takes the same early-stopping decision).  With a ragged last batch that differs slightly from the mean of batch
+    values, and for the pairwise time-matching term (a sum over the LOCAL pairs, vq_vae.py:331) it is a different
+    quantity altogether: documented deviation, there is no multi-device behaviour in the reference to match.
+    The exchanged vector has the same length on every rank: the key list is rank 0's (rank 0 holds the first shard of
+    every batch, dist.shard_range, so it has data whenever any rank has); a rank that had no data in the whole phase
+    contributes zeros."""
+
+    def __init__(self, device, world=1):
+        self.values, self.sums, self.count, self.device, self.world = {}, {}, 0.0, device, world
 
     def add(self, batch_losses, n):
         for key, values in batch_losses.items():
-            self.sums[key] = self.sums.get(key, 0.0) + float(values[-1]) * n
+            v = float(values[-1])
+            self.values.setdefault(key, []).append(v)
+            self.sums[key] = self.sums.get(key, 0.0) + v * n
         self.count += n
 
     def means(self):
-        keys = sorted(self.sums)
-        tot = D.allreduce_sum_host([self.sums[k] for k in keys] + [self.count], device=self.device)
+        if self.world == 1:
+            return {k: sum(v) / len(v) for k, v in self.values.items()}
+        keys = D.broadcast_object(list(self.sums))
+        tot = D.allreduce_sum_host([self.sums.get(k, 0.0) for k in keys] + [self.count], device=self.device)
         return {k: v / max(tot[-1], 1.0) for k, v in zip(keys, tot[:-1])}
 
 
@@ -402,7 +415,10 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     batch loops, TensorBoard-style scalars, EarlyStopping checkpoint of the state_dict to <output_dir>/model.pt -- made
     data parallel (one process per GPU, torch.distributed initialised by the launcher):
 
-      * the validation split and every shuffle come from ONE seed drawn on rank 0, so all ranks walk the same batches;
+      * one process: split, shuffles and epoch losses exactly as the reference draws / aggregates them (numpy's global
+        generator in the reference's order, mean of the per-batch values);
+      * world > 1: the validation split and every shuffle come from ONE seed drawn on rank 0, so all ranks walk the same
+        batches;
       * each global batch of `batch_size` samples is cut into contiguous per-rank shards (dist.shard_range); a rank
         weights its gradient by n_local * world / n_global before the single all-reduce, so the averaged gradient is the
         global-batch mean loss's (BatchNorm statistics and the pairwise time-matching term stay rank-local: standard
@@ -425,13 +441,17 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     optimizer = _make_optimizer(model, lr, fused)
     model.zero_grad()
 
-    seed = D.broadcast_object(int(np.random.randint(0, 2 ** 31 - 1)))
-    order = np.random.RandomState(seed)                     # split and shuffles: the same stream on every rank
-    if world > 1:
-        np.random.seed((seed + 7919 * rank) % (2 ** 32))    # augmentation draws: a stream of its own per rank
     n_samples = len(dataset)
     sample_ids = list(range(n_samples))
     split = int(np.floor(val_split_ratio * n_samples))
+    if world == 1:
+        # the reference's draws from numpy's global generator, in the reference's order (run_training.py:490-493, 536):
+        # a caller's np.random.seed reproduces the reference's split and shuffles
+        order = np.random
+    else:
+        seed = D.broadcast_object(int(np.random.randint(0, 2 ** 31 - 1)))
+        order = np.random.RandomState(seed)                 # split and shuffles: the same stream on every rank
+        np.random.seed((seed + 7919 * rank) % (2 ** 32))    # augmentation draws: a stream of its own per rank
     split_start = int(order.randint(0, n_samples - split))
     if shuffle_data:
         order.shuffle(sample_ids)
@@ -446,7 +466,7 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
         say('start epoch %d' % epoch)
         epoch_means = {}
         for phase, ids in phases.items():
-            losses = _EpochLosses(dev if dev.type == "cuda" else None)
+            losses = _EpochLosses(dev if dev.type == "cuda" else None, world)
             for start in range(0, len(ids), batch_size):
                 ids_batch = ids[start:start + batch_size]
                 lo, hi = D.shard_range(len(ids_batch), rank, world)

@@ -86,10 +86,15 @@ def test_data_parallel_plumbing_world2(tmp_path):
 # oracle (same constructor / forward contract); what is under test is the LOOP: one seed for split and shuffles, contiguous
 # per-rank shards of every global batch, the weighted single gradient exchange, the collective early-stopping decision
 # and the rank-0 checkpoint.
-N_SAMPLES, BATCH, EPOCHS, LR = 22, 6, 2, 1e-3
+LR = 1e-3
+# (samples, batch, epochs, validation ratio).  The second case has a 1-sample last training batch and a 1-sample
+# validation set: rank 1's shard of both is EMPTY, so it joins the gradient exchange with zeros and the epoch-loss
+# exchange with no keys of its own (the vector must still have rank 0's length on every rank).
+TRAIN_CASES = [(22, 6, 2, 0.2), (7, 5, 1, 0.15)]
 
 
-def _train_worker(rank, world, port, out_dir):
+def _train_worker(rank, world, port, out_dir, case):
+    n_samples, batch, epochs, ratio = case
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -101,14 +106,14 @@ def _train_worker(rank, world, port, out_dir):
     torch.manual_seed(500 + rank)                       # different replicas: train() must broadcast rank 0's
     np.random.seed(11 + rank)                           # different host generators: the split must still agree
     model = O.OracleVQVAE()
-    data = torch.utils.data.TensorDataset(torch.randn(N_SAMPLES, 2, 128, 128, generator=torch.Generator().manual_seed(3)))
+    data = torch.utils.data.TensorDataset(torch.randn(n_samples, 2, 128, 128, generator=torch.Generator().manual_seed(3)))
     rows = {}
 
     class Scalars:
         def add_scalar(self, key, value, epoch):
             rows.setdefault(key, []).append(float(value))
-    train(model, data, os.path.join(out_dir, "run"), n_epochs=EPOCHS, lr=LR, batch_size=BATCH, device="cpu",
-          transform=None, val_split_ratio=0.2, patience=5, writer=Scalars(), fused=False)
+    train(model, data, os.path.join(out_dir, "run"), n_epochs=epochs, lr=LR, batch_size=batch, device="cpu",
+          transform=None, val_split_ratio=ratio, patience=5, writer=Scalars(), fused=False)
     torch.save({"params": [p.detach().clone() for p in model.parameters()], "rows": rows},
                os.path.join(out_dir, f"train_rank{rank}.pt"))
     dist.barrier()
@@ -116,16 +121,19 @@ def _train_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_train_loop_world2_shards_batches_and_checkpoints_on_rank0(tmp_path):
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=["even-shards", "empty-shards"])
+def test_train_loop_world2_shards_batches_and_checkpoints_on_rank0(tmp_path, case):
     from dynamorph_amd import dist as D
     from oracle import vqvae_oracle as O
+    n_samples, batch, epochs, ratio = case
     world = 2
-    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"train_rank{r}.pt")) for r in range(world)]
     # identical replicas after training, and rank 0 alone reported the epoch scalars
     for a, b in zip(res[0]["params"], res[1]["params"]):
         assert torch.equal(a, b)
-    assert len(res[0]["rows"]["Loss/total_loss"]) == EPOCHS and not res[1]["rows"]
+    assert len(res[0]["rows"]["Loss/total_loss"]) == epochs and not res[1]["rows"]
+    assert len(res[0]["rows"]["Val loss/total_loss"]) == epochs
     ck = torch.load(os.path.join(tmp_path, "run", "model.pt"))
     assert not os.path.exists(os.path.join(tmp_path, "run", "model.pt.tmp"))
 
@@ -134,17 +142,19 @@ def test_train_loop_world2_shards_batches_and_checkpoints_on_rank0(tmp_path):
     np.random.seed(11)
     model = O.OracleVQVAE()
     opt = O.make_adam(model, LR)
-    data = torch.randn(N_SAMPLES, 2, 128, 128, generator=torch.Generator().manual_seed(3))
+    data = torch.randn(n_samples, 2, 128, 128, generator=torch.Generator().manual_seed(3))
     seed = int(np.random.randint(0, 2 ** 31 - 1))       # what train() drew on rank 0
     order = np.random.RandomState(seed)
-    split = int(np.floor(0.2 * N_SAMPLES))
-    start = int(order.randint(0, N_SAMPLES - split))
-    ids = list(range(N_SAMPLES))
-    train_ids = ids[:start] + ids[start + split:]
+    split = int(np.floor(ratio * n_samples))
+    start = int(order.randint(0, n_samples - split))
+    ids = list(range(n_samples))
+    train_ids, val_ids = ids[:start] + ids[start + split:], ids[start:start + split]
+    if case == TRAIN_CASES[1]:
+        assert len(val_ids) == 1 and len(train_ids) % batch == 1         # the empty-shard situations really occur
     params = [p for p in model.parameters() if p.requires_grad]
-    for _ in range(EPOCHS):
-        for s0 in range(0, len(train_ids), BATCH):
-            gb = train_ids[s0:s0 + BATCH]
+    for epoch in range(epochs):
+        for s0 in range(0, len(train_ids), batch):
+            gb = train_ids[s0:s0 + batch]
             acc = [torch.zeros_like(p) for p in params]
             for r in range(world):
                 lo, hi = D.shard_range(len(gb), r, world)
@@ -156,13 +166,61 @@ def test_train_loop_world2_shards_batches_and_checkpoints_on_rank0(tmp_path):
             for a, p in zip(acc, params):
                 p.grad = a
             opt.step()
+        # the exchanged epoch value: sample-weighted mean over every rank's shards of the validation batches
+        tot = cnt = 0.0
+        for s0 in range(0, len(val_ids), batch):
+            gb = val_ids[s0:s0 + batch]
+            for r in range(world):
+                lo, hi = D.shard_range(len(gb), r, world)
+                if hi > lo:
+                    with torch.no_grad():
+                        tot += float(model(data[gb[lo:hi]])[1]["total_loss"]) * (hi - lo)
+                    cnt += hi - lo
+        assert abs(res[0]["rows"]["Val loss/total_loss"][epoch] - tot / cnt) <= 2e-5 * max(1.0, abs(tot / cnt))
     # (biases of convolutions that feed a train-mode BatchNorm have an identically zero gradient; autograd returns
     # +-1e-9 of rounding noise there, which Adam turns into +-lr steps whose signs depend on the summation order)
     noise = ("enc.1.bias", "enc.4.bias", "enc.7.bias", "enc.10.bias", ".1.bias", ".4.bias")
     for (name, w_), g in zip(model.named_parameters(), res[0]["params"]):
         if name.endswith(noise) and "enc" in name:
-            assert (g - w_).abs().max() <= 2.5 * LR * EPOCHS * 4
+            assert (g - w_).abs().max() <= 2.5 * LR * epochs * 4
             continue
         assert torch.allclose(g, w_.detach(), rtol=0, atol=2e-6), (name, float((g - w_).abs().max()))
     # the checkpoint holds one of the epochs' weights (the best validation loss), written by rank 0
     assert set(ck.keys()) == set(model.state_dict().keys())
+
+
+def test_single_process_train_keeps_the_reference_draws_and_aggregation(tmp_path):
+    """world == 1: split / shuffles from numpy's global generator in the reference's order (run_training.py:490-493,
+    536) and epoch losses as the mean of the per-batch values (run_training.py:538-543), ragged last batch included."""
+    sys.path.insert(0, ROOT)
+    from dynamorph_amd.train import train
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(9)
+    model = O.OracleVQVAE()
+    n, batch = 9, 4
+    data = torch.randn(n, 2, 128, 128, generator=torch.Generator().manual_seed(4))
+    rows = {}
+
+    class Scalars:
+        def add_scalar(self, key, value, epoch):
+            rows.setdefault(key, []).append(float(value))
+    np.random.seed(21)
+    train(model, torch.utils.data.TensorDataset(data), str(tmp_path / "run"), n_epochs=1, lr=LR, batch_size=batch,
+          device="cpu", shuffle_data=True, val_split_ratio=0.25, patience=3, writer=Scalars(), fused=False)
+    after = np.random.randint(0, 1 << 30)
+    # the reference's draw order on the same seed
+    np.random.seed(21)
+    split = int(np.floor(0.25 * n))
+    start = np.random.randint(0, n - split)
+    ids = list(range(n))
+    np.random.shuffle(ids)
+    train_ids = ids[:start] + ids[start + split:]
+    np.random.shuffle(train_ids)                       # end of epoch 0
+    assert after == np.random.randint(0, 1 << 30)      # same number of draws, same stream position
+    torch.manual_seed(9)
+    ref = O.OracleVQVAE()
+    opt = O.make_adam(ref, LR)
+    train_ids = ids[:start] + ids[start + split:]
+    per_batch = [float(O.train_step(ref, opt, data[train_ids[s:s + batch]])["total_loss"]) for s in range(0, len(train_ids), batch)]
+    assert len(per_batch) == 2 and len(train_ids) % batch != 0
+    assert abs(rows["Loss/total_loss"][0] - sum(per_batch) / len(per_batch)) <= 1e-6 * max(1.0, abs(per_batch[0]))

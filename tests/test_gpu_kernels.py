@@ -1055,3 +1055,46 @@ def test_dec_tail_fused_forward_backward(ops, nin, masked, B):
     close(flat_t[nin * c:nin * c + nin], b6.grad, 1e-4, 1e-4 * sc(b6.grad), "train: db6")
     close(flat_t[nin * c + nin:nin * c + nin + c], b4.grad, 1e-4, 1e-4 * sc(b4.grad), "train: db4")
     close(flat_t[nin * c + nin + c:], pre.grad.sum((0, 2, 3)), 1e-4, 1e-4 * sc(pre.grad.sum((0, 2, 3))), "train: db2")
+
+
+def _neg_nan():
+    """x86's default NaN (0/0 on the host): 0xFFC00000, sign bit set."""
+    return torch.tensor([-4194304], dtype=torch.int32).view(torch.float32)[0]
+
+
+def test_relu_keeps_nans_of_either_sign(ops):
+    """torch.relu keeps every NaN; until round 2 the operand-load ReLU (an integer max on the bits) turned a NaN with the
+    sign bit set into +0, and the epilogue / decoder-tail ReLUs (fmaxf) turned every NaN into 0.  A NaN patch must stay
+    visible in the latents, the reconstruction and the loss."""
+    B, C, H = 2, 16, 16
+    x = rnd(B, C, H, H, seed=1)
+    x[0, 3, 5, 7] = _neg_nan()
+    x[1, 9, 0, 0] = float("nan")
+    assert int(x.view(torch.int32)[0, 3, 5, 7]) < 0
+    coef = torch.stack([rnd(C, seed=4).abs() + 0.5, torch.zeros(C), rnd(C, seed=5) * 0.3, torch.zeros(C)], 1)
+    for mode in (1, 3):
+        # operand_load4 (dm_apply) and the tile commit of the MFMA convolutions (tile.h)
+        ref = load_ref(x, mode, coef) if mode == 3 else torch.relu(x)
+        out = ops.apply(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None), B, C, H, H)
+        assert torch.equal(torch.isnan(out.cpu()), torch.isnan(ref)) and int(torch.isnan(ref).sum()) == 2, mode
+        w = rnd(16, C, 3, 3, seed=2, scale=0.2)
+        refc = F.conv2d(ref, w, None, padding=1)
+        outc, _ = ops.conv3x3(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None),
+                              ops.weight_view(w.to(DEV), C * 9, 9, 3, 1), B, C, 16, H, H, taps=9)
+        nan_ref = torch.isnan(refc)
+        assert torch.equal(torch.isnan(outc.cpu()), nan_ref) and int(nan_ref.sum()) == 16 * (9 + 4), mode
+        close(torch.nan_to_num(outc.cpu()), torch.nan_to_num(refc), 2e-5, 2e-5, "finite part")
+    # epilogue ReLU of the transposed convolutions (dec.0 / dec.2) and the fused decoder tail (dec.4 + ReLU + dec.6)
+    wt = rnd(C, 8, 4, 4, seed=6, scale=0.2)
+    bias = rnd(8, seed=7)
+    ref = torch.relu(F.conv_transpose2d(x, wt, bias, stride=2, padding=1))
+    out, _ = ops.conv3x3(ops.Op(x.to(DEV)), ops.weight_view(wt.to(DEV), 16, 8 * 16, 4, 1), B, C, 4 * 8, H, H, taps=9,
+                         pixel_shuffle=True, bias=bias.to(DEV), relu=True)
+    assert torch.equal(torch.isnan(out.cpu()), torch.isnan(ref)) and int(torch.isnan(ref).sum()) > 0
+    d2 = rnd(B, 4, 64, 64, seed=8)
+    d2[1, 2, 10, 11] = _neg_nan()
+    w4, b4, w6, b6 = rnd(4, 4, 4, 4, seed=9, scale=0.3), rnd(4, seed=10), rnd(2, 4, 1, 1, seed=11), rnd(2, seed=12)
+    ref = F.conv2d(torch.relu(F.conv_transpose2d(d2, w4, b4, stride=2, padding=1)), w6, b6)
+    dec, _ = ops.dec_tail_forward(d2.to(DEV), w4.to(DEV), b4.to(DEV), w6.to(DEV), b6.to(DEV), None, None,
+                                  torch.ones(2, device=DEV))
+    assert torch.equal(torch.isnan(dec.cpu()), torch.isnan(ref)) and int(torch.isnan(ref).sum()) > 0

@@ -154,3 +154,57 @@ def test_relation_tensor_and_mask_slicing():
     bm = get_mask(TensorDataset(m), ids, device="cpu")
     assert bm.shape == (4, 1, 8, 8)
     assert torch.equal(bm, (m[ids][:, 1:2] + 1) / 2) and set(bm.unique().tolist()) <= {0., 1.}
+
+
+class _FakeDeviceTensor:
+    """What ops._ptr looks at, for a tensor that claims to live on device `index` (no GPU needed: nothing is launched)."""
+
+    def __init__(self, index, dtype=torch.float32):
+        import types
+        self.is_cuda, self.dtype, self.device = True, dtype, types.SimpleNamespace(index=index, type="cuda")
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return 0x1000
+
+
+def test_operands_on_different_devices_raise_and_leave_no_state_behind(monkeypatch):
+    """The device guard (dynamorph_amd/_lib.py, ops._op): every pointer of ONE call is checked against the call's device,
+    also across the host-only queries in between; an error while a launch is being assembled leaves nothing behind."""
+    from dynamorph_amd import _lib, ops
+    lib = _lib.load()
+    assert _lib.call_device.index is None
+    a0, b0, a1 = _FakeDeviceTensor(0), _FakeDeviceTensor(0), _FakeDeviceTensor(1)
+    # dm_apply(inp on cuda:0, resid on cuda:1): raises before anything is launched
+    with pytest.raises(ValueError, match="different devices"):
+        ops.apply(ops.Op(a0), 1, 1, 4, 4, resid=a1, out=b0)
+    assert _lib.call_device.index is None                       # cleared although the call died half-way
+    # a host-only query between two pointers of a call does not forget the first pointer's device
+    @ops._op
+    def call():
+        ops._ptr(a0)
+        assert lib.dm_vq_num_blocks(4096) > 0 and lib.dm_conv3x3_num_blocks(4, 16, 16, 16, 16, 9, 0, 0) == 4
+        assert _lib.call_device.index == 0
+        ops._ptr(a1)
+    with pytest.raises(ValueError, match=r"cuda:0 and cuda:1"):
+        call()
+    assert _lib.call_device.index is None
+    # an unrelated error (dtype) after the first pointer: the next call starts clean, on another device
+    with pytest.raises(ValueError, match="dtype"):
+        ops.apply(ops.Op(a0), 1, 1, 4, 4, resid=_FakeDeviceTensor(0, torch.float64), out=b0)
+    assert _lib.call_device.index is None
+    with pytest.raises(ValueError, match="different devices"):
+        ops.apply(ops.Op(a1), 1, 1, 4, 4, resid=a0, out=a1)      # (would be 'cuda:0 and ...' with a stale index)
+    # the weights of a convolution are operands too
+    w = _FakeDeviceTensor(1)
+    wv = ops.WView.__new__(ops.WView)
+    wv._keep, wv._scratch, wv.struct = w, None, _lib.WeightView(0x1000, 0, 1, 1, 1, 1, None, 0)
+    @ops._op
+    def conv_like():
+        ops._ptr(a0)
+        wv.ref()
+    with pytest.raises(ValueError, match="different devices"):
+        conv_like()
+    assert _lib.is_host_only("dm_conv3x3_scratch_floats") and not _lib.is_host_only("dm_conv3x3")
