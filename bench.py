@@ -10,6 +10,8 @@ resident in HBM.  Default workload = BASELINE.json configs[2]/[3]: one TRAINING 
 Adam, batch 2048 per GPU; weak scaling, one RCCL all-reduce of the flat 96 KB gradient bucket per step).
 `--workload c2` times configs[1] instead (inference latents, batch 1024, per-sample BatchNorm statistics).
 
+`--workload c5` times configs[4] (stress: VQ_VAE(num_inputs=4, num_embeddings=4096) on 4x256x256 patches, training step).
+
 Rank 0 prints ONE JSON line.  It also carries
   roofline     -- the dominant kernel of the step, timed live with events on the launch stream
   cpu_baseline -- the CPU oracle (oracle/vqvae_oracle.py, "port") timed on this host's cores on a bounded
@@ -33,15 +35,19 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFL
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 200; 50 for c5 / z32ex)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["c3", "c2", "z32ex"], default="c3")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 2048 for c3, 1024 for c2, 256 for z32ex)")
+    ap.add_argument("--workload", choices=["c3", "c2", "c5", "z32ex"], default="c3")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="per-GPU batch (default 2048 for c3, 1024 for c2, 1024 for c5, 256 for z32ex)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-targets", action="store_true", help="skip the north-star target measurements and the C2 sub-record")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps <= 0:
+        args.steps = 50 if args.workload in ("c5", "z32ex") else 200
+    return args
 
 
 def event_time_ms(fn, iters=20, warmup=3):
@@ -62,7 +68,7 @@ def pmc_traffic(kernel_key, batch):
     profiles/r0N_pmc_traffic.json (tools/pmc_traffic.py writes it; bench.py cannot run under the profiler
     itself).  None when no measurement for this kernel and batch has been committed."""
     rec = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):       # the newest measurement that has this kernel
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(kernel_key)
@@ -74,8 +80,6 @@ def pmc_traffic(kernel_key, batch):
         return None
     return rec.get("hbm_bytes_per_launch")
 
-
-MFMA_F32_PEAK_TFLOPS = 157.3     # 256 CUs x 256 FLOP/clk (v_mfma_f32_16x16x4_f32) x 2.4 GHz, MI355X_MICROARCH.md
 
 EXAMPLE_CONFIG = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)     # config_example.yml:157-163
 
@@ -98,6 +102,33 @@ def roofline_wide_conv(B):
     return {"kernel": "wide_pack_kernel + conv_wide_kernel<1, 9, 4> (residual 3x3, 64 -> 64 channels, 32 x 32)", "bound": "mfma",
             "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
             "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops}
+
+
+def roofline_vq_large_codebook(model, x):
+    """c5 (BASELINE.json configs[4]: "LDS-tiled codebook distance kernel vs roofline"): the K = 4096 distance + argmin
+    kernel (vq_forward_mfma_kernel<16, false, ...>: the codebook walks through LDS in 32 KB pieces, MFMA filter + exact
+    re-check) on the model's own latents, alone, as T(21 launches) - T(1 launch) with events on the launch stream.  Compute
+    bound: achieved = 2*K*D*P FLOP of the filter product / average launch, against the f32 MFMA peak."""
+    from dynamorph_amd import engine as E
+    from dynamorph_amd import ops
+    L = E.Layers(model)
+    with torch.no_grad():
+        z, _ = E.encoder_forward(L, x)
+    cbk = L.codebook.weight.detach()
+    bufs = ops.vq_forward_repeat(z, cbk, 1)
+    t1 = event_time_ms(lambda: ops.vq_forward_repeat(z, cbk, 1, bufs=bufs), iters=10, warmup=3)
+    t21 = event_time_ms(lambda: ops.vq_forward_repeat(z, cbk, 21, bufs=bufs), iters=5, warmup=1)
+    ms = max((t21 - t1) / 20.0, 1e-6)
+    K, D = cbk.shape
+    P = z.shape[0] * z.shape[2] * z.shape[3]
+    flops = 2.0 * K * D * P
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": f"vq_forward_mfma_kernel<{D}, false, ...> (K = {K} codes through LDS pieces; distance + first-min argmin + gather "
+                      "+ straight-through value + squared error)", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": pmc_traffic("vq_forward_mfma_k4096", x.shape[0]), "avg_launch_ms": round(ms, 5),
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": P * (2 * D * 4 + 8),
+            "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()), "positions": P}
 
 
 def roofline_dominant_kernel(model, x, workload):
@@ -211,23 +242,13 @@ def north_star_targets(model, x):
                 fn()
         return event_time_ms(gg.replay, iters=10, warmup=2) / launches
 
-    # rocprof's own MFMA-busy share of the same kernels inside the step (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles a wave
-    # is resident; separate --pmc passes summarised in profiles/ by tools/sqprof.sh -- bench.py cannot run under the profiler)
-    sq = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_c3_b2048_sq_counters.json")) as f:
-            sq = json.load(f).get("kernels", {}) if B == 2048 else {}
-    except (OSError, ValueError):
-        sq = {}
-
     def add(name, macs_per_patch, fn, note=None, kernel=None):
         ms = graph_time_ms(fn)
         fl = 2.0 * macs_per_patch * B
         rec = {"layer": name, "flops": fl, "avg_launch_ms": round(ms, 5),
                "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
-        if kernel and kernel in sq:
+        if kernel:
             rec["kernel"] = kernel
-            rec["mfma_busy_pmc"] = round(sq[kernel]["mfma_busy_pct_of_wave_cycles"] / 100.0, 3)
         if note:
             rec["note"] = note
         convs.append(rec)
@@ -266,12 +287,7 @@ def north_star_targets(model, x):
     tot_ms = sum(c["avg_launch_ms"] * (2 if "each of 2" in c["layer"] else 1) for c in convs)
     total = {"flops": tot_fl, "ms": round(tot_ms, 5),
              "frac_mfma": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
-    if all("mfma_busy_pmc" in c for c in convs):
-        wsum = sum(c["mfma_busy_pmc"] * c["avg_launch_ms"] * (2 if "each of 2" in c["layer"] else 1) for c in convs)
-        total["mfma_busy_pmc"] = round(wsum / tot_ms, 3)       # time-weighted
-        total["note"] = ("frac_mfma = executed FLOPs / launch time / 157.3 TFLOP/s (clock- and prologue-inclusive); mfma_busy_pmc = "
-                         "rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / resident wave cycles of the same kernels in the step "
-                         "(profiles/r02_c3_b2048_sq_counters.txt)")
+    total["note"] = "frac_mfma = executed FLOPs / average launch (graph replay of 10 launches) / 157.3 TFLOP/s: clock- and prologue-inclusive"
     return {"vq": vq, "enc_convs": convs, "enc_convs_total": total}
 
 
@@ -342,9 +358,16 @@ def cpu_baseline(workload, budget_s=25.0):
     import statistics
     cpu_name, phys = _host_cpu()
     torch.manual_seed(0)
-    nb = 16 if workload == "z32ex" else 64
-    ref = O.OracleVQVAEz32(**EXAMPLE_CONFIG) if workload == "z32ex" else O.OracleVQVAE()
-    x = torch.randn(nb, 2, 128, 128, generator=torch.Generator().manual_seed(1234))
+    nb = {"z32ex": 16, "c5": 4}.get(workload, 64)
+    if workload == "c5":
+        # the reference's distance tensor (vq_vae.py:65) is B*K*D*H*W floats = 268 MB per patch at K = 4096 on a 32 x 32
+        # latent grid: the CPU path can only run this configuration in small chunks
+        import numpy as np
+        ref = O.OracleVQVAE(num_inputs=4, num_embeddings=4096, channel_var=np.ones(4))
+        x = torch.randn(nb, 4, 256, 256, generator=torch.Generator().manual_seed(1234))
+    else:
+        ref = O.OracleVQVAEz32(**EXAMPLE_CONFIG) if workload == "z32ex" else O.OracleVQVAE()
+        x = torch.randn(nb, 2, 128, 128, generator=torch.Generator().manual_seed(1234))
     opt = O.make_adam(ref, 1e-4)
 
     def train_step():
@@ -376,19 +399,21 @@ def cpu_baseline(workload, budget_s=25.0):
         return statistics.median(ts)
     saved = torch.get_num_threads()
     tried = {}
-    for n in sorted({t for t in (8, 16, 32, 64, phys) if 1 <= t <= (os.cpu_count() or 1)}):
+    sweep = (16, 32) if workload == "c5" else (8, 16, 32, 64, phys)
+    for n in sorted({t for t in sweep if 1 <= t <= (os.cpu_count() or 1)}):
         if time.perf_counter() - t_start > 0.5 * budget_s:
             break
         torch.set_num_threads(n)
-        tried[n] = round(nb / timed(headline, 3, warm=1), 1)
+        tried[n] = round(nb / timed(headline, 2 if workload == "c5" else 3, warm=1), 1)
     best = max(tried, key=tried.get) if tried else saved
     torch.set_num_threads(best)
-    med = timed(headline, 10)
+    reps = 5 if workload == "c5" else 10
+    med = timed(headline, reps, warm=1 if workload == "c5" else 2)
     rec = {"value": round(nb / med, 1), "unit": "patches/s", "cores": best, "kind": "port",
-           "sample": f"median of 10 x {'process_VAE batch-of-one loop (enc -> vq) over' if workload == 'c2' else 'training step (fwd+bwd+Adam) on a batch of'} "
+           "sample": f"median of {reps} x {'process_VAE batch-of-one loop (enc -> vq) over' if workload == 'c2' else 'training step (fwd+bwd+Adam) on a batch of'} "
                      f"{nb} patches, PyTorch CPU fp32, {best} threads (best of {sorted(tried)})",
            "cpu_model": cpu_name, "physical_cores": phys, "logical_cpus": os.cpu_count(), "threads_tried_patches_per_s": tried}
-    if workload != "z32ex" and time.perf_counter() - t_start < budget_s:
+    if workload not in ("z32ex", "c5") and time.perf_counter() - t_start < budget_s:
         rec["c1_forward_b64_patches_per_s"] = round(nb / timed(forward, 10), 1)          # BASELINE.json configs[0]
         if workload != "c2" and time.perf_counter() - t_start < budget_s:
             rec["process_vae_loop_patches_per_s"] = round(nb / timed(latents, 5, warm=1), 1)
@@ -409,10 +434,17 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B = args.batch or {"c3": 2048, "c2": 1024, "z32ex": 256}[args.workload]
+    B = args.batch or {"c3": 2048, "c2": 1024, "c5": 1024, "z32ex": 256}[args.workload]
 
     torch.manual_seed(0)
-    x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    if args.workload == "c5":
+        # BASELINE.json configs[4] / SURVEY 8(d): 4-channel 256 x 256 patches, 4096 codes
+        import numpy as np
+        x = torch.randn(B, 4, 256, 256, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+        model = VQ_VAE(num_inputs=4, num_embeddings=4096, channel_var=np.ones(4)).to(dev)
+    else:
+        x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    trainer = None
     if args.workload == "z32ex":
         # the variant and widths the reference's example configuration trains; the
         # run_training.py loop as it is (autograd + torch.optim.Adam), every conv on the implicit-GEMM kernels
@@ -429,12 +461,12 @@ def main():
             model.zero_grad()
             return torch.stack([ld["recon_loss"].detach(), ld["commitment_loss"].detach(), ld["total_loss"].detach(),
                                 ld["perplexity"].detach()])
-    else:
+    elif args.workload != "c5":
         model = VQ_VAE().to(dev)
 
     if args.workload == "z32ex":
         pass
-    elif args.workload == "c3":
+    elif args.workload in ("c3", "c5"):
         trainer = FusedTrainer(model, lr=1e-4, use_graph=not args.no_graph)
 
         def step():
@@ -452,7 +484,7 @@ def main():
 
     for i in range(args.warmup):
         out = step()
-        if i == 0 and args.workload == "c3" and trainer.input_buffer() is not None:
+        if i == 0 and trainer is not None and trainer.input_buffer() is not None:
             x = trainer.input_buffer()      # the batch now lives in the graph's input buffer: no per-step copy
     if world > 1:
         torch.distributed.barrier()
@@ -466,11 +498,32 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device=dev)
 
-    losses = out.tolist() if args.workload in ("c3", "z32ex") else None
+    losses = out.tolist() if args.workload in ("c3", "c5", "z32ex") else None
+    # evidence of the gradient exchange (after the timed region, every rank takes part): backend, world size and the
+    # device / host time of the three parts of a step, from events on the launch stream around FusedTrainer._allreduce
+    collective = None
+    if trainer is not None:
+        import torch.distributed as dist
+        marks = []
+        for _ in range(20 if world > 1 else 5):
+            trainer.step(x, timers=marks)
+        parts = FusedTrainer.timer_summary(marks)
+        backend = dist.get_backend() if world > 1 else None
+        collective = {"backend": backend, "world": world, "message_bytes": trainer.grad.numel() * 4,
+                      "allreduce_us": parts["allreduce_us"] if world > 1 else None,
+                      "allreduce_host_us": parts["allreduce_host_us"] if world > 1 else None,
+                      "fwd_bwd_graph_us": parts["fwd_bwd_us"], "adam_us": parts["adam_us"],
+                      "fwd_bwd_host_us": parts["fwd_bwd_host_us"], "adam_host_us": parts["adam_host_us"],
+                      "nccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+                      "op": "all_reduce(SUM) of the flat fp32 gradient bucket, then x 1/world" if world > 1 else "none (one process)"}
+        if world > 1:
+            dist.barrier()
     if args.no_roofline or rank != 0:
         roof = None
     elif args.workload == "z32ex":
         roof = roofline_wide_conv(B)
+    elif args.workload == "c5":
+        roof = roofline_vq_large_codebook(model, x)
     else:
         roof = roofline_dominant_kernel(model, x, args.workload)
     targets = c2 = None
@@ -483,11 +536,14 @@ def main():
 
     if rank == 0:
         wl = {"c3": "C3: VQ_VAE training step (forward + backward + fused Adam), 2x128x128 fp32 synthetic patches",
+              "c5": "C5: large-codebook stress, VQ_VAE(num_inputs=4, num_embeddings=4096) training step (forward + backward + fused "
+                    "Adam), 4x256x256 fp32 synthetic patches",
               "c2": "C2: VQ_VAE inference latents (enc + vq, per-sample BatchNorm statistics = process_VAE), 2x128x128 fp32",
               "z32ex": "VQ_VAE_z32 with the reference's example widths (num_hiddens 64, num_residual_hiddens 64, 512 codes): "
                        "training step (forward + backward + torch Adam), 2x128x128 fp32 synthetic patches"}[args.workload]
         line = {
-            "metric": "cell-patches/sec (128x128x2) VQ-VAE " + ("latent encoding" if args.workload == "c2" else "fwd+bwd"),
+            "metric": ("cell-patches/sec (256x256x4, 4096 codes) VQ-VAE fwd+bwd" if args.workload == "c5" else
+                       "cell-patches/sec (128x128x2) VQ-VAE " + ("latent encoding" if args.workload == "c2" else "fwd+bwd")),
             "value": round(world * B * args.steps / elapsed, 1),
             "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -495,9 +551,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "hip_graph": (not args.no_graph) if args.workload in ("c3", "c2") else False},
+                       "hip_graph": (not args.no_graph) if args.workload in ("c3", "c2", "c5") else False},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "collective": collective,
         }
         if targets is not None:
             line["targets"] = targets

@@ -113,8 +113,16 @@ extern "C" int dm_pair_msd_backward(const float *z, const float *g_sim, float *d
 //
 // The reference materialises a (B, B, n) tensor for this (9.7 GB at its example batch of 768); the first version here
 // formed the differences on the VALU (3 B^2 n operations, two LDS reads per multiply).  The Gram form costs 2 B^2 n on
-// v_mfma_f32_16x16x4_f32; its cancellation error is ~ sqrt(n) u |z|^2 / n absolute on sim (1e-6 for N(0,1) latents of
-// length 4096, K split into chunks whose partial sums are added in double), inside the north star's 1e-5 on the loss.
+// v_mfma_f32_16x16x4_f32; its cancellation error is ~ c u (|z_i|^2 + |z_j|^2) / n ABSOLUTE on sim (K split into chunks
+// whose partial sums are added in double): harmless for a pair of unrelated cells, whose distance is of the order of the
+// norms, but the pairs this loss exists for -- adjacent frames of ONE cell, tm in {1, 2}, weight_matching = 100 in the
+// reference's example configuration (config_example.yml:164) -- lie close together, where |a|^2 + |b|^2 - 2ab has
+// cancelled most of its bits (a pair at 1e-3 relative distance keeps none).  The reference takes differences first
+// (vae.py:441-455).  So the Gram value is a FILTER, as in the VectorQuantizer kernel: a pair whose Gram distance is below
+// TM_NEAR x (|z_i|^2 + |z_j|^2) (relative distance under 25 %) is re-evaluated from differences -- sum_d (z_i - z_j)^2
+// by the whole wave, fp32 products added in double -- in the epilogue, and its gradient term S_ij (z_i - z_j) is taken
+// from differences too (tm_near_backward_kernel) instead of the second GEMM, where rowsum(S) z_i - sum_j S_ij z_j
+// cancels the same way.  Every other pair keeps a relative error <= c u / TM_NEAR ~ 3e-6 on sim.
 namespace {
 
 constexpr int TM_T = 64;          // 64 x 64 output tile per workgroup: 4 waves, 32 x 32 each (2 x 2 MFMA tiles)
@@ -187,33 +195,98 @@ __device__ __forceinline__ void tm_value(const TmParams &p, float sim, float tm,
     dsim = w * live * inv_count;
 }
 
-// one thread per (i, j): sim from the Gram slabs, both orientations of the loss term, S_ij, loss partials per workgroup
-__global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restrict__ P, int ksplit, const float *__restrict__ tm,
-                                                          int B, int n, TmParams p, float *__restrict__ S,
-                                                          double *__restrict__ loss_slabs)
+constexpr float TM_NEAR = 1.f / 16.f;   // Gram distance below this share of |z_i|^2 + |z_j|^2: re-evaluate from differences
+
+// one thread per (i, j): sim from the Gram slabs (near pairs: from differences, by the wave), both orientations of the loss
+// term, S_ij split into its far part (for the gradient GEMM) and its near part (for tm_near_backward_kernel), loss
+// partials per workgroup.  S: (2, B, B).
+__global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restrict__ z, const float *__restrict__ P, int ksplit,
+                                                          const float *__restrict__ tm, int B, int n, TmParams p,
+                                                          float *__restrict__ S, double *__restrict__ loss_slabs)
 {
     __shared__ double s_red[4];
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x, BB = (long long)B * B;
+    const int lane = threadIdx.x & 63;
     double val = 0.0;
+    int i = 0, j = 0;
+    float sim = 0.f;
+    bool near = false;
     if (e < BB) {
-        const int i = (int)(e / B), j = (int)(e - (long long)i * B);
+        i = (int)(e / B); j = (int)(e - (long long)i * B);
+        const int lo = i < j ? i : j, hi = i < j ? j : i;           // one orientation of the Gram entry: sim is symmetric to the bit
         double gij = 0.0, gii = 0.0, gjj = 0.0;
         for (int ks = 0; ks < ksplit; ++ks) {             // chunk sums added in double, in a fixed order
             const float *__restrict__ Pk = P + ks * BB;
-            gij += (double)Pk[(long long)i * B + j];
-            gii += (double)Pk[(long long)i * B + i];
-            gjj += (double)Pk[(long long)j * B + j];
+            gij += (double)Pk[(long long)lo * B + hi];
+            gii += (double)Pk[(long long)lo * B + lo];
+            gjj += (double)Pk[(long long)hi * B + hi];
         }
-        const float sim = i == j ? 0.f : (float)((gii + gjj - 2.0 * gij) / (double)n);
+        const double d2 = gii + gjj - 2.0 * gij;
+        sim = i == j ? 0.f : (float)(d2 / (double)n);
+        near = i != j && !(d2 >= (double)TM_NEAR * (gii + gjj));    // (also when the Gram value is not finite)
+    }
+    // near pairs, one at a time, by the whole wave: sum of squared differences, 16 bytes per lane and step
+    unsigned long long todo = __ballot(near);
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int pi = __shfl(i, l, 64), pj = __shfl(j, l, 64);
+        const float *__restrict__ zi = z + (long long)pi * n, *__restrict__ zj = z + (long long)pj * n;
+        double acc = 0.0;
+        for (int d = 4 * lane; d < n; d += 256) {          // n % 32 == 0: whole float4s
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(zi + d), b = *reinterpret_cast<const f32x4 *>(zj + d);
+            const f32x4 df = a - b;
+            acc += (double)((df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w));
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == l) sim = (float)(acc / (double)n);
+    }
+    if (e < BB) {
         const float inv_count = p.mode == 0 ? 1.f : 1.f / (float)BB;
         float d_ij, d_ji;
         double v_ji;
         tm_value(p, sim, tm[(long long)i * B + j], inv_count, val, d_ij);
         tm_value(p, sim, tm[(long long)j * B + i], inv_count, v_ji, d_ji);
-        S[e] = d_ij + d_ji;
+        const float sij = d_ij + d_ji;
+        S[e] = near ? 0.f : sij;
+        S[BB + e] = near ? sij : 0.f;
     }
     const double tot = block_sum(val, s_red);
     if (threadIdx.x == 0) { loss_slabs[2 * blockIdx.x] = tot; loss_slabs[2 * blockIdx.x + 1] = 0.0; }
+}
+
+// dz[i][d] += scale * g * sum_{j near i} S_ij (z[i][d] - z[j][d]): the near pairs' share of the gradient from differences.
+// One workgroup per row i; rows without a near pair (the usual case for most of them) leave after reading their S row.
+__global__ __launch_bounds__(256) void tm_near_backward_kernel(const float *__restrict__ z, const float *__restrict__ Snear,
+                                                               const float *__restrict__ g_dev, float scale,
+                                                               float *__restrict__ dz, int B, int n)
+{
+    extern __shared__ float s_row[];                       // S_near[i][0..B)
+    __shared__ int s_any;
+    const int i = blockIdx.x;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    bool any = false;
+    for (int j = threadIdx.x; j < B; j += 256) {
+        const float v = Snear[(long long)i * B + j];
+        s_row[j] = v;
+        any |= v != 0.f;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    if (!s_any) return;
+    const float sc = scale * (g_dev ? g_dev[0] : 1.f);
+    const float *__restrict__ zi = z + (long long)i * n;
+    for (int d = 4 * threadIdx.x; d < n; d += 1024) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(zi + d);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < B; ++j) {                      // ascending j: a fixed order
+            const float sv = s_row[j];
+            if (sv != 0.f) acc += sv * (a - *reinterpret_cast<const f32x4 *>(z + (long long)j * n + d));
+        }
+        f32x4 *o = reinterpret_cast<f32x4 *>(dz + (long long)i * n + d);
+        *o = *o + sc * acc;
+    }
 }
 
 // dz[i][d] = scale * g * (rowsum(S)_i z[i][d] - sum_j S_ij z[j][d]);  64 rows x 64 columns per workgroup, K = B
@@ -325,8 +398,8 @@ extern "C" int dm_time_matching_forward(const float *z, const float *tm, int B, 
     klen = (klen + TM_KC - 1) / TM_KC * TM_KC;
     hipLaunchKernelGGL(tm_gram_kernel, dim3(nt, nt, ks), dim3(256), 0, s, z, workspace, B, n, klen);
     const TmParams p{mode, w_a, w_t, w_n, margin};
-    hipLaunchKernelGGL(tm_epilogue_kernel, dim3((unsigned)dm_time_matching_num_slabs(B)), dim3(256), 0, s, workspace, ks, tm, B, n,
-                       p, S, loss_slabs);
+    hipLaunchKernelGGL(tm_epilogue_kernel, dim3((unsigned)dm_time_matching_num_slabs(B)), dim3(256), 0, s, z, workspace, ks, tm, B,
+                       n, p, S, loss_slabs);
     return dm_launch_status("dm_time_matching_forward");
 }
 
@@ -336,7 +409,10 @@ extern "C" int dm_time_matching_backward(const float *z, const float *S, const f
     DM_REQUIRE(z && S && dz, "dm_time_matching_backward: NULL pointer");
     DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_backward: latent length %d is not a multiple of %d", n, TM_KC);
     DM_REQUIRE((long long)B * n < (1LL << 31), "dm_time_matching_backward: tensor too large");
+    DM_REQUIRE(B <= 16384, "dm_time_matching_backward: batch %d too large (a row of S is staged in LDS)", B);
     hipLaunchKernelGGL(tm_backward_kernel, dim3((n + TM_T - 1) / TM_T, (B + TM_T - 1) / TM_T), dim3(256), 0, (hipStream_t)stream,
                        z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n);
+    hipLaunchKernelGGL(tm_near_backward_kernel, dim3((unsigned)B), dim3(256), (size_t)B * sizeof(float), (hipStream_t)stream, z,
+                       S + (long long)B * B, g_loss_dev, scale * 2.f / (float)n, dz, B, n);
     return dm_launch_status("dm_time_matching_backward");
 }

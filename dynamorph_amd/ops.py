@@ -571,12 +571,13 @@ def time_matching_supported(B, n):
 @_op
 def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0):
     """The whole pairwise term on the MFMA (include/dynamorph_hip.h, dm_time_matching_forward).  z (B, n), tm (B, B) float32.
-    Returns (loss: 1-element device tensor, S (B, B) = dloss/dsim + its transpose, for time_matching_backward)."""
+    Returns (loss: 1-element device tensor, S (2, B, B) = dloss/dsim + its transpose, far pairs / near pairs, for
+    time_matching_backward)."""
     lib = L.load()
     B, n = z.shape
     wsf = lib.dm_time_matching_workspace_floats(B, n)
     ws = _new((wsf,), z)
-    S = _new((B, B), z)
+    S = _new((2, B, B), z)
     nsl = lib.dm_time_matching_num_slabs(B)
     slabs = _new((nsl, 1, 2), z, torch.float64)
     L.check(lib.dm_time_matching_forward(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),

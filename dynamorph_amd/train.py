@@ -29,6 +29,20 @@ from .train_utils import EarlyStopping
 LOSS_KEYS = ("recon_loss", "commitment_loss", "total_loss", "perplexity")
 
 
+class _Marks:
+    """Four (stream event, host clock) pairs around the parts of one FusedTrainer.step (measurement only)."""
+
+    def __init__(self):
+        self.ev, self.t = [], []
+
+    def __call__(self):
+        import time
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev.append(e)
+        self.t.append(time.perf_counter())
+
+
 class FusedTrainer:
     """Adam(lr, betas=(.9,.999), eps=1e-8) exactly as run_training.py:485 builds it, fused."""
 
@@ -145,21 +159,45 @@ class FusedTrainer:
             self._allreduce()
             self._adam()
 
-    def step(self, x, mask=None, time_matching_mat=None, grad_weight=1.0):
+    def step(self, x, mask=None, time_matching_mat=None, grad_weight=1.0, timers=None):
         """One optimisation step on a device batch; returns the device tensor of LOSS_KEYS values (+ the time-matching
-        loss as a fifth entry when a matrix is given).  grad_weight: see _allreduce."""
+        loss as a fifth entry when a matrix is given).  grad_weight: see _allreduce.
+        timers: a list -> this step appends (events, host_times): four events on the launch stream and four
+        time.perf_counter() readings around its three parts (forward+backward | gradient exchange | Adam); read them with
+        FusedTrainer.timer_summary after a synchronize.  Measurement only: the default path records nothing."""
         if not x.is_cuda:
             raise RuntimeError("FusedTrainer.step: batch must be on the GPU")
         if x.device != self.flat.device:
             raise RuntimeError(f"FusedTrainer.step: batch on {x.device}, model on {self.flat.device}")
         x = x.contiguous()
         with torch.cuda.device(self.flat.device):       # graph capture / replay and the streams are the model's device's
+            mark = _Marks() if timers is not None else None
+            if mark: mark()
             if not self.use_graph:
                 out = self.forward_backward(x, mask, time_matching_mat)
             else:
                 out = self._graph_step(x, mask, time_matching_mat)
+            if mark: mark()
             self._allreduce(grad_weight)
+            if mark: mark()
             self._adam()
+            if mark:
+                mark()
+                timers.append(mark)
+        return out
+
+    @staticmethod
+    def timer_summary(timers):
+        """Averages (microseconds) over the steps recorded with step(..., timers=list): device time between the stream
+        events and host time between the enqueue points, for forward+backward (graph replay), the gradient exchange and
+        the fused Adam launch."""
+        torch.cuda.synchronize()
+        n = max(len(timers), 1)
+        out = {}
+        for i, part in enumerate(("fwd_bwd", "allreduce", "adam")):
+            out[part + "_us"] = round(sum(m.ev[i].elapsed_time(m.ev[i + 1]) for m in timers) * 1e3 / n, 2)
+            out[part + "_host_us"] = round(sum(m.t[i + 1] - m.t[i] for m in timers) * 1e6 / n, 2)
+        out["steps"] = len(timers)
         return out
 
     def _graph_step(self, x, mask, tm=None):

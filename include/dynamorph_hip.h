@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 110
+#define DM_VERSION 111
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -349,10 +349,14 @@ int dm_pair_msd_backward(const float *z, const float *g_sim, float *dz, int B, i
 /* The whole term on the matrix pipe (csrc/pairwise.hip): sim from the Gram matrix Z Z^T (f32 MFMA, K split into chunks added
  * in double), the loss form of either model family, and S_ij = dloss/dsim_ij + dloss/dsim_ji for the backward, which is a
  * second MFMA GEMM: dz_i = (2/n) (rowsum(S)_i z_i - sum_j S_ij z_j).
+ * Near pairs -- Gram distance below 1/16 of |z_i|^2 + |z_j|^2, where the Gram form has cancelled: adjacent frames of one
+ * cell, the pairs the term exists for -- are re-evaluated from differences as the reference does (vae.py:441-455), forward
+ * (sim) and backward (S_ij (z_i - z_j)); S is therefore TWO (B, B) planes: [0] the far pairs' S for the GEMM, [1] the near
+ * pairs' (zero elsewhere).
  *   mode 0  vq_vae.py:330-331   loss = sum_ij sim_ij * tm_ij
  *   mode 1  vae.py:327-336      w = {2: w_a, 1: w_t, 0: w_n}[tm]; v = sim * w; tm == 0: v = max(v + margin, 0); loss = mean v
  * z (B, n) contiguous with n % 32 == 0 (dm_time_matching_supported; other lengths: dm_pair_msd); tm (B, B) float32;
- * workspace: dm_time_matching_workspace_floats(B, n) floats of scratch; S (B, B) out; loss_slabs: dm_time_matching_num_slabs(B)
+ * workspace: dm_time_matching_workspace_floats(B, n) floats of scratch; S (2, B, B) out; loss_slabs: dm_time_matching_num_slabs(B)
  * pairs of doubles, (partial loss, 0) each -- dm_sum_slabs(loss_slabs, nslabs, 1, 1, loss) gives the scalar.
  * dm_time_matching_backward: dz = scale * g_loss_dev[0] * d loss / d z  (g_loss_dev NULL: 1). */
 int dm_time_matching_supported(int B, int n);

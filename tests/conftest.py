@@ -58,3 +58,44 @@ def codes_gate(flips, z_ref, codebook, what="codes", rel=1e-4):
     print(f"{what}: {nflip} of {P} codes differ, {nnear} reference near-ties (relative gap <= {rel})")
     assert not bool((flips & ~near).any()), f"{what}: {int((flips & ~near).sum())} codes differ away from near-ties"
     assert nflip <= 1e-5 * P + 1, f"{what}: {nflip} flips in {P} positions"
+
+
+def oracle_truth(ref, x, **kw):
+    """Runs the fp32 oracle `ref` AND a float64 copy of it on the same input (forward + backward of total_loss).
+    Returns (loss dict of the fp32 run, {name: fp32 grad}, {name: float64 grad}).  The float64 run is the yardstick of
+    grad_gate: what the fp32 reference itself misses it by is the accumulation noise no fp32 implementation can undercut."""
+    import copy
+    import torch
+    ref64 = copy.deepcopy(ref).double()
+    _, ld = ref(x, **kw)
+    ld["total_loss"].backward()
+    kw64 = {k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    _, ld64 = ref64(x.double(), **kw64)
+    ld64["total_loss"].backward()
+    g32 = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    g64 = {k: p.grad for k, p in ref64.named_parameters() if p.grad is not None}
+    return ld, g32, g64
+
+
+def grad_gate(model, g32, g64, keys=None, skip=(), factor=1.5, floor=2e-4, what=""):
+    """Every gradient of the HIP `model` (p.grad) is as close to the float64 truth as the reference's own fp32 CPU path is
+    (x factor), or within floor x the tensor's scale -- the yardstick of test_oracle_parity_fresh_seed_larger_batch, in
+    place of the flat 2 % of scale the shape sweeps used until round 2 (a dropped tile row or a missing tap at B = 2..7
+    hid under that)."""
+    worst = ("", 0.0)
+    checked = 0
+    for k, p in model.named_parameters():
+        if not p.requires_grad or k in skip or (keys is not None and k not in keys) or k not in g64:
+            continue
+        assert p.grad is not None, k
+        truth = g64[k]
+        scale = max(truth.abs().max().item(), 1e-6)
+        e_ref = (g32[k].double() - truth).abs().max().item()
+        e_hip = (p.grad.detach().cpu().double() - truth).abs().max().item()
+        assert e_hip <= max(factor * e_ref, floor * scale) + 1e-9, (what, k, "hip", e_hip, "fp32 reference", e_ref, "scale", scale)
+        checked += 1
+        if e_hip / scale > worst[1]:
+            worst = (k, e_hip / scale)
+    assert checked > 0
+    print(f"{what}: {checked} gradients within the float64 yardstick; worst {worst[0]} {worst[1]:.2e} of scale")
+    return checked

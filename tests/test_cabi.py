@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header():
 def test_version_and_host_only_queries(lib):
     assert lib.dm_vq_backward_num_slabs(524288, 64, 16) == 512 and lib.dm_vq_backward_num_slabs(262144, 4096, 16) == 128
     assert lib.dm_vq_backward_num_slabs(3000, 64, 16) == 3 and lib.dm_vq_backward_num_slabs(1 << 22, 65536, 16) == 32
-    assert lib.dm_version() == 110          # 104: dm_vq_forward_variant (MFMA filter + exact re-check); 105: dm_vq_forward_repeat
+    assert lib.dm_version() == 111          # 111: time-matching S has two planes (far / near pairs), near pairs from differences
     # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows (csrc/vq.hip)
     # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows + counter replicas
     assert lib.dm_vq_workspace_bytes(64, 16) == (32 + 64 * 16 + 64 * 16 + 64 + 64 * 16 + 64 * 64) * 4

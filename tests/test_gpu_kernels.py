@@ -934,6 +934,74 @@ def test_time_matching_fused_forward_backward(ops, B, n, mode):
     assert (za.grad.cpu().double() - zr.grad).abs().max() <= 2e-5 * zr.grad.abs().max() + 1e-9
 
 
+def _tm_reference(z, tm, mode, w_a=1.1, w_t=0.1, w_n=-0.5, margin=0.5):
+    """vq_vae.py:324-332 (mode 0) / vae.py:322-336 (mode 1) in float64, differences first as the reference takes them."""
+    B, n = z.shape
+    zr = z.double().requires_grad_(True)
+    sim = (zr.reshape(1, B, n) - zr.reshape(B, 1, n)).pow(2).mean(2)
+    if mode == 0:
+        ref = (sim * tm.double()).sum()
+    else:
+        wts = tm.double().clone()
+        wts[tm == 2], wts[tm == 1], wts[tm == 0] = w_a, w_t, w_n
+        val = sim * wts
+        val = torch.where(tm == 0, torch.clamp(val + margin, min=0), val)
+        ref = val.mean()
+    ref.backward()
+    return float(ref), zr.grad
+
+
+@pytest.mark.parametrize("B,n,mode,only_near", [(24, 4096, 0, True), (24, 4096, 0, False), (40, 4096, 1, False),
+                                                (70, 1024, 0, True), (12, 65536, 0, True)])
+def test_time_matching_related_pairs_lie_close_together(ops, B, n, mode, only_near):
+    """The regime the term exists for: related pairs (tm in {1, 2}) are adjacent frames of ONE cell,
+    |a - b|^2 << |a|^2, where the Gram form |a|^2 + |b|^2 - 2ab has cancelled -- and the example configuration multiplies
+    the term by weight_matching = 100 (config_example.yml:164).  Latents come in groups: a base row, a copy at 1e-3
+    relative distance, an EXACT duplicate, one at 10 % distance; tm marks pairs inside a group (only_near: nothing else,
+    so loss and gradient consist of near pairs alone and are gated RELATIVE to themselves).  Loss and dz against the
+    reference's expression (differences first) in float64."""
+    g = torch.Generator().manual_seed(7 * B + n + mode)
+    groups = B // 4
+    base = torch.randn(groups, n, generator=g) * 0.7 + 0.1
+    z = torch.randn(B, n, generator=g) * 0.7 + 0.1
+    tm = torch.zeros(B, B)
+    for q in range(groups):
+        r = 4 * q
+        z[r] = base[q]
+        z[r + 1] = base[q] + 1e-3 * torch.randn(n, generator=g)
+        z[r + 2] = base[q]
+        z[r + 3] = base[q] + 0.07 * torch.randn(n, generator=g)
+        for a in range(4):
+            for b in range(4):
+                if a != b:
+                    tm[r + a, r + b] = 1.0 + ((a + b) % 2)
+    if not only_near:
+        far = torch.randint(0, 3, (B, B), generator=g).float()
+        tm = torch.where(tm > 0, tm, far)
+    wm = 100.0                                             # weight_matching of the example configuration
+    ref, gref = _tm_reference(z, tm, mode)
+    zd = z.to(DEV)
+    loss, S = ops.time_matching_forward(zd, tm.to(DEV), mode, 1.1, 0.1, -0.5, 0.5)
+    assert S.shape == (2, B, B)
+    near = S[1].cpu() != 0
+    assert bool(near[0, 1]) and bool(near[1, 0]) and bool(near[0, 3]) and not bool(near[0, 0])     # the planted pairs are re-evaluated
+    assert bool(((S[0].cpu() != 0) & near).sum() == 0)
+    tol = 1e-5 * (abs(ref) if only_near else max(1.0, abs(ref)))
+    assert abs(float(loss) - ref) <= tol, (float(loss), ref)
+    dz = ops.time_matching_backward(zd, S, None, wm).cpu().double()
+    want = gref * wm
+    assert (dz - want).abs().max() <= 2e-5 * want.abs().max() + 1e-12, (float((dz - want).abs().max()), float(want.abs().max()))
+    # exact duplicates: distance exactly 0, and no gradient flows between them beyond what their other partners cause
+    assert float(S.sum()) == float(S.sum())                # finite
+    if only_near and mode == 0:
+        # a pair of exact duplicates with no other partner: zero loss, zero gradient, bit for bit (the reference: 0 - 0)
+        z2 = torch.cat([base[:1], base[:1], base[1:2] * 3.0, base[2:3] - 5.0], 0)
+        tm2 = torch.zeros(4, 4); tm2[0, 1] = tm2[1, 0] = 2.0
+        l2, S2 = ops.time_matching_forward(z2.to(DEV), tm2.to(DEV), 0)
+        assert float(l2) == 0.0
+        assert float(ops.time_matching_backward(z2.to(DEV), S2, None, wm).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_zscore_patch_matches_numpy(ops, dtype):
     """pipeline/train_utils.py:252-274 zscore_patch (float64 numpy, population std, + eps) then .float()."""

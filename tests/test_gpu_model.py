@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import codes_gate
+from conftest import codes_gate, grad_gate, oracle_truth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -446,18 +446,15 @@ def test_shape_sweep_losses_and_gradients(B, nin, hw, masked):
     mask = ((torch.rand(B, 1, hw, hw, generator=torch.Generator().manual_seed(B + 1)) > 0.5).float() if masked else None)
     m = dynamorph_amd.VQ_VAE(**kw).to(DEV)
     m.load_state_dict(ref.state_dict())
-    _, ld_r = ref(x, batch_mask=mask)
-    ld_r["total_loss"].backward()
+    ld_r, g32, g64 = oracle_truth(ref, x, batch_mask=mask)
     dec, ld = m(x.to(DEV), batch_mask=None if mask is None else mask.to(DEV))
     ld["total_loss"].backward()
     assert dec.shape == x.shape
     for k in ("recon_loss", "commitment_loss", "total_loss"):
         assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
-    g_ref = dict(ref.named_parameters())
-    for k in ("dec.6.weight", "dec.6.bias", "dec.4.weight", "dec.0.weight", "enc.0.weight", "enc.4.weight", "vq.w.weight"):
-        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
-        scale = max(b.abs().max().item(), 1e-6)
-        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+    # every parameter gradient against the float64 yardstick (a code chosen differently at a near-tie moves the
+    # gradients discretely at these batch sizes: the reference's own fp32-vs-float64 error then widens the gate by itself)
+    grad_gate(m, g32, g64, skip=BN_FED_BIASES, floor=5e-4, what=f"shape sweep B={B} nin={nin} hw={hw}")
 
 
 @pytest.mark.parametrize("nin", [1, 3])
@@ -470,17 +467,12 @@ def test_z32_other_input_channel_counts(nin):
     x = torch.randn(3, nin, 128, 128, generator=torch.Generator().manual_seed(nin))
     m = dynamorph_amd.VQ_VAE_z32(**kw).to(DEV)
     m.load_state_dict(ref.state_dict())
-    _, ld_r = ref(x)
-    ld_r["total_loss"].backward()
+    ld_r, g32, g64 = oracle_truth(ref, x)
     _, ld = m(x.to(DEV))
     ld["total_loss"].backward()
     for k in ("recon_loss", "commitment_loss", "total_loss"):
         assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
-    g_ref = dict(ref.named_parameters())
-    for k in ("dec.4.weight", "dec.4.bias", "dec.1.weight", "enc.0.weight", "enc.3.weight"):
-        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
-        scale = max(b.abs().max().item(), 1e-6)
-        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+    grad_gate(m, g32, g64, skip=Z32_BN_FED_BIASES, floor=5e-4, what=f"z32 nin={nin}")
 
 
 @pytest.mark.parametrize("B,nin,masked,use_graph", [(5, 1, True, False), (3, 4, True, True), (6, 3, False, True)])
@@ -523,18 +515,16 @@ def test_non_square_patches(H, W):
     x = torch.randn(2, 2, H, W, generator=torch.Generator().manual_seed(H + W))
     m = dynamorph_amd.VQ_VAE().to(DEV)
     m.load_state_dict(ref.state_dict())
-    dec_r, ld_r = ref(x)
-    ld_r["total_loss"].backward()
+    with torch.no_grad():
+        import copy
+        dec_r = copy.deepcopy(ref)(x)[0]
+    ld_r, g32, g64 = oracle_truth(ref, x)
     dec, ld = m(x.to(DEV))
     ld["total_loss"].backward()
     close(dec, dec_r, 2e-4, 2e-4, "decoded")
     for k in ("recon_loss", "commitment_loss", "total_loss"):
         assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
-    g_ref = dict(ref.named_parameters())
-    for k in ("dec.4.weight", "dec.2.weight", "enc.0.weight", "enc.7.weight"):
-        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
-        scale = max(b.abs().max().item(), 1e-6)
-        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+    grad_gate(m, g32, g64, skip=BN_FED_BIASES, floor=5e-4, what=f"non-square {H}x{W}")
 
 
 @pytest.mark.parametrize("nlayers,K", [(1, 64), (3, 100), (0, 7)])
@@ -547,17 +537,14 @@ def test_other_residual_depths_and_codebook_sizes(nlayers, K):
     x = torch.randn(3, 2, 128, 128, generator=torch.Generator().manual_seed(nlayers))
     m = dynamorph_amd.VQ_VAE(**kw).to(DEV)
     m.load_state_dict(ref.state_dict())
-    _, ld_r = ref(x)
-    ld_r["total_loss"].backward()
+    ld_r, g32, g64 = oracle_truth(ref, x)
     _, ld = m(x.to(DEV))
     ld["total_loss"].backward()
     for k in ("recon_loss", "commitment_loss", "total_loss"):
         assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
-    g_ref = dict(ref.named_parameters())
-    for k in ("enc.10.weight", "enc.0.weight", "vq.w.weight", "dec.0.weight"):
-        a, b = dict(m.named_parameters())[k].grad.cpu(), g_ref[k].grad
-        scale = max(b.abs().max().item(), 1e-6)
-        assert (a - b).abs().max().item() <= 2e-2 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+    skip = tuple(b for b in BN_FED_BIASES if "layers" not in b) + tuple(
+        f"enc.12.layers.{i}.{j}.bias" for i in range(nlayers) for j in (1, 4))
+    grad_gate(m, g32, g64, skip=skip, floor=5e-4, what=f"{nlayers} residual layers, K={K}")
 
 
 WIDE = [("VQ_VAE", dict(num_hiddens=32, num_residual_hiddens=32)),

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import codes_gate
+from conftest import codes_gate, grad_gate, oracle_truth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -62,8 +62,8 @@ def test_stress_config_4ch_256px_k4096():
     x = torch.randn(2, 4, 256, 256, generator=torch.Generator().manual_seed(9))
     m = dynamorph_amd.VQ_VAE(**kw).to(DEV)
     m.load_state_dict(ref.state_dict())
-    dec_r, ld_r = ref(x)
-    ld_r["total_loss"].backward()
+    ref.vq.chunk = 1                      # 268 MB of distances per patch at K = 4096 (float64: twice that)
+    ld_r, g32, g64 = oracle_truth(ref, x)
     dec, ld = m(x.to(DEV))
     ld["total_loss"].backward()
     assert dec.shape == (2, 4, 256, 256)
@@ -76,11 +76,8 @@ def test_stress_config_4ch_256px_k4096():
     zb_r = ref2.enc(x).detach()
     idx, idx_r = m.vq.encode_inputs(zb).cpu(), ref2.vq.encode_inputs(zb_r)
     codes_gate(idx != idx_r, zb_r, ref2.vq.w.weight.detach(), "stress configuration (K = 4096)")
-    gr = dict(ref.named_parameters())
-    for k in ("enc.4.weight", "enc.10.weight", "dec.0.weight", "dec.6.weight", "vq.w.weight", "enc.0.weight"):
-        r = gr[k].grad
-        g = dict(m.named_parameters())[k].grad.cpu()
-        assert (g - r).abs().max().item() <= 2e-2 * r.abs().max().item() + 1e-7, k
+    from test_gpu_model import BN_FED_BIASES
+    grad_gate(m, g32, g64, skip=BN_FED_BIASES, floor=5e-4, what="stress configuration (K = 4096)")
 
 
 def test_train_loop_mirror_runs_and_checkpoints(tmp_path):

@@ -229,3 +229,34 @@ def test_zscore(golden):
     np.testing.assert_allclose(O.zscore_patch(p), g["zscore_patch"], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(O.zscore(p), g["zscore"], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(O.zscore(p, [40., 55.], [20., 30.]), g["zscore_given"], rtol=1e-12, atol=1e-12)
+
+
+def test_chunked_distances_equal_the_full_tensor(golden):
+    """OracleVQ.chunk (memory bound for the full-size parity tests): same indices, losses and gradients, bit for bit, as
+    the reference's single (B, K, D, H, W) expression -- on the golden vectors of the reference itself and on a batch
+    that does not divide by the chunk."""
+    g5, g4 = golden("g5_vq_forward.npz"), golden("g4_vq_indices.npz")
+    m = fresh(golden)
+    m.vq.chunk = 3
+    z = torch.from_numpy(g5["z_before"])
+    assert np.array_equal(m.vq.encode_inputs(z).numpy(), g4["idx"])
+    q, loss, perp = m.vq(z)
+    assert np.array_equal(q.detach().numpy(), g5["quantized"]) and float(loss) == float(g5["loss"])
+    for name, D, K in (("g9_vq_k4096.npz", 16, 4096), ("g9_vq_d64.npz", 64, 512), ("g9_vq_ties.npz", None, None)):
+        g = golden(name)
+        K, D = g["codebook"].shape
+        vq = O.OracleVQ(D, K)
+        with torch.no_grad():
+            vq.w.weight.copy_(torch.from_numpy(g["codebook"]))
+        vq.chunk = 1
+        assert np.array_equal(vq.encode_inputs(torch.from_numpy(g["z"])).numpy(), g["idx"]), name
+    torch.manual_seed(3)
+    a, b = O.OracleVQVAE(), O.OracleVQVAE()
+    b.load_state_dict(a.state_dict())
+    b.vq.chunk = 2
+    x = torch.randn(5, 2, 128, 128)
+    la, lb = a(x)[1], b(x)[1]
+    la["total_loss"].backward(); lb["total_loss"].backward()
+    assert all(float(la[k]) == float(lb[k]) for k in la)
+    for (k, p), (_, q_) in zip(a.named_parameters(), b.named_parameters()):
+        assert p.grad is None and q_.grad is None or torch.equal(p.grad, q_.grad), k

@@ -46,6 +46,12 @@ zq = torch.randn(B, 16, 16, 16, device=dev); cbk = torch.randn(64, 16, device=de
 vq_bufs = ops.vq_forward_repeat(zq, cbk, 1)
 cases["vq_fwd"] = (lambda: ops.vq_forward_repeat(zq, cbk, 1, bufs=vq_bufs), B * 34816)      # prep + distance kernel + counter reduction
 
+# stress shape of BASELINE configs[4]: 4096 codes, 32 x 32 latents of KB_B5 patches (bench.py --workload c5 default batch)
+B5 = int(os.environ.get("KB_B5", "1024"))
+zq5 = torch.randn(B5, 16, 32, 32, device=dev); cbk5 = torch.randn(4096, 16, device=dev)
+vq5_bufs = ops.vq_forward_repeat(zq5, cbk5, 1)
+cases["vq_fwd_k4096"] = (lambda: ops.vq_forward_repeat(zq5, cbk5, 1, bufs=vq5_bufs), B5 * 1024 * 136)
+
 vq_idx = ops.vq_forward(zq, cbk, want_out=False)[0]
 gq = torch.randn_like(zq)
 cases["vq_bwd"] = (lambda: ops.vq_backward_slabs(zq, cbk, vq_idx, gq, None, 0.25), B * 256 * (3 * 64 + 8))  # z, g_out, dz, idx

@@ -19,7 +19,8 @@ KEYS = {                       # key in the JSON -> substring of the kernel name
     "dec_tail_backward": "false>(float const",        # dec_tail_backward_kernel<NIN, false>
     "dec_tail_forward": "dec_tail_forward_kernel",
     "conv4x4s2_e1": "conv4x4s2_kernel",
-    "vq_forward_mfma": "vq_forward_mfma_kernel",
+    "vq_forward_mfma": "vq_forward_mfma_kernel<16, true",         # K = 64: the whole codebook in one LDS piece
+    "vq_forward_mfma_k4096": "vq_forward_mfma_kernel<16, false",  # K = 4096 (KB_B5 patches): codebook walks through LDS
     "vq_backward_mfma": "vq_backward_mfma_kernel",
     "copy_calib": "elementwise_kernel",
 }
@@ -42,6 +43,7 @@ def per_kernel(directory, counter):
 
 def main():
     fetch_dir, write_dir, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    batch5 = int(sys.argv[4]) if len(sys.argv) > 4 else 1024       # KB_B5 of the kbench run (stress shape)
     fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
     write, _ = per_kernel(write_dir, "WRITE_SIZE")
     out = {}
@@ -52,7 +54,7 @@ def main():
         # the heaviest kernel under that pattern (the calibration copy is the only large elementwise launch)
         n = max(names, key=lambda k: fetch[k])
         fk, wk = fetch[n], write.get(n, 0.0)
-        out[key] = {"kernel": n[:160], "batch": batch, "launches": nf[n], "FETCH_SIZE_KiB": round(fk, 1),
+        out[key] = {"kernel": n[:160], "batch": batch5 if key.endswith("k4096") else batch, "launches": nf[n], "FETCH_SIZE_KiB": round(fk, 1),
                     "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
                     "uncorrected_bytes_per_launch": int((fk + wk) * 1024)}
     json.dump(out, sys.stdout, indent=1)
