@@ -286,17 +286,20 @@ __global__ void vq_hist_reduce_kernel(const int *__restrict__ hrep, int R, int K
 // (A = -2 e, exact), the positions on the columns (B = z) and |e_k|^2 as the initial accumulator gives
 // s(k) = fl-chain(S(k)) at 2*K*D FLOP on the matrix pipe.  The result is only an approximation of the reference's
 // d_ref(k) = sum_d fl(fl(z_d - e_kd)^2) (summed in ATen's order), so it is used as a FILTER:
-//   * per position the two smallest s' are tracked (s' = s with its low 6 bits replaced by the code's number inside
-//     the 64-code chunk, so the minimum carries its own index: v_and_or, v_med3, v_min per score);
+//   * per position the two smallest s' are tracked (s' = s with its low 5 bits replaced by the code's number -- 4 bits
+//     inside the lane's 16 scores, 1 more in the first merge step -- so the minimum carries its own index: v_and_or,
+//     v_med3, v_min per score);
 //   * error bounds, u = 2^-24, A = |z|^2 + 2 max_k |e_k|^2:
 //       |s'(k) - S(k)| <= (D + 1) u A   (rounded |e|^2 + D fused multiply-adds, every partial sum <= A in magnitude)
-//                         + 128 u A     (64 ulp of the index bits)                         =: eta
+//                         + 64 u A      (at most 31 ulp of index bits, 1 ulp <= 2 u |s'|)   =: eta = (D + 65) u A
 //       |d_ref(k) - D(k)| <= (D/16 + 18) u D(k) =: rho D(k),  D(k) = |z|^2 + S(k)  (3 roundings per square, then at
 //                                                              most 15 + D/16 - 1 additions of non-negative terms);
 //     with g' = s'(j) - s'(k*) the reference orders d_ref(k*) < d_ref(j) whenever
 //       g' > [2 eta + 2 rho (|z|^2 + s'(k*)) + 2 rho eta] / (1 - rho);
-//     the kernel tests g' > tol with tol = 2 x (2 eta + 2 rho max(|z|^2 + s'(k*), 0)) (a factor 2 of margin over the
-//     first-order bound, |z|^2 from an fp32 dot product) for the runner-up, which then holds for every other code;
+//     the kernel tests g' > tol with tol = 1.25 x (2 eta + 2 rho max(|z|^2 + s'(k*), 0)) = TOL_A A + TOL_D max(..., 0)
+//     (TOL_A = 2.5 (D + 65) u, TOL_D = 2.5 (D/16 + 18) u in the kernel: a margin of 1.25 over the first-order bound --
+//     the neglected terms 2 rho eta and the 1/(1 - rho) are O(u) relative to it -- |z|^2 from an fp32 dot product) for
+//     the runner-up, which then holds for every other code;
 //   * a position that fails the test (1e-3 of them on N(0,1) data; every position whose z or codebook is not finite,
 //     because tol is then inf or NaN) is re-evaluated EXACTLY over all K codes by the whole wave: lane l takes codes
 //     l, l + 64, ... in the reference's arithmetic and order, first minimum and torch.argmax(-dist) NaN rule included.
@@ -442,8 +445,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     constexpr int CHUNK_F4 = 4 * SQ * 64;                          // f32x4 of packed A operand per 64-code chunk
     constexpr int PIECE = SINGLE ? 1 : (2048 / CHUNK_F4 > 0 ? 2048 / CHUNK_F4 : 1);   // code chunks per 32 KB LDS piece
     constexpr float U = 5.9604645e-8f;                             // 2^-24
-    // 32 ulp of index bits (4 in the lane, 1 in the first merge step) instead of the 64 of the header comment's bound
-    // (margin 1.25 over the first-order bound: the neglected terms are O(u) relative to it)
+    // the header comment's bound: tol = 1.25 x (2 eta + 2 rho max(|z|^2 + s', 0)), eta = (D + 65) u A, rho = (D/16 + 18) u
     constexpr float TOL_A = 2.5f * (D + 65) * U, TOL_D = 2.5f * (D / 16 + 18) * U;
     __shared__ f32x4 s_A[SINGLE ? 1 : PIECE * CHUNK_F4];
     __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];

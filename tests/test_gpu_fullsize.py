@@ -1,0 +1,132 @@
+"""GPU: the MODEL at BASELINE.json's batch sizes against the CPU oracle (missing 4) -- not only the
+size-independent properties of test_gpu_model.py::test_round_trip_properties_full_size.
+
+  C3  one FusedTrainer.step on 2048 patches  vs  oracle.train_step (run_training.py:504-532's body at that batch):
+      losses <= 1e-5, codes over all 524 288 positions (conftest.codes_gate), every gradient on the float64 yardstick;
+  C2  encode_patches on 1024 patches          vs  oracle.encode_per_sample (patch_VAE.py:445-452's loop).
+
+The oracle evaluates the VectorQuantizer distances in chunks of 64 samples (OracleVQ.chunk; the reference's single
+expression is 8.6 GB at this batch, 17 GB in float64) -- bit-identical, tests/test_oracle.py."""
+import copy
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import codes_gate, grad_gate
+from test_gpu_model import BN_FED_BIASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _host_memory_ok(need_gb):
+    try:
+        import psutil
+        return psutil.virtual_memory().available >= need_gb * (1 << 30)
+    except Exception:
+        return True
+
+
+@pytest.mark.timeout(900)
+def test_c3_training_step_at_batch_2048_against_the_oracle():
+    if not _host_memory_ok(24):
+        pytest.skip("host has < 24 GB available for the float64 oracle run at B = 2048")
+    import dynamorph_amd
+    from dynamorph_amd.train import FusedTrainer
+    from oracle import vqvae_oracle as O
+    B = 2048
+    torch.manual_seed(2048)
+    ref = O.OracleVQVAE()
+    ref.vq.chunk = 64
+    x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(1234))
+    m = dynamorph_amd.VQ_VAE().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    xd = x.to(DEV)
+
+    # codes of the untouched model on the whole batch, HIP encoder vs the oracle's (train-mode batch statistics)
+    probe = copy.deepcopy(ref)
+    with torch.no_grad():
+        zb_r = probe.enc(x)
+        idx_r = probe.vq.encode_inputs(zb_r)
+        mp = copy.deepcopy(m)
+        idx = mp.vq.encode_inputs(mp.enc(xd)).cpu()
+    assert idx.shape == (B, 16, 16)
+    codes_gate(idx != idx_r, zb_r, probe.vq.w.weight.detach(), "C3, B = 2048: all 524 288 positions")
+    del probe, mp, zb_r
+    gc.collect()
+
+    # float64 truth of the gradients first (its graph is freed before the fp32 run starts)
+    ref64 = copy.deepcopy(ref).double()
+    _, ld64 = ref64(x.double())
+    ld64["total_loss"].backward()
+    g64 = {k: p.grad for k, p in ref64.named_parameters() if p.grad is not None}
+    del ld64
+    gc.collect()
+    opt = O.make_adam(ref, 1e-4)
+    _, ld_r = ref(x)
+    ld_r["total_loss"].backward()
+    g32 = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    opt.step()
+    ld_r = {k: float(v) for k, v in ld_r.items()}
+    gc.collect()
+
+    tr = FusedTrainer(m, lr=1e-4, use_graph=True)
+    vals = tr.step(xd).tolist()
+    for i, k in enumerate(("recon_loss", "commitment_loss", "total_loss")):
+        assert abs(vals[i] - ld_r[k]) <= 1e-5, (k, vals[i], ld_r[k])                 # the north star's tolerance
+    assert abs(vals[3] - ld_r["perplexity"]) <= 1e-3 * ld_r["perplexity"]
+    tr.expose_grads()
+    grad_gate(m, g32, g64, skip=BN_FED_BIASES, what="C3 step at B = 2048")
+    # one Adam step at lr = 1e-4 moves every weight by at most lr; where the reference's own gradient is above its fp32
+    # noise the step has the same direction
+    sd_r = ref.state_dict()
+    for k, v in m.state_dict().items():
+        if k in BN_FED_BIASES or "tracked" in k:
+            continue
+        if "running" in k:
+            assert (v.cpu() - sd_r[k]).abs().max().item() <= 1e-5 * max(1.0, sd_r[k].abs().max().item()), k
+        else:
+            assert (v.cpu() - sd_r[k]).abs().max().item() <= 2.0e-4 + 1e-9, k
+    noisy = 0
+    for k, p in ref.named_parameters():
+        if not p.requires_grad or k in BN_FED_BIASES:
+            continue
+        clear = g32[k].abs() > 50 * (g32[k].double() - g64[k]).abs().max().float()   # well above the fp32 noise
+        moved = (m.state_dict()[k].cpu() - sd_r[k]).abs()
+        assert moved[clear].max().item() <= 2.5e-5 if clear.any() else True, k
+        noisy += int((~clear).sum())
+    print("entries whose reference gradient is inside its own fp32 noise:", noisy)
+
+
+@pytest.mark.timeout(600)
+def test_c2_latents_of_1024_patches_against_the_oracle_loop():
+    import dynamorph_amd
+    from dynamorph_amd.patch_vae import encode_patches
+    from oracle import vqvae_oracle as O
+    N = 1024
+    torch.manual_seed(1024)
+    ref = O.OracleVQVAE()
+    m = dynamorph_amd.VQ_VAE().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(N, 2, 128, 128, generator=torch.Generator().manual_seed(4321))
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    with torch.no_grad():
+        zb_r, za_r = O.encode_per_sample(ref, x)          # patch_VAE.py:445-452: 1024 batch-of-one calls, train-mode BN
+    zb, za = encode_patches(m, x, device=DEV, batch_size=1024)
+    assert zb.shape == (N, 4096) and za.shape == (N, 4096) and zb.dtype == np.float32
+    err = np.abs(zb - zb_r.reshape(N, -1).numpy())
+    assert err.max() <= 3e-4, err.max()
+    # quantised latents: equal wherever the code is the same; codes may differ only at the reference's own near-ties
+    diff = (np.abs(za.reshape(N, 16, 16, 16) - za_r.numpy()) > 1e-3).any(axis=1)
+    codes_gate(diff, zb_r, ref.vq.w.weight.detach(), "C2, N = 1024: all 262 144 positions")
+    same = ~diff
+    assert np.abs(za.reshape(N, 16, 16, 16) - za_r.numpy()).transpose(0, 2, 3, 1)[same].max() <= 3e-4
+    # the side effect the loop has on the checkpointed buffers: 1024 momentum updates of the running statistics
+    sd_r = ref.state_dict()
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert (v.cpu() - sd_r[k]).abs().max().item() <= 2e-4 * max(1.0, sd_r[k].abs().max().item()), k
+        if "tracked" in k:
+            assert int(v) == int(sd_r[k]) == N, k
