@@ -30,21 +30,28 @@ from .ops import (DM_LOAD_AFFINE, DM_LOAD_AFFINE2, DM_LOAD_AFFINE_RELU, DM_LOAD_
 
 
 class Layers:
-    """Parameter handles resolved from a VQ_VAE-shaped nn.Module (state-dict names of the reference)."""
+    """Parameter handles resolved from a VQ_VAE-shaped nn.Module (state-dict names of the reference), or from one of its
+    halves: `model.enc` / `model.dec` called on their own build Layers(enc=self) / Layers(dec=self) -- no back-reference
+    to the parent, so copy.deepcopy(model) and pickling give an independent, working module."""
 
-    def __init__(self, model):
-        enc, dec = model.enc, model.dec
-        self.enc0, self.enc1, self.bn1 = enc[0], enc[1], enc[2]
-        self.enc4, self.bn2 = enc[4], enc[5]
-        self.enc7, self.bn3 = enc[7], enc[8]
-        self.enc10, self.bn4 = enc[10], enc[11]
-        self.res = [(l[1], l[2], l[4], l[5]) for l in enc[12].layers]
-        self.codebook = model.vq.w
-        self.dec0, self.dec2, self.dec4, self.dec6 = dec[0], dec[2], dec[4], dec[6]
-        self.channel_var = model.channel_var
-        self.nin = self.enc0.weight.shape[1]
-        self.nh = self.enc10.weight.shape[0]
-        self.nrh = self.res[0][0].weight.shape[0] if self.res else 0
+    def __init__(self, model=None, enc=None, dec=None):
+        if model is not None:
+            enc, dec = model.enc, model.dec
+        self.codebook = model.vq.w if model is not None else None
+        self.channel_var = model.channel_var if model is not None else None
+        if enc is not None:
+            self.enc0, self.enc1, self.bn1 = enc[0], enc[1], enc[2]
+            self.enc4, self.bn2 = enc[4], enc[5]
+            self.enc7, self.bn3 = enc[7], enc[8]
+            self.enc10, self.bn4 = enc[10], enc[11]
+            self.res = [(l[1], l[2], l[4], l[5]) for l in enc[12].layers]
+            self.nin = self.enc0.weight.shape[1]
+            self.nh = self.enc10.weight.shape[0]
+            self.nrh = self.res[0][0].weight.shape[0] if self.res else 0
+        if dec is not None:
+            self.dec0, self.dec2, self.dec4, self.dec6 = dec[0], dec[2], dec[4], dec[6]
+            if enc is None:
+                self.nin, self.nh = self.dec6.weight.shape[0], self.dec0.weight.shape[0]
 
     def encoder_params(self):
         ps = [self.enc0.weight, self.enc0.bias, self.enc1.weight, self.enc1.bias, self.bn1.weight, self.bn1.bias,
@@ -256,7 +263,8 @@ def decoder_forward(L, zq, x=None, mask=None, defer_tail=False):
                         pixel_shuffle=True, bias=_w(L.dec0.bias), relu=True)
     d2, _ = ops.conv3x3(Op(d0), weight_view(_w(L.dec2.weight), 16, c2 * 16, 4, 1), B, c1, 4 * c2, 2 * H3, 2 * W3, taps=9,
                         pixel_shuffle=True, bias=_w(L.dec2.bias), relu=True)
-    var = _w(L.channel_var).reshape(-1)
+    # (model.dec called on its own has no loss and hence no channel variances)
+    var = _w(L.channel_var).reshape(-1) if L.channel_var is not None else torch.ones(L.dec6.weight.shape[0], device=zq.device)
     fused = ops.dec_tail_supported(c2, L.dec6.weight.shape[0], 4 * H3, 4 * W3)
     if fused and defer_tail and x is not None:
         cx = SimpleNamespace(zq=zq, d0=d0, d2=d2, d4=None, dec=None, x=x, mask=mask, loss_slabs=None, deferred=True)
@@ -313,7 +321,7 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
     B, nh, H3, W3 = zq.shape
     c1, c2 = nh // 2, nh // 4
     NIN = L.dec6.weight.shape[0]
-    var = _w(L.channel_var).reshape(-1)
+    var = _w(L.channel_var).reshape(-1) if L.channel_var is not None else torch.ones(NIN, device=zq.device)
     pending = []
     if cx.deferred:
         if gdec_ext is not None or gscale is None:
@@ -407,7 +415,7 @@ def z32_tail_forward(up0, bn, up1, r, x, mask, channel_var):
     coefd, savedd = _bn_coef(st, bn, B * 4 * H2 * W2, False, B)
     dec, _ = ops.conv3x3(Op(d1, DM_LOAD_AFFINE_RELU, coefd), weight_view(_w(up1.weight), 16, NIN * 16, 4, 1), B, c1,
                          4 * NIN, 2 * H2, 2 * W2, taps=9, pixel_shuffle=True, bias=_w(up1.bias))
-    var = _w(channel_var).reshape(-1)
+    var = _w(channel_var).reshape(-1) if channel_var is not None else torch.ones(NIN, device=r.device)
     slabs = ops.recon_loss(dec, x, mask, var) if x is not None else None
     cx = SimpleNamespace(r=r, d1=d1, coefd=coefd, savedd=savedd, dec=dec, x=x, mask=mask, var=var, loss_slabs=slabs,
                          dims=(B, nh, c1, NIN, H2, W2))

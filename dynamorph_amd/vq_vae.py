@@ -237,7 +237,8 @@ def _held(base):
         def forward(self, *args, **kwargs):
             raise RuntimeError(f"{base.__name__} inside dynamorph_amd is a parameter container of the HIP pipeline: call the "
                                "enclosing module (model.enc / model.dec / ResidualBlock); there is no ATen fallback")
-    Held.__name__ = Held.__qualname__ = base.__name__
+    Held.__name__ = base.__name__              # what a reader of repr(model) / type(layer).__name__ sees: the reference's
+    Held.__qualname__ = "_" + base.__name__     # where pickle finds the class again: the module-level names below
     return Held
 
 
@@ -284,7 +285,7 @@ class _HipEncoder(nn.Sequential):
 
     def forward(self, x):
         _require_gpu(x, "VQ_VAE.enc")
-        layers = E.Layers(self._owner())
+        layers = E.Layers(enc=self)
         return _EncoderFn.apply(_prep(x), layers, self.per_sample_stats, *layers.encoder_params())
 
 
@@ -293,7 +294,7 @@ class _HipDecoder(nn.Sequential):
 
     def forward(self, z):
         _require_gpu(z, "VQ_VAE.dec")
-        layers = E.Layers(self._owner())
+        layers = E.Layers(dec=self)
         dec, _ = _DecoderFn.apply(_prep(z), None, None, layers, *layers.decoder_params())
         return dec
 
@@ -362,11 +363,6 @@ class VQ_VAE(nn.Module):
             _ConvTranspose2d(nh // 4, nh // 4, 4, stride=2, padding=1),
             _ReLU(),
             _Conv2d(nh // 4, num_inputs, 1))
-        # weak back-references (not registered as submodules: state_dict stays the reference's 68 keys)
-        import weakref
-        ref = weakref.ref(self)
-        object.__setattr__(self.enc, "_owner", ref)
-        object.__setattr__(self.dec, "_owner", ref)
 
     # ---- the pairwise term (vq_vae.py:324-332; weighted / hinge form of VQ_VAE_z16, vae.py:322-336): one fused op ----
     def _time_matching(self, z_before, time_matching_mat):
@@ -474,7 +470,8 @@ class _Z32Decoder(nn.Sequential):
 
     def forward(self, z):
         _require_gpu(z, "VQ_VAE_z32.dec")
-        dec, _ = self._tail(self[0](_prep(z)), None, None, self._owner().channel_var)
+        # (no loss here, so the channel variances are not needed: `model.dec` holds no reference to its parent)
+        dec, _ = self._tail(self[0](_prep(z)), None, None, None)
         return dec
 
 
@@ -520,8 +517,6 @@ class VQ_VAE_z32(nn.Module):
             _ReLU(),
             _ConvTranspose2d(nh // 2, num_inputs, 4, stride=2, padding=1))
         self.extra_loss = None
-        import weakref
-        object.__setattr__(self.dec, "_owner", weakref.ref(self))
 
     def forward(self, inputs, labels=None, time_matching_mat=None, batch_mask=None):
         """inputs (B, C, H, W) -> (decoded, loss dict)   [vae.py:430-470]"""

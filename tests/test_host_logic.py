@@ -208,3 +208,28 @@ def test_operands_on_different_devices_raise_and_leave_no_state_behind(monkeypat
     with pytest.raises(ValueError, match="different devices"):
         conv_like()
     assert _lib.is_host_only("dm_conv3x3_scratch_floats") and not _lib.is_host_only("dm_conv3x3")
+
+
+def test_deepcopy_and_pickle_give_an_independent_module():
+    """model.enc / model.dec hold no reference to their parent: a deep copy's halves work on the COPY's parameters (a weak
+    back-reference used to survive copy.deepcopy pointing at the original: the copy's enc then ran -- and advanced the
+    BatchNorm running statistics of -- the original), and the whole module pickles (torch.save(model))."""
+    import copy
+    import io
+    from dynamorph_amd import engine as E
+    for cls in (dynamorph_amd.VQ_VAE, dynamorph_amd.VQ_VAE_z16, dynamorph_amd.VQ_VAE_z32):
+        m = cls()
+        c = copy.deepcopy(m)
+        assert not hasattr(m.enc, "_owner") and not hasattr(m.dec, "_owner")
+        assert all(a.data_ptr() != b.data_ptr() for a, b in zip(m.parameters(), c.parameters()))
+        if cls is not dynamorph_amd.VQ_VAE_z32:
+            Lc, Lm = E.Layers(enc=c.enc), E.Layers(enc=m.enc)
+            assert Lc.enc1.weight is c.enc[1].weight and Lc.bn1.running_mean is c.enc[2].running_mean
+            assert Lc.enc1.weight is not Lm.enc1.weight
+            Ld = E.Layers(dec=c.dec)
+            assert Ld.dec4.weight is c.dec[4].weight and Ld.channel_var is None and (Ld.nh, Ld.nin) == (16, 2)
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        r = torch.load(buf, weights_only=False)
+        assert list(r.state_dict().keys()) == list(m.state_dict().keys())
