@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM_LIB_PATH") or os.path.join(_HERE, "libdynamorph_hip.so")
 
 DM_LOAD_IDENT, DM_LOAD_RELU, DM_LOAD_AFFINE, DM_LOAD_AFFINE_RELU, DM_LOAD_AFFINE2 = range(5)
-DM_VQ_AUTO, DM_VQ_EXACT, DM_VQ_MFMA = range(3)
+DM_VQ_AUTO, DM_VQ_EXACT, DM_VQ_MFMA, DM_VQ_BF16 = range(4)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

@@ -26,11 +26,14 @@ constexpr int VQ_MAX_LDS_HIST = 4096;
 //   cbA     [K64/64][4 kt][SQ][64 lanes][4]  A operand of v_mfma_f32_16x16x4_f32: -2 * e[64 cc + 16 kt + (lane & 15)]
 //           [4 (4 sq + j) + (lane >> 4)], zero beyond K / D  (K64 = K rounded up to 64, SQ = ceil(D / 16))
 //   nrm     [K64]  ||e_k||^2 summed in double, rounded once; VQ2_PAD_NORM beyond K (such a code never wins)
+//   cbB     [K64/64][4 kt][U][2 (hi, lo)][64 lanes][4 x u32]  A operand of v_mfma_f32_16x16x32_bf16 (the bf16-split filter,
+//           U = D / 16 K-groups): the bf16 head (resp. remainder) of -2 * e[64 cc + 16 kt + (lane & 15)][4 (4 u + j) + (lane >> 4)],
+//           j = 0..3, packed in pairs and repeated, so that the 8 k-slots of a lane group multiply (z_hi[0..3], z_lo[0..3])
 //   cbH     [K][4 h][D / 4]  e[k][4 s + h]: the codebook row in the order a lane of the MFMA kernel holds z
 //   hrep    [R][K] int32  replicated code-usage counters (vq_hist_replicas)
 constexpr int VQ2_HDR = 32;
 constexpr float VQ2_PAD_NORM = 3.0e38f;
-struct Vq2Layout { long long cbT, cbA, nrm, cbH, hrep, total; int R; };
+struct Vq2Layout { long long cbT, cbA, cbB, nrm, cbH, hrep, total; int R; };
 
 // Code-usage counters: every workgroup flushing its LDS histogram into ONE set of K global counters serialises
 // (workgroups x K atomics on K addresses: 8 us of a 28 us kernel at 512 workgroups, K = 64).  The workgroups add into
@@ -49,12 +52,22 @@ Vq2Layout vq2_layout(int K, int D)
     long long o = VQ2_HDR;
     L.cbT = o; o += (long long)((K + 1) / 2) * 2 * D; o = (o + 3) & ~3LL;
     L.cbA = o; o += K64 * 16 * SQ;
+    L.cbB = o; o += (D % 16 == 0 && D <= 64) ? K64 * 2 * D : 0;
     L.nrm = o; o += K64;
     L.cbH = o; o += (long long)K * D; o = (o + 3) & ~3LL;
     L.R = vq_hist_replicas(K);
     L.hrep = o; o += (long long)L.R * K; o = (o + 3) & ~3LL;
     L.total = o;
     return L;
+}
+
+// float -> bf16 bits, round to nearest even, exactly what v_cvt_pk_bf16_f32 does for finite values (a NaN stays a NaN, an
+// overflow becomes inf: either makes the filter's tolerance non-finite and sends the position down the exact path)
+__device__ __forceinline__ unsigned vq_bf16_rne(float v)
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t r = __builtin_convertvector((f32x2){v, 0.f}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, r) & 0xffffu;
 }
 
 __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ ws, Vq2Layout L, int K, int D,
@@ -88,6 +101,32 @@ __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__
         const long long code = cc * 64 + kt * 16 + (lane & 15);
         const int d = 4 * (4 * sq + j) + (lane >> 4);
         cbA[i] = (code < K && d < D) ? -2.f * cb[code * D + d] : 0.f;
+    }
+    if (D % 16 == 0 && D <= 64) {
+        // bf16-split A operand: -2e = hi + lo + r with hi = bf16(-2e), lo = bf16(-2e - hi), |r| <= 2^-18 |2e|
+        unsigned *__restrict__ cbB = reinterpret_cast<unsigned *>(ws + L.cbB);
+        const int U = D / 16;
+        for (long long i = t0; i < K64 * 2 * D / 2; i += nt) {           // one packed pair of k-slots (j = 2 jp, 2 jp + 1) per step
+            const int jp = (int)(i & 1), lane = (int)((i >> 1) & 63), half = (int)((i >> 7) & 1);
+            long long rest = i >> 8;
+            const int u = (int)(rest % U); rest /= U;
+            const int kt = (int)(rest & 3);
+            const long long cc = rest >> 2;
+            const long long code = cc * 64 + kt * 16 + (lane & 15);
+            unsigned pair = 0;
+            for (int q = 0; q < 2; ++q) {
+                const int d = 4 * (4 * u + 2 * jp + q) + (lane >> 4);
+                const float a = code < K ? -2.f * cb[code * D + d] : 0.f;
+                const unsigned hi = vq_bf16_rne(a);
+                const float rem = a - __builtin_bit_cast(float, hi << 16);
+                const unsigned part = half ? vq_bf16_rne(rem) : hi;
+                pair |= part << (16 * q);
+            }
+            // u32x4 of a lane = (pair 0, pair 1, pair 0, pair 1): slots 0..3 meet z_hi, slots 4..7 meet z_lo
+            const long long base = ((((cc * 4 + kt) * U + u) * 2 + half) * 64 + lane) * 4;
+            cbB[base + jp] = pair;
+            cbB[base + 2 + jp] = pair;
+        }
     }
     float *__restrict__ nrm = ws + L.nrm;
     for (long long k = t0; k < K64; k += nt) {
@@ -432,7 +471,14 @@ __device__ __forceinline__ void vq2_swap(float &x, float &y)
 // re-checks, an all-gather of the four chosen codes, the gather / straight-through value / squared error, the stores.
 // On gfx950 the f32 MFMA and the VALU do not overlap (SQ_VALU_MFMA_COEXEC_CYCLES = 0: the kernel's time is the SUM of its
 // matrix and vector instructions), so what is left to optimise is the instruction count of everything around the MFMAs.
-template <int D, bool SINGLE, int MINW>
+// BF: the filter product on v_mfma_f32_16x16x32_bf16 with both operands split into a bf16 head and a bf16 remainder
+// (z = z_hi + z_lo + r, |r| <= 2^-18 |z|; likewise -2e, split once by vq_prep_kernel).  The 32 k-slots of one instruction
+// are (z_hi, z_lo) of 16 dimensions; two instructions per 16 dimensions (A = the heads of -2e, then its remainders) give
+// (a_hi + a_lo) . (z_hi + z_lo): a quarter of the matrix-pipe cycles of four v_mfma_f32_16x16x4_f32 steps (2 x 16 against
+// 4 x 32), on the real matrix cores -- the f32-input instruction runs at the vector rate and (SQ_VALU_MFMA_COEXEC_CYCLES
+// = 0) never beside vector instructions.  Price: 12 vector instructions per position tile to split z, and a wider
+// tolerance (below), i.e. more positions on the exact path.  cbA is then the cbB region of the workspace.
+template <int D, bool SINGLE, int MINW, bool BF>
 __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbA,
     const float *__restrict__ nrm, const float *__restrict__ cbH, long long *__restrict__ idx,
@@ -442,11 +488,22 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     constexpr int BLOCK = 256, NW = 4;
     int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;     // this workgroup's replica of the counters
     constexpr int S = D / 4, SQ = (S + 3) / 4;
-    constexpr int CHUNK_F4 = 4 * SQ * 64;                          // f32x4 of packed A operand per 64-code chunk
+    constexpr int UG = BF ? D / 16 : 1;                            // K-groups of 16 dimensions (bf16-split filter)
+    static_assert(!BF || D % 16 == 0, "bf16-split filter: embedding_dim 16, 32 or 64");
+    constexpr int AQ = BF ? 2 * UG : SQ;                           // 16-byte A operands per lane and code tile
+    constexpr int CHUNK_F4 = 4 * AQ * 64;                          // 16-byte units of packed A operand per 64-code chunk
     constexpr int PIECE = SINGLE ? 1 : (2048 / CHUNK_F4 > 0 ? 2048 / CHUNK_F4 : 1);   // code chunks per 32 KB LDS piece
     constexpr float U = 5.9604645e-8f;                             // 2^-24
-    // the header comment's bound: tol = 1.25 x (2 eta + 2 rho max(|z|^2 + s', 0)), eta = (D + 65) u A, rho = (D/16 + 18) u
-    constexpr float TOL_A = 2.5f * (D + 65) * U, TOL_D = 2.5f * (D / 16 + 18) * U;
+    // the header comment's bound: tol = 1.25 x (2 eta + 2 rho max(|z|^2 + s', 0)), eta = ETA u A, rho = (D/16 + 18) u.
+    // f32 filter: ETA = D + 65 (D fused multiply-adds + the rounded norm, 64 of index bits).
+    // bf16-split filter: ETA = 66 (norm, index bits)
+    //   + 128: the split's remainders -- |sum_d a z - sum_d (a_hi + a_lo)(z_hi + z_lo)| <= (2^-18 + 2^-18 + 2^-36) sum |a||z|
+    //          <= 2^-17 (|e|^2 + |z|^2) <= 2^-17 A = 128 u A  (the products of bf16 values are exact in fp32)
+    //   + 100 per matrix instruction: its 32 products + C are added in an order and with intermediate roundings the ISA does
+    //          not specify; every partial sum is <= 1.01 A in magnitude, so 33 additions that each lose at most one ulp
+    //          (2 u relative: truncation) stay below 67 u A -- taken as 100.
+    constexpr float ETA = BF ? 66.f + 128.f + 100.f * (2 * UG) : (float)(D + 65);
+    constexpr float TOL_A = 2.5f * ETA * U, TOL_D = 2.5f * (D / 16 + 18) * U;
     __shared__ f32x4 s_A[SINGLE ? 1 : PIECE * CHUNK_F4];
     __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];
     constexpr int HROW = S + 1;                                       // f32x4 per code in s_H: D floats + 16 bytes of padding (banks)
@@ -494,7 +551,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     z_load(zr, chunk, cb_, cw_);
     // every global load of the prologue is issued before the first wait: z of the first chunk, the A operand and the
     // norms (small codebooks: registers), the rows for the gather -- one memory round trip instead of four
-    f32x4 areg[4][SQ], nreg[4];
+    f32x4 areg[4][AQ], nreg[4];
     constexpr int HCOPY = SINGLE ? (64 * S + BLOCK - 1) / BLOCK : 1;
     f32x4 hreg[HCOPY];
     if constexpr (SINGLE) {
@@ -502,7 +559,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int sq = 0; sq < SQ; ++sq) areg[kt][sq] = reinterpret_cast<const f32x4 *>(cbA)[(kt * SQ + sq) * 64 + lane];
+            for (int sq = 0; sq < AQ; ++sq) areg[kt][sq] = reinterpret_cast<const f32x4 *>(cbA)[(kt * AQ + sq) * 64 + lane];
             nreg[kt] = *reinterpret_cast<const f32x4 *>(nrm + kt * 16 + h * 4);
         }
 #pragma unroll
@@ -542,7 +599,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int sq = 0; sq < SQ; ++sq) asm volatile("" ::"v"(areg[kt][sq]));
+            for (int sq = 0; sq < AQ; ++sq) asm volatile("" ::"v"(areg[kt][sq]));
             asm volatile("" ::"v"(nreg[kt]));
         }
     } else {
@@ -581,11 +638,52 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) { m1[t] = 3.4028235e38f; m2[t] = 3.4028235e38f; c1[t] = 0; }
 
+        // bf16-split filter: the B operands of the chunk's four position tiles, (z_hi[0..3], z_lo[0..3]) of the lane's four
+        // dimensions of K-group u as four packed pairs -- built once per chunk of positions, used by every code chunk
+        typedef unsigned vq_u32x4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 vq_bf16x8 __attribute__((ext_vector_type(8)));
+        typedef __bf16 vq_bf16x2 __attribute__((ext_vector_type(2)));
+        vq_u32x4 bq[BF ? 4 : 1][UG];
+        if constexpr (BF) {
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) {
+                        const float z0 = zr[4 * u][t], z1 = zr[4 * u + 1][t], z2 = zr[4 * u + 2][t], z3 = zr[4 * u + 3][t];
+                        const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){z0, z1}, vq_bf16x2));
+                        const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){z2, z3}, vq_bf16x2));
+                        const float r0 = z0 - __builtin_bit_cast(float, h01 << 16), r1 = z1 - __builtin_bit_cast(float, h01 & 0xffff0000u);
+                        const float r2 = z2 - __builtin_bit_cast(float, h23 << 16), r3 = z3 - __builtin_bit_cast(float, h23 & 0xffff0000u);
+                        const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, vq_bf16x2));
+                        const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r2, r3}, vq_bf16x2));
+                        bq[t][u] = (vq_u32x4){h01, h23, l01, l23};
+                    }
+            }
+        }
+
         // scores of one 64-code chunk against the 4 position tiles; na: the chunk's |e|^2, aq(kt, sq): 4 K-steps of A
+        // (bf16-split: aq(kt, 2 u + half) = heads / remainders of -2e for K-group u)
         auto chunk_scores = [&](const f32x4 (&na)[4], auto &&aq, int ccg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 f32x4 acc[4];
+                if constexpr (BF) {
+#pragma unroll
+                    for (int u = 0; u < UG; ++u)
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            f32x4 a4[4];
+#pragma unroll
+                            for (int kt = 0; kt < 4; ++kt) a4[kt] = aq(kt, 2 * u + half);
+                            // code tile inner: consecutive instructions belong to four independent accumulator chains
+#pragma unroll
+                            for (int kt = 0; kt < 4; ++kt)
+                                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vq_bf16x8, a4[kt]),
+                                                                                   __builtin_bit_cast(vq_bf16x8, bq[t][u]),
+                                                                                   (u == 0 && half == 0) ? na[kt] : acc[kt], 0, 0, 0);
+                        }
+                } else {
 #pragma unroll
                 for (int sq = 0; sq < SQ; ++sq) {
                     f32x4 a4[4];
@@ -601,6 +699,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                                 acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[kt][j], zr[s][t], s == 0 ? na[kt] : acc[kt], 0, 0, 0);
                         }
                     }
+                }
                 }
                 // the score's low 4 bits become its number inside the lane (code = 16 kt + 4 h + r): the minimum carries it
                 float v[16];
@@ -641,7 +740,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                         for (int kt = 0; kt < 4; ++kt) na[kt] = s_n[cc * 16 + kt * 4 + h];
                         const f32x4 *__restrict__ ab = s_A + cc * CHUNK_F4 + lane;
                         // (conflict-free ds_read_b128: consecutive lanes, consecutive 16-byte slots)
-                        chunk_scores(na, [&](int kt, int sq) { return ab[(kt * SQ + sq) * 64]; }, p0 + cc);
+                        chunk_scores(na, [&](int kt, int sq) { return ab[(kt * AQ + sq) * 64]; }, p0 + cc);
                     }
                 }
             }
@@ -1200,6 +1299,12 @@ extern "C" int dm_vq_num_blocks(int64_t positions)
 }
 
 namespace {
+// DM_VQ_AUTO's choice of filter; DM_VQ_FILTER=f32 in the environment keeps the f32-input one (A/B measurements)
+bool vq2_auto_bf16()
+{
+    static const bool on = [] { const char *e = getenv("DM_VQ_FILTER"); return !(e && e[0] == 'f'); }();
+    return on;
+}
 bool vq2_applicable(const float *z, const int64_t *idx, const float *out, const void *ws, int D, int HW)
 {
     const uintptr_t al = (uintptr_t)z | (uintptr_t)idx | (uintptr_t)out | (uintptr_t)ws;
@@ -1239,15 +1344,16 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
     DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
     DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d not built (8/16/32/64/128)", D);
     DM_REQUIRE(workspace && workspace_bytes >= dm_vq_workspace_bytes(K, D), "dm_vq_forward: workspace too small");
-    DM_REQUIRE(variant >= DM_VQ_AUTO && variant <= DM_VQ_MFMA, "dm_vq_forward: bad variant %d", variant);
+    DM_REQUIRE(variant >= DM_VQ_AUTO && variant <= DM_VQ_BF16, "dm_vq_forward: bad variant %d", variant);
+    DM_REQUIRE(variant != DM_VQ_BF16 || D % 16 == 0, "dm_vq_forward: the bf16-split filter needs embedding_dim 16, 32 or 64");
     hipStream_t s = (hipStream_t)stream;
     const long long P = (long long)B * H * W;
     const Vq2Layout L = vq2_layout(K, D);
     float *ws = (float *)workspace;
     const bool can2 = vq2_applicable(z, idx, out, workspace, D, H * W);
-    DM_REQUIRE(variant != DM_VQ_MFMA || can2,
+    DM_REQUIRE((variant != DM_VQ_MFMA && variant != DM_VQ_BF16) || can2,
                "dm_vq_forward: the MFMA variant needs embedding_dim 8/16/32/64, H*W %% 64 == 0 and 16-byte aligned tensors");
-    const bool use2 = variant == DM_VQ_MFMA || (variant == DM_VQ_AUTO && can2);
+    const bool use2 = variant == DM_VQ_MFMA || variant == DM_VQ_BF16 || (variant == DM_VQ_AUTO && can2);
     const long long n = L.total;
     const int nslabs = dm_vq_num_blocks(P);
     int pgrid = (int)((n + 255) / 256);
@@ -1257,14 +1363,23 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
     int *hrep = reinterpret_cast<int *>(ws + L.hrep);
     if (use2) {
         const long long groups = ((P >> 6) + 3) / 4;
-#define DM_VQ2(DD, SINGLE_, MINW, WGS)                                                                               \
+#define DM_VQ2K(DD, SINGLE_, MINW, WGS, BF_)                                                                         \
     {                                                                                                                \
         const int wgs = (WGS);                                                                                       \
-        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW>), dim3((unsigned)(groups < 256 * wgs ? groups : 256 * wgs)), \
-                           dim3(256), 0, s, z, codebook, ws + L.cbA, ws + L.nrm, ws + L.cbH, (long long *)idx, out,    \
-                           sse_slabs, hrep, L.R, (int *)ws, K, H * W, P);                                            \
+        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW, BF_>),                                         \
+                           dim3((unsigned)(groups < 256 * wgs ? groups : 256 * wgs)), dim3(256), 0, s, z, codebook,  \
+                           ws + (BF_ ? L.cbB : L.cbA), ws + L.nrm, ws + L.cbH, (long long *)idx, out, sse_slabs, hrep, \
+                           L.R, (int *)ws, K, H * W, P);                                                             \
+    }
+#define DM_VQ2(DD, SINGLE_, MINW, WGS)                                                                               \
+    {                                                                                                                \
+        if constexpr (DD % 16 == 0) {                                                                                \
+            if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true) else DM_VQ2K(DD, SINGLE_, MINW, WGS, false)                \
+        } else DM_VQ2K(DD, SINGLE_, MINW, WGS, false)                                                                \
     }
         const bool single = K <= 64;
+        // bf16-split filter (DM_VQ_BF16; DM_VQ_AUTO takes it where it applies) or the f32 one (DM_VQ_MFMA)
+        const bool bf = D % 16 == 0 && (variant == DM_VQ_BF16 || (variant == DM_VQ_AUTO && vq2_auto_bf16()));
         for (int rep = 0; rep < repeats; ++rep) {
             switch (D) {
             case 8: if (single) DM_VQ2(8, true, 3, 3) else DM_VQ2(8, false, 3, 3) break;
@@ -1274,6 +1389,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
             }
         }
 #undef DM_VQ2
+#undef DM_VQ2K
         if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
         return dm_launch_status("dm_vq_forward");
     }

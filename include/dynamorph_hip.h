@@ -115,9 +115,13 @@ int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *ou
  *   DM_VQ_MFMA   |e|^2 - 2 z.e on the matrix pipe as a filter, the exact arithmetic only for positions whose two best
  *                scores are closer than the proven error bound (csrc/vq.hip) -- identical indices; needs
  *                embedding_dim 8/16/32/64, H*W a multiple of 64 and 16-byte aligned tensors (else a negative return);
- *   DM_VQ_AUTO   DM_VQ_MFMA where it applies, DM_VQ_EXACT otherwise.
- * After a DM_VQ_MFMA call the first int32 of `workspace` holds the number of positions that took the exact path. */
-enum { DM_VQ_AUTO = 0, DM_VQ_EXACT = 1, DM_VQ_MFMA = 2 };
+ *   DM_VQ_BF16   the same filter on v_mfma_f32_16x16x32_bf16 with both operands split into a bf16 head and remainder
+ *                (a quarter of the matrix cycles, a wider proven tolerance, more positions on the exact path) -- identical
+ *                indices; embedding_dim 16/32/64;
+ *   DM_VQ_AUTO   DM_VQ_BF16 where it applies (DM_VQ_FILTER=f32 in the environment: DM_VQ_MFMA), else DM_VQ_MFMA, else
+ *                DM_VQ_EXACT.
+ * After a filtered call the first int32 of `workspace` holds the number of positions that took the exact path. */
+enum { DM_VQ_AUTO = 0, DM_VQ_EXACT = 1, DM_VQ_MFMA = 2, DM_VQ_BF16 = 3 };
 int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
                           double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
                           void *workspace, size_t workspace_bytes, int variant, void *stream);
