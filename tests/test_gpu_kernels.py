@@ -61,9 +61,9 @@ def load_ref(p0, mode, coef=None, p1=None):
 
 
 # =================================================================================== VQ
-from dynamorph_amd._lib import DM_VQ_AUTO, DM_VQ_EXACT, DM_VQ_MFMA          # noqa: E402
+from dynamorph_amd._lib import DM_VQ_AUTO, DM_VQ_BF16, DM_VQ_EXACT, DM_VQ_MFMA          # noqa: E402
 
-VQ_VARIANTS = [pytest.param(DM_VQ_EXACT, id="exact"), pytest.param(DM_VQ_MFMA, id="mfma")]
+VQ_VARIANTS = [pytest.param(DM_VQ_EXACT, id="exact"), pytest.param(DM_VQ_MFMA, id="mfma"), pytest.param(DM_VQ_BF16, id="bf16split")]
 
 
 @pytest.mark.parametrize("variant", VQ_VARIANTS)
@@ -87,8 +87,8 @@ def test_vq_forward_bit_exact_golden(ops, golden, variant):
 def test_vq_forward_stress_golden(ops, golden, name, variant):
     g = golden(name)
     z, cb = torch.from_numpy(g["z"]).to(DEV), torch.from_numpy(g["codebook"]).to(DEV)
-    if variant == DM_VQ_MFMA and (z.shape[2] * z.shape[3]) % 64:
-        pytest.skip("the MFMA kernel takes latent grids that are multiples of 64 positions")
+    if variant in (DM_VQ_MFMA, DM_VQ_BF16) and (z.shape[2] * z.shape[3]) % 64:
+        pytest.skip("the MFMA kernels take latent grids that are multiples of 64 positions")
     idx, out, slabs, hist = ops.vq_forward(z, cb, variant=variant)
     assert np.array_equal(idx.cpu().numpy(), g["idx"]), name
     if "loss" in g:
@@ -116,7 +116,8 @@ def test_vq_forward_vs_c_oracle(ops, cvq, B, D, K, H, W):
     cb = rnd(K, D, seed=K).numpy()
     idx_ref = _c_oracle_idx(cvq, z, cb)
     q = cb[idx_ref].transpose(0, 3, 1, 2)
-    variants = [DM_VQ_AUTO, DM_VQ_EXACT] + ([DM_VQ_MFMA] if (H * W) % 64 == 0 and D <= 64 else [])
+    variants = [DM_VQ_AUTO, DM_VQ_EXACT] + ([DM_VQ_MFMA] if (H * W) % 64 == 0 and D <= 64 else []) + (
+        [DM_VQ_BF16] if (H * W) % 64 == 0 and D in (16, 32, 64) else [])
     for variant in variants:
         idx, out, slabs, hist = ops.vq_forward(torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV), variant=variant)
         assert np.array_equal(idx.cpu().numpy(), idx_ref), variant
@@ -131,10 +132,13 @@ def test_vq_mfma_rejects_what_it_cannot_tile(ops):
         ops.vq_forward(rnd(1, 16, 8, 12).to(DEV), rnd(4, 16).to(DEV), variant=DM_VQ_MFMA)     # 96 positions per sample
     with pytest.raises(ValueError):
         ops.vq_forward(rnd(1, 128, 8, 8).to(DEV), rnd(4, 128).to(DEV), variant=DM_VQ_MFMA)    # embedding_dim 128
+    with pytest.raises(ValueError):
+        ops.vq_forward(rnd(1, 8, 8, 8).to(DEV), rnd(4, 8).to(DEV), variant=DM_VQ_BF16)        # one K-group needs 16 dimensions
 
 
-@pytest.mark.parametrize("D,K", [(16, 64), (16, 512), (64, 128)])
-def test_vq_mfma_near_ties_and_non_finite_values(ops, cvq, D, K):
+@pytest.mark.parametrize("filt", [pytest.param(DM_VQ_MFMA, id="f32"), pytest.param(DM_VQ_BF16, id="bf16split")])
+@pytest.mark.parametrize("D,K", [(16, 64), (16, 512), (64, 128), (32, 64)])
+def test_vq_mfma_near_ties_and_non_finite_values(ops, cvq, D, K, filt):
     """The cases the MFMA filter must hand to the exact path: latents on (and a few ulp off) the bisector of two codes,
     duplicated codes (exact ties: the FIRST index wins, vq_vae.py:68), NaN / inf latents, and -- second half -- a
     codebook with a NaN and an inf row (torch.argmax(-dist): the first NaN wins)."""
@@ -168,7 +172,7 @@ def test_vq_mfma_near_ties_and_non_finite_values(ops, cvq, D, K):
         idx_ref = _c_oracle_idx(cvq, z, cb)
         zd, cbd = torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV)
         idx_e = ops.vq_forward(zd, cbd, want_out=False, variant=DM_VQ_EXACT)[0].cpu().numpy()
-        idx_m, _, _, _, nre = ops.vq_forward(zd, cbd, want_out=False, variant=DM_VQ_MFMA, want_rechecked=True)
+        idx_m, _, _, _, nre = ops.vq_forward(zd, cbd, want_out=False, variant=filt, want_rechecked=True)
         assert np.array_equal(idx_e, idx_ref)
         assert np.array_equal(idx_m.cpu().numpy(), idx_ref)
         nre = int(nre.cpu())
@@ -185,7 +189,8 @@ def test_vq_mfma_near_ties_and_non_finite_values(ops, cvq, D, K):
             assert nre >= near, (nre, near, P)
 
 
-def test_vq_mfma_large_sweep(ops, cvq):
+@pytest.mark.parametrize("filt", [pytest.param(DM_VQ_MFMA, id="f32"), pytest.param(DM_VQ_BF16, id="bf16split")])
+def test_vq_mfma_large_sweep(ops, cvq, filt):
     """4 M random positions at the headline shape (K = 64, D = 16, 16 x 16 latents): the MFMA kernel equals the exact
     kernel everywhere and the C oracle on the first 0.5 M positions; the share of positions it has to re-evaluate
     exactly stays small (it is the price of the filter, printed for DESIGN.md)."""
@@ -197,7 +202,7 @@ def test_vq_mfma_large_sweep(ops, cvq):
         z = torch.randn(B, D, H, W, generator=torch.Generator().manual_seed(100 + rep)) * (0.5 + 0.25 * rep)
         zd = z.to(DEV)
         idx_e, out_e, _, hist_e = ops.vq_forward(zd, cbd, variant=DM_VQ_EXACT)
-        idx_m, out_m, _, hist_m, nre = ops.vq_forward(zd, cbd, variant=DM_VQ_MFMA, want_rechecked=True)
+        idx_m, out_m, _, hist_m, nre = ops.vq_forward(zd, cbd, variant=filt, want_rechecked=True)
         assert torch.equal(idx_e, idx_m), rep
         assert torch.equal(out_e, out_m), rep
         assert torch.equal(hist_e, hist_m), rep
@@ -206,7 +211,7 @@ def test_vq_mfma_large_sweep(ops, cvq):
         if rep == 0:
             assert np.array_equal(idx_m.cpu().numpy(), _c_oracle_idx(cvq, z.numpy(), cb.numpy()))
     frac = rechecked / total
-    print(f"vq mfma sweep: {total} positions, {rechecked} re-evaluated exactly ({frac:.2e})")
+    print(f"vq mfma sweep (filter {filt}): {total} positions, {rechecked} re-evaluated exactly ({frac:.2e})")
     assert 0 < frac < 1e-2
 
 
@@ -1171,3 +1176,22 @@ def test_relu_keeps_nans_of_either_sign(ops):
     dec, _ = ops.dec_tail_forward(d2.to(DEV), w4.to(DEV), b4.to(DEV), w6.to(DEV), b6.to(DEV), None, None,
                                   torch.ones(2, device=DEV))
     assert torch.equal(torch.isnan(dec.cpu()), torch.isnan(ref)) and int(torch.isnan(ref).sum()) > 0
+
+
+@pytest.mark.parametrize("D,K,scale_z,scale_e", [(16, 64, 1.0, 1.0), (16, 64, 30.0, 0.05), (16, 64, 1e-3, 4.0), (16, 64, 1e4, 1e4),
+                                                   (32, 200, 0.3, 2.0), (64, 512, 1.0, 0.2), (16, 4096, 1.0, 1.0)])
+def test_vq_bf16_split_filter_scales_and_clusters(ops, D, K, scale_z, scale_e):
+    """The bf16-split filter's tolerance is proven relative to A = |z|^2 + 2 max |e|^2: magnitudes far from 1, latents much
+    larger or smaller than the codes, and a codebook whose codes sit in tight clusters (many runner-ups inside the
+    tolerance) must all come out with the exact kernel's indices."""
+    g = torch.Generator().manual_seed(D * K)
+    centres = torch.randn(max(K // 8, 1), D, generator=g)
+    cb = (centres[torch.arange(K) % centres.shape[0]] + 1e-3 * torch.randn(K, D, generator=g)) * scale_e
+    cb[: K // 2] = torch.randn(K // 2, D, generator=g) * scale_e          # half spread out, half clustered
+    z = torch.randn(24, D, 16, 16, generator=g) * scale_z
+    z[:4] = cb[torch.randint(0, K, (4 * 256,), generator=g)].reshape(4, 16, 16, D).permute(0, 3, 1, 2) * (1 + 1e-4 * torch.randn(4, D, 16, 16, generator=g))
+    zd, cbd = z.to(DEV), cb.to(DEV)
+    idx_e, out_e, _, hist_e = ops.vq_forward(zd, cbd, variant=DM_VQ_EXACT)
+    idx_b, out_b, _, hist_b, nre = ops.vq_forward(zd, cbd, variant=DM_VQ_BF16, want_rechecked=True)
+    assert torch.equal(idx_e, idx_b) and torch.equal(out_e, out_b) and torch.equal(hist_e, hist_b)
+    print(f"D={D} K={K} scales ({scale_z}, {scale_e}): {int(nre.cpu())} of {idx_b.numel()} positions re-evaluated exactly")

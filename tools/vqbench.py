@@ -11,7 +11,7 @@ straight-through value, write int64 indices): SURVEY section 8(d).
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dynamorph_amd import ops
-from dynamorph_amd._lib import DM_VQ_EXACT, DM_VQ_MFMA
+from dynamorph_amd._lib import DM_VQ_BF16, DM_VQ_EXACT, DM_VQ_MFMA
 
 
 def t_ms(fn, iters=20, warm=3):
@@ -36,12 +36,19 @@ for name in want:
     P = B * H * W
     nbytes = P * (2 * D * 4 + 8)
     ref = None
-    for vname, variant in (("exact", DM_VQ_EXACT), ("mfma", DM_VQ_MFMA)):
+    for vname, variant in (("exact", DM_VQ_EXACT), ("mfma", DM_VQ_MFMA), ("bf16", DM_VQ_BF16)):
+        if variant == DM_VQ_BF16 and D % 16:
+            continue
         idx, out, slabs, hist, nre = ops.vq_forward(z, cb, variant=variant, want_rechecked=True)
         if ref is None:
             ref = idx
         same = bool(torch.equal(idx, ref))
         ms = t_ms(lambda: ops.vq_forward(z, cb, variant=variant))
-        print(f"{name:9s} {vname:6s} B={B} D={D} K={K} P={P}: {ms * 1e3:8.1f} us/call  {nbytes / ms / 1e6:8.1f} GB/s algorithmic "
-              f"({nbytes / ms / 1e6 / 8000:.3f} of HBM peak)  rechecked={int(nre.cpu())} ({int(nre.cpu()) / P:.2e})  same_idx={same}",
+        # the distance kernel alone: T(21 launches) - T(1 launch) of dm_vq_forward_repeat
+        bufs = ops.vq_forward_repeat(z, cb, 1, variant=variant)
+        k1 = t_ms(lambda: ops.vq_forward_repeat(z, cb, 1, variant=variant, bufs=bufs), iters=10)
+        k21 = t_ms(lambda: ops.vq_forward_repeat(z, cb, 21, variant=variant, bufs=bufs), iters=5)
+        kms = max((k21 - k1) / 20, 1e-6)
+        print(f"{name:9s} {vname:6s} B={B} D={D} K={K} P={P}: {ms * 1e3:8.1f} us/call  kernel {kms * 1e3:7.1f} us = {nbytes / kms / 1e6 / 8000:.3f} of HBM peak"
+              f" ({2.0 * K * D * P / kms / 1e9:7.1f} TFLOP/s of filter product)  rechecked={int(nre.cpu())} ({int(nre.cpu()) / P:.2e})  same_idx={same}",
               flush=True)
