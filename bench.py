@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA ~2.5 PFLOP/s dense
 
 
 def parse():
@@ -39,8 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["c3", "c2", "c5", "z32ex"], default="c3")
     ap.add_argument("--batch", type=int, default=0,
-                    help="per-GPU batch (default 2048 for c3, 1024 for c2, 1024 for c5, 256 for z32ex)")
+                    help="per-GPU batch (default 2048 for c3, 1024 for c2, 1024 for c5, 768 for z32ex)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-fused", action="store_true", help="z32ex: the autograd + torch.optim.Adam loop instead of FusedTrainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-targets", action="store_true", help="skip the north-star target measurements and the C2 sub-record")
@@ -121,13 +123,21 @@ def roofline_vq_large_codebook(model, x):
     ms = max((t21 - t1) / 20.0, 1e-6)
     K, D = cbk.shape
     P = z.shape[0] * z.shape[2] * z.shape[3]
-    flops = 2.0 * K * D * P
-    ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": f"vq_forward_mfma_kernel<{D}, false, ...> (K = {K} codes through LDS pieces; distance + first-min argmin + gather "
-                      "+ straight-through value + squared error)", "bound": "mfma", "achieved": round(ach, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+    flops = 2.0 * K * D * P                      # the filter product |e|^2 - 2 z.e as an f32 GEMM: the algorithmic count
+    useful = flops / (ms * 1e-3) / 1e12
+    # DM_VQ_AUTO runs the product on v_mfma_f32_16x16x32_bf16 with both operands split into a bf16 head and remainder:
+    # 4 bf16 multiply-adds per f32 one, on the bf16 matrix pipe (2.5 PFLOP/s dense); DM_VQ_FILTER=f32 keeps the f32-input
+    # instruction (157.3 TFLOP/s, 1 executed per algorithmic)
+    bf16 = D % 16 == 0 and os.environ.get("DM_VQ_FILTER", "")[:1] != "f"
+    executed, peak = (4.0 * useful, MFMA_BF16_PEAK_TFLOPS) if bf16 else (useful, MFMA_F32_PEAK_TFLOPS)
+    return {"kernel": f"vq_forward_mfma_kernel<{D}, false, ..., {'bf16-split' if bf16 else 'f32'} filter> (K = {K} codes through LDS pieces; "
+                      "distance + first-min argmin + gather + straight-through value + squared error)", "bound": "mfma",
+            "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
             "traffic": pmc_traffic("vq_forward_mfma_k4096", x.shape[0]), "avg_launch_ms": round(ms, 5),
-            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": P * (2 * D * 4 + 8),
+            "algorithmic_flops_per_launch": flops, "algorithmic_tflops": round(useful, 2),
+            "algorithmic_vs_f32_mfma_peak": round(useful / MFMA_F32_PEAK_TFLOPS, 4),
+            "executed_flops_per_launch": flops * (4.0 if bf16 else 1.0),
+            "algorithmic_bytes_per_launch": P * (2 * D * 4 + 8),
             "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()), "positions": P}
 
 
@@ -434,7 +444,7 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B = args.batch or {"c3": 2048, "c2": 1024, "c5": 1024, "z32ex": 256}[args.workload]
+    B = args.batch or {"c3": 2048, "c2": 1024, "c5": 1024, "z32ex": 768}[args.workload]
 
     torch.manual_seed(0)
     if args.workload == "c5":
@@ -444,23 +454,37 @@ def main():
         model = VQ_VAE(num_inputs=4, num_embeddings=4096, channel_var=np.ones(4)).to(dev)
     else:
         x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
-    trainer = None
+    trainer, targs = None, ()
     if args.workload == "z32ex":
-        # the variant and widths the reference's example configuration trains; the
-        # run_training.py loop as it is (autograd + torch.optim.Adam), every conv on the implicit-GEMM kernels
+        # the variant, widths, batch and loss weights the reference's example configuration trains
+        # (config_example.yml:156-186: VQ_VAE_z32 64 / 64 / 512, batch 768, weight_matching 100, margin 1, w_a 1, w_t 0.5,
+        # w_n -0.5; the relation matrix marks adjacent frames of one trajectory: here 4 consecutive samples per group)
         if world != 1:
             raise SystemExit("--workload z32ex is a single-GPU measurement")
         from dynamorph_amd import VQ_VAE_z32
-        model = VQ_VAE_z32(**EXAMPLE_CONFIG).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        model = VQ_VAE_z32(weight_matching=100., margin=1., w_a=1., w_t=0.5, w_n=-0.5, **EXAMPLE_CONFIG).to(dev)
+        tm_mat = torch.zeros(B, B)
+        for i in range(B):
+            for j in range(max(0, i - 2), min(B, i + 3)):
+                if j != i and j // 4 == i // 4:
+                    tm_mat[i, j] = 2.0 if abs(i - j) == 1 else 1.0
+        tm_mat = tm_mat.to(dev)
+        if args.no_fused:
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
-        def step():
-            _, ld = model(x)
-            ld["total_loss"].backward()
-            opt.step()
-            model.zero_grad()
-            return torch.stack([ld["recon_loss"].detach(), ld["commitment_loss"].detach(), ld["total_loss"].detach(),
-                                ld["perplexity"].detach()])
+            def step():
+                _, ld = model(x, time_matching_mat=tm_mat)
+                ld["total_loss"].backward()
+                opt.step()
+                model.zero_grad()
+                return torch.stack([ld["recon_loss"].detach(), ld["commitment_loss"].detach(), ld["total_loss"].detach(),
+                                    ld["perplexity"].detach()])
+        else:
+            trainer = FusedTrainer(model, lr=1e-4, use_graph=not args.no_graph)
+            targs = (None, tm_mat)
+
+            def step():
+                return trainer.step(x, *targs)
     elif args.workload != "c5":
         model = VQ_VAE().to(dev)
 
@@ -506,7 +530,7 @@ def main():
         import torch.distributed as dist
         marks = []
         for _ in range(20 if world > 1 else 5):
-            trainer.step(x, timers=marks)
+            trainer.step(x, *targs, timers=marks)
         parts = FusedTrainer.timer_summary(marks)
         backend = dist.get_backend() if world > 1 else None
         collective = {"backend": backend, "world": world, "message_bytes": trainer.grad.numel() * 4,
@@ -539,8 +563,9 @@ def main():
               "c5": "C5: large-codebook stress, VQ_VAE(num_inputs=4, num_embeddings=4096) training step (forward + backward + fused "
                     "Adam), 4x256x256 fp32 synthetic patches",
               "c2": "C2: VQ_VAE inference latents (enc + vq, per-sample BatchNorm statistics = process_VAE), 2x128x128 fp32",
-              "z32ex": "VQ_VAE_z32 with the reference's example widths (num_hiddens 64, num_residual_hiddens 64, 512 codes): "
-                       "training step (forward + backward + torch Adam), 2x128x128 fp32 synthetic patches"}[args.workload]
+              "z32ex": "VQ_VAE_z32 as the reference's example configuration trains it (num_hiddens 64, num_residual_hiddens 64, 512 "
+                       "codes, batch 768, time-matching term on with weight_matching 100): training step (forward + backward + "
+                       "Adam), 2x128x128 fp32 synthetic patches"}[args.workload]
         line = {
             "metric": ("cell-patches/sec (256x256x4, 4096 codes) VQ-VAE fwd+bwd" if args.workload == "c5" else
                        "cell-patches/sec (128x128x2) VQ-VAE " + ("latent encoding" if args.workload == "c2" else "fwd+bwd")),
@@ -551,7 +576,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "hip_graph": (not args.no_graph) if args.workload in ("c3", "c2", "c5") else False},
+                       "hip_graph": (not args.no_graph) if (args.workload in ("c3", "c2", "c5") or trainer is not None) else False,
+                       "fused_trainer": trainer is not None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "collective": collective,

@@ -1305,6 +1305,10 @@ bool vq2_auto_bf16()
     static const bool on = [] { const char *e = getenv("DM_VQ_FILTER"); return !(e && e[0] == 'f'); }();
     return on;
 }
+// measurement knobs of the headline shape (embedding_dim 16, <= 64 codes): DM_VQ_OCC=4 takes the build bounded to 128
+// registers (4 waves per SIMD), DM_VQ_WGS=n launches n workgroups per CU instead of the occupancy's
+int vq2_occ() { static const int v = [] { const char *e = getenv("DM_VQ_OCC"); return e ? atoi(e) : 3; }(); return v; }
+int vq2_wgs(int dflt) { static const int v = [] { const char *e = getenv("DM_VQ_WGS"); return e ? atoi(e) : 0; }(); return v > 0 ? v : dflt; }
 bool vq2_applicable(const float *z, const int64_t *idx, const float *out, const void *ws, int D, int HW)
 {
     const uintptr_t al = (uintptr_t)z | (uintptr_t)idx | (uintptr_t)out | (uintptr_t)ws;
@@ -1383,7 +1387,11 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         for (int rep = 0; rep < repeats; ++rep) {
             switch (D) {
             case 8: if (single) DM_VQ2(8, true, 3, 3) else DM_VQ2(8, false, 3, 3) break;
-            case 16: if (single) DM_VQ2(16, true, 3, 3) else DM_VQ2(16, false, 3, 3) break;
+            case 16:
+                if (single && vq2_occ() == 4) DM_VQ2(16, true, 4, vq2_wgs(4))
+                else if (single) DM_VQ2(16, true, 3, vq2_wgs(3))
+                else DM_VQ2(16, false, 3, 3)
+                break;
             case 32: if (single) DM_VQ2(32, true, 2, 2) else DM_VQ2(32, false, 2, 2) break;
             default: if (single) DM_VQ2(64, true, 1, 1) else DM_VQ2(64, false, 1, 2) break;
             }

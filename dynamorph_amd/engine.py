@@ -383,27 +383,35 @@ def z32_stem_forward(conv0, bn0, conv1, bn1, x, per_sample=False):
     return h, cx
 
 
-def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G):
+def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G, stats=None, pending=None, zero_fed_biases=True):
+    """stats: the (sum g, sum g*a2) slabs when the caller's last kernel already produced them (residual_backward with
+    q_below = cx.a2); pending: the caller's list for ONE slab reduction of the whole backward pass (None: reduced here);
+    zero_fed_biases=False: the gradient buffer is zero already (FusedTrainer) -- the identically zero gradients of the
+    conv biases that feed a BatchNorm are not written."""
     if getattr(cx, "per_sample", False) and cx.dims[0] > 1:
         raise NotImplementedError("backward through per-sample BatchNorm statistics with B > 1")
     if cx.saved1 is None or cx.saved2 is None:
         raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
     B, NIN, c1, nh, H1, W1, H2, W2 = cx.dims
     g_h = g_h.contiguous()
-    pending = []
-    stats = ops.channel_stats(g_h, cx.a2)
+    own = pending is None
+    if own:
+        pending = []
+    if stats is None:
+        stats = ops.channel_stats(g_h, cx.a2)
     c2b = ops.bn_backward_finalize(stats, B * H2 * W2, _w(bn1.weight), cx.saved2, G(bn1.weight), G(bn1.bias))
     da2 = Op(g_h, DM_LOAD_AFFINE2, c2b, p1=cx.a2)
     ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(conv1.weight), B, nh, c1, H2, W2, 4, pending=pending)
-    G(conv1.bias).zero_()                            # feeds a train-mode BatchNorm: identically zero
+    _zero(G(conv1.bias), zero_fed_biases)            # feeds a train-mode BatchNorm: identically zero
     dy1, st = ops.conv3x3(da2, weight_view(_w(conv1.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
                           pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
                           stat_q=cx.a1)
     c1b = ops.bn_backward_finalize(st, B * H1 * W1, _w(bn0.weight), cx.saved1, G(bn0.weight), G(bn0.bias))
     da1 = Op(dy1, DM_LOAD_AFFINE2, c1b, p1=cx.a1)
     ops.wgrad(da1, Op(cx.x), G(conv0.weight), B, c1, NIN, H1, W1, 4, pending=pending)
-    G(conv0.bias).zero_()
-    ops.reduce_slabs_multi(pending)
+    _zero(G(conv0.bias), zero_fed_biases)
+    if own:
+        ops.reduce_slabs_multi(pending)
 
 
 def z32_tail_forward(up0, bn, up1, r, x, mask, channel_var):
@@ -422,12 +430,15 @@ def z32_tail_forward(up0, bn, up1, r, x, mask, channel_var):
     return dec, cx
 
 
-def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True):
-    """gscale: 1-element device tensor d(total)/d(recon_loss) or None; gdec_ext: upstream gradient w.r.t. decoded or None."""
+def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True, pending=None, zero_fed_biases=True):
+    """gscale: 1-element device tensor d(total)/d(recon_loss) or None; gdec_ext: upstream gradient w.r.t. decoded or None.
+    pending / zero_fed_biases: as in z32_stem_backward."""
     if cx.savedd is None:
         raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
     B, nh, c1, NIN, H2, W2 = cx.dims
-    pending = []
+    own = pending is None
+    if own:
+        pending = []
     if gscale is not None:
         g, part = ops.recon_loss_backward(cx.dec, cx.x, cx.mask, cx.var, gscale)
         if gdec_ext is not None:
@@ -435,10 +446,8 @@ def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True):
             part = None
     else:
         g, part = gdec_ext.contiguous(), None
-    if part is not None:
-        ops.sum_slabs(part, G(up1.bias))
-    else:
-        ops.sum_slabs(ops.channel_stats(g), G(up1.bias))
+    # the last layer's bias gradient (channel sums of g) rides in the slab reduction
+    ops.pend_stats(pending, part if part is not None else ops.channel_stats(g), [G(up1.bias)])
     ops.wgrad(Op(cx.d1, DM_LOAD_AFFINE_RELU, cx.coefd), Op(g), G(up1.weight), B, c1, NIN, 2 * H2, 2 * W2, 4,
               pending=pending)
     dy, st = ops.conv4x4s2(Op(g), weight_view(_w(up1.weight), NIN * 16, 16, 4, 1), B, NIN, c1, 4 * H2, 4 * W2,
@@ -447,9 +456,10 @@ def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True):
     # the weight-gradient kernel takes the BatchNorm-backward transform on its S operand only: materialise it here
     da = ops.apply(Op(dy, DM_LOAD_AFFINE2, cdb, p1=cx.d1), B, c1, 2 * H2, 2 * W2)
     ops.wgrad(Op(cx.r), Op(da), G(up0.weight), B, nh, c1, H2, W2, 4, pending=pending)
-    G(up0.bias).zero_()
+    _zero(G(up0.bias), zero_fed_biases)
     g_r = None
     if want_gr:
         g_r, _ = ops.conv4x4s2(Op(da), weight_view(_w(up0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H2, 2 * W2)
-    ops.reduce_slabs_multi(pending)
+    if own:
+        ops.reduce_slabs_multi(pending)
     return g_r

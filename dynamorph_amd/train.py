@@ -47,10 +47,11 @@ class FusedTrainer:
     """Adam(lr, betas=(.9,.999), eps=1e-8) exactly as run_training.py:485 builds it, fused."""
 
     def __init__(self, model, lr=1e-3, betas=(.9, .999), eps=1e-8, process_group=None, use_graph=True):
-        from .vq_vae import VQ_VAE
-        if not isinstance(model, VQ_VAE):
-            raise TypeError("FusedTrainer is built for VQ_VAE / VQ_VAE_z16; train other modules with a torch optimizer")
+        from .vq_vae import VQ_VAE, VQ_VAE_z32
+        if not isinstance(model, (VQ_VAE, VQ_VAE_z32)):
+            raise TypeError("FusedTrainer is built for VQ_VAE / VQ_VAE_z16 / VQ_VAE_z32; train other modules with a torch optimizer")
         self.model = model
+        self._z32 = isinstance(model, VQ_VAE_z32)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = process_group
         self.world = D.world_size(process_group)
@@ -64,8 +65,9 @@ class FusedTrainer:
         self.v = torch.zeros(n, device=dev)
         self.step_dev = torch.zeros(2, device=dev)        # completed-step counter, ping-ponged between the two words
         self._step_slot = 0
-        self.w_recon = torch.tensor([float(model.weight_recon)], device=dev)
-        self.w_commit = torch.tensor([float(model.weight_commitment)], device=dev)
+        # (VQ_VAE_z32 has no loss weights besides weight_matching: total = recon + commitment + matching, vae.py:456-470)
+        self.w_recon = torch.tensor([float(getattr(model, "weight_recon", 1.0))], device=dev)
+        self.w_commit = torch.tensor([float(getattr(model, "weight_commitment", 1.0))], device=dev)
         self.use_graph = use_graph
         self._graphs = {}            # input shapes -> (graph, static x, static mask, static matrix, static output)
         self._static_x = None        # input tensor of the graph replayed last
@@ -94,8 +96,55 @@ class FusedTrainer:
         val = torch.where(hinge, torch.clamp(val + model.margin, min=0), val)
         return val.mean(), wts * live / float(sim.numel())
 
+    def _forward_backward_z32(self, x, mask, tm):
+        """VQ_VAE_z32 (vae.py:430-470): two-conv stem + residual stack | VectorQuantizer | residual stack + BatchNorm tail,
+        the weighted-hinge time-matching term on z_after.  Same kernels as the autograd path (dynamorph_amd.vq_vae), called
+        in order on the flat gradient views: no autograd bookkeeping, ONE slab reduction for the whole backward pass, the
+        four scalars from one launch -- and a launch sequence a HIP graph can replay."""
+        m = self.model
+        enc, dec = m.enc, m.dec
+        er, dr = enc[5]._handles(), dec[0]._handles()
+        cc = float(m.commitment_cost)
+        B, NIN, H, W = x.shape
+        h, scx = E.z32_stem_forward(enc[0], enc[1], enc[3], enc[4], x)
+        z, esaved = E.residual_forward(er, h)
+        zq, idx, vqs = E.vq_forward(m.vq.w.weight, z, cc, defer_scalars=True)
+        r, dsaved = E.residual_forward(dr, zq)
+        _, tcx = E.z32_tail_forward(dec[1], dec[2], dec[4], r, x, mask, m.channel_var)
+        scalars = ops.vq_loss_finalize(vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, tcx.loss_slabs,
+                                       B * NIN * H * W, 1.0, 1.0)
+        pending = []
+        g_r = E.z32_tail_backward(dec[1], dec[2], dec[4], tcx, self.w_recon, None, self.G, pending=pending,
+                                  zero_fed_biases=False)
+        g_zq, _ = E.residual_backward(dr, dsaved, g_r, self.G, None, pending=pending, zero_fed_biases=False)
+        if tm is not None:
+            # the pairwise term acts on z_after (vae.py:441-455); its gradient reaches z through the straight-through value
+            zf = zq.reshape(B, -1)
+            wm = float(m.weight_matching)
+            tmf = tm.to(torch.float32).contiguous()
+            if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
+                tml, S = ops.time_matching_forward(zf, tmf, 1, float(m.w_a), float(m.w_t), float(m.w_n), float(m.margin))
+                g_zq = g_zq + ops.time_matching_backward(zf, S, None, wm).reshape(zq.shape)
+                tml = tml.reshape(())
+            else:
+                sim = ops.pair_msd(zf)
+                self.model._z16_loss = True                 # (the weighted-hinge form)
+                tml, g_sim = self._time_matching(sim, tmf)
+                g_zq = g_zq + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(zq.shape)
+            scalars = torch.cat([scalars[:2], (scalars[2] + wm * tml).reshape(1), scalars[3:4], tml.reshape(1)])
+        gcb = self.G(m.vq.w.weight)
+        dz, cb_slabs = ops.vq_backward_slabs(z, m.vq.w.weight.detach(), idx, g_zq, self.w_commit, cc)
+        pending.append((cb_slabs, gcb))
+        g_h, stats = E.residual_backward(er, esaved, dz, self.G, scx.a2, pending=pending, zero_fed_biases=False)
+        E.z32_stem_backward(enc[0], enc[1], enc[3], enc[4], scx, g_h, self.G, stats=stats, pending=pending,
+                            zero_fed_biases=False)
+        ops.reduce_slabs_multi(pending)                     # every weight / bias / codebook gradient of the step
+        return scalars
+
     def forward_backward(self, x, mask=None, time_matching_mat=None):
         """One forward + backward; returns the device tensor (recon, commitment, total, perplexity[, time matching])."""
+        if self._z32:
+            return self._forward_backward_z32(x, mask, time_matching_mat)
         model = self.model
         L = E.Layers(model)
         cc = float(model.commitment_cost)
@@ -433,16 +482,16 @@ class _EpochLosses:
 
 def _make_optimizer(model, lr, fused):
     from .vq_vae import VQ_VAE
-    if D.world_size() > 1 and not (fused and isinstance(model, VQ_VAE)):
+    from .vq_vae import VQ_VAE_z32
+    fusable = isinstance(model, (VQ_VAE, VQ_VAE_z32))
+    if D.world_size() > 1 and not (fused and fused != "graph" and fusable):
         # FusedTrainer broadcasts its flat buffer itself; any other module: same replica everywhere before the first step
         for t in list(model.parameters()) + list(model.buffers()):
             torch.distributed.broadcast(t.data, src=0)
     if fused == "graph" and D.world_size() == 1:
         return GraphedTrainer(model, lr=lr)               # any module: the autograd step as a replayed HIP graph
-    if fused and isinstance(model, VQ_VAE):
+    if fused and fusable:
         return FusedTrainer(model, lr=lr)
-    # VQ_VAE_z32 is GPU bound through autograd at every batch size measured (8.2 ms eager vs 8.5 ms replayed at
-    # B = 2048), so the plain loop stays the default there
     return torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
 
 

@@ -682,3 +682,71 @@ def test_graphed_trainer_z32_equals_eager_adam(kw, B, with_tm):
             # (the LDS float atomics of the codebook gradient are order-dependent; Adam turns a last-bit difference of a
             #  near-zero gradient into a fraction of lr)
             assert (sd1[k] - sd2[k]).abs().max().item() <= 2.5e-4 * max(1.0, sd1[k].abs().max().item()), k
+
+
+def test_fused_trainer_z32_against_reference_vectors(golden):
+    """FusedTrainer's VQ_VAE_z32 path (no autograd: the kernels in order on flat gradient views, one slab reduction) on
+    the vectors captured from the reference (g8_z32_tm.npz: mask + time matching): losses within 1e-5, every gradient
+    within the accumulation noise of fp32 -- the gates of test_z32_time_matching_mask_and_gradients_against_reference."""
+    import dynamorph_amd
+    from dynamorph_amd.train import FusedTrainer
+    g = golden("g8_z32_tm.npz")
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    m = dynamorph_amd.VQ_VAE_z32().to(DEV)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd/")})
+    tr = FusedTrainer(m, lr=1e-4, use_graph=False)
+    vals = tr.forward_backward(x, torch.from_numpy(g["mask"]).to(DEV), torch.from_numpy(g["tm"]).to(DEV)).tolist()
+    for i, k in ((0, "recon_loss"), (1, "commitment_loss"), (2, "total_loss"), (4, "time_matching_loss")):
+        assert abs(vals[i] - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), (k, vals[i], float(g[k]))
+    assert abs(vals[3] - float(g["perplexity"])) <= 1e-3 * float(g["perplexity"])
+    tr.expose_grads()
+    n = 0
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        if k in Z32_BN_FED_BIASES:
+            assert float(p.grad.abs().max()) == 0.0, k              # never written: exactly zero
+            continue
+        ref = g["grad/" + k]
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = float((p.grad.cpu() - torch.from_numpy(ref)).abs().max())
+        assert err <= 4e-3 * scale + 1e-8, (k, err, scale)
+        n += 1
+    assert n >= 30
+
+
+@pytest.mark.parametrize("kw,B,with_tm,use_graph", [({}, 6, True, False), ({}, 5, True, True),
+                                                    (dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512), 3, True, True)])
+def test_fused_trainer_z32_equals_eager_adam(kw, B, with_tm, use_graph):
+    """FusedTrainer on VQ_VAE_z32 (default widths and the reference's example widths 64 / 64 / 512) against the same module
+    stepped through autograd + torch.optim.Adam (run_training.py:404-408, 485): same losses, same parameters and BatchNorm
+    buffers after 3 steps, with a mask and the time-matching matrix."""
+    import copy
+    import dynamorph_amd
+    from dynamorph_amd.train import FusedTrainer
+    torch.manual_seed(4321)
+    m1 = dynamorph_amd.VQ_VAE_z32(weight_matching=1.0, **kw).to(DEV)
+    m2 = copy.deepcopy(m1)
+    opt = torch.optim.Adam(m1.parameters(), lr=1e-3)
+    tr = FusedTrainer(m2, lr=1e-3, use_graph=use_graph)
+    mask = (torch.rand(B, 1, 128, 128, generator=torch.Generator().manual_seed(2)) > 0.4).float().to(DEV)
+    for step in range(3):
+        x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(10 + step)).to(DEV)
+        tm = torch.randint(0, 3, (B, B), generator=torch.Generator().manual_seed(20 + step)).float().to(DEV) if with_tm else None
+        _, ld = m1(x, time_matching_mat=tm, batch_mask=mask)
+        ld["total_loss"].backward()
+        opt.step()
+        m1.zero_grad()
+        vals = tr.step(x, mask, tm).tolist()
+        for i, k in enumerate(("recon_loss", "commitment_loss", "total_loss", "perplexity")):
+            assert abs(vals[i] - float(ld[k])) <= 1e-5 * max(1.0, abs(float(ld[k]))), (step, k, vals[i], float(ld[k]))
+        if with_tm:
+            assert abs(vals[4] - float(ld["time_matching_loss"])) <= 1e-5 * max(1.0, abs(float(ld["time_matching_loss"])))
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        if "tracked" in k:
+            assert int(sd1[k]) == int(sd2[k]) == 3, k
+        elif k in Z32_BN_FED_BIASES:
+            continue                                           # (torch's Adam random-walks on the autograd path's rounding noise)
+        else:
+            assert (sd1[k] - sd2[k]).abs().max().item() <= 2.5e-4 * max(1.0, sd1[k].abs().max().item()), k
