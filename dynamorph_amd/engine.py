@@ -89,17 +89,38 @@ def _w(p):
 
 
 # ------------------------------------------------------------------------------- encoder
-def encoder_forward(L, x, per_sample=False):
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One helper stream per device for work that is off the critical path (the running-statistics replay)."""
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def e1_operands(L):
+    """(weff, bias_border) of the composite enc.0 o enc.1 convolution.  A function of the stored parameters only: the
+    inference path builds them once per encode_patches call (weights do not change there), the training path every step."""
+    return ops.e1_compose_border(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight), _w(L.enc1.bias))
+
+
+def encoder_forward(L, x, per_sample=False, e1=None, join=True):
     """x (B,NIN,H,W) -> z_before (B,nh,H/8,W/8).  per_sample=True normalises every BatchNorm with
-    that sample's own statistics = pipeline/patch_VAE.py:445-452 (batch-of-one calls in train mode)."""
+    that sample's own statistics = pipeline/patch_VAE.py:445-452 (batch-of-one calls in train mode).
+    e1: e1_operands(L) computed by the caller (inference: once per call).
+    join=False (per_sample only): the running-statistics replay -- a side effect no kernel of the path reads -- is left
+    running on a helper stream beside whatever the caller launches next (the VectorQuantizer); the caller MUST call
+    cx.join() before it hands the stream back (a HIP-graph capture cannot end with unjoined work)."""
     B, NIN, H, W = x.shape
     nh, nrh, c1 = L.nh, L.nrh, L.nh // 2
     ps = per_sample
-    cx = SimpleNamespace(x=x, per_sample=ps, B=B, H=H, W=W, res=[])
+    cx = SimpleNamespace(x=x, per_sample=ps, B=B, H=H, W=W, res=[], join=lambda: None)
     defer = [] if ps else None       # per-sample path: running statistics of all eight layers in one launch at the end
 
     # forward: K = 16*NIN; the ones channel of the composite is folded into a per-position bias table (bias_border)
-    weff, border = ops.e1_compose_border(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight), _w(L.enc1.bias))
+    weff, border = e1 if e1 is not None else e1_operands(L)
     H1, W1 = H // 2, W // 2
     a1, st = ops.conv4x4s2(Op(x), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN, c1, H, W,
                            want_stats=True, bias_border=border, per_tile=ps)
@@ -125,7 +146,16 @@ def encoder_forward(L, x, per_sample=False):
                        saved1=saved1, saved2=saved2, saved3=saved3, saved4=saved4, dims=(H1, W1, H2, W2, H3, W3))
     z, cx.res = residual_forward(L.res, h, ps, defer)
     if defer:
-        ops.bn_running_replay(defer)
+        cur = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for seg in defer:
+                seg[0].record_stream(side)                 # the statistics slabs are read on the helper stream
+            ops.bn_running_replay(defer)
+        cx.join = lambda: cur.wait_stream(side)
+        if join:
+            cx.join()
     return z, cx
 
 
@@ -240,10 +270,15 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
 
 
 # ------------------------------------------------------------------------------------ VQ
-def vq_forward(codebook, z, commitment_cost, want_out=True, defer_scalars=False):
+def vq_forward(codebook, z, commitment_cost, want_out=True, defer_scalars=False, want_scalars=True):
     """defer_scalars (training pass): no scalar launches here; the third return value is the state
-    ops.vq_loss_finalize needs to produce them together with the reconstruction loss at the end of the step."""
+    ops.vq_loss_finalize needs to produce them together with the reconstruction loss at the end of the step.
+    want_scalars=False (inference latents, patch_VAE.py:445-452 discards loss and perplexity): no counter reduction and no
+    scalar launch at all; the third return value is None."""
     B, D, H, W = z.shape
+    if not want_scalars:
+        idx, out, _, _ = ops.vq_forward(z, _w(codebook), want_out=want_out, want_hist=False)
+        return out, idx, None
     if defer_scalars:
         idx, out, slabs, ws = ops.vq_forward(z, _w(codebook), want_out=want_out, want_hist=False)
         return out, idx, SimpleNamespace(slabs=slabs, ws=ws, K=codebook.shape[0], D=D, positions=B * H * W, cc=commitment_cost)

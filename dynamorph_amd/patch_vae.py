@@ -29,21 +29,26 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
     if isinstance(model, VQ_VAE):
         layers = E.Layers(model)
         codebook = layers.codebook.weight
+        e1 = None                           # composite first-layer weights: once per call (the weights do not change here)
 
         def encode(x):
-            return E.encoder_forward(layers, x, per_sample=True)[0]
+            nonlocal e1
+            if e1 is None:
+                e1 = E.e1_operands(layers)
+            z, cx = E.encoder_forward(layers, x, per_sample=True, e1=e1, join=False)
+            return z, cx.join
     elif isinstance(model, VQ_VAE_z32):
         enc = model.enc                     # children 0/1/3/4: conv, BatchNorm, conv, BatchNorm; 5: ResidualBlock
         codebook = model.vq.w.weight
 
         def encode(x):
             h, _ = E.z32_stem_forward(enc[0], enc[1], enc[3], enc[4], x, per_sample=True)
-            return E.residual_forward(enc[5]._handles(), h, True)[0]
+            return E.residual_forward(enc[5]._handles(), h, True)[0], None
     else:
         codebook = model.vq.w.weight
 
         def encode(x):                      # any other module: the reference's batch-of-one loop as it is
-            return torch.cat([model.enc(x[j:j + 1]) for j in range(x.shape[0])], 0)
+            return torch.cat([model.enc(x[j:j + 1]) for j in range(x.shape[0])], 0), None
     device = torch.device(device)
     N = patches.shape[0]
     if N == 0:
@@ -98,8 +103,10 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
             x = x_dev[k][:n]
             if zscore_on_device:
                 x = ops.zscore_patch(x)
-            z_b = encode(x)
-            z_a, _, _ = E.vq_forward(codebook, z_b, float(model.commitment_cost))
+            z_b, join = encode(x)
+            z_a, _, _ = E.vq_forward(codebook, z_b, float(model.commitment_cost), want_scalars=False)
+            if join is not None:
+                join()                                          # the running-statistics replay ran beside the quantiser
             ev_done[k].record(compute)
             z_b, z_a = z_b.reshape(n, -1), z_a.reshape(n, -1)
             if res[0] is None:

@@ -50,7 +50,8 @@ def test_version_and_host_only_queries(lib):
     # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows (csrc/vq.hip)
     # header + pair-interleaved codebook (exact kernel) + MFMA A operand + norms + lane-ordered rows + counter replicas
     # ... + the bf16-split A operand (twice the f32 one)
-    assert lib.dm_vq_workspace_bytes(64, 16) == (32 + 64 * 16 + 64 * 16 + 2 * 64 * 16 + 64 + 64 * 16 + 64 * 64) * 4
+    # (<= 64 codes: 1024 per-workgroup counter rows of 72 ints instead of the 64 replicas)
+    assert lib.dm_vq_workspace_bytes(64, 16) == (32 + 64 * 16 + 64 * 16 + 2 * 64 * 16 + 64 + 64 * 16 + 1024 * 72) * 4
     assert lib.dm_vq_workspace_bytes(4096, 16) == (32 + 4096 * 16 * 5 + 4096 + 16 * 4096) * 4
     assert lib.dm_vq_num_blocks(524288) == 2048
     assert lib.dm_conv4x4s2_num_blocks(2048, 3, 8, 128, 128, 1) == 2048 * 8   # one slab per tile (per-sample stats)
