@@ -658,6 +658,226 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
     }
 }
 
+// ============================================================================ kernel D
+// Backward of a Conv2d(CX -> CD, 4, stride 2, padding 1) in ONE pass over its operands: the data gradient (the
+// phase-decomposed transposed convolution of kernel C) AND the weight gradient (wgrad_mfma.hip) from one staging of
+//   da  = A*dy + B*a_out + C   (BatchNorm backward folded into the load; CD channels on the dy grid, with a 1-pixel halo)
+//   T   = relu(scale*a_in + shift)   (the layer's input as the forward saw it; CX channels, the 2x grid, (2TH+2) x (2TW+8))
+// As two kernels each of them staged da (two tensors) and re-read a_in: 1.34 GB moved for 0.54 GB of tensors on enc.4 at
+// B = 2048.  One workgroup of 512 threads per CU (two waves per SIMD): the staging registers of both tiles are spread
+// over 512 threads (64 VGPRs per thread), which is what lets the transposed convolution's weights (48), the weight
+// gradient's accumulators (32) and the next tile's loads live together below 256 registers.
+//   data gradient   wave w takes M tiles w and w + 8 of the tile's TH x TW/16 (16 positions each), both output phase rows
+//   weight gradient wave w takes position row w: M = dy channels (one 16-row tile), N = (ct, ky, kx) in NTT tiles,
+//                   K = the row's positions; the A operand is read 16 bytes per lane (positions 4 kq .. 4 kq + 3 of a
+//                   16-position span = K-steps 0..3), one ds_read_b128 per four MFMA steps
+// The weight-gradient accumulators persist over the workgroup's tiles; the eight waves are combined in wave order and the
+// workgroup writes one slab (dm_reduce_slabs_multi adds the slabs in slab order): bit-reproducible.
+constexpr int FB_BLOCK = 512, FB_WAVES = 8;
+
+template <int CD, int CX, int TH, int TW>
+struct FusedBwdGeom {
+    static_assert(CD == 16 && CX == 8 && TH == FB_WAVES && TW % 16 == 0, "built for enc.4: 8 -> 16 channels");
+    static constexpr int IH = TH + 2, RS = TW + 8, COLS4 = RS / 4, PSRAW = IH * RS;
+    static constexpr int PS = PSRAW + ((16 - (PSRAW % 32)) + 32) % 32;            // == 16 (mod 32): kernel C's A reads
+    static constexpr int TROWS = 2 * TH + 2, RST = 2 * TW + 8, TCOLS4 = RST / 4, PST = TROWS * RST;
+    static constexpr int N = CX * 16, NTT = N / 16;
+    static constexpr int TILE_FLOATS = CD * PS + CX * PST, RED_FLOATS = NTT * 256;
+    static constexpr int LDS_FLOATS = (TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) + 2 * DM_COEF_MAX_C * 4;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4 + FB_WAVES * 16 * 2 * sizeof(double);
+};
+
+template <int CD, int CX, int TH, int TW>
+__global__ __launch_bounds__(FB_BLOCK, 2)
+void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
+                         float *__restrict__ wslabs, int H, int W, int ntiles)
+{
+    using G = FusedBwdGeom<CD, CX, TH, TW>;
+    constexpr int IH = G::IH, RS = G::RS, COLS4 = G::COLS4, PS = G::PS;
+    constexpr int TROWS = G::TROWS, RST = G::RST, TCOLS4 = G::TCOLS4, PST = G::PST, NTT = G::NTT, N = G::N;
+    constexpr int CGN = TW / 16, MP = 2;                   // 16-position groups per row; M tiles per wave = TH * CGN / 8
+    static_assert(TH * CGN == FB_WAVES * MP, "two M tiles per wave");
+    constexpr int TAPX = 3, KS = (CD / 4) * 2 * TAPX;      // kernel C with 8 output channels: n = (px, co), 2 x 3 taps
+    extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+    float *tileD = fb_lds, *tileT = fb_lds + CD * PS;
+    float *s_coefD = fb_lds + (G::LDS_FLOATS - 2 * DM_COEF_MAX_C * 4), *s_coefT = s_coefD + DM_COEF_MAX_C * 4;
+    double (*s_stat)[2] = reinterpret_cast<double (*)[2]>(fb_lds + G::LDS_FLOATS);
+
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int OH = 2 * H, OW = 2 * W;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int co = m & 7, pxl = m >> 3;                    // data gradient: the lane's a_in channel and x phase
+
+    TileStage<CD, IH, COLS4, RS, PS, true, FB_BLOCK> stD;
+    TileStage<CX, TROWS, TCOLS4, RST, PST, false, FB_BLOCK> stT;
+    stD.init(H, W);
+    stT.init(OH, OW);
+    int tidx = blockIdx.x, b = 0, y0 = 0, x0 = 0;
+    if (tidx < ntiles) {
+        int t = tidx;
+        x0 = (t % tiles_x) * TW; t /= tiles_x;
+        y0 = (t % tiles_y) * TH; b = t / tiles_y;
+        stD.issue(dy, b, CD, H, W, y0 - 1, x0 - 4);
+        stT.issue(tin, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
+        stage_coef(s_coefD, dy, b, CD);
+        stage_coef(s_coefT, tin, b, CX);
+    }
+
+    // data-gradient weights (kernel C, COUT = 8): N tile per phase row py, n = (px, co); step s = (cg4, a, bb)
+    float wreg[2][1][KS];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+            const int c = 4 * cg4 + kq;
+            const int ky = py + 3 - 2 * (py + a), kx = pxl + 3 - 2 * bb;
+            float wvl = 0.f;
+            if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
+            wreg[py][0][s] = wvl;
+        }
+    float mc0, mc2;
+    mask_coef(ep, 0, co, mc0, mc2);
+    double s1 = 0.0, s2 = 0.0;
+    const int abase = kq * PS + m + 3;
+    EpiCtx<SIDE_MASK> cx;
+    const long long sample_elems = (long long)CX * OH * OW;
+    const int chan_off = (co * OH * OW + 8 * kq + 4 * pxl) * 4;
+
+    // weight gradient: B column n = 16 t + m = (ct, ky, kx); this lane's positions of a 16-position span are 4 kq .. 4 kq + 3
+    int bl[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+        const int n = 16 * t + m;
+        bl[t] = (n >> 4) * PST + ((n >> 2) & 3) * RST + (n & 3) + 3 + 8 * kq + 2 * wave * RST;
+    }
+    const int al = m * PS + (wave + 1) * RS + 4 + 4 * kq;       // A row m = dy channel, position row `wave`
+    f32x4 wacc[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    while (tidx < ntiles) {
+        __syncthreads();                                   // previous tile consumed
+        stD.commit(tileD, s_coefD, CD, H, W, y0 - 1, x0 - 4, dy.mode);
+        stT.commit(tileT, s_coefT, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4, tin.mode);
+        __syncthreads();
+        const int cb = b, cy0 = y0, cx0 = x0;
+        const int next = tidx + gridDim.x;
+        {
+            int t = next < ntiles ? next : tidx;
+            x0 = (t % tiles_x) * TW; t /= tiles_x;
+            y0 = (t % tiles_y) * TH; b = t / tiles_y;
+        }
+        const auto scD = stD.begin(dy, next < ntiles, b, CD, H, W, y0 - 1, x0 - 4);
+        const auto scT = stT.begin(tin, next < ntiles, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
+        cx.rebase(ep, dx, sample_elems, cb);
+        constexpr int NED = decltype(stD)::N, NET = decltype(stT)::N;
+
+        // ---- data gradient: M tiles (wave, wave + 8), phase rows py = 0, 1 ------------------------------------------
+        const float *ap[MP];
+        int obase[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            const int ti = wave + FB_WAVES * i;
+            const int r = ti / CGN, cg = ti % CGN;
+            ap[i] = tileD + r * RS + 16 * cg + abase;
+            obase[i] = chan_off + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
+        }
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            // the next tile's da elements are requested under the products of this one
+#pragma unroll
+            for (int e = 0; e < NED; ++e)
+                if (e >= py * NED / 2 && e < (py + 1) * NED / 2) stD.issue_one(e, scD);
+            EpiIn<SIDE_MASK> e[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) epilogue_loads<SIDE_MASK>(e[i], cx, obase[i] + py * OW * 4);
+            f32x4 acc[MP][1];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            auto off = [py](int s) {
+                const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                return 4 * cg4 * PS + (py + a) * RS + bb;
+            };
+            mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py], acc, off);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) {
+                const f32x4 v = acc[i][0];
+                const f32x4 pv = lane_xor8(v);             // partner lane holds the other x phase of the same channel
+                epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y}, ep, cx, e[i],
+                                         mc0, mc2, obase[i] + py * OW * 4, s1, s2);
+            }
+        }
+
+        // ---- weight gradient: position row `wave`, TW / 16 spans of 16 positions, 4 K-steps per span ------------------
+        {
+            constexpr int NSPAN = TW / 16;
+            f32x4 av[2];
+            float bv[2][NTT];
+            av[0] = *reinterpret_cast<const f32x4 *>(tileD + al);
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) bv[0][t] = tileT[bl[t]];
+#pragma unroll
+            for (int q = 0; q < NSPAN * 4; ++q) {           // q = 4 * span + K-step
+                const int sp = q >> 2, st = q & 3;
+                if (q + 1 < NSPAN * 4) {
+                    const int sp1 = (q + 1) >> 2, st1 = (q + 1) & 3;
+                    if (st1 == 0) av[sp1 & 1] = *reinterpret_cast<const f32x4 *>(tileD + al + 16 * sp1);
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) bv[(q + 1) & 1][t] = tileT[bl[t] + 32 * sp1 + 2 * st1];
+                }
+                // the next tile's T elements trickle out between the steps
+#pragma unroll
+                for (int e = 0; e < NET; ++e)
+                    if (e >= q * NET / (NSPAN * 4) && e < (q + 1) * NET / (NSPAN * 4)) stT.issue_one(e, scT);
+                __builtin_amdgcn_sched_barrier(0);
+                const float a = av[sp & 1][st];
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[q & 1][t], wacc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        tidx = next;
+    }
+
+    // ---- statistics of the data gradient: (sum v, sum v * a_in) per a_in channel -> stats[blockIdx][CX][2] --------------
+    if (ep.stats) {
+        double a = s1, c = s2;
+        a += __shfl_xor(a, 16, 64); c += __shfl_xor(c, 16, 64);
+        a += __shfl_xor(a, 32, 64); c += __shfl_xor(c, 32, 64);
+        a += __shfl_xor(a, 8, 64); c += __shfl_xor(c, 8, 64);
+        if (lane < CX) { s_stat[wave * 16 + lane][0] = a; s_stat[wave * 16 + lane][1] = c; }
+        __syncthreads();
+        if (threadIdx.x < CX) {
+            double ta = 0.0, tc = 0.0;
+#pragma unroll
+            for (int w = 0; w < FB_WAVES; ++w) { ta += s_stat[w * 16 + threadIdx.x][0]; tc += s_stat[w * 16 + threadIdx.x][1]; }
+            ep.stats[((long long)blockIdx.x * CX + threadIdx.x) * 2 + 0] = ta;
+            ep.stats[((long long)blockIdx.x * CX + threadIdx.x) * 2 + 1] = tc;
+        }
+    }
+    // ---- weight-gradient slab: the eight waves in wave order.  wacc[t][j] is dy channel 4 (lane >> 4) + j, column 16 t + m
+    float *red = fb_lds;
+    for (int w = 0; w < FB_WAVES; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+                f32x4 *p = reinterpret_cast<f32x4 *>(red + (t * 64 + lane) * 4);
+                if (w == 0) *p = wacc[t];
+                else *p = *p + wacc[t];
+            }
+        }
+    }
+    __syncthreads();
+    float *slab = wslabs + (long long)blockIdx.x * (CD * N);
+    for (int i = threadIdx.x; i < NTT * 256; i += FB_BLOCK) {
+        const int j = i & 3, l = (i >> 2) & 63, t = i >> 8;
+        slab[(4 * (l >> 4) + j) * N + 16 * t + (l & 15)] = red[i];
+    }
+}
+
 // ------------------------------------------------------------------------------ dispatch
 struct ConvArgs {
     Operand in; WeightView wv; float *out; Epilogue ep;
@@ -977,4 +1197,51 @@ extern "C" int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *
     else
         dm_generic_conv(pix ? 2 : 1, a.in, a.wv, out, a.ep, B, CIN, CIN, NOUT, H, W, taps, nslabs, a.per_tile, a.stream);
     return dm_launch_status("dm_conv3x3");
+}
+
+
+// ---- fused backward of the stride-2 encoder convolutions (kernel D) ------------------------------------------------------
+static bool fused_bwd_shape(int CD, int CX, int H, int W)
+{
+    return CD == 16 && CX == 8 && H > 0 && W > 0 && H % 8 == 0 && W % 32 == 0;
+}
+
+extern "C" int dm_conv_bwd_s2_fused_supported(int CD, int CX, int H, int W) { return fused_bwd_shape(CD, CX, H, W) ? 1 : 0; }
+
+extern "C" int dm_conv_bwd_s2_fused_num_blocks(int B, int CD, int CX, int H, int W)
+{
+    if (B <= 0 || !fused_bwd_shape(CD, CX, H, W)) return -1;
+    const long long ntiles = (long long)B * (H / 8) * (W / 32);
+    return (int)(ntiles < 256 ? ntiles : 256);            // one 512-thread workgroup per CU, one slab each
+}
+
+extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin, const dm_weight_view *w, float *dx,
+                                    const dm_epilogue *ep, float *w_slabs, int B, int CD, int CX, int H, int W,
+                                    void *stream)
+{
+    if (dm_check_operand(dy, "dm_conv_bwd_s2_fused(dy)") || dm_check_operand(tin, "dm_conv_bwd_s2_fused(in)")) return -1;
+    DM_REQUIRE(w && w->w && dx && w_slabs && ep, "dm_conv_bwd_s2_fused: NULL pointer");
+    DM_REQUIRE(fused_bwd_shape(CD, CX, H, W), "dm_conv_bwd_s2_fused: shape %d -> %d channels on %dx%d not built", CX, CD, H, W);
+    DM_REQUIRE(B > 0 && (long long)B * CD * 4 * H * W < (1LL << 31), "dm_conv_bwd_s2_fused: tensor too large for 32-bit offsets");
+    DM_REQUIRE(!dy->ones_channel && !tin->ones_channel && tin->mode != DM_LOAD_AFFINE2,
+               "dm_conv_bwd_s2_fused: operand modes");
+    DM_REQUIRE(dy->coef_bstride == 0 && tin->coef_bstride == 0, "dm_conv_bwd_s2_fused: batch-statistics coefficients only");
+    // the ReLU mask of the data gradient and the second-moment partner are the layer input itself (SIDE_MASK of kernel C)
+    DM_REQUIRE(ep->mask.p0 == tin->p0 && (!ep->stat_q || ep->stat_q == tin->p0) && !ep->resid && !ep->bias && !ep->relu &&
+                   ep->mask.coef_bstride == 0,
+               "dm_conv_bwd_s2_fused: the epilogue must mask by (and take its statistics against) the layer input");
+    if (dm_check_operand(&ep->mask, "dm_conv_bwd_s2_fused(mask)")) return -1;
+    using G = FusedBwdGeom<16, 8, 8, 32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int ntiles = B * (H / 8) * (W / 32);
+    const int grid = dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W);
+    hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32>), dim3(grid), dim3(FB_BLOCK), G::LDS_BYTES, (hipStream_t)stream,
+                       to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
+    return dm_launch_status("dm_conv_bwd_s2_fused");
 }

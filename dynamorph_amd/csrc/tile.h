@@ -66,11 +66,12 @@ typedef unsigned short dm_u16x2 __attribute__((ext_vector_type(2)));
 // whatever FMAs propagate from it) into +0.  Costs a compare + a select per value.
 __device__ __forceinline__ f32x4 relu_keep_nan(f32x4 v) { return dm_relu4(v); }
 
-template <int CIN, int ROWS, int COLS4, int RS, int PS, bool TWO>
+// BLOCK: threads of the workgroup (256 everywhere except the fused backward kernel, conv_bwd_fused.hip: 512)
+template <int CIN, int ROWS, int COLS4, int RS, int PS, bool TWO, int BLOCK = DM_BLOCK>
 struct TileStage {
     static constexpr int PER_C = ROWS * COLS4;
-    static constexpr int G = PER_C < DM_BLOCK ? DM_BLOCK / PER_C : 1;       // channels side by side across the workgroup
-    static constexpr int P = (PER_C + DM_BLOCK - 1) / DM_BLOCK;             // passes over one channel plane
+    static constexpr int G = PER_C < BLOCK ? BLOCK / PER_C : 1;             // channels side by side across the workgroup
+    static constexpr int P = (PER_C + BLOCK - 1) / BLOCK;                   // passes over one channel plane
     static constexpr int NC = (CIN + G - 1) / G;                            // channel steps
     static constexpr int N = NC * P;
     static constexpr unsigned OOB = 0x80000000u;   // + any channel offset (< 2^31) stays past every sample, never wraps
@@ -91,7 +92,7 @@ struct TileStage {
         HW4 = H * W * 4;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int e = e0 + p * DM_BLOCK;
+            const int e = e0 + p * BLOCK;
             const bool have = e < PER_C && cs < G;
             const int r = e / COLS4, j4 = e - r * COLS4;
             rj[p] = have ? (r | (j4 << 16)) : 0x7fff;

@@ -326,14 +326,34 @@ __device__ __forceinline__ int vq_count_column(const int *__restrict__ hrep, int
     return s;
 }
 
-__global__ void vq_hist_reduce_kernel(const int *__restrict__ hrep, int *__restrict__ hdr, int K, int *__restrict__ hist)
+// hist[k] = column sum over the counter rows.  One workgroup per 64 codes: its four waves take every fourth row (64 codes
+// side by side = one coalesced 256-byte read per row), 32 rows in flight per wave.
+__global__ __launch_bounds__(256) void vq_hist_reduce_kernel(const int *__restrict__ hrep, int *__restrict__ hdr, int K,
+                                                             int *__restrict__ hist)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_cnt[4][65];
     const int R = hdr[1], stride = hdr[2];
-    // per-workgroup slabs carry the workgroup's re-evaluated positions in column 64: their total goes to header[0]
-    if (stride == VQ2_SLAB_STRIDE && k == 64) hdr[0] = vq_count_column(hrep, R, stride, 64);
-    if (k >= K) return;
-    hist[k] = vq_count_column(hrep, R, stride, k);
+    const int kl = threadIdx.x & 63, g = threadIdx.x >> 6, k = blockIdx.x * 64 + kl;
+    const bool slabs = stride == VQ2_SLAB_STRIDE;          // per-workgroup rows: column 64 = positions re-evaluated exactly
+    int h = 0, n = 0;
+    for (int r0 = g; r0 < R; r0 += 128) {
+        int v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = (r0 + 4 * j < R && k < K) ? hrep[(long long)(r0 + 4 * j) * stride + k] : 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) h += v[j];
+        if (slabs && kl == 0 && blockIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) n += r0 + 4 * j < R ? hrep[(long long)(r0 + 4 * j) * stride + 64] : 0;
+        }
+    }
+    s_cnt[g][kl] = h;
+    if (kl == 0) s_cnt[g][64] = n;
+    __syncthreads();
+    if (g == 0) {
+        if (k < K) hist[k] = (s_cnt[0][kl] + s_cnt[1][kl]) + (s_cnt[2][kl] + s_cnt[3][kl]);
+        if (slabs && kl == 0 && blockIdx.x == 0) hdr[0] = (s_cnt[0][64] + s_cnt[1][64]) + (s_cnt[2][64] + s_cnt[3][64]);
+    }
 }
 
 // ================================================================================================================
@@ -1523,7 +1543,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
 #undef DM_VQ2
 #undef DM_VQ2K
-        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
+        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
         return dm_launch_status("dm_vq_forward");
     }
     const float *cbT = ws + L.cbT;
@@ -1540,7 +1560,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
     }
 #undef DM_VQ_FWD
-    if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
+    if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
     return dm_launch_status("dm_vq_forward");
 }
 }  // namespace

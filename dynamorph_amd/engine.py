@@ -29,6 +29,11 @@ from .ops import (DM_LOAD_AFFINE, DM_LOAD_AFFINE2, DM_LOAD_AFFINE_RELU, DM_LOAD_
                   weight_view)
 
 
+# DM_FUSED_BACKWARD=0 in the environment: the two-kernel backward of enc.4 (A/B measurements)
+import os as _os
+FUSED_BACKWARD = _os.environ.get("DM_FUSED_BACKWARD", "1") != "0"
+
+
 class Layers:
     """Parameter handles resolved from a VQ_VAE-shaped nn.Module (state-dict names of the reference), or from one of its
     halves: `model.enc` / `model.dec` called on their own build Layers(enc=self) / Layers(dec=self) -- no back-reference
@@ -253,11 +258,17 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
 
     c2b = ops.bn_backward_finalize(st, B * H2 * W2, _w(L.bn2.weight), cx.saved2, G(L.bn2.weight), G(L.bn2.bias))
     da2 = Op(dy2, DM_LOAD_AFFINE2, c2b, p1=cx.a2)
-    ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(L.enc4.weight), B, nh, c1, H2, W2, 4, pending=pending)
     _zero(G(L.enc4.bias), zero_fed_biases)
-    dy1, st = ops.conv3x3(da2, weight_view(_w(L.enc4.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
-                          pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
-                          stat_q=cx.a1)
+    if FUSED_BACKWARD and ops.conv_bwd_s2_fused_supported(nh, c1, H2, W2):
+        # enc.4: data gradient + weight gradient from ONE staging of (dy2, a2, a1) -- csrc/conv_mfma.hip, kernel D
+        dy1, st = ops.conv_bwd_s2_fused(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), weight_view(_w(L.enc4.weight), 16, c1 * 16, 4, 1),
+                                        G(L.enc4.weight), B, nh, c1, H2, W2, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
+                                        stat_q=cx.a1, pending=pending)
+    else:
+        ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(L.enc4.weight), B, nh, c1, H2, W2, 4, pending=pending)
+        dy1, st = ops.conv3x3(da2, weight_view(_w(L.enc4.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
+                              pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
+                              stat_q=cx.a1)
 
     c1b = ops.bn_backward_finalize(st, B * H1 * W1, _w(L.bn1.weight), cx.saved1, G(L.bn1.weight), G(L.bn1.bias))
     da1 = Op(dy1, DM_LOAD_AFFINE2, c1b, p1=cx.a1)

@@ -286,6 +286,35 @@ def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
     return dst
 
 
+def conv_bwd_s2_fused_supported(CD, CX, H, W):
+    return bool(L.load().dm_conv_bwd_s2_fused_supported(CD, CX, H, W))
+
+
+@_op
+def conv_bwd_s2_fused(dy, tin, wv, dst, B, CD, CX, H, W, mask, stat_q=None, pending=None, want_stats=True):
+    """Backward of a Conv2d(CX -> CD, 4, 2, 1) in one kernel (include/dynamorph_hip.h, dm_conv_bwd_s2_fused): data
+    gradient (B, CX, 2H, 2W), masked by `mask` (the layer input, AFFINE) with its (sum, sum * input) statistics slabs, and
+    the weight-gradient slabs, queued for reduce_slabs_multi into `dst` (pending) or reduced at once (pending None).
+    dy: the output gradient as an AFFINE2 operand (BatchNorm backward folded in) on the (H, W) grid; tin: the layer input as
+    the forward read it (AFFINE_RELU).  Returns (dx, stats)."""
+    lib = L.load()
+    nb = lib.dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W)
+    if nb <= 0:
+        raise ValueError(f"dm_conv_bwd_s2_fused: shape {(B, CD, CX, H, W)} not built")
+    dx = _new((B, CX, 2 * H, 2 * W), dy.p0)
+    stats = _new((nb, CX, 2), dy.p0, torch.float64) if want_stats else None
+    slabs = _new((nb, CD * CX * 16), dy.p0)
+    e = epilogue(mask=mask, stat_q=stat_q, stats=stats)
+    d, t = dy.struct(), tin.struct()
+    L.check(lib.dm_conv_bwd_s2_fused(C.byref(d), C.byref(t), wv.ref(), _ptr(dx), C.byref(e), _ptr(slabs), B, CD, CX, H, W,
+                                     _stream()), "dm_conv_bwd_s2_fused")
+    if pending is not None:
+        pending.append((slabs, dst))
+    else:
+        reduce_slabs(slabs, dst)
+    return dx, stats
+
+
 def pend_stats(pending, stats, dsts):
     """Queue the column sums of a statistics slab tensor (nslabs, N, 2) for reduce_slabs_multi: consecutive runs of
     columns go to the tensors `dsts` (what sum_slabs / sum_slabs_scatter would do in a launch of their own)."""

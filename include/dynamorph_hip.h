@@ -197,6 +197,22 @@ int dm_conv3x3(const dm_operand *in, const dm_weight_view *w, float *out, const 
 int dm_conv3x3_num_blocks(int B, int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile);
 int64_t dm_conv3x3_scratch_floats(int CIN, int NOUT, int H, int W, int taps, int pixel_shuffle, int per_tile);
 
+/* Backward of a Conv2d(CX -> CD, kernel 4, stride 2, padding 1) in ONE kernel (csrc/conv_mfma.hip, kernel D) -- the
+ * aten::convolution_backward of enc.4 (vq_vae.py:281): data gradient and weight gradient from one staging of its operands.
+ *   dy      the output gradient on the (H, W) grid, (B, CD, H, W); normally AFFINE2 (BatchNorm backward: A*dy + B*a_out + C)
+ *   in      the layer input as the forward read it, (B, CX, 2H, 2W); normally AFFINE_RELU (BatchNorm + ReLU on load)
+ *   w       the layer's weight [CD][CX][4][4] viewed for the transposed convolution: sn = 16, sc = CX * 16, sky = 4, skx = 1
+ *   dx      out: the data gradient (B, CX, 2H, 2W), zero where ep->mask (= the layer input, IDENT or AFFINE) is <= 0;
+ *           ep->stats (dm_conv_bwd_s2_fused_num_blocks slabs of [CX][2] doubles): (sum dx, sum dx * input) per channel
+ *           (ep->stat_q = the layer input or NULL); ep->bias / relu / resid must be unset
+ *   w_slabs out: num_blocks slabs of CD*CX*16 floats, each in the weight's own layout; dm_reduce_slabs(_multi) adds them
+ * Built for CD = 16, CX = 8, H % 8 == 0, W % 32 == 0 (dm_conv_bwd_s2_fused_supported); batch-statistics coefficients
+ * (coef_bstride = 0) only. */
+int dm_conv_bwd_s2_fused_supported(int CD, int CX, int H, int W);
+int dm_conv_bwd_s2_fused_num_blocks(int B, int CD, int CX, int H, int W);
+int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *in, const dm_weight_view *w, float *dx,
+                         const dm_epilogue *ep, float *w_slabs, int B, int CD, int CX, int H, int W, void *stream);
+
 /* Weight gradient:  R[cs][ct][ky][kx] = sum_{b,y,x} S[b,cs,y,x] * T[b,ct,y*s+ky-p,x*s+kx-p]
  * (k,s,p) in {(4,2,1),(3,1,1),(1,1,0)}.  For a Conv2d: S = output gradient,
  * T = layer input, R = dW [co][ci][k][k].  For a ConvTranspose2d: S = layer

@@ -1195,3 +1195,45 @@ def test_vq_bf16_split_filter_scales_and_clusters(ops, D, K, scale_z, scale_e):
     idx_b, out_b, _, hist_b, nre = ops.vq_forward(zd, cbd, variant=DM_VQ_BF16, want_rechecked=True)
     assert torch.equal(idx_e, idx_b) and torch.equal(out_e, out_b) and torch.equal(hist_e, hist_b)
     print(f"D={D} K={K} scales ({scale_z}, {scale_e}): {int(nre.cpu())} of {idx_b.numel()} positions re-evaluated exactly")
+
+
+@pytest.mark.parametrize("B,hw", [(3, 32), (2, 64), (5, 32), (300, 32)])
+def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
+    """Kernel D (csrc/conv_mfma.hip): data gradient + weight gradient of a Conv2d(8 -> 16, 4, 2, 1) from one staging of
+    (dy, a_out, a_in), with the BatchNorm-backward operand, the ReLU mask of the layer input and the (sum, sum * input)
+    statistics -- against torch autograd, and against the two kernels it replaces (the data gradient bit for bit: same
+    MFMA order; the weight gradient to summation order).  B = 300: more tiles than workgroups (persistent loop)."""
+    CD, CX, H, W = 16, 8, hw, hw
+    dy, a_out = rnd(B, CD, H, W, seed=1), rnd(B, CD, H, W, seed=2)
+    coefD = torch.stack([rnd(CD, seed=3), rnd(CD, seed=4) * 0.1, rnd(CD, seed=5) * 0.1, torch.zeros(CD)], 1)
+    a_in = rnd(B, CX, 2 * H, 2 * W, seed=6)
+    coefT = torch.stack([rnd(CX, seed=7).abs() + 0.5, torch.zeros(CX), rnd(CX, seed=8) * 0.3, torch.zeros(CX)], 1)
+    w = rnd(CD, CX, 4, 4, seed=9, scale=0.2)
+    da = load_ref(dy, 4, coefD, a_out)
+    t_in = load_ref(a_in, 3, coefT)
+    x = t_in.clone().requires_grad_(True)
+    wt = w.clone().requires_grad_(True)
+    F.conv2d(x, wt, None, stride=2, padding=1).backward(da)
+    dx_ref = x.grad * (load_ref(a_in, 2, coefT) > 0)
+    assert ops.conv_bwd_s2_fused_supported(CD, CX, H, W) and not ops.conv_bwd_s2_fused_supported(CD, CX, H, 16)
+    d = lambda t: t.to(DEV)
+    dst = torch.empty(CD, CX, 4, 4, device=DEV)
+    dyop = lambda: ops.Op(d(dy), 4, d(coefD), p1=d(a_out))
+    dx, st = ops.conv_bwd_s2_fused(dyop(), ops.Op(d(a_in), 3, d(coefT)), ops.weight_view(d(w), 16, CX * 16, 4, 1), dst, B, CD, CX,
+                                   H, W, mask=ops.Op(d(a_in), 2, d(coefT)), stat_q=d(a_in))
+    close(dx, dx_ref, 3e-5, 3e-5, "fused data gradient")
+    close(dst, wt.grad, 3e-5, 3e-5 * float(wt.grad.abs().max()), "fused weight gradient")
+    close_stats(st.sum(0), dx_ref, a_in, "fused statistics")
+    # the two kernels it replaces
+    dx2, st2 = ops.conv3x3(dyop(), ops.weight_view(d(w), 16, CX * 16, 4, 1), B, CD, 4 * CX, H, W, taps=9, pixel_shuffle=True,
+                           want_stats=True, mask=ops.Op(d(a_in), 2, d(coefT)), stat_q=d(a_in))
+    dst2 = torch.empty_like(dst)
+    ops.wgrad(dyop(), ops.Op(d(a_in), 3, d(coefT)), dst2, B, CD, CX, H, W, 4)
+    assert torch.equal(dx, dx2)
+    close(dst, dst2, 2e-5, 2e-5 * float(dst2.abs().max()), "fused vs separate weight gradient")
+    close(st.sum(0), st2.sum(0), 1e-9, 1e-9 * float(st2.sum(0).abs().max()), "statistics vs separate")
+    # two runs agree to the bit (fixed slab order, no float atomics)
+    dstb = torch.empty_like(dst)
+    dxb, stb = ops.conv_bwd_s2_fused(dyop(), ops.Op(d(a_in), 3, d(coefT)), ops.weight_view(d(w), 16, CX * 16, 4, 1), dstb, B, CD,
+                                     CX, H, W, mask=ops.Op(d(a_in), 2, d(coefT)), stat_q=d(a_in))
+    assert torch.equal(dst, dstb) and torch.equal(dx, dxb) and torch.equal(st, stb)
