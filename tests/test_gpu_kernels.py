@@ -1216,24 +1216,27 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     F.conv2d(x, wt, None, stride=2, padding=1).backward(da)
     dx_ref = x.grad * (load_ref(a_in, 2, coefT) > 0)
     assert ops.conv_bwd_s2_fused_supported(CD, CX, H, W) and not ops.conv_bwd_s2_fused_supported(CD, CX, H, 16)
-    d = lambda t: t.to(DEV)
-    dst = torch.empty(CD, CX, 4, 4, device=DEV)
-    dyop = lambda: ops.Op(d(dy), 4, d(coefD), p1=d(a_out))
-    dx, st = ops.conv_bwd_s2_fused(dyop(), ops.Op(d(a_in), 3, d(coefT)), ops.weight_view(d(w), 16, CX * 16, 4, 1), dst, B, CD, CX,
-                                   H, W, mask=ops.Op(d(a_in), 2, d(coefT)), stat_q=d(a_in))
+    dyd, aod, aid, cDd, cTd, wd = (t.to(DEV) for t in (dy, a_out, a_in, coefD, coefT, w))     # (one device copy each: the
+    dst = torch.empty(CD, CX, 4, 4, device=DEV)                                               #  kernel checks mask IS the input)
+    dyop = lambda: ops.Op(dyd, 4, cDd, p1=aod)
+    run = lambda out: ops.conv_bwd_s2_fused(dyop(), ops.Op(aid, 3, cTd), ops.weight_view(wd, 16, CX * 16, 4, 1), out, B, CD, CX,
+                                            H, W, mask=ops.Op(aid, 2, cTd), stat_q=aid)
+    dx, st = run(dst)
     close(dx, dx_ref, 3e-5, 3e-5, "fused data gradient")
     close(dst, wt.grad, 3e-5, 3e-5 * float(wt.grad.abs().max()), "fused weight gradient")
     close_stats(st.sum(0), dx_ref, a_in, "fused statistics")
     # the two kernels it replaces
-    dx2, st2 = ops.conv3x3(dyop(), ops.weight_view(d(w), 16, CX * 16, 4, 1), B, CD, 4 * CX, H, W, taps=9, pixel_shuffle=True,
-                           want_stats=True, mask=ops.Op(d(a_in), 2, d(coefT)), stat_q=d(a_in))
+    dx2, st2 = ops.conv3x3(dyop(), ops.weight_view(wd, 16, CX * 16, 4, 1), B, CD, 4 * CX, H, W, taps=9, pixel_shuffle=True,
+                           want_stats=True, mask=ops.Op(aid, 2, cTd), stat_q=aid)
     dst2 = torch.empty_like(dst)
-    ops.wgrad(dyop(), ops.Op(d(a_in), 3, d(coefT)), dst2, B, CD, CX, H, W, 4)
+    ops.wgrad(dyop(), ops.Op(aid, 3, cTd), dst2, B, CD, CX, H, W, 4)
     assert torch.equal(dx, dx2)
     close(dst, dst2, 2e-5, 2e-5 * float(dst2.abs().max()), "fused vs separate weight gradient")
     close(st.sum(0), st2.sum(0), 1e-9, 1e-9 * float(st2.sum(0).abs().max()), "statistics vs separate")
     # two runs agree to the bit (fixed slab order, no float atomics)
     dstb = torch.empty_like(dst)
-    dxb, stb = ops.conv_bwd_s2_fused(dyop(), ops.Op(d(a_in), 3, d(coefT)), ops.weight_view(d(w), 16, CX * 16, 4, 1), dstb, B, CD,
-                                     CX, H, W, mask=ops.Op(d(a_in), 2, d(coefT)), stat_q=d(a_in))
+    dxb, stb = run(dstb)
     assert torch.equal(dst, dstb) and torch.equal(dx, dxb) and torch.equal(st, stb)
+    with pytest.raises(ValueError, match="layer input"):       # a mask that is not the layer input is refused on the host
+        ops.conv_bwd_s2_fused(dyop(), ops.Op(aid, 3, cTd), ops.weight_view(wd, 16, CX * 16, 4, 1), dstb, B, CD, CX, H, W,
+                              mask=ops.Op(aid.clone(), 2, cTd))
