@@ -1232,7 +1232,7 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     ops.wgrad(dyop(), ops.Op(aid, 3, cTd), dst2, B, CD, CX, H, W, 4)
     assert torch.equal(dx, dx2)
     close(dst, dst2, 2e-5, 2e-5 * float(dst2.abs().max()), "fused vs separate weight gradient")
-    close(st.sum(0), st2.sum(0), 1e-9, 1e-9 * float(st2.sum(0).abs().max()), "statistics vs separate")
+    close(st.sum(0), st2.sum(0), 1e-7, 1e-7 * float(st2.sum(0).abs().max()), "statistics vs separate")   # (fp32 quads, grouped by tile)
     # two runs agree to the bit (fixed slab order, no float atomics)
     dstb = torch.empty_like(dst)
     dxb, stb = run(dstb)
