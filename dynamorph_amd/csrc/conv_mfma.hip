@@ -673,30 +673,34 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
 //                   16-position span = K-steps 0..3), one ds_read_b128 per four MFMA steps
 // The weight-gradient accumulators persist over the workgroup's tiles; the eight waves are combined in wave order and the
 // workgroup writes one slab (dm_reduce_slabs_multi adds the slabs in slab order): bit-reproducible.
-constexpr int FB_BLOCK = 512, FB_WAVES = 8;
-
+// FB_BLOCK threads per workgroup: 512 (one workgroup per CU, two waves per SIMD; the staging registers of both tiles
+// spread over 512 threads) or 256 (two independent workgroups per CU, whose load / commit phases can hide under each
+// other's matrix phase instead of all eight waves of a CU committing at the same time).
 template <int CD, int CX, int TH, int TW>
 struct FusedBwdGeom {
-    static_assert(CD == 16 && CX == 8 && TH == FB_WAVES && TW % 16 == 0, "built for enc.4: 8 -> 16 channels");
+    static_assert(CD == 16 && CX == 8 && TH == 8 && TW % 16 == 0, "built for enc.4: 8 -> 16 channels");
     static constexpr int IH = TH + 2, RS = TW + 8, COLS4 = RS / 4, PSRAW = IH * RS;
     static constexpr int PS = PSRAW + ((16 - (PSRAW % 32)) + 32) % 32;            // == 16 (mod 32): kernel C's A reads
     static constexpr int TROWS = 2 * TH + 2, RST = 2 * TW + 8, TCOLS4 = RST / 4, PST = TROWS * RST;
     static constexpr int N = CX * 16, NTT = N / 16;
     static constexpr int TILE_FLOATS = CD * PS + CX * PST, RED_FLOATS = NTT * 256;
     static constexpr int LDS_FLOATS = (TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) + 2 * DM_COEF_MAX_C * 4;
-    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4 + FB_WAVES * 16 * 2 * sizeof(double);
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4 + 8 * 16 * 2 * sizeof(double);
 };
 
-template <int CD, int CX, int TH, int TW>
+template <int CD, int CX, int TH, int TW, int FB_BLOCK>
 __global__ __launch_bounds__(FB_BLOCK, 2)
 void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
                          float *__restrict__ wslabs, int H, int W, int ntiles)
 {
     using G = FusedBwdGeom<CD, CX, TH, TW>;
+    constexpr int FB_WAVES = FB_BLOCK / 64;
     constexpr int IH = G::IH, RS = G::RS, COLS4 = G::COLS4, PS = G::PS;
     constexpr int TROWS = G::TROWS, RST = G::RST, TCOLS4 = G::TCOLS4, PST = G::PST, NTT = G::NTT, N = G::N;
-    constexpr int CGN = TW / 16, MP = 2;                   // 16-position groups per row; M tiles per wave = TH * CGN / 8
-    static_assert(TH * CGN == FB_WAVES * MP, "two M tiles per wave");
+    constexpr int CGN = TW / 16, MP = 2;                   // 16-position groups per row; M tiles in flight per wave
+    constexpr int NPASS = TH * CGN / (FB_WAVES * MP);      // data-gradient passes per wave: 1 (512 threads) or 2 (256)
+    constexpr int WROWS = TH / FB_WAVES;                   // weight-gradient position rows per wave: 1 or 2
+    static_assert(TH * CGN == FB_WAVES * MP * NPASS && TH == FB_WAVES * WROWS, "tile split over the waves");
     constexpr int TAPX = 3, KS = (CD / 4) * 2 * TAPX;      // kernel C with 8 output channels: n = (px, co), 2 x 3 taps
     extern __shared__ __attribute__((aligned(16))) float fb_lds[];
     float *tileD = fb_lds, *tileT = fb_lds + CD * PS;
@@ -752,7 +756,7 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
         const int n = 16 * t + m;
         bl[t] = (n >> 4) * PST + ((n >> 2) & 3) * RST + (n & 3) + 3 + 8 * kq + 2 * wave * RST;
     }
-    const int al = m * PS + (wave + 1) * RS + 4 + 4 * kq;       // A row m = dy channel, position row `wave`
+    const int al = m * PS + (wave + 1) * RS + 4 + 4 * kq;       // A row m = dy channel, position rows wave, wave + FB_WAVES
     f32x4 wacc[NTT];
 #pragma unroll
     for (int t = 0; t < NTT; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -774,65 +778,70 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
         cx.rebase(ep, dx, sample_elems, cb);
         constexpr int NED = decltype(stD)::N, NET = decltype(stT)::N;
 
-        // ---- data gradient: M tiles (wave, wave + 8), phase rows py = 0, 1 ------------------------------------------
-        const float *ap[MP];
-        int obase[MP];
+        // ---- data gradient: M tiles wave + FB_WAVES * (MP * pass + i), phase rows py = 0, 1 ------------------------------
 #pragma unroll
-        for (int i = 0; i < MP; ++i) {
-            const int ti = wave + FB_WAVES * i;
-            const int r = ti / CGN, cg = ti % CGN;
-            ap[i] = tileD + r * RS + 16 * cg + abase;
-            obase[i] = chan_off + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
-        }
-#pragma unroll
-        for (int py = 0; py < 2; ++py) {
-            // the next tile's da elements are requested under the products of this one
-#pragma unroll
-            for (int e = 0; e < NED; ++e)
-                if (e >= py * NED / 2 && e < (py + 1) * NED / 2) stD.issue_one(e, scD);
-            EpiIn<SIDE_MASK> e[MP];
-#pragma unroll
-            for (int i = 0; i < MP; ++i) epilogue_loads<SIDE_MASK>(e[i], cx, obase[i] + py * OW * 4);
-            f32x4 acc[MP][1];
-#pragma unroll
-            for (int i = 0; i < MP; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            auto off = [py](int s) {
-                const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
-                return 4 * cg4 * PS + (py + a) * RS + bb;
-            };
-            mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py], acc, off);
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const float *ap[MP];
+            int obase[MP];
 #pragma unroll
             for (int i = 0; i < MP; ++i) {
-                const f32x4 v = acc[i][0];
-                const f32x4 pv = lane_xor8(v);             // partner lane holds the other x phase of the same channel
-                epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y}, ep, cx, e[i],
-                                         mc0, mc2, obase[i] + py * OW * 4, s1, s2);
+                const int ti = wave + FB_WAVES * (MP * pass + i);
+                const int r = ti / CGN, cg = ti % CGN;
+                ap[i] = tileD + r * RS + 16 * cg + abase;
+                obase[i] = chan_off + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
+            }
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                // the next tile's da elements are requested under the products of this one
+                constexpr int NQ = 2 * NPASS;
+                const int qd = 2 * pass + py;
+#pragma unroll
+                for (int e = 0; e < NED; ++e)
+                    if (e >= qd * NED / NQ && e < (qd + 1) * NED / NQ) stD.issue_one(e, scD);
+                EpiIn<SIDE_MASK> e[MP];
+#pragma unroll
+                for (int i = 0; i < MP; ++i) epilogue_loads<SIDE_MASK>(e[i], cx, obase[i] + py * OW * 4);
+                f32x4 acc[MP][1];
+#pragma unroll
+                for (int i = 0; i < MP; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                auto off = [py](int s) {
+                    const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                    return 4 * cg4 * PS + (py + a) * RS + bb;
+                };
+                mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py], acc, off);
+#pragma unroll
+                for (int i = 0; i < MP; ++i) {
+                    const f32x4 v = acc[i][0];
+                    const f32x4 pv = lane_xor8(v);         // partner lane holds the other x phase of the same channel
+                    epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y}, ep, cx,
+                                             e[i], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
+                }
             }
         }
 
-        // ---- weight gradient: position row `wave`, TW / 16 spans of 16 positions, 4 K-steps per span ------------------
+        // ---- weight gradient: position rows wave (+ FB_WAVES), TW / 16 spans of 16 positions, 4 K-steps per span ---------
         {
-            constexpr int NSPAN = TW / 16;
+            constexpr int NSPAN = TW / 16, NQ = WROWS * NSPAN * 4;      // q = (row, span, K-step)
+            auto aoff = [](int q) { return (q / (NSPAN * 4)) * FB_WAVES * RS + 16 * ((q >> 2) % NSPAN); };
+            auto boff = [](int q) { return (q / (NSPAN * 4)) * FB_WAVES * 2 * RST + 32 * ((q >> 2) % NSPAN) + 2 * (q & 3); };
             f32x4 av[2];
             float bv[2][NTT];
             av[0] = *reinterpret_cast<const f32x4 *>(tileD + al);
 #pragma unroll
             for (int t = 0; t < NTT; ++t) bv[0][t] = tileT[bl[t]];
 #pragma unroll
-            for (int q = 0; q < NSPAN * 4; ++q) {           // q = 4 * span + K-step
-                const int sp = q >> 2, st = q & 3;
-                if (q + 1 < NSPAN * 4) {
-                    const int sp1 = (q + 1) >> 2, st1 = (q + 1) & 3;
-                    if (st1 == 0) av[sp1 & 1] = *reinterpret_cast<const f32x4 *>(tileD + al + 16 * sp1);
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) {
+                    if (((q + 1) & 3) == 0) av[((q + 1) >> 2) & 1] = *reinterpret_cast<const f32x4 *>(tileD + al + aoff(q + 1));
 #pragma unroll
-                    for (int t = 0; t < NTT; ++t) bv[(q + 1) & 1][t] = tileT[bl[t] + 32 * sp1 + 2 * st1];
+                    for (int t = 0; t < NTT; ++t) bv[(q + 1) & 1][t] = tileT[bl[t] + boff(q + 1)];
                 }
                 // the next tile's T elements trickle out between the steps
 #pragma unroll
                 for (int e = 0; e < NET; ++e)
-                    if (e >= q * NET / (NSPAN * 4) && e < (q + 1) * NET / (NSPAN * 4)) stT.issue_one(e, scT);
+                    if (e >= q * NET / NQ && e < (q + 1) * NET / NQ) stT.issue_one(e, scT);
                 __builtin_amdgcn_sched_barrier(0);
-                const float a = av[sp & 1][st];
+                const float a = av[(q >> 2) & 1][q & 3];
 #pragma unroll
                 for (int t = 0; t < NTT; ++t) wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[q & 1][t], wacc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -857,7 +866,7 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
             ep.stats[((long long)blockIdx.x * CX + threadIdx.x) * 2 + 1] = tc;
         }
     }
-    // ---- weight-gradient slab: the eight waves in wave order.  wacc[t][j] is dy channel 4 (lane >> 4) + j, column 16 t + m
+    // ---- weight-gradient slab: the waves in wave order.  wacc[t][j] is dy channel 4 (lane >> 4) + j, column 16 t + m
     float *red = fb_lds;
     for (int w = 0; w < FB_WAVES; ++w) {
         __syncthreads();
@@ -1208,11 +1217,19 @@ static bool fused_bwd_shape(int CD, int CX, int H, int W)
 
 extern "C" int dm_conv_bwd_s2_fused_supported(int CD, int CX, int H, int W) { return fused_bwd_shape(CD, CX, H, W) ? 1 : 0; }
 
+// threads per workgroup of kernel D: 256 (two workgroups per CU) unless DM_FUSED_BWD_BLOCK=512 asks for one of 512
+static int fused_bwd_block()
+{
+    static const int v = [] { const char *e = getenv("DM_FUSED_BWD_BLOCK"); return (e && atoi(e) == 512) ? 512 : 256; }();
+    return v;
+}
+
 extern "C" int dm_conv_bwd_s2_fused_num_blocks(int B, int CD, int CX, int H, int W)
 {
     if (B <= 0 || !fused_bwd_shape(CD, CX, H, W)) return -1;
     const long long ntiles = (long long)B * (H / 8) * (W / 32);
-    return (int)(ntiles < 256 ? ntiles : 256);            // one 512-thread workgroup per CU, one slab each
+    const long long cap = fused_bwd_block() == 512 ? 256 : 512;       // resident workgroups: one slab each
+    return (int)(ntiles < cap ? ntiles : cap);
 }
 
 extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin, const dm_weight_view *w, float *dx,
@@ -1234,14 +1251,21 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
     using G = FusedBwdGeom<16, 8, 8, 32>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32>,
+        hipError_t e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 512>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 256>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     const int ntiles = B * (H / 8) * (W / 32);
     const int grid = dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W);
-    hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32>), dim3(grid), dim3(FB_BLOCK), G::LDS_BYTES, (hipStream_t)stream,
-                       to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
+    if (fused_bwd_block() == 512)
+        hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 512>), dim3(grid), dim3(512), G::LDS_BYTES, (hipStream_t)stream,
+                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
+    else
+        hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 256>), dim3(grid), dim3(256), G::LDS_BYTES, (hipStream_t)stream,
+                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
     return dm_launch_status("dm_conv_bwd_s2_fused");
 }
