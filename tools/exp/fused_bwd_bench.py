@@ -16,7 +16,19 @@ w = torch.randn(CD, CX, 4, 4, device=dev) * .2
 dst = torch.empty_like(w)
 
 
-def t_ms(fn, iters=20, warm=3):
+def t_ms(fn0, iters=10, warm=2, launches=10):
+    """average duration of one call inside a HIP graph of `launches` back-to-back calls (no host launch gaps)"""
+    fn0()
+    gg = torch.cuda.CUDAGraph()
+    sd = torch.cuda.Stream()
+    sd.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(sd):
+        fn0()
+    torch.cuda.current_stream().wait_stream(sd)
+    with torch.cuda.graph(gg):
+        for _ in range(launches):
+            fn0()
+    fn = gg.replay
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,7 +36,7 @@ def t_ms(fn, iters=20, warm=3):
     for _ in range(iters):
         fn()
     e1.record(); e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / iters / launches
 
 
 dyop = lambda: ops.Op(dy, 4, cD, p1=a_out)
