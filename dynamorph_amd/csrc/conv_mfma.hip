@@ -686,9 +686,16 @@ struct FusedBwdGeom {
     static constexpr int TILE_FLOATS = CD * PS + CX * PST, RED_FLOATS = NTT * 256;
     static constexpr int LDS_FLOATS = (TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) + 2 * DM_COEF_MAX_C * 4;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4 + 8 * 16 * 2 * sizeof(double);
+    // role-split form: two tile buffers + the coefficient tables + the statistics scratch
+    static constexpr size_t SPLIT_LDS_BYTES = (size_t)(2 * TILE_FLOATS + 2 * DM_COEF_MAX_C * 4) * 4 + 4 * 16 * 2 * sizeof(double);
+    static_assert(RED_FLOATS <= TILE_FLOATS, "the slab combine reuses a tile buffer");
 };
 
-template <int CD, int CX, int TH, int TW, int FB_BLOCK>
+// TPRE: the next tile's T elements are prefetched into registers during the matrix phase like the da elements; false
+// (the 256-thread build): they are loaded at the top of the tile, while the da tile is committed -- their registers are
+// then dead during the matrix phase (64 fewer live there: no spills), and the load latency is left to the CU's other
+// workgroup to fill.
+template <int CD, int CX, int TH, int TW, int FB_BLOCK, bool TPRE>
 __global__ __launch_bounds__(FB_BLOCK, 2)
 void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
                          float *__restrict__ wslabs, int H, int W, int ntiles)
@@ -723,7 +730,7 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
         x0 = (t % tiles_x) * TW; t /= tiles_x;
         y0 = (t % tiles_y) * TH; b = t / tiles_y;
         stD.issue(dy, b, CD, H, W, y0 - 1, x0 - 4);
-        stT.issue(tin, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
+        if constexpr (TPRE) stT.issue(tin, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
         stage_coef(s_coefD, dy, b, CD);
         stage_coef(s_coefT, tin, b, CX);
     }
@@ -762,6 +769,7 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
     for (int t = 0; t < NTT; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     while (tidx < ntiles) {
+        if constexpr (!TPRE) stT.issue(tin, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);      // (in flight across the barrier and the da commit)
         __syncthreads();                                   // previous tile consumed
         stD.commit(tileD, s_coefD, CD, H, W, y0 - 1, x0 - 4, dy.mode);
         stT.commit(tileT, s_coefT, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4, tin.mode);
@@ -774,7 +782,8 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
             y0 = (t % tiles_y) * TH; b = t / tiles_y;
         }
         const auto scD = stD.begin(dy, next < ntiles, b, CD, H, W, y0 - 1, x0 - 4);
-        const auto scT = stT.begin(tin, next < ntiles, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
+        const auto scT = stT.begin(tin, TPRE && next < ntiles, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
+        (void)scT;
         cx.rebase(ep, dx, sample_elems, cb);
         constexpr int NED = decltype(stD)::N, NET = decltype(stT)::N;
 
@@ -837,9 +846,11 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                     for (int t = 0; t < NTT; ++t) bv[(q + 1) & 1][t] = tileT[bl[t] + boff(q + 1)];
                 }
                 // the next tile's T elements trickle out between the steps
+                if constexpr (TPRE) {
 #pragma unroll
-                for (int e = 0; e < NET; ++e)
-                    if (e >= q * NET / NQ && e < (q + 1) * NET / NQ) stT.issue_one(e, scT);
+                    for (int e = 0; e < NET; ++e)
+                        if (e >= q * NET / NQ && e < (q + 1) * NET / NQ) stT.issue_one(e, scT);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const float a = av[(q >> 2) & 1][q & 3];
 #pragma unroll
@@ -884,6 +895,229 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
     for (int i = threadIdx.x; i < NTT * 256; i += FB_BLOCK) {
         const int j = i & 3, l = (i >> 2) & 63, t = i >> 8;
         slab[(4 * (l >> 4) + j) * N + 16 * t + (l & 15)] = red[i];
+    }
+}
+
+// ---- kernel D, role-split form.  One 512-thread workgroup per CU, TWO LDS buffers (2 x 67 KB), and two kinds of waves:
+//   waves 0..3  data gradient of tile i (kernel C's products and epilogue) -- they never touch global inputs;
+//   waves 4..7  request tile i+1 (every load up front), run the weight-gradient products of tile i while the loads are
+//               in flight, then transform + write tile i+1 into the other buffer.
+// Each SIMD hosts one wave of either kind, one barrier per tile.  With all eight waves in the same phase (the form above)
+// the matrix pipe idles while everybody commits and waits at the two barriers: 261 us for enc.4 at B = 2048 against a
+// 137 us matrix floor; here the commit, the load latency and the epilogue of one kind overlap the other kind's products.
+// The two kinds run separate loops (same trip count, one s_barrier per iteration each): their registers -- transposed-
+// convolution weights on one side, weight-gradient accumulators and 32 staged float4 on the other -- are then never live
+// together.
+template <int CD, int CX, int TH, int TW>
+__global__ __launch_bounds__(512, 2)
+void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
+                         float *__restrict__ wslabs, int H, int W, int ntiles)
+{
+    using G = FusedBwdGeom<CD, CX, TH, TW>;
+    constexpr int RW = 4;                                   // waves per role
+    constexpr int IH = G::IH, RS = G::RS, COLS4 = G::COLS4, PS = G::PS;
+    constexpr int TROWS = G::TROWS, RST = G::RST, TCOLS4 = G::TCOLS4, PST = G::PST, NTT = G::NTT, N = G::N;
+    constexpr int BUF = CD * PS + CX * PST;                 // floats of one (da, T) tile pair
+    constexpr int CGN = TW / 16, MP = 2, NPASS = TH * CGN / (RW * MP), WROWS = TH / RW;
+    static_assert(TH * CGN == RW * MP * NPASS && TH == RW * WROWS, "tile split over the waves of a role");
+    constexpr int TAPX = 3, KS = (CD / 4) * 2 * TAPX;
+    extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+    float *s_coefD = fb_lds + 2 * BUF, *s_coefT = s_coefD + DM_COEF_MAX_C * 4;
+    double (*s_stat)[2] = reinterpret_cast<double (*)[2]>(s_coefT + DM_COEF_MAX_C * 4);
+
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= RW;                         // (wave-uniform)
+    const int rw = wave & (RW - 1);
+    const int OH = 2 * H, OW = 2 * W;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    auto coords = [&](int t, int &tb, int &ty0, int &tx0) {
+        tx0 = (t % tiles_x) * TW; t /= tiles_x;
+        ty0 = (t % tiles_y) * TH; tb = t / tiles_y;
+    };
+    stage_coef(s_coefD, dy, 0, CD);
+    stage_coef(s_coefT, tin, 0, CX);
+    int tidx = blockIdx.x;
+
+    if (loader) {
+        // ================================================================ waves 4..7: loads, commits, weight gradient
+        TileStage<CD, IH, COLS4, RS, PS, true, 256> stD;
+        TileStage<CX, TROWS, TCOLS4, RST, PST, false, 256> stT;
+        const int tl = (int)threadIdx.x - 256;
+        stD.init(H, W, tl);
+        stT.init(OH, OW, tl);
+        int b, y0, x0;
+        if (tidx < ntiles) {
+            coords(tidx, b, y0, x0);
+            stD.issue(dy, b, CD, H, W, y0 - 1, x0 - 4);
+            stT.issue(tin, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
+        }
+        int bl[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+            const int n = 16 * t + m;
+            bl[t] = CD * PS + (n >> 4) * PST + ((n >> 2) & 3) * RST + (n & 3) + 3 + 8 * kq + 2 * rw * RST;
+        }
+        const int al = m * PS + (rw + 1) * RS + 4 + 4 * kq;
+        f32x4 wacc[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                    // coefficient tables staged
+        if (tidx < ntiles) {
+            stD.commit(fb_lds, s_coefD, CD, H, W, y0 - 1, x0 - 4, dy.mode);
+            stT.commit(fb_lds + CD * PS, s_coefT, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4, tin.mode);
+        }
+        __syncthreads();                                    // tile 0 in buffer 0
+        int p = 0;
+        while (tidx < ntiles) {
+            const int next = tidx + gridDim.x;
+            const float *cur = fb_lds + p * BUF;
+            float *nxt = fb_lds + (1 - p) * BUF;
+            int nb = 0, ny0 = 0, nx0 = 0;
+            if (next < ntiles) {                            // (uniform) every load of the next tile, now
+                coords(next, nb, ny0, nx0);
+                stD.issue(dy, nb, CD, H, W, ny0 - 1, nx0 - 4);
+                stT.issue(tin, nb, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4);
+            }
+            // ---- weight gradient of the current tile: position rows rw, rw + 4; spans of 16 positions; 4 K-steps per span
+            {
+                constexpr int NSPAN = TW / 16, NQ = WROWS * NSPAN * 4;
+                auto aoff = [](int q) { return (q / (NSPAN * 4)) * RW * RS + 16 * ((q >> 2) % NSPAN); };
+                auto boff = [](int q) { return (q / (NSPAN * 4)) * RW * 2 * RST + 32 * ((q >> 2) % NSPAN) + 2 * (q & 3); };
+                f32x4 av[2];
+                float bv[2][NTT];
+                av[0] = *reinterpret_cast<const f32x4 *>(cur + al);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) bv[0][t] = cur[bl[t]];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + 1 < NQ) {
+                        if (((q + 1) & 3) == 0) av[((q + 1) >> 2) & 1] = *reinterpret_cast<const f32x4 *>(cur + al + aoff(q + 1));
+#pragma unroll
+                        for (int t = 0; t < NTT; ++t) bv[(q + 1) & 1][t] = cur[bl[t] + boff(q + 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float a = av[(q >> 2) & 1][q & 3];
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[q & 1][t], wacc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (next < ntiles) {                            // the next tile into the other buffer (nobody reads it yet)
+                stD.commit(nxt, s_coefD, CD, H, W, ny0 - 1, nx0 - 4, dy.mode);
+                stT.commit(nxt + CD * PS, s_coefT, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4, tin.mode);
+            }
+            __syncthreads();                                // tile i consumed by everybody, tile i+1 complete
+            p ^= 1;
+            tidx = next;
+        }
+        // ---- weight-gradient slab: the four loader waves in wave order (buffer 0 is free: the last barrier is behind us)
+        float *red = fb_lds;
+        for (int w = 0; w < RW; ++w) {
+            __syncthreads();
+            if (rw == w) {
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    f32x4 *pp = reinterpret_cast<f32x4 *>(red + (t * 64 + lane) * 4);
+                    if (w == 0) *pp = wacc[t];
+                    else *pp = *pp + wacc[t];
+                }
+            }
+        }
+        __syncthreads();
+        __syncthreads();                                    // (the statistics write-out of the other role)
+    } else {
+        // ================================================================ waves 0..3: data gradient
+        const int co = m & 7, pxl = m >> 3;
+        float wreg[2][1][KS];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                const int c = 4 * cg4 + kq;
+                const int ky = py + 3 - 2 * (py + a), kx = pxl + 3 - 2 * bb;
+                float wvl = 0.f;
+                if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
+                wreg[py][0][s] = wvl;
+            }
+        float mc0, mc2;
+        mask_coef(ep, 0, co, mc0, mc2);
+        double s1 = 0.0, s2 = 0.0;
+        const int abase = kq * PS + m + 3;
+        EpiCtx<SIDE_MASK> cx;
+        const long long sample_elems = (long long)CX * OH * OW;
+        const int chan_off = (co * OH * OW + 8 * kq + 4 * pxl) * 4;
+        __syncthreads();                                    // (coefficient tables)
+        __syncthreads();                                    // tile 0 in buffer 0
+        int p = 0;
+        while (tidx < ntiles) {
+            int cb, cy0, cx0;
+            coords(tidx, cb, cy0, cx0);
+            const float *cur = fb_lds + p * BUF;
+            cx.rebase(ep, dx, sample_elems, cb);
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const float *ap[MP];
+                int obase[MP];
+#pragma unroll
+                for (int i = 0; i < MP; ++i) {
+                    const int ti = rw + RW * (MP * pass + i);
+                    const int r = ti / CGN, cg = ti % CGN;
+                    ap[i] = cur + r * RS + 16 * cg + abase;
+                    obase[i] = chan_off + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
+                }
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    EpiIn<SIDE_MASK> e[MP];
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) epilogue_loads<SIDE_MASK>(e[i], cx, obase[i] + py * OW * 4);
+                    f32x4 acc[MP][1];
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    auto off = [py](int s) {
+                        const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                        return 4 * cg4 * PS + (py + a) * RS + bb;
+                    };
+                    mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py], acc, off);
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) {
+                        const f32x4 v = acc[i][0];
+                        const f32x4 pv = lane_xor8(v);
+                        epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y}, ep, cx,
+                                                 e[i], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
+                    }
+                }
+            }
+            __syncthreads();
+            p ^= 1;
+            tidx += gridDim.x;
+        }
+        // (the loaders combine their accumulators through LDS: RW + 1 barriers)
+        for (int w = 0; w < RW + 1; ++w) __syncthreads();
+        if (ep.stats) {
+            double a = s1, c = s2;
+            a += __shfl_xor(a, 16, 64); c += __shfl_xor(c, 16, 64);
+            a += __shfl_xor(a, 32, 64); c += __shfl_xor(c, 32, 64);
+            a += __shfl_xor(a, 8, 64); c += __shfl_xor(c, 8, 64);
+            if (lane < CX) { s_stat[rw * 16 + lane][0] = a; s_stat[rw * 16 + lane][1] = c; }
+        }
+        __syncthreads();
+        if (ep.stats && threadIdx.x < CX) {
+            double ta = 0.0, tc = 0.0;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) { ta += s_stat[w * 16 + threadIdx.x][0]; tc += s_stat[w * 16 + threadIdx.x][1]; }
+            ep.stats[((long long)blockIdx.x * CX + threadIdx.x) * 2 + 0] = ta;
+            ep.stats[((long long)blockIdx.x * CX + threadIdx.x) * 2 + 1] = tc;
+        }
+    }
+    // (barriers after the tile loop: RW + 2 on either side)
+    // ---- all 512 threads: this workgroup's weight-gradient slab out of LDS.  red[(t * 64 + l) * 4 + j] is dy channel
+    //      4 (l >> 4) + j, column 16 t + (l & 15)
+    float *slab = wslabs + (long long)blockIdx.x * (CD * N);
+    for (int i = threadIdx.x; i < NTT * 256; i += 512) {
+        const int j = i & 3, l = (i >> 2) & 63, t = i >> 8;
+        slab[(4 * (l >> 4) + j) * N + 16 * t + (l & 15)] = fb_lds[i];
     }
 }
 
@@ -1217,10 +1451,11 @@ static bool fused_bwd_shape(int CD, int CX, int H, int W)
 
 extern "C" int dm_conv_bwd_s2_fused_supported(int CD, int CX, int H, int W) { return fused_bwd_shape(CD, CX, H, W) ? 1 : 0; }
 
-// threads per workgroup of kernel D: 256 (two workgroups per CU) unless DM_FUSED_BWD_BLOCK=512 asks for one of 512
+// form of kernel D: 0 = role-split (default: one 512-thread workgroup per CU, two LDS buffers), 512 / 256 = the lockstep
+// forms with that many threads per workgroup (DM_FUSED_BWD_BLOCK=512|256 in the environment: A/B measurements)
 static int fused_bwd_block()
 {
-    static const int v = [] { const char *e = getenv("DM_FUSED_BWD_BLOCK"); return (e && atoi(e) == 512) ? 512 : 256; }();
+    static const int v = [] { const char *e = getenv("DM_FUSED_BWD_BLOCK"); const int n = e ? atoi(e) : 0; return (n == 512 || n == 256) ? n : 0; }();
     return v;
 }
 
@@ -1228,7 +1463,7 @@ extern "C" int dm_conv_bwd_s2_fused_num_blocks(int B, int CD, int CX, int H, int
 {
     if (B <= 0 || !fused_bwd_shape(CD, CX, H, W)) return -1;
     const long long ntiles = (long long)B * (H / 8) * (W / 32);
-    const long long cap = fused_bwd_block() == 512 ? 256 : 512;       // resident workgroups: one slab each
+    const long long cap = fused_bwd_block() == 256 ? 512 : 256;       // resident workgroups: one slab each
     return (int)(ntiles < cap ? ntiles : cap);
 }
 
@@ -1251,21 +1486,27 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
     using G = FusedBwdGeom<16, 8, 8, 32>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 512>,
+        hipError_t e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 512, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 256>,
+            e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 256, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
         if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     const int ntiles = B * (H / 8) * (W / 32);
     const int grid = dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W);
-    if (fused_bwd_block() == 512)
-        hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 512>), dim3(grid), dim3(512), G::LDS_BYTES, (hipStream_t)stream,
+    if (fused_bwd_block() == 0)
+        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream,
+                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
+    else if (fused_bwd_block() == 512)
+        hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 512, true>), dim3(grid), dim3(512), G::LDS_BYTES, (hipStream_t)stream,
                            to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
     else
-        hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 256>), dim3(grid), dim3(256), G::LDS_BYTES, (hipStream_t)stream,
+        hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 256, false>), dim3(grid), dim3(256), G::LDS_BYTES, (hipStream_t)stream,
                            to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
     return dm_launch_status("dm_conv_bwd_s2_fused");
 }

@@ -84,9 +84,10 @@ struct TileStage {
     int cs;          // channel sub-index of this thread (< G)
     int HW4;         // bytes of one channel plane (uniform)
 
-    __device__ __forceinline__ void init(int H, int W)
+    __device__ __forceinline__ void init(int H, int W) { init(H, W, (int)threadIdx.x); }
+    // t: this thread's index among the BLOCK threads that stage the tile (a role-split kernel: not threadIdx.x)
+    __device__ __forceinline__ void init(int H, int W, int t)
     {
-        const int t = threadIdx.x;
         cs = G > 1 ? t / PER_C : 0;
         const int e0 = G > 1 ? t - cs * PER_C : t;
         HW4 = H * W * 4;
