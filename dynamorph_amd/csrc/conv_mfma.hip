@@ -911,8 +911,10 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
 template <int CD, int CX, int TH, int TW>
 __global__ __launch_bounds__(512, 2)
 void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
-                         float *__restrict__ wslabs, int H, int W, int ntiles)
+                         float *__restrict__ wslabs, int H, int W, int ntiles, int dbg)
 {
+    // dbg (DM_FUSED_BWD_DBG, measurements only; results are then wrong): 1 skips the weight-gradient products, 2 the data
+    // gradient, 4 the loads and commits of every tile but the first
     using G = FusedBwdGeom<CD, CX, TH, TW>;
     constexpr int RW = 4;                                   // waves per role
     constexpr int IH = G::IH, RS = G::RS, COLS4 = G::COLS4, PS = G::PS;
@@ -974,13 +976,13 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
             const float *cur = fb_lds + p * BUF;
             float *nxt = fb_lds + (1 - p) * BUF;
             int nb = 0, ny0 = 0, nx0 = 0;
-            if (next < ntiles) {                            // (uniform) every load of the next tile, now
+            if (next < ntiles && !(dbg & 4)) {              // (uniform) every load of the next tile, now
                 coords(next, nb, ny0, nx0);
                 stD.issue(dy, nb, CD, H, W, ny0 - 1, nx0 - 4);
                 stT.issue(tin, nb, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4);
             }
             // ---- weight gradient of the current tile: position rows rw, rw + 4; spans of 16 positions; 4 K-steps per span
-            {
+            if (!(dbg & 1)) {
                 constexpr int NSPAN = TW / 16, NQ = WROWS * NSPAN * 4;
                 auto aoff = [](int q) { return (q / (NSPAN * 4)) * RW * RS + 16 * ((q >> 2) % NSPAN); };
                 auto boff = [](int q) { return (q / (NSPAN * 4)) * RW * 2 * RST + 32 * ((q >> 2) % NSPAN) + 2 * (q & 3); };
@@ -1003,7 +1005,7 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (next < ntiles) {                            // the next tile into the other buffer (nobody reads it yet)
+            if (next < ntiles && !(dbg & 4)) {              // the next tile into the other buffer (nobody reads it yet)
                 stD.commit(nxt, s_coefD, CD, H, W, ny0 - 1, nx0 - 4, dy.mode);
                 stT.commit(nxt + CD * PS, s_coefT, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4, tin.mode);
             }
@@ -1056,6 +1058,7 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
             coords(tidx, cb, cy0, cx0);
             const float *cur = fb_lds + p * BUF;
             cx.rebase(ep, dx, sample_elems, cb);
+            if (!(dbg & 2)) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const float *ap[MP];
@@ -1088,6 +1091,7 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                                                  e[i], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
                     }
                 }
+            }
             }
             __syncthreads();
             p ^= 1;
@@ -1459,6 +1463,12 @@ static int fused_bwd_block()
     return v;
 }
 
+static int fused_bwd_dbg()
+{
+    static const int v = [] { const char *e = getenv("DM_FUSED_BWD_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 extern "C" int dm_conv_bwd_s2_fused_num_blocks(int B, int CD, int CX, int H, int W)
 {
     if (B <= 0 || !fused_bwd_shape(CD, CX, H, W)) return -1;
@@ -1501,7 +1511,7 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
     const int grid = dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W);
     if (fused_bwd_block() == 0)
         hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream,
-                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
+                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg());
     else if (fused_bwd_block() == 512)
         hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 512, true>), dim3(grid), dim3(512), G::LDS_BYTES, (hipStream_t)stream,
                            to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);
