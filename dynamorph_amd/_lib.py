@@ -67,6 +67,7 @@ SIGNATURES = {
     "dm_conv3x3": (C.c_int, [OP, WV, vp, EP] + [C.c_int] * 7 + [vp]),
     "dm_conv3x3_num_blocks": (C.c_int, [C.c_int] * 8),
     "dm_conv3x3_scratch_floats": (i64, [C.c_int] * 7),
+    "dm_backward_precision": (C.c_int, [C.c_int]),
     "dm_conv_bwd_s2_fused_supported": (C.c_int, [C.c_int] * 4),
     "dm_conv_bwd_s2_fused_num_blocks": (C.c_int, [C.c_int] * 5),
     "dm_conv_bwd_s2_fused": (C.c_int, [OP, OP, WV, vp, EP, vp] + [C.c_int] * 5 + [vp]),
@@ -130,7 +131,7 @@ call_device = _CallDevice()
 # entry points that only compute on the host (grid sizes, scratch sizes, capability queries): they touch no device, so
 # they are bound without the device guard and do NOT consume the device recorded for the launch being assembled
 HOST_ONLY_SUFFIXES = ("_num_blocks", "_num_slabs", "_scratch_floats", "_workspace_bytes", "_workspace_floats", "_supported")
-HOST_ONLY = ("dm_last_error", "dm_version")
+HOST_ONLY = ("dm_last_error", "dm_version", "dm_backward_precision")
 
 
 def is_host_only(name):

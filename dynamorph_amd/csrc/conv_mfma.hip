@@ -908,7 +908,9 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
 // The two kinds run separate loops (same trip count, one s_barrier per iteration each): their registers -- transposed-
 // convolution weights on one side, weight-gradient accumulators and 32 staged float4 on the other -- are then never live
 // together.
-template <int CD, int CX, int TH, int TW>
+// BF: split-bf16 operands (tile.h: split_pack4) -- both LDS tiles and the transposed-convolution weights hold (hi, lo) bf16
+// pairs, the products run on v_mfma_f32_16x16x32_bf16 at four K-steps per instruction pair: a quarter of the matrix time.
+template <int CD, int CX, int TH, int TW, bool BF>
 __global__ __launch_bounds__(512, 2)
 void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
                          float *__restrict__ wslabs, int H, int W, int ntiles, int dbg)
@@ -966,8 +968,8 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
         for (int t = 0; t < NTT; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                                    // coefficient tables staged
         if (tidx < ntiles) {
-            stD.commit(fb_lds, s_coefD, CD, H, W, y0 - 1, x0 - 4, dy.mode);
-            stT.commit(fb_lds + CD * PS, s_coefT, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4, tin.mode);
+            stD.template commit<BF>(fb_lds, s_coefD, CD, H, W, y0 - 1, x0 - 4, dy.mode);
+            stT.template commit<BF>(fb_lds + CD * PS, s_coefT, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4, tin.mode);
         }
         __syncthreads();                                    // tile 0 in buffer 0
         int p = 0;
@@ -986,6 +988,41 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                 constexpr int NSPAN = TW / 16, NQ = WROWS * NSPAN * 4;
                 auto aoff = [](int q) { return (q / (NSPAN * 4)) * RW * RS + 16 * ((q >> 2) % NSPAN); };
                 auto boff = [](int q) { return (q / (NSPAN * 4)) * RW * 2 * RST + 32 * ((q >> 2) % NSPAN) + 2 * (q & 3); };
+                if constexpr (BF) {
+                    // a span of 16 positions = four K-steps = ONE operand: A from one 16-byte read, B four 4-byte reads per
+                    // N tile; units of (span, half of the N tiles), the next unit's operands requested before this one's products
+                    constexpr int NU = WROWS * NSPAN * 2, HT = NTT / 2;
+                    f32x4 av[2];
+                    float bv[2][HT][4];
+                    av[0] = *reinterpret_cast<const f32x4 *>(cur + al);
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bv[0][t][j] = cur[bl[t] + boff(j)];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int sp = u >> 1, half = u & 1;
+                        if (u + 1 < NU) {
+                            const int sp1 = (u + 1) >> 1, half1 = (u + 1) & 1;
+                            if (half1 == 0) av[sp1 & 1] = *reinterpret_cast<const f32x4 *>(cur + al + aoff(4 * sp1));
+#pragma unroll
+                            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) bv[(u + 1) & 1][t][j] = cur[bl[half1 * HT + t] + boff(4 * sp1 + j)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const dm_u32x4_t a4 = __builtin_bit_cast(dm_u32x4_t, av[sp & 1]);
+                        const dm_u32x4_t ar = dm_rot16(a4);
+#pragma unroll
+                        for (int t = 0; t < HT; ++t) {
+                            const float(&b)[4] = bv[u & 1][t];
+                            const dm_u32x4_t b4 = {__builtin_bit_cast(unsigned, b[0]), __builtin_bit_cast(unsigned, b[1]),
+                                                   __builtin_bit_cast(unsigned, b[2]), __builtin_bit_cast(unsigned, b[3])};
+                            wacc[half * HT + t] = dm_mfma_split(a4, ar, b4, wacc[half * HT + t]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
                 f32x4 av[2];
                 float bv[2][NTT];
                 av[0] = *reinterpret_cast<const f32x4 *>(cur + al);
@@ -1004,10 +1041,11 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                     for (int t = 0; t < NTT; ++t) wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[q & 1][t], wacc[t], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                }
             }
             if (next < ntiles && !(dbg & 4)) {              // the next tile into the other buffer (nobody reads it yet)
-                stD.commit(nxt, s_coefD, CD, H, W, ny0 - 1, nx0 - 4, dy.mode);
-                stT.commit(nxt + CD * PS, s_coefT, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4, tin.mode);
+                stD.template commit<BF>(nxt, s_coefD, CD, H, W, ny0 - 1, nx0 - 4, dy.mode);
+                stT.template commit<BF>(nxt + CD * PS, s_coefT, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4, tin.mode);
             }
             __syncthreads();                                // tile i consumed by everybody, tile i+1 complete
             p ^= 1;
@@ -1041,7 +1079,7 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                 const int ky = py + 3 - 2 * (py + a), kx = pxl + 3 - 2 * bb;
                 float wvl = 0.f;
                 if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
-                wreg[py][0][s] = wvl;
+                wreg[py][0][s] = BF ? split_pack1(wvl) : wvl;
             }
         float mc0, mc2;
         mask_coef(ep, 0, co, mc0, mc2);
@@ -1082,7 +1120,8 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                         const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
                         return 4 * cg4 * PS + (py + a) * RS + bb;
                     };
-                    mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py], acc, off);
+                    if constexpr (BF) mfma_tiles_split<MP, 1, KS>(ap, wreg[py], acc, off);
+                    else mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py], acc, off);
 #pragma unroll
                     for (int i = 0; i < MP; ++i) {
                         const f32x4 v = acc[i][0];
@@ -1463,6 +1502,22 @@ static int fused_bwd_block()
     return v;
 }
 
+// Arithmetic of the BACKWARD matrix products (data and weight gradients): 1 = split-bf16 operands (tile.h: ~2^-17 relative
+// per product, a quarter of the matrix time; the default), 0 = the f32-input instruction (bit for bit the fp32 chain).
+// Process-wide; DM_BACKWARD_PRECISION=f32 in the environment starts with 0; dm_backward_precision(mode >= 0) sets it.
+static int g_backward_split = -1;
+bool dm_backward_split_bf16()
+{
+    if (g_backward_split < 0) { const char *e = getenv("DM_BACKWARD_PRECISION"); g_backward_split = (e && e[0] == 'f') ? 0 : 1; }
+    return g_backward_split != 0;
+}
+extern "C" int dm_backward_precision(int mode)
+{
+    const int cur = dm_backward_split_bf16() ? 1 : 0;
+    if (mode == 0 || mode == 1) g_backward_split = mode;
+    return cur;
+}
+
 static int fused_bwd_dbg()
 {
     static const int v = [] { const char *e = getenv("DM_FUSED_BWD_DBG"); return e ? atoi(e) : 0; }();
@@ -1502,15 +1557,21 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
             e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 256, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32>,
+            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
         if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     const int ntiles = B * (H / 8) * (W / 32);
     const int grid = dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W);
-    if (fused_bwd_block() == 0)
-        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream,
+    if (fused_bwd_block() == 0 && dm_backward_split_bf16())
+        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, true>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream,
+                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg());
+    else if (fused_bwd_block() == 0)
+        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, false>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream,
                            to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg());
     else if (fused_bwd_block() == 512)
         hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 512, true>), dim3(grid), dim3(512), G::LDS_BYTES, (hipStream_t)stream,

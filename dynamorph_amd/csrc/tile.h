@@ -66,6 +66,39 @@ typedef unsigned short dm_u16x2 __attribute__((ext_vector_type(2)));
 // whatever FMAs propagate from it) into +0.  Costs a compare + a select per value.
 __device__ __forceinline__ f32x4 relu_keep_nan(f32x4 v) { return dm_relu4(v); }
 
+// ---- split-bf16 operands (backward kernels) ------------------------------------------------------------------------------
+// A float v is stored in its own 4-byte slot as the pair (hi, lo) of bf16 values, hi = bf16(v) in the low half, lo =
+// bf16(v - hi) in the high half: v = hi + lo + r with |r| <= 2^-18 |v|.  Eight such slots (four registers of a lane) are
+// the A or B operand of one v_mfma_f32_16x16x32_bf16, whose 32 k-slots then are (hi, lo) of four K-steps of the f32
+// kernels; with P_a, P_b the packed operands,
+//     mfma(P_a, P_b) + mfma(rot16(P_a), P_b) = sum (a_hi + a_lo) (b_hi + b_lo)      (rot16 swaps hi and lo of every slot)
+// i.e. the fp32 product to ~2^-17 relative, in 2 x 16 cycles for four K-steps instead of 4 x 32 on the f32-input
+// instruction -- same LDS layouts, same lane mapping, same accumulator layout.  Used for GRADIENTS only (their consumers
+// are Adam and tests gated on the float64 yardstick); the forward pass, whose latents pick the codes, stays exact.
+__device__ __forceinline__ f32x4 split_pack4(f32x4 v)
+{
+    typedef __bf16 dm_bf16x2 __attribute__((ext_vector_type(2)));
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.x, v.y}, dm_bf16x2));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.z, v.w}, dm_bf16x2));
+    const float r0 = v.x - __builtin_bit_cast(float, h01 << 16), r1 = v.y - __builtin_bit_cast(float, h01 & 0xffff0000u);
+    const float r2 = v.z - __builtin_bit_cast(float, h23 << 16), r3 = v.w - __builtin_bit_cast(float, h23 & 0xffff0000u);
+    const unsigned l01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, dm_bf16x2));
+    const unsigned l23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r2, r3}, dm_bf16x2));
+    // (hi_i | lo_i << 16): bytes 0,1 of h, bytes 0,1 of l  /  bytes 2,3 of h, bytes 2,3 of l
+    const unsigned p0 = __builtin_amdgcn_perm(l01, h01, 0x05040100u), p1 = __builtin_amdgcn_perm(l01, h01, 0x07060302u);
+    const unsigned p2 = __builtin_amdgcn_perm(l23, h23, 0x05040100u), p3 = __builtin_amdgcn_perm(l23, h23, 0x07060302u);
+    typedef unsigned dm_u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, (dm_u32x4){p0, p1, p2, p3});
+}
+__device__ __forceinline__ float split_pack1(float v)
+{
+    typedef __bf16 dm_bf16x2 __attribute__((ext_vector_type(2)));
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v, 0.f}, dm_bf16x2)) & 0xffffu;
+    const float r = v - __builtin_bit_cast(float, h << 16);
+    const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r, 0.f}, dm_bf16x2)) & 0xffffu;
+    return __builtin_bit_cast(float, h | (l << 16));
+}
+
 // BLOCK: threads of the workgroup (256 everywhere except the fused backward kernel, conv_bwd_fused.hip: 512)
 template <int CIN, int ROWS, int COLS4, int RS, int PS, bool TWO, int BLOCK = DM_BLOCK>
 struct TileStage {
@@ -161,7 +194,7 @@ struct TileStage {
     // the physical channels.
     // One straight-line body per (KIND, ONES): the mode tests stay out of the element loop, so the coefficient reads
     // of a pass are requested together and the loop is a single basic block.
-    template <int KIND, bool ONES>
+    template <int KIND, bool ONES, bool SPLIT = false>
     __device__ __forceinline__ void commit_as(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
                                               int H, int W, int gy0, int gx0)
     {
@@ -192,6 +225,7 @@ struct TileStage {
                     const float one = in ? 1.f : 0.f;
                     if (step * G + cs >= Cphys) val = (f32x4){one, one, one, one};
                 }
+                if constexpr (SPLIT) val = split_pack4(val);       // (0 stays 0: the padding needs no special case)
                 if (CIN % G != 0 && step == NC - 1) {      // tail of the last channel step
                     if (cs < CIN - step * G) *reinterpret_cast<f32x4 *>(dst + step * G * PS) = val;
                 } else {
@@ -204,22 +238,24 @@ struct TileStage {
     // mode: the operand's load mode (workgroup uniform).  IDENT tiles skip the transform altogether (their padding is
     // already zero: elements outside the image were read as 0); RELU tiles only clamp; the AFFINE family takes the
     // per-channel coefficients from the LDS table.
+    // SPLIT: every value is stored as its (hi, lo) bf16 pair (split_pack4) for the split-bf16 matrix products
+    template <bool SPLIT = false>
     __device__ __forceinline__ void commit(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
                                            int H, int W, int gy0, int gx0, int mode)
     {
         if (CIN > 1 && Cphys < CIN) {                      // (uniform) with a synthetic ones channel: rare, one body
-            if (mode == DM_LOAD_IDENT) commit_as<0, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
-            else if (mode == DM_LOAD_RELU) commit_as<1, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
-            else if (mode == DM_LOAD_AFFINE_RELU) commit_as<3, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
-            else commit_as<2, true>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            if (mode == DM_LOAD_IDENT) commit_as<0, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else if (mode == DM_LOAD_RELU) commit_as<1, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else if (mode == DM_LOAD_AFFINE_RELU) commit_as<3, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else commit_as<2, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_IDENT) {
-            commit_as<0, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<0, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_RELU) {
-            commit_as<1, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<1, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_AFFINE_RELU) {
-            commit_as<3, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<3, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else {
-            commit_as<2, false>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<2, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         }
     }
 };

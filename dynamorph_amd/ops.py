@@ -286,6 +286,14 @@ def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
     return dst
 
 
+def backward_precision(mode=None):
+    """Arithmetic of the backward matrix products: "split-bf16" (default) or "f32" (include/dynamorph_hip.h,
+    dm_backward_precision).  mode None: query.  Returns the previous setting."""
+    names = ("f32", "split-bf16")
+    prev = L.load().dm_backward_precision(-1 if mode is None else names.index(mode))
+    return names[prev]
+
+
 def conv_bwd_s2_fused_supported(CD, CX, H, W):
     return bool(L.load().dm_conv_bwd_s2_fused_supported(CD, CX, H, W))
 

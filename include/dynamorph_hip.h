@@ -208,6 +208,13 @@ int64_t dm_conv3x3_scratch_floats(int CIN, int NOUT, int H, int W, int taps, int
  *   w_slabs out: num_blocks slabs of CD*CX*16 floats, each in the weight's own layout; dm_reduce_slabs(_multi) adds them
  * Built for CD = 16, CX = 8, H % 8 == 0, W % 32 == 0 (dm_conv_bwd_s2_fused_supported); batch-statistics coefficients
  * (coef_bstride = 0) only. */
+/* Arithmetic of the backward matrix products (gradients only; the forward pass is always exact fp32):
+ *   1  split-bf16 operands: every fp32 value as a (bf16 head, bf16 remainder) pair, four products per pair on the bf16
+ *      matrix instruction -- the fp32 product to ~2^-17 relative, a quarter of the matrix time (default);
+ *   0  the f32-input matrix instruction: bit for bit the fp32 multiply-add chain.
+ * Process-wide.  mode 0 / 1 sets it, any other value only queries; returns the previous setting.  DM_BACKWARD_PRECISION=f32
+ * in the environment starts with 0. */
+int dm_backward_precision(int mode);
 int dm_conv_bwd_s2_fused_supported(int CD, int CX, int H, int W);
 int dm_conv_bwd_s2_fused_num_blocks(int B, int CD, int CX, int H, int W);
 int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *in, const dm_weight_view *w, float *dx,

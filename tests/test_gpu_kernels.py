@@ -1204,6 +1204,7 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     statistics -- against torch autograd, and against the two kernels it replaces (the data gradient bit for bit: same
     MFMA order; the weight gradient to summation order).  B = 300: more tiles than workgroups (persistent loop)."""
     CD, CX, H, W = 16, 8, hw, hw
+    prev = ops.backward_precision("f32")                     # (the bit-for-bit comparisons below; restored at the end)
     dy, a_out = rnd(B, CD, H, W, seed=1), rnd(B, CD, H, W, seed=2)
     coefD = torch.stack([rnd(CD, seed=3), rnd(CD, seed=4) * 0.1, rnd(CD, seed=5) * 0.1, torch.zeros(CD)], 1)
     a_in = rnd(B, CX, 2 * H, 2 * W, seed=6)
@@ -1240,3 +1241,20 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     with pytest.raises(ValueError, match="layer input"):       # a mask that is not the layer input is refused on the host
         ops.conv_bwd_s2_fused(dyop(), ops.Op(aid, 3, cTd), ops.weight_view(wd, 16, CX * 16, 4, 1), dstb, B, CD, CX, H, W,
                               mask=ops.Op(aid.clone(), 2, cTd))
+    # split-bf16 operands (the default of the backward pass): the same gradients to ~2^-17 of the products' magnitude
+    assert ops.backward_precision("split-bf16") == "f32"
+    dsts = torch.empty_like(dst)
+    dxs, sts = run(dsts)
+    mag_dx = F.conv_transpose2d(da.abs(), w.abs(), None, stride=2, padding=1)       # sum |da| |w| per output element
+    err = (dxs.cpu() - dx_ref).abs()
+    assert bool((err <= 2e-5 * mag_dx + 1e-30).all()), float((err / (mag_dx + 1e-30)).max())
+    xa = t_in.abs().requires_grad_(True)
+    wa = w.abs().clone().requires_grad_(True)
+    F.conv2d(xa, wa, None, stride=2, padding=1).backward(da.abs())
+    errw = (dsts.cpu() - wt.grad).abs()
+    assert bool((errw <= 2e-5 * wa.grad + 1e-30).all()), float((errw / (wa.grad + 1e-30)).max())
+    close(sts.sum(0), st.sum(0), 3e-5, 3e-5 * float(st.sum(0).abs().max()), "statistics under split-bf16")
+    dsts2 = torch.empty_like(dst)
+    dxs2, sts2 = run(dsts2)
+    assert torch.equal(dsts, dsts2) and torch.equal(dxs, dxs2)         # still reproducible to the bit
+    ops.backward_precision(prev)
