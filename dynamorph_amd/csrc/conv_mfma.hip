@@ -1088,24 +1088,6 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
         EpiCtx<SIDE_MASK> cx;
         const long long sample_elems = (long long)CX * OH * OW;
         const int chan_off = (co * OH * OW + 8 * kq + 4 * pxl) * 4;
-        // The mask / statistics partner of every output quad (the layer input at the output positions) is requested one TILE
-        // ahead: with the products on the bf16 pipe a group of 48 of them is shorter than a trip to L2, and eight such waits
-        // per tile were the data-gradient waves' time (155 of 216 us).
-        constexpr int NG = NPASS * 2 * MP;                  // output quads per lane and tile
-        auto quad_offset = [&](int g, int ty0, int tx0) {  // g = (pass, py, i)
-            const int i = g % MP, py = (g / MP) & 1, pass = g / (2 * MP);
-            const int ti = rw + RW * (MP * pass + i);
-            const int r = ti / CGN, cg = ti % CGN;
-            return chan_off + ((2 * (ty0 + r) + py) * OW + 2 * (tx0 + 16 * cg)) * 4;
-        };
-        EpiIn<SIDE_MASK> em[NG], emn[NG];
-        {
-            int fb, fy0, fx0;
-            coords(tidx < ntiles ? tidx : 0, fb, fy0, fx0);
-            cx.rebase(ep, dx, sample_elems, fb);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) epilogue_loads<SIDE_MASK>(em[g], cx, tidx < ntiles ? quad_offset(g, fy0, fx0) : DM_VOFF_NONE);
-        }
         __syncthreads();                                    // (coefficient tables)
         __syncthreads();                                    // tile 0 in buffer 0
         int p = 0;
@@ -1113,14 +1095,6 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
             int cb, cy0, cx0;
             coords(tidx, cb, cy0, cx0);
             const float *cur = fb_lds + p * BUF;
-            {
-                const int next = tidx + gridDim.x;
-                int nb, ny0, nx0;
-                coords(next < ntiles ? next : tidx, nb, ny0, nx0);
-                cx.rebase(ep, dx, sample_elems, nb);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) epilogue_loads<SIDE_MASK>(emn[g], cx, next < ntiles ? quad_offset(g, ny0, nx0) : DM_VOFF_NONE);
-            }
             cx.rebase(ep, dx, sample_elems, cb);
             if (!(dbg & 2)) {
 #pragma unroll
@@ -1136,6 +1110,9 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                 }
 #pragma unroll
                 for (int py = 0; py < 2; ++py) {
+                    EpiIn<SIDE_MASK> e[MP];
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) epilogue_loads<SIDE_MASK>(e[i], cx, obase[i] + py * OW * 4);
                     f32x4 acc[MP][1];
 #pragma unroll
                     for (int i = 0; i < MP; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1150,13 +1127,11 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                         const f32x4 v = acc[i][0];
                         const f32x4 pv = lane_xor8(v);
                         epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y}, ep, cx,
-                                                 em[(pass * 2 + py) * MP + i], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
+                                                 e[i], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
                     }
                 }
             }
             }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) em[g] = emn[g];
             __syncthreads();
             p ^= 1;
             tidx += gridDim.x;
