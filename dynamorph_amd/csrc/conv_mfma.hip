@@ -45,6 +45,9 @@ long long dm_wide_conv_scratch_floats(int form, int CIN, int NOUT, int taps);
 int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scratch, float *out, const Epilogue &ep, int B,
                  int Cphys, int CIN, int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st);
 
+// arithmetic of the gradient kernels (defined with the C ABI at the end of this file; also used by wgrad_mfma.hip)
+bool dm_backward_split_bf16();
+
 namespace {
 
 // ----------------------------------------------------------------------------- epilogue
@@ -183,7 +186,8 @@ __device__ __forceinline__ void zero_unowned_slabs(const Epilogue &ep, int NCH, 
 // ============================================================================ kernel A
 // BB: per-position bias from ep.bias_border[3][3][NOUT] (first / interior / last output row x column) instead of
 // ep.bias -- the enc.0 bias seen through enc.1's zero padding, so the first conv needs no ones channel (K = 32, not 48).
-template <int CIN, int NT, int TH, int TW, int SIDE, int WPS, bool BB>
+// BF (gradients only: kernels with side inputs or the BatchNorm-backward operand): split-bf16 operands, tile.h
+template <int CIN, int NT, int TH, int TW, int SIDE, int WPS, bool BB, bool BF = false>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
                       int W, int ntiles, int nslabs, int per_tile)
@@ -229,6 +233,10 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             wreg[t][s] = n < NOUT ? wv.w[wv.off + n * wv.sn + (s >> 2) * wv.sc + (s & 3) * wv.sky + kq * wv.skx] : 0.f;
+        if constexpr (BF) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wreg[t][s] = split_pack1(wreg[t][s]);
+        }
     }
 
     double s1[NT], s2[NT];
@@ -243,7 +251,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
     for (int t = 0; t < NT; ++t) chan_off[t] = 16 * t + m < NOUT ? ((16 * t + m) * Ho * Wo + 4 * kq) * 4 : DM_VOFF_NONE;
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile consumed; coefficient table visible
-        stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4, in.mode);
+        stage.template commit<BF>(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4, in.mode);
         __syncthreads();
         const int cb = b, cy0 = oy0, cx0 = ox0;            // the tile now in LDS
         const int next = tidx + gridDim.x;
@@ -287,7 +295,8 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
             for (int i = 0; i < MP; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mfma_tiles<MP, NT, KS, 4>(ap, wreg, acc, off);
+            if constexpr (BF) mfma_tiles_split<MP, NT, KS>(ap, wreg, acc, off);
+            else mfma_tiles<MP, NT, KS, 4>(ap, wreg, acc, off);
 #pragma unroll
             for (int i = 0; i < MP; ++i)
 #pragma unroll
@@ -325,7 +334,7 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
 }
 
 // ============================================================================ kernel B
-template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO, int SIDE, int WPS>
+template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO, int SIDE, int WPS, bool BF = false>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int NOUT, int H,
                     int W, int ntiles, int nslabs, int per_tile)
@@ -399,7 +408,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                         wvl = wv.w[wv.off + n * wv.sn + c * wv.sc + tyy * wv.sky + txx * wv.skx];
                     }
                 }
-                wreg[t][s] = wvl;
+                wreg[t][s] = BF ? split_pack1(wvl) : wvl;
             }
         }
 
@@ -417,7 +426,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
 
         while (tidx < ntiles) {
             __syncthreads();
-            stage.commit(tile, s_coef, Cphys, H, W, y0 - PADR, x0 - 4 * PADR, in.mode);
+            stage.template commit<BF>(tile, s_coef, Cphys, H, W, y0 - PADR, x0 - 4 * PADR, in.mode);
             __syncthreads();
             const int cb = b, cy0 = y0, cx0 = x0;
             const int next = tidx + gridDim.x;
@@ -465,7 +474,8 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
                 for (int i = 0; i < MP; ++i)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                mfma_tiles<MP, NT, KS, (TAPS == 9 ? 3 : 4)>(ap, wreg, acc, off);
+                if constexpr (BF) mfma_tiles_split<MP, NT, KS>(ap, wreg, acc, off);
+                else mfma_tiles<MP, NT, KS, (TAPS == 9 ? 3 : 4)>(ap, wreg, acc, off);
 #pragma unroll
                 for (int i = 0; i < MP; ++i)
 #pragma unroll
@@ -506,7 +516,7 @@ void conv3x3_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue
 // not matrix-pipe time -- and these kernels are matrix-pipe bound (60-70 % busy).
 // Output: the two x phases of a row are interleaved in registers (COUT = 16: both live in the lane, two 16-byte
 // stores per row; COUT = 8: lanes m and m^8 swap halves, one store), so stores stay 16 contiguous bytes per lane.
-template <int CIN, int COUT, int TH, int TW, bool TWO, int SIDE, int WPS>
+template <int CIN, int COUT, int TH, int TW, bool TWO, int SIDE, int WPS, bool BF = false>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
 void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int H, int W,
                         int ntiles, int nslabs)
@@ -556,7 +566,7 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
                 const int ky = py + 3 - 2 * row, kx = px + 3 - 2 * col;
                 float wvl = 0.f;
                 if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
-                wreg[py][pxt][0][s] = wvl;
+                wreg[py][pxt][0][s] = BF ? split_pack1(wvl) : wvl;
             }
     const float bias = ep.bias ? ep.bias[co] : 0.f;
     float mc0, mc2;
@@ -571,7 +581,7 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
 
     while (tidx < ntiles) {
         __syncthreads();
-        stage.commit(tile, s_coef, Cphys, H, W, y0 - 1, x0 - 4, in.mode);
+        stage.template commit<BF>(tile, s_coef, Cphys, H, W, y0 - 1, x0 - 4, in.mode);
         __syncthreads();
         const int cb = b, cy0 = y0, cx0 = x0;
         const int next = tidx + gridDim.x;
@@ -617,7 +627,8 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
                         const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
                         return 4 * cg4 * PS + (py + a) * RS + (COUT == 16 ? pxt + bb : bb);
                     };
-                    mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py][pxt], acc[pxt], off);
+                    if constexpr (BF) mfma_tiles_split<MP, 1, KS>(ap, wreg[py][pxt], acc[pxt], off);
+                    else mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py][pxt], acc[pxt], off);
                 }
 #pragma unroll
                 for (int i = 0; i < MP; ++i) {
@@ -1224,6 +1235,11 @@ void launch_conv4(const ConvArgs &a)
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
                                a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
                                a.per_tile);                                                                           \
+        else if (SIDE_ != SIDE_NONE && dm_backward_split_bf16())        /* a data gradient: split-bf16 operands */ \
+            hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS, false, SIDE_ != SIDE_NONE>),             \
+                               dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
+                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
+                               a.per_tile);                                                                           \
         else                                                                                                      \
             hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS, false>),                                 \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
@@ -1261,6 +1277,12 @@ void launch_conv3(const ConvArgs &a)
 #define DM_L3(TWO_, SIDE_)                                                                                        \
     {                                                                                                             \
         constexpr int WPS = conv_wps(LDS, NT * (CIN / 4) * TAPS, F4, TWO_, NT == 1 ? 2 : 1, NT, SIDE_);          \
+        constexpr bool GRAD = (TWO_ || SIDE_ != SIDE_NONE) && ((CIN / 4) * TAPS) % 4 == 0;   /* a data gradient */      \
+        if (GRAD && dm_backward_split_bf16())                                                                     \
+            hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS, GRAD>),           \
+                               dim3(conv_grid(ntiles, WPS, a.per_tile, NPASS)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
+                               a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile), a.per_tile); \
+        else                                                                                                      \
         hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS>),                 \
                            dim3(conv_grid(ntiles, WPS, a.per_tile, NPASS)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
                            a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile), a.per_tile); \
@@ -1286,6 +1308,12 @@ void launch_convT_phase(const ConvArgs &a)
 #define DM_LP(TWO_, SIDE_)                                                                                        \
     {                                                                                                             \
         constexpr int WPS = clampi(conv_wps(LDS, KSW, F4, TWO_, 2, COUT == 16 ? 2 : 1, SIDE_), 1, 2);             \
+        constexpr bool GRAD = TWO_ || SIDE_ != SIDE_NONE;                  /* a data gradient */                     \
+        if (GRAD && dm_backward_split_bf16())                                                                     \
+            hipLaunchKernelGGL((convT_phase_kernel<CIN, COUT, TH, TW, TWO_, SIDE_, WPS, GRAD>),                       \
+                               dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
+                               a.out, a.ep, a.Cphys, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));               \
+        else                                                                                                      \
         hipLaunchKernelGGL((convT_phase_kernel<CIN, COUT, TH, TW, TWO_, SIDE_, WPS>),                             \
                            dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
                            a.out, a.ep, a.Cphys, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));               \

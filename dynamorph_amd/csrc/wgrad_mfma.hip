@@ -17,6 +17,9 @@
 // order -> bitwise reproducible, no float atomics.
 #include "dm_common.h"
 #include "tile.h"
+#include "mfma_util.h"
+
+bool dm_backward_split_bf16();         // conv_mfma.hip: arithmetic of the gradient kernels (dm_backward_precision)
 
 // fallback for shapes / channel families without an MFMA instantiation (conv_generic.hip)
 int dm_generic_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int CTphys, int Hs, int Ws,
@@ -31,7 +34,8 @@ namespace {
 
 constexpr int WG_MAX_BLOCKS = 512;     // 2 workgroups per CU
 
-template <int CS, int CT, int KK, int TH, int TW, bool STWO>
+// BF: split-bf16 operands (tile.h: both tiles hold (hi, lo) bf16 pairs; four position steps per instruction pair).
+template <int CS, int CT, int KK, int TH, int TW, bool STWO, bool BF = false>
 __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, float *__restrict__ slabs,
                                                          int CTphys, int Hs, int Ws, int ntiles)
 {
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
     }
     while (tile < ntiles) {
         __syncthreads();                             // previous tile fully consumed; coefficient tables visible
-        stS.commit(sS, s_coefS, CS, Hs, Ws, cy0, cx0, S.mode);
-        stT.commit(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD, T.mode);
+        stS.template commit<BF>(sS, s_coefS, CS, Hs, Ws, cy0, cx0, S.mode);
+        stT.template commit<BF>(sT, s_coefT, CTphys, Ht, Wt, cy0 * STRIDE - PAD, cx0 * STRIDE - 4 * PAD, T.mode);
         __syncthreads();
         const int next = tile + gridDim.x;
         const int pb = cb;                               // sample of the tile now in LDS
@@ -117,6 +121,68 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
         if (recoefT) cfT = coef_fetch(T, cb, CTphys);
         constexpr int NES = decltype(stS)::N, NET = decltype(stT)::N, NE = NES + NET;
         constexpr int ROWS_W = TH / 4, NSTEPS = ROWS_W * (TW / 4);
+        if constexpr (BF) {
+            // quads of position steps: four 4-byte reads per operand tile and quad (the lane's element of steps 4q .. 4q+3)
+            // make one operand of v_mfma_f32_16x16x32_bf16; operands of quad q+1 requested before the products of quad q
+            static_assert((TW / 4) % 4 == 0, "position steps of a row in quads");
+            constexpr int QR = TW / 16, NQ = ROWS_W * QR;         // quads per row, per wave and tile
+            auto qoffA = [&](int q) { return (wave + 4 * (q / QR)) * RSS + 16 * (q % QR); };
+            auto qoffB = [&](int q) { return (wave + 4 * (q / QR)) * STRIDE * RST + 16 * (q % QR) * STRIDE; };
+            // units of (quad, group of GT N tiles): the B operands of the next unit (and, at a new quad, its A operands)
+            // are requested before the products of this one -- 16 registers of B in flight whatever NTT is
+            constexpr int GT = NTT < 4 ? NTT : 4, NGRP = (NTT + GT - 1) / GT, NU = NQ * NGRP;
+            float a[2][MT][4], bv[2][GT][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[0][i][j] = sS[aoff[i] + qoffA(0) + 4 * j];
+#pragma unroll
+                for (int t = 0; t < GT; ++t) bv[0][t][j] = sT[boff[t] + qoffB(0) + 4 * j * STRIDE];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int q = u / NGRP, grp = u % NGRP;
+                if (u + 1 < NU) {
+                    const int q1 = (u + 1) / NGRP, g1 = (u + 1) % NGRP;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (g1 == 0) {
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) a[q1 & 1][i][j] = sS[aoff[i] + qoffA(q1) + 4 * j];
+                        }
+#pragma unroll
+                        for (int t = 0; t < GT; ++t)
+                            if (g1 * GT + t < NTT) bv[(u + 1) & 1][t][j] = sT[boff[g1 * GT + t] + qoffB(q1) + 4 * j * STRIDE];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    if (e >= u * NE / NU && e < (u + 1) * NE / NU) {
+                        if (e < NES) stS.issue_one(e, cxS);
+                        else stT.issue_one(e - NES, cxT);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                dm_u32x4_t a4[MT], ar[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float(&x)[4] = a[q & 1][i];
+                    a4[i] = (dm_u32x4_t){__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]),
+                                         __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
+                    ar[i] = dm_rot16(a4[i]);
+                }
+#pragma unroll
+                for (int t = 0; t < GT; ++t) {
+                    if (grp * GT + t < NTT) {
+                        const float(&y)[4] = bv[u & 1][t];
+                        const dm_u32x4_t b4 = {__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]),
+                                               __builtin_bit_cast(unsigned, y[2]), __builtin_bit_cast(unsigned, y[3])};
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i][grp * GT + t] = dm_mfma_split(a4[i], ar[i], b4, acc[i][grp * GT + t]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int ri = 0; ri < ROWS_W; ++ri) {
             const int r = wave + 4 * ri;
@@ -154,6 +220,7 @@ __global__ __launch_bounds__(DM_BLOCK) void wgrad_kernel(Operand S, Operand T, f
                         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x4 & 1][i], bv[x4 & 1][t], acc[i][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         if (recoefS) coef_put(s_coefS, S, cfS, CS);
         if (recoefT) coef_put(s_coefT, T, cfT, CTphys);
@@ -441,6 +508,16 @@ void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
         else
             hipLaunchKernelGGL((wgrad_ys_kernel<CT, TH, TW, false>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs, CTphys,
                                Hs, Ws, ntiles);
+        return;
+    }
+    constexpr bool CAN_BF = (TW / 4) % 4 == 0;             // position steps of a row in quads
+    if (CAN_BF && dm_backward_split_bf16()) {
+        if (S.mode == DM_LOAD_AFFINE2)
+            hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW, true, CAN_BF>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs,
+                               CTphys, Hs, Ws, ntiles);
+        else
+            hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW, false, CAN_BF>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs,
+                               CTphys, Hs, Ws, ntiles);
         return;
     }
     if (S.mode == DM_LOAD_AFFINE2)

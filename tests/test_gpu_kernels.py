@@ -23,6 +23,16 @@ def ops():
     return o
 
 
+@pytest.fixture(autouse=True)
+def exact_backward_products(request, ops):
+    """The kernel tests pin the ARITHMETIC: gradient kernels on the f32-input matrix instruction (bit for bit the fp32
+    chain, tolerances of a few 1e-5) unless a test asks for the default split-bf16 operands itself
+    (@pytest.mark.split_bf16 or ops.backward_precision inside the test).  The model-level tests run the default."""
+    prev = ops.backward_precision(None if request.node.get_closest_marker("split_bf16") else "f32")
+    yield
+    ops.backward_precision(prev)
+
+
 @pytest.fixture(scope="module")
 def cvq():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
@@ -1258,3 +1268,71 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     dxs2, sts2 = run(dsts2)
     assert torch.equal(dsts, dsts2) and torch.equal(dxs, dxs2)         # still reproducible to the bit
     ops.backward_precision(prev)
+
+
+@pytest.mark.split_bf16
+@pytest.mark.parametrize("cs,ct,k,hs,B", [(16, 8, 4, 32, 5), (16, 16, 4, 16, 9), (16, 16, 3, 16, 7), (32, 16, 3, 16, 7), (16, 32, 1, 16, 7),
+                                          (8, 4, 4, 32, 3), (4, 4, 4, 64, 3)])
+def test_wgrad_split_bf16(ops, cs, ct, k, hs, B):
+    """Weight gradients with split-bf16 operands (the default of the backward pass): every element within 2e-5 of the sum of
+    the products' magnitudes (2^-17 per product plus the fp32 accumulation), reproducible to the bit."""
+    assert ops.backward_precision() == "split-bf16"
+    stride, pad = (2, 1) if k == 4 else (1, k // 2)
+    S = rnd(B, cs, hs, hs, seed=1)
+    T = rnd(B, ct, hs * stride, hs * stride, seed=2)
+    t = T.clone().requires_grad_(True)
+    w = torch.zeros(cs, ct, k, k, requires_grad=True)
+    F.conv2d(t, w, None, stride=stride, padding=pad).backward(S)
+    wm = torch.zeros(cs, ct, k, k, requires_grad=True)
+    F.conv2d(T.abs(), wm, None, stride=stride, padding=pad).backward(S.abs())
+    dst, dst2 = torch.empty(cs, ct, k, k, device=DEV), torch.empty(cs, ct, k, k, device=DEV)
+    Sd, Td = S.to(DEV), T.to(DEV)
+    ops.wgrad(ops.Op(Sd), ops.Op(Td), dst, B, cs, ct, hs, hs, k)
+    ops.wgrad(ops.Op(Sd), ops.Op(Td), dst2, B, cs, ct, hs, hs, k)
+    err = (dst.cpu() - w.grad).abs()
+    assert bool((err <= 2e-5 * wm.grad + 1e-30).all()), float((err / (wm.grad + 1e-30)).max())
+    assert float((err / (wm.grad + 1e-30)).max()) > 1e-8          # (it IS the split path: the f32 chain is ~1e-7 here)
+    assert torch.equal(dst, dst2)
+
+
+@pytest.mark.split_bf16
+def test_data_gradients_split_bf16(ops):
+    """The data-gradient kernels with split-bf16 operands: 3x3 / 1x1 (BatchNorm-backward operand, mask, residual join),
+    the phase-decomposed transposed convolution (enc.7) and the 4x4/s2 form (decoder), each within 2e-5 of the products'
+    magnitude sum of the float64 result."""
+    def gate(out, ref, mag, what):
+        err = (out.detach().cpu().double() - ref.double()).abs()
+        assert bool((err <= 2e-5 * mag.double() + 1e-30).all()), (what, float((err / (mag.double() + 1e-30)).max()))
+    B, ci, co, h = 3, 16, 32, 16
+    w = rnd(co, ci, 3, 3, seed=1, scale=0.2)
+    dy, a = rnd(B, co, h, h, seed=2), rnd(B, co, h, h, seed=3)
+    coef = torch.stack([rnd(co, seed=4), rnd(co, seed=5) * 0.1, rnd(co, seed=6) * 0.1, torch.zeros(co)], 1)
+    prev = rnd(B, ci, h, h, seed=7)
+    resid = rnd(B, ci, h, h, seed=10)
+    da = load_ref(dy, 4, coef, a)
+    ref = F.conv_transpose2d(da.double(), w.double(), None, padding=1) * (prev > 0) + resid
+    mag = F.conv_transpose2d(da.abs(), w.abs(), None, padding=1) + resid.abs()
+    out, _ = ops.conv3x3(ops.Op(dy.to(DEV), 4, coef.to(DEV), p1=a.to(DEV)), ops.weight_view(w.to(DEV), 9, ci * 9, -3, -1, off=8),
+                         B, co, ci, h, h, taps=9, want_stats=True, mask=ops.Op(prev.to(DEV)), resid=resid.to(DEV), stat_q=prev.to(DEV))
+    gate(out, ref, mag, "3x3 data gradient")
+    # enc.7-like: Conv2d(16 -> 16, 4, 2, 1) data gradient = transposed convolution by phase, AFFINE2 operand, AFFINE mask
+    wt = rnd(16, 16, 4, 4, seed=11, scale=0.2)
+    dy7, a7 = rnd(B, 16, 16, 16, seed=12), rnd(B, 16, 16, 16, seed=13)
+    cf7 = torch.stack([rnd(16, seed=14), rnd(16, seed=15) * 0.1, rnd(16, seed=16) * 0.1, torch.zeros(16)], 1)
+    ain = rnd(B, 16, 32, 32, seed=17)
+    mc = torch.stack([rnd(16, seed=18).abs() + 0.5, torch.zeros(16), rnd(16, seed=19) * 0.2, torch.zeros(16)], 1)
+    da7 = load_ref(dy7, 4, cf7, a7)
+    ref7 = F.conv_transpose2d(da7.double(), wt.double(), None, stride=2, padding=1) * (load_ref(ain, 2, mc) > 0)
+    mag7 = F.conv_transpose2d(da7.abs(), wt.abs(), None, stride=2, padding=1)
+    out7, _ = ops.conv3x3(ops.Op(dy7.to(DEV), 4, cf7.to(DEV), p1=a7.to(DEV)), ops.weight_view(wt.to(DEV), 16, 16 * 16, 4, 1), B, 16, 64,
+                          16, 16, taps=9, pixel_shuffle=True, want_stats=True, mask=ops.Op(ain.to(DEV), 2, mc.to(DEV)), stat_q=ain.to(DEV))
+    gate(out7, ref7, mag7, "transposed convolution by phase")
+    # decoder-like: data gradient of ConvTranspose2d(8 -> 4) = 4x4/s2 convolution over g with a ReLU mask
+    wd = rnd(8, 4, 4, 4, seed=21, scale=0.2)
+    g = rnd(B, 4, 64, 64, seed=22)
+    act = rnd(B, 8, 32, 32, seed=23)
+    refd = F.conv2d(g.double(), wd.double(), None, stride=2, padding=1) * (act > 0)
+    magd = F.conv2d(g.abs(), wd.abs(), None, stride=2, padding=1)
+    outd, _ = ops.conv4x4s2(ops.Op(g.to(DEV)), ops.weight_view(wd.to(DEV), 4 * 16, 16, 4, 1), B, 4, 8, 64, 64, want_stats=True,
+                            mask=ops.Op(act.to(DEV)))
+    gate(outd, refd, magd, "4x4/s2 data gradient")
