@@ -348,6 +348,32 @@ def c2_record(model, steps=50, warmup=3, B=1024):
             "unit": "patches/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "hip_graph": True}
 
 
+def split_bf16_record(x, B, args, steps=100, warmup=10):
+    """The same C3 step with the OPT-IN gradient arithmetic (include/dynamorph_hip.h, dm_backward_precision(1): fp32
+    operands of the backward matrix products as bf16 head + remainder pairs on the bf16 matrix instruction, ~2^-17 relative
+    per product; forward pass, codes and losses unchanged).  A sub-record: `value` above is the exact-fp32 default."""
+    from dynamorph_amd import VQ_VAE, ops
+    from dynamorph_amd.train import FusedTrainer
+    prev = ops.backward_precision("split-bf16")
+    try:
+        torch.manual_seed(0)
+        tr = FusedTrainer(VQ_VAE().to(x.device), lr=1e-4, use_graph=not args.no_graph)
+        for _ in range(warmup):
+            out = tr.step(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = tr.step(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        ops.backward_precision(prev)
+    return {"value": round(B * steps / dt, 1), "unit": "patches/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+            "backward_products": "split-bf16", "total_loss_after": round(float(out[2]), 6),
+            "note": "opt-in (DM_BACKWARD_PRECISION=split): gradients within ~1e-5 of their products' magnitude of the fp32 "
+                    "chain; not the headline value"}
+
+
 def _host_cpu():
     """(model name, physical cores) of the host from lscpu; falls back to os.cpu_count() // 2."""
     import subprocess
@@ -439,6 +465,7 @@ def main():
     from dynamorph_amd import VQ_VAE
     from dynamorph_amd import dist as D
     from dynamorph_amd import engine as E
+    from dynamorph_amd import ops
     from dynamorph_amd.train import FusedTrainer
 
     rank, world, local = D.init_from_env()
@@ -555,10 +582,11 @@ def main():
         roof = roofline_vq_large_codebook(model, x)
     else:
         roof = roofline_dominant_kernel(model, x, args.workload)
-    targets = c2 = None
+    targets = c2 = split = None
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_targets:
         targets = north_star_targets(model, x)
         c2 = c2_record(model)
+        split = split_bf16_record(x, B, args)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload)
@@ -582,7 +610,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hip_graph": (not args.no_graph) if (args.workload in ("c3", "c2", "c5") or trainer is not None) else False,
-                       "fused_trainer": trainer is not None},
+                       "fused_trainer": trainer is not None,
+                       "backward_products": ops.backward_precision()},
             "roofline": roof,
             "cpu_baseline": cpu,
             "collective": collective,
@@ -590,6 +619,7 @@ def main():
         if targets is not None:
             line["targets"] = targets
             line["c2"] = c2
+            line["split_bf16_backward"] = split
         if losses is not None:
             line["final_losses"] = dict(zip(("recon", "commitment", "total", "perplexity"), [round(v, 6) for v in losses]))
         print(json.dumps(line), flush=True)

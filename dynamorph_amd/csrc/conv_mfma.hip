@@ -1530,13 +1530,14 @@ static int fused_bwd_block()
     return v;
 }
 
-// Arithmetic of the BACKWARD matrix products (data and weight gradients): 1 = split-bf16 operands (tile.h: ~2^-17 relative
-// per product, a quarter of the matrix time; the default), 0 = the f32-input instruction (bit for bit the fp32 chain).
-// Process-wide; DM_BACKWARD_PRECISION=f32 in the environment starts with 0; dm_backward_precision(mode >= 0) sets it.
+// Arithmetic of the BACKWARD matrix products (data and weight gradients): 0 = the f32-input instruction, bit for bit the
+// fp32 multiply-add chain (the default: every number the library produces by default is plain fp32 arithmetic);
+// 1 = split-bf16 operands (tile.h: ~2^-17 relative per product, a quarter of the matrix time) -- opt-in.
+// Process-wide; DM_BACKWARD_PRECISION=split in the environment starts with 1; dm_backward_precision(mode >= 0) sets it.
 static int g_backward_split = -1;
 bool dm_backward_split_bf16()
 {
-    if (g_backward_split < 0) { const char *e = getenv("DM_BACKWARD_PRECISION"); g_backward_split = (e && e[0] == 'f') ? 0 : 1; }
+    if (g_backward_split < 0) { const char *e = getenv("DM_BACKWARD_PRECISION"); g_backward_split = (e && e[0] == 's') ? 1 : 0; }
     return g_backward_split != 0;
 }
 extern "C" int dm_backward_precision(int mode)

@@ -287,8 +287,9 @@ def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
 
 
 def backward_precision(mode=None):
-    """Arithmetic of the backward matrix products: "split-bf16" (default) or "f32" (include/dynamorph_hip.h,
-    dm_backward_precision).  mode None: query.  Returns the previous setting."""
+    """Arithmetic of the backward matrix products: "f32" (default: the exact fp32 chain) or "split-bf16" (opt-in: fp32
+    values as bf16 head + remainder pairs on the bf16 matrix instruction, ~2^-17 relative per product) --
+    include/dynamorph_hip.h, dm_backward_precision.  mode None: query.  Returns the previous setting."""
     names = ("f32", "split-bf16")
     prev = L.load().dm_backward_precision(-1 if mode is None else names.index(mode))
     return names[prev]

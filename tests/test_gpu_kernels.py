@@ -24,11 +24,10 @@ def ops():
 
 
 @pytest.fixture(autouse=True)
-def exact_backward_products(request, ops):
-    """The kernel tests pin the ARITHMETIC: gradient kernels on the f32-input matrix instruction (bit for bit the fp32
-    chain, tolerances of a few 1e-5) unless a test asks for the default split-bf16 operands itself
-    (@pytest.mark.split_bf16 or ops.backward_precision inside the test).  The model-level tests run the default."""
-    prev = ops.backward_precision(None if request.node.get_closest_marker("split_bf16") else "f32")
+def backward_products(request, ops):
+    """The gradient kernels run on the f32-input matrix instruction by default (bit for bit the fp32 chain: tolerances of a
+    few 1e-5 below); tests marked split_bf16 run them with the opt-in split-bf16 operands."""
+    prev = ops.backward_precision("split-bf16" if request.node.get_closest_marker("split_bf16") else "f32")
     yield
     ops.backward_precision(prev)
 
@@ -1214,7 +1213,7 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     statistics -- against torch autograd, and against the two kernels it replaces (the data gradient bit for bit: same
     MFMA order; the weight gradient to summation order).  B = 300: more tiles than workgroups (persistent loop)."""
     CD, CX, H, W = 16, 8, hw, hw
-    prev = ops.backward_precision("f32")                     # (the bit-for-bit comparisons below; restored at the end)
+    prev = ops.backward_precision("f32")                     # (the bit-for-bit comparisons below)
     dy, a_out = rnd(B, CD, H, W, seed=1), rnd(B, CD, H, W, seed=2)
     coefD = torch.stack([rnd(CD, seed=3), rnd(CD, seed=4) * 0.1, rnd(CD, seed=5) * 0.1, torch.zeros(CD)], 1)
     a_in = rnd(B, CX, 2 * H, 2 * W, seed=6)
@@ -1251,7 +1250,7 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     with pytest.raises(ValueError, match="layer input"):       # a mask that is not the layer input is refused on the host
         ops.conv_bwd_s2_fused(dyop(), ops.Op(aid, 3, cTd), ops.weight_view(wd, 16, CX * 16, 4, 1), dstb, B, CD, CX, H, W,
                               mask=ops.Op(aid.clone(), 2, cTd))
-    # split-bf16 operands (the default of the backward pass): the same gradients to ~2^-17 of the products' magnitude
+    # split-bf16 operands (opt-in): the same gradients to ~2^-17 of the products' magnitude
     assert ops.backward_precision("split-bf16") == "f32"
     dsts = torch.empty_like(dst)
     dxs, sts = run(dsts)
@@ -1274,7 +1273,7 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
 @pytest.mark.parametrize("cs,ct,k,hs,B", [(16, 8, 4, 32, 5), (16, 16, 4, 16, 9), (16, 16, 3, 16, 7), (32, 16, 3, 16, 7), (16, 32, 1, 16, 7),
                                           (8, 4, 4, 32, 3), (4, 4, 4, 64, 3)])
 def test_wgrad_split_bf16(ops, cs, ct, k, hs, B):
-    """Weight gradients with split-bf16 operands (the default of the backward pass): every element within 2e-5 of the sum of
+    """Weight gradients with split-bf16 operands (opt-in, dm_backward_precision): every element within 2e-5 of the sum of
     the products' magnitudes (2^-17 per product plus the fp32 accumulation), reproducible to the bit."""
     assert ops.backward_precision() == "split-bf16"
     stride, pad = (2, 1) if k == 4 else (1, k // 2)

@@ -457,6 +457,47 @@ def test_shape_sweep_losses_and_gradients(B, nin, hw, masked):
     grad_gate(m, g32, g64, skip=BN_FED_BIASES, floor=5e-4, what=f"shape sweep B={B} nin={nin} hw={hw}")
 
 
+@pytest.mark.parametrize("B,family", [(8, "VQ_VAE"), (64, "VQ_VAE"), (3, "VQ_VAE_z32")])
+def test_split_bf16_backward_on_the_float64_yardstick(B, family):
+    """The opt-in gradient arithmetic (dm_backward_precision(1): bf16 head + remainder operands on the bf16 matrix
+    instruction): the forward pass -- losses, codes -- is the exact path's bit for bit, and every gradient stays within
+    1.5 x the reference's own fp32-vs-float64 error (or 2e-4 of the gradient's scale)."""
+    import dynamorph_amd
+    from dynamorph_amd import ops
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(77 + B)
+    ref = (O.OracleVQVAE if family == "VQ_VAE" else O.OracleVQVAEz32)()
+    x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(B))
+    m = getattr(dynamorph_amd, family)().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    ld_r, g32, g64 = oracle_truth(ref, x)
+    import copy
+    m_exact = copy.deepcopy(m)
+    _, ld_e = m_exact(x.to(DEV))
+    ld_e["total_loss"].backward()
+    prev = ops.backward_precision("split-bf16")
+    try:
+        _, ld = m(x.to(DEV))
+        ld["total_loss"].backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.backward_precision(prev)
+    for k in ("recon_loss", "commitment_loss", "total_loss", "perplexity"):
+        assert float(ld[k]) == float(ld_e[k]), k                           # forward untouched
+    grad_gate(m, g32, g64, skip=BN_FED_BIASES if family == "VQ_VAE" else Z32_BN_FED_BIASES, floor=2e-4,
+              what=f"split-bf16 backward, {family}, B={B}")
+    # and against the exact path directly: a few 1e-5 of each gradient's scale
+    worst = 0.0
+    ge = dict(m_exact.named_parameters())
+    for k, p in m.named_parameters():
+        if p.grad is None or k in BN_FED_BIASES or k in Z32_BN_FED_BIASES:
+            continue
+        sc = max(ge[k].grad.abs().max().item(), 1e-6)
+        worst = max(worst, (p.grad - ge[k].grad).abs().max().item() / sc)
+    assert worst <= 2e-4, worst
+    assert worst > 0.0 or family != "VQ_VAE"          # (> 0: the split kernels did run)
+
+
 @pytest.mark.parametrize("nin", [1, 3])
 def test_z32_other_input_channel_counts(nin):
     import dynamorph_amd
