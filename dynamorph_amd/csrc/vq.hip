@@ -326,33 +326,36 @@ __device__ __forceinline__ int vq_count_column(const int *__restrict__ hrep, int
     return s;
 }
 
-// hist[k] = column sum over the counter rows.  One workgroup per 64 codes: its four waves take every fourth row (64 codes
-// side by side = one coalesced 256-byte read per row), 32 rows in flight per wave.
-__global__ __launch_bounds__(256) void vq_hist_reduce_kernel(const int *__restrict__ hrep, int *__restrict__ hdr, int K,
-                                                             int *__restrict__ hist)
+// hist[k] = column sum over the counter rows.  One workgroup per 64 codes: its sixteen waves take every sixteenth row (64
+// codes side by side = one coalesced 256-byte read per row), 32 rows in flight per wave.
+__global__ __launch_bounds__(1024) void vq_hist_reduce_kernel(const int *__restrict__ hrep, int *__restrict__ hdr, int K,
+                                                              int *__restrict__ hist)
 {
-    __shared__ int s_cnt[4][65];
+    __shared__ int s_cnt[16][65];
     const int R = hdr[1], stride = hdr[2];
     const int kl = threadIdx.x & 63, g = threadIdx.x >> 6, k = blockIdx.x * 64 + kl;
     const bool slabs = stride == VQ2_SLAB_STRIDE;          // per-workgroup rows: column 64 = positions re-evaluated exactly
     int h = 0, n = 0;
-    for (int r0 = g; r0 < R; r0 += 128) {
+    for (int r0 = g; r0 < R; r0 += 512) {
         int v[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = (r0 + 4 * j < R && k < K) ? hrep[(long long)(r0 + 4 * j) * stride + k] : 0;
+        for (int j = 0; j < 32; ++j) v[j] = (r0 + 16 * j < R && k < K) ? hrep[(long long)(r0 + 16 * j) * stride + k] : 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) h += v[j];
         if (slabs && kl == 0 && blockIdx.x == 0) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) n += r0 + 4 * j < R ? hrep[(long long)(r0 + 4 * j) * stride + 64] : 0;
+            for (int j = 0; j < 32; ++j) n += r0 + 16 * j < R ? hrep[(long long)(r0 + 16 * j) * stride + 64] : 0;
         }
     }
     s_cnt[g][kl] = h;
     if (kl == 0) s_cnt[g][64] = n;
     __syncthreads();
     if (g == 0) {
-        if (k < K) hist[k] = (s_cnt[0][kl] + s_cnt[1][kl]) + (s_cnt[2][kl] + s_cnt[3][kl]);
-        if (slabs && kl == 0 && blockIdx.x == 0) hdr[0] = (s_cnt[0][64] + s_cnt[1][64]) + (s_cnt[2][64] + s_cnt[3][64]);
+        int th = 0, tn = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { th += s_cnt[w][kl]; tn += s_cnt[w][64]; }
+        if (k < K) hist[k] = th;
+        if (slabs && kl == 0 && blockIdx.x == 0) hdr[0] = tn;
     }
 }
 
@@ -1113,13 +1116,13 @@ __global__ void vq_finalize_kernel(const double *__restrict__ sse_slabs, int nsl
 // The training step's last scalar launch: vq_finalize_kernel + the reconstruction-loss finaliser in one, reading the
 // code counters straight from their replicas (no vq_hist_reduce launch before it).  out = (recon, commitment, total,
 // perplexity), same arithmetic as dm_vq_finalize followed by dm_loss_finalize.
-__global__ void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, int nslabs, const int *__restrict__ hrep,
+__global__ __launch_bounds__(1024) void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, int nslabs, const int *__restrict__ hrep,
                                         const int *__restrict__ hdr,
                                         int K, long long P, int D, float cc, const double *__restrict__ loss_slabs, int nloss,
                                         long long count, float w_recon, float w_commit, float *__restrict__ out)
 {
-    __shared__ double s_red[4];
-    __shared__ int s_cnt[4][64];
+    __shared__ double s_red[16];
+    __shared__ int s_cnt[16][64];
     const int R = hdr[1], stride = hdr[2];
     double s = 0.0, l = 0.0, e = 0.0;
     // (eight slabs per thread requested together: one memory round trip for up to 2048 slabs)
@@ -1137,21 +1140,24 @@ __global__ void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) l += v[j];
     }
-    if (stride == VQ2_SLAB_STRIDE && blockDim.x == 256) {
-        // per-workgroup slabs (<= 64 codes, up to 1024 rows): the four waves take every fourth row, 64 codes side by side
+    if (stride == VQ2_SLAB_STRIDE && blockDim.x == 1024) {
+        // per-workgroup slabs (<= 64 codes, up to 1024 rows): the sixteen waves take every sixteenth row, 64 codes side by
+        // side, 32 rows in flight per wave: two memory round trips for 1024 rows
         const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
         int h = 0;
-        for (int r0 = g; r0 < R; r0 += 128) {
+        for (int r0 = g; r0 < R; r0 += 512) {
             int v[32];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = r0 + 4 * j < R ? hrep[(long long)(r0 + 4 * j) * stride + k] : 0;
+            for (int j = 0; j < 32; ++j) v[j] = r0 + 16 * j < R ? hrep[(long long)(r0 + 16 * j) * stride + k] : 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) h += v[j];
         }
         s_cnt[g][k] = h;
         __syncthreads();
         if (threadIdx.x < K) {
-            const int tot_k = (s_cnt[0][k] + s_cnt[1][k]) + (s_cnt[2][k] + s_cnt[3][k]);
+            int tot_k = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) tot_k += s_cnt[w][k];
             const float pk = (float)tot_k / (float)P;
             e += (double)(pk * logf(pk + 1e-10f));
         }
@@ -1543,7 +1549,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
 #undef DM_VQ2
 #undef DM_VQ2K
-        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
+        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, hrep, (int *)ws, K, (int *)hist);
         return dm_launch_status("dm_vq_forward");
     }
     const float *cbT = ws + L.cbT;
@@ -1560,7 +1566,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
     }
 #undef DM_VQ_FWD
-    if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(256), 0, s, hrep, (int *)ws, K, (int *)hist);
+    if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, hrep, (int *)ws, K, (int *)hist);
     return dm_launch_status("dm_vq_forward");
 }
 }  // namespace
@@ -1602,7 +1608,7 @@ extern "C" int dm_vq_loss_finalize(const double *sse_slabs, int nslabs, const vo
                    positions > 0 && count > 0, "dm_vq_loss_finalize: bad argument");
     const Vq2Layout L = vq2_layout(K, D);
     const int *hrep = reinterpret_cast<const int *>(reinterpret_cast<const float *>(workspace) + L.hrep);
-    hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sse_slabs, nslabs, hrep,
+    hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sse_slabs, nslabs, hrep,
                        reinterpret_cast<const int *>(workspace), K,
                        (long long)positions, D, commitment_cost, loss_slabs, nloss, (long long)count, weight_recon,
                        weight_commitment, scalars_out);
