@@ -15,8 +15,12 @@
 // Algorithmic bytes/patch: forward 65 536 (d2) + 131 072 (x) + 131 072 (decoded) = 327 680;
 // backward 65 536 + 131 072 + 131 072 + 65 536 (g2) = 393 216  (unfused: 851 968 and 1 507 328).
 //
-// Built for the default decoder family: num_hiddens//4 = 4 channels, d2 exactly 64 wide (128x128 patches);
-// other shapes use the unfused kernels (dynamorph_amd/engine.py decides).
+// Built for the default decoder family: num_hiddens//4 = 4 channels.  d2 exactly 64 wide (128x128 patches): one tile spans
+// the row.  Any other width (a multiple of 4; 256x256 patches: 128) takes the WIDE instantiation: a tile still is 64 lanes =
+// 64 columns, x0 - 4 .. x0 + 59, of which the middle 56 are OWNED (sums, stores, weight-gradient terms); the four columns on
+// either side are recomputed halo, so that everything an owned column needs from its neighbours (lane shifts, the g4 columns
+// 2x-1 and 2x+2) exists in the tile exactly as in the full-row form.  Other channel counts use the unfused kernels
+// (dynamorph_amd/engine.py decides).
 #include "dm_common.h"
 #include "tile.h"
 #include "mfma_util.h"
@@ -28,6 +32,8 @@ constexpr int TT_TH = 8;       // d2 rows per tile
 constexpr int TT_W = 64;       // d2 width (one tile spans the full row = one lane per column)
 constexpr int TT_MAX_GRID = 768;            // 3 workgroups per CU (LDS-limited)
 constexpr int TT_DRS = 2 * TT_W + 8;        // d4 / g4 LDS row: col j <-> ox = j - 4 (zero pad columns for the MFMA weight gradient)
+constexpr int TT_HALO = 4;                  // WIDE: halo lanes on either side of a tile (a multiple of 4: 16-byte staging chunks)
+constexpr int TT_OWN = TT_W - 2 * TT_HALO;  // WIDE: owned columns per tile
 
 // Thin layers (4 channels) waste 75 % of an MFMA tile, so dec.4 forward/recompute and its data gradient run on the
 // VALU: one wave per output channel (its 64 weights are wave-uniform), one lane per column; the left/right
@@ -108,12 +114,12 @@ __device__ __forceinline__ void convT_pair(const RowVals &P, const RowVals &C, c
 __device__ __forceinline__ f32x2 relu2(f32x2 v) { return (f32x2){dm_relu(v.x), dm_relu(v.y)}; }
 
 // =================================================================================== forward
-template <int NIN>
+template <int NIN, bool WIDE>
 __global__ __launch_bounds__(DM_BLOCK, 3)
 void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restrict__ w4, const float *__restrict__ b4,
                              const float *__restrict__ w6, const float *__restrict__ b6, const float *__restrict__ x,
                              const float *__restrict__ mask, int MC, const float *__restrict__ cvar,
-                             float *__restrict__ dec, double *__restrict__ loss_slabs, int H2, int ntiles)
+                             float *__restrict__ dec, double *__restrict__ loss_slabs, int H2, int ntiles, int W2arg, int tiles_x)
 {
     constexpr int AROWS = TT_TH + 2, APS = AROWS * TT_W + 4;     // d2 rows y0-1 .. y0+TH
     constexpr int DROWS = 2 * TT_TH, DPS = DROWS * TT_DRS;       // d4 rows 2*y0 .. 2*y0+2*TH-1
@@ -124,16 +130,22 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // = output channel in phase A
-    const int tiles_y = H2 / TT_TH, OH = 2 * H2, OW = 2 * TT_W;
+    const int W2 = WIDE ? W2arg : TT_W;
+    const int tiles_y = H2 / TT_TH, OH = 2 * H2, OW = 2 * W2;
     Operand in;
     in.p0 = d2; in.p1 = nullptr; in.coef = nullptr; in.coef_bstride = 0; in.mode = DM_LOAD_IDENT; in.ones = 0;
 
     TileStage<TT_C, AROWS, TT_W / 4, TT_W, APS, false> stage;
-    stage.init(H2, TT_W);
-    int tidx = blockIdx.x, b = 0, y0 = 0;
+    stage.init(H2, W2);
+    // tile -> (sample, row band, column band); WIDE: lane <-> column x0 + lane, x0 = 56 * tx - 4
+    auto tile_of = [&](int t, int &tb, int &ty0, int &tx0) {
+        if (WIDE) { const int q = t / tiles_x; tx0 = (t - q * tiles_x) * TT_OWN - TT_HALO; t = q; } else tx0 = 0;
+        ty0 = (t % tiles_y) * TT_TH; tb = t / tiles_y;
+    };
+    int tidx = blockIdx.x, b = 0, y0 = 0, x0 = 0;
     if (tidx < ntiles) {
-        y0 = (tidx % tiles_y) * TT_TH; b = tidx / tiles_y;
-        stage.issue(in, b, TT_C, H2, TT_W, y0 - 1, 0);
+        tile_of(tidx, b, y0, x0);
+        stage.issue(in, b, TT_C, H2, W2, y0 - 1, x0);
     }
     if (threadIdx.x < TT_C) *reinterpret_cast<f32x4 *>(s_coef + threadIdx.x * 4) = (f32x4){1.f, 0.f, 0.f, -__builtin_inff()};
 
@@ -152,13 +164,16 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA / sD
-        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 1, 0, DM_LOAD_IDENT);
+        stage.commit(sA, s_coef, TT_C, H2, W2, y0 - 1, x0, DM_LOAD_IDENT);
         __syncthreads();
         const int cb = b, cy0 = y0;
+        const int colx = x0 + lane;                        // this lane's d2 column (WIDE: may lie outside the image / be halo)
+        const bool colin = !WIDE || (unsigned)colx < (unsigned)W2;
+        const bool ownl = !WIDE || (lane >= TT_HALO && lane < TT_W - TT_HALO && colx < W2);
         const int next = tidx + gridDim.x;
         if (next < ntiles) {
-            y0 = (next % tiles_y) * TT_TH; b = next / tiles_y;
-            stage.issue(in, b, TT_C, H2, TT_W, y0 - 1, 0);
+            tile_of(next, b, y0, x0);
+            stage.issue(in, b, TT_C, H2, W2, y0 - 1, x0);
         }
         // x / mask rows this wave needs in phase B: requested now, they land while phase A computes
         f32x2 xr[DROWS / 4][NIN];       // (the optional batch_mask is read in phase B: rare path, no registers kept for it)
@@ -168,7 +183,7 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
 #pragma unroll
             for (int c = 0; c < NIN; ++c) {
                 xr[j][c] = (f32x2){0.f, 0.f};
-                if (x) xr[j][c] = *reinterpret_cast<const f32x2 *>(x + ((cb * NIN + c) * OH + oy) * OW + 2 * lane);
+                if (x && colin) xr[j][c] = *reinterpret_cast<const f32x2 *>(x + ((cb * NIN + c) * OH + oy) * OW + 2 * colx);
             }
         }
         // ---- phase A: d4[co = wave] = relu(dec.4(d2)) for the 16 output rows of this tile -> LDS ---------------
@@ -205,12 +220,12 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
                 f32x2 o = {b6r[c], b6r[c]};
 #pragma unroll
                 for (int co = 0; co < TT_C; ++co) o += w6r[c][co] * dv[co];
-                const int off = ((cb * NIN + c) * OH + oy) * OW + 2 * lane;
-                *reinterpret_cast<f32x2 *>(dec + off) = o;
-                if (x) {
+                const int off = ((cb * NIN + c) * OH + oy) * OW + 2 * colx;
+                if (ownl) *reinterpret_cast<f32x2 *>(dec + off) = o;
+                if (x && ownl) {
                     f32x2 t = o - xr[j][c];
                     if (mask) {
-                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
+                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * colx);
                         t = o * mv - xr[j][c] * mv;
                     }
                     tl += (t.x * t.x + t.y * t.y) * ivar[c];
@@ -253,14 +268,15 @@ __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const 
 // ================================================================================== backward
 // FUSED (training pass, dm_dec_tail_train): decoded is not read but formed in phase B from the recomputed d4 tile
 // (dec.6 is 1x1), the reconstruction-loss partials are taken there too, and `decoded` never exists in HBM.
-template <int NIN, bool FUSED>
+template <int NIN, bool FUSED, bool WIDE>
 __global__ __launch_bounds__(DM_BLOCK, 2)
 void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restrict__ w4, const float *__restrict__ b4,
                               const float *__restrict__ w6, const float *__restrict__ b6, double *__restrict__ loss_slabs,
                               const float *__restrict__ decp, const float *__restrict__ x,
                               const float *__restrict__ mask, int MC, const float *__restrict__ cvar,
                               const float *__restrict__ gscale_dev, float *__restrict__ g2, double *__restrict__ part,
-                              float *__restrict__ wslabs, int H2, int ntiles, double inv_count, int nslabs)
+                              float *__restrict__ wslabs, int H2, int ntiles, double inv_count, int nslabs, int W2arg,
+                              int tiles_x)
 {
     constexpr int AROWS = TT_TH + 4, APS = AROWS * TT_W + 4;     // d2 rows y0-2 .. y0+TH+1
     constexpr int GROWS = 2 * TT_TH + 2, GPS = GROWS * TT_DRS;   // g4 rows 2*y0-1 .. 2*y0+2*TH ; col j <-> ox = j - 4
@@ -274,16 +290,22 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 
     const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles_y = H2 / TT_TH, OH = 2 * H2, OW = 2 * TT_W;
+    const int W2 = WIDE ? W2arg : TT_W;
+    const int tiles_y = H2 / TT_TH, OH = 2 * H2, OW = 2 * W2;
     Operand in;
     in.p0 = d2; in.p1 = nullptr; in.coef = nullptr; in.coef_bstride = 0; in.mode = DM_LOAD_IDENT; in.ones = 0;
 
     TileStage<TT_C, AROWS, TT_W / 4, TT_W, APS, false> stage;
-    stage.init(H2, TT_W);
-    int tidx = blockIdx.x, b = 0, y0 = 0;
+    stage.init(H2, W2);
+    // tile -> (sample, row band, column band); WIDE: lane <-> column x0 + lane, x0 = 56 * tx - 4 (header comment)
+    auto tile_of = [&](int t, int &tb, int &ty0, int &tx0) {
+        if (WIDE) { const int q = t / tiles_x; tx0 = (t - q * tiles_x) * TT_OWN - TT_HALO; t = q; } else tx0 = 0;
+        ty0 = (t % tiles_y) * TT_TH; tb = t / tiles_y;
+    };
+    int tidx = blockIdx.x, b = 0, y0 = 0, x0 = 0;
     if (tidx < ntiles) {
-        y0 = (tidx % tiles_y) * TT_TH; b = tidx / tiles_y;
-        stage.issue(in, b, TT_C, H2, TT_W, y0 - 2, 0);
+        tile_of(tidx, b, y0, x0);
+        stage.issue(in, b, TT_C, H2, W2, y0 - 2, x0);
     }
     if (threadIdx.x < TT_C) *reinterpret_cast<f32x4 *>(s_coef + threadIdx.x * 4) = (f32x4){1.f, 0.f, 0.f, -__builtin_inff()};
     // the padding columns of the g4 tile (ox = -4..-1 and 128..131) are zero for every tile
@@ -333,26 +355,27 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     // every row when there is no next tile: empty descriptor) get an out-of-range offset and read as 0.  The
     // requests are spread over the MFMA (weight-gradient) phase instead of going out in one burst (a CU keeps only so many bytes
     // in flight; a burst stalls the wave at the issue point).
-    struct RowCtx { __amdgpu_buffer_rsrc_t rx, rd; int ty0; };
-    auto rows_begin = [&](bool live, int tb, int ty0) {
+    struct RowCtx { __amdgpu_buffer_rsrc_t rx, rd; int ty0, tx0; };
+    auto rows_begin = [&](bool live, int tb, int ty0, int tx0) {
         RowCtx rc;
         const long long se = (long long)NIN * OH * OW;
         const int bytes = live ? (int)(se * 4) : 0;
         rc.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + se * tb), 0, bytes, 0x00020000);
         rc.rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((FUSED ? x : decp) + se * tb), 0, FUSED ? 0 : bytes,
                                                   0x00020000);
-        rc.ty0 = ty0;
+        rc.ty0 = ty0; rc.tx0 = tx0;
         return rc;
     };
     auto issue_row = [&](const RowCtx &rc, int j, int c) {
         const int gr = wave + 4 * j, oy = 2 * rc.ty0 - 1 + gr;
-        const bool ok = gr < GROWS && (unsigned)oy < (unsigned)OH;
-        const int voff = ok ? ((c * OH + oy) * OW + 2 * lane) * 4 : 0x7ffffff0;
+        const int cx = rc.tx0 + lane;
+        const bool ok = gr < GROWS && (unsigned)oy < (unsigned)OH && (!WIDE || (unsigned)cx < (unsigned)W2);
+        const int voff = ok ? ((c * OH + oy) * OW + 2 * cx) * 4 : 0x7ffffff0;
         if (!FUSED) rdv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rd, voff, 0, 0);
         rxv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rx, voff, 0, 0);
     };
     {
-        const RowCtx rc0 = rows_begin(tidx < ntiles, b, y0);
+        const RowCtx rc0 = rows_begin(tidx < ntiles, b, y0, x0);
 #pragma unroll
         for (int j = 0; j < BR; ++j)
 #pragma unroll
@@ -362,12 +385,15 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA and sG
-        stage.commit(sA, s_coef, TT_C, H2, TT_W, y0 - 2, 0, DM_LOAD_IDENT);
+        stage.commit(sA, s_coef, TT_C, H2, W2, y0 - 2, x0, DM_LOAD_IDENT);
         __syncthreads();
         const int cb = b, cy0 = y0;
+        const int colx = x0 + lane;                        // this lane's d2 column (WIDE: may be halo / outside the image)
+        const bool colin = !WIDE || (unsigned)colx < (unsigned)W2;
+        const bool ownl = !WIDE || (lane >= TT_HALO && lane < TT_W - TT_HALO && colx < W2);
         const int next = tidx + gridDim.x;
-        if (next < ntiles) { y0 = (next % tiles_y) * TT_TH; b = next / tiles_y; }
-        const auto scx = stage.begin(in, next < ntiles, b, TT_C, H2, TT_W, y0 - 2, 0);   // requested during phase A
+        if (next < ntiles) tile_of(next, b, y0, x0);
+        const auto scx = stage.begin(in, next < ntiles, b, TT_C, H2, W2, y0 - 2, x0);   // requested during phase A
 
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
         {
@@ -405,9 +431,10 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             const int gr = wave + 4 * j;
             if (gr < GROWS) {
                 const int oy = 2 * cy0 - 1 + gr;
-                const bool live = oy >= 0 && oy < OH;
-                // rows 2*y0 .. 2*y0+2*TH-1 belong to this tile: the halo rows get their g4 but add nothing to the sums
-                const float own = (gr >= 1 && gr <= 2 * TT_TH) ? 1.f : 0.f;
+                const bool live = oy >= 0 && oy < OH && colin;
+                // rows 2*y0 .. 2*y0+2*TH-1 (WIDE: and the owned columns) belong to this tile: the halo gets its g4 but
+                // adds nothing to the sums
+                const float own = (gr >= 1 && gr <= 2 * TT_TH && ownl) ? 1.f : 0.f;
                 f32x2 gd[NIN], gdo[NIN], d4v[TT_C];
 #pragma unroll
                 for (int co = 0; co < TT_C; ++co)
@@ -422,7 +449,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     }
                     f32x2 t = dv - rxv[j][c];            // not FUSED: rows outside the image were loaded as 0
                     if (mask && live) {
-                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * lane);
+                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * colx);
                         t = dv * mv - rxv[j][c] * mv;
                         if (FUSED) tl += (t * t * own) * ivar[c];
                         t = t * mv;
@@ -451,7 +478,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             }
         }
         if (FUSED) loss += (double)tl.x + (double)tl.y;
-        const RowCtx rcn = rows_begin(next < ntiles, b, y0);   // next tile's rows: requested during the wgrad phase
+        const RowCtx rcn = rows_begin(next < ntiles, b, y0, x0);   // next tile's rows: requested during the wgrad phase
         __syncthreads();
 
         // ---- phase 3: data gradient of dec.4 for input channel ci = wave:  g2[ci][y][x] = sum_co,ky,kx
@@ -499,8 +526,8 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 const int r = (gr - 3) >> 1;
                 const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
                 const float sum = (acc[r].x + acc[r].y) + (lane_from_right(side[r].x) + lane_from_left(side[r].y));
-                const float v = dd > 0.f ? sum : 0.f;
-                g2[((cb * TT_C + wave) * H2 + cy0 + r) * TT_W + lane] = v;
+                const float v = (dd > 0.f && ownl) ? sum : 0.f;
+                if (ownl) g2[((cb * TT_C + wave) * H2 + cy0 + r) * W2 + colx] = v;
                 pb2 += v;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -517,19 +544,39 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     if (e >= part * NR / 3 && e < (part + 1) * NR / 3) issue_row(rcn, e / NIN, e % NIN);
             };
             const float rm0 = (wave == 0 && wsy == 1) ? 0.f : 1.f;
-            issue_part(0);
-            wgrad_steps<17, true, true>(sA, sG, wa_base + wave * TT_W, wb_base + 2 * wave * TT_DRS, rm0, w_first_bad,
-                                        w_last_ok, wacc);
-            issue_part(1);
-            wgrad_steps<17, true, true>(sA, sG, wa_base + (wave + 4) * TT_W, wb_base + 2 * (wave + 4) * TT_DRS, 1.f,
-                                        w_first_bad, w_last_ok, wacc);
-            issue_part(2);
             const float rm8 = wsy == 1 ? 1.f : 0.f;
-            const int a8 = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
-            if (wave < 3)
-                wgrad_steps<4, true, false>(sA, sG, a8, b8, rm8, w_first_bad && wave == 0, false, wacc);
-            else
-                wgrad_steps<5, false, true>(sA, sG, a8, b8, rm8, false, w_last_ok, wacc);
+            if constexpr (!WIDE) {
+                issue_part(0);
+                wgrad_steps<17, true, true>(sA, sG, wa_base + wave * TT_W, wb_base + 2 * wave * TT_DRS, rm0, w_first_bad,
+                                            w_last_ok, wacc);
+                issue_part(1);
+                wgrad_steps<17, true, true>(sA, sG, wa_base + (wave + 4) * TT_W, wb_base + 2 * (wave + 4) * TT_DRS, 1.f,
+                                            w_first_bad, w_last_ok, wacc);
+                issue_part(2);
+                const int a8 = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
+                if (wave < 3)
+                    wgrad_steps<4, true, false>(sA, sG, a8, b8, rm8, w_first_bad && wave == 0, false, wacc);
+                else
+                    wgrad_steps<5, false, true>(sA, sG, a8, b8, rm8, false, w_last_ok, wacc);
+            } else {
+                // owned d2 columns 4 .. 59 of the tile: the term (X, sx) has its d2 column at X - sx, so steps 1 .. 15 with
+                // X = 4 (sx = 1: column 3) struck from the first and only (X = 60, sx = 1: column 59) kept of the last --
+                // the full-row form's edge handling, one step in.  Columns beyond the image hold zeros in sA.
+                issue_part(0);
+                wgrad_steps<15, true, true>(sA, sG, wa_base + wave * TT_W + 4, wb_base + 2 * wave * TT_DRS + 8, rm0,
+                                            w_first_bad, w_last_ok, wacc);
+                issue_part(1);
+                wgrad_steps<15, true, true>(sA, sG, wa_base + (wave + 4) * TT_W + 4, wb_base + 2 * (wave + 4) * TT_DRS + 8,
+                                            1.f, w_first_bad, w_last_ok, wacc);
+                issue_part(2);
+                const int a8 = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
+                if (wave == 0)
+                    wgrad_steps<3, true, false>(sA, sG, a8 + 4, b8 + 8, rm8, w_first_bad, false, wacc);
+                else if (wave < 3)
+                    wgrad_steps<4, false, false>(sA, sG, a8, b8, rm8, false, false, wacc);
+                else
+                    wgrad_steps<4, false, true>(sA, sG, a8, b8, rm8, false, w_last_ok, wacc);
+            }
         }
         tidx = next;
     }
@@ -590,6 +637,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     }
 }
 
+int tail_tiles_x(int W2) { return W2 == TT_W ? 1 : (W2 + TT_OWN - 1) / TT_OWN; }               // (64 wide: one tile spans the row)
 int tail_grid(int ntiles) { return ntiles < TT_MAX_GRID ? ntiles : TT_MAX_GRID; }               // forward: 3 per CU
 int tail_grid_bwd(int ntiles) { return ntiles < 512 ? ntiles : 512; }                           // backward: 2 per CU
 
@@ -597,8 +645,8 @@ int tail_checks(const char *who, int B, int C2, int NIN, int H2, int W2)
 {
     DM_REQUIRE(C2 == TT_C, "%s: num_hiddens//4 = %d not built (4)", who, C2);
     DM_REQUIRE(NIN >= 1 && NIN <= 4, "%s: num_inputs %d not built (1..4)", who, NIN);
-    DM_REQUIRE(W2 == TT_W && H2 % TT_TH == 0 && B > 0, "%s: d2 must be %d wide and a multiple of %d high (got %dx%d)",
-               who, TT_W, TT_TH, H2, W2);
+    DM_REQUIRE(W2 >= 4 && W2 % 4 == 0 && H2 > 0 && H2 % TT_TH == 0 && B > 0,
+               "%s: d2 must be a multiple of 4 wide and a multiple of %d high (got %dx%d)", who, TT_TH, H2, W2);
     DM_REQUIRE((long long)B * 4 * (2 * H2) * (2 * W2) < (1LL << 31), "%s: tensor too large for 32-bit offsets", who);
     return 0;
 }
@@ -607,13 +655,12 @@ int tail_checks(const char *who, int B, int C2, int NIN, int H2, int W2)
 
 extern "C" int dm_dec_tail_supported(int C2, int NIN, int H2, int W2)
 {
-    return C2 == TT_C && NIN >= 1 && NIN <= 4 && W2 == TT_W && H2 % TT_TH == 0;
+    return C2 == TT_C && NIN >= 1 && NIN <= 4 && W2 >= 4 && W2 % 4 == 0 && H2 > 0 && H2 % TT_TH == 0;
 }
 
 extern "C" int dm_dec_tail_num_blocks(int B, int H2, int W2)
 {
-    (void)W2;
-    return tail_grid(B * (H2 / TT_TH));
+    return tail_grid(B * (H2 / TT_TH) * tail_tiles_x(W2));
 }
 
 extern "C" int dm_dec_tail_forward(const float *d2, const float *w4, const float *b4, const float *w6, const float *b6,
@@ -625,11 +672,15 @@ extern "C" int dm_dec_tail_forward(const float *d2, const float *w4, const float
     DM_REQUIRE(!x || loss_slabs, "dm_dec_tail_forward: loss_slabs required when x is given");
     DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "dm_dec_tail_forward: mask channels %d", mask_channels);
     if (tail_checks("dm_dec_tail_forward", B, C2, NIN, H2, W2)) return -1;
-    const int ntiles = B * (H2 / TT_TH), grid = tail_grid(ntiles);
+    const int tiles_x = tail_tiles_x(W2), ntiles = B * (H2 / TT_TH) * tiles_x, grid = tail_grid(ntiles);
     hipStream_t st = (hipStream_t)stream;
-#define DM_TF(N_) hipLaunchKernelGGL((dec_tail_forward_kernel<N_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, w6, b6, \
-                                     x, mask, mask_channels, channel_var, decoded, loss_slabs, H2, ntiles)
-    switch (NIN) { case 1: DM_TF(1); break; case 2: DM_TF(2); break; case 3: DM_TF(3); break; default: DM_TF(4); }
+#define DM_TF(N_, W_) hipLaunchKernelGGL((dec_tail_forward_kernel<N_, W_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, w6, b6, \
+                                         x, mask, mask_channels, channel_var, decoded, loss_slabs, H2, ntiles, W2, tiles_x)
+    if (W2 == TT_W) {
+        switch (NIN) { case 1: DM_TF(1, false); break; case 2: DM_TF(2, false); break; case 3: DM_TF(3, false); break; default: DM_TF(4, false); }
+    } else {
+        switch (NIN) { case 1: DM_TF(1, true); break; case 2: DM_TF(2, true); break; case 3: DM_TF(3, true); break; default: DM_TF(4, true); }
+    }
 #undef DM_TF
     return dm_launch_status("dm_dec_tail_forward");
 }
@@ -644,17 +695,19 @@ int tail_backward_launch(const char *who, bool fused, const float *d2, const flo
     DM_REQUIRE(fused ? loss_slabs != nullptr : decoded != nullptr, "%s: NULL pointer", who);
     DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "%s: mask channels %d", who, mask_channels);
     if (tail_checks(who, B, C2, NIN, H2, W2)) return -1;
-    const int ntiles = B * (H2 / TT_TH), grid = tail_grid_bwd(ntiles), nslabs = tail_grid(ntiles);
+    const int tiles_x = tail_tiles_x(W2), ntiles = B * (H2 / TT_TH) * tiles_x, grid = tail_grid_bwd(ntiles), nslabs = tail_grid(ntiles);
     const double inv_count = 1.0 / ((double)B * NIN * (2.0 * H2) * (2.0 * W2));
     hipStream_t st = (hipStream_t)stream;
-#define DM_TB(N_, F_) hipLaunchKernelGGL((dec_tail_backward_kernel<N_, F_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, \
-                                         w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
-                                         part_slabs, w_slabs, H2, ntiles, inv_count, nslabs)
-    if (fused) {
-        switch (NIN) { case 1: DM_TB(1, true); break; case 2: DM_TB(2, true); break; case 3: DM_TB(3, true); break; default: DM_TB(4, true); }
+#define DM_TB(N_, F_, W_) hipLaunchKernelGGL((dec_tail_backward_kernel<N_, F_, W_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, \
+                                             w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
+                                             part_slabs, w_slabs, H2, ntiles, inv_count, nslabs, W2, tiles_x)
+#define DM_TBN(F_, W_) switch (NIN) { case 1: DM_TB(1, F_, W_); break; case 2: DM_TB(2, F_, W_); break; case 3: DM_TB(3, F_, W_); break; default: DM_TB(4, F_, W_); }
+    if (W2 == TT_W) {
+        if (fused) { DM_TBN(true, false) } else { DM_TBN(false, false) }
     } else {
-        switch (NIN) { case 1: DM_TB(1, false); break; case 2: DM_TB(2, false); break; case 3: DM_TB(3, false); break; default: DM_TB(4, false); }
+        if (fused) { DM_TBN(true, true) } else { DM_TBN(false, true) }
     }
+#undef DM_TBN
 #undef DM_TB
     return dm_launch_status(who);
 }

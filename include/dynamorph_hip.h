@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 111
+#define DM_VERSION 112
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -311,11 +311,13 @@ int dm_head_backward(const float *decoded, const float *x, const float *mask, in
 
 /* ----- fused decoder tail (dec.4 + dec.5 + dec.6 + loss, vq_vae.py:296-298, 320-323) ---------------------
  * The 4 x 2H2 x 2W2 tensor d4 = relu(dec.4(d2)) and its gradient are never written to HBM.
- * Built for num_hiddens//4 = 4 channels and d2 exactly 64 wide; dm_dec_tail_supported() tells. */
+ * Built for num_hiddens//4 = 4 channels, 1..4 input channels, H2 a multiple of 8 and W2 a multiple of 4 (W2 = 64, the
+ * 128 x 128 patches, has its own instantiation: one tile spans the row; other widths run 64-lane tiles with 56 owned
+ * columns); dm_dec_tail_supported() tells. */
 int dm_dec_tail_supported(int C2, int NIN, int H2, int W2);
 int dm_dec_tail_num_blocks(int B, int H2, int W2);
-/* d2 (B,4,H2,64) post-ReLU input of dec.4; w4 (4,4,4,4) ConvTranspose2d weight [ci][co][ky][kx]; w6 (NIN,4).
- * decoded (B,NIN,2H2,128); loss_slabs: dm_dec_tail_num_blocks doubles (x = NULL: decoder-only, no loss). */
+/* d2 (B,4,H2,W2) post-ReLU input of dec.4; w4 (4,4,4,4) ConvTranspose2d weight [ci][co][ky][kx]; w6 (NIN,4).
+ * decoded (B,NIN,2H2,2W2); loss_slabs: dm_dec_tail_num_blocks doubles (x = NULL: decoder-only, no loss). */
 int dm_dec_tail_forward(const float *d2, const float *w4, const float *b4, const float *w6, const float *b6,
                         const float *x, const float *mask, int mask_channels, const float *channel_var,
                         float *decoded, double *loss_slabs, int B, int C2, int NIN, int H2, int W2, void *stream);

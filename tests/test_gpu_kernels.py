@@ -1077,17 +1077,23 @@ def test_e1_border_bias_table_replaces_the_ones_channel(ops):
 
 
 # ===================================================================== fused decoder tail
-@pytest.mark.parametrize("nin,masked,B", [(2, False, 3), (2, True, 2), (4, True, 2), (1, False, 70)])
-def test_dec_tail_fused_forward_backward(ops, nin, masked, B):
+@pytest.mark.parametrize("nin,masked,B,hw", [(2, False, 3, (64, 64)), (2, True, 2, (64, 64)), (4, True, 2, (64, 64)),
+                                              (1, False, 70, (64, 64)),
+                                              # other widths: 64 lanes = 56 owned columns + 4 halo columns either side
+                                              (4, True, 2, (128, 128)), (2, False, 3, (16, 32)), (3, True, 2, (24, 100)),
+                                              (2, False, 2, (8, 56)), (2, True, 2, (16, 60)), (1, False, 5, (8, 4)),
+                                              (2, False, 1, (64, 256)), (4, False, 1, (128, 64))])
+def test_dec_tail_fused_forward_backward(ops, nin, masked, B, hw):
     """dec.4 + ReLU + dec.6 + masked loss in one kernel, and its fused backward, vs the ATen composition."""
-    c, h = 4, 64
-    pre = rnd(B, c, h, h, seed=1).requires_grad_(True)
+    c, (h, w) = 4, hw
+    assert ops.dec_tail_supported(c, nin, h, w)
+    pre = rnd(B, c, h, w, seed=1).requires_grad_(True)
     w4 = (rnd(c, c, 4, 4, seed=2) * 0.3).requires_grad_(True)
     b4 = rnd(c, seed=3).requires_grad_(True)
     w6 = rnd(nin, c, 1, 1, seed=4).requires_grad_(True)
     b6 = rnd(nin, seed=5).requires_grad_(True)
-    x = rnd(B, nin, 2 * h, 2 * h, seed=6)
-    mask = (torch.rand(B, 1, 2 * h, 2 * h, generator=torch.Generator().manual_seed(7)) > 0.4).float() * 0.5 + 0.5 if masked else None
+    x = rnd(B, nin, 2 * h, 2 * w, seed=6)
+    mask = (torch.rand(B, 1, 2 * h, 2 * w, generator=torch.Generator().manual_seed(7)) > 0.4).float() * 0.5 + 0.5 if masked else None
     var = torch.linspace(0.5, 1.5, nin)
     d2 = F.relu(pre)
     d4 = F.relu(F.conv_transpose2d(d2, w4, b4, stride=2, padding=1))
