@@ -382,8 +382,11 @@ __global__ __launch_bounds__(1024) void vq_hist_reduce_kernel(const int *__restr
 //     the neglected terms 2 rho eta and the 1/(1 - rho) are O(u) relative to it -- |z|^2 from an fp32 dot product) for
 //     the runner-up, which then holds for every other code;
 //   * a position that fails the test (1e-3 of them on N(0,1) data; every position whose z or codebook is not finite,
-//     because tol is then inf or NaN) is re-evaluated EXACTLY over all K codes by the whole wave: lane l takes codes
-//     l, l + 64, ... in the reference's arithmetic and order, first minimum and torch.argmax(-dist) NaN rule included.
+//     because tol is then inf or NaN) is re-evaluated EXACTLY by the whole wave: lane l takes codes l, l + 64, ... in the
+//     reference's arithmetic and order, first minimum and torch.argmax(-dist) NaN rule included.  Codebooks of more than
+//     64 codes (round 3): only over the GROUPS of codes whose smallest filter score lies within tol of the best one -- the
+//     bound that clears the runner-up clears, code by code, every group whose minimum is farther away (s_pm in the kernel).
+//     4096 codes on N(0,1) latents: 1-3 of 6 groups of 768 instead of all of them, for the 10 % of positions that fail.
 // So the index is the reference's for every position; only the work per position differs.
 //
 // Layout: a wave owns a chunk of 64 consecutive positions of one sample; lane (h = lane >> 4, c = lane & 15) loads
@@ -560,6 +563,12 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     __shared__ double s_red[NW];
     __shared__ float s_em[NW];
     __shared__ __attribute__((aligned(16))) float s_nrm[INL ? 64 : 4];
+    // Large codebooks: the smallest filter score of every GROUP of codes, per position (bf16, rounded down), so that a
+    // position that fails the tolerance test is re-evaluated exactly only against the groups that can hold a code within the
+    // tolerance of its best score -- the same proven bound that clears the runner-up clears every code of a group whose
+    // minimum is farther away.  Groups are whole LDS pieces; their number is what fits beside the piece at this occupancy.
+    constexpr int NG = SINGLE ? 1 : (MINW >= 3 ? (BF ? 6 : 4) : 16);      // (3 workgroups per CU: 53 KB each, 512-byte granules)
+    __shared__ unsigned short s_pm[SINGLE ? 2 : NG * BLOCK];
     const int lane = threadIdx.x & 63, h = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // provably wave-uniform: scalar branches
     const bool lds_hist = K <= VQ_MAX_LDS_HIST;
@@ -572,6 +581,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const unsigned qstep = (unsigned)NW * gridDim.x;
     const unsigned step_b = qstep / cps, step_c = qstep - step_b * cps;
     const int ncc = (K + 63) >> 6;                             // 64-code chunks
+    const int gch = ((ncc + NG - 1) / NG + PIECE - 1) / PIECE * PIECE;       // code chunks per group (whole pieces)
     int staged = -1;                                           // first code chunk of the piece held in LDS
     double sse = 0.0;
     int nflag = 0;
@@ -736,10 +746,14 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
         z_load(zn, nchunk, nb, nw);
 
         VQ2_STAMP(1)                                           // prefetch issue
-        float m1[4], m2[4];
+        float m1[4], m2[4], pmv[SINGLE ? 1 : 4];
         int c1[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) { m1[t] = 3.4028235e38f; m2[t] = 3.4028235e38f; c1[t] = 0; }
+        if constexpr (!SINGLE) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pmv[t] = 3.4028235e38f;
+        }
 
         // bf16-split filter: the B operands of the chunk's four position tiles, (z_hi[0..3], z_lo[0..3]) of the lane's four
         // dimensions of K-group u as four packed pairs -- built once per chunk of positions, used by every code chunk
@@ -818,6 +832,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                     m2[t] = vq2_min3(m2[t], t2, vq2_max(m1[t], t1));
                     c1[t] = t1 < m1[t] ? ccg : c1[t];
                     m1[t] = vq2_min(m1[t], t1);
+                    pmv[t] = vq2_min(pmv[t], t1);
                 }
             }
         };
@@ -844,6 +859,29 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                         const f32x4 *__restrict__ ab = s_A + cc * CHUNK_F4 + lane;
                         // (conflict-free ds_read_b128: consecutive lanes, consecutive 16-byte slots)
                         chunk_scores(na, [&](int kt, int sq) { return ab[(kt * AQ + sq) * 64]; }, p0 + cc);
+                    }
+                    const int done = p0 + pn;
+                    if (done % gch == 0 || done == ncc) {      // (uniform) a group of codes is complete
+                        // the same lane-pair steps as the final reduce-scatter below: the lane ends up with the minimum of
+                        // the position it will own there
+                        float pj[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            float x1 = pmv[j], y1 = pmv[j + 2];
+                            vq2_swap<16>(x1, y1);
+                            pj[j] = vq2_min(x1, y1);
+                        }
+                        float x1 = pj[0], y1 = pj[1];
+                        vq2_swap<32>(x1, y1);
+                        const float pmin = vq2_min(x1, y1);
+                        // bf16, rounded toward -inf (a stored minimum is never above the true one); NaN stays NaN
+                        const unsigned pb = __builtin_bit_cast(unsigned, pmin);
+                        unsigned ph = pb >> 16;
+                        ph += (pmin < 0.f && (pb & 0xffffu)) ? 1u : 0u;
+                        ph = pmin != pmin ? 0xffffu : ph;
+                        s_pm[((done - 1) / gch) * BLOCK + threadIdx.x] = (unsigned short)ph;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) pmv[t] = 3.4028235e38f;
                     }
                 }
             }
@@ -905,6 +943,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
             }
             const float tol = TOL_A * (zz + 2.f * emax) + TOL_D * fmaxf(zz + a1, 0.f) + 1e-30f;
             const bool flagged = !((a2 - a1) > tol);           // also true when anything is NaN / inf
+            const float thrv = a1 + tol;                       // no code with a filter score above this can be the reference's
             {
                 const unsigned bits = __builtin_bit_cast(unsigned, a1);
                 const int kt = (bits >> 2) & 3, r = bits & 3, hw = hb1 | ((bits >> 4) & 1);
@@ -947,11 +986,19 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                     }
                     if (lane < K) { bd = vq_exact_dist<D>(zv, er); bk = lane; }
                 } else {
-                    if (lane < K) { bd = vq_exact_dist<D>(zv, cb + (long long)lane * D); bk = lane; }
-                    for (int k = lane + 64; k < K; k += 64) {
-                        const float dk = vq_exact_dist<D>(zv, cb + (long long)k * D);
-                        const bool bt = vq_better(dk, bd);
-                        bd = bt ? dk : bd; bk = bt ? k : bk;
+                    // only the groups whose minimum is within the tolerance of the best score (a NaN on either side of the
+                    // comparison -- non-finite latents or codes -- keeps the group); the best code's own group always is
+                    const float thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thrv), fl));
+                    const int ng = (ncc + gch - 1) / gch;
+                    for (int g = 0; g < ng; ++g) {
+                        const float pg = __builtin_bit_cast(float, (unsigned)s_pm[g * BLOCK + wave * 64 + fl] << 16);
+                        if (pg > thr) continue;
+                        const int kend = min((g + 1) * gch * 64, K);
+                        for (int k = g * gch * 64 + lane; k < kend; k += 64) {
+                            const float dk = vq_exact_dist<D>(zv, cb + (long long)k * D);
+                            const bool bt = (bk == 0x7fffffff) | vq_better(dk, bd);      // (a lane's first code is taken as it is)
+                            bd = bt ? dk : bd; bk = bt ? k : bk;
+                        }
                     }
                 }
                 // wave-wide first minimum: DPP moves inside the 16-lane rows, lane-pair swaps across them (no LDS round trips)
