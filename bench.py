@@ -331,7 +331,7 @@ def c2_record(model, steps=50, warmup=3, B=1024):
 
     def step():
         with torch.no_grad():
-            z_b, cx = E.encoder_forward(L, x, per_sample=True, e1=e1, join=False)
+            z_b, cx = E.encoder_forward(L, x, per_sample=True, e1=e1, join=False, latents_only=True)
             z_a = E.vq_forward(L.codebook.weight, z_b, float(model.commitment_cost), want_scalars=False)[0]
             cx.join()                # the running-statistics replay ran on a helper stream beside the quantiser
             return z_a
@@ -531,7 +531,7 @@ def main():
 
         def step():
             with torch.no_grad():
-                z_b, cx = E.encoder_forward(L, x, per_sample=True, e1=e1, join=False)
+                z_b, cx = E.encoder_forward(L, x, per_sample=True, e1=e1, join=False, latents_only=True)
                 z_a, _, _ = E.vq_forward(L.codebook.weight, z_b, float(model.commitment_cost), want_scalars=False)
                 cx.join()
             return z_a

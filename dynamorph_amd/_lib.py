@@ -44,6 +44,17 @@ class ReplaySeg(C.Structure):
                 ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp), ("momentum", f32)]
 
 
+class LatentTailRes(C.Structure):
+    _fields_ = [("wa", vp), ("ba", vp), ("gamma_a", vp), ("beta_a", vp), ("stats_a", vp),
+                ("wb", vp), ("bb", vp), ("gamma_b", vp), ("beta_b", vp), ("stats_b", vp), ("eps_a", f32), ("eps_b", f32)]
+
+
+class LatentTailArgs(C.Structure):
+    _fields_ = [("a3", vp), ("coef3", vp), ("w10", vp), ("b10", vp), ("gamma4", vp), ("beta4", vp), ("stats4", vp), ("z", vp),
+                ("eps4", f32), ("B", i32), ("C", i32), ("CR", i32), ("H", i32), ("W", i32), ("nres", i32),
+                ("res", LatentTailRes * 4)]
+
+
 OP, WV, EP = C.POINTER(Operand), C.POINTER(WeightView), C.POINTER(Epilogue)
 
 # name -> (restype, argtypes); every symbol include/dynamorph_hip.h declares
@@ -82,6 +93,8 @@ SIGNATURES = {
     "dm_sum_slabs_scatter": (C.c_int, [vp, C.c_int, C.c_int, f32, C.POINTER(Scatter), vp]),
     "dm_reduce_slabs_multi": (C.c_int, [C.POINTER(ReduceSeg), C.c_int, vp]),
     "dm_bn_running_replay": (C.c_int, [C.POINTER(ReplaySeg), C.c_int, vp]),
+    "dm_latent_tail_supported": (C.c_int, [C.c_int] * 5),
+    "dm_latent_tail_forward": (C.c_int, [C.POINTER(LatentTailArgs), vp]),
     "dm_head_supported": (C.c_int, [C.c_int] * 2),
     "dm_head_num_blocks": (C.c_int, [C.c_int] * 3),
     "dm_head_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),

@@ -31,6 +31,7 @@ from .ops import (DM_LOAD_AFFINE, DM_LOAD_AFFINE2, DM_LOAD_AFFINE_RELU, DM_LOAD_
 
 # DM_FUSED_BACKWARD=0 in the environment: the two-kernel backward of enc.4 (A/B measurements)
 import os as _os
+LATENT_TAIL = _os.environ.get("DM_LATENT_TAIL", "1") != "0"
 FUSED_BACKWARD = _os.environ.get("DM_FUSED_BACKWARD", "1") != "0"
 
 
@@ -111,10 +112,13 @@ def e1_operands(L):
     return ops.e1_compose_border(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight), _w(L.enc1.bias))
 
 
-def encoder_forward(L, x, per_sample=False, e1=None, join=True):
+def encoder_forward(L, x, per_sample=False, e1=None, join=True, latents_only=False):
     """x (B,NIN,H,W) -> z_before (B,nh,H/8,W/8).  per_sample=True normalises every BatchNorm with
     that sample's own statistics = pipeline/patch_VAE.py:445-452 (batch-of-one calls in train mode).
     e1: e1_operands(L) computed by the caller (inference: once per call).
+    latents_only (per_sample only): the caller wants z and the running statistics, nothing to differentiate through --
+    the 16 x 16 part of the encoder (enc.10 .. enc.12) then is ONE launch that keeps a patch on its CU
+    (ops.latent_tail_forward; DM_LATENT_TAIL=0 in the environment keeps the layer-by-layer kernels).
     join=False (per_sample only): the running-statistics replay -- a side effect no kernel of the path reads -- is left
     running on a helper stream beside whatever the caller launches next (the VectorQuantizer); the caller MUST call
     cx.join() before it hands the stream back (a HIP-graph capture cannot end with unjoined work)."""
@@ -142,6 +146,20 @@ def encoder_forward(L, x, per_sample=False, e1=None, join=True):
     n3 = H3 * W3 * (1 if ps else B)
     coef3, saved3 = _bn_coef(st, L.bn3, n3, ps, B, defer)
 
+    if (ps and latents_only and LATENT_TAIL and L.bn4.training and all(bna.training and bnb.training for _, bna, _, bnb in L.res)
+            and ops.latent_tail_supported(nh, nrh, H3, W3, len(L.res))):
+        mom = lambda bn: 0.1 if bn.momentum is None else bn.momentum
+        z, st4, sts = ops.latent_tail_forward(
+            a3, coef3, _w(L.enc10.weight), _w(L.enc10.bias), _w(L.bn4.weight), _w(L.bn4.bias), L.bn4.eps,
+            [(_w(ca.weight), _w(ca.bias), _w(bna.weight), _w(bna.bias), bna.eps, _w(cb.weight), _w(cb.bias), _w(bnb.weight),
+              _w(bnb.bias), bnb.eps) for ca, bna, cb, bnb in L.res])
+        defer.append((st4, 1, n3, L.bn4.running_mean, L.bn4.running_var, L.bn4.num_batches_tracked, mom(L.bn4)))
+        for (sa, sb), (_, bna, _, bnb) in zip(sts, L.res):
+            defer.append((sa, 1, n3, bna.running_mean, bna.running_var, bna.num_batches_tracked, mom(bna)))
+            defer.append((sb, 1, n3, bnb.running_mean, bnb.running_var, bnb.num_batches_tracked, mom(bnb)))
+        cx.__dict__.update(a1=a1, a2=a2, a3=a3, coef1=coef1, coef2=coef2, coef3=coef3, saved1=None, dims=(H1, W1, H2, W2, H3, W3))
+        _replay(cx, x, defer, join)
+        return z, cx
     a4, st = ops.conv3x3(Op(a3, DM_LOAD_AFFINE_RELU, coef3, per_sample=ps), weight_view(_w(L.enc10.weight), nh * 9, 9, 3, 1),
                          B, nh, nh, H3, W3, taps=9, want_stats=True, bias=_w(L.enc10.bias), per_tile=ps)
     coef4, saved4 = _bn_coef(st, L.bn4, n3, ps, B, defer)
@@ -150,6 +168,12 @@ def encoder_forward(L, x, per_sample=False, e1=None, join=True):
     cx.__dict__.update(a1=a1, a2=a2, a3=a3, a4=a4, coef1=coef1, coef2=coef2, coef3=coef3, coef4=coef4,
                        saved1=saved1, saved2=saved2, saved3=saved3, saved4=saved4, dims=(H1, W1, H2, W2, H3, W3))
     z, cx.res = residual_forward(L.res, h, ps, defer)
+    _replay(cx, x, defer, join)
+    return z, cx
+
+
+def _replay(cx, x, defer, join):
+    """The deferred running-statistics updates of the per-sample path, one launch on the helper stream."""
     if defer:
         cur = torch.cuda.current_stream(x.device)
         side = _side_stream(x.device)
@@ -161,7 +185,6 @@ def encoder_forward(L, x, per_sample=False, e1=None, join=True):
         cx.join = lambda: cur.wait_stream(side)
         if join:
             cx.join()
-    return z, cx
 
 
 def residual_forward(res_layers, h, per_sample=False, defer=None):

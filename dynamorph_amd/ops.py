@@ -411,6 +411,36 @@ def bn_running_replay(deferred):
         L.check(lib.dm_bn_running_replay(segs, len(chunk), _stream()), "dm_bn_running_replay")
 
 
+def latent_tail_supported(c, cr, h, w, nres):
+    return bool(L.load().dm_latent_tail_supported(c, cr, h, w, nres))
+
+
+@_op
+def latent_tail_forward(a3, coef3, w10, b10, gamma4, beta4, eps4, res):
+    """enc.10 .. enc.12 of every patch with that patch's own BatchNorm statistics, one launch (csrc/latent_tail.hip).
+    res: per residual layer (wa, ba, gamma_a, beta_a, eps_a, wb, bb, gamma_b, beta_b, eps_b).
+    Returns (z, stats4, [(stats_a, stats_b), ...]): the per-patch sums (B, C, 2) float64 for bn_running_replay."""
+    lib = L.load()
+    B, Cn, H, W = a3.shape
+    z = _new((B, Cn, H, W), a3)
+    st4 = _new((B, Cn, 2), a3, torch.float64)
+    args = L.LatentTailArgs()
+    args.a3, args.coef3, args.w10, args.b10 = _ptr(a3), _ptr(coef3), _ptr(w10), _ptr(b10)
+    args.gamma4, args.beta4, args.stats4, args.z = _ptr(gamma4), _ptr(beta4), _ptr(st4, torch.float64), _ptr(z)
+    args.eps4, args.B, args.C, args.H, args.W, args.nres = eps4, B, Cn, H, W, len(res)
+    args.CR = res[0][0].shape[0] if res else 32
+    sts = []
+    for i, (wa, ba, ga, bea, epsa, wb, bb, gb, beb, epsb) in enumerate(res):
+        sa = _new((B, wa.shape[0], 2), a3, torch.float64)
+        sb = _new((B, wb.shape[0], 2), a3, torch.float64)
+        r = args.res[i]
+        r.wa, r.ba, r.gamma_a, r.beta_a, r.stats_a, r.eps_a = _ptr(wa), _ptr(ba), _ptr(ga), _ptr(bea), _ptr(sa, torch.float64), epsa
+        r.wb, r.bb, r.gamma_b, r.beta_b, r.stats_b, r.eps_b = _ptr(wb), _ptr(bb), _ptr(gb), _ptr(beb), _ptr(sb, torch.float64), epsb
+        sts.append((sa, sb))
+    L.check(lib.dm_latent_tail_forward(C.byref(args), _stream()), "dm_latent_tail_forward")
+    return z, st4, sts
+
+
 @_op
 def bn_backward_finalize(stats, count, gamma, saved, dgamma, dbeta):
     lib = L.load()

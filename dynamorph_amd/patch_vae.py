@@ -35,7 +35,7 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
             nonlocal e1
             if e1 is None:
                 e1 = E.e1_operands(layers)
-            z, cx = E.encoder_forward(layers, x, per_sample=True, e1=e1, join=False)
+            z, cx = E.encoder_forward(layers, x, per_sample=True, e1=e1, join=False, latents_only=True)
             return z, cx.join
     elif isinstance(model, VQ_VAE_z32):
         enc = model.enc                     # children 0/1/3/4: conv, BatchNorm, conv, BatchNorm; 5: ResidualBlock

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 112
+#define DM_VERSION 113
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -260,6 +260,36 @@ typedef struct dm_bn_replay_seg {
     float momentum;
 } dm_bn_replay_seg;
 int dm_bn_running_replay(const dm_bn_replay_seg *segs, int nseg, void *stream);
+
+/* ----- the 16 x 16 part of the encoder, per-sample statistics, one kernel (csrc/latent_tail.hip) ----------------------
+ * Replaces vq_vae.py:287-289 (enc.10 Conv2d 3x3, enc.11 BatchNorm2d, enc.12 ResidualBlock = :203-224) as
+ * pipeline/patch_VAE.py:445-452 runs them: batch-of-one calls in train mode, i.e. every BatchNorm normalises a patch with
+ * that patch's own statistics.  A workgroup takes a patch from a3 (raw output of enc.7) to z (the encoder's output) with
+ * the activations in LDS / registers; the per-patch sums of the five (1 + 2 nres) BatchNorm inputs are written out as one
+ * slab per patch and layer for dm_bn_running_replay (slabs_per_group = 1, count_per_group = 256).
+ *   a3 (B,16,16,16); coef3 (B,16,4): per-sample coefficients of enc.8 from dm_bn_finalize(per_sample = 1);
+ *   w10 (16,16,3,3), b10 (16) or NULL; gamma4 / beta4 (16) or NULL (1 / 0); stats4 (B,16,2) doubles;
+ *   per residual layer: wa (32,16,3,3), ba (32), gamma_a / beta_a (32), stats_a (B,32,2); wb (16,32[,1,1]), bb (16),
+ *   gamma_b / beta_b (16), stats_b (B,16,2);  z (B,16,16,16).
+ * Built for num_hiddens 16, num_residual_hiddens 32, a 16 x 16 latent grid (128 x 128 patches), <= 4 residual layers:
+ * dm_latent_tail_supported() tells; other shapes take the layer-by-layer kernels. */
+typedef struct dm_latent_tail_res {
+    const float *wa, *ba, *gamma_a, *beta_a;
+    double *stats_a;
+    const float *wb, *bb, *gamma_b, *beta_b;
+    double *stats_b;
+    float eps_a, eps_b;
+} dm_latent_tail_res;
+typedef struct dm_latent_tail_args {
+    const float *a3, *coef3, *w10, *b10, *gamma4, *beta4;
+    double *stats4;
+    float *z;
+    float eps4;
+    int32_t B, C, CR, H, W, nres;
+    dm_latent_tail_res res[4];
+} dm_latent_tail_args;
+int dm_latent_tail_supported(int C, int CR, int H, int W, int nres);
+int dm_latent_tail_forward(const dm_latent_tail_args *args, void *stream);
 
 /* Backward finalize: slabs hold (sum dy, sum dy*a).  Writes dgamma, dbeta and the
  * AFFINE2 coefficients (A,B,C) with da = A*dy + B*a + C. */

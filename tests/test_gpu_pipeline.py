@@ -136,6 +136,50 @@ def test_encode_patches_per_sample_shape_sweep(N, nin, hw):
     np.testing.assert_allclose(m.enc[2].running_var.cpu().numpy(), ref.enc[2].running_var.numpy(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,nin", [(1, 2), (3, 2), (5, 4), (700, 2), (1024, 2)])
+def test_latent_tail_kernel_against_the_layer_by_layer_path_and_the_oracle(B, nin):
+    """enc.10 .. enc.12 of a patch inside one workgroup (csrc/latent_tail.hip, what encode_patches runs) vs the same layers
+    as separate launches, and vs the oracle's batch-of-one loop: latents, and the running statistics / batch counters of
+    ALL eight BatchNorm layers (the fused kernel writes the per-patch sums the replay kernel reads).  BatchNorm weights and
+    biases are randomised so that gamma / beta / bias plumbing is exercised."""
+    import copy
+    import dynamorph_amd
+    from dynamorph_amd import engine as E
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(9000 + B)
+    kw = dict(num_inputs=nin, channel_var=np.ones(nin))
+    ref = O.OracleVQVAE(**kw)
+    with torch.no_grad():
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.5, 0.5)
+    m1 = dynamorph_amd.VQ_VAE(**kw).to(DEV)
+    m1.load_state_dict(ref.state_dict())
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(B, nin, 128, 128, generator=torch.Generator().manual_seed(B)).to(DEV)
+    with torch.no_grad():
+        z1, _ = E.encoder_forward(E.Layers(m1), x, per_sample=True, latents_only=True)
+        z2, _ = E.encoder_forward(E.Layers(m2), x, per_sample=True)
+    torch.cuda.synchronize()
+    scale = z2.abs().max().item()
+    assert (z1 - z2).abs().max().item() <= 2e-5 * scale, ((z1 - z2).abs().max().item(), scale)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        if "running" in k:
+            assert torch.allclose(sd1[k], sd2[k], rtol=1e-5, atol=1e-7), k
+        if "tracked" in k:
+            assert int(sd1[k]) == int(sd2[k]) == B, k
+    if B <= 5:
+        with torch.no_grad():
+            zb_r, _ = O.encode_per_sample(ref, x.cpu())
+        assert (z1.cpu() - zb_r).abs().max().item() <= 3e-4 * max(1.0, zb_r.abs().max().item())
+        sd_r = ref.state_dict()
+        for k in sd1:
+            if "running" in k:
+                assert torch.allclose(sd1[k].cpu(), sd_r[k], rtol=2e-4, atol=2e-6), k
+
+
 @pytest.mark.parametrize("kw,N", [({}, 5), (dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512), 3)])
 def test_encode_patches_z32_per_sample(kw, N):
     """process_VAE semantics for VQ_VAE_z32 (the network config_example.yml names), default and example widths: the batched
