@@ -47,16 +47,40 @@ struct LtParams {
     int B, nres;
 };
 
-__device__ __forceinline__ double lt_xor_sum(double v, int mask)
+// sum of a double over the four 16-lane rows of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48): v_permlane16_swap /
+// v_permlane32_swap exchange two registers between partner rows in one instruction (no LDS round trip)
+__device__ __forceinline__ double lt_row_sum(double v)
 {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __shfl_xor((int)(b & 0xffffffffLL), mask, 64), hi = __shfl_xor((int)(b >> 32), mask, 64);
-    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    unsigned lo = (unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
+    unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    {
+        // (x, x): afterwards the even rows hold (own, partner's) and the odd rows (partner's, own)
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        const double p = __builtin_bit_cast(double, ((unsigned long long)b0 << 32) | a0);
+        const double r = __builtin_bit_cast(double, ((unsigned long long)b1 << 32) | a1);
+        v = p + r;
+    }
+    lo = (unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
+    hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        const double p = __builtin_bit_cast(double, ((unsigned long long)b0 << 32) | a0);
+        const double r = __builtin_bit_cast(double, ((unsigned long long)b1 << 32) | a1);
+        v = p + r;
+    }
+    return v;
 }
 
 // Per-sample statistics of a layer's raw output v (+ bias already added) and the BatchNorm coefficients of this lane's
 // channels: scale[nt], shift[nt] for channel 16 nt + n.  buf: [4 waves][NT][16][2] doubles of LDS, a different one from
-// the previous layer's.  One barrier.
+// the previous layer's.  One barrier.  Vector instructions here do not hide under the other workgroup's products (the
+// f32-input matrix instruction and the vector unit exclude each other), so the arithmetic is kept short: sums in double
+// (full rate), mean = sum / 256 as a multiplication, 1 / sqrt(var + eps) from v_rsq_f32 with two Newton steps in double
+// (agrees with (float)(1.0 / sqrt(x)) to the last bit but for rounding ties) instead of a double division and square root.
 template <int NT>
 __device__ __forceinline__ void lt_batchnorm(const f32x4 (&v)[4][NT], double *__restrict__ buf, const float *__restrict__ gamma,
                                              const float *__restrict__ beta, float eps, double *__restrict__ slab, int wave,
@@ -73,8 +97,8 @@ __device__ __forceinline__ void lt_batchnorm(const f32x4 (&v)[4][NT], double *__
                 const double d = (double)v[mt][nt][r];
                 s1 += d; s2 += d * d;
             }
-        s1 = lt_xor_sum(lt_xor_sum(s1, 16), 32);
-        s2 = lt_xor_sum(lt_xor_sum(s2, 16), 32);
+        s1 = lt_row_sum(s1);
+        s2 = lt_row_sum(s2);
         if (q == 0) {
             buf[((wave * NT + nt) * 16 + n) * 2 + 0] = s1;
             buf[((wave * NT + nt) * 16 + n) * 2 + 1] = s2;
@@ -89,12 +113,16 @@ __device__ __forceinline__ void lt_batchnorm(const f32x4 (&v)[4][NT], double *__
             t1 += buf[((w * NT + nt) * 16 + n) * 2 + 0];
             t2 += buf[((w * NT + nt) * 16 + n) * 2 + 1];
         }
-        const double cnt = (double)(LT_HW * LT_HW);
-        const double mean = t1 / cnt;
-        double var = t2 / cnt - mean * mean;
+        constexpr double inv_cnt = 1.0 / (double)(LT_HW * LT_HW);      // (a power of two: the product is the quotient)
+        const double mean = t1 * inv_cnt;
+        double var = t2 * inv_cnt - mean * mean;
         if (var < 0.0) var = 0.0;
         const float mean_f = (float)mean;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const double xv = var + (double)eps;
+        double y = (double)__builtin_amdgcn_rsqf((float)xv);           // ~1 ulp of float; two Newton steps: ~1e-15
+        y = y * (1.5 - 0.5 * xv * y * y);
+        y = y * (1.5 - 0.5 * xv * y * y);
+        const float invstd = (float)y;
         const float g = gamma ? gamma[16 * nt + n] : 1.f, bt = beta ? beta[16 * nt + n] : 0.f;
         scale[nt] = g * invstd;
         shift[nt] = bt - mean_f * scale[nt];
