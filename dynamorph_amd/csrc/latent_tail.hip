@@ -44,7 +44,7 @@ struct LtParams {
     double *sta[LT_MAX_RES], *stb[LT_MAX_RES];     // (B,32,2), (B,16,2)
     float *z;                 // (B,16,16,16)
     float eps4, epsa[LT_MAX_RES], epsb[LT_MAX_RES];
-    int B, nres;
+    int B, nres, dbg;          // dbg: measurement only (DM_LT_DBG, tools/exp/lt_bench.py): 1 no products, 2 no statistics arithmetic, 4 no weight loads
 };
 
 // sum of a double over the four 16-lane rows of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48): v_permlane16_swap /
@@ -84,9 +84,15 @@ __device__ __forceinline__ double lt_row_sum(double v)
 template <int NT>
 __device__ __forceinline__ void lt_batchnorm(const f32x4 (&v)[4][NT], double *__restrict__ buf, const float *__restrict__ gamma,
                                              const float *__restrict__ beta, float eps, double *__restrict__ slab, int wave,
-                                             int lane, float (&scale)[NT], float (&shift)[NT])
+                                             int lane, float (&scale)[NT], float (&shift)[NT], int dbg)
 {
     const int n = lane & 15, q = lane >> 4;
+    if (dbg & 2) {                                             // (measurement: barrier only)
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { scale[nt] = 1.f; shift[nt] = 0.f; }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         double s1 = 0.0, s2 = 0.0;
@@ -142,6 +148,7 @@ __device__ __forceinline__ void lt_load_w3(const float *__restrict__ w, int lane
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s = 0; s < 36; ++s) wreg[nt][s] = w[((16 * nt + n) * LT_C + 4 * (s & 3) + q) * 9 + (s >> 2)];
+
 }
 
 __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
@@ -196,13 +203,13 @@ __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
             f32x4 acc[4][1];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mfma_tiles<4, 1, 36, 4>(apT, reinterpret_cast<const float(&)[1][36]>(w3), acc, off3);
-            if (P.nres > 0) lt_load_w3<2>(P.wa[0], lane, w3);
+            if (!(P.dbg & 1)) mfma_tiles<4, 1, 36, 4>(apT, reinterpret_cast<const float(&)[1][36]>(w3), acc, off3);
+            if (P.nres > 0 && !(P.dbg & 4)) lt_load_w3<2>(P.wa[0], lane, w3);
             const float bias = P.b10 ? P.b10[n] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt][0] = acc[mt][0] + bias;
             float sc[1], sh[1];
-            lt_batchnorm<1>(acc, s_stat[0], P.g4, P.be4, P.eps4, P.st4 + (long long)b * LT_C * 2, wave, lane, sc, sh);
+            lt_batchnorm<1>(acc, s_stat[0], P.g4, P.be4, P.eps4, P.st4 + (long long)b * LT_C * 2, wave, lane, sc, sh, P.dbg);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) h[mt] = sc[0] * acc[mt][0] + sh[0];
         }
@@ -219,14 +226,14 @@ __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
                 f32x4 acc[4][2];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-                mfma_tiles<4, 2, 36, 2>(apT, w3, acc, off3);
+                if (!(P.dbg & 1)) mfma_tiles<4, 2, 36, 2>(apT, w3, acc, off3);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) w1[0][s] = P.wb[l][n * LT_CR + 4 * s + q];
                 const float b0 = P.ba[l] ? P.ba[l][n] : 0.f, b1 = P.ba[l] ? P.ba[l][16 + n] : 0.f;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = acc[mt][0] + b0; acc[mt][1] = acc[mt][1] + b1; }
                 float sc[2], sh[2];
-                lt_batchnorm<2>(acc, s_stat[1], P.ga[l], P.bea[l], P.epsa[l], P.sta[l] + (long long)b * LT_CR * 2, wave, lane, sc, sh);
+                lt_batchnorm<2>(acc, s_stat[1], P.ga[l], P.bea[l], P.epsa[l], P.sta[l] + (long long)b * LT_CR * 2, wave, lane, sc, sh, P.dbg);
                 // (U's previous readers are behind the barrier inside lt_batchnorm)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -241,13 +248,13 @@ __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
                 f32x4 acc[4][1];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                mfma_tiles<4, 1, 8, 4>(apU, w1, acc, off1);
-                if (l + 1 < P.nres) lt_load_w3<2>(P.wa[l + 1], lane, w3);
+                if (!(P.dbg & 1)) mfma_tiles<4, 1, 8, 4>(apU, w1, acc, off1);
+                if (l + 1 < P.nres && !(P.dbg & 4)) lt_load_w3<2>(P.wa[l + 1], lane, w3);
                 const float bias = P.bb[l] ? P.bb[l][n] : 0.f;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[mt][0] = acc[mt][0] + bias;
                 float sc[1], sh[1];
-                lt_batchnorm<1>(acc, s_stat[0], P.gb[l], P.beb[l], P.epsb[l], P.stb[l] + (long long)b * LT_C * 2, wave, lane, sc, sh);
+                lt_batchnorm<1>(acc, s_stat[0], P.gb[l], P.beb[l], P.epsb[l], P.stb[l] + (long long)b * LT_C * 2, wave, lane, sc, sh, P.dbg);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) h[mt] = h[mt] + (sc[0] * acc[mt][0] + sh[0]);
             }
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
             *reinterpret_cast<f32x4 *>(P.z + (long long)b * (LT_C * 256) + n * 256 + (4 * wave + mt) * LT_HW + 4 * q) = h[mt];
-        if (nb < P.B) lt_load_w3<1>(P.w10, lane, reinterpret_cast<float(&)[1][36]>(w3));
+        if (nb < P.B && !(P.dbg & 4)) lt_load_w3<1>(P.w10, lane, reinterpret_cast<float(&)[1][36]>(w3));
         // (T is rewritten at the top of the loop: its last readers are behind at least one barrier)
     }
 }
@@ -279,6 +286,8 @@ extern "C" int dm_latent_tail_forward(const dm_latent_tail_args *a, void *stream
     LtParams P;
     P.a3 = a->a3; P.coef3 = a->coef3; P.w10 = a->w10; P.b10 = a->b10; P.g4 = a->gamma4; P.be4 = a->beta4; P.st4 = a->stats4;
     P.eps4 = a->eps4; P.z = a->z; P.B = a->B; P.nres = a->nres;
+    static const int dbg = [] { const char *e = getenv("DM_LT_DBG"); return e ? atoi(e) : 0; }();
+    P.dbg = dbg;
     for (int l = 0; l < LT_MAX_RES; ++l) {
         const bool on = l < a->nres;
         if (on)
