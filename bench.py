@@ -183,7 +183,12 @@ def roofline_dominant_kernel(model, x, workload):
         name = f"dec_tail_backward_kernel<{NIN}, true> (dm_dec_tail_train: dec.4/dec.5/dec.6 + loss, forward and backward fused)"
         # read d2 and x once, write g2 once
         algo_bytes = B * (2 * c2 * (H // 2) * (W // 2) + NIN * H * W) * 4
-    ms = event_time_ms(fn)
+    # ten launches captured in one HIP graph and replayed, events on the launch stream around the replays: the average is
+    # the kernel's (a fresh box's first eager launches can be host-bound: allocations, the ctypes call)
+    def ten():
+        for _ in range(10):
+            fn()
+    ms = event_time_ms(graphed(ten), iters=5, warmup=2) / 10.0
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key, B), "avg_launch_ms": round(ms, 4),
@@ -195,8 +200,10 @@ def north_star_targets(model, x):
     stream (the same kernels the timed step replays):
       vq        -- VectorQuantizer distance + argmin (+ gather, straight-through value, squared error, code counters):
                    34 816 algorithmic bytes per patch / average launch of the distance kernel alone
-                   (dm_vq_forward_repeat: T(21 launches) - T(1 launch), prepared codebook); `call_ms` is the whole
-                   dm_vq_forward (codebook preparation + that kernel + counter reduction) as the step pays it;
+                   (dm_vq_forward_repeat: T(21 launches) - T(1 launch)); `call_ms` is the whole dm_vq_forward as the
+                   training step and the inference path call it (hist = NULL: one launch -- the step's single scalar launch
+                   reads the per-workgroup counters from the workspace), `call_with_hist_ms` the stand-alone form that also
+                   reduces the counters into `hist` (two launches);
       enc_convs -- every forward convolution of the encoder: useful FLOPs (2 x MACs of SURVEY 2.2) / average launch
                    (inside a HIP graph of 10 launches, as the step replays them), against the f32 MFMA peak."""
     from dynamorph_amd import engine as E
@@ -212,17 +219,19 @@ def north_star_targets(model, x):
     bufs = ops.vq_forward_repeat(z, cbk, 1)
     t1 = event_time_ms(lambda: ops.vq_forward_repeat(z, cbk, 1, bufs=bufs), iters=30, warmup=5)
     t21 = event_time_ms(lambda: ops.vq_forward_repeat(z, cbk, 21, bufs=bufs), iters=10, warmup=2)
-    # back-to-back calls from the host are launch bound (three launches per call): the whole call is timed as a graph replay
-    g = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        ops.vq_forward_repeat(z, cbk, 1, bufs=bufs)
-    torch.cuda.current_stream().wait_stream(side)
-    with torch.cuda.graph(g):
-        for _ in range(10):
-            ops.vq_forward_repeat(z, cbk, 1, bufs=bufs)
-    call_ms = event_time_ms(g.replay, iters=10, warmup=2) / 10
+    # back-to-back calls from the host are launch bound: the whole call is timed as a graph replay of ten
+    def call_time(want_hist):
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.vq_forward_repeat(z, cbk, 1, bufs=bufs, want_hist=want_hist)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g):
+            for _ in range(10):
+                ops.vq_forward_repeat(z, cbk, 1, bufs=bufs, want_hist=want_hist)
+        return event_time_ms(g.replay, iters=10, warmup=2) / 10
+    call_ms, call_hist_ms = call_time(False), call_time(True)
     k_ms = max((t21 - t1) / 20.0, 1e-6)
     D = z.shape[1]
     P = z.shape[0] * z.shape[2] * z.shape[3]
@@ -230,6 +239,7 @@ def north_star_targets(model, x):
     vq = {"kernel": "vq_forward_mfma_kernel (MFMA filter + exact re-check)", "bytes": vq_bytes, "avg_launch_ms": round(k_ms, 5),
           "frac_hbm": round(vq_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "call_ms": round(call_ms, 5),
           "call_frac_hbm": round(vq_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+          "call_with_hist_ms": round(call_hist_ms, 5),
           "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()) // 1}
     # ---- encoder forward convolutions, on the step's own activations
     nh, nrh, c1 = L.nh, L.nrh, L.nh // 2

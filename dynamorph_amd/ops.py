@@ -141,10 +141,12 @@ def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, 
 
 
 @_op
-def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None):
+def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None, want_hist=True):
     """Measurement helper (include/dynamorph_hip.h, dm_vq_forward_repeat): one preparation, `repeats` launches of the
     distance / argmin kernel, one counter reduction, on preallocated buffers `bufs` (from a first call) so that nothing is
-    allocated inside a timed region.  Returns bufs."""
+    allocated inside a timed region.  want_hist=False: hist = NULL, i.e. no counter reduction -- how the training step and
+    the inference path call dm_vq_forward (their counters are read from the workspace by the step's one scalar launch, or
+    not at all).  Returns bufs."""
     lib = L.load()
     B, D, H, W = z.shape
     K = codebook.shape[0]
@@ -154,7 +156,8 @@ def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None):
                 _new((K,), z, torch.int32), _new((wsb // 4,), z), wsb)
     idx, out, slabs, hist, ws, wsb = bufs
     L.check(lib.dm_vq_forward_repeat(_ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out), _ptr(slabs, torch.float64),
-                                     _ptr(hist, torch.int32), B, D, K, H, W, _ptr(ws), wsb, variant, repeats, _stream()),
+                                     _ptr(hist if want_hist else None, torch.int32), B, D, K, H, W, _ptr(ws), wsb, variant,
+                                     repeats, _stream()),
             "dm_vq_forward_repeat")
     return bufs
 
