@@ -1145,6 +1145,53 @@ def test_dec_tail_fused_forward_backward(ops, nin, masked, B, hw):
     close(flat_t[nin * c + nin + c:], pre.grad.sum((0, 2, 3)), 1e-4, 1e-4 * sc(pre.grad.sum((0, 2, 3))), "train: db2")
 
 
+# ===================================================================== latent tail (inference path, per-sample statistics)
+@pytest.mark.parametrize("B,nres", [(1, 2), (3, 0), (2, 1), (5, 3), (4, 4), (600, 2)])
+def test_latent_tail_kernel_vs_aten_batch_of_one_calls(ops, B, nres):
+    """dm_latent_tail_forward (enc.10 + enc.11 + nres residual layers of every patch, per-patch BatchNorm statistics)
+    against the ATen composition called one patch at a time in train mode -- the arithmetic of patch_VAE.py:445-452 on
+    vq_vae.py:287-289 / :203-224 -- for 0..4 residual layers, random BatchNorm weights / biases / conv biases; and the
+    per-patch sums it writes for the running-statistics replay."""
+    C, CR = 16, 32
+    g = torch.Generator().manual_seed(100 * B + nres)
+    r = lambda *s, k=1.0: torch.randn(*s, generator=g) * k
+    a3 = r(B, C, 16, 16)
+    coef3 = torch.stack([r(B, C).abs() + 0.5, torch.zeros(B, C), r(B, C, k=0.3), torch.zeros(B, C)], 2).contiguous()
+    w10, b10, g4, be4 = r(C, C, 3, 3, k=0.15), r(C, k=0.2), r(C).abs() + 0.5, r(C, k=0.3)
+    res = [(r(CR, C, 3, 3, k=0.15), r(CR, k=0.2), r(CR).abs() + 0.5, r(CR, k=0.3), 1e-5,
+            r(C, CR, 1, 1, k=0.2), r(C, k=0.2), r(C).abs() + 0.5, r(C, k=0.3), 1e-5) for _ in range(nres)]
+    assert ops.latent_tail_supported(C, CR, 16, 16, nres) and not ops.latent_tail_supported(C, CR, 16, 16, 5)
+
+    def bn(v, gam, bet):                                   # batch-of-one train-mode BatchNorm
+        return F.batch_norm(v, None, None, gam, bet, True, 0.1, 1e-5)
+    nref = min(B, 6)
+    zs, sums = [], []
+    for i in range(nref):
+        t = torch.relu(coef3[i, :, 0].reshape(1, C, 1, 1) * a3[i:i + 1] + coef3[i, :, 2].reshape(1, C, 1, 1))
+        a4 = F.conv2d(t, w10, b10, padding=1)
+        per = [a4]
+        h = bn(a4, g4, be4)
+        for wa, ba, ga, bea, _, wb, bb, gb, beb, _ in res:
+            ra = F.conv2d(torch.relu(h), wa, ba, padding=1)
+            rb = F.conv2d(torch.relu(bn(ra, ga, bea)), wb, bb)
+            per += [ra, rb]
+            h = h + bn(rb, gb, beb)
+        zs.append(h)
+        sums.append([torch.stack([v.double().sum((0, 2, 3)), (v.double() ** 2).sum((0, 2, 3))], 1) for v in per])
+    d = lambda t: t.to(DEV).contiguous()
+    z, st4, sts = ops.latent_tail_forward(d(a3), d(coef3), d(w10), d(b10), d(g4), d(be4), 1e-5,
+                                          [tuple(d(v) if torch.is_tensor(v) else v for v in layer) for layer in res])
+    torch.cuda.synchronize()
+    assert z.shape == (B, C, 16, 16) and st4.shape == (B, C, 2) and len(sts) == nres
+    zr = torch.cat(zs, 0)
+    close(z[:nref], zr, 2e-5, 2e-5 * max(1.0, zr.abs().max().item()), "z")
+    assert bool(torch.isfinite(z).all())
+    flat = [st4] + [t for pair in sts for t in pair]
+    for i in range(nref):
+        for got, want in zip(flat, sums[i]):
+            assert torch.allclose(got[i].cpu(), want, rtol=1e-5, atol=1e-4), (i, got.shape)
+
+
 def _neg_nan():
     """x86's default NaN (0/0 on the host): 0xFFC00000, sign bit set."""
     return torch.tensor([-4194304], dtype=torch.int32).view(torch.float32)[0]
