@@ -52,7 +52,8 @@ class LatentTailRes(C.Structure):
 class LatentTailArgs(C.Structure):
     _fields_ = [("a3", vp), ("coef3", vp), ("w10", vp), ("b10", vp), ("gamma4", vp), ("beta4", vp), ("stats4", vp), ("z", vp),
                 ("eps4", f32), ("B", i32), ("C", i32), ("CR", i32), ("H", i32), ("W", i32), ("nres", i32),
-                ("res", LatentTailRes * 4)]
+                ("res", LatentTailRes * 4),
+                ("a2", vp), ("coef2", vp), ("w7", vp), ("b7", vp), ("gamma3", vp), ("beta3", vp), ("stats3", vp), ("eps3", f32)]
 
 
 OP, WV, EP = C.POINTER(Operand), C.POINTER(WeightView), C.POINTER(Epilogue)

@@ -39,6 +39,11 @@ struct LtParams {
     const float *coef3;       // (B,16,4) per-sample BatchNorm coefficients of enc.8 (dm_bn_finalize, per-sample form)
     const float *w10, *b10, *g4, *be4;
     double *st4;              // (B,16,2) sums of enc.10's output (for the running statistics)
+    // E7 form: the patch enters as a2 (raw output of enc.4, 16 x 32 x 32) and enc.7 / enc.8 run here too
+    const float *a2, *coef2;  // (B,16,32,32); (B,16,4) per-sample coefficients of enc.5
+    const float *w7, *b7, *g3, *be3;
+    double *st3;              // (B,16,2) sums of enc.7's output
+    float eps3;
     const float *wa[LT_MAX_RES], *ba[LT_MAX_RES], *ga[LT_MAX_RES], *bea[LT_MAX_RES];
     const float *wb[LT_MAX_RES], *bb[LT_MAX_RES], *gb[LT_MAX_RES], *beb[LT_MAX_RES];
     double *sta[LT_MAX_RES], *stb[LT_MAX_RES];     // (B,32,2), (B,16,2)
@@ -151,10 +156,16 @@ __device__ __forceinline__ void lt_load_w3(const float *__restrict__ w, int lane
 
 }
 
+// E7: the kernel starts one layer earlier, at a2 (enc.4's raw output): enc.7's 4x4 / stride-2 product runs on the two
+// halves of the patch (8 output rows each: a 16 x 18 x 40 input tile, BatchNorm + ReLU of enc.5 / enc.6 applied on the way in,
+// laid over T and U, which are dead then), its statistics and enc.8's coefficients are taken in registers like the others.
+constexpr int LT_E_RS = 40, LT_E_PS = 18 * LT_E_RS;          // the 4x4 / stride-2 input tile: column x at j = x + 4
+template <bool E7>
 __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
 {
-    __shared__ __attribute__((aligned(16))) float sT[LT_C * LT_PS];
-    __shared__ __attribute__((aligned(16))) float sU[LT_CR * LT_UPS];
+    __shared__ __attribute__((aligned(16))) float s_all[LT_C * LT_PS + LT_CR * LT_UPS];
+    float *const sT = s_all, *const sU = s_all + LT_C * LT_PS;
+    static_assert(LT_C * LT_E_PS <= LT_C * LT_PS + LT_CR * LT_UPS, "the enc.7 input tile fits over T and U");
     __shared__ double s_stat[2][4 * 2 * 16 * 2];
 
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
@@ -174,19 +185,80 @@ __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
     auto off1 = [](int s) { return 4 * s * LT_UPS; };
 
     // this thread's part of a3: four 16-byte pieces (channel i >> 6, row (i & 63) >> 2, columns 4 (i & 3) ..)
-    f32x4 pre[4];
+    f32x4 pre[E7 ? 1 : 4];
     auto fetch = [&](int b) {
+        if constexpr (!E7) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            pre[j] = *reinterpret_cast<const f32x4 *>(P.a3 + (long long)b * (LT_C * 256) + 4 * (threadIdx.x + LT_BLOCK * j));
+            for (int j = 0; j < 4; ++j)
+                pre[j] = *reinterpret_cast<const f32x4 *>(P.a3 + (long long)b * (LT_C * 256) + 4 * (threadIdx.x + LT_BLOCK * j));
+        }
     };
     int b = blockIdx.x;
     if (b < P.B) fetch(b);
     float w3[2][36];
-    lt_load_w3<1>(P.w10, lane, reinterpret_cast<float(&)[1][36]>(w3));
+    // enc.7's weights as B operands: step s = 4 c + ky, k lane = kx (the operand layout of conv4x4s2_kernel, conv_mfma.hip)
+    auto load_w7 = [&]() {
+        float(&w7)[72] = reinterpret_cast<float(&)[72]>(w3);
+#pragma unroll
+        for (int s = 0; s < 64; ++s) w7[s] = P.w7[((n * LT_C + (s >> 2)) * 4 + (s & 3)) * 4 + q];
+    };
+    if constexpr (E7) load_w7();
+    else lt_load_w3<1>(P.w10, lane, reinterpret_cast<float(&)[1][36]>(w3));
     __syncthreads();
 
     for (; b < P.B; b += gridDim.x) {
+        const int nb = b + gridDim.x;
+        if constexpr (E7) {
+            // ---- enc.7 + enc.8 + enc.9: T <- relu(BatchNorm(conv4x4s2(relu(BatchNorm(a2))))) ------------------------------
+            f32x4 a3r[4][1];
+            float *const tile = s_all;
+            const float *ap7[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ap7[i] = tile + 2 * (2 * wave + i) * LT_E_RS + 2 * n + q + 3;
+            auto off7 = [](int s) { return (s >> 2) * LT_E_PS + (s & 3) * LT_E_RS; };
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                if (half) __syncthreads();                     // the first half's readers are done with the tile
+                // (half 0: the previous patch's last readers of T / U are behind its last statistics barrier)
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    const int e = threadIdx.x + LT_BLOCK * j;  // (channel, tile row, 16-byte column): 16 x 18 x 10
+                    const int c = e / 180, rem = e - c * 180, row = rem / 10, qq = rem - row * 10;
+                    const int gy = 16 * half - 1 + row;
+                    const bool in = e < 2880 && qq >= 1 && qq <= 8 && (unsigned)gy < 32u;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (in) {
+                        const f32x4 cf = *reinterpret_cast<const f32x4 *>(P.coef2 + ((long long)b * LT_C + c) * 4);
+                        v = *reinterpret_cast<const f32x4 *>(P.a2 + (((long long)b * LT_C + c) * 32 + gy) * 32 + 4 * (qq - 1));
+                        v = dm_relu4(cf.x * v + cf.z);
+                    }
+                    if (e < 2880) *reinterpret_cast<f32x4 *>(tile + c * LT_E_PS + row * LT_E_RS + 4 * qq) = v;
+                }
+                __syncthreads();
+                f32x4 acc[2][1];
+                acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(P.dbg & 1)) mfma_tiles<2, 1, 64, 4>(ap7, reinterpret_cast<const float(&)[1][64]>(w3), acc, off7);
+                a3r[2 * half][0] = acc[0][0]; a3r[2 * half + 1][0] = acc[1][0];
+            }
+            lt_load_w3<1>(P.w10, lane, reinterpret_cast<float(&)[1][36]>(w3));      // enc.10's weights: under the statistics
+            const float bias7 = P.b7 ? P.b7[n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a3r[mt][0] = a3r[mt][0] + bias7;
+            float sc[1], sh[1];
+            lt_batchnorm<1>(a3r, s_stat[1], P.g3, P.be3, P.eps3, P.st3 + (long long)b * LT_C * 2, wave, lane, sc, sh, P.dbg);
+            // (the tile is dead: every wave is past its products)  T, with its zero padding (the tile lay over it)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int y = 8 * (mt >> 1) + 2 * wave + (mt & 1);
+                float *rowp = sT + n * LT_PS + (y + 1) * LT_RS;
+                *reinterpret_cast<f32x4 *>(rowp + 4 + 4 * q) = dm_relu4(sc[0] * a3r[mt][0] + sh[0]);
+                if (q == 0) rowp[3] = 0.f;
+                if (q == 3) rowp[20] = 0.f;
+            }
+            if (wave == 0 || wave == 3)
+                for (int i = lane; i < LT_C * LT_RS; i += 64) sT[(i / LT_RS) * LT_PS + (wave ? 17 : 0) * LT_RS + i % LT_RS] = 0.f;
+            __syncthreads();
+        } else {
         // ---- T <- relu(BatchNorm(a3)) (per-sample coefficients of enc.8) -------------------------------------------
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -194,8 +266,8 @@ __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
             const f32x4 cf = *reinterpret_cast<const f32x4 *>(P.coef3 + ((long long)b * LT_C + c) * 4);
             *reinterpret_cast<f32x4 *>(sT + c * LT_PS + (y + 1) * LT_RS + 4 + 4 * x4) = dm_relu4(cf.x * pre[j] + cf.z);
         }
-        const int nb = b + gridDim.x;
         __syncthreads();
+        }
 
         // ---- enc.10 + enc.11: h = BatchNorm(conv3x3(T)) ------------------------------------------------------------
         f32x4 h[4];
@@ -264,7 +336,10 @@ __global__ __launch_bounds__(LT_BLOCK, 2) void latent_tail_kernel(LtParams P)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
             *reinterpret_cast<f32x4 *>(P.z + (long long)b * (LT_C * 256) + n * 256 + (4 * wave + mt) * LT_HW + 4 * q) = h[mt];
-        if (nb < P.B && !(P.dbg & 4)) lt_load_w3<1>(P.w10, lane, reinterpret_cast<float(&)[1][36]>(w3));
+        if (nb < P.B && !(P.dbg & 4)) {
+            if constexpr (E7) load_w7();
+            else lt_load_w3<1>(P.w10, lane, reinterpret_cast<float(&)[1][36]>(w3));
+        }
         // (T is rewritten at the top of the loop: its last readers are behind at least one barrier)
     }
 }
@@ -282,10 +357,14 @@ extern "C" int dm_latent_tail_forward(const dm_latent_tail_args *a, void *stream
     DM_REQUIRE(dm_latent_tail_supported(a->C, a->CR, a->H, a->W, a->nres), "dm_latent_tail_forward: built for 16 channels, 32 residual "
                "channels on a 16 x 16 latent grid, at most %d residual layers (got %d / %d on %d x %d, %d layers)", LT_MAX_RES,
                a->C, a->CR, a->H, a->W, a->nres);
-    DM_REQUIRE(a->B > 0 && a->a3 && a->coef3 && a->w10 && a->stats4 && a->z, "dm_latent_tail_forward: NULL pointer");
+    const bool e7 = a->a2 != nullptr;
+    DM_REQUIRE(a->B > 0 && a->w10 && a->stats4 && a->z, "dm_latent_tail_forward: NULL pointer");
+    DM_REQUIRE(e7 ? (a->coef2 && a->w7 && a->stats3) : (a->a3 && a->coef3),
+               "dm_latent_tail_forward: give (a3, coef3) or (a2, coef2, w7, stats3)");
     LtParams P;
     P.a3 = a->a3; P.coef3 = a->coef3; P.w10 = a->w10; P.b10 = a->b10; P.g4 = a->gamma4; P.be4 = a->beta4; P.st4 = a->stats4;
     P.eps4 = a->eps4; P.z = a->z; P.B = a->B; P.nres = a->nres;
+    P.a2 = a->a2; P.coef2 = a->coef2; P.w7 = a->w7; P.b7 = a->b7; P.g3 = a->gamma3; P.be3 = a->beta3; P.st3 = a->stats3; P.eps3 = a->eps3;
     static const int dbg = [] { const char *e = getenv("DM_LT_DBG"); return e ? atoi(e) : 0; }();
     P.dbg = dbg;
     for (int l = 0; l < LT_MAX_RES; ++l) {
@@ -300,6 +379,7 @@ extern "C" int dm_latent_tail_forward(const dm_latent_tail_args *a, void *stream
         P.epsa[l] = on ? a->res[l].eps_a : 0.f; P.epsb[l] = on ? a->res[l].eps_b : 0.f;
     }
     const int grid = a->B < 512 ? a->B : 512;                 // two workgroups per CU
-    hipLaunchKernelGGL(latent_tail_kernel, dim3(grid), dim3(LT_BLOCK), 0, (hipStream_t)stream, P);
+    if (e7) hipLaunchKernelGGL(latent_tail_kernel<true>, dim3(grid), dim3(LT_BLOCK), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(latent_tail_kernel<false>, dim3(grid), dim3(LT_BLOCK), 0, (hipStream_t)stream, P);
     return dm_launch_status("dm_latent_tail_forward");
 }

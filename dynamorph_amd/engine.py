@@ -32,6 +32,9 @@ from .ops import (DM_LOAD_AFFINE, DM_LOAD_AFFINE2, DM_LOAD_AFFINE_RELU, DM_LOAD_
 # DM_FUSED_BACKWARD=0 in the environment: the two-kernel backward of enc.4 (A/B measurements)
 import os as _os
 LATENT_TAIL = _os.environ.get("DM_LATENT_TAIL", "1") != "0"
+# ... starting one layer earlier, at enc.7: built and tested, but measured slower (C2 0.354 vs 0.320 ms: the 46 KB input
+# tile of the strided convolution is staged twice per patch with its loads exposed, and the instantiation spills) -- opt-in
+LATENT_TAIL_E7 = _os.environ.get("DM_LATENT_TAIL_E7", "0") == "1"
 FUSED_BACKWARD = _os.environ.get("DM_FUSED_BACKWARD", "1") != "0"
 
 
@@ -141,22 +144,37 @@ def encoder_forward(L, x, per_sample=False, e1=None, join=True, latents_only=Fal
     coef2, saved2 = _bn_coef(st, L.bn2, H2 * W2 * (1 if ps else B), ps, B, defer)
 
     H3, W3 = H2 // 2, W2 // 2
-    a3, st = ops.conv4x4s2(Op(a2, DM_LOAD_AFFINE_RELU, coef2, per_sample=ps), weight_view(_w(L.enc7.weight), nh * 16, 16, 4, 1),
-                           B, nh, nh, H2, W2, want_stats=True, bias=_w(L.enc7.bias), per_tile=ps)
     n3 = H3 * W3 * (1 if ps else B)
-    coef3, saved3 = _bn_coef(st, L.bn3, n3, ps, B, defer)
+    fuse_tail = (ps and latents_only and LATENT_TAIL and L.bn3.training and L.bn4.training
+                 and all(bna.training and bnb.training for _, bna, _, bnb in L.res)
+                 and ops.latent_tail_supported(nh, nrh, H3, W3, len(L.res)))
+    mom = lambda bn: 0.1 if bn.momentum is None else bn.momentum
+    res_args = lambda: [(_w(ca.weight), _w(ca.bias), _w(bna.weight), _w(bna.bias), bna.eps, _w(cb.weight), _w(cb.bias),
+                         _w(bnb.weight), _w(bnb.bias), bnb.eps) for ca, bna, cb, bnb in L.res]
 
-    if (ps and latents_only and LATENT_TAIL and L.bn4.training and all(bna.training and bnb.training for _, bna, _, bnb in L.res)
-            and ops.latent_tail_supported(nh, nrh, H3, W3, len(L.res))):
-        mom = lambda bn: 0.1 if bn.momentum is None else bn.momentum
-        z, st4, sts = ops.latent_tail_forward(
-            a3, coef3, _w(L.enc10.weight), _w(L.enc10.bias), _w(L.bn4.weight), _w(L.bn4.bias), L.bn4.eps,
-            [(_w(ca.weight), _w(ca.bias), _w(bna.weight), _w(bna.bias), bna.eps, _w(cb.weight), _w(cb.bias), _w(bnb.weight),
-              _w(bnb.bias), bnb.eps) for ca, bna, cb, bnb in L.res])
+    def defer_tail(st4, sts):
         defer.append((st4, 1, n3, L.bn4.running_mean, L.bn4.running_var, L.bn4.num_batches_tracked, mom(L.bn4)))
         for (sa, sb), (_, bna, _, bnb) in zip(sts, L.res):
             defer.append((sa, 1, n3, bna.running_mean, bna.running_var, bna.num_batches_tracked, mom(bna)))
             defer.append((sb, 1, n3, bnb.running_mean, bnb.running_var, bnb.num_batches_tracked, mom(bnb)))
+    if fuse_tail and LATENT_TAIL_E7:
+        # enc.7 .. enc.12 of a patch in one workgroup, from a2 (csrc/latent_tail.hip, E7 form)
+        z, st4, sts, st3 = ops.latent_tail_forward(
+            None, None, _w(L.enc10.weight), _w(L.enc10.bias), _w(L.bn4.weight), _w(L.bn4.bias), L.bn4.eps, res_args(),
+            enc7=(a2, coef2, _w(L.enc7.weight), _w(L.enc7.bias), _w(L.bn3.weight), _w(L.bn3.bias), L.bn3.eps))
+        defer.append((st3, 1, n3, L.bn3.running_mean, L.bn3.running_var, L.bn3.num_batches_tracked, mom(L.bn3)))
+        defer_tail(st4, sts)
+        cx.__dict__.update(a1=a1, a2=a2, coef1=coef1, coef2=coef2, saved1=None, dims=(H1, W1, H2, W2, H3, W3))
+        _replay(cx, x, defer, join)
+        return z, cx
+    a3, st = ops.conv4x4s2(Op(a2, DM_LOAD_AFFINE_RELU, coef2, per_sample=ps), weight_view(_w(L.enc7.weight), nh * 16, 16, 4, 1),
+                           B, nh, nh, H2, W2, want_stats=True, bias=_w(L.enc7.bias), per_tile=ps)
+    coef3, saved3 = _bn_coef(st, L.bn3, n3, ps, B, defer)
+
+    if fuse_tail:
+        z, st4, sts = ops.latent_tail_forward(a3, coef3, _w(L.enc10.weight), _w(L.enc10.bias), _w(L.bn4.weight), _w(L.bn4.bias),
+                                              L.bn4.eps, res_args())
+        defer_tail(st4, sts)
         cx.__dict__.update(a1=a1, a2=a2, a3=a3, coef1=coef1, coef2=coef2, coef3=coef3, saved1=None, dims=(H1, W1, H2, W2, H3, W3))
         _replay(cx, x, defer, join)
         return z, cx

@@ -419,16 +419,31 @@ def latent_tail_supported(c, cr, h, w, nres):
 
 
 @_op
-def latent_tail_forward(a3, coef3, w10, b10, gamma4, beta4, eps4, res):
+def latent_tail_forward(a3, coef3, w10, b10, gamma4, beta4, eps4, res, enc7=None):
     """enc.10 .. enc.12 of every patch with that patch's own BatchNorm statistics, one launch (csrc/latent_tail.hip).
     res: per residual layer (wa, ba, gamma_a, beta_a, eps_a, wb, bb, gamma_b, beta_b, eps_b).
-    Returns (z, stats4, [(stats_a, stats_b), ...]): the per-patch sums (B, C, 2) float64 for bn_running_replay."""
+    enc7 = (a2, coef2, w7, b7, gamma3, beta3, eps3): start at a2 (enc.4's raw output) instead -- enc.7 / enc.8 run in the
+    kernel too, a3 / coef3 are None and a fourth return value holds the per-patch sums of enc.7's output.
+    Returns (z, stats4, [(stats_a, stats_b), ...][, stats3]): the per-patch sums (B, C, 2) float64 for bn_running_replay."""
     lib = L.load()
-    B, Cn, H, W = a3.shape
+    if enc7 is not None:
+        a2 = enc7[0]
+        B, Cn, H, W = a2.shape[0], a2.shape[1], a2.shape[2] // 2, a2.shape[3] // 2
+        a3 = a2                                          # (allocation template only)
+    else:
+        B, Cn, H, W = a3.shape
     z = _new((B, Cn, H, W), a3)
     st4 = _new((B, Cn, 2), a3, torch.float64)
     args = L.LatentTailArgs()
-    args.a3, args.coef3, args.w10, args.b10 = _ptr(a3), _ptr(coef3), _ptr(w10), _ptr(b10)
+    st3 = None
+    if enc7 is not None:
+        a2, coef2, w7, b7, g3, be3, eps3 = enc7
+        st3 = _new((B, Cn, 2), a2, torch.float64)
+        args.a2, args.coef2, args.w7, args.b7 = _ptr(a2), _ptr(coef2), _ptr(w7), _ptr(b7)
+        args.gamma3, args.beta3, args.stats3, args.eps3 = _ptr(g3), _ptr(be3), _ptr(st3, torch.float64), eps3
+    else:
+        args.a3, args.coef3 = _ptr(a3), _ptr(coef3)
+    args.w10, args.b10 = _ptr(w10), _ptr(b10)
     args.gamma4, args.beta4, args.stats4, args.z = _ptr(gamma4), _ptr(beta4), _ptr(st4, torch.float64), _ptr(z)
     args.eps4, args.B, args.C, args.H, args.W, args.nres = eps4, B, Cn, H, W, len(res)
     args.CR = res[0][0].shape[0] if res else 32
@@ -441,7 +456,7 @@ def latent_tail_forward(a3, coef3, w10, b10, gamma4, beta4, eps4, res):
         r.wb, r.bb, r.gamma_b, r.beta_b, r.stats_b, r.eps_b = _ptr(wb), _ptr(bb), _ptr(gb), _ptr(beb), _ptr(sb, torch.float64), epsb
         sts.append((sa, sb))
     L.check(lib.dm_latent_tail_forward(C.byref(args), _stream()), "dm_latent_tail_forward")
-    return z, st4, sts
+    return (z, st4, sts, st3) if enc7 is not None else (z, st4, sts)
 
 
 @_op

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 113
+#define DM_VERSION 114
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -287,6 +287,12 @@ typedef struct dm_latent_tail_args {
     float eps4;
     int32_t B, C, CR, H, W, nres;
     dm_latent_tail_res res[4];
+    /* Start one layer earlier (all NULL / 0: start at a3): a2 (B,16,32,32) = raw output of enc.4 with coef2 (B,16,4), the
+     * per-sample coefficients of enc.5; then enc.7 (w7 (16,16,4,4), b7) and enc.8 (gamma3, beta3, eps3) run in the kernel
+     * too, a3 / coef3 are ignored and stats3 (B,16,2) receives the per-patch sums of enc.7's output. */
+    const float *a2, *coef2, *w7, *b7, *gamma3, *beta3;
+    double *stats3;
+    float eps3;
 } dm_latent_tail_args;
 int dm_latent_tail_supported(int C, int CR, int H, int W, int nres);
 int dm_latent_tail_forward(const dm_latent_tail_args *args, void *stream);

@@ -1146,8 +1146,9 @@ def test_dec_tail_fused_forward_backward(ops, nin, masked, B, hw):
 
 
 # ===================================================================== latent tail (inference path, per-sample statistics)
+@pytest.mark.parametrize("from_a2", [False, True])
 @pytest.mark.parametrize("B,nres", [(1, 2), (3, 0), (2, 1), (5, 3), (4, 4), (600, 2)])
-def test_latent_tail_kernel_vs_aten_batch_of_one_calls(ops, B, nres):
+def test_latent_tail_kernel_vs_aten_batch_of_one_calls(ops, B, nres, from_a2):
     """dm_latent_tail_forward (enc.10 + enc.11 + nres residual layers of every patch, per-patch BatchNorm statistics)
     against the ATen composition called one patch at a time in train mode -- the arithmetic of patch_VAE.py:445-452 on
     vq_vae.py:287-289 / :203-224 -- for 0..4 residual layers, random BatchNorm weights / biases / conv biases; and the
@@ -1157,6 +1158,10 @@ def test_latent_tail_kernel_vs_aten_batch_of_one_calls(ops, B, nres):
     r = lambda *s, k=1.0: torch.randn(*s, generator=g) * k
     a3 = r(B, C, 16, 16)
     coef3 = torch.stack([r(B, C).abs() + 0.5, torch.zeros(B, C), r(B, C, k=0.3), torch.zeros(B, C)], 2).contiguous()
+    # from_a2: the kernel starts one layer earlier (enc.7 on enc.4's raw output a2, then enc.8's per-patch BatchNorm)
+    a2 = r(B, C, 32, 32)
+    coef2 = torch.stack([r(B, C).abs() + 0.5, torch.zeros(B, C), r(B, C, k=0.3), torch.zeros(B, C)], 2).contiguous()
+    w7, b7, g3, be3 = r(C, C, 4, 4, k=0.1), r(C, k=0.2), r(C).abs() + 0.5, r(C, k=0.3)
     w10, b10, g4, be4 = r(C, C, 3, 3, k=0.15), r(C, k=0.2), r(C).abs() + 0.5, r(C, k=0.3)
     res = [(r(CR, C, 3, 3, k=0.15), r(CR, k=0.2), r(CR).abs() + 0.5, r(CR, k=0.3), 1e-5,
             r(C, CR, 1, 1, k=0.2), r(C, k=0.2), r(C).abs() + 0.5, r(C, k=0.3), 1e-5) for _ in range(nres)]
@@ -1167,9 +1172,14 @@ def test_latent_tail_kernel_vs_aten_batch_of_one_calls(ops, B, nres):
     nref = min(B, 6)
     zs, sums = [], []
     for i in range(nref):
-        t = torch.relu(coef3[i, :, 0].reshape(1, C, 1, 1) * a3[i:i + 1] + coef3[i, :, 2].reshape(1, C, 1, 1))
+        if from_a2:
+            t2 = torch.relu(coef2[i, :, 0].reshape(1, C, 1, 1) * a2[i:i + 1] + coef2[i, :, 2].reshape(1, C, 1, 1))
+            a3i = F.conv2d(t2, w7, b7, stride=2, padding=1)
+            t = torch.relu(bn(a3i, g3, be3))
+        else:
+            t = torch.relu(coef3[i, :, 0].reshape(1, C, 1, 1) * a3[i:i + 1] + coef3[i, :, 2].reshape(1, C, 1, 1))
         a4 = F.conv2d(t, w10, b10, padding=1)
-        per = [a4]
+        per = ([a3i] if from_a2 else []) + [a4]
         h = bn(a4, g4, be4)
         for wa, ba, ga, bea, _, wb, bb, gb, beb, _ in res:
             ra = F.conv2d(torch.relu(h), wa, ba, padding=1)
@@ -1179,14 +1189,18 @@ def test_latent_tail_kernel_vs_aten_batch_of_one_calls(ops, B, nres):
         zs.append(h)
         sums.append([torch.stack([v.double().sum((0, 2, 3)), (v.double() ** 2).sum((0, 2, 3))], 1) for v in per])
     d = lambda t: t.to(DEV).contiguous()
-    z, st4, sts = ops.latent_tail_forward(d(a3), d(coef3), d(w10), d(b10), d(g4), d(be4), 1e-5,
-                                          [tuple(d(v) if torch.is_tensor(v) else v for v in layer) for layer in res])
+    dres = [tuple(d(v) if torch.is_tensor(v) else v for v in layer) for layer in res]
+    if from_a2:
+        z, st4, sts, st3 = ops.latent_tail_forward(None, None, d(w10), d(b10), d(g4), d(be4), 1e-5, dres,
+                                                   enc7=(d(a2), d(coef2), d(w7), d(b7), d(g3), d(be3), 1e-5))
+    else:
+        z, st4, sts = ops.latent_tail_forward(d(a3), d(coef3), d(w10), d(b10), d(g4), d(be4), 1e-5, dres)
     torch.cuda.synchronize()
     assert z.shape == (B, C, 16, 16) and st4.shape == (B, C, 2) and len(sts) == nres
     zr = torch.cat(zs, 0)
     close(z[:nref], zr, 2e-5, 2e-5 * max(1.0, zr.abs().max().item()), "z")
     assert bool(torch.isfinite(z).all())
-    flat = [st4] + [t for pair in sts for t in pair]
+    flat = ([st3] if from_a2 else []) + [st4] + [t for pair in sts for t in pair]
     for i in range(nref):
         for got, want in zip(flat, sums[i]):
             assert torch.allclose(got[i].cpu(), want, rtol=1e-5, atol=1e-4), (i, got.shape)
