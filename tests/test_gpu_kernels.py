@@ -1255,7 +1255,9 @@ def test_relu_keeps_nans_of_either_sign(ops):
 
 
 @pytest.mark.parametrize("D,K,scale_z,scale_e", [(16, 64, 1.0, 1.0), (16, 64, 30.0, 0.05), (16, 64, 1e-3, 4.0), (16, 64, 1e4, 1e4),
-                                                   (32, 200, 0.3, 2.0), (64, 512, 1.0, 0.2), (16, 4096, 1.0, 1.0)])
+                                                   (32, 200, 0.3, 2.0), (64, 512, 1.0, 0.2), (16, 4096, 1.0, 1.0),
+                                                   # code groups of the exact re-check: one group, four, five with a ragged last
+                                                   (16, 65, 1.0, 1.0), (16, 1000, 1.0, 0.5), (16, 5000, 1.0, 1.0), (32, 3000, 1.0, 1.0)])
 def test_vq_bf16_split_filter_scales_and_clusters(ops, D, K, scale_z, scale_e):
     """The bf16-split filter's tolerance is proven relative to A = |z|^2 + 2 max |e|^2: magnitudes far from 1, latents much
     larger or smaller than the codes, and a codebook whose codes sit in tight clusters (many runner-ups inside the
