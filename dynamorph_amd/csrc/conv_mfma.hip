@@ -149,9 +149,7 @@ __device__ __forceinline__ void stats_reduce(double (&s1)[NTT], double (&s2)[NTT
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
-        double a = s1[t], c = s2[t];
-        a += __shfl_xor(a, 16, 64); c += __shfl_xor(c, 16, 64);
-        a += __shfl_xor(a, 32, 64); c += __shfl_xor(c, 32, 64);
+        double a = dm_row_sum_f64(s1[t]), c = dm_row_sum_f64(s2[t]);
         if (PIX) {
             a += __shfl_xor(a, 1, 64); c += __shfl_xor(c, 1, 64);
             a += __shfl_xor(a, 2, 64); c += __shfl_xor(c, 2, 64);

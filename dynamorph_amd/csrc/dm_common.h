@@ -151,6 +151,31 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Sum of a double over the four 16-lane rows of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48), every lane gets it:
+// v_permlane16_swap / v_permlane32_swap exchange registers between partner rows without an LDS round trip (a __shfl_xor of
+// a double is two ds_bpermute_b32).
+__device__ __forceinline__ double dm_row_sum_f64(double v)
+{
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        const unsigned lo = (unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
+        const unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
+        unsigned a0, a1, b0, b1;
+        if (step == 0) {
+            // (x, x): afterwards the even rows hold (own, partner's) and the odd rows (partner's, own)
+            const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            a0 = a[0]; a1 = a[1]; b0 = b[0]; b1 = b[1];
+        } else {
+            const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            a0 = a[0]; a1 = a[1]; b0 = b[0]; b1 = b[1];
+        }
+        v = __builtin_bit_cast(double, ((unsigned long long)b0 << 32) | a0) + __builtin_bit_cast(double, ((unsigned long long)b1 << 32) | a1);
+    }
+    return v;
+}
+
 // Sum over the 256 threads of a block; result valid in thread 0.  scratch: >= 4 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double *scratch)
 {

@@ -52,34 +52,6 @@ struct LtParams {
     int B, nres, dbg;          // dbg: measurement only (DM_LT_DBG, tools/exp/lt_bench.py): 1 no products, 2 no statistics arithmetic, 4 no weight loads
 };
 
-// sum of a double over the four 16-lane rows of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48): v_permlane16_swap /
-// v_permlane32_swap exchange two registers between partner rows in one instruction (no LDS round trip)
-__device__ __forceinline__ double lt_row_sum(double v)
-{
-    unsigned lo = (unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
-    unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
-    {
-        // (x, x): afterwards the even rows hold (own, partner's) and the odd rows (partner's, own)
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-        const double p = __builtin_bit_cast(double, ((unsigned long long)b0 << 32) | a0);
-        const double r = __builtin_bit_cast(double, ((unsigned long long)b1 << 32) | a1);
-        v = p + r;
-    }
-    lo = (unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
-    hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
-    {
-        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-        const double p = __builtin_bit_cast(double, ((unsigned long long)b0 << 32) | a0);
-        const double r = __builtin_bit_cast(double, ((unsigned long long)b1 << 32) | a1);
-        v = p + r;
-    }
-    return v;
-}
-
 // Per-sample statistics of a layer's raw output v (+ bias already added) and the BatchNorm coefficients of this lane's
 // channels: scale[nt], shift[nt] for channel 16 nt + n.  buf: [4 waves][NT][16][2] doubles of LDS, a different one from
 // the previous layer's.  One barrier.  Vector instructions here do not hide under the other workgroup's products (the
@@ -108,8 +80,8 @@ __device__ __forceinline__ void lt_batchnorm(const f32x4 (&v)[4][NT], double *__
                 const double d = (double)v[mt][nt][r];
                 s1 += d; s2 += d * d;
             }
-        s1 = lt_row_sum(s1);
-        s2 = lt_row_sum(s2);
+        s1 = dm_row_sum_f64(s1);
+        s2 = dm_row_sum_f64(s2);
         if (q == 0) {
             buf[((wave * NT + nt) * 16 + n) * 2 + 0] = s1;
             buf[((wave * NT + nt) * 16 + n) * 2 + 1] = s2;
