@@ -333,6 +333,10 @@ extern "C" int dm_latent_tail_forward(const dm_latent_tail_args *a, void *stream
     DM_REQUIRE(a->B > 0 && a->w10 && a->stats4 && a->z, "dm_latent_tail_forward: NULL pointer");
     DM_REQUIRE(e7 ? (a->coef2 && a->w7 && a->stats3) : (a->a3 && a->coef3),
                "dm_latent_tail_forward: give (a3, coef3) or (a2, coef2, w7, stats3)");
+    {
+        uintptr_t al = (uintptr_t)a->z | (uintptr_t)a->a3 | (uintptr_t)a->coef3 | (uintptr_t)a->a2 | (uintptr_t)a->coef2;
+        DM_REQUIRE((al & 15) == 0, "dm_latent_tail_forward: a2 / a3 / coef / z must be 16-byte aligned");
+    }
     LtParams P;
     P.a3 = a->a3; P.coef3 = a->coef3; P.w10 = a->w10; P.b10 = a->b10; P.g4 = a->gamma4; P.be4 = a->beta4; P.st4 = a->stats4;
     P.eps4 = a->eps4; P.z = a->z; P.B = a->B; P.nres = a->nres;

@@ -92,6 +92,14 @@ def test_argument_errors_are_reported_before_any_launch(lib):
         _lib.check(rc, "dm_apply")
     rc = lib.dm_adam(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, None, None)
     assert rc == -1
+    args = _lib.LatentTailArgs()
+    args.B, args.C, args.CR, args.H, args.W, args.nres = 4, 16, 32, 16, 16, 2
+    assert lib.dm_latent_tail_forward(ctypes.byref(args), None) == -1 and b"NULL" in lib.dm_last_error()
+    args.C = 64
+    assert lib.dm_latent_tail_forward(ctypes.byref(args), None) == -1 and b"built for 16 channels" in lib.dm_last_error()
+    assert lib.dm_latent_tail_forward(None, None) == -1
+    rc = lib.dm_dec_tail_train(None, None, None, None, None, None, None, 0, None, None, None, None, None, None, 1, 4, 2, 64, 66, None)
+    assert rc == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
