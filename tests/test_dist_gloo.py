@@ -90,7 +90,9 @@ LR = 1e-3
 # (samples, batch, epochs, validation ratio).  The second case has a 1-sample last training batch and a 1-sample
 # validation set: rank 1's shard of both is EMPTY, so it joins the gradient exchange with zeros and the epoch-loss
 # exchange with no keys of its own (the vector must still have rank 0's length on every rank).
-TRAIN_CASES = [(22, 6, 2, 0.2), (7, 5, 1, 0.15)]
+# The third runs FOUR ranks (ragged last batch of 5 over 4 ranks, validation batches smaller than the world).
+TRAIN_CASES = [(22, 6, 2, 0.2), (7, 5, 1, 0.15), (26, 8, 1, 0.2)]
+TRAIN_WORLDS = [2, 2, 4]
 
 
 def _train_worker(rank, world, port, out_dir, case):
@@ -121,18 +123,20 @@ def _train_worker(rank, world, port, out_dir, case):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("case", TRAIN_CASES, ids=["even-shards", "empty-shards"])
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=["even-shards", "empty-shards", "four-ranks"])
 def test_train_loop_world2_shards_batches_and_checkpoints_on_rank0(tmp_path, case):
     from dynamorph_amd import dist as D
     from oracle import vqvae_oracle as O
     n_samples, batch, epochs, ratio = case
-    world = 2
+    world = TRAIN_WORLDS[TRAIN_CASES.index(case)]
     mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"train_rank{r}.pt")) for r in range(world)]
     # identical replicas after training, and rank 0 alone reported the epoch scalars
-    for a, b in zip(res[0]["params"], res[1]["params"]):
-        assert torch.equal(a, b)
-    assert len(res[0]["rows"]["Loss/total_loss"]) == epochs and not res[1]["rows"]
+    for r in range(1, world):
+        for a, b in zip(res[0]["params"], res[r]["params"]):
+            assert torch.equal(a, b)
+        assert not res[r]["rows"]
+    assert len(res[0]["rows"]["Loss/total_loss"]) == epochs
     assert len(res[0]["rows"]["Val loss/total_loss"]) == epochs
     ck = torch.load(os.path.join(tmp_path, "run", "model.pt"))
     assert not os.path.exists(os.path.join(tmp_path, "run", "model.pt.tmp"))
