@@ -69,18 +69,18 @@ def pmc_traffic(kernel_key, batch):
     """HBM bytes per launch of the roofline kernel, from the separate `rocprofv3 --pmc` passes summarised in
     profiles/r0N_pmc_traffic.json (tools/pmc_traffic.py writes it; bench.py cannot run under the profiler
     itself).  None when no measurement for this kernel and batch has been committed."""
-    rec = None
+    stem = {"dec_tail_train": "dec_tail_backward_kernel", "conv4x4s2_e1": "conv4x4s2_kernel"}.get(
+        kernel_key, kernel_key.split("_k4096")[0].replace("vq_forward_mfma", "vq_forward_mfma_kernel"))
     for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(kernel_key)
         except (OSError, ValueError):
             rec = None
-        if rec:
-            break
-    if not rec or rec.get("batch") != batch:
-        return None
-    return rec.get("hbm_bytes_per_launch")
+        # (a record names the kernel it was measured on: a pattern that drifted onto another kernel must not pass as this one's)
+        if rec and rec.get("batch") == batch and stem in rec.get("kernel", ""):
+            return rec.get("hbm_bytes_per_launch")
+    return None
 
 
 EXAMPLE_CONFIG = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)     # config_example.yml:157-163

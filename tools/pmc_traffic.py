@@ -15,13 +15,14 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 KEYS = {                       # key in the JSON -> substring of the kernel name
-    "dec_tail_train": "true>(float const",            # dec_tail_backward_kernel<NIN, true>
-    "dec_tail_backward": "false>(float const",        # dec_tail_backward_kernel<NIN, false>
+    "dec_tail_train": "dec_tail_backward_kernel<2, true",       # <NIN, FUSED, WIDE>: the fused training pass
+    "dec_tail_backward": "dec_tail_backward_kernel<2, false",
     "dec_tail_forward": "dec_tail_forward_kernel",
     "conv4x4s2_e1": "conv4x4s2_kernel",
     "vq_forward_mfma": "vq_forward_mfma_kernel<16, true",         # K = 64: the whole codebook in one LDS piece
     "vq_forward_mfma_k4096": "vq_forward_mfma_kernel<16, false",  # K = 4096 (KB_B5 patches): codebook walks through LDS
     "vq_backward_mfma": "vq_backward_mfma_kernel",
+    "latent_tail": "latent_tail_kernel",
     "copy_calib": "elementwise_kernel",
 }
 
