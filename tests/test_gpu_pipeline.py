@@ -180,6 +180,33 @@ def test_latent_tail_kernel_against_the_layer_by_layer_path_and_the_oracle(B, ni
                 assert torch.allclose(sd1[k].cpu(), sd_r[k], rtol=2e-4, atol=2e-6), k
 
 
+def test_encode_patches_constant_and_huge_patches():
+    """Degenerate patches through the per-sample path (latent tail kernel included): a constant patch (every BatchNorm sees
+    zero variance: 1 / sqrt(eps) scaling, variance clamped at 0), an all-zero patch, and one with values of 1e4 -- finite
+    latents that match the oracle's batch-of-one calls."""
+    import dynamorph_amd
+    from dynamorph_amd.patch_vae import encode_patches
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(77)
+    ref = O.OracleVQVAE()
+    m = dynamorph_amd.VQ_VAE().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(5, 2, 128, 128, generator=torch.Generator().manual_seed(5))
+    x[0] = 3.25
+    x[1] = 0.0
+    x[2] *= 1e4
+    x[3, 0] = -1.5                      # one constant channel
+    with torch.no_grad():
+        zb_r, za_r = O.encode_per_sample(ref, x)
+    zb, za = encode_patches(m, x, device=DEV, batch_size=8)
+    zb_r = zb_r.reshape(5, -1).numpy()
+    assert np.isfinite(zb).all() and np.isfinite(za).all()
+    scale = np.abs(zb_r).max(axis=1, keepdims=True) + 1e-6
+    assert (np.abs(zb - zb_r) / scale).max() <= 2e-3, (np.abs(zb - zb_r) / scale).max(axis=1)
+    # the non-degenerate patches to the usual tolerance
+    np.testing.assert_allclose(zb[3:], zb_r[3:], rtol=3e-4, atol=3e-4)
+
+
 @pytest.mark.parametrize("kw,N", [({}, 5), (dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512), 3)])
 def test_encode_patches_z32_per_sample(kw, N):
     """process_VAE semantics for VQ_VAE_z32 (the network config_example.yml names), default and example widths: the batched
