@@ -249,7 +249,17 @@ class FusedTrainer:
         out["steps"] = len(timers)
         return out
 
-    def _graph_step(self, x, mask, tm=None):
+    def prepare(self, x, mask=None, time_matching_mat=None):
+        """Capture the HIP graph for this input shape WITHOUT taking a step (the capture's internal warm-up run has its
+        BatchNorm side effects put back, parameters and Adam state are untouched): a caller that times steps can keep the
+        one-off capture out of its timed region.  Returns the graph's input buffer (fill it in place to skip the copy)."""
+        if not self.use_graph:
+            return None
+        with torch.cuda.device(self.flat.device):
+            self._graph_step(x.contiguous(), mask, time_matching_mat, replay=False)
+        return self._static_x
+
+    def _graph_step(self, x, mask, tm=None, replay=True):
         """Graphs are cached per input shape (a ragged last batch gets its own, captured once, not once per epoch)."""
         key = (tuple(x.shape), None if mask is None else tuple(mask.shape), None if tm is None else tuple(tm.shape))
         entry = self._graphs.get(key)
@@ -286,7 +296,8 @@ class FusedTrainer:
             if tm is not None:
                 stm.copy_(tm)
         self._static_x = entry[1]
-        entry[0].replay()
+        if replay:
+            entry[0].replay()
         return entry[4]
 
     def input_buffer(self):

@@ -352,6 +352,30 @@ def test_fused_trainer_equals_autograd_path(golden):
         close(a, b, 1e-6, 1e-6, k)       # (the two paths differ in their decoder-tail and codebook-gradient kernels)
 
 
+def test_fused_trainer_prepare_captures_without_taking_a_step(golden):
+    """FusedTrainer.prepare (bench.py keeps the one-off graph capture out of its timed steps with it): parameters,
+    BatchNorm buffers and the Adam state are untouched, and the steps that follow equal those of a trainer that captured
+    inside its first step."""
+    from dynamorph_amd.train import FusedTrainer
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    m1, m2 = fresh(golden), fresh(golden)
+    t1, t2 = FusedTrainer(m1, lr=1e-4, use_graph=True), FusedTrainer(m2, lr=1e-4, use_graph=True)
+    before = {k: v.clone() for k, v in m1.state_dict().items()}
+    buf = t1.prepare(x)
+    torch.cuda.synchronize()
+    assert buf is not None and buf.shape == x.shape and torch.equal(buf, x)
+    for k, v in m1.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert float(t1.m.abs().max()) == 0.0 and float(t1.v.abs().max()) == 0.0
+    outs = []
+    for _ in range(2):
+        outs.append((t1.step(buf).clone(), t2.step(x).clone()))
+    for a, b in outs:
+        assert torch.equal(a, b)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 # ===================================================================================== VQ_VAE_z32
 Z32_BN_FED_BIASES = ("enc.0.bias", "enc.3.bias", "dec.1.bias") + tuple(
     f"{blk}.layers.{i}.{j}.bias" for blk in ("enc.5", "dec.0") for i in (0, 1) for j in (1, 4))
