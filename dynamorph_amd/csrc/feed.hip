@@ -1,0 +1,210 @@
+// feed.hip -- feeding the training step from a dataset that lives in HBM.
+//
+// Reference: run_training.py:504-532 (the batch loop: `dataset[ids][0].to(device)`, get_relation_tensor, get_mask),
+// :396-403 (per-sample flip / rot90 drawn from numpy's global generator), :335-374 (relation block, mask plane).
+// The reference gathers every batch on the host and copies it over PCIe; on a 288 GB part the whole dataset (and its
+// masks, and the CSR relation matrix) is uploaded once and a batch is ONE kernel that gathers the chosen samples,
+// applies each sample's flip / rotation and writes straight into the input buffer the captured step replays on.
+#include "dm_common.h"
+
+namespace {
+
+constexpr int FT = 64;          // a workgroup moves one 64 x 64 tile of one (sample, channel) plane
+
+// Source coordinates of output (y, x) under out = rot90(flip(in, f), k): the dihedral map of run_training.py:396-403
+// (torch.flip dims (1,) / (2,) of a (C, H, W) patch, torch.rot90 k times counter-clockwise over dims [1, 2]).
+__device__ __forceinline__ void source_of(int y, int x, int H, int k, int f, int &sy, int &sx)
+{
+    switch (k) {
+    case 0: sy = y; sx = x; break;
+    case 1: sy = x; sx = H - 1 - y; break;
+    case 2: sy = H - 1 - y; sx = H - 1 - x; break;
+    default: sy = H - 1 - x; sx = y; break;
+    }
+    if (f == 1) sy = H - 1 - sy;
+    else if (f == 2) sx = H - 1 - sx;
+}
+
+// H % 64 == 0.  A dihedral map sends 64 x 64 tiles to 64 x 64 tiles, so the source tile of an output tile is read in
+// full rows (16 B per lane, 256 B per row segment), parked in LDS (row stride 65: the transposing reads of the odd
+// rotations hit 64 different banks) and written out in full rows again.
+__global__ __launch_bounds__(256) void gather_augment_tiled_kernel(const float *__restrict__ src, float *__restrict__ out,
+                                                                   const int *__restrict__ ids,
+                                                                   const int *__restrict__ flip_code,
+                                                                   const int *__restrict__ rot_code, int C, int H,
+                                                                   long long n_src)
+{
+    __shared__ float tile[FT][FT + 1];
+    const int tiles = H / FT;
+    int w = blockIdx.x;
+    const int tx = w % tiles; w /= tiles;
+    const int ty = w % tiles; w /= tiles;
+    const int c = w % C;
+    const int b = w / C;
+    const long long s = ids ? (long long)ids[b] : (long long)b;
+    const int k = rot_code ? (rot_code[b] & 3) : 0;
+    const int f = flip_code ? flip_code[b] : 0;
+    float *dst = out + ((long long)b * C + c) * H * H;
+    const int col = (threadIdx.x & 15) * 4, row0 = threadIdx.x >> 4;
+    if (s < 0 || s >= n_src) {           // an id outside the dataset: zeros, never a stray read
+        for (int r = row0; r < FT; r += 16)
+            *reinterpret_cast<f32x4 *>(dst + (long long)(ty * FT + r) * H + tx * FT + col) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const float *pl = src + (s * C + c) * H * H;
+    // where the output tile's corner (and its opposite corner) come from: the source tile is the box between them
+    int ay, ax, by, bx;
+    source_of(ty * FT, tx * FT, H, k, f, ay, ax);
+    source_of(ty * FT + FT - 1, tx * FT + FT - 1, H, k, f, by, bx);
+    const int sy0 = ay < by ? ay : by, sx0 = ax < bx ? ax : bx;
+#pragma unroll
+    for (int r = row0; r < FT; r += 16) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(pl + (long long)(sy0 + r) * H + sx0 + col);
+        tile[r][col] = v.x; tile[r][col + 1] = v.y; tile[r][col + 2] = v.z; tile[r][col + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = row0; r < FT; r += 16) {
+        f32x4 v;
+        int sy, sx;
+        source_of(ty * FT + r, tx * FT + col, H, k, f, sy, sx);     v.x = tile[sy - sy0][sx - sx0];
+        source_of(ty * FT + r, tx * FT + col + 1, H, k, f, sy, sx); v.y = tile[sy - sy0][sx - sx0];
+        source_of(ty * FT + r, tx * FT + col + 2, H, k, f, sy, sx); v.z = tile[sy - sy0][sx - sx0];
+        source_of(ty * FT + r, tx * FT + col + 3, H, k, f, sy, sx); v.w = tile[sy - sy0][sx - sx0];
+        *reinterpret_cast<f32x4 *>(dst + (long long)(ty * FT + r) * H + tx * FT + col) = v;
+    }
+}
+
+// Any H: one element per thread and trip (coverage form; the odd rotations read with a stride of one row).
+__global__ __launch_bounds__(256) void gather_augment_kernel(const float *__restrict__ src, float *__restrict__ out,
+                                                             const int *__restrict__ ids, const int *__restrict__ flip_code,
+                                                             const int *__restrict__ rot_code, int C, int H,
+                                                             long long n_src, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % H), y = (int)((i / H) % H);
+        const long long plane = i / ((long long)H * H);
+        const int b = (int)(plane / C), c = (int)(plane % C);
+        const long long s = ids ? (long long)ids[b] : (long long)b;
+        int sy, sx;
+        source_of(y, x, H, rot_code ? (rot_code[b] & 3) : 0, flip_code ? flip_code[b] : 0, sy, sx);
+        out[i] = (s < 0 || s >= n_src) ? 0.f : src[(s * C + c) * H * H + (long long)sy * H + sx];
+    }
+}
+
+// out[b] = src[ids[b]] for rows of `row` floats (row % 4 == 0, 16-byte aligned): the cell masks of a batch.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, float *__restrict__ out,
+                                                          const int *__restrict__ ids, long long row4, long long n_src,
+                                                          long long total4)
+{
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+    f32x4 *o4 = reinterpret_cast<f32x4 *>(out);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / row4, e = i - b * row4;
+        const long long s = ids ? (long long)ids[b] : b;
+        o4[i] = (s < 0 || s >= n_src) ? f32x4{0.f, 0.f, 0.f, 0.f} : s4[s * row4 + e];
+    }
+}
+
+// pos[ids[j]] = stamp * 2^32 + j: which column of the block a sample id lands in, valid for this call only (a stale
+// entry carries an older stamp), so the N-entry table is never cleared.
+__global__ void csr_mark_kernel(long long *__restrict__ pos, const int *__restrict__ ids, int B, long long n,
+                                long long stamp)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < B) {
+        const long long s = ids[j];
+        if (s >= 0 && s < n) pos[s] = (stamp << 32) | (long long)j;
+    }
+}
+
+// One workgroup per row of the block: zero the row, then walk CSR row ids[i] and drop every entry whose column is in
+// the batch at its block column.  (relation_mat[ids, :][:, ids].todense(), run_training.py:348-351; duplicate entries
+// of a column are summed on the host before the upload, as scipy's todense() does.)
+__global__ __launch_bounds__(256) void csr_block_kernel(const long long *__restrict__ indptr, const int *__restrict__ indices,
+                                                        const float *__restrict__ data, const long long *__restrict__ pos,
+                                                        const int *__restrict__ ids, int B, long long n, long long stamp,
+                                                        float *__restrict__ out)
+{
+    const int i = blockIdx.x;
+    float *row = out + (long long)i * B;
+    for (int j = threadIdx.x; j < B; j += blockDim.x) row[j] = 0.f;
+    __syncthreads();
+    const long long s = ids[i];
+    if (s < 0 || s >= n) return;
+    const long long lo = indptr[s], hi = indptr[s + 1];
+    for (long long e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        const long long col = indices[e];
+        if (col < 0 || col >= n) continue;
+        const long long p = pos[col];
+        if ((p >> 32) == stamp) row[(int)(p & 0xffffffffLL)] = data[e];
+    }
+}
+
+}  // namespace
+
+extern "C" int dm_gather_augment(const float *src, int64_t n_src, const int32_t *ids, const int32_t *flip_code,
+                                 const int32_t *rot_code, float *out, int B, int C, int H, void *stream)
+{
+    DM_REQUIRE(src && out && B > 0 && C > 0 && H > 0 && n_src > 0, "dm_gather_augment: bad argument");
+    DM_REQUIRE((const void *)src != (const void *)out, "dm_gather_augment: in-place not supported");
+    DM_REQUIRE(ids || (int64_t)B <= n_src, "dm_gather_augment: B exceeds the number of source samples");
+    if (H % FT == 0) {
+        const long long blocks = (long long)B * C * (H / FT) * (H / FT);
+        DM_REQUIRE(blocks < (1LL << 31), "dm_gather_augment: batch too large for one launch");
+        hipLaunchKernelGGL(gather_augment_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, out,
+                           (const int *)ids, (const int *)flip_code, (const int *)rot_code, C, H, (long long)n_src);
+    } else {
+        const long long total = (long long)B * C * H * H;
+        const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(gather_augment_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, out, (const int *)ids,
+                           (const int *)flip_code, (const int *)rot_code, C, H, (long long)n_src, total);
+    }
+    return dm_launch_status("dm_gather_augment");
+}
+
+extern "C" int dm_gather_rows(const float *src, int64_t n_src, const int32_t *ids, float *out, int B, int64_t row_floats,
+                              void *stream)
+{
+    DM_REQUIRE(src && out && B > 0 && row_floats > 0 && n_src > 0, "dm_gather_rows: bad argument");
+    DM_REQUIRE(row_floats % 4 == 0, "dm_gather_rows: rows must be a multiple of 4 floats");
+    DM_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0, "dm_gather_rows: pointers must be 16-byte aligned");
+    DM_REQUIRE(ids || (int64_t)B <= n_src, "dm_gather_rows: B exceeds the number of source rows");
+    const long long total4 = (long long)B * (row_floats / 4);
+    const int grid = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, out, (const int *)ids,
+                       (long long)(row_floats / 4), (long long)n_src, total4);
+    return dm_launch_status("dm_gather_rows");
+}
+
+extern "C" int dm_csr_block(const int64_t *indptr, const int32_t *indices, const float *data, int64_t n, const int32_t *ids,
+                            int B, int64_t *pos, int64_t stamp, float *out, void *stream)
+{
+    DM_REQUIRE(indptr && ids && pos && out && n > 0 && B > 0, "dm_csr_block: bad argument");
+    DM_REQUIRE(stamp > 0 && stamp < (1LL << 31), "dm_csr_block: stamp must be in [1, 2^31)");
+    hipLaunchKernelGGL(csr_mark_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long *)pos,
+                       (const int *)ids, B, (long long)n, (long long)stamp);
+    hipLaunchKernelGGL(csr_block_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)indptr,
+                       (const int *)indices, data, (const long long *)pos, (const int *)ids, B, (long long)n, (long long)stamp,
+                       out);
+    return dm_launch_status("dm_csr_block");
+}
+
+// Host only.  run_training.py:396-403 draws, per sample and in this order, np.random.choice([0, 1, 2]) and
+// np.random.choice([0, 1, 2, 3]).  numpy's legacy generator serves both from 32-bit words of the Mersenne twister by
+// masked rejection: word & 3, redrawn while it exceeds the largest value (so only the flip draw ever rejects).  `raw` is
+// a run of such words (np.random.randint(0, 2**32, dtype=uint32) hands them out one per value); the codes of n samples
+// are parsed from it exactly as n interleaved choice() calls would have consumed them.  Returns the number of words
+// used (the caller rewinds the generator and skips that many), or -1 when `raw` is too short.
+extern "C" int64_t dm_augment_codes(const uint32_t *raw, int64_t n_raw, int64_t n, int32_t *flip_code, int32_t *rot_code)
+{
+    if (!raw || !flip_code || !rot_code || n < 0 || n_raw < 0) return -1;
+    int64_t i = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        while (i < n_raw && (raw[i] & 3u) == 3u) ++i;
+        if (i + 1 >= n_raw) return -1;
+        flip_code[s] = (int32_t)(raw[i++] & 3u);
+        rot_code[s] = (int32_t)(raw[i++] & 3u);
+    }
+    return i;
+}

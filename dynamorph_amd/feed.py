@@ -1,0 +1,221 @@
+"""Batch feeding for train(): where the samples of a batch come from and how they reach the step's input buffer.
+
+The reference's loop (run_training.py:509-520) gathers every batch on the host (`dataset[ids][0]`, a fancy-index copy of
+B x 131 KB), copies it over PCIe synchronously (`.to(device)`), slices the relation matrix with scipy and the masks with
+another fancy index, then augments sample by sample in Python.  At B = 2048 that is 268 MB per step against a 2.2 ms GPU
+step.  Three feeds, same batches bit for bit:
+
+  resident   the MI355X-first one: the whole dataset (fp32), the mask planes and the CSR relation matrix are uploaded
+             ONCE into HBM (288 GB: 2 M patches of 2 x 128 x 128 fit); a batch is then one gather + augment launch
+             (dm_gather_augment) that writes straight into the input buffer the captured step replays on, one row
+             gather for the masks (dm_gather_rows) and one CSR block launch (dm_csr_block).  The ids of a whole phase
+             and its flip / rotation codes are uploaded once per phase: nothing crosses PCIe per step and the host
+             never waits for the device inside an epoch.
+  stream     the dataset does not fit: a helper thread gathers batch i+1 into pinned staging while batch i trains, a copy
+             stream moves it into one of two device slots, and the same gather + augment kernel (identity ids) writes it
+             into the step's input buffer.  Bounded by the host gather and PCIe (268 MB per 2048 patches), not the GPU.
+  sync       the reference's loop as it is (host gather, pageable copy, float() per step) for dataset objects that only
+             support `dataset[ids]`, and as the A/B partner of the tests.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def dataset_tensor(dataset):
+    """The (N, C, H, W) host tensor behind a TensorDataset-like object (`dataset[ids][0]` == tensor[ids]), or None when
+    the object only supports indexing."""
+    if torch.is_tensor(dataset):
+        return dataset
+    ts = getattr(dataset, "tensors", None)
+    if ts is not None and len(ts) >= 1 and torch.is_tensor(ts[0]):
+        return ts[0]
+    if isinstance(dataset, np.ndarray):
+        return torch.from_numpy(dataset)
+    return None
+
+
+def mask_plane(mask_tensor):
+    """run_training.py:371-372 for every sample at once: the second mask channel (the large mask), {-1, 1} -> {0, 1}."""
+    m = mask_tensor[:, 1:2, :, :]
+    return ((m + 1.) / 2.).to(torch.float32).contiguous()
+
+
+def _csr_arrays(relation_mat):
+    """(indptr int64, indices int32, data float32, n) of the (n, n) relation matrix, duplicates summed (what
+    `.todense()` of run_training.py:350 does) -- from a scipy sparse matrix or a dense array."""
+    import scipy.sparse as sp
+    m = relation_mat if sp.issparse(relation_mat) else sp.csr_matrix(np.asarray(relation_mat))
+    m = m.tocsr().copy()
+    m.sum_duplicates()
+    if m.shape[0] != m.shape[1]:
+        raise ValueError("relation matrix must be square")
+    return (torch.from_numpy(m.indptr.astype(np.int64)), torch.from_numpy(m.indices.astype(np.int32)),
+            torch.from_numpy(np.asarray(m.data).astype(np.float32)), m.shape[0])
+
+
+def resident_budget(device):
+    """Bytes of HBM the resident feed may take: DM_RESIDENT_BYTES if set, else DM_RESIDENT_FRACTION (default 0.6) of what
+    is free now (the step's activations, ~1.6 MB per patch of the batch, have to fit beside it)."""
+    if "DM_RESIDENT_BYTES" in os.environ:
+        return int(os.environ["DM_RESIDENT_BYTES"])
+    free, _ = torch.cuda.mem_get_info(device)
+    return int(free * float(os.environ.get("DM_RESIDENT_FRACTION", "0.6")))
+
+
+class Feed:
+    """One per train() call.  `phase(batches, transform)` yields, for every non-empty list of sample ids in `batches`,
+    (n, x, kwargs): the batch as a device tensor and the model kwargs (`time_matching_mat`, `batch_mask`) -- written
+    into `trainer.static_inputs(...)` when a FusedTrainer is given, into buffers of the feed otherwise."""
+
+    def __init__(self, dataset, device, mode="auto", mask=None, relation_mat=None, batch_size=None, trainer=None):
+        self.dev = torch.device(device)
+        self.trainer = trainer
+        src = dataset_tensor(dataset)
+        if src is None or src.dim() != 4:
+            raise ValueError("Feed: the dataset must expose an (N, C, H, W) tensor (TensorDataset / tensor / ndarray); "
+                             "use feed='sync' for objects that only support dataset[ids]")
+        if src.shape[2] != src.shape[3]:
+            raise ValueError("Feed: square patches only")
+        self.src = src
+        self.N, self.C, self.H = src.shape[0], src.shape[1], src.shape[2]
+        self.bs = int(batch_size or 1)
+        mten = dataset_tensor(mask) if mask is not None else None
+        if mask is not None and (mten is None or mten.shape[0] != self.N or mten.shape[1] < 2):
+            raise ValueError("Feed: masks must expose an (N, >= 2, H, W) tensor")
+        self.has_mask = mten is not None
+        need = self.N * self.C * self.H * self.H * 4 + (self.N * mten.shape[2] * mten.shape[3] * 4 if self.has_mask else 0)
+        if mode == "auto":
+            mode = "resident" if need <= resident_budget(self.dev) else "stream"
+        if mode not in ("resident", "stream"):
+            raise ValueError(f"Feed: unknown mode {mode!r}")
+        self.mode = mode
+        self.bytes_resident = 0
+        with torch.cuda.device(self.dev):
+            if mode == "resident":
+                self.data = self._upload(src)
+                self.mplane = self._upload(mask_plane(mten)) if self.has_mask else None
+                self.bytes_resident = need
+            else:
+                self.mplane_host = mask_plane(mten) if self.has_mask else None
+                self._init_stream()
+            self.csr = None
+            if relation_mat is not None:
+                indptr, indices, data, n = _csr_arrays(relation_mat)
+                if n != self.N:
+                    raise ValueError("relation matrix and dataset disagree on the number of samples")
+                self.csr = (indptr.to(self.dev), indices.to(self.dev), data.to(self.dev), n)
+                self.pos = torch.zeros(n, dtype=torch.int64, device=self.dev)
+                self.stamp = 0
+        self._own = {}               # buffers of the feed (no FusedTrainer, or shapes it does not own)
+
+    # ------------------------------------------------------------------------------------------ resident
+    def _upload(self, t, chunk_bytes=1 << 29):
+        """Host tensor -> fp32 device tensor in chunks (a pinned source goes at the link rate; a pageable one through the
+        runtime's staging; another dtype is converted on the way)."""
+        out = torch.empty(tuple(t.shape), dtype=torch.float32, device=self.dev)
+        rows = max(1, chunk_bytes // max(1, t[0].numel() * t.element_size()))
+        nb = t.is_pinned() and t.dtype == torch.float32           # (anything else is staged by the runtime: blocking)
+        for lo in range(0, t.shape[0], rows):
+            out[lo:lo + rows].copy_(t[lo:lo + rows], non_blocking=nb)
+        return out
+
+    # ------------------------------------------------------------------------------------------ streaming
+    def _init_stream(self):
+        shape = (self.bs, self.C, self.H, self.H)
+        self.pin = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.slot = [torch.empty(shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        if self.has_mask:
+            mshape = (self.bs,) + tuple(self.mplane_host.shape[1:])
+            self.mpin = [torch.empty(mshape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self.mslot = [torch.empty(mshape, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.ev_ready = [torch.cuda.Event() for _ in range(2)]      # the batch has reached slot k
+        self.ev_used = [torch.cuda.Event() for _ in range(2)]       # the kernels reading slot k have finished
+        self.helper = ThreadPoolExecutor(1)
+
+    def _stage(self, k, ids):
+        """Helper thread: host gather of one batch into pinned staging k, then its copy into device slot k."""
+        n = len(ids)
+        idx = torch.as_tensor(ids, dtype=torch.int64)
+        self.ev_ready[k].synchronize()                               # staging k's previous copy has left the host
+        if self.src.dtype == torch.float32:
+            torch.index_select(self.src, 0, idx, out=self.pin[k][:n])
+        else:
+            self.pin[k][:n].copy_(self.src.index_select(0, idx))     # the reference's dtype handling: cast to fp32
+        if self.has_mask:
+            torch.index_select(self.mplane_host, 0, idx, out=self.mpin[k][:n])
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.ev_used[k])             # slot k is no longer being read
+            self.slot[k][:n].copy_(self.pin[k][:n], non_blocking=True)
+            if self.has_mask:
+                self.mslot[k][:n].copy_(self.mpin[k][:n], non_blocking=True)
+            self.ev_ready[k].record(self.copy_stream)
+
+    # ------------------------------------------------------------------------------------------ targets
+    def _targets(self, n, want_tm, fused):
+        xs = (n, self.C, self.H, self.H)
+        ms = ((n,) + tuple((self.mplane if self.mode == "resident" else self.mplane_host).shape[1:])) if self.has_mask else None
+        ts = (n, n) if want_tm else None
+        if fused and self.trainer is not None:
+            return self.trainer.static_inputs(xs, ms, ts)
+        key = (n, want_tm)
+        if key not in self._own:
+            self._own[key] = (torch.empty(xs, device=self.dev), torch.empty(ms, device=self.dev) if ms else None,
+                              torch.empty(ts, device=self.dev) if ts else None)
+        return self._own[key]
+
+    def phase(self, batches, transform=None, fused=True):
+        """Generator over the non-empty batches of one phase (lists of sample ids): (n, x, kwargs)."""
+        batches = [list(b) for b in batches if len(b)]
+        if not batches:
+            return
+        total = sum(len(b) for b in batches)
+        with torch.cuda.device(self.dev):
+            # the ids and the augmentation codes of the WHOLE phase: one small upload each.  The codes are drawn batch by
+            # batch in the order the reference draws them (nothing else draws from numpy's generator inside a phase).
+            flat = np.concatenate([np.asarray(b, dtype=np.int32) for b in batches])
+            ids_dev = torch.from_numpy(flat).to(self.dev)
+            flips = rots = None
+            if transform is not None:
+                codes = [ops.augment_codes(len(b)) for b in batches]
+                flips = torch.from_numpy(np.concatenate([c[0] for c in codes])).to(self.dev)
+                rots = torch.from_numpy(np.concatenate([c[1] for c in codes])).to(self.dev)
+            compute = torch.cuda.current_stream(self.dev)
+            pending = None
+            if self.mode == "stream":
+                pending = self.helper.submit(self._stage, 0, batches[0])
+            off = 0
+            for i, ids in enumerate(batches):
+                n = len(ids)
+                x, m, tm = self._targets(n, self.csr is not None, fused)
+                sl = slice(off, off + n)
+                fl, ro = (flips[sl], rots[sl]) if flips is not None else (None, None)
+                if self.mode == "resident":
+                    ops.gather_augment(self.data, ids_dev[sl], fl, ro, x, n)
+                    if m is not None:
+                        ops.gather_rows(self.mplane, ids_dev[sl], m, n)
+                else:
+                    k = i & 1
+                    pending.result()
+                    if i + 1 < len(batches):
+                        pending = self.helper.submit(self._stage, 1 - k, batches[i + 1])
+                    compute.wait_event(self.ev_ready[k])
+                    ops.gather_augment(self.slot[k], None, fl, ro, x, n)
+                    if m is not None:
+                        ops.gather_rows(self.mslot[k], None, m, n)
+                    self.ev_used[k].record(compute)
+                if tm is not None:
+                    self.stamp = self.stamp % ((1 << 31) - 2) + 1
+                    ops.csr_block(*self.csr, ids_dev[sl], self.pos, self.stamp, tm)
+                off += n
+                yield n, x, {"time_matching_mat": tm, "batch_mask": m}
+        assert off == total
+
+    def close(self):
+        if self.mode == "stream":
+            self.helper.shutdown(wait=True)

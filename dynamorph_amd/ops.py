@@ -755,3 +755,79 @@ def augment(x, flip_code, rot_code):
     L.check(lib.dm_augment(_ptr(x), _ptr(out), _ptr(flip_code, torch.int32), _ptr(rot_code, torch.int32), B, Cn, H,
                            _stream()), "dm_augment")
     return out
+
+
+# ----------------------------------------------------------------------------- feeding the step (csrc/feed.hip)
+@_op
+def gather_augment(src, ids, flip_code, rot_code, out, n=None):
+    """out[:n] = rot90(flip(src[ids], flip), rot) (run_training.py:512 + :396-403) in one launch.  src (N, C, H, H) fp32
+    in HBM, ids / codes int32 device vectors (None: the first n samples in order / no augmentation); `out` is written in
+    place (the captured step's input buffer) and returned."""
+    lib = L.load()
+    N, Cn, H, W = src.shape
+    if H != W:
+        raise ValueError("dm_gather_augment: square patches only")
+    n = int(n if n is not None else (ids.numel() if ids is not None else out.shape[0]))
+    if out.shape[0] < n or tuple(out.shape[1:]) != (Cn, H, W):
+        raise ValueError(f"dm_gather_augment: out {tuple(out.shape)} does not hold {n} x {(Cn, H, W)}")
+    for t in (ids, flip_code, rot_code):
+        if t is not None and t.numel() < n:
+            raise ValueError("dm_gather_augment: fewer ids / codes than samples")
+    L.check(lib.dm_gather_augment(_ptr(src), N, _ptr(ids, torch.int32), _ptr(flip_code, torch.int32),
+                                  _ptr(rot_code, torch.int32), _ptr(out), n, Cn, H, _stream()), "dm_gather_augment")
+    return out
+
+
+@_op
+def gather_rows(src, ids, out, n=None):
+    """out[:n] = src[ids] for (N, ...) fp32 rows (the mask planes of a batch, run_training.py:371)."""
+    lib = L.load()
+    row = src[0].numel()
+    n = int(n if n is not None else (ids.numel() if ids is not None else out.shape[0]))
+    if out.shape[0] < n or out[0].numel() != row:
+        raise ValueError("dm_gather_rows: out does not hold n rows of the source's size")
+    if ids is not None and ids.numel() < n:
+        raise ValueError("dm_gather_rows: fewer ids than rows")
+    L.check(lib.dm_gather_rows(_ptr(src), src.shape[0], _ptr(ids, torch.int32), _ptr(out), n, row, _stream()),
+            "dm_gather_rows")
+    return out
+
+
+@_op
+def csr_block(indptr, indices, data, n, ids, pos, stamp, out):
+    """out (B, B) = relation_mat[ids, :][:, ids].todense() (run_training.py:348-351) from CSR arrays in HBM."""
+    lib = L.load()
+    B = ids.numel()
+    if tuple(out.shape) != (B, B) or pos.numel() < n or indptr.numel() != n + 1:
+        raise ValueError("dm_csr_block: shapes do not match")
+    if indices.numel() == 0:                      # an empty matrix: scipy hands over zero-length arrays (no pointer)
+        out.zero_()
+        return out
+    L.check(lib.dm_csr_block(_ptr(indptr, torch.int64), _ptr(indices, torch.int32), _ptr(data), n, _ptr(ids, torch.int32),
+                             B, _ptr(pos, torch.int64), int(stamp), _ptr(out), _stream()), "dm_csr_block")
+    return out
+
+
+def augment_codes(n):
+    """(flip, rot) int32 numpy arrays for n samples, drawn from numpy's GLOBAL legacy generator exactly as the
+    reference's per-sample loop draws them (run_training.py:399-402: choice([0,1,2]) then choice([0,1,2,3]), interleaved)
+    -- a caller's np.random.seed reproduces the reference's augmentation -- without 2n Python-level draws: the
+    generator's 32-bit words are drawn in one block, parsed by dm_augment_codes (host C), and the generator is left
+    where the n interleaved calls would have left it."""
+    import numpy as np
+    lib = L.load()
+    flip = np.empty(n, np.int32)
+    rot = np.empty(n, np.int32)
+    if n == 0:
+        return flip, rot
+    state = np.random.get_state()
+    m = 3 * n + 64                                 # expected 2.33 words per sample; retried (doubling) if short
+    while True:
+        raw = np.random.randint(0, 2 ** 32, size=m, dtype=np.uint32)
+        used = lib.dm_augment_codes(raw.ctypes.data, m, n, flip.ctypes.data, rot.ctypes.data)
+        np.random.set_state(state)
+        if used >= 0:
+            break
+        m *= 2
+    np.random.randint(0, 2 ** 32, size=int(used), dtype=np.uint32)      # advance by exactly the words consumed
+    return flip, rot

@@ -69,7 +69,7 @@ class FusedTrainer:
         self.w_recon = torch.tensor([float(getattr(model, "weight_recon", 1.0))], device=dev)
         self.w_commit = torch.tensor([float(getattr(model, "weight_commitment", 1.0))], device=dev)
         self.use_graph = use_graph
-        self._graphs = {}            # input shapes -> (graph, static x, static mask, static matrix, static output)
+        self._graphs = {}            # input shapes -> {x, mask, tm: static inputs; train / eval: (graph, static output)}
         self._static_x = None        # input tensor of the graph replayed last
         D.broadcast_(self.flat, list(model.buffers()), group=self.group)    # same replica everywhere
 
@@ -81,11 +81,14 @@ class FusedTrainer:
         """Make p.grad point at the flat gradient views (for inspection / torch tooling)."""
         self.fp.expose_grads()
 
-    def _time_matching(self, sim, tm):
+    def _time_matching(self, sim, tm, z16_form=None):
         """(loss, d loss / d sim) of the pairwise term on the (B, B) matrix of mean-squared latent distances:
-        vq_vae.py:330-331 (sum of sim * matrix) or, for VQ_VAE_z16, vae.py:327-336 (weights, hinge, mean)."""
+        vq_vae.py:330-331 (sum of sim * matrix) or, for VQ_VAE_z16 / VQ_VAE_z32 (z16_form), vae.py:327-336 (weights,
+        hinge, mean).  Only for latent lengths the MFMA kernels do not tile (n % 32 != 0)."""
         model = self.model
-        if not getattr(model, "_z16_loss", False):
+        if z16_form is None:
+            z16_form = getattr(model, "_z16_loss", False)
+        if not z16_form:
             return (sim * tm).sum(), tm
         wts = torch.where(tm == 2, torch.full_like(tm, model.w_a),
                           torch.where(tm == 1, torch.full_like(tm, model.w_t),
@@ -128,10 +131,9 @@ class FusedTrainer:
                 tml = tml.reshape(())
             else:
                 sim = ops.pair_msd(zf)
-                self.model._z16_loss = True                 # (the weighted-hinge form)
-                tml, g_sim = self._time_matching(sim, tmf)
+                tml, g_sim = self._time_matching(sim, tmf, True)      # (VQ_VAE_z32: always the weighted-hinge form)
                 g_zq = g_zq + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(zq.shape)
-            scalars = torch.cat([scalars[:2], (scalars[2] + wm * tml).reshape(1), scalars[3:4], tml.reshape(1)])
+            scalars = _with_matching(scalars, tml, wm)
         gcb = self.G(m.vq.w.weight)
         dz, cb_slabs = ops.vq_backward_slabs(z, m.vq.w.weight.detach(), idx, g_zq, self.w_commit, cc)
         pending.append((cb_slabs, gcb))
@@ -179,7 +181,7 @@ class FusedTrainer:
                 sim = ops.pair_msd(zf)
                 tml, g_sim = self._time_matching(sim, tm)
                 dz = dz + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(z.shape)
-            scalars = torch.cat([scalars[:2], (scalars[2] + wm * tml).reshape(1), scalars[3:4], tml.reshape(1)])
+            scalars = _with_matching(scalars, tml, wm)
         # the flat gradient buffer starts at zero and nothing ever writes the BatchNorm-fed conv biases' slots
         E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False, pending_extra=extra)
         return scalars
@@ -249,6 +251,49 @@ class FusedTrainer:
         out["steps"] = len(timers)
         return out
 
+    def forward_only(self, x, mask=None, time_matching_mat=None):
+        """The validation pass (run_training.py:522-531: forward with the module left in train mode, so BatchNorm uses
+        batch statistics and advances its running statistics; no backward, no step).  Same kernels as forward_backward;
+        returns the same device tensor (recon, commitment, total, perplexity[, time matching])."""
+        m, tm = self.model, time_matching_mat
+        B, NIN, H, W = x.shape
+        cc = float(m.commitment_cost)
+        if self._z32:
+            enc, dec = m.enc, m.dec
+            h, _ = E.z32_stem_forward(enc[0], enc[1], enc[3], enc[4], x)
+            z, _ = E.residual_forward(enc[5]._handles(), h)
+            zq, _, vqs = E.vq_forward(m.vq.w.weight, z, cc, defer_scalars=True)
+            r, _ = E.residual_forward(dec[0]._handles(), zq)
+            _, tcx = E.z32_tail_forward(dec[1], dec[2], dec[4], r, x, mask, m.channel_var)
+            slabs, wr, wc, lat = tcx.loss_slabs, 1.0, 1.0, zq
+        else:
+            L = E.Layers(m)
+            z, _ = E.encoder_forward(L, x)
+            zq, _, vqs = E.vq_forward(L.codebook.weight, z, cc, defer_scalars=True)
+            _, dcx = E.decoder_forward(L, zq, x, mask)
+            slabs, wr, wc, lat = dcx.loss_slabs, float(m.weight_recon), float(m.weight_commitment), z
+        scalars = ops.vq_loss_finalize(vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, slabs, B * NIN * H * W, wr, wc)
+        if tm is not None:
+            zf = lat.reshape(B, -1)
+            z16 = self._z32 or getattr(m, "_z16_loss", False)
+            if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
+                tml, _ = ops.time_matching_forward(zf, tm.to(torch.float32).contiguous(), 1 if z16 else 0,
+                                                   float(getattr(m, "w_a", 0.0)), float(getattr(m, "w_t", 0.0)),
+                                                   float(getattr(m, "w_n", 0.0)), float(getattr(m, "margin", 0.0)))
+            else:
+                tml, _ = self._time_matching(ops.pair_msd(zf), tm.to(torch.float32), z16)
+            scalars = _with_matching(scalars, tml, float(m.weight_matching))
+        return scalars
+
+    def evaluate(self, x, mask=None, time_matching_mat=None):
+        """forward_only through a captured HIP graph (one per input shape); returns the device tensor of loss values."""
+        if not x.is_cuda or x.device != self.flat.device:
+            raise RuntimeError(f"FusedTrainer.evaluate: batch on {x.device}, model on {self.flat.device}")
+        with torch.cuda.device(self.flat.device):
+            if not self.use_graph:
+                return self.forward_only(x.contiguous(), mask, time_matching_mat)
+            return self._graph_step(x.contiguous(), mask, time_matching_mat, kind="eval")
+
     def prepare(self, x, mask=None, time_matching_mat=None):
         """Capture the HIP graph for this input shape WITHOUT taking a step (the capture's internal warm-up run has its
         BatchNorm side effects put back, parameters and Adam state are untouched): a caller that times steps can keep the
@@ -259,19 +304,31 @@ class FusedTrainer:
             self._graph_step(x.contiguous(), mask, time_matching_mat, replay=False)
         return self._static_x
 
-    def _graph_step(self, x, mask, tm=None, replay=True):
+    def static_inputs(self, x_shape, mask_shape=None, tm_shape=None):
+        """(x, mask, matrix) buffers the graphs of this input shape read: a loader that fills them in place and passes
+        them to step() / evaluate() skips every copy (dynamorph_amd.train._Feed writes its gathered batches here).
+        Allocated on first use, shared by the training and the validation graph of the shape; nothing is captured here."""
+        key = (tuple(x_shape), None if mask_shape is None else tuple(mask_shape), None if tm_shape is None else tuple(tm_shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            dev = self.flat.device
+            ent = self._graphs[key] = {
+                "x": torch.zeros(key[0], device=dev), "mask": torch.zeros(key[1], device=dev) if key[1] else None,
+                "tm": torch.zeros(key[2], device=dev) if key[2] else None, "train": None, "eval": None}
+        return ent["x"], ent["mask"], ent["tm"]
+
+    def _graph_step(self, x, mask, tm=None, replay=True, kind="train"):
         """Graphs are cached per input shape (a ragged last batch gets its own, captured once, not once per epoch)."""
-        key = (tuple(x.shape), None if mask is None else tuple(mask.shape), None if tm is None else tuple(tm.shape))
-        entry = self._graphs.get(key)
-        if entry is None:
-            sx = torch.empty_like(x)
-            smask = torch.empty_like(mask) if mask is not None else None
-            stm = torch.empty_like(tm, dtype=torch.float32) if tm is not None else None
+        sx, smask, stm = self.static_inputs(x.shape, None if mask is None else mask.shape, None if tm is None else tm.shape)
+        if x.data_ptr() != sx.data_ptr():           # a loader may write straight into the static buffers
             sx.copy_(x)
-            if mask is not None:
-                smask.copy_(mask)
-            if tm is not None:
-                stm.copy_(tm)
+        if mask is not None and mask.data_ptr() != smask.data_ptr():
+            smask.copy_(mask)
+        if tm is not None and tm.data_ptr() != stm.data_ptr():
+            stm.copy_(tm)
+        ent = self._graphs[(tuple(x.shape), None if mask is None else tuple(mask.shape), None if tm is None else tuple(tm.shape))]
+        if ent[kind] is None:
+            fn = self.forward_backward if kind == "train" else self.forward_only
             # warm-up on a side stream (allocator + lazy init), then capture.  The warm-up really executes,
             # so the BatchNorm running statistics it advanced are put back: only replays count as steps.
             bufs = list(self.model.buffers())
@@ -279,30 +336,28 @@ class FusedTrainer:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.forward_backward(sx, smask, stm)
+                fn(sx, smask, stm)
             torch.cuda.current_stream().wait_stream(s)
             for b, sv in zip(bufs, saved):
                 b.copy_(sv)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                sout = self.forward_backward(sx, smask, stm)
-            entry = self._graphs[key] = (g, sx, smask, stm, sout)
-        else:
-            _, sx, smask, stm, _ = entry
-            if x.data_ptr() != sx.data_ptr():      # a loader may write straight into input_buffer()
-                sx.copy_(x)
-            if mask is not None and mask.data_ptr() != smask.data_ptr():
-                smask.copy_(mask)
-            if tm is not None:
-                stm.copy_(tm)
-        self._static_x = entry[1]
+                sout = fn(sx, smask, stm)
+            ent[kind] = (g, sout)
+        self._static_x = sx
         if replay:
-            entry[0].replay()
-        return entry[4]
+            ent[kind][0].replay()
+        return ent[kind][1]
 
     def input_buffer(self):
         """Input tensor of the graph replayed last (None before the first step): fill it in place to skip the copy."""
         return self._static_x
+
+
+def _with_matching(scalars, tml, wm):
+    """(recon, commitment, total, perplexity) + the pairwise term -> the five values of a step with a relation matrix."""
+    tml = tml.reshape(1)
+    return torch.cat([scalars[:2], scalars[2:3] + wm * tml, scalars[3:4], tml])
 
 
 class GraphedTrainer:
@@ -387,10 +442,12 @@ class GraphedTrainer:
 # ================================================================ reference-style loop mirrors
 def _augment(batch):
     """run_training.py:396-403: a random flip (none / up-down / left-right) and a random multiple of 90 degrees per
-    sample, drawn from numpy's global generator like the reference -- applied by ONE kernel instead of the O(B) loop."""
-    n = len(batch)
-    flips = torch.from_numpy(np.random.choice([0, 1, 2], size=n)).to(device=batch.device, dtype=torch.int32)
-    rots = torch.from_numpy(np.random.choice([0, 1, 2, 3], size=n)).to(device=batch.device, dtype=torch.int32)
+    sample, drawn from numpy's global generator in the reference's order (flip, rotation, flip, rotation, ...: a caller's
+    np.random.seed reproduces the reference's augmentation, ops.augment_codes) -- applied by ONE kernel instead of the
+    O(B) loop."""
+    flips, rots = ops.augment_codes(len(batch))
+    flips = torch.from_numpy(flips).to(batch.device)
+    rots = torch.from_numpy(rots).to(batch.device)
     return ops.augment(batch.contiguous(), flips, rots)
 
 
@@ -506,15 +563,69 @@ def _make_optimizer(model, lr, fused):
     return torch.optim.Adam(model.parameters(), lr=lr, betas=(.9, .999))
 
 
+class _LossLog:
+    """Per-batch loss values of one phase, kept on the device: a step's values are copied into a row (stream-ordered,
+    the captured step overwrites its output tensor on the next replay) and the whole phase is read back ONCE, instead of
+    the reference's float(loss) per key and step (run_training.py:409-414), which stalls the host on every step."""
+
+    def __init__(self, device, n_batches, width=8):
+        self.buf = torch.zeros((max(n_batches, 1), width), device=device)
+        self.meta = []                      # (keys, number of values, samples) per logged batch
+
+    def add(self, keys, vals, n):
+        k = vals.numel()
+        self.buf[len(self.meta), :k].copy_(vals.detach().reshape(-1), non_blocking=True)
+        self.meta.append((keys, k, n))
+
+    def rows(self):
+        """[(dict key -> float, samples)] in batch order; the one device synchronisation of the phase."""
+        host = self.buf[:max(len(self.meta), 1)].tolist()
+        out = []
+        for (keys, k, n), row in zip(self.meta, host):
+            d = dict(zip(keys, row[:k]))
+            d.setdefault("time_matching_loss", 0.)
+            out.append((d, n))
+        return out
+
+
+_FUSED_KEYS = LOSS_KEYS + ("time_matching_loss",)
+
+
+def _device_step(model, optimizer, x, kw, training, grad_weight):
+    """One batch that is already on the device -> (loss keys, device tensor of their values); nothing here waits for the
+    GPU.  Same arithmetic as run_one_batch for every kind of optimizer."""
+    mask, tm = kw.get("batch_mask"), kw.get("time_matching_mat")
+    if isinstance(optimizer, FusedTrainer):
+        vals = (optimizer.step(x, mask, tm, grad_weight=grad_weight) if training else optimizer.evaluate(x, mask, tm))
+        return _FUSED_KEYS[:vals.numel()], vals
+    if isinstance(optimizer, GraphedTrainer) and training:
+        vals = optimizer.step(x, mask, tm)
+        return _FUSED_KEYS[:vals.numel()], vals
+    with torch.enable_grad() if training else torch.no_grad():
+        _, loss_dict = model(x, **kw)
+        if training:
+            loss_dict['total_loss'].backward()
+            params = [p for p in model.parameters() if p.requires_grad]
+            if grad_weight != 1.0:
+                for p in params:
+                    if p.grad is not None:
+                        p.grad.mul_(float(grad_weight))
+            D.allreduce_grads_(params)
+            optimizer.step()
+            model.zero_grad()
+    keys = tuple(k for k, v in loss_dict.items() if torch.is_tensor(v))      # (a float entry is the constant 0. of :382)
+    return keys, torch.stack([loss_dict[k].detach().reshape(()).float() for k in keys])
+
+
 def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10, lr=0.001, batch_size=16,
           device='cuda:0', shuffle_data=False, transform=None, val_split_ratio=0.15, patience=20,
-          get_relation_tensor=None, get_mask=None, writer=None, fused=True):
+          get_relation_tensor=None, get_mask=None, writer=None, fused=True, feed="auto", stats=None):
     """The training loop of run_training.py:455-551 -- Adam, a contiguous validation block at a random start, epoch and
     batch loops, TensorBoard-style scalars, EarlyStopping checkpoint of the state_dict to <output_dir>/model.pt -- made
     data parallel (one process per GPU, torch.distributed initialised by the launcher):
 
-      * one process: split, shuffles and epoch losses exactly as the reference draws / aggregates them (numpy's global
-        generator in the reference's order, mean of the per-batch values);
+      * one process: split, shuffles, augmentation codes and epoch losses exactly as the reference draws / aggregates them
+        (numpy's global generator in the reference's order, mean of the per-batch values);
       * world > 1: the validation split and every shuffle come from ONE seed drawn on rank 0, so all ranks walk the same
         batches;
       * each global batch of `batch_size` samples is cut into contiguous per-rank shards (dist.shard_range); a rank
@@ -524,10 +635,19 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
       * epoch losses are exchanged once per epoch, the early-stopping decision is therefore the same everywhere;
       * rank 0 alone writes model.pt (atomically), the others wait at a barrier.
 
+    feed (dynamorph_amd.feed): where a batch comes from.  "auto": the dataset, its masks and the CSR relation matrix are
+    uploaded once and stay in HBM when they fit ("resident": a batch is one gather + augment launch into the captured
+    step's input buffer, losses are read back once per phase, the host never waits inside an epoch), else "stream"
+    (pinned staging, copy stream, two device slots: PCIe-bound); "sync": the reference's loop as it is (host gather,
+    synchronous copy, float() per step) -- taken automatically on the CPU, for dataset objects that only support
+    dataset[ids], and when the caller brings its own get_relation_tensor / get_mask.  All feeds produce the same batches.
+    stats: a dict that receives {"feed", "phase_seconds": {phase: [per epoch]}, "phase_samples": {phase: n}}.
+
     `dataset` is a TensorDataset-like object indexable with a list of ids (dataset[ids][0] -> host tensor)."""
     assert val_split_ratio is None or 0 < val_split_ratio < 1
     if patience is not None:
         assert val_split_ratio is not None
+    custom_hooks = get_relation_tensor is not None or get_mask is not None
     if get_relation_tensor is None and relation_mat is not None:
         get_relation_tensor = globals()["get_relation_tensor"]
     if get_mask is None and mask is not None:
@@ -538,6 +658,21 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     rank, world = D.get_rank(), D.world_size()
     optimizer = _make_optimizer(model, lr, fused)
     model.zero_grad()
+
+    if feed not in ("auto", "resident", "stream", "sync"):
+        raise ValueError(f"train: unknown feed {feed!r}")
+    feeder = None
+    if feed != "sync":
+        from . import feed as F
+        usable = dev.type == "cuda" and not custom_hooks and F.dataset_tensor(dataset) is not None
+        if usable:
+            feeder = F.Feed(dataset, dev, mode=feed, mask=mask, relation_mat=relation_mat, batch_size=batch_size,
+                            trainer=optimizer if isinstance(optimizer, FusedTrainer) else None)
+        elif feed != "auto":
+            raise ValueError(f"train: feed={feed!r} needs a CUDA device, a tensor-backed dataset and the default "
+                             "get_relation_tensor / get_mask")
+    if stats is not None:
+        stats.update(feed=feeder.mode if feeder else "sync", phase_seconds={"train": [], "val": []}, phase_samples={})
 
     n_samples = len(dataset)
     sample_ids = list(range(n_samples))
@@ -560,27 +695,54 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     early_stopping = EarlyStopping(patience=patience, verbose=(rank == 0), path=os.path.join(output_dir, 'model.pt'))
     early_stopping.writes = rank == 0
     say = print if rank == 0 else (lambda *a, **k: None)
+    import time
     for epoch in range(n_epochs):
         say('start epoch %d' % epoch)
         epoch_means = {}
         for phase, ids in phases.items():
+            t_phase = time.perf_counter()
+            training = phase == "train"
             losses = _EpochLosses(dev if dev.type == "cuda" else None, world)
+            # this rank's shard of every global batch and the weight of its gradient in the data-parallel mean
+            plan = []
             for start in range(0, len(ids), batch_size):
                 ids_batch = ids[start:start + batch_size]
                 lo, hi = D.shard_range(len(ids_batch), rank, world)
-                ids_local = ids_batch[lo:hi]
-                if not ids_local:
-                    if phase == "train":
-                        _step_without_data(model, optimizer)
-                    continue
-                batch = dataset[ids_local][0].to(dev)
-                kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_local, device=dev) if get_relation_tensor else None,
-                      'batch_mask': get_mask(mask, ids_local, device=dev) if get_mask else None}
-                last = {}
-                run_one_batch(model, batch, last, optimizer=optimizer, model_kwargs=kw, transform=transform,
-                              training=(phase == "train"), grad_weight=len(ids_local) * world / len(ids_batch))
-                losses.add(last, len(ids_local))
+                plan.append((ids_batch[lo:hi], (hi - lo) * world / len(ids_batch)))
+            if feeder is not None:
+                log = _LossLog(dev, len(plan))
+                batches = feeder.phase([p[0] for p in plan], transform, fused=isinstance(optimizer, FusedTrainer))
+                for ids_local, weight in plan:
+                    if not ids_local:
+                        if training:
+                            _step_without_data(model, optimizer)
+                        continue
+                    n, x, kw = next(batches)
+                    keys, vals = _device_step(model, optimizer, x, kw, training, weight)
+                    log.add(keys, vals, n)
+                for _ in batches:                                   # (runs the generator to its end)
+                    pass
+                for row, n in log.rows():                           # the phase's one read-back
+                    losses.add({k: [v] for k, v in row.items()}, n)
+            else:
+                for ids_local, weight in plan:
+                    if not ids_local:
+                        if training:
+                            _step_without_data(model, optimizer)
+                        continue
+                    batch = dataset[ids_local][0].to(dev)
+                    kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_local, device=dev) if get_relation_tensor else None,
+                          'batch_mask': get_mask(mask, ids_local, device=dev) if get_mask else None}
+                    last = {}
+                    run_one_batch(model, batch, last, optimizer=optimizer, model_kwargs=kw, transform=transform,
+                                  training=training, grad_weight=weight)
+                    losses.add(last, len(ids_local))
             epoch_means[phase] = losses.means()
+            if stats is not None:
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                stats["phase_seconds"][phase].append(time.perf_counter() - t_phase)
+                stats["phase_samples"][phase] = sum(len(p[0]) for p in plan)
         if shuffle_data:
             order.shuffle(phases["train"])
         if writer is not None and rank == 0:
@@ -595,4 +757,6 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
         say('epoch %d' % epoch)
         for phase, label in (("train", 'train: '), ("val", 'validation: ')):
             say(label, ''.join(['{}:{:0.4f}  '.format(key, loss) for key, loss in epoch_means[phase].items()]))
+    if feeder is not None:
+        feeder.close()
     return model

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 114
+#define DM_VERSION 115
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -473,6 +473,27 @@ int dm_zscore_patch(const void *in, int in_is_f64, float *out, int planes, int H
  * flip_code 0 none / 1 flip H / 2 flip W, rot_code 0..3 (counter-clockwise, dims [1,2]). */
 int dm_augment(const float *in, float *out, const int32_t *flip_code, const int32_t *rot_code,
                int B, int C, int H, void *stream);
+
+/* ===== feeding the step from a dataset resident in HBM (run_training.py:504-532) ======================= */
+/* out[b] = rot90(flip(src[ids[b]], flip_code[b]), rot_code[b]): `dataset[ids][0].to(device)` (run_training.py:512) and the
+ * per-sample augmentation loop (run_training.py:396-403) as ONE launch that writes the batch where the step reads it.
+ * src is the whole dataset (n_src, C, H, H) fp32 in HBM; ids NULL = the first B samples in order (a batch that was
+ * copied over PCIe already); flip_code / rot_code NULL = no augmentation.  An id outside [0, n_src) yields zeros. */
+int dm_gather_augment(const float *src, int64_t n_src, const int32_t *ids, const int32_t *flip_code,
+                      const int32_t *rot_code, float *out, int B, int C, int H, void *stream);
+/* out[b] = src[ids[b]] for rows of row_floats floats (a multiple of 4; 16-byte aligned pointers): the mask planes of a
+ * batch, `mask[ids][0][:, 1:2]` of run_training.py:371 with the {-1,1} -> {0,1} map applied once at upload. */
+int dm_gather_rows(const float *src, int64_t n_src, const int32_t *ids, float *out, int B, int64_t row_floats,
+                   void *stream);
+/* out (B, B) = relation_mat[ids, :][:, ids].todense() (run_training.py:348-351) from the CSR arrays of the (n, n)
+ * matrix in HBM (duplicates summed, float32 values).  pos: n int64 of caller scratch, zeroed once; stamp: a number in
+ * [1, 2^31) that differs from the previous call's on the same scratch (entries of older calls are recognised by it). */
+int dm_csr_block(const int64_t *indptr, const int32_t *indices, const float *data, int64_t n, const int32_t *ids, int B,
+                 int64_t *pos, int64_t stamp, float *out, void *stream);
+/* HOST function (no device work): the flip / rotation codes of n samples parsed from `raw`, a run of 32-bit words of
+ * numpy's legacy generator, exactly as n interleaved np.random.choice([0,1,2]) / np.random.choice([0,1,2,3]) calls
+ * (run_training.py:399-402) consume them.  Returns the number of words consumed, -1 if `raw` is too short. */
+int64_t dm_augment_codes(const uint32_t *raw, int64_t n_raw, int64_t n, int32_t *flip_code, int32_t *rot_code);
 
 #ifdef __cplusplus
 }

@@ -233,3 +233,36 @@ def test_deepcopy_and_pickle_give_an_independent_module():
         buf.seek(0)
         r = torch.load(buf, weights_only=False)
         assert list(r.state_dict().keys()) == list(m.state_dict().keys())
+
+
+def test_augmentation_codes_follow_the_reference_draw_order():
+    """run_training.py:396-403 draws np.random.choice([0,1,2]) then np.random.choice([0,1,2,3]) per sample, interleaved;
+    ops.augment_codes must hand out the same codes from the same seed and leave numpy's generator where the loop leaves it."""
+    from dynamorph_amd import ops
+    for n in (0, 1, 7, 2048, 5000):
+        np.random.seed(1000 + n)
+        want = [(int(np.random.choice([0, 1, 2])), int(np.random.choice([0, 1, 2, 3]))) for _ in range(n)]
+        after = np.random.randint(0, 1 << 30, size=4).tolist()
+        np.random.seed(1000 + n)
+        flips, rots = ops.augment_codes(n)
+        assert flips.dtype == np.int32 and rots.dtype == np.int32 and len(flips) == n
+        assert list(zip(flips.tolist(), rots.tolist())) == want
+        assert np.random.randint(0, 1 << 30, size=4).tolist() == after
+
+
+def test_feed_host_helpers():
+    """mask_plane = run_training.py:371-372 for all samples at once; _csr_arrays sums duplicates like todense()."""
+    import scipy.sparse as sp
+    from dynamorph_amd.feed import _csr_arrays, dataset_tensor, mask_plane
+    m = (torch.rand(5, 2, 8, 8) > 0.5).float() * 2 - 1
+    ids = [3, 0, 4]
+    want = (torch.utils.data.TensorDataset(m)[ids][0][:, 1:2, :, :] + 1.) / 2.
+    assert torch.equal(mask_plane(m)[ids], want)
+    assert dataset_tensor(torch.utils.data.TensorDataset(m)) is m and dataset_tensor(object()) is None
+    coo = sp.coo_matrix((np.array([1.0, 1.0, 2.0]), (np.array([0, 0, 2]), np.array([1, 1, 0]))), shape=(3, 3))
+    indptr, indices, data, n = _csr_arrays(coo)
+    dense = np.zeros((3, 3), np.float32)
+    for r in range(3):
+        for e in range(int(indptr[r]), int(indptr[r + 1])):
+            dense[r, int(indices[e])] += float(data[e])
+    assert n == 3 and np.array_equal(dense, np.asarray(coo.todense(), np.float32))
