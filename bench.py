@@ -620,6 +620,13 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * elapsed / args.steps]
+    if world > 1:
+        # every rank's own wall time of the timed region (after the closing barrier they differ only by launch skew)
+        mine = torch.tensor([rank_ms[0]], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        rank_ms = [float(t.item()) for t in allr]
     elapsed = D.max_over_ranks(elapsed, device=dev)
 
     losses = out.tolist() if args.workload in ("c3", "c5", "z32ex") else None
@@ -639,6 +646,7 @@ def main():
                       "fwd_bwd_graph_us": parts["fwd_bwd_us"], "adam_us": parts["adam_us"],
                       "fwd_bwd_host_us": parts["fwd_bwd_host_us"], "adam_host_us": parts["adam_host_us"],
                       "nccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+                      "rank_ms_per_step_min": round(min(rank_ms), 4), "rank_ms_per_step_max": round(max(rank_ms), 4),
                       "op": "all_reduce(SUM) of the flat fp32 gradient bucket, then x 1/world" if world > 1 else "none (one process)"}
         if world > 1:
             dist.barrier()

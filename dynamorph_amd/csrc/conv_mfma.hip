@@ -1547,7 +1547,11 @@ extern "C" int dm_backward_precision(int mode)
 
 static int fused_bwd_dbg()
 {
+#ifdef DM_MEASURE      // ablation switches exist only in a measurement build (make MEASURE=1): they make results wrong
     static const int v = [] { const char *e = getenv("DM_FUSED_BWD_DBG"); return e ? atoi(e) : 0; }();
+#else
+    static const int v = 0;
+#endif
     return v;
 }
 

@@ -33,8 +33,10 @@ constexpr int VQ_MAX_LDS_HIST = 4096;
 //   hrep    [R][K] int32  replicated code-usage counters (vq_hist_replicas), or -- codebooks of at most 64 codes with
 //           embedding_dim 16/32/64 through the MFMA kernel, which then needs no preparation launch at all -- one row of
 //           VQ2_SLAB_STRIDE ints per WORKGROUP: its 64 counters and, at [64], the positions it re-evaluated exactly
-//           (plain stores: nothing to zero, no atomics).  header[1] = rows in use, header[2] = row stride (written by
-//           whichever kernel filled the counters; the finalisers read them on the device)
+//           (plain stores: nothing to zero, no atomics).  header[1] = rows in use, header[2] = row stride, header[3] = row
+//           format (1: per-workgroup rows, 0: replicas -- an explicit flag: a codebook of exactly VQ2_SLAB_STRIDE codes has
+//           that stride on the replica path too), written by whichever kernel filled the counters; the finalisers read
+//           them on the device
 constexpr int VQ2_HDR = 32;
 constexpr int VQ2_SLAB_ROWS = 1024, VQ2_SLAB_STRIDE = 72;
 constexpr float VQ2_PAD_NORM = 3.0e38f;
@@ -111,7 +113,7 @@ __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__
         cbA[i] = (code < K && d < D) ? -2.f * cb[code * D + d] : 0.f;
     }
     if (D % 16 == 0 && D <= 64) {
-        // bf16-split A operand: -2e = hi + lo + r with hi = bf16(-2e), lo = bf16(-2e - hi), |r| <= 2^-18 |2e|
+        // bf16-split A operand: -2e = hi + lo + r with hi = bf16(-2e), lo = bf16(-2e - hi), |r| <= 2^-17 |2e|
         unsigned *__restrict__ cbB = reinterpret_cast<unsigned *>(ws + L.cbB);
         const int U = D / 16;
         for (long long i = t0; i < K64 * 2 * D / 2; i += nt) {           // one packed pair of k-slots (j = 2 jp, 2 jp + 1) per step
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(1024) void vq_hist_reduce_kernel(const int *__restr
     __shared__ int s_cnt[16][65];
     const int R = hdr[1], stride = hdr[2];
     const int kl = threadIdx.x & 63, g = threadIdx.x >> 6, k = blockIdx.x * 64 + kl;
-    const bool slabs = stride == VQ2_SLAB_STRIDE;          // per-workgroup rows: column 64 = positions re-evaluated exactly
+    const bool slabs = hdr[3] == 1;                        // per-workgroup rows: column 64 = positions re-evaluated exactly
     int h = 0, n = 0;
     for (int r0 = g; r0 < R; r0 += 512) {
         int v[32];
@@ -517,7 +519,7 @@ __device__ __forceinline__ void vq2_swap(float &x, float &y)
 // On gfx950 the f32 MFMA and the VALU do not overlap (SQ_VALU_MFMA_COEXEC_CYCLES = 0: the kernel's time is the SUM of its
 // matrix and vector instructions), so what is left to optimise is the instruction count of everything around the MFMAs.
 // BF: the filter product on v_mfma_f32_16x16x32_bf16 with both operands split into a bf16 head and a bf16 remainder
-// (z = z_hi + z_lo + r, |r| <= 2^-18 |z|; likewise -2e, split once by vq_prep_kernel).  The 32 k-slots of one instruction
+// (z = z_hi + z_lo + r, |r| <= 2^-17 |z|; likewise -2e, split once by vq_prep_kernel).  The 32 k-slots of one instruction
 // are (z_hi, z_lo) of 16 dimensions; two instructions per 16 dimensions (A = the heads of -2e, then its remainders) give
 // (a_hi + a_lo) . (z_hi + z_lo): a quarter of the matrix-pipe cycles of four v_mfma_f32_16x16x4_f32 steps (2 x 16 against
 // 4 x 32), on the real matrix cores -- the f32-input instruction runs at the vector rate and (SQ_VALU_MFMA_COEXEC_CYCLES
@@ -548,12 +550,15 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     // the header comment's bound: tol = 1.25 x (2 eta + 2 rho max(|z|^2 + s', 0)), eta = ETA u A, rho = (D/16 + 18) u.
     // f32 filter: ETA = D + 65 (D fused multiply-adds + the rounded norm, 64 of index bits).
     // bf16-split filter: ETA = 66 (norm, index bits)
-    //   + 128: the split's remainders -- |sum_d a z - sum_d (a_hi + a_lo)(z_hi + z_lo)| <= (2^-18 + 2^-18 + 2^-36) sum |a||z|
-    //          <= 2^-17 (|e|^2 + |z|^2) <= 2^-17 A = 128 u A  (the products of bf16 values are exact in fp32)
+    //   + 256: the split's remainders.  bf16 keeps 8 significand bits (unit roundoff 2^-8): |z - z_hi| <= 2^-8 2^e for z in
+    //          [2^e, 2^(e+1)), that remainder lies in a binade at or below 2^(e-9) (or is exactly 2^(e-8), which bf16 holds),
+    //          so |z - z_hi - z_lo| <= 2^-8 2^(e-9) <= 2^-17 |z| (attained: z = 1 + 2^-9 (2 - 2^-8)); hence
+    //          |sum_d a z - sum_d (a_hi + a_lo)(z_hi + z_lo)| <= (2^-17 + 2^-17 + 2^-34) sum |a||z|
+    //          <= 2^-16 (|e|^2 + |z|^2) <= 2^-16 A = 256 u A  (the products of bf16 values are exact in fp32)
     //   + 100 per matrix instruction: its 32 products + C are added in an order and with intermediate roundings the ISA does
     //          not specify; every partial sum is <= 1.01 A in magnitude, so 33 additions that each lose at most one ulp
     //          (2 u relative: truncation) stay below 67 u A -- taken as 100.
-    constexpr float ETA = BF ? 66.f + 128.f + 100.f * (2 * UG) : (float)(D + 65);
+    constexpr float ETA = BF ? 66.f + 256.f + 100.f * (2 * UG) : (float)(D + 65);
     constexpr float TOL_A = 2.5f * ETA * U, TOL_D = 2.5f * (D / 16 + 18) * U;
     __shared__ f32x4 s_A[SINGLE ? 1 : PIECE * CHUNK_F4];
     __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];
@@ -1100,7 +1105,8 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
         // this workgroup's row (its 64 counters, its re-evaluated positions at [64]), the header says how to read them
         for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x)
             if (threadIdx.x == 0) sse_slabs[t2] = 0.0;
-        if (blockIdx.x == 0 && threadIdx.x < 3) hdr[threadIdx.x] = threadIdx.x == 1 ? (int)gridDim.x : (threadIdx.x == 2 ? VQ2_SLAB_STRIDE : 0);
+        if (blockIdx.x == 0 && threadIdx.x < 4)
+            hdr[threadIdx.x] = threadIdx.x == 1 ? (int)gridDim.x : (threadIdx.x == 2 ? VQ2_SLAB_STRIDE : (threadIdx.x == 3 ? 1 : 0));
         if (lane == 0) s_em[wave] = __builtin_bit_cast(float, nflag);
         __syncthreads();                                       // (also: every wave's s_hist adds are done)
         if (threadIdx.x < 64) hist[threadIdx.x] = s_hist[threadIdx.x];
@@ -1187,7 +1193,7 @@ __global__ __launch_bounds__(1024) void vq_loss_finalize_kernel(const double *__
 #pragma unroll
         for (int j = 0; j < 8; ++j) l += v[j];
     }
-    if (stride == VQ2_SLAB_STRIDE && blockDim.x == 1024) {
+    if (hdr[3] == 1 && blockDim.x == 1024) {
         // per-workgroup slabs (<= 64 codes, up to 1024 rows): the sixteen waves take every sixteenth row, 64 codes side by
         // side, 32 rows in flight per wave: two memory round trips for 1024 rows
         const int k = threadIdx.x & 63, g = threadIdx.x >> 6;

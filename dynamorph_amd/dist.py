@@ -138,20 +138,62 @@ def allreduce_grads_(params, group=None):
         off += g.numel()
 
 
-def gather_shards(local, group=None):
-    """Host arrays of the contiguous per-rank shards (shard_range order) -> the full arrays, on every rank, in rank order
-    = input order.  The data path itself has no collective; this is the final hand-over of results on the host."""
+_host_groups = {}
+
+
+def host_group(group=None):
+    """A gloo group over the same ranks for hand-overs of HOST arrays: under the nccl (RCCL) backend every collective
+    moves device memory, so shipping results that already live in host memory through it would be a host -> HBM ->
+    xGMI -> HBM -> host round trip.  The default group itself when it is gloo already."""
+    if dist.get_backend(group) == "gloo":
+        return group
+    key = id(group)
+    if key not in _host_groups:
+        ranks = None if group is None else dist.get_process_group_ranks(group)
+        _host_groups[key] = dist.new_group(ranks=ranks, backend="gloo")     # (collective: every rank reaches this call)
+    return _host_groups[key]
+
+
+def gather_shards(local, group=None, dst=0):
+    """Host arrays of the contiguous per-rank shards (dist.shard_range order) -> the full arrays ON RANK `dst` ONLY (None
+    elsewhere), in rank order = input order (patch_VAE.py:454,459 stack in file-path order).  The data path itself has no
+    collective; this is the final hand-over of results on the host: rank `dst` allocates the (N, cols) result once and
+    every other rank's shard is received straight into its rows (point-to-point over gloo, no pickling, nothing
+    replicated -- round 3 all-gathered pickled copies of every shard onto every rank)."""
     if world_size(group) == 1:
         return local
     import numpy as np
-    parts = [None] * world_size(group)
-    dist.all_gather_object(parts, local, group=group)
-    def cat(arrs):
-        arrs = [a for a in arrs if a.shape[0] > 0] or [arrs[0]]          # ranks with an empty shard contribute nothing
-        return np.concatenate(arrs, 0)
-    if isinstance(local, (tuple, list)):
-        return type(local)(cat([p[i] for p in parts]) for i in range(len(local)))
-    return cat(parts)
+    single = not isinstance(local, (tuple, list))
+    arrs = [np.ascontiguousarray(a) for a in ((local,) if single else local)]
+    hg = host_group(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    to_global = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    # every rank's row count and the column layout of rank dst's result (a rank with an empty shard may not know it)
+    meta = [None] * world
+    dist.all_gather_object(meta, [(a.shape, str(a.dtype)) for a in arrs], group=hg)       # a few bytes per rank
+    if rank != dst:
+        for a in arrs:
+            if a.shape[0] > 0:
+                dist.send(torch.from_numpy(a), dst=to_global(dst), group=hg)
+        return None
+    out = []
+    for i, a in enumerate(arrs):
+        rows = [m[i][0][0] for m in meta]
+        tail = next((m[i][0][1:] for m in meta if m[i][0][0] > 0), a.shape[1:])
+        full = np.empty((sum(rows),) + tuple(tail), dtype=a.dtype)
+        out.append(full)
+    # (same order as the senders: array by array inside a rank)
+    for i, full in enumerate(out):
+        off = 0
+        for r in range(world):
+            n = meta[r][i][0][0]
+            if n > 0:
+                if r == dst:
+                    full[off:off + n] = arrs[i]
+                else:
+                    dist.recv(torch.from_numpy(full[off:off + n]), src=to_global(r), group=hg)
+            off += n
+    return out[0] if single else type(local)(out)
 
 
 def max_over_ranks(value, device=None, group=None):

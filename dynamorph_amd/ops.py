@@ -81,6 +81,10 @@ class WView:
     def __init__(self, w, sn, sc, sky, skx, off=0):
         if not (w.is_cuda and w.dtype == torch.float32):
             raise ValueError("dynamorph_amd: weights must be fp32 device tensors (the HIP path has no CPU fallback)")
+        if not w.is_contiguous():
+            # the strides below address a contiguous (n, c, ky, kx) tensor: a channels_last / transposed / sliced parameter
+            # would be read with the wrong layout
+            raise ValueError("dynamorph_amd: weights must be contiguous")
         self._keep = w
         self._scratch = None
         self.struct = L.WeightView(w.data_ptr(), off, sn, sc, sky, skx, None, 0)
@@ -123,6 +127,8 @@ def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, 
     want_rechecked: a fifth return value, the 1-element int32 device tensor counting the positions the MFMA kernel
     re-evaluated exactly (0 after the exact kernel)."""
     lib = L.load()
+    if want_rechecked and not want_hist:
+        raise ValueError("vq_forward: the re-check count is summed by the counter reduction (want_hist=True)")
     B, D, H, W = z.shape
     K = codebook.shape[0]
     nb = lib.dm_vq_num_blocks(B * H * W)

@@ -129,10 +129,11 @@ def encode_patches(model, patches, device="cuda:0", batch_size=1024, zscore_on_d
     return res[0].numpy(), res[1].numpy()
 
 
-def encode_patches_sharded(model, patches, device="cuda:0", batch_size=1024, zscore_on_device=False, group=None):
+def encode_patches_sharded(model, patches, device="cuda:0", batch_size=1024, zscore_on_device=False, group=None, dst=0):
     """encode_patches over a torch.distributed group: patches are independent (per-sample BatchNorm statistics), so rank r
     encodes the contiguous shard dist.shard_range(N, r, world) with no collective on the data path, and the (N, D*h*w)
-    results are handed over on the host in rank order = input order (patch_VAE.py:454,459 stack in file-path order).
+    results are handed over on the host to rank `dst` (the one that writes the pickles) in rank order = input order
+    (patch_VAE.py:454,459 stack in file-path order); the other ranks return None.
     BatchNorm running statistics advance per rank by that rank's shard only (they are not part of the outputs)."""
     from . import dist as D
     import torch.distributed as tdist
@@ -141,7 +142,7 @@ def encode_patches_sharded(model, patches, device="cuda:0", batch_size=1024, zsc
     rank = tdist.get_rank(group) if world > 1 else 0
     lo, hi = D.shard_range(patches.shape[0], rank, world)
     z_b, z_a = encode_patches(model, patches[lo:hi], device=device, batch_size=batch_size, zscore_on_device=zscore_on_device)
-    return D.gather_shards((z_b, z_a), group=group) if world > 1 else (z_b, z_a)
+    return D.gather_shards((z_b, z_a), group=group, dst=dst) if world > 1 else (z_b, z_a)
 
 
 def process_VAE(raw_folder, supp_folder, sites, config_, gpu=0, network_module=None, **kwargs):

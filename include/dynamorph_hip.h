@@ -120,7 +120,9 @@ int dm_vq_forward(const float *z, const float *codebook, int64_t *idx, float *ou
  *                indices; embedding_dim 16/32/64;
  *   DM_VQ_AUTO   DM_VQ_BF16 where it applies (DM_VQ_FILTER=f32 in the environment: DM_VQ_MFMA), else DM_VQ_MFMA, else
  *                DM_VQ_EXACT.
- * After a filtered call the first int32 of `workspace` holds the number of positions that took the exact path. */
+ * After a filtered call WITH hist != NULL the first int32 of `workspace` holds the number of positions that took the exact
+ * path.  With hist = NULL and at most 64 codes the count stays in column 64 of the per-workgroup counter rows (it is summed
+ * into workspace[0] only by the counter reduction that hist != NULL launches) and workspace[0] reads 0. */
 enum { DM_VQ_AUTO = 0, DM_VQ_EXACT = 1, DM_VQ_MFMA = 2, DM_VQ_BF16 = 3 };
 int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
                           double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,

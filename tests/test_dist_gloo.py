@@ -57,8 +57,15 @@ def _worker(rank, world, port, out_dir):
     n_items = 7
     a, b_ = D.shard_range(n_items, rank, world)
     full = np.arange(n_items * 3, dtype=np.float32).reshape(n_items, 3)
-    got = D.gather_shards((full[a:b_], 2 * full[a:b_]))
-    assert np.array_equal(got[0], full) and np.array_equal(got[1], 2 * full)
+    got = D.gather_shards((full[a:b_], 2 * full[a:b_]))          # to rank 0 only: nothing is replicated
+    if rank == 0:
+        assert np.array_equal(got[0], full) and np.array_equal(got[1], 2 * full)
+    else:
+        assert got is None
+    one = D.gather_shards(full[a:b_].astype(np.float64), dst=world - 1)
+    assert (np.array_equal(one, full) and one.dtype == np.float64) if rank == world - 1 else one is None
+    few = D.gather_shards(full[:1] if rank == world - 1 else full[:0])      # empty shards everywhere but on the last rank
+    assert np.array_equal(few, full[:1]) if rank == 0 else few is None
     t = D.max_over_ranks(1.0 + rank)
     torch.save({"flat0": flat0, "local": local, "mean": fp.grad.clone(), "helper": helper, "tmax": t, "range": (lo, hi)},
                os.path.join(out_dir, f"rank{rank}.pt"))

@@ -136,6 +136,33 @@ def test_vq_forward_vs_c_oracle(ops, cvq, B, D, K, H, W):
         assert abs(sse - float(((q - z).astype(np.float64) ** 2).sum())) <= 1e-6 * sse, variant
 
 
+@pytest.mark.parametrize("K", [64, 65, 71, 72, 73, 80, 144])
+def test_vq_counter_rows_are_told_apart_by_their_flag_not_their_stride(ops, cvq, K):
+    """A codebook of exactly 72 codes has the per-workgroup rows' stride (72 ints) on the REPLICA path: the finalisers must
+    go by the format word of the workspace header.  Histogram, re-check count and the step's fused scalar launch
+    (perplexity from the counters in the workspace) for code counts around it, on both counter formats (K = 64: rows)."""
+    B, D, H, W = 9, 16, 16, 16
+    z = rnd(B, D, H, W, seed=K).numpy()
+    cb = rnd(K, D, seed=K + 1).numpy()
+    idx_ref = _c_oracle_idx(cvq, z, cb)
+    counts = np.bincount(idx_ref.ravel(), minlength=K)
+    zt, ct = torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV)
+    for variant in (DM_VQ_AUTO, DM_VQ_MFMA, DM_VQ_BF16):
+        idx, out, slabs, hist = ops.vq_forward(zt, ct, variant=variant)
+        assert np.array_equal(idx.cpu().numpy(), idx_ref), variant
+        assert np.array_equal(hist.cpu().numpy(), counts), variant
+        # the training step's form: no counter reduction, one scalar launch reading the rows / replicas in the workspace
+        idx2, out2, slabs2, ws = ops.vq_forward(zt, ct, variant=variant, want_hist=False)
+        loss_slabs = torch.zeros(4, dtype=torch.float64, device=DEV)
+        sc = ops.vq_loss_finalize(slabs2, ws, K, D, B * H * W, 0.25, loss_slabs, 10, 1.0, 1.0).cpu().numpy()
+        p = counts.astype(np.float32) / np.float32(B * H * W)
+        perp = np.exp(-np.sum(p * np.log(p + np.float32(1e-10)), dtype=np.float64))
+        assert abs(sc[3] - perp) <= 2e-5 * perp, (variant, sc[3], perp)
+        q = cb[idx_ref].transpose(0, 3, 1, 2)
+        mse = float(((q - z).astype(np.float64) ** 2).mean())
+        assert abs(sc[1] - 1.25 * mse) <= 2e-6 * mse, variant
+
+
 def test_vq_mfma_rejects_what_it_cannot_tile(ops):
     with pytest.raises(ValueError):
         ops.vq_forward(rnd(1, 16, 8, 12).to(DEV), rnd(4, 16).to(DEV), variant=DM_VQ_MFMA)     # 96 positions per sample
