@@ -390,7 +390,9 @@ def train_loop_record(dev, resident_ms_per_step, n=16384, B=2048, epochs=3, feed
     synthetic HOST dataset: n patches, batch B, `epochs` timed epochs after one warm-up epoch (graph captures, allocator),
     augmentation on, validation block 1/8 of the data.  What `value` above cannot show: gathering a batch (on the device
     from the dataset in HBM, or over PCIe), the augmentation, the validation pass, the loss read-back.
-    train_patches_per_s = training-phase samples / training-phase wall time; loop_patches_per_s counts both phases."""
+    train_patches_per_s = training-phase samples / device time between the phase's first and last launch (every gap the
+    host leaves inside the phase included); loop_patches_per_s = samples of both phases / wall clock of whole epochs
+    (validation pass, loss read-back, early-stopping checkpoint included)."""
     import tempfile
     import numpy as np
     from dynamorph_amd import VQ_VAE
@@ -427,10 +429,9 @@ def train_loop_record(dev, resident_ms_per_step, n=16384, B=2048, epochs=3, feed
            "batch": B, "timed_epochs": len(tr), "augmentation": bool(transform), "masks": masks, "relation_matrix": relation,
            "host_dataset": "pinned" if pinned else "pageable",
            "train_patches_per_s": round(rate, 1), "train_ms_per_step": round(1e3 * sum(tr) / len(tr) / (ntr / B), 4),
-           "loop_patches_per_s": round((ntr + nva) * len(tr) / (sum(tr) + sum(va)), 1),
+           "loop_patches_per_s": round((ntr + nva) * len(tr) / sum(st["epoch_seconds"][1:]), 1),
            "val_patches_per_s": round(nva * len(va) / sum(va), 1),
-           "first_epoch_s": round(st["phase_seconds"]["train"][0] + st["phase_seconds"]["val"][0], 3),
-           "setup_s": round(total - sum(st["phase_seconds"]["train"]) - sum(st["phase_seconds"]["val"]), 3)}
+           "first_epoch_s": round(st["epoch_seconds"][0], 3), "setup_s": round(total - sum(st["epoch_seconds"]), 3)}
     if resident_ms_per_step:
         rec["vs_resident_bench"] = round(rate / (B / (resident_ms_per_step * 1e-3)), 4)
     return rec

@@ -641,7 +641,8 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     (pinned staging, copy stream, two device slots: PCIe-bound); "sync": the reference's loop as it is (host gather,
     synchronous copy, float() per step) -- taken automatically on the CPU, for dataset objects that only support
     dataset[ids], and when the caller brings its own get_relation_tensor / get_mask.  All feeds produce the same batches.
-    stats: a dict that receives {"feed", "phase_seconds": {phase: [per epoch]}, "phase_samples": {phase: n}}.
+    stats: a dict that receives {"feed", "phase_seconds": {phase: [per epoch]} (device time between the phase's first and
+    last launch; host wall time on the CPU), "phase_samples": {phase: n}, "epoch_seconds": [wall clock per epoch]}.
 
     `dataset` is a TensorDataset-like object indexable with a list of ids (dataset[ids][0] -> host tensor)."""
     assert val_split_ratio is None or 0 < val_split_ratio < 1
@@ -696,11 +697,16 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     early_stopping.writes = rank == 0
     say = print if rank == 0 else (lambda *a, **k: None)
     import time
+    timed = stats is not None and dev.type == "cuda"
     for epoch in range(n_epochs):
         say('start epoch %d' % epoch)
-        epoch_means = {}
+        t_epoch = time.perf_counter()
+        epoch_means, logs, marks = {}, {}, {}
         for phase, ids in phases.items():
             t_phase = time.perf_counter()
+            if timed:
+                marks[phase] = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+                marks[phase][0].record()
             training = phase == "train"
             losses = _EpochLosses(dev if dev.type == "cuda" else None, world)
             # this rank's shard of every global batch and the weight of its gradient in the data-parallel mean
@@ -722,8 +728,7 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                     log.add(keys, vals, n)
                 for _ in batches:                                   # (runs the generator to its end)
                     pass
-                for row, n in log.rows():                           # the phase's one read-back
-                    losses.add({k: [v] for k, v in row.items()}, n)
+                logs[phase] = (log, losses)                         # read back after BOTH phases are enqueued
             else:
                 for ids_local, weight in plan:
                     if not ids_local:
@@ -737,12 +742,23 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                     run_one_batch(model, batch, last, optimizer=optimizer, model_kwargs=kw, transform=transform,
                                   training=training, grad_weight=weight)
                     losses.add(last, len(ids_local))
-            epoch_means[phase] = losses.means()
+                epoch_means[phase] = losses.means()
             if stats is not None:
-                if dev.type == "cuda":
-                    torch.cuda.synchronize(dev)
-                stats["phase_seconds"][phase].append(time.perf_counter() - t_phase)
+                if timed:
+                    marks[phase][1].record()
+                else:
+                    stats["phase_seconds"][phase].append(time.perf_counter() - t_phase)
                 stats["phase_samples"][phase] = sum(len(p[0]) for p in plan)
+        # the epoch's one device synchronisation: the loss rows of both phases (the validation pass was enqueued behind the
+        # training steps without waiting for them)
+        for phase, (log, losses) in logs.items():
+            for row, n in log.rows():
+                losses.add({k: [v] for k, v in row.items()}, n)
+            epoch_means[phase] = losses.means()
+        if timed:
+            torch.cuda.synchronize(dev)
+            for phase, (e0, e1) in marks.items():                   # device time between the phase's first and last launch
+                stats["phase_seconds"][phase].append(e0.elapsed_time(e1) * 1e-3)
         if shuffle_data:
             order.shuffle(phases["train"])
         if writer is not None and rank == 0:
@@ -751,6 +767,8 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                     writer.add_scalar(prefix + key, value, epoch)
         early_stopping(epoch_means["val"]['total_loss'], model)
         D.barrier()                                          # model.pt is complete before any rank moves on
+        if stats is not None:
+            stats.setdefault("epoch_seconds", []).append(time.perf_counter() - t_epoch)      # wall clock, checkpoint included
         if early_stopping.early_stop:
             say("Early stopping")
             break
