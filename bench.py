@@ -83,6 +83,20 @@ def pmc_traffic(kernel_key, batch):
     return None
 
 
+def profile_avg_us(kernel_stem, stats_csv="r04_c3_b2048_kernel_stats.csv"):
+    """Average per-dispatch duration (us) of a kernel inside the step, from this round's committed `rocprofv3 --kernel-trace
+    --stats` summary of `bench.py` (bench.py cannot run under the profiler itself); None when it is not committed."""
+    import csv
+    try:
+        with open(os.path.join(ROOT, "profiles", stats_csv)) as f:
+            for r in csv.DictReader(f):
+                if kernel_stem in r["Name"]:
+                    return round(float(r["AverageNs"]) / 1e3, 2)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 EXAMPLE_CONFIG = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)     # config_example.yml:157-163
 
 
@@ -126,16 +140,20 @@ def roofline_vq_large_codebook(model, x):
     flops = 2.0 * K * D * P                      # the filter product |e|^2 - 2 z.e as an f32 GEMM: the algorithmic count
     useful = flops / (ms * 1e-3) / 1e12
     # DM_VQ_AUTO runs the product on v_mfma_f32_16x16x32_bf16 with both operands split into a bf16 head and remainder:
-    # 4 bf16 multiply-adds per f32 one, on the bf16 matrix pipe (2.5 PFLOP/s dense); DM_VQ_FILTER=f32 keeps the f32-input
-    # instruction (157.3 TFLOP/s, 1 executed per algorithmic)
+    # 4 bf16 multiply-adds EXECUTED per algorithmic one, on the bf16 matrix pipe (2.5 PFLOP/s dense); DM_VQ_FILTER=f32 keeps
+    # the f32-input instruction (157.3 TFLOP/s, 1 executed per algorithmic).  The roofline fraction is ALGORITHMIC work over
+    # the peak of the pipe the kernel runs on; the executed rate is reported beside it, not as `achieved`.
     bf16 = D % 16 == 0 and os.environ.get("DM_VQ_FILTER", "")[:1] != "f"
-    executed, peak = (4.0 * useful, MFMA_BF16_PEAK_TFLOPS) if bf16 else (useful, MFMA_F32_PEAK_TFLOPS)
+    peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+    executed = useful * (4.0 if bf16 else 1.0)
     return {"kernel": f"vq_forward_mfma_kernel<{D}, false, ..., {'bf16-split' if bf16 else 'f32'} filter> (K = {K} codes through LDS pieces; "
                       "distance + first-min argmin + gather + straight-through value + squared error)", "bound": "mfma",
-            "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
+            "achieved": round(useful, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(useful / peak, 4),
+            "pipe": "bf16 matrix (v_mfma_f32_16x16x32_bf16)" if bf16 else "f32 matrix (v_mfma_f32_16x16x4_f32)",
             "traffic": pmc_traffic("vq_forward_mfma_k4096", x.shape[0]), "avg_launch_ms": round(ms, 5),
-            "algorithmic_flops_per_launch": flops, "algorithmic_tflops": round(useful, 2),
+            "algorithmic_flops_per_launch": flops,
             "algorithmic_vs_f32_mfma_peak": round(useful / MFMA_F32_PEAK_TFLOPS, 4),
+            "executed_tflops": round(executed, 2), "executed_frac_of_pipe_peak": round(executed / peak, 4),
             "executed_flops_per_launch": flops * (4.0 if bf16 else 1.0),
             "algorithmic_bytes_per_launch": P * (2 * D * 4 + 8),
             "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()), "positions": P}
@@ -236,11 +254,33 @@ def north_star_targets(model, x):
     D = z.shape[1]
     P = z.shape[0] * z.shape[2] * z.shape[3]
     vq_bytes = P * (2 * D * 4 + 8)
-    vq = {"kernel": "vq_forward_mfma_kernel (MFMA filter + exact re-check)", "bytes": vq_bytes, "avg_launch_ms": round(k_ms, 5),
-          "frac_hbm": round(vq_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "call_ms": round(call_ms, 5),
+    # ONE dispatch at a time, as the step runs it: events on the launch stream around a single launch that follows its
+    # producer (in the step the residual join writes z just before; here a device copy of z does).  ~150 us of unrelated
+    # device work in front keeps the host ahead of the device, so the interval holds no wait for the host.
+    z_src = z.clone()
+    pad = torch.empty(64 << 20, device=z.device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(24)]
+    for e0, e1 in ev:
+        pad.fill_(0.0)
+        z.copy_(z_src)
+        e0.record()
+        ops.vq_forward_repeat(z, cbk, 1, bufs=bufs, want_hist=False)
+        e1.record()
+    torch.cuda.synchronize()
+    d_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev[4:])
+    d_ms = d_ms[len(d_ms) // 2]                                # median of 20
+    prof_us = profile_avg_us("vq_forward_mfma_kernel")
+    vq = {"kernel": "vq_forward_mfma_kernel (MFMA filter + exact re-check)", "bytes": vq_bytes,
+          "dispatch_ms": round(d_ms, 5), "frac_hbm": round(vq_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+          "frac_hbm_is": "per dispatch: events around single launches behind their producer (median of 20)",
+          "profile_avg_us": prof_us,
+          "frac_hbm_profile": round(vq_bytes / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof_us else None,
+          "back_to_back_launch_ms": round(k_ms, 5),
+          "frac_hbm_back_to_back": round(vq_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "call_ms": round(call_ms, 5),
           "call_frac_hbm": round(vq_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
           "call_with_hist_ms": round(call_hist_ms, 5),
           "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()) // 1}
+    del pad, z_src
     # ---- encoder forward convolutions, on the step's own activations
     nh, nrh, c1 = L.nh, L.nrh, L.nh // 2
     H1, W1, H2, W2, H3, W3 = cx.dims
@@ -356,6 +396,57 @@ def c2_record(model, steps=50, warmup=3, B=1024):
     el = time.perf_counter() - t0
     return {"workload": "C2: inference latents (enc + vq, per-sample BatchNorm statistics), batch 1024", "value": round(B * steps / el, 1),
             "unit": "patches/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "hip_graph": True}
+
+
+def c5_record(dev, steps=8, warmup=3, B=1024):
+    """BASELINE.json configs[4]'s single-GPU leg beside the headline line, budgeted to a few seconds: the large-codebook
+    stress model (4-channel 256 x 256 patches, 4096 codes) training step at its bench batch, and its K = 4096 distance /
+    argmin kernel timed per dispatch on the model's own latents (`python bench.py --workload c5` is the full record)."""
+    import numpy as np
+    from dynamorph_amd import VQ_VAE
+    from dynamorph_amd import engine as E
+    from dynamorph_amd import ops
+    from dynamorph_amd.train import FusedTrainer
+    torch.manual_seed(0)
+    model = VQ_VAE(num_inputs=4, num_embeddings=4096, channel_var=np.ones(4)).to(dev)
+    x = torch.randn(B, 4, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+    tr = FusedTrainer(model, lr=1e-4)
+    x = tr.prepare(x)
+    for _ in range(warmup):
+        out = tr.step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.step(x)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L = E.Layers(model)
+    with torch.no_grad():
+        z, _ = E.encoder_forward(L, x)
+    cbk = L.codebook.weight.detach()
+    bufs = ops.vq_forward_repeat(z, cbk, 1)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(7)]
+    for e0, e1 in ev:
+        e0.record()
+        ops.vq_forward_repeat(z, cbk, 1, bufs=bufs)          # preparation + kernel + counter reduction (3 launches)
+        e1.record()
+    torch.cuda.synchronize()
+    call_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev[2:])[2]
+    K, D = cbk.shape
+    P = z.shape[0] * z.shape[2] * z.shape[3]
+    flops = 2.0 * K * D * P
+    useful = flops / (call_ms * 1e-3) / 1e12
+    rec = {"workload": "C5: VQ_VAE(num_inputs=4, num_embeddings=4096) training step, 4x256x256 fp32, batch %d" % B,
+           "value": round(B * steps / el, 1), "unit": "patches/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps,
+           "vq_call_ms": round(call_ms, 4), "vq_call_is": "dm_vq_forward on the model's own latents: preparation + distance/argmin "
+           "kernel + counter reduction, events around single calls (median of 5)",
+           "vq_algorithmic_tflops": round(useful, 2), "vq_frac_of_bf16_matrix_peak": round(useful / MFMA_BF16_PEAK_TFLOPS, 4),
+           "vq_frac_of_f32_matrix_peak": round(useful / MFMA_F32_PEAK_TFLOPS, 4),
+           "rechecked_share": round(int(bufs[4][:1].view(torch.int32).item()) / P, 5), "positions": P,
+           "total_loss_after": round(float(out[2]), 6)}
+    del tr, model, x, z, bufs
+    torch.cuda.empty_cache()
+    return rec
 
 
 def split_bf16_record(x, B, args, steps=100, warmup=10):
@@ -659,12 +750,13 @@ def main():
         roof = roofline_vq_large_codebook(model, x)
     else:
         roof = roofline_dominant_kernel(model, x, args.workload)
-    targets = c2 = split = loop = None
+    targets = c2 = split = loop = c5 = None
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_targets:
         targets = north_star_targets(model, x)
         c2 = c2_record(model)
         split = split_bf16_record(x, B, args)
         loop = train_loop_record(dev, 1e3 * elapsed / args.steps, B=B)
+        c5 = c5_record(dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload)
@@ -699,6 +791,7 @@ def main():
             line["c2"] = c2
             line["split_bf16_backward"] = split
             line["train_loop"] = loop
+            line["c5"] = c5
         if losses is not None:
             line["final_losses"] = dict(zip(("recon", "commitment", "total", "perplexity"), [round(v, 6) for v in losses]))
         print(json.dumps(line), flush=True)

@@ -47,6 +47,17 @@ int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scrat
 
 // arithmetic of the gradient kernels (defined with the C ABI at the end of this file; also used by wgrad_mfma.hip)
 bool dm_backward_split_bf16();
+#ifdef DM_MEASURE
+// Measurement builds only (make measure): DM_FORWARD_SPLIT=1 runs the FORWARD convolutions on the two-piece split-bf16
+// products too.  Results are then not fp32 (latents pick codes): this exists to bound what ANY bf16-piece arithmetic could
+// buy the convolution family and is compiled out of the shipped library.
+static bool dm_forward_split() { static const bool v = getenv("DM_FORWARD_SPLIT") != nullptr; return v; }
+#define DM_FWD_SPLIT(cond) ((cond) && dm_forward_split())
+constexpr bool MEASURE_BF = true;
+#else
+#define DM_FWD_SPLIT(cond) false
+constexpr bool MEASURE_BF = false;
+#endif
 
 namespace {
 
@@ -1228,7 +1239,18 @@ void launch_conv4(const ConvArgs &a)
 #define DM_L4(SIDE_)                                                                                              \
     {                                                                                                             \
         constexpr int WPS = conv_wps(LDS, CIN * 4, F4, false, 2, 1, SIDE_);                                       \
-        if (SIDE_ == SIDE_NONE && CIN <= 5 && a.ep.bias_border)                                                   \
+        if (DM_FWD_SPLIT(SIDE_ == SIDE_NONE)) {                                                                   \
+            if (CIN <= 5 && a.ep.bias_border)                                                                     \
+                hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_NONE, WPS, true, MEASURE_BF>),              \
+                                   dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
+                                   a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),    \
+                                   a.per_tile);                                                                       \
+            else                                                                                                  \
+                hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_NONE, WPS, false, MEASURE_BF>),             \
+                                   dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
+                                   a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),    \
+                                   a.per_tile);                                                                       \
+        } else if (SIDE_ == SIDE_NONE && CIN <= 5 && a.ep.bias_border)                                            \
             hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_NONE, WPS, true>),                              \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
                                a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
@@ -1276,8 +1298,9 @@ void launch_conv3(const ConvArgs &a)
     {                                                                                                             \
         constexpr int WPS = conv_wps(LDS, NT * (CIN / 4) * TAPS, F4, TWO_, NT == 1 ? 2 : 1, NT, SIDE_);          \
         constexpr bool GRAD = (TWO_ || SIDE_ != SIDE_NONE) && ((CIN / 4) * TAPS) % 4 == 0;   /* a data gradient */      \
-        if (GRAD && dm_backward_split_bf16())                                                                     \
-            hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS, GRAD>),           \
+        constexpr bool FWDK = ((CIN / 4) * TAPS) % 4 == 0;                                                        \
+        if ((GRAD && dm_backward_split_bf16()) || DM_FWD_SPLIT(!GRAD && FWDK))                                    \
+            hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS, GRAD || (MEASURE_BF && FWDK)>),           \
                                dim3(conv_grid(ntiles, WPS, a.per_tile, NPASS)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
                                a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile), a.per_tile); \
         else                                                                                                      \
@@ -1307,8 +1330,8 @@ void launch_convT_phase(const ConvArgs &a)
     {                                                                                                             \
         constexpr int WPS = clampi(conv_wps(LDS, KSW, F4, TWO_, 2, COUT == 16 ? 2 : 1, SIDE_), 1, 2);             \
         constexpr bool GRAD = TWO_ || SIDE_ != SIDE_NONE;                  /* a data gradient */                     \
-        if (GRAD && dm_backward_split_bf16())                                                                     \
-            hipLaunchKernelGGL((convT_phase_kernel<CIN, COUT, TH, TW, TWO_, SIDE_, WPS, GRAD>),                       \
+        if ((GRAD && dm_backward_split_bf16()) || DM_FWD_SPLIT(!GRAD))                                            \
+            hipLaunchKernelGGL((convT_phase_kernel<CIN, COUT, TH, TW, TWO_, SIDE_, WPS, GRAD || MEASURE_BF>),         \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
                                a.out, a.ep, a.Cphys, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));               \
         else                                                                                                      \
@@ -1547,7 +1570,7 @@ extern "C" int dm_backward_precision(int mode)
 
 static int fused_bwd_dbg()
 {
-#ifdef DM_MEASURE      // ablation switches exist only in a measurement build (make MEASURE=1): they make results wrong
+#ifdef DM_MEASURE      // ablation switches exist only in a measurement build (make measure): they make results wrong
     static const int v = [] { const char *e = getenv("DM_FUSED_BWD_DBG"); return e ? atoi(e) : 0; }();
 #else
     static const int v = 0;

@@ -12,29 +12,38 @@ namespace {
 constexpr int FT = 64;          // a workgroup moves one 64 x 64 tile of one (sample, channel) plane
 
 // Source coordinates of output (y, x) under out = rot90(flip(in, f), k): the dihedral map of run_training.py:396-403
-// (torch.flip dims (1,) / (2,) of a (C, H, W) patch, torch.rot90 k times counter-clockwise over dims [1, 2]).
+// (torch.flip dims (1,) / (2,) of a (C, H, W) patch, torch.rot90 k times counter-clockwise over dims [1, 2]) is affine,
+//   k = 0: (y, x)   1: (x, H-1-y)   2: (H-1-y, H-1-x)   3: (H-1-x, y);   f = 1: sy -> H-1-sy;   f = 2: sx -> H-1-sx,
+// kept as six coefficients in {-1, 0, 1, H-1} (no branch, no table in memory: a switch over k ended up in scratch).
+struct Dihedral { int ay, by, cy, ax, bx, cx; };
+
+__device__ __forceinline__ Dihedral dihedral(int k, int f, int H)
+{
+    Dihedral d;
+    d.ay = (k == 0) - (k == 2); d.by = (k == 1) - (k == 3); d.cy = k >= 2 ? H - 1 : 0;
+    d.ax = (k == 3) - (k == 1); d.bx = (k == 0) - (k == 2); d.cx = (k == 1 || k == 2) ? H - 1 : 0;
+    if (f == 1) { d.ay = -d.ay; d.by = -d.by; d.cy = H - 1 - d.cy; }
+    if (f == 2) { d.ax = -d.ax; d.bx = -d.bx; d.cx = H - 1 - d.cx; }
+    return d;
+}
+
 __device__ __forceinline__ void source_of(int y, int x, int H, int k, int f, int &sy, int &sx)
 {
-    switch (k) {
-    case 0: sy = y; sx = x; break;
-    case 1: sy = x; sx = H - 1 - y; break;
-    case 2: sy = H - 1 - y; sx = H - 1 - x; break;
-    default: sy = H - 1 - x; sx = y; break;
-    }
-    if (f == 1) sy = H - 1 - sy;
-    else if (f == 2) sx = H - 1 - sx;
+    const Dihedral d = dihedral(k, f, H);
+    sy = d.ay * y + d.by * x + d.cy;
+    sx = d.ax * y + d.bx * x + d.cx;
 }
 
 // H % 64 == 0.  A dihedral map sends 64 x 64 tiles to 64 x 64 tiles, so the source tile of an output tile is read in
-// full rows (16 B per lane, 256 B per row segment), parked in LDS (row stride 65: the transposing reads of the odd
-// rotations hit 64 different banks) and written out in full rows again.
+// full rows (16 B per lane, 256 B per row segment, all four loads of a thread in flight together), parked in LDS (row
+// stride 65: the transposing reads of the odd rotations hit 64 different banks) and written out in full rows again.
 __global__ __launch_bounds__(256) void gather_augment_tiled_kernel(const float *__restrict__ src, float *__restrict__ out,
                                                                    const int *__restrict__ ids,
                                                                    const int *__restrict__ flip_code,
                                                                    const int *__restrict__ rot_code, int C, int H,
                                                                    long long n_src)
 {
-    __shared__ float tile[FT][FT + 1];
+    __shared__ float tile[FT * (FT + 1)];
     const int tiles = H / FT;
     int w = blockIdx.x;
     const int tx = w % tiles; w /= tiles;
@@ -44,34 +53,40 @@ __global__ __launch_bounds__(256) void gather_augment_tiled_kernel(const float *
     const long long s = ids ? (long long)ids[b] : (long long)b;
     const int k = rot_code ? (rot_code[b] & 3) : 0;
     const int f = flip_code ? flip_code[b] : 0;
-    float *dst = out + ((long long)b * C + c) * H * H;
+    float *dst = out + ((long long)b * C + c) * H * H + (long long)(ty * FT) * H + tx * FT;
     const int col = (threadIdx.x & 15) * 4, row0 = threadIdx.x >> 4;
     if (s < 0 || s >= n_src) {           // an id outside the dataset: zeros, never a stray read
-        for (int r = row0; r < FT; r += 16)
-            *reinterpret_cast<f32x4 *>(dst + (long long)(ty * FT + r) * H + tx * FT + col) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4 *>(dst + (long long)(row0 + 16 * j) * H + col) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
-    const float *pl = src + (s * C + c) * H * H;
-    // where the output tile's corner (and its opposite corner) come from: the source tile is the box between them
-    int ay, ax, by, bx;
-    source_of(ty * FT, tx * FT, H, k, f, ay, ax);
-    source_of(ty * FT + FT - 1, tx * FT + FT - 1, H, k, f, by, bx);
+    const Dihedral d = dihedral(k, f, H);
+    // where the output tile's corner and its opposite corner come from: the source tile is the box between them
+    const int y0 = ty * FT, x0 = tx * FT;
+    const int ay = d.ay * y0 + d.by * x0 + d.cy, ax = d.ax * y0 + d.bx * x0 + d.cx;
+    const int by = ay + (d.ay + d.by) * (FT - 1), bx = ax + (d.ax + d.bx) * (FT - 1);
     const int sy0 = ay < by ? ay : by, sx0 = ax < bx ? ax : bx;
+    const float *pl = src + (s * C + c) * H * H + (long long)sy0 * H + sx0;
+    f32x4 v[4];
 #pragma unroll
-    for (int r = row0; r < FT; r += 16) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(pl + (long long)(sy0 + r) * H + sx0 + col);
-        tile[r][col] = v.x; tile[r][col + 1] = v.y; tile[r][col + 2] = v.z; tile[r][col + 3] = v.w;
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4 *>(pl + (long long)(row0 + 16 * j) * H + col);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float *t = tile + (row0 + 16 * j) * (FT + 1) + col;
+        t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
     }
     __syncthreads();
+    // LDS address of output (r, col + e) inside the tile: linear in r and e
+    const int base = (ay - sy0) * (FT + 1) + (ax - sx0);              // output (0, 0) of the tile
+    const int dr = d.ay * (FT + 1) + d.ax, dc = d.by * (FT + 1) + d.bx;
 #pragma unroll
-    for (int r = row0; r < FT; r += 16) {
-        f32x4 v;
-        int sy, sx;
-        source_of(ty * FT + r, tx * FT + col, H, k, f, sy, sx);     v.x = tile[sy - sy0][sx - sx0];
-        source_of(ty * FT + r, tx * FT + col + 1, H, k, f, sy, sx); v.y = tile[sy - sy0][sx - sx0];
-        source_of(ty * FT + r, tx * FT + col + 2, H, k, f, sy, sx); v.z = tile[sy - sy0][sx - sx0];
-        source_of(ty * FT + r, tx * FT + col + 3, H, k, f, sy, sx); v.w = tile[sy - sy0][sx - sx0];
-        *reinterpret_cast<f32x4 *>(dst + (long long)(ty * FT + r) * H + tx * FT + col) = v;
+    for (int j = 0; j < 4; ++j) {
+        const int r = row0 + 16 * j;
+        const float *t = tile + base + r * dr + col * dc;
+        f32x4 o;
+        o.x = t[0]; o.y = t[dc]; o.z = t[2 * dc]; o.w = t[3 * dc];
+        *reinterpret_cast<f32x4 *>(dst + (long long)r * H + col) = o;
     }
 }
 

@@ -341,7 +341,7 @@ extern "C" int dm_latent_tail_forward(const dm_latent_tail_args *a, void *stream
     P.a3 = a->a3; P.coef3 = a->coef3; P.w10 = a->w10; P.b10 = a->b10; P.g4 = a->gamma4; P.be4 = a->beta4; P.st4 = a->stats4;
     P.eps4 = a->eps4; P.z = a->z; P.B = a->B; P.nres = a->nres;
     P.a2 = a->a2; P.coef2 = a->coef2; P.w7 = a->w7; P.b7 = a->b7; P.g3 = a->gamma3; P.be3 = a->beta3; P.st3 = a->stats3; P.eps3 = a->eps3;
-#ifdef DM_MEASURE      // ablation switches exist only in a measurement build (make MEASURE=1): they make results wrong
+#ifdef DM_MEASURE      // ablation switches exist only in a measurement build (make measure): they make results wrong
     static const int dbg = [] { const char *e = getenv("DM_LT_DBG"); return e ? atoi(e) : 0; }();
 #else
     static const int dbg = 0;

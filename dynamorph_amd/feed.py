@@ -169,7 +169,9 @@ class Feed:
 
         def part(lo):
             hi = min(n, lo + step)
-            if run:
+            if run and src.dtype == torch.float32:
+                np.copyto(out[lo:hi].numpy(), src[ids[0] + lo:ids[0] + hi].numpy())     # (a plain memcpy per thread)
+            elif run:
                 out[lo:hi].copy_(src[ids[0] + lo:ids[0] + hi])
             elif src.dtype == torch.float32:
                 torch.index_select(src, 0, torch.as_tensor(ids[lo:hi], dtype=torch.int64), out=out[lo:hi])
@@ -203,8 +205,8 @@ class Feed:
             flat = np.concatenate([np.asarray(b, dtype=np.int32) for b in batches])
             parts = [flat]
             if transform is not None:
-                codes = [ops.augment_codes(len(b)) for b in batches]
-                parts += [np.concatenate([c[0] for c in codes]), np.concatenate([c[1] for c in codes])]
+                # (one draw for the phase: per sample and in batch order, exactly the interleaved stream of the batch loop)
+                parts += list(ops.augment_codes(total))
             stage = torch.empty(len(parts) * total, dtype=torch.int32, pin_memory=True)
             stage.copy_(torch.from_numpy(np.concatenate(parts)))
             meta_dev = stage.to(self.dev, non_blocking=True)

@@ -19,18 +19,29 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def resident_step_ms(dev, B, steps=100):
+def resident_step_ms(dev, B, full=False, steps=100):
+    """The bench's step on one batch resident in HBM; full: with a mask and a relation block (the time-matching term on)."""
     from dynamorph_amd import VQ_VAE
     from dynamorph_amd.train import FusedTrainer
     torch.manual_seed(0)
     tr = FusedTrainer(VQ_VAE().to(dev), lr=1e-4)
-    x = tr.prepare(torch.randn(B, 2, 128, 128, device=dev))
+    x = torch.randn(B, 2, 128, 128, device=dev)
+    mask = tm = None
+    if full:
+        mask = (torch.rand(B, 1, 128, 128, device=dev) > 0.3).float()
+        i = torch.arange(B - 1, device=dev)
+        same = (i // 8) == ((i + 1) // 8)
+        tm = torch.zeros(B, B, device=dev)
+        tm[i[same], i[same] + 1] = 2.0
+        tm[i[same] + 1, i[same]] = 2.0
+    tr.prepare(x, mask, tm)
+    x, mask, tm = tr.static_inputs(x.shape, None if mask is None else mask.shape, None if tm is None else tm.shape)
     for _ in range(10):
-        tr.step(x)
+        tr.step(x, mask, tm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        tr.step(x)
+        tr.step(x, mask, tm)
     torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / steps
 
@@ -45,14 +56,16 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    ms = resident_step_ms(dev, a.batch)
-    print(json.dumps({"resident_bench_ms_per_step": round(ms, 4), "resident_bench_patches_per_s": round(a.batch / ms * 1e3, 1)}),
-          flush=True)
+    base = {}
+    for full in ((False, True) if a.full else (False,)):
+        base[full] = resident_step_ms(dev, a.batch, full)
+        print(json.dumps({"resident_bench": "with mask + time-matching term" if full else "plain",
+                          "ms_per_step": round(base[full], 4), "patches_per_s": round(a.batch / base[full] * 1e3, 1)}), flush=True)
     for feed in a.feeds.split(","):
         for full in ((False, True) if a.full else (False,)):
             for pinned in ((False, True) if feed == "stream" else (False,)):
-                rec = bench.train_loop_record(dev, ms, n=a.n, B=a.batch, epochs=a.epochs, feed=feed, masks=full, relation=full,
-                                              pinned=pinned)
+                rec = bench.train_loop_record(dev, base[full], n=a.n, B=a.batch, epochs=a.epochs, feed=feed, masks=full,
+                                              relation=full, pinned=pinned)
                 print(json.dumps(rec), flush=True)
 
 
