@@ -67,6 +67,8 @@ SIGNATURES = {
     "dm_vq_forward": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, vp]),
     "dm_vq_forward_variant": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, C.c_int, vp]),
     "dm_vq_forward_repeat": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, C.c_int, C.c_int, vp]),
+    "dm_vq_forward_join_supported": (C.c_int, [C.c_int] * 4),
+    "dm_vq_forward_join": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp, C.c_size_t, vp]),
     "dm_vq_decode": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_vq_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp, vp]),
     "dm_vq_loss_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, i64, f32, vp, C.c_int, i64, f32, f32, vp, vp]),

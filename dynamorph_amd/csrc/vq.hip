@@ -529,15 +529,22 @@ __device__ __forceinline__ void vq2_swap(float &x, float &y)
 // workgroup builds its A operands, norms and gather rows from the raw codebook in its prologue (cbA / nrm / cbH are then
 // unused), writes its code counters as one row of plain stores (hrep = the slab region, R ignored) and zeroes the squared-
 // error slabs no workgroup owns.  dm_vq_forward is ONE launch for every configuration of the reference.
-template <int D, bool SINGLE, int MINW, bool BF, bool INL>
+// JOIN (with INL): the encoder's last residual join runs in the load path -- z = fma(c0, rb, c2) + h_in per channel
+// (BatchNorm of the block's last convolution applied to its raw output rb, plus the block's input: dm_apply's arithmetic,
+// ResidualBlock.forward vq_vae.py:222-224) -- and the kernel writes z (`jz`: the latents the backward pass and the callers
+// need) itself: `z` is then rb, `jh` the block input, `jcoef` the [D][4] coefficient table of dm_bn_finalize.  One launch
+// (dm_apply) and one round trip of the latents fewer per step.
+template <int D, bool SINGLE, int MINW, bool BF, bool INL, bool JOIN = false>
 __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ cbA,
     const float *__restrict__ nrm, const float *__restrict__ cbH, long long *__restrict__ idx,
     float *__restrict__ out, double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int *__restrict__ hdr,
-    int K, int HW, long long P, int nslabs)
+    int K, int HW, long long P, int nslabs, const float *__restrict__ jh = nullptr, const float *__restrict__ jcoef = nullptr,
+    float *__restrict__ jz = nullptr)
 {
     constexpr int BLOCK = 256, NW = 4;
     static_assert(!INL || (SINGLE && D % 16 == 0), "inline preparation: <= 64 codes, embedding_dim 16 / 32 / 64");
+    static_assert(!JOIN || INL, "the fused residual join is built for the one-launch form");
     // this workgroup's replica of the counters (INL: its own row)
     int *__restrict__ hist = INL ? hrep + (long long)blockIdx.x * VQ2_SLAB_STRIDE : hrep + (long long)(blockIdx.x % (unsigned)R) * K;
     constexpr int S = D / 4, SQ = (S + 3) / 4;
@@ -602,17 +609,50 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(z) + (long long)bb * D * HW, 0, sample_bytes, 0x00020000);
     };
     auto z_soff = [&](unsigned chunk, unsigned cw) { return (chunk < NC ? cw : cps - 1) * 256u; };
-    auto z_load = [&](f32x4 (&dst)[S], unsigned chunk, unsigned b, unsigned cw) {
+    auto z_load = [&](f32x4 (&dst)[S], f32x4 (&dsth)[JOIN ? S : 1], unsigned chunk, unsigned b, unsigned cw) {
         const __amdgpu_buffer_rsrc_t r = z_rsrc(chunk, b);
         const unsigned so = z_soff(chunk, cw);
 #pragma unroll
         for (int s = 0; s < S; ++s)
             dst[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, zvoff, so + (unsigned)(4 * s) * (unsigned)HW * 4u, 0));
+        if constexpr (JOIN) {
+            const unsigned bb = chunk < NC ? b : NC / cps - 1;
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(jh) + (long long)bb * D * HW, 0,
+                                                                                sample_bytes, 0x00020000);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                dsth[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, zvoff, so + (unsigned)(4 * s) * (unsigned)HW * 4u, 0));
+        }
+    };
+    // JOIN: z = fma(c0, rb, c2) + h_in for the lane's channels 4 s + h, written to jz for the chunk it belongs to
+    // (the (c0, c2) pairs of the D channels wait in LDS: eight more live registers would spill at three waves per SIMD)
+    __shared__ __attribute__((aligned(8))) float s_jc[JOIN ? 2 * D : 2];
+    if constexpr (JOIN) {
+        if (threadIdx.x < D) { s_jc[2 * threadIdx.x] = jcoef[threadIdx.x * 4]; s_jc[2 * threadIdx.x + 1] = jcoef[threadIdx.x * 4 + 2]; }
+    }
+    auto z_join_store = [&](f32x4 (&zv)[S], const f32x4 (&hv)[JOIN ? S : 1], bool live, unsigned b, unsigned cw) {
+        if constexpr (JOIN) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const f32x2 cf = *reinterpret_cast<const f32x2 *>(s_jc + 2 * (4 * s + h));
+                f32x4 v;
+                v.x = __builtin_fmaf(cf.x, zv[s].x, cf.y) + hv[s].x; v.y = __builtin_fmaf(cf.x, zv[s].y, cf.y) + hv[s].y;
+                v.z = __builtin_fmaf(cf.x, zv[s].z, cf.y) + hv[s].z; v.w = __builtin_fmaf(cf.x, zv[s].w, cf.y) + hv[s].w;
+                zv[s] = v;
+            }
+            if (live) {
+                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(jz + (long long)b * D * HW, 0, sample_bytes, 0x00020000);
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, zv[s]),
+                                                           rz, zvoff, cw * 256u + (unsigned)(4 * s) * (unsigned)HW * 4u, 0);
+            }
+        }
     };
     unsigned chunk = blockIdx.x * (unsigned)NW + (unsigned)wave;
     unsigned cb_ = chunk / cps, cw_ = chunk - cb_ * cps;       // sample and chunk-in-sample of `chunk`
-    f32x4 zr[S];
-    z_load(zr, chunk, cb_, cw_);
+    f32x4 zr[S], hq[JOIN ? S : 1];
+    z_load(zr, hq, chunk, cb_, cw_);
     // every global load of the prologue is issued before the first wait: z of the first chunk, the A operand and the
     // norms (small codebooks: registers), the rows for the gather -- one memory round trip instead of four
     f32x4 areg[4][AQ], nreg[4];
@@ -742,13 +782,15 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const unsigned ovoff = zvoff;                                  // `out` has z's layout
     const unsigned ivoff = (4u * (unsigned)c + 2u * (unsigned)h) * 8u;      // int64 indices of positions 4c + 2h, + 1 (lanes h < 2)
 
+    z_join_store(zr, hq, chunk < NC, cb_, cw_);                   // (JOIN) the first chunk's latents
+
     for (unsigned q = blockIdx.x; q * (unsigned)NW < NC; q += gridDim.x) {
         const bool act = chunk < NC;                           // wave-uniform
         unsigned nchunk = chunk + qstep, nb = cb_ + step_b, nw = cw_ + step_c;
         if (nw >= cps) { nw -= cps; ++nb; }
         // the next chunk's z is requested now and lands under this chunk's MFMAs
         f32x4 zn[S];
-        z_load(zn, nchunk, nb, nw);
+        z_load(zn, hq, nchunk, nb, nw);
 
         VQ2_STAMP(1)                                           // prefetch issue
         float m1[4], m2[4], pmv[SINGLE ? 1 : 4];
@@ -1076,8 +1118,13 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
             asm volatile("" : "+v"(zn[s]));                    // (an opaque use pins the wait here; a plain copy is only renaming)
             zr[s] = zn[s];
         }
+        if constexpr (JOIN) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) asm volatile("" : "+v"(hq[s]));
+        }
         __builtin_amdgcn_sched_barrier(0);
         VQ2_STAMP(0)                                           // wait for the prefetched z
+        z_join_store(zr, hq, nchunk < NC, nb, nw);             // (JOIN) the next chunk's latents: formed and written here
         if (act) {
             if (out) {
                 const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long long)cb_ * D * HW, 0, sample_bytes, 0x00020000);
@@ -1512,7 +1559,7 @@ bool vq2_applicable(const float *z, const int64_t *idx, const float *out, const 
 namespace {
 int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float *out, double *sse_slabs, int32_t *hist,
                       int B, int D, int K, int H, int W, void *workspace, size_t workspace_bytes, int variant, int repeats,
-                      void *stream);
+                      void *stream, const float *jh = nullptr, const float *jcoef = nullptr, float *jz = nullptr);
 }
 
 extern "C" int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
@@ -1535,7 +1582,7 @@ extern "C" int dm_vq_forward_repeat(const float *z, const float *codebook, int64
 namespace {
 int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float *out, double *sse_slabs, int32_t *hist,
                       int B, int D, int K, int H, int W, void *workspace, size_t workspace_bytes, int variant, int repeats,
-                      void *stream)
+                      void *stream, const float *jh, const float *jcoef, float *jz)
 {
     DM_REQUIRE(z && codebook && sse_slabs, "dm_vq_forward: NULL pointer");     // hist == NULL: the counters stay in their replicas
     DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
@@ -1559,31 +1606,34 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
     // operands and writes its counters as per-workgroup rows -- no preparation launch, no counter reduction
     // (DM_VQ_PREP=1 in the environment keeps the separate preparation: A/B measurements)
     const bool inl = use2 && K <= 64 && D % 16 == 0 && !vq2_force_prep();
+    DM_REQUIRE(!jz || (inl && D == 16), "dm_vq_forward_join: built for the one-launch form (<= 64 codes, embedding_dim 16, H*W %% 64 == 0)");
     if (!inl) hipLaunchKernelGGL(vq_prep_kernel, dim3(pgrid), dim3(256), 0, s, codebook, ws, L, K, D, sse_slabs, nslabs);
     // (vq_prep_kernel cleared the counter replicas and all slabs: there are fewer workgroups than slabs)
     int *hrep = reinterpret_cast<int *>(ws + L.hrep);
     if (use2) {
         const long long groups = ((P >> 6) + 3) / 4;
-#define DM_VQ2K(DD, SINGLE_, MINW, WGS, BF_, INL_)                                                                   \
+#define DM_VQ2K(DD, SINGLE_, MINW, WGS, BF_, INL_, JOIN_)                                                            \
     {                                                                                                                \
         const int wgs = (WGS);                                                                                       \
         long long g_ = groups < 256 * wgs ? groups : 256 * wgs;                                                      \
         if (INL_ && g_ > VQ2_SLAB_ROWS) g_ = VQ2_SLAB_ROWS;          /* one counter row per workgroup */              \
-        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW, BF_, INL_>),                                   \
+        hipLaunchKernelGGL((vq_forward_mfma_kernel<DD, SINGLE_, MINW, BF_, INL_, JOIN_>),                            \
                            dim3((unsigned)g_), dim3(256), 0, s, z, codebook,                                         \
                            ws + (BF_ ? L.cbB : L.cbA), ws + L.nrm, ws + L.cbH, (long long *)idx, out, sse_slabs, hrep, \
-                           L.R, (int *)ws, K, H * W, P, nslabs);                                                     \
+                           L.R, (int *)ws, K, H * W, P, nslabs, jh, jcoef, jz);                                      \
     }
 #define DM_VQ2(DD, SINGLE_, MINW, WGS)                                                                               \
     {                                                                                                                \
         if constexpr (DD % 16 == 0 && SINGLE_) {                                                                     \
-            if (inl && bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, true)                                               \
-            else if (inl) DM_VQ2K(DD, SINGLE_, MINW, WGS, false, true)                                               \
-            else if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, false)                                                \
-            else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false)                                                       \
+            if (inl && bf && jz) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, true, DD == 16)                               \
+            else if (inl && jz) DM_VQ2K(DD, SINGLE_, MINW, WGS, false, true, DD == 16)                               \
+            else if (inl && bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, true, false)                                          \
+            else if (inl) DM_VQ2K(DD, SINGLE_, MINW, WGS, false, true, false)                                               \
+            else if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, false, false)                                                \
+            else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false, false)                                                       \
         } else if constexpr (DD % 16 == 0) {                                                                         \
-            if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, false) else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false)  \
-        } else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false)                                                         \
+            if (bf) DM_VQ2K(DD, SINGLE_, MINW, WGS, true, false, false) else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false, false)  \
+        } else DM_VQ2K(DD, SINGLE_, MINW, WGS, false, false, false)                                                         \
     }
         const bool single = K <= 64;
         // bf16-split filter (DM_VQ_BF16; DM_VQ_AUTO takes it where it applies) or the f32 one (DM_VQ_MFMA)
@@ -1630,6 +1680,24 @@ extern "C" int dm_vq_forward(const float *z, const float *codebook, int64_t *idx
 {
     return dm_vq_forward_variant(z, codebook, idx, out, sse_slabs, hist, B, D, K, H, W, workspace, workspace_bytes,
                                  DM_VQ_AUTO, stream);
+}
+
+extern "C" int dm_vq_forward_join_supported(int D, int K, int H, int W)
+{
+    // (embedding_dim 16 = the reference's num_hiddens: at 32 / 64 the second prefetched tensor does not fit the registers)
+    return (K > 0 && K <= 64 && D == 16 && H > 0 && W > 0 && (H * W) % 64 == 0 && !vq2_force_prep()) ? 1 : 0;
+}
+
+extern "C" int dm_vq_forward_join(const float *rb, const float *h_in, const float *coef, float *z_out, const float *codebook,
+                                  int64_t *idx, float *out, double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    DM_REQUIRE(rb && h_in && coef && z_out, "dm_vq_forward_join: NULL pointer");
+    DM_REQUIRE(rb != z_out && h_in != z_out, "dm_vq_forward_join: z_out must not alias an input (chunks are read ahead)");
+    DM_REQUIRE(dm_vq_forward_join_supported(D, K, H, W), "dm_vq_forward_join: shape not built (D %d, K %d, %dx%d)", D, K, H, W);
+    DM_REQUIRE((((uintptr_t)h_in | (uintptr_t)z_out) & 15) == 0, "dm_vq_forward_join: 16-byte aligned tensors");
+    return vq_forward_launch(rb, codebook, idx, out, sse_slabs, hist, B, D, K, H, W, workspace, workspace_bytes, DM_VQ_AUTO, 1,
+                             stream, h_in, coef, z_out);
 }
 
 extern "C" int dm_vq_decode(const int64_t *idx, const float *codebook, float *q,

@@ -115,13 +115,16 @@ def e1_operands(L):
     return ops.e1_compose_border(_w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight), _w(L.enc1.bias))
 
 
-def encoder_forward(L, x, per_sample=False, e1=None, join=True, latents_only=False):
+def encoder_forward(L, x, per_sample=False, e1=None, join=True, latents_only=False, defer_last_join=0):
     """x (B,NIN,H,W) -> z_before (B,nh,H/8,W/8).  per_sample=True normalises every BatchNorm with
     that sample's own statistics = pipeline/patch_VAE.py:445-452 (batch-of-one calls in train mode).
     e1: e1_operands(L) computed by the caller (inference: once per call).
     latents_only (per_sample only): the caller wants z and the running statistics, nothing to differentiate through --
     the 16 x 16 part of the encoder (enc.10 .. enc.12) then is ONE launch that keeps a patch on its CU
     (ops.latent_tail_forward; DM_LATENT_TAIL=0 in the environment keeps the layer-by-layer kernels).
+    defer_last_join = K (training step only): when the quantiser can do it (ops.vq_forward_join_supported for K codes), the
+    LAST residual join is left to the VectorQuantizer kernel's load path: the return value is then (None, cx) and
+    cx.pending_join = (rb, h_in, coef) goes to vq_forward_joined, which also produces z.
     join=False (per_sample only): the running-statistics replay -- a side effect no kernel of the path reads -- is left
     running on a helper stream beside whatever the caller launches next (the VectorQuantizer); the caller MUST call
     cx.join() before it hands the stream back (a HIP-graph capture cannot end with unjoined work)."""
@@ -185,7 +188,10 @@ def encoder_forward(L, x, per_sample=False, e1=None, join=True, latents_only=Fal
 
     cx.__dict__.update(a1=a1, a2=a2, a3=a3, a4=a4, coef1=coef1, coef2=coef2, coef3=coef3, coef4=coef4,
                        saved1=saved1, saved2=saved2, saved3=saved3, saved4=saved4, dims=(H1, W1, H2, W2, H3, W3))
-    z, cx.res = residual_forward(L.res, h, ps, defer)
+    fuse = bool(defer_last_join) and not ps and len(L.res) > 0 and L.res[-1][3].training and \
+        ops.vq_forward_join_supported(nh, int(defer_last_join), H3, W3)
+    z, cx.res = residual_forward(L.res, h, ps, defer, defer_last_join=fuse)
+    cx.pending_join = (cx.res[-1].rb, cx.res[-1].h_in, cx.res[-1].coefb) if fuse else None
     _replay(cx, x, defer, join)
     return z, cx
 
@@ -205,9 +211,11 @@ def _replay(cx, x, defer, join):
             cx.join()
 
 
-def residual_forward(res_layers, h, per_sample=False, defer=None):
+def residual_forward(res_layers, h, per_sample=False, defer=None, defer_last_join=False):
     """ResidualBlock.forward (vq_vae.py:212-225) on a materialised h (B,nh,H,W).
-    defer: the caller's list of postponed running-statistics updates (per-sample path); None: flushed here."""
+    defer: the caller's list of postponed running-statistics updates (per-sample path); None: flushed here.
+    defer_last_join: the last layer's `h + BN(rb)` is NOT launched (the caller fuses it into its consumer); returns None
+    for the output then."""
     B, nh, H, W = h.shape
     n = H * W * (1 if per_sample else B)
     saved = []
@@ -222,7 +230,8 @@ def residual_forward(res_layers, h, per_sample=False, defer=None):
         rb, st = ops.conv3x3(Op(ra, DM_LOAD_AFFINE_RELU, coefa, per_sample=per_sample), weight_view(_w(cb.weight), nrh, 1, 0, 0),
                              B, nrh, nh, H, W, taps=1, want_stats=True, bias=_w(cb.bias), per_tile=per_sample)
         coefb, savedb = _bn_coef(st, bnb, n, per_sample, B, defer)
-        hn = ops.apply(Op(rb, DM_LOAD_AFFINE, coefb, per_sample=per_sample), B, nh, H, W, resid=h)
+        last = defer_last_join and ca is res_layers[-1][0]
+        hn = None if last else ops.apply(Op(rb, DM_LOAD_AFFINE, coefb, per_sample=per_sample), B, nh, H, W, resid=h)
         saved.append(SimpleNamespace(h_in=h, ra=ra, rb=rb, coefa=coefa, saveda=saveda, coefb=coefb, savedb=savedb))
         h = hn
     if own and defer:
@@ -337,6 +346,16 @@ def vq_forward(codebook, z, commitment_cost, want_out=True, defer_scalars=False,
     idx, out, slabs, hist = ops.vq_forward(z, _w(codebook), want_out=want_out)
     scalars = ops.vq_finalize(slabs, hist, B * H * W, D, commitment_cost)     # (loss, perplexity, mse)
     return out, idx, scalars
+
+
+def vq_forward_joined(codebook, pending_join, commitment_cost):
+    """encoder_forward(..., defer_last_join=K) left the last residual join to the quantiser: one launch forms z, quantises
+    it and writes both.  Returns (z, out, idx, state for ops.vq_loss_finalize) -- vq_forward(defer_scalars=True)'s contract
+    plus the latents."""
+    rb, h_in, coef = pending_join
+    B, D, H, W = rb.shape
+    idx, out, slabs, ws, z = ops.vq_forward_join(rb, h_in, coef, _w(codebook))
+    return z, out, idx, SimpleNamespace(slabs=slabs, ws=ws, K=codebook.shape[0], D=D, positions=B * H * W, cc=commitment_cost)
 
 
 # -------------------------------------------------------------------------------- decoder

@@ -146,6 +146,33 @@ def vq_forward(z, codebook, want_idx=True, want_out=True, variant=L.DM_VQ_AUTO, 
     return idx, out, slabs, (hist if want_hist else ws)
 
 
+def vq_forward_join_supported(D, K, H, W):
+    return bool(L.load().dm_vq_forward_join_supported(D, K, H, W))
+
+
+@_op
+def vq_forward_join(rb, h_in, coef, codebook, want_idx=True, want_out=True):
+    """The last residual join and the VectorQuantizer in one launch (include/dynamorph_hip.h, dm_vq_forward_join):
+    z = fma(coef[:, 0], rb, coef[:, 2]) + h_in, quantised like vq_forward(z, ..., want_hist=False).
+    Returns (idx, out, sse_slabs, workspace, z)."""
+    lib = L.load()
+    B, D, H, W = rb.shape
+    K = codebook.shape[0]
+    if tuple(h_in.shape) != tuple(rb.shape) or tuple(coef.shape) != (D, 4):
+        raise ValueError("dm_vq_forward_join: rb / h_in (B, D, H, W) and a shared (D, 4) coefficient table")
+    nb = lib.dm_vq_num_blocks(B * H * W)
+    z = torch.empty_like(rb)
+    idx = _new((B, H, W), rb, torch.int64) if want_idx else None
+    out = torch.empty_like(rb) if want_out else None
+    slabs = _new((nb,), rb, torch.float64)
+    wsb = lib.dm_vq_workspace_bytes(K, D)
+    ws = _new((wsb // 4,), rb)
+    L.check(lib.dm_vq_forward_join(_ptr(rb), _ptr(h_in), _ptr(coef), _ptr(z), _ptr(codebook), _ptr(idx, torch.int64), _ptr(out),
+                                   _ptr(slabs, torch.float64), None, B, D, K, H, W, _ptr(ws), wsb, _stream()),
+            "dm_vq_forward_join")
+    return idx, out, slabs, ws, z
+
+
 @_op
 def vq_forward_repeat(z, codebook, repeats, variant=L.DM_VQ_AUTO, bufs=None, want_hist=True):
     """Measurement helper (include/dynamorph_hip.h, dm_vq_forward_repeat): one preparation, `repeats` launches of the

@@ -27,6 +27,8 @@ from . import ops
 from .train_utils import EarlyStopping
 
 LOSS_KEYS = ("recon_loss", "commitment_loss", "total_loss", "perplexity")
+# DM_VQ_JOIN=0 in the environment: the last residual join as its own launch (dm_apply) in front of the quantiser (A/B runs)
+JOIN_IN_VQ = os.environ.get("DM_VQ_JOIN", "1") != "0"
 
 
 class _Marks:
@@ -150,8 +152,11 @@ class FusedTrainer:
         model = self.model
         L = E.Layers(model)
         cc = float(model.commitment_cost)
-        z, ecx = E.encoder_forward(L, x)
-        zq, idx, vqs = E.vq_forward(L.codebook.weight, z, cc, defer_scalars=True)
+        z, ecx = E.encoder_forward(L, x, defer_last_join=L.codebook.weight.shape[0] if JOIN_IN_VQ else 0)
+        if z is None:       # the last residual join runs in the quantiser's load path (dm_vq_forward_join), which writes z
+            z, zq, idx, vqs = E.vq_forward_joined(L.codebook.weight, ecx.pending_join, cc)
+        else:
+            zq, idx, vqs = E.vq_forward(L.codebook.weight, z, cc, defer_scalars=True)
         # the tail of the decoder (dec.4, dec.6, loss) runs inside decoder_backward, fused with its own backward
         dec, dcx = E.decoder_forward(L, zq, x, mask, defer_tail=True)
         B, NIN, H, W = x.shape
@@ -268,8 +273,11 @@ class FusedTrainer:
             slabs, wr, wc, lat = tcx.loss_slabs, 1.0, 1.0, zq
         else:
             L = E.Layers(m)
-            z, _ = E.encoder_forward(L, x)
-            zq, _, vqs = E.vq_forward(L.codebook.weight, z, cc, defer_scalars=True)
+            z, ecx = E.encoder_forward(L, x, defer_last_join=L.codebook.weight.shape[0] if JOIN_IN_VQ else 0)
+            if z is None:
+                z, zq, _, vqs = E.vq_forward_joined(L.codebook.weight, ecx.pending_join, cc)
+            else:
+                zq, _, vqs = E.vq_forward(L.codebook.weight, z, cc, defer_scalars=True)
             _, dcx = E.decoder_forward(L, zq, x, mask)
             slabs, wr, wc, lat = dcx.loss_slabs, float(m.weight_recon), float(m.weight_commitment), z
         scalars = ops.vq_loss_finalize(vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, slabs, B * NIN * H * W, wr, wc)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 115
+#define DM_VERSION 116
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -127,6 +127,19 @@ enum { DM_VQ_AUTO = 0, DM_VQ_EXACT = 1, DM_VQ_MFMA = 2, DM_VQ_BF16 = 3 };
 int dm_vq_forward_variant(const float *z, const float *codebook, int64_t *idx, float *out,
                           double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
                           void *workspace, size_t workspace_bytes, int variant, void *stream);
+
+/* dm_vq_forward with the encoder's LAST RESIDUAL JOIN in its load path (ResidualBlock.forward, vq_vae.py:222-224, followed
+ * by VectorQuantizer.forward, vq_vae.py:52-84): the latents are formed on the way in,
+ *     z = fma(coef[d][0], rb, coef[d][2]) + h_in        (dm_apply's arithmetic: BatchNorm of the block's last conv + skip)
+ * quantised exactly as dm_vq_forward quantises a stored z, and written to z_out (the backward pass, the time-matching
+ * term and the callers of `model.enc` need them) -- one launch and one round trip of the latents fewer than dm_apply +
+ * dm_vq_forward.  coef: the [D][4] table of dm_bn_finalize (batch statistics).  Built for the one-launch form: at most 64
+ * codes, embedding_dim 16 (the reference's num_hiddens), H*W a multiple of 64 (dm_vq_forward_join_supported; else use dm_apply + dm_vq_forward).
+ * z_out must not alias rb or h_in.  hist NULL: counters stay in the workspace (dm_vq_loss_finalize), as in dm_vq_forward. */
+int dm_vq_forward_join_supported(int D, int K, int H, int W);
+int dm_vq_forward_join(const float *rb, const float *h_in, const float *coef, float *z_out, const float *codebook,
+                       int64_t *idx, float *out, double *sse_slabs, int32_t *hist, int B, int D, int K, int H, int W,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* Measurement entry (bench.py, tools/vqbench.py): the same launches, the distance / argmin kernel `repeats` times in a row
  * between ONE preparation and ONE counter reduction, so that T(repeats = n + 1) - T(repeats = 1) times n launches of that

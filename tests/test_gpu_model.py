@@ -352,6 +352,25 @@ def test_fused_trainer_equals_autograd_path(golden):
         close(a, b, 1e-6, 1e-6, k)       # (the two paths differ in their decoder-tail and codebook-gradient kernels)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_trainer_join_in_the_quantiser_changes_no_bit(golden, monkeypatch, use_graph):
+    """The last residual join inside the quantiser's load path (dm_vq_forward_join, the default) against the join as its
+    own launch (DM_VQ_JOIN=0): same losses, parameters and BatchNorm buffers bit for bit over three steps."""
+    import dynamorph_amd.train as T
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    res = {}
+    for join in (True, False):
+        monkeypatch.setattr(T, "JOIN_IN_VQ", join)
+        m = fresh(golden)
+        tr = T.FusedTrainer(m, lr=1e-3, use_graph=use_graph)
+        vals = [tr.step(x).tolist() for _ in range(3)]
+        vals.append(tr.evaluate(x).tolist())
+        res[join] = (vals, {k: v.clone() for k, v in m.state_dict().items()})
+    assert res[True][0] == res[False][0]
+    for k, v in res[True][1].items():
+        assert torch.equal(v, res[False][1][k]), k
+
+
 def test_fused_trainer_prepare_captures_without_taking_a_step(golden):
     """FusedTrainer.prepare (bench.py keeps the one-off graph capture out of its timed steps with it): parameters,
     BatchNorm buffers and the Adam state are untouched, and the steps that follow equal those of a trainer that captured
