@@ -72,6 +72,7 @@ SIGNATURES = {
     "dm_vq_decode": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_vq_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp, vp]),
     "dm_vq_loss_finalize": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, i64, f32, vp, C.c_int, i64, f32, f32, vp, vp]),
+    "dm_vq_loss_finalize_tm": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, i64, f32, vp, C.c_int, i64, f32, f32, vp, C.c_int, f32, vp, vp]),
     "dm_vq_backward": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_vq_backward_num_slabs": (C.c_int, [i64, C.c_int, C.c_int]),
     "dm_vq_backward_slabs": (C.c_int, [vp, vp, vp, vp, vp, f32, vp, vp] + [C.c_int] * 5 + [vp]),
@@ -119,6 +120,7 @@ SIGNATURES = {
     "dm_time_matching_num_slabs": (C.c_int, [C.c_int]),
     "dm_time_matching_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, i64, vp, vp, vp]),
     "dm_time_matching_backward": (C.c_int, [vp, vp, vp, f32, vp, C.c_int, C.c_int, vp]),
+    "dm_time_matching_backward_add": (C.c_int, [vp, vp, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
     "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_compose_border": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

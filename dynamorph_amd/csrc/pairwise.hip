@@ -291,9 +291,10 @@ __global__ __launch_bounds__(256) void tm_near_backward_kernel(const float *__re
 
 // dz[i][d] = scale * g * (rowsum(S)_i z[i][d] - sum_j S_ij z[j][d]);  64 rows x 64 columns per workgroup, K = B
 constexpr int TM_LDZ = TM_T + 16;  // LDS row stride of the [j][d] tile: == 16 (mod 32), conflict-free B-operand reads
+// add (optional): another gradient of the same latents (the quantiser's), added here instead of in a pass of its own
 __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restrict__ z, const float *__restrict__ S,
                                                           const float *__restrict__ g_dev, float scale,
-                                                          float *__restrict__ dz, int B, int n)
+                                                          float *__restrict__ dz, int B, int n, const float *__restrict__ add)
 {
     __shared__ float sS[TM_T * TM_LDA], sZ[TM_KC * TM_LDZ], s_rs[TM_T], s_part[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
                 const int il = wr * 32 + a * 16 + (lane >> 4) * 4 + r, i = i0 + il, d = d0 + wc * 32 + b * 16 + (lane & 15);
                 if (i < B && d < n) {
                     const long long o = (long long)i * n + d;
-                    dz[o] = sc * (s_rs[il] * z[o] - acc[a][b][r]);
+                    const float t = sc * (s_rs[il] * z[o] - acc[a][b][r]);
+                    dz[o] = add ? __fadd_rn(add[o], t) : t;            // (rounded like the separate elementwise add it replaces)
                 }
             }
 }
@@ -403,15 +405,31 @@ extern "C" int dm_time_matching_forward(const float *z, const float *tm, int B, 
     return dm_launch_status("dm_time_matching_forward");
 }
 
+static int tm_backward_launch(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
+                              float *dz, int B, int n, void *stream);
+
 extern "C" int dm_time_matching_backward(const float *z, const float *S, const float *g_loss_dev, float scale, float *dz,
                                          int B, int n, void *stream)
+{
+    return tm_backward_launch(z, S, g_loss_dev, scale, nullptr, dz, B, n, stream);
+}
+
+extern "C" int dm_time_matching_backward_add(const float *z, const float *S, const float *g_loss_dev, float scale,
+                                             const float *add, float *dz, int B, int n, void *stream)
+{
+    DM_REQUIRE(add, "dm_time_matching_backward_add: NULL pointer");
+    return tm_backward_launch(z, S, g_loss_dev, scale, add, dz, B, n, stream);
+}
+
+static int tm_backward_launch(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
+                              float *dz, int B, int n, void *stream)
 {
     DM_REQUIRE(z && S && dz, "dm_time_matching_backward: NULL pointer");
     DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_backward: latent length %d is not a multiple of %d", n, TM_KC);
     DM_REQUIRE((long long)B * n < (1LL << 31), "dm_time_matching_backward: tensor too large");
     DM_REQUIRE(B <= 16384, "dm_time_matching_backward: batch %d too large (a row of S is staged in LDS)", B);
     hipLaunchKernelGGL(tm_backward_kernel, dim3((n + TM_T - 1) / TM_T, (B + TM_T - 1) / TM_T), dim3(256), 0, (hipStream_t)stream,
-                       z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n);
+                       z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n, add);
     hipLaunchKernelGGL(tm_near_backward_kernel, dim3((unsigned)B), dim3(256), (size_t)B * sizeof(float), (hipStream_t)stream, z,
                        S + (long long)B * B, g_loss_dev, scale * 2.f / (float)n, dz, B, n);
     return dm_launch_status("dm_time_matching_backward");

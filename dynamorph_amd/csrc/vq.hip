@@ -1219,12 +1219,15 @@ __global__ void vq_finalize_kernel(const double *__restrict__ sse_slabs, int nsl
 __global__ __launch_bounds__(1024) void vq_loss_finalize_kernel(const double *__restrict__ sse_slabs, int nslabs, const int *__restrict__ hrep,
                                         const int *__restrict__ hdr,
                                         int K, long long P, int D, float cc, const double *__restrict__ loss_slabs, int nloss,
-                                        long long count, float w_recon, float w_commit, float *__restrict__ out)
+                                        long long count, float w_recon, float w_commit, float *__restrict__ out,
+                                        const double *__restrict__ tm_slabs, int ntm, float w_matching)
 {
     __shared__ double s_red[16];
     __shared__ int s_cnt[16][64];
     const int R = hdr[1], stride = hdr[2];
-    double s = 0.0, l = 0.0, e = 0.0;
+    double s = 0.0, l = 0.0, e = 0.0, m = 0.0;
+    // the pairwise term's partial losses (dm_time_matching_forward: pairs of doubles, the loss in the first)
+    for (int i = threadIdx.x; i < ntm; i += blockDim.x) m += tm_slabs[2 * i];
     // (eight slabs per thread requested together: one memory round trip for up to 2048 slabs)
     for (int i0 = threadIdx.x; i0 < nslabs; i0 += 8 * (int)blockDim.x) {
         double v[8];
@@ -1270,14 +1273,21 @@ __global__ __launch_bounds__(1024) void vq_loss_finalize_kernel(const double *__
     const double sse = block_sum(s, s_red);
     const double tot = block_sum(l, s_red);
     const double ent = block_sum(e, s_red);
+    const double tml = ntm > 0 ? block_sum(m, s_red) : 0.0;
     if (threadIdx.x == 0) {
         const float mse = (float)(sse / ((double)P * (double)D));
         const float commit = mse + cc * mse;
         const float recon = (float)(tot / (double)count);
         out[0] = recon;
         out[1] = commit;
-        out[2] = w_recon * recon + w_commit * commit;
+        const float total = w_recon * recon + w_commit * commit;
+        out[2] = total;
         out[3] = expf(-(float)ent);
+        if (ntm > 0) {        // total + weight_matching * time_matching_loss (vq_vae.py:332; vae.py:470), the term as a fifth value
+            const float tl = (float)tml;
+            out[2] = __fadd_rn(total, __fmul_rn(w_matching, tl));
+            out[4] = tl;
+        }
     }
 }
 
@@ -1732,8 +1742,24 @@ extern "C" int dm_vq_loss_finalize(const double *sse_slabs, int nslabs, const vo
     hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sse_slabs, nslabs, hrep,
                        reinterpret_cast<const int *>(workspace), K,
                        (long long)positions, D, commitment_cost, loss_slabs, nloss, (long long)count, weight_recon,
-                       weight_commitment, scalars_out);
+                       weight_commitment, scalars_out, (const double *)nullptr, 0, 0.f);
     return dm_launch_status("dm_vq_loss_finalize");
+}
+
+extern "C" int dm_vq_loss_finalize_tm(const double *sse_slabs, int nslabs, const void *workspace, int K, int D,
+                                      int64_t positions, float commitment_cost, const double *loss_slabs, int nloss,
+                                      int64_t count, float weight_recon, float weight_commitment, const double *tm_slabs,
+                                      int ntm, float weight_matching, float *scalars_out, void *stream)
+{
+    DM_REQUIRE(sse_slabs && workspace && loss_slabs && scalars_out && tm_slabs && nslabs > 0 && nloss > 0 && ntm > 0 && K > 0 &&
+                   D > 0 && positions > 0 && count > 0, "dm_vq_loss_finalize_tm: bad argument");
+    const Vq2Layout L = vq2_layout(K, D);
+    const int *hrep = reinterpret_cast<const int *>(reinterpret_cast<const float *>(workspace) + L.hrep);
+    hipLaunchKernelGGL(vq_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sse_slabs, nslabs, hrep,
+                       reinterpret_cast<const int *>(workspace), K,
+                       (long long)positions, D, commitment_cost, loss_slabs, nloss, (long long)count, weight_recon,
+                       weight_commitment, scalars_out, tm_slabs, ntm, weight_matching);
+    return dm_launch_status("dm_vq_loss_finalize_tm");
 }
 
 namespace {

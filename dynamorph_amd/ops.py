@@ -217,6 +217,20 @@ def vq_loss_finalize(sse_slabs, ws, K, D, positions, commitment_cost, loss_slabs
 
 
 @_op
+def vq_loss_finalize_tm(sse_slabs, ws, K, D, positions, commitment_cost, loss_slabs, count, weight_recon, weight_commitment,
+                        tm_slabs, weight_matching):
+    """vq_loss_finalize with the pairwise term: (recon, commitment, total + weight_matching * tm, perplexity, tm) in one
+    launch from the partial losses time_matching_forward(..., want_slabs=True) left."""
+    lib = L.load()
+    out = _new((5,), sse_slabs)
+    L.check(lib.dm_vq_loss_finalize_tm(_ptr(sse_slabs, torch.float64), sse_slabs.numel(), _ptr(ws), K, D, positions,
+                                       commitment_cost, _ptr(loss_slabs, torch.float64), loss_slabs.numel(), count,
+                                       weight_recon, weight_commitment, _ptr(tm_slabs, torch.float64), tm_slabs.shape[0],
+                                       weight_matching, _ptr(out), _stream()), "dm_vq_loss_finalize_tm")
+    return out
+
+
+@_op
 def vq_decode(idx, codebook):
     lib = L.load()
     B, H, W = idx.shape
@@ -688,10 +702,11 @@ def time_matching_supported(B, n):
 
 
 @_op
-def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0):
+def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0, want_slabs=False):
     """The whole pairwise term on the MFMA (include/dynamorph_hip.h, dm_time_matching_forward).  z (B, n), tm (B, B) float32.
     Returns (loss: 1-element device tensor, S (2, B, B) = dloss/dsim + its transpose, far pairs / near pairs, for
-    time_matching_backward)."""
+    time_matching_backward).  want_slabs: the partial losses (nslabs, 1, 2) float64 instead of their sum (the training
+    step's scalar launch adds them: vq_loss_finalize_tm)."""
     lib = L.load()
     B, n = z.shape
     wsf = lib.dm_time_matching_workspace_floats(B, n)
@@ -701,16 +716,25 @@ def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0):
     slabs = _new((nsl, 1, 2), z, torch.float64)
     L.check(lib.dm_time_matching_forward(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),
                                          _ptr(slabs, torch.float64), _stream()), "dm_time_matching_forward")
+    if want_slabs:
+        return slabs, S
     loss = sum_slabs(slabs, _new((1,), z))
     return loss, S
 
 
 @_op
-def time_matching_backward(z, S, g_loss=None, scale=1.0):
-    """dz = scale * g_loss[0] * d loss / d z  (g_loss: 1-element device tensor or None = 1)."""
+def time_matching_backward(z, S, g_loss=None, scale=1.0, add=None):
+    """dz = [add +] scale * g_loss[0] * d loss / d z  (g_loss: 1-element device tensor or None = 1; add: a gradient of the
+    same latents, (B, n) or any shape with as many elements, summed in the kernel's store instead of an elementwise pass)."""
     lib = L.load()
     B, n = z.shape
     dz = torch.empty_like(z)
+    if add is not None:
+        if add.numel() != z.numel():
+            raise ValueError("dm_time_matching_backward_add: `add` must have the latents' size")
+        L.check(lib.dm_time_matching_backward_add(_ptr(z), _ptr(S), _ptr(g_loss), scale, _ptr(add), _ptr(dz), B, n, _stream()),
+                "dm_time_matching_backward_add")
+        return dz
     L.check(lib.dm_time_matching_backward(_ptr(z), _ptr(S), _ptr(g_loss), scale, _ptr(dz), B, n, _stream()),
             "dm_time_matching_backward")
     return dz

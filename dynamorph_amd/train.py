@@ -116,26 +116,30 @@ class FusedTrainer:
         zq, idx, vqs = E.vq_forward(m.vq.w.weight, z, cc, defer_scalars=True)
         r, dsaved = E.residual_forward(dr, zq)
         _, tcx = E.z32_tail_forward(dec[1], dec[2], dec[4], r, x, mask, m.channel_var)
-        scalars = ops.vq_loss_finalize(vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, tcx.loss_slabs,
-                                       B * NIN * H * W, 1.0, 1.0)
-        pending = []
-        g_r = E.z32_tail_backward(dec[1], dec[2], dec[4], tcx, self.w_recon, None, self.G, pending=pending,
-                                  zero_fed_biases=False)
-        g_zq, _ = E.residual_backward(dr, dsaved, g_r, self.G, None, pending=pending, zero_fed_biases=False)
+        # the pairwise term acts on z_after (vae.py:441-455); its gradient reaches z through the straight-through value
+        tm_S = tm_fallback = None
+        fin = (vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, tcx.loss_slabs, B * NIN * H * W, 1.0, 1.0)
         if tm is not None:
-            # the pairwise term acts on z_after (vae.py:441-455); its gradient reaches z through the straight-through value
             zf = zq.reshape(B, -1)
             wm = float(m.weight_matching)
             tmf = tm.to(torch.float32).contiguous()
             if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
-                tml, S = ops.time_matching_forward(zf, tmf, 1, float(m.w_a), float(m.w_t), float(m.w_n), float(m.margin))
-                g_zq = g_zq + ops.time_matching_backward(zf, S, None, wm).reshape(zq.shape)
-                tml = tml.reshape(())
+                tm_slabs, tm_S = ops.time_matching_forward(zf, tmf, *_tm_args(m, True), want_slabs=True)
+                scalars = ops.vq_loss_finalize_tm(*fin, tm_slabs, wm)        # the five scalars in one launch
             else:
-                sim = ops.pair_msd(zf)
-                tml, g_sim = self._time_matching(sim, tmf, True)      # (VQ_VAE_z32: always the weighted-hinge form)
-                g_zq = g_zq + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(zq.shape)
-            scalars = _with_matching(scalars, tml, wm)
+                tml, g_sim = self._time_matching(ops.pair_msd(zf), tmf, True)      # (VQ_VAE_z32: always the weighted-hinge form)
+                tm_fallback = ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(zq.shape)
+                scalars = _with_matching(ops.vq_loss_finalize(*fin), tml, wm)
+        else:
+            scalars = ops.vq_loss_finalize(*fin)
+        pending = []
+        g_r = E.z32_tail_backward(dec[1], dec[2], dec[4], tcx, self.w_recon, None, self.G, pending=pending,
+                                  zero_fed_biases=False)
+        g_zq, _ = E.residual_backward(dr, dsaved, g_r, self.G, None, pending=pending, zero_fed_biases=False)
+        if tm_S is not None:
+            g_zq = ops.time_matching_backward(zf, tm_S, None, wm, add=g_zq).reshape(zq.shape)     # (summed in the kernel's store)
+        elif tm_fallback is not None:
+            g_zq = g_zq + tm_fallback
         gcb = self.G(m.vq.w.weight)
         dz, cb_slabs = ops.vq_backward_slabs(z, m.vq.w.weight.detach(), idx, g_zq, self.w_commit, cc)
         pending.append((cb_slabs, gcb))
@@ -161,32 +165,33 @@ class FusedTrainer:
         dec, dcx = E.decoder_forward(L, zq, x, mask, defer_tail=True)
         B, NIN, H, W = x.shape
         g_zq = E.decoder_backward(L, dcx, self.w_recon, None, self.G)
-        # (recon, commitment, total, perplexity): the VectorQuantizer's scalars and the reconstruction loss in one launch
-        scalars = ops.vq_loss_finalize(vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, dcx.loss_slabs,
-                                       B * NIN * H * W, float(model.weight_recon), float(model.weight_commitment))
+        # (recon, commitment, total, perplexity[, time matching]): the VectorQuantizer's scalars, the reconstruction loss and
+        # the pairwise term on z_before (vq_vae.py:324-332) in one launch
+        fin = (vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, dcx.loss_slabs, B * NIN * H * W,
+               float(model.weight_recon), float(model.weight_commitment))
+        tm_S = tm_fallback = None
+        if time_matching_mat is not None:
+            zf = z.reshape(B, -1)
+            wm = float(model.weight_matching)
+            tm = time_matching_mat.to(torch.float32).contiguous()
+            if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
+                tm_slabs, tm_S = ops.time_matching_forward(zf, tm, *_tm_args(model), want_slabs=True)
+                scalars = ops.vq_loss_finalize_tm(*fin, tm_slabs, wm)
+            else:       # latent lengths the MFMA kernels do not tile: distances from dm_pair_msd, the B x B weighting in torch
+                tml, g_sim = self._time_matching(ops.pair_msd(zf), tm)
+                tm_fallback = ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(z.shape)
+                scalars = _with_matching(ops.vq_loss_finalize(*fin), tml, wm)
+        else:
+            scalars = ops.vq_loss_finalize(*fin)
         gcb = self.G(L.codebook.weight)
         # codebook gradient as slabs, added in the encoder's single slab reduction: nothing to zero, no global atomics
         # (K <= 64: an ordered one-hot product on the matrix cores, bit-reproducible; larger K: LDS adds in arrival order)
         dz, cb_slabs = ops.vq_backward_slabs(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc)
         extra = [(cb_slabs, gcb)]
-        if time_matching_mat is not None:
-            # pairwise term on z_before (vq_vae.py:324-332): HIP kernels for the (B, B) distances and their gradient,
-            # the B*B weighting in torch
-            zf = z.reshape(B, -1)
-            wm = float(model.weight_matching)
-            tm = time_matching_mat.to(torch.float32).contiguous()
-            if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
-                z16 = getattr(model, "_z16_loss", False)
-                tml, S = ops.time_matching_forward(zf, tm, 1 if z16 else 0, float(getattr(model, "w_a", 0.0)),
-                                                   float(getattr(model, "w_t", 0.0)), float(getattr(model, "w_n", 0.0)),
-                                                   float(getattr(model, "margin", 0.0)))
-                dz = dz + ops.time_matching_backward(zf, S, None, wm).reshape(z.shape)
-                tml = tml.reshape(())
-            else:
-                sim = ops.pair_msd(zf)
-                tml, g_sim = self._time_matching(sim, tm)
-                dz = dz + ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(z.shape)
-            scalars = _with_matching(scalars, tml, wm)
+        if tm_S is not None:
+            dz = ops.time_matching_backward(zf, tm_S, None, wm, add=dz).reshape(z.shape)      # (summed in the kernel's store)
+        elif tm_fallback is not None:
+            dz = dz + tm_fallback
         # the flat gradient buffer starts at zero and nothing ever writes the BatchNorm-fed conv biases' slots
         E.encoder_backward(L, ecx, dz, self.G, zero_fed_biases=False, pending_extra=extra)
         return scalars
@@ -280,18 +285,16 @@ class FusedTrainer:
                 zq, _, vqs = E.vq_forward(L.codebook.weight, z, cc, defer_scalars=True)
             _, dcx = E.decoder_forward(L, zq, x, mask)
             slabs, wr, wc, lat = dcx.loss_slabs, float(m.weight_recon), float(m.weight_commitment), z
-        scalars = ops.vq_loss_finalize(vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, slabs, B * NIN * H * W, wr, wc)
-        if tm is not None:
-            zf = lat.reshape(B, -1)
-            z16 = self._z32 or getattr(m, "_z16_loss", False)
-            if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
-                tml, _ = ops.time_matching_forward(zf, tm.to(torch.float32).contiguous(), 1 if z16 else 0,
-                                                   float(getattr(m, "w_a", 0.0)), float(getattr(m, "w_t", 0.0)),
-                                                   float(getattr(m, "w_n", 0.0)), float(getattr(m, "margin", 0.0)))
-            else:
-                tml, _ = self._time_matching(ops.pair_msd(zf), tm.to(torch.float32), z16)
-            scalars = _with_matching(scalars, tml, float(m.weight_matching))
-        return scalars
+        fin = (vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, slabs, B * NIN * H * W, wr, wc)
+        if tm is None:
+            return ops.vq_loss_finalize(*fin)
+        zf = lat.reshape(B, -1)
+        tmf = tm.to(torch.float32).contiguous()
+        if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
+            tm_slabs, _ = ops.time_matching_forward(zf, tmf, *_tm_args(m, self._z32), want_slabs=True)
+            return ops.vq_loss_finalize_tm(*fin, tm_slabs, float(m.weight_matching))
+        tml, _ = self._time_matching(ops.pair_msd(zf), tmf, self._z32 or getattr(m, "_z16_loss", False))
+        return _with_matching(ops.vq_loss_finalize(*fin), tml, float(m.weight_matching))
 
     def evaluate(self, x, mask=None, time_matching_mat=None):
         """forward_only through a captured HIP graph (one per input shape); returns the device tensor of loss values."""
@@ -360,6 +363,13 @@ class FusedTrainer:
     def input_buffer(self):
         """Input tensor of the graph replayed last (None before the first step): fill it in place to skip the copy."""
         return self._static_x
+
+
+def _tm_args(model, z32=False):
+    """(mode, w_a, w_t, w_n, margin) of dm_time_matching_forward for this model family (vq_vae.py:330-331 / vae.py:327-336)."""
+    z16 = z32 or getattr(model, "_z16_loss", False)
+    return (1 if z16 else 0, float(getattr(model, "w_a", 0.0)), float(getattr(model, "w_t", 0.0)),
+            float(getattr(model, "w_n", 0.0)), float(getattr(model, "margin", 0.0)))
 
 
 def _with_matching(scalars, tml, wm):

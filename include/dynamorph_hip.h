@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 116
+#define DM_VERSION 117
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -165,6 +165,13 @@ int dm_vq_finalize(const double *sse_slabs, int nslabs, const int32_t *hist, int
 int dm_vq_loss_finalize(const double *sse_slabs, int nslabs, const void *workspace, int K, int D,
                         int64_t positions, float commitment_cost, const double *loss_slabs, int nloss,
                         int64_t count, float weight_recon, float weight_commitment, float *scalars_out, void *stream);
+/* ... with the pairwise time-matching term in the same launch: tm_slabs = the loss_slabs of dm_time_matching_forward (ntm
+ * pairs of doubles); scalars_out has FIVE entries: (recon, commitment, total + weight_matching * tm, perplexity, tm)
+ * (vq_vae.py:324-336; vae.py:456-470). */
+int dm_vq_loss_finalize_tm(const double *sse_slabs, int nslabs, const void *workspace, int K, int D, int64_t positions,
+                           float commitment_cost, const double *loss_slabs, int nloss, int64_t count, float weight_recon,
+                           float weight_commitment, const double *tm_slabs, int ntm, float weight_matching,
+                           float *scalars_out, void *stream);
 
 /* Autograd of vq_vae.py:71-76 for upstream (g_out, g_loss):
  *   dz = g_out + g_loss*2*cc*(z-q)/N   [g_out may be NULL = 0]
@@ -449,6 +456,10 @@ int dm_time_matching_forward(const float *z, const float *tm, int B, int n, int 
                              void *stream);
 int dm_time_matching_backward(const float *z, const float *S, const float *g_loss_dev, float scale, float *dz, int B, int n,
                               void *stream);
+/* The same with another gradient of the same latents added on the way out: dz = add + scale * g * dloss/dz (`add` may be
+ * `dz` itself).  The training step adds the pairwise term's gradient to the quantiser's without an elementwise pass. */
+int dm_time_matching_backward_add(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
+                                  float *dz, int B, int n, void *stream);
 
 /* ===== enc.0 o enc.1 composition (vq_vae.py:277-278) ========================== */
 

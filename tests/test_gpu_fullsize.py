@@ -181,12 +181,22 @@ def test_c5_at_its_bench_batch_1024_self_consistency():
         tr = FusedTrainer(mm, lr=1e-3, use_graph=graph)
         vals = tr.step(x).tolist()
         assert all(np.isfinite(v) for v in vals), vals
-        got[graph] = (vals, tr.flat.clone(), [b.clone() for b in mm.buffers()])
+        got[graph] = (vals, {k: v.detach().clone() for k, v in mm.state_dict().items()})
         del tr, mm
         gc.collect()
         torch.cuda.empty_cache()
     assert got[True][0] == got[False][0]
-    assert torch.equal(got[True][1], got[False][1])                       # parameters after the step, bit for bit
-    for a, b in zip(got[True][2], got[False][2]):
-        assert torch.equal(a, b)
-    assert not torch.equal(got[True][1], torch.nn.utils.parameters_to_vector([p for p in m.parameters() if p.requires_grad]))
+    before = m.state_dict()
+    moved = 0
+    for k, a in got[True][1].items():
+        b = got[False][1][k]
+        if k == "vq.w.weight":
+            # codebooks above 64 codes: the gradient's LDS adds run in arrival order inside a workgroup,
+            # its low bits may differ between two runs; Adam's first step turns that into +-lr on entries whose gradient is
+            # at rounding level, so compare the step itself
+            assert float((a - b).abs().max()) <= 2.1e-3
+            assert float(((a - before[k]) - (b - before[k])).abs().mean()) <= 1e-4
+        else:
+            assert torch.equal(a, b), k                               # everything else: bit for bit
+        moved += int(not torch.equal(a, before[k]))
+    assert moved > 40

@@ -1023,6 +1023,34 @@ def _tm_reference(z, tm, mode, w_a=1.1, w_t=0.1, w_n=-0.5, margin=0.5):
     return float(ref), zr.grad
 
 
+@pytest.mark.parametrize("B,n", [(6, 4096), (70, 1024)])
+def test_time_matching_folds_into_the_step(ops, B, n):
+    """The two folds of the training step: dm_time_matching_backward_add (the pairwise term's gradient summed onto another
+    gradient of the latents in the kernel's store) and dm_vq_loss_finalize_tm (the term's loss and the weighted total in
+    the step's one scalar launch) against the separate launches they replace."""
+    g = torch.Generator().manual_seed(B)
+    z = (torch.randn(B, n, generator=g) * 0.5).to(DEV)
+    tm = torch.randint(0, 3, (B, B), generator=g).float().to(DEV)
+    other = torch.randn(B, n, generator=g).to(DEV)
+    loss, S = ops.time_matching_forward(z, tm, 1, 1.1, 0.1, -0.5, 0.5)
+    slabs, S2 = ops.time_matching_forward(z, tm, 1, 1.1, 0.1, -0.5, 0.5, want_slabs=True)
+    assert torch.equal(S, S2)
+    sep = other + ops.time_matching_backward(z, S, None, 0.7)
+    fused = ops.time_matching_backward(z, S, None, 0.7, add=other)
+    close(fused, sep, 1e-6, 1e-7 * float(sep.abs().max()), "gradient sum")      # (near pairs are added in another order)
+    # scalars: a VQ call's state + reconstruction slabs + the pairwise slabs
+    zq = torch.randn(4, 16, 16, 16, generator=g).to(DEV)
+    cb = torch.randn(64, 16, generator=g).to(DEV)
+    _, _, sse, ws = ops.vq_forward(zq, cb, want_hist=False)
+    ls = torch.rand(8, dtype=torch.float64, device=DEV)
+    four = ops.vq_loss_finalize(sse, ws, 64, 16, 4 * 256, 0.25, ls, 1000, 0.9, 1.1)
+    five = ops.vq_loss_finalize_tm(sse, ws, 64, 16, 4 * 256, 0.25, ls, 1000, 0.9, 1.1, slabs, 0.005)
+    assert torch.equal(five[:2], four[:2]) and torch.equal(five[3], four[3])
+    assert abs(float(five[4]) - float(loss)) <= 1e-6 * abs(float(loss)) + 1e-12
+    want_total = float(four[2]) + 0.005 * float(five[4])
+    assert abs(float(five[2]) - want_total) <= 2e-7 * abs(want_total)
+
+
 @pytest.mark.parametrize("B,n,mode,only_near", [(24, 4096, 0, True), (24, 4096, 0, False), (40, 4096, 1, False),
                                                 (70, 1024, 0, True), (12, 65536, 0, True)])
 def test_time_matching_related_pairs_lie_close_together(ops, B, n, mode, only_near):
