@@ -71,7 +71,7 @@ def pmc_traffic(kernel_key, batch):
     itself).  None when no measurement for this kernel and batch has been committed."""
     stem = {"dec_tail_train": "dec_tail_backward_kernel", "conv4x4s2_e1": "conv4x4s2_kernel"}.get(
         kernel_key, kernel_key.split("_k4096")[0].replace("vq_forward_mfma", "vq_forward_mfma_kernel"))
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(kernel_key)

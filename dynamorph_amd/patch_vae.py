@@ -196,4 +196,47 @@ def process_VAE(raw_folder, supp_folder, sites, config_, gpu=0, network_module=N
     for name, dats in (('%s_latent_space.pkl' % well, z_b), ('%s_latent_space_after.pkl' % well, z_a)):
         with open(os.path.join(output_dir, name), 'wb') as f:
             pickle.dump(dats, f, protocol=4)
+    if getattr(le, "save_output", False):
+        save_recon_samples(model, dataset, output_dir, device, zscored=not on_dev)
     return z_b, z_a
+
+
+def save_recon_samples(model, dataset, output_dir, device, zscored=True, n_samples=20):
+    """patch_VAE.py:464-489 (`save_output`): 20 samples drawn with np.random.seed(0), each reconstructed by a batch-of-one
+    `model(sample)[0]` (train mode, like every call of this path) on the HIP pipeline.  The arrays go to
+    <output_dir>/recon_<i>.npz (sample, output); the 2 x 2 figure recon_<i>.jpg of the reference is drawn from them when
+    matplotlib is importable (plotting itself is outside the hot path: same layout, a percentile stretch for contrast)."""
+    np.random.seed(0)
+    random_inds = np.random.randint(0, len(dataset), (n_samples,))
+    written = []
+    for i in random_inds:
+        sample = dataset[i:(i + 1)]
+        if not zscored:                                        # raw float64 patches were handed over: z-score this one
+            sample = torch.from_numpy(zscore_patch(sample.numpy()))
+        sample = sample.float().to(device)
+        with torch.no_grad():
+            output = model(sample)[0]
+        a, b = sample[0].cpu().numpy(), output[0].detach().cpu().numpy()
+        path = os.path.join(output_dir, 'recon_%d.npz' % i)
+        np.savez(path, sample=a, output=b)
+        written.append(path)
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:
+            continue
+
+        def stretch(im, tol=1):                                # contrast limits at the tol / 100 - tol percentiles
+            lo, hi = np.percentile(im, [tol, 100 - tol])
+            return np.clip((im - lo) / max(hi - lo, 1e-12), 0, 1)
+        fig, ax = plt.subplots(2, 2, squeeze=False)
+        fig.set_size_inches((15, 10))
+        ims = [a[0], b[0], a[min(1, a.shape[0] - 1)], b[min(1, b.shape[0] - 1)]]
+        for axis, im, name in zip(ax.flatten(), ims, ['phase', 'phase_recon', 'im_retard', 'retard_recon']):
+            axis.imshow(stretch(im), cmap='gray')
+            axis.axis('off')
+            axis.set_title(name, fontsize=12)
+        fig.savefig(os.path.join(output_dir, 'recon_%d.jpg' % i), dpi=100, bbox_inches='tight')
+        plt.close(fig)
+    return written

@@ -14,6 +14,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def copy_of(module):
+    import copy
+    return copy.deepcopy(module)
+
+
 def test_process_vae_pickle_contract(tmp_path, golden):
     """pipeline/patch_VAE.py:343-462: <well>_file_paths.pkl + <well>_static_patches.pkl + <weights>/model.pt in,
     <raw>/<model_name>/<well>_latent_space[_after].pkl out (protocol 4, (N,4096) float32)."""
@@ -47,6 +52,19 @@ def test_process_vae_pickle_contract(tmp_path, golden):
     m.load_state_dict(sd)
     idx = m.vq.encode_inputs(torch.from_numpy(zb).reshape(5, 16, 16, 16).to(DEV)).cpu()
     codes_gate(idx != idx_ref, zb_ref, ref.vq.w.weight.detach(), "process_VAE latents")
+    # save_output (patch_VAE.py:464-489): 20 samples drawn with seed 0, reconstructed one by one through model(sample)[0]
+    cfg.latent_encoding.save_output = True
+    process_VAE(str(raw), None, ["C5-Site_0"], cfg, gpu=0, batch_size=2)
+    np.random.seed(0)
+    picks = sorted(set(int(i) for i in np.random.randint(0, 5, (20,))))
+    for i in picks:
+        rec = np.load(out / f"recon_{i}.npz")
+        assert rec["sample"].shape == (2, 128, 128) and rec["output"].shape == (2, 128, 128)
+        np.testing.assert_allclose(rec["sample"], x[i].numpy(), rtol=0, atol=0)
+        with torch.no_grad():
+            want = copy_of(ref)(x[i:i + 1])[0][0].numpy()
+        assert np.abs(rec["output"] - want).max() < 5e-4
+    cfg.latent_encoding.save_output = False
     with pytest.raises(ValueError, match="Error in loading model weights"):
         os.remove(wdir / "model.pt")
         process_VAE(str(raw), None, ["C5-Site_0"], cfg, gpu=0)

@@ -46,6 +46,17 @@ zq = torch.randn(B, 16, 16, 16, device=dev); cbk = torch.randn(64, 16, device=de
 vq_bufs = ops.vq_forward_repeat(zq, cbk, 1)
 cases["vq_fwd"] = (lambda: ops.vq_forward_repeat(zq, cbk, 1, bufs=vq_bufs), B * 34816)      # prep + distance kernel + counter reduction
 
+rbk, hk = torch.randn(B, 16, 16, 16, device=dev), torch.randn(B, 16, 16, 16, device=dev)
+coefk = torch.rand(16, 4, device=dev) + 0.5
+cases["vq_join"] = (lambda: ops.vq_forward_join(rbk, hk, coefk, cbk), B * (4 * 16384 + 2048))     # rb, h_in read; z, out, idx written
+
+# train()'s resident feed: a batch gathered from a dataset in HBM with per-sample flip / rot90 (read + write of every patch)
+srcg = torch.randn(B + B // 2, 2, 128, 128, device=dev)
+idsg = torch.randperm(srcg.shape[0], device=dev)[:B].to(torch.int32)
+flg = torch.randint(0, 3, (B,), device=dev, dtype=torch.int32); rog = torch.randint(0, 4, (B,), device=dev, dtype=torch.int32)
+outg = torch.empty(B, 2, 128, 128, device=dev)
+cases["gather_aug"] = (lambda: ops.gather_augment(srcg, idsg, flg, rog, outg), B * 2 * 131072)
+
 # stress shape of BASELINE configs[4]: 4096 codes, 32 x 32 latents of KB_B5 patches (bench.py --workload c5 default batch)
 B5 = int(os.environ.get("KB_B5", "1024"))
 zq5 = torch.randn(B5, 16, 32, 32, device=dev); cbk5 = torch.randn(4096, 16, device=dev)

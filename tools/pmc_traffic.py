@@ -19,7 +19,9 @@ KEYS = {                       # key in the JSON -> substring of the kernel name
     "dec_tail_backward": "dec_tail_backward_kernel<2, false",
     "dec_tail_forward": "dec_tail_forward_kernel",
     "conv4x4s2_e1": "conv4x4s2_kernel",
-    "vq_forward_mfma": "vq_forward_mfma_kernel<16, true",         # K = 64: the whole codebook in one LDS piece
+    "vq_forward_mfma": ("vq_forward_mfma_kernel<16, true", ", true>("),   # K = 64: the whole codebook in one LDS piece (not the JOIN form)
+    "vq_forward_join": "vq_forward_mfma_kernel<16, true, 3, true, true, true>",   # ... with the last residual join in its load path
+    "gather_augment": "gather_augment_tiled_kernel",             # train()'s resident feed: gather + flip / rot90 of a batch
     "vq_forward_mfma_k4096": "vq_forward_mfma_kernel<16, false",  # K = 4096 (KB_B5 patches): codebook walks through LDS
     "vq_backward_mfma": "vq_backward_mfma_kernel",
     "latent_tail": "latent_tail_kernel",
@@ -49,7 +51,8 @@ def main():
     write, _ = per_kernel(write_dir, "WRITE_SIZE")
     out = {}
     for key, pat in KEYS.items():
-        names = [n for n in fetch if pat in n]
+        inc, exc = pat if isinstance(pat, tuple) else (pat, None)
+        names = [n for n in fetch if inc in n and not (exc and exc in n)]
         if not names:
             continue
         # the heaviest kernel under that pattern (the calibration copy is the only large elementwise launch)

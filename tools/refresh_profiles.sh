@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the round's judged artefacts under gpurun_out/refresh (run from the repo root on the GPU box, copy into profiles/ afterwards):
-#   tools/refresh_profiles.sh r03
+#   tools/refresh_profiles.sh r04
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/refresh
 mkdir -p $out
@@ -34,5 +34,16 @@ cd $root
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write 2048 > $out/${tag}_pmc_traffic.json
 rm -rf $out/pmc_fetch $out/pmc_write
 python3 tools/vqbench.py > $out/${tag}_vq_kernels.txt 2>&1
+# train() end to end (resident / streaming / synchronous feeds) and the kernels of the resident loop
+python3 tools/trainbench.py --full > $out/${tag}_trainbench.jsonl 2> $out/trainbench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/tb -- python3 $root/tools/trainbench.py --feeds resident --epochs 2 > $out/tb_under_profiler.jsonl 2> $out/tb.err
+cd $root
+python3 tools/kstats_summary.py $out/tb > $out/${tag}_trainloop_resident_kernel_table.txt
+rm -rf $out/tb
+# SQ counters of the step's kernels (two --pmc passes, no trace domains)
+tools/sqprof.sh ${tag}_c3 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-targets --no-roofline > /dev/null 2>&1
+cp gpurun_out/${tag}_c3_sq.txt $out/${tag}_c3_b2048_sq_counters.txt 2>/dev/null
+cp gpurun_out/${tag}_c3_sq.json $out/${tag}_c3_b2048_sq_counters.json 2>/dev/null
 DM_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 > $out/${tag}_bench_dp2_gloo_rehearsal.json 2> $out/dp2.err
 tail -c 600 $out/${tag}_c3_b2048_bench.json; echo; tail -3 $out/${tag}_c3_b2048_kernel_table.txt; tail -c 400 $out/${tag}_bench_dp2_gloo_rehearsal.json
