@@ -269,7 +269,7 @@ def north_star_targets(model, x):
     torch.cuda.synchronize()
     d_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev[4:])
     d_ms = d_ms[len(d_ms) // 2]                                # median of 20
-    prof_us = profile_avg_us("vq_forward_mfma_kernel")
+    prof_us = profile_avg_us("vq_forward_mfma_kernel<16, true, 3, true, true, false>")
     f_ev = round(vq_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     f_prof = round(vq_bytes / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof_us else None
     vq = {"kernel": "vq_forward_mfma_kernel (MFMA filter + exact re-check)", "bytes": vq_bytes,
@@ -285,6 +285,33 @@ def north_star_targets(model, x):
           "call_frac_hbm": round(vq_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
           "call_with_hist_ms": round(call_hist_ms, 5),
           "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()) // 1}
+    # the quantiser as the STEP dispatches it since round 4: the encoder's last residual join in its load path
+    # (dm_vq_forward_join reads rb and h_in, writes z, the quantised value and the codes: twice the bytes in one launch)
+    sv = cx.res[-1] if cx.res else None
+    if sv is not None and ops.vq_forward_join_supported(D, cbk.shape[0], z.shape[2], z.shape[3]):
+        rb_src, h_src = sv.rb.clone(), sv.h_in.clone()
+        rb_b, h_b = torch.empty_like(rb_src), torch.empty_like(h_src)
+        for e0, e1 in ev:
+            pad.fill_(0.0)
+            rb_b.copy_(rb_src)
+            h_b.copy_(h_src)
+            e0.record()
+            ops.vq_forward_join(rb_b, h_b, sv.coefb, cbk)
+            e1.record()
+        torch.cuda.synchronize()
+        j_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev[4:])
+        j_ms = j_ms[len(j_ms) // 2]
+        j_bytes = P * (4 * D * 4 + 8)
+        j_prof = profile_avg_us("vq_forward_mfma_kernel<16, true, 3, true, true, true>")
+        jf_ev = round(j_bytes / (j_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        jf_prof = round(j_bytes / (j_prof * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if j_prof else None
+        vq["in_step"] = {"kernel": "vq_forward_mfma_kernel<16, true, 3, true, true, JOIN> (dm_vq_forward_join: residual join + distance + "
+                                   "argmin + gather + straight-through value + squared error + code counters)",
+                         "bytes": j_bytes, "bytes_are": "rb + h_in read, z + quantised written (4 x 16 384 B per patch) + int64 codes",
+                         "frac_hbm": jf_prof if jf_prof else jf_ev, "profile_avg_us": j_prof, "frac_hbm_profile": jf_prof,
+                         "dispatch_ms_events": round(j_ms, 5), "frac_hbm_events": jf_ev,
+                         "vq_only_bytes_frac_hbm": round(vq_bytes / ((j_prof * 1e-6) if j_prof else (j_ms * 1e-3)) / 1e9 / HBM_PEAK_GBS, 4)}
+        del rb_src, h_src, rb_b, h_b
     del pad, z_src
     # ---- encoder forward convolutions, on the step's own activations
     nh, nrh, c1 = L.nh, L.nrh, L.nh // 2
