@@ -261,10 +261,14 @@ def residual_backward(res_layers, saved, g_h, G, q_below, pending=None, zero_fed
             raise NotImplementedError("backward needs batch-statistics BatchNorm (train mode, per_sample=False)")
         cb_bwd = ops.bn_backward_finalize(stats, cnt, _w(bnb.weight), s.savedb, G(bnb.weight), G(bnb.bias))
         da_rb = Op(g_h, DM_LOAD_AFFINE2, cb_bwd, p1=s.rb)
-        ops.wgrad(da_rb, Op(s.ra, DM_LOAD_AFFINE_RELU, s.coefa), G(cb.weight), B, nh, nrh, H, W, 1, pending=pending)
         _zero(G(cb.bias), zero_fed_biases)
-        dy_ra, st = ops.conv3x3(da_rb, weight_view(_w(cb.weight), 1, nrh, 0, 0), B, nh, nrh, H, W, taps=1, want_stats=True,
-                                like=g_h, mask=Op(s.ra, DM_LOAD_AFFINE, s.coefa), stat_q=s.ra)
+        if FUSED_BACKWARD and s.coefa.dim() == 2 and ops.conv1x1_bwd_fused_supported(nh, nrh, H, W):
+            # the 1x1 convolution's data and weight gradient from ONE staging of (g_h, rb, ra) -- csrc/conv1x1_bwd.hip
+            dy_ra, st = ops.conv1x1_bwd_fused(da_rb, s.ra, s.coefa, _w(cb.weight), G(cb.weight), B, nh, nrh, H, W, pending=pending)
+        else:
+            ops.wgrad(da_rb, Op(s.ra, DM_LOAD_AFFINE_RELU, s.coefa), G(cb.weight), B, nh, nrh, H, W, 1, pending=pending)
+            dy_ra, st = ops.conv3x3(da_rb, weight_view(_w(cb.weight), 1, nrh, 0, 0), B, nh, nrh, H, W, taps=1, want_stats=True,
+                                    like=g_h, mask=Op(s.ra, DM_LOAD_AFFINE, s.coefa), stat_q=s.ra)
         ca_bwd = ops.bn_backward_finalize(st, cnt, _w(bna.weight), s.saveda, G(bna.weight), G(bna.bias))
         da_ra = Op(dy_ra, DM_LOAD_AFFINE2, ca_bwd, p1=s.ra)
         ops.wgrad(da_ra, Op(s.h_in, DM_LOAD_RELU), G(ca.weight), B, nrh, nh, H, W, 3, pending=pending)

@@ -145,10 +145,11 @@ class Feed:
     def _stage(self, k, ids):
         """Helper thread: host gather of one batch into pinned staging k, then its copy into device slot k."""
         n = len(ids)
-        run = n > 0 and ids[-1] - ids[0] == n - 1 and all(ids[j + 1] - ids[j] == 1 for j in range(n - 1))
+        ids = np.asarray(ids, dtype=np.int64)
+        run = n > 0 and int(ids[-1] - ids[0]) == n - 1 and bool((np.diff(ids) == 1).all())
         self.ev_ready[k].synchronize()                               # staging k's previous copy has left the host
         if run and self.src.dtype == torch.float32 and self.src.is_pinned():
-            src_x = self.src[ids[0]:ids[0] + n]                      # consecutive samples of a pinned dataset: DMA from where they lie
+            src_x = self.src[int(ids[0]):int(ids[0]) + n]            # consecutive samples of a pinned dataset: DMA from where they lie
         else:
             src_x = self.pin[k][:n]
             self._host_gather(self.src, ids, run, src_x)
@@ -169,14 +170,15 @@ class Feed:
 
         def part(lo):
             hi = min(n, lo + step)
+            first = int(ids[0])
             if run and src.dtype == torch.float32:
-                np.copyto(out[lo:hi].numpy(), src[ids[0] + lo:ids[0] + hi].numpy())     # (a plain memcpy per thread)
+                np.copyto(out[lo:hi].numpy(), src[first + lo:first + hi].numpy())     # (a plain memcpy per thread)
             elif run:
-                out[lo:hi].copy_(src[ids[0] + lo:ids[0] + hi])
+                out[lo:hi].copy_(src[first + lo:first + hi])
             elif src.dtype == torch.float32:
-                torch.index_select(src, 0, torch.as_tensor(ids[lo:hi], dtype=torch.int64), out=out[lo:hi])
+                torch.index_select(src, 0, torch.from_numpy(ids[lo:hi]), out=out[lo:hi])
             else:
-                out[lo:hi].copy_(src.index_select(0, torch.as_tensor(ids[lo:hi], dtype=torch.int64)))   # the reference's cast to fp32
+                out[lo:hi].copy_(src.index_select(0, torch.from_numpy(ids[lo:hi])))   # the reference's cast to fp32
         list(self.gatherers.map(part, range(0, n, step)))
 
     # ------------------------------------------------------------------------------------------ targets
@@ -194,7 +196,7 @@ class Feed:
 
     def phase(self, batches, transform=None, fused=True):
         """Generator over the non-empty batches of one phase (lists of sample ids): (n, x, kwargs)."""
-        batches = [list(b) for b in batches if len(b)]
+        batches = [np.asarray(b) for b in batches if len(b)]
         if not batches:
             return
         total = sum(len(b) for b in batches)
@@ -202,15 +204,24 @@ class Feed:
             # the ids and the augmentation codes of the WHOLE phase in ONE small asynchronous upload from pinned staging.
             # The codes are drawn batch by batch in the order the reference draws them (nothing else draws from numpy's
             # generator inside a phase).
-            flat = np.concatenate([np.asarray(b, dtype=np.int32) for b in batches])
-            parts = [flat]
+            parts = [np.concatenate(batches).astype(np.int32, copy=False)]
             if transform is not None:
                 # (one draw for the phase: per sample and in batch order, exactly the interleaved stream of the batch loop)
                 parts += list(ops.augment_codes(total))
-            stage = torch.empty(len(parts) * total, dtype=torch.int32, pin_memory=True)
-            stage.copy_(torch.from_numpy(np.concatenate(parts)))
+            # two pinned staging blocks, used in turn (the copy out of one may still be queued when the next phase fills
+            # the other); a third phase waits for the first block's copy
+            need = len(parts) * total
+            k = self._meta_turn = 1 - getattr(self, "_meta_turn", 1)
+            if not hasattr(self, "_meta_pin"):
+                self._meta_pin, self._meta_ev = [None, None], [torch.cuda.Event(), torch.cuda.Event()]
+            if self._meta_pin[k] is None or self._meta_pin[k].numel() < need:
+                self._meta_pin[k] = torch.empty(max(need, 1 << 16), dtype=torch.int32, pin_memory=True)
+            else:
+                self._meta_ev[k].synchronize()
+            stage = self._meta_pin[k][:need]
+            np.concatenate(parts, out=stage.numpy())
             meta_dev = stage.to(self.dev, non_blocking=True)
-            self._keep = (stage, meta_dev)           # (the pinned block must outlive the copy: kept until the next phase)
+            self._meta_ev[k].record(torch.cuda.current_stream(self.dev))
             ids_dev = meta_dev[:total]
             flips, rots = (meta_dev[total:2 * total], meta_dev[2 * total:]) if transform is not None else (None, None)
             compute = torch.cuda.current_stream(self.dev)

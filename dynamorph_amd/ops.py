@@ -374,6 +374,33 @@ def conv_bwd_s2_fused(dy, tin, wv, dst, B, CD, CX, H, W, mask, stat_q=None, pend
     return dx, stats
 
 
+def conv1x1_bwd_fused_supported(CD, CX, H, W):
+    return bool(L.load().dm_conv1x1_bwd_fused_supported(CD, CX, H, W))
+
+
+@_op
+def conv1x1_bwd_fused(dy, x, xcoef, w, dst, B, CD, CX, H, W, pending=None):
+    """Data AND weight gradient of a 1x1 convolution (CX -> CD channels) that feeds a train-mode BatchNorm, one launch
+    (include/dynamorph_hip.h, dm_conv1x1_bwd_fused).  dy: Op of the output gradient (AFFINE2 = BatchNorm backward folded in);
+    x: the layer input raw, xcoef (CX, 4) its BatchNorm + ReLU coefficients; w (CD, CX, 1, 1); dst: the weight gradient.
+    Returns (dx, stats (nslabs, CX, 2)); the weight slabs are reduced into dst here, or queued on `pending`."""
+    lib = L.load()
+    nb = lib.dm_conv1x1_bwd_fused_num_blocks(B, CD, CX, H, W)
+    if nb <= 0:
+        raise ValueError(f"dm_conv1x1_bwd_fused: shape {CX} -> {CD} channels on {H}x{W} not built")
+    dx = _new((B, CX, H, W), x)
+    stats = _new((nb, CX, 2), x, torch.float64)
+    slabs = _new((nb, CD * CX), x)
+    d = dy.struct()
+    L.check(lib.dm_conv1x1_bwd_fused(C.byref(d), _ptr(x), _ptr(xcoef), _ptr(w), _ptr(dx), _ptr(stats, torch.float64),
+                                     _ptr(slabs), B, CD, CX, H, W, _stream()), "dm_conv1x1_bwd_fused")
+    if pending is not None:
+        pending.append((slabs, dst))
+    else:
+        reduce_slabs(slabs, dst)
+    return dx, stats
+
+
 def pend_stats(pending, stats, dsts):
     """Queue the column sums of a statistics slab tensor (nslabs, N, 2) for reduce_slabs_multi: consecutive runs of
     columns go to the tensors `dsts` (what sum_slabs / sum_slabs_scatter would do in a launch of their own)."""

@@ -694,7 +694,9 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
         stats.update(feed=feeder.mode if feeder else "sync", phase_seconds={"train": [], "val": []}, phase_samples={})
 
     n_samples = len(dataset)
-    sample_ids = list(range(n_samples))
+    # (an int array instead of the reference's list: the same draws shuffle it into the same order -- numpy's shuffle is
+    # the same Fisher-Yates walk for both -- and slicing a phase into batches costs nothing)
+    sample_ids = np.arange(n_samples, dtype=np.int64)
     split = int(np.floor(val_split_ratio * n_samples))
     if world == 1:
         # the reference's draws from numpy's global generator, in the reference's order (run_training.py:490-493, 536):
@@ -707,8 +709,8 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     split_start = int(order.randint(0, n_samples - split))
     if shuffle_data:
         order.shuffle(sample_ids)
-    phases = {"train": sample_ids[:split_start] + sample_ids[split_start + split:],
-              "val": sample_ids[split_start: split_start + split]}
+    phases = {"train": np.concatenate([sample_ids[:split_start], sample_ids[split_start + split:]]),
+              "val": sample_ids[split_start: split_start + split].copy()}
 
     os.makedirs(output_dir, exist_ok=True)
     early_stopping = EarlyStopping(patience=patience, verbose=(rank == 0), path=os.path.join(output_dir, 'model.pt'))
@@ -737,7 +739,7 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                 log = _LossLog(dev, len(plan))
                 batches = feeder.phase([p[0] for p in plan], transform, fused=isinstance(optimizer, FusedTrainer))
                 for ids_local, weight in plan:
-                    if not ids_local:
+                    if not len(ids_local):
                         if training:
                             _step_without_data(model, optimizer)
                         continue
@@ -749,10 +751,11 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                 logs[phase] = (log, losses)                         # read back after BOTH phases are enqueued
             else:
                 for ids_local, weight in plan:
-                    if not ids_local:
+                    if not len(ids_local):
                         if training:
                             _step_without_data(model, optimizer)
                         continue
+                    ids_local = ids_local.tolist()                  # (the reference indexes with lists)
                     batch = dataset[ids_local][0].to(dev)
                     kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_local, device=dev) if get_relation_tensor else None,
                           'batch_mask': get_mask(mask, ids_local, device=dev) if get_mask else None}

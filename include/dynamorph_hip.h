@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 117
+#define DM_VERSION 118
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -254,6 +254,22 @@ int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *in, const dm_we
 int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k);
 int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, float *dst,
              int B, int CS, int CT, int Hs, int Ws, int k, void *stream);   /* dst = NULL: leave the slabs unreduced */
+
+/* Backward of a 1x1 convolution whose output feeds a train-mode BatchNorm (the second convolution of a ResidualBlock
+ * layer, vq_vae.py:207-209): aten::convolution_backward for input AND weight from ONE staging of its operands,
+ *   dy     the output gradient as an operand (AFFINE2: BatchNorm's backward folded into the load; or IDENT), CD channels
+ *   x      the layer input RAW (CX channels), xcoef [CX][4] = (c0, -, c2, -): the forward saw t = relu(c0 x + c2)
+ *   w      [CD][CX] (the Conv2d weight)
+ *   dx     [B][CX][H][W] out = (c0 x + c2 > 0) * sum_co w[co][ci] dy[co]     (the ReLU's mask applied)
+ *   stats  dm_conv1x1_bwd_fused_num_blocks slabs of [CX][2] doubles: (sum dx, sum dx * x) -- what dm_bn_backward_finalize
+ *          of the layer below needs
+ *   wslabs the same number of slabs of CD*CX floats: partial dW[co][ci] = sum dy[co] * t[ci]; dm_reduce_slabs(_multi) adds them
+ * Built for 32 -> 16 channels (num_residual_hiddens 32, num_hiddens 16) on grids of a multiple of 256 positions
+ * (dm_conv1x1_bwd_fused_supported); other shapes: dm_conv3x3 (taps = 1) + dm_wgrad. */
+int dm_conv1x1_bwd_fused_supported(int CD, int CX, int H, int W);
+int dm_conv1x1_bwd_fused_num_blocks(int B, int CD, int CX, int H, int W);
+int dm_conv1x1_bwd_fused(const dm_operand *dy, const float *x, const float *xcoef, const float *w, float *dx,
+                         double *stats, float *wslabs, int B, int CD, int CX, int H, int W, void *stream);
 
 /* ===== BatchNorm2d in training mode (vq_vae.py:206,209,279-288) =============== */
 

@@ -696,6 +696,55 @@ def test_wide_wgrad_random_shapes(ops, B, cs, ct, k, hs, ws, smode, tmode, seed)
 
 
 # =============================================================================== wgrad
+@pytest.mark.parametrize("B,H,W,two", [(3, 16, 16, True), (70, 16, 16, True), (5, 32, 32, True), (2, 16, 16, False), (513, 16, 16, True)])
+def test_conv1x1_backward_fused_equals_the_two_kernels(ops, B, H, W, two):
+    """dm_conv1x1_bwd_fused (data + weight gradient of the ResidualBlock's 1x1 convolution from one staging) against
+    dm_conv3x3(taps = 1, mask, stat_q) + dm_wgrad and against a float64 restatement of both."""
+    CD, CX = 16, 32
+    g = torch.Generator().manual_seed(B * 7 + H)
+    gy, y = torch.randn(B, CD, H, W, generator=g), torch.randn(B, CD, H, W, generator=g)
+    x = torch.randn(B, CX, H, W, generator=g)
+    w = torch.randn(CD, CX, 1, 1, generator=g) * 0.2
+    cd = torch.randn(CD, 4, generator=g) * 0.5
+    cx = torch.zeros(CX, 4)
+    cx[:, 0] = torch.rand(CX, generator=g) + 0.5
+    cx[:, 2] = torch.randn(CX, generator=g) * 0.3
+    d = lambda t: t.to(DEV)
+    dy_op = ops.Op(d(gy), 4, d(cd), p1=d(y)) if two else ops.Op(d(gy))
+    dst = torch.zeros(CD, CX, 1, 1, device=DEV)
+    dx, st = ops.conv1x1_bwd_fused(dy_op, d(x), d(cx), d(w), dst, B, CD, CX, H, W)
+    # the two kernels it replaces
+    dst2 = torch.zeros(CD, CX, 1, 1, device=DEV)
+    ops.wgrad(dy_op, ops.Op(d(x), 3, d(cx)), dst2, B, CD, CX, H, W, 1)
+    dx2, st2 = ops.conv3x3(dy_op, ops.weight_view(d(w), 1, CX, 0, 0), B, CD, CX, H, W, taps=1, want_stats=True,
+                           like=d(gy), mask=ops.Op(d(x), 2, d(cx)), stat_q=d(x))
+    # float64 truth
+    da = (cd[:, 0].view(1, CD, 1, 1).double() * gy.double() + cd[:, 1].view(1, CD, 1, 1).double() * y.double()
+          + cd[:, 2].view(1, CD, 1, 1).double()) if two else gy.double()
+    t = cx[:, 0].view(1, CX, 1, 1).double() * x.double() + cx[:, 2].view(1, CX, 1, 1).double()
+    dx_ref = torch.einsum("oc,bohw->bchw", w[:, :, 0, 0].double(), da) * (t > 0)
+    dw_ref = torch.einsum("bohw,bchw->oc", da, t.clamp(min=0))
+    tol = 2e-6 * float(dx_ref.abs().max())
+    near = t.abs() < 1e-5                                                # (a fp32 / fp64 disagreement about the sign of t)
+    assert float(((dx.cpu().double() - dx_ref).abs() * ~near).max()) <= tol
+    assert float(((dx.cpu().double() - dx2.cpu().double()).abs()).max()) <= tol
+    close(dst.cpu().reshape(CD, CX), dw_ref.float(), 1e-5, 2e-5 * float(dw_ref.abs().max()), "weight gradient vs float64")
+    close(dst, dst2, 1e-5, 2e-5 * float(dw_ref.abs().max()), "weight gradient vs dm_wgrad")
+    s_f = st.sum(0).cpu()
+    s_2 = st2.sum(0).cpu()
+    assert st.shape[1:] == (CX, 2)
+    close(s_f, s_2, 1e-9, 1e-9 * float(s_2.abs().max()) + 1e-6, "statistics slabs")
+    want1 = (dx.cpu().double()).sum((0, 2, 3))
+    want2 = (dx.cpu().double() * x.double()).sum((0, 2, 3))
+    close(s_f[:, 0], want1, 1e-6, 1e-6 * float(want1.abs().max()) + 1e-6, "sum dx")
+    close(s_f[:, 1], want2, 1e-6, 1e-6 * float(want2.abs().max()) + 1e-6, "sum dx * x")
+    # bit-reproducible (no float atomics: slabs in slab order, waves in wave order)
+    dst3 = torch.zeros(CD, CX, 1, 1, device=DEV)
+    dx3, st3 = ops.conv1x1_bwd_fused(dy_op, d(x), d(cx), d(w), dst3, B, CD, CX, H, W)
+    assert torch.equal(dx3, dx) and torch.equal(st3, st) and torch.equal(dst3, dst)
+    assert not ops.conv1x1_bwd_fused_supported(CD, CX, 8, 8) and not ops.conv1x1_bwd_fused_supported(64, 64, 16, 16)
+
+
 @pytest.mark.parametrize("cs,ct,k,hs,ones,B", [
     (8, 3, 4, 64, True, 3), (16, 8, 4, 32, False, 3), (16, 16, 4, 16, False, 5), (16, 16, 3, 16, False, 5),
     (32, 16, 3, 16, False, 5), (16, 32, 1, 16, False, 5), (16, 8, 4, 16, False, 5), (8, 4, 4, 32, False, 3),
