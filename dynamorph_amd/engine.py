@@ -457,15 +457,26 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
         g2, st = ops.conv4x4s2(Op(g4), weight_view(_w(L.dec4.weight), c2 * 16, 16, 4, 1), B, c2, c2, 8 * H3, 8 * W3,
                                want_stats=True, mask=Op(cx.d2))
         ops.pend_stats(pending, st, [G(L.dec2.bias)])
-    ops.wgrad(Op(cx.d0), Op(g2), G(L.dec2.weight), B, c1, c2, 2 * H3, 2 * W3, 4, pending=pending)
-    g0, st = ops.conv4x4s2(Op(g2), weight_view(_w(L.dec2.weight), c2 * 16, 16, 4, 1), B, c2, c1, 4 * H3, 4 * W3,
-                           want_stats=True, mask=Op(cx.d0))
+    g2 = g2.contiguous()
+    if FUSED_BACKWARD and ops.convT_bwd_fused_supported(c1, c2, 2 * H3, 2 * W3):
+        # dec.2: input and weight gradient from ONE staging of (d0, g2) -- csrc/convT_bwd.hip
+        g0, st = ops.convT_bwd_fused(cx.d0, g2, _w(L.dec2.weight), G(L.dec2.weight), mask_relu=True, want_stats=True,
+                                     pending=pending)
+    else:
+        ops.wgrad(Op(cx.d0), Op(g2), G(L.dec2.weight), B, c1, c2, 2 * H3, 2 * W3, 4, pending=pending)
+        g0, st = ops.conv4x4s2(Op(g2), weight_view(_w(L.dec2.weight), c2 * 16, 16, 4, 1), B, c2, c1, 4 * H3, 4 * W3,
+                               want_stats=True, mask=Op(cx.d0))
     ops.pend_stats(pending, st, [G(L.dec0.bias)])         # bias gradients ride in the one slab reduction below
-    ops.wgrad(Op(zq), Op(g0), G(L.dec0.weight), B, nh, c1, H3, W3, 4, pending=pending)
+    g_zq = None
+    if want_gz and FUSED_BACKWARD and ops.convT_bwd_fused_supported(nh, c1, H3, W3):
+        g_zq, _ = ops.convT_bwd_fused(zq.contiguous(), g0, _w(L.dec0.weight), G(L.dec0.weight), pending=pending)     # dec.0 likewise
+    else:
+        ops.wgrad(Op(zq), Op(g0), G(L.dec0.weight), B, nh, c1, H3, W3, 4, pending=pending)
     ops.reduce_slabs_multi(pending)                  # all decoder weight gradients in one launch
     if not want_gz:
         return None
-    g_zq, _ = ops.conv4x4s2(Op(g0), weight_view(_w(L.dec0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H3, 2 * W3)
+    if g_zq is None:
+        g_zq, _ = ops.conv4x4s2(Op(g0), weight_view(_w(L.dec0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H3, 2 * W3)
     return g_zq
 
 

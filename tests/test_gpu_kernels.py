@@ -745,6 +745,46 @@ def test_conv1x1_backward_fused_equals_the_two_kernels(ops, B, H, W, two):
     assert not ops.conv1x1_bwd_fused_supported(CD, CX, 8, 8) and not ops.conv1x1_bwd_fused_supported(64, 64, 16, 16)
 
 
+@pytest.mark.parametrize("B,CI,CO,H,W,mask", [(3, 8, 4, 32, 32, True), (70, 8, 4, 32, 32, True), (2, 8, 4, 64, 64, True),
+                                             (5, 16, 8, 16, 16, False), (130, 16, 8, 16, 16, False), (2, 16, 8, 32, 32, False),
+                                             (2, 16, 8, 8, 48, True)])
+def test_conv_transpose_backward_fused_equals_the_two_kernels(ops, B, CI, CO, H, W, mask):
+    """dm_convT_bwd_fused (input + weight gradient of dec.0 / dec.2 from one staging) against dm_conv4x4s2 + dm_wgrad and
+    against autograd's conv_transpose2d backward in float64."""
+    g = torch.Generator().manual_seed(B + CI + H)
+    S = torch.randn(B, CI, H, W, generator=g)
+    if mask:
+        S = S.clamp(min=0)                                   # the forward stored relu(.)
+    G = torch.randn(B, CO, 2 * H, 2 * W, generator=g)
+    w = torch.randn(CI, CO, 4, 4, generator=g) * 0.2
+    d = lambda t: t.to(DEV)
+    dst = torch.zeros(CI, CO, 4, 4, device=DEV)
+    gin, st = ops.convT_bwd_fused(d(S), d(G), d(w), dst, mask_relu=mask, want_stats=True)
+    # float64 truth through autograd
+    S64, w64 = S.double().requires_grad_(True), w.double().requires_grad_(True)
+    out = F.conv_transpose2d(S64, w64, stride=2, padding=1)
+    out.backward(G.double())
+    gin_ref = S64.grad * (S.double() > 0) if mask else S64.grad
+    assert float((gin.cpu().double() - gin_ref).abs().max()) <= 3e-6 * float(gin_ref.abs().max())
+    close(dst, w64.grad.float(), 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs float64")
+    close(st.sum(0)[:, 0].cpu(), gin.cpu().double().sum((0, 2, 3)), 1e-6, 1e-6 * float(gin_ref.abs().sum((0, 2, 3)).max()), "channel sums")
+    # the two kernels it replaces
+    dst2 = torch.zeros(CI, CO, 4, 4, device=DEV)
+    ops.wgrad(ops.Op(d(S)), ops.Op(d(G)), dst2, B, CI, CO, H, W, 4)
+    gin2, st2 = ops.conv4x4s2(ops.Op(d(G)), ops.weight_view(d(w), CO * 16, 16, 4, 1), B, CO, CI, 2 * H, 2 * W, want_stats=True,
+                              **({"mask": ops.Op(d(S))} if mask else {}))
+    assert float((gin - gin2).abs().max()) <= 3e-6 * float(gin_ref.abs().max())
+    close(dst, dst2, 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs dm_wgrad")
+    close(st.sum(0)[:, 0], st2.sum(0)[:, 0], 1e-9, 1e-7 * float(gin_ref.abs().sum((0, 2, 3)).max()), "channel sums vs dm_conv4x4s2")
+    # bit-reproducible
+    dst3 = torch.zeros(CI, CO, 4, 4, device=DEV)
+    gin3, st3 = ops.convT_bwd_fused(d(S), d(G), d(w), dst3, mask_relu=mask, want_stats=True)
+    assert torch.equal(gin3, gin) and torch.equal(dst3, dst) and torch.equal(st3, st)
+    gin4, st4 = ops.convT_bwd_fused(d(S), d(G), d(w), dst3, mask_relu=mask)          # without the sums
+    assert st4 is None and torch.equal(gin4, gin)
+    assert not ops.convT_bwd_fused_supported(8, 4, 32, 16) and not ops.convT_bwd_fused_supported(4, 4, 64, 64)
+
+
 @pytest.mark.parametrize("cs,ct,k,hs,ones,B", [
     (8, 3, 4, 64, True, 3), (16, 8, 4, 32, False, 3), (16, 16, 4, 16, False, 5), (16, 16, 3, 16, False, 5),
     (32, 16, 3, 16, False, 5), (16, 32, 1, 16, False, 5), (16, 8, 4, 16, False, 5), (8, 4, 4, 32, False, 3),
