@@ -62,6 +62,7 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_convT_bwd_fused_supported(8, 4, 32, 32) == 1 and lib.dm_convT_bwd_fused_supported(16, 8, 16, 16) == 1
     assert lib.dm_convT_bwd_fused_supported(8, 4, 32, 16) == 0 and lib.dm_convT_bwd_fused_supported(4, 4, 64, 64) == 0
     assert lib.dm_convT_bwd_fused_num_blocks(2048, 8, 4, 32, 32) == 768 and lib.dm_convT_bwd_fused_num_blocks(2, 16, 8, 16, 16) == 4
+    assert lib.dm_convT_bwd_fused_num_blocks(2048, 16, 8, 16, 16) == 512
     assert lib.dm_conv1x1_bwd_fused_supported(16, 32, 16, 16) == 1 and lib.dm_conv1x1_bwd_fused_supported(16, 32, 8, 8) == 0
     assert lib.dm_conv1x1_bwd_fused_supported(64, 64, 16, 16) == 0 and lib.dm_conv1x1_bwd_fused_num_blocks(2048, 16, 32, 16, 16) == 512
     assert lib.dm_conv1x1_bwd_fused_num_blocks(3, 16, 32, 32, 32) == 12
