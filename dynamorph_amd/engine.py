@@ -271,11 +271,16 @@ def residual_backward(res_layers, saved, g_h, G, q_below, pending=None, zero_fed
                                     like=g_h, mask=Op(s.ra, DM_LOAD_AFFINE, s.coefa), stat_q=s.ra)
         ca_bwd = ops.bn_backward_finalize(st, cnt, _w(bna.weight), s.saveda, G(bna.weight), G(bna.bias))
         da_ra = Op(dy_ra, DM_LOAD_AFFINE2, ca_bwd, p1=s.ra)
-        ops.wgrad(da_ra, Op(s.h_in, DM_LOAD_RELU), G(ca.weight), B, nrh, nh, H, W, 3, pending=pending)
         _zero(G(ca.bias), zero_fed_biases)
         q = saved[i - 1].rb if i > 0 else q_below
-        g_h, stats = ops.conv3x3(da_ra, weight_view(_w(ca.weight), 9, nh * 9, -3, -1, off=8), B, nrh, nh, H, W, taps=9,
-                                 want_stats=q is not None, like=g_h, mask=Op(s.h_in), resid=g_h, stat_q=q)
+        if FUSED_BACKWARD and ops.conv3x3_bwd_fused_supported(nrh, nh, H, W):
+            # the 3x3 convolution's data and weight gradient from ONE staging of the patch -- csrc/conv3x3_bwd.hip
+            g_h, stats = ops.conv3x3_bwd_fused(da_ra, s.h_in, None, _w(ca.weight), G(ca.weight), B, nrh, resid=g_h, q=q,
+                                               want_stats=q is not None, pending=pending)
+        else:
+            ops.wgrad(da_ra, Op(s.h_in, DM_LOAD_RELU), G(ca.weight), B, nrh, nh, H, W, 3, pending=pending)
+            g_h, stats = ops.conv3x3(da_ra, weight_view(_w(ca.weight), 9, nh * 9, -3, -1, off=8), B, nrh, nh, H, W, taps=9,
+                                     want_stats=q is not None, like=g_h, mask=Op(s.h_in), resid=g_h, stat_q=q)
     return g_h, stats
 
 
@@ -297,10 +302,15 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
     cnt3 = B * H3 * W3
     c4b = ops.bn_backward_finalize(stats, cnt3, _w(L.bn4.weight), cx.saved4, G(L.bn4.weight), G(L.bn4.bias))
     da4 = Op(g_h, DM_LOAD_AFFINE2, c4b, p1=cx.a4)
-    ops.wgrad(da4, Op(cx.a3, DM_LOAD_AFFINE_RELU, cx.coef3), G(L.enc10.weight), B, nh, nh, H3, W3, 3, pending=pending)
     _zero(G(L.enc10.bias), zero_fed_biases)
-    dy3, st = ops.conv3x3(da4, weight_view(_w(L.enc10.weight), 9, nh * 9, -3, -1, off=8), B, nh, nh, H3, W3, taps=9,
-                          want_stats=True, like=g_h, mask=Op(cx.a3, DM_LOAD_AFFINE, cx.coef3), stat_q=cx.a3)
+    if FUSED_BACKWARD and cx.coef3.dim() == 2 and ops.conv3x3_bwd_fused_supported(nh, nh, H3, W3):
+        # enc.10: data and weight gradient from ONE staging of the patch -- csrc/conv3x3_bwd.hip
+        dy3, st = ops.conv3x3_bwd_fused(da4, cx.a3, cx.coef3, _w(L.enc10.weight), G(L.enc10.weight), B, nh, q=cx.a3,
+                                        pending=pending)
+    else:
+        ops.wgrad(da4, Op(cx.a3, DM_LOAD_AFFINE_RELU, cx.coef3), G(L.enc10.weight), B, nh, nh, H3, W3, 3, pending=pending)
+        dy3, st = ops.conv3x3(da4, weight_view(_w(L.enc10.weight), 9, nh * 9, -3, -1, off=8), B, nh, nh, H3, W3, taps=9,
+                              want_stats=True, like=g_h, mask=Op(cx.a3, DM_LOAD_AFFINE, cx.coef3), stat_q=cx.a3)
 
     c3b = ops.bn_backward_finalize(st, cnt3, _w(L.bn3.weight), cx.saved3, G(L.bn3.weight), G(L.bn3.bias))
     da3 = Op(dy3, DM_LOAD_AFFINE2, c3b, p1=cx.a3)

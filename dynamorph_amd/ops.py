@@ -401,6 +401,35 @@ def conv1x1_bwd_fused(dy, x, xcoef, w, dst, B, CD, CX, H, W, pending=None):
     return dx, stats
 
 
+def conv3x3_bwd_fused_supported(CD, CX, H, W):
+    return bool(L.load().dm_conv3x3_bwd_fused_supported(CD, CX, H, W))
+
+
+@_op
+def conv3x3_bwd_fused(dy, x, xcoef, w, dst, B, CD, resid=None, q=None, want_stats=True, pending=None):
+    """Data AND weight gradient of a 3x3 convolution (16 -> CD channels, 16 x 16 latents) that feeds a train-mode BatchNorm,
+    one launch (include/dynamorph_hip.h, dm_conv3x3_bwd_fused).  dy: Op of the output gradient; x: the layer input raw,
+    xcoef (16, 4) its BatchNorm + ReLU coefficients (None: plain ReLU); resid: added to dx; q: second factor of the statistics.
+    Returns (dx, stats (nslabs, 16, 2) or None); the weight slabs are reduced into dst here, or queued on `pending`."""
+    lib = L.load()
+    CX, H, W = x.shape[1], x.shape[2], x.shape[3]
+    nb = lib.dm_conv3x3_bwd_fused_num_blocks(B, CD, CX, H, W)
+    if nb <= 0:
+        raise ValueError(f"dm_conv3x3_bwd_fused: shape {CX} -> {CD} channels on {H}x{W} not built")
+    dx = torch.empty_like(x)
+    stats = _new((nb, CX, 2), x, torch.float64) if want_stats else None
+    slabs = _new((nb, CD * CX * 9), x)
+    d = dy.struct()
+    L.check(lib.dm_conv3x3_bwd_fused(C.byref(d), _ptr(x), _ptr(xcoef), _ptr(w), _ptr(resid), _ptr(q), _ptr(dx),
+                                     _ptr(stats, torch.float64), _ptr(slabs), B, CD, CX, H, W, _stream()),
+            "dm_conv3x3_bwd_fused")
+    if pending is not None:
+        pending.append((slabs, dst))
+    else:
+        reduce_slabs(slabs, dst)
+    return dx, stats
+
+
 def convT_bwd_fused_supported(CI, CO, H, W):
     return bool(L.load().dm_convT_bwd_fused_supported(CI, CO, H, W))
 

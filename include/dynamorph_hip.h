@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 119
+#define DM_VERSION 120
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -270,6 +270,25 @@ int dm_conv1x1_bwd_fused_supported(int CD, int CX, int H, int W);
 int dm_conv1x1_bwd_fused_num_blocks(int B, int CD, int CX, int H, int W);
 int dm_conv1x1_bwd_fused(const dm_operand *dy, const float *x, const float *xcoef, const float *w, float *dx,
                          double *stats, float *wslabs, int B, int CD, int CX, int H, int W, void *stream);
+
+/* Backward of a 3x3 convolution (padding 1) on a 16 x 16 latent grid whose output feeds a train-mode BatchNorm (enc.10 and
+ * the first convolution of a ResidualBlock layer, vq_vae.py:287, 205): aten::convolution_backward for input AND weight from
+ * ONE staging of a whole patch,
+ *   dy     the output gradient as an operand (AFFINE2: BatchNorm's backward folded into the load; or IDENT), CD channels
+ *   x      the layer input RAW (16 channels); xcoef [16][4] = (c0, -, c2, -): the forward saw t = relu(c0 x + c2); NULL: relu(x)
+ *   w      [CD][16][3][3] (the Conv2d weight)
+ *   resid  NULL or [B][16][16][16], added to dx after the mask (the residual join's other branch)
+ *   q      NULL or [B][16][16][16]: second factor of the statistics (the raw output of the convolution below)
+ *   dx     [B][16][16][16] out = (t > 0) * sum_{co,ky,kx} dy[co][y+1-ky][x+1-kx] w[co][ci][ky][kx]  (+ resid)
+ *   stats  NULL or dm_conv3x3_bwd_fused_num_blocks slabs of [16][2] doubles: (sum dx, sum dx * q)   (q NULL: sum dx^2)
+ *   wslabs the same number of slabs of CD*144 floats: partial dW; dm_reduce_slabs(_multi) adds them
+ * Built for CD = 16 or 32 output channels, 16 input channels, H = W = 16 (dm_conv3x3_bwd_fused_supported); other shapes:
+ * dm_conv3x3 + dm_wgrad. */
+int dm_conv3x3_bwd_fused_supported(int CD, int CX, int H, int W);
+int dm_conv3x3_bwd_fused_num_blocks(int B, int CD, int CX, int H, int W);
+int dm_conv3x3_bwd_fused(const dm_operand *dy, const float *x, const float *xcoef, const float *w, const float *resid,
+                         const float *q, float *dx, double *stats, float *wslabs, int B, int CD, int CX, int H, int W,
+                         void *stream);
 
 /* Backward of a thin ConvTranspose2d(CI -> CO, 4, stride 2, padding 1) (dec.0, dec.2: vq_vae.py:291-296):
  * aten::convolution_backward for input AND weight from ONE staging of

@@ -745,6 +745,67 @@ def test_conv1x1_backward_fused_equals_the_two_kernels(ops, B, H, W, two):
     assert not ops.conv1x1_bwd_fused_supported(CD, CX, 8, 8) and not ops.conv1x1_bwd_fused_supported(64, 64, 16, 16)
 
 
+@pytest.mark.parametrize("B,CD,form", [(3, 16, "enc10"), (70, 16, "enc10"), (5, 32, "res"), (300, 32, "res"), (4, 32, "res_noq"),
+                                       (2, 16, "ident")])
+def test_conv3x3_backward_fused_equals_the_two_kernels(ops, B, CD, form):
+    """dm_conv3x3_bwd_fused (data + weight gradient of enc.10 / the ResidualBlock's 3x3 convolution from one staging of the
+    patch) against dm_conv3x3 + dm_wgrad and against autograd's conv2d backward in float64."""
+    CX, H = 16, 16
+    g = torch.Generator().manual_seed(B * 3 + CD)
+    gy, y = torch.randn(B, CD, H, H, generator=g), torch.randn(B, CD, H, H, generator=g)
+    x = torch.randn(B, CX, H, H, generator=g)
+    w = torch.randn(CD, CX, 3, 3, generator=g) * 0.2
+    cd = torch.randn(CD, 4, generator=g) * 0.5
+    d = lambda t: t.to(DEV)
+    two = form != "ident"
+    dy_op = ops.Op(d(gy), 4, d(cd), p1=d(y)) if two else ops.Op(d(gy))
+    da = (cd[:, 0].view(1, CD, 1, 1).double() * gy.double() + cd[:, 1].view(1, CD, 1, 1).double() * y.double()
+          + cd[:, 2].view(1, CD, 1, 1).double()) if two else gy.double()
+    if form in ("enc10", "ident"):
+        cx = torch.zeros(CX, 4)
+        cx[:, 0] = torch.rand(CX, generator=g) + 0.5
+        cx[:, 2] = torch.randn(CX, generator=g) * 0.3
+        xcoef, resid, q = d(cx), None, d(x)
+        t = cx[:, 0].view(1, CX, 1, 1).double() * x.double() + cx[:, 2].view(1, CX, 1, 1).double()
+        T_op, mask_op = ops.Op(d(x), 3, d(cx)), ops.Op(d(x), 2, d(cx))
+    else:
+        xcoef, t = None, x.double()
+        resid = d(torch.randn(B, CX, H, H, generator=g))
+        q = d(torch.randn(B, CX, H, H, generator=g)) if form == "res" else None
+        T_op, mask_op = ops.Op(d(x), 1), ops.Op(d(x))
+    dst = torch.zeros(CD, CX, 3, 3, device=DEV)
+    dx, st = ops.conv3x3_bwd_fused(dy_op, d(x), xcoef, d(w), dst, B, CD, resid=resid, q=q, want_stats=form != "res_noq")
+    # float64 truth through autograd
+    t_in = t.clamp(min=0).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    F.conv2d(t_in, w64, padding=1).backward(da)
+    dx_ref = t_in.grad * (t > 0) + (resid.cpu().double() if resid is not None else 0.0)
+    near = t.abs() < 1e-5
+    scale = float(dx_ref.abs().max())
+    assert float(((dx.cpu().double() - dx_ref).abs() * ~near).max()) <= 3e-6 * scale
+    close(dst, w64.grad.float(), 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs float64")
+    # the two kernels it replaces
+    dst2 = torch.zeros(CD, CX, 3, 3, device=DEV)
+    ops.wgrad(dy_op, T_op, dst2, B, CD, CX, H, H, 3)
+    dx2, st2 = ops.conv3x3(dy_op, ops.weight_view(d(w), 9, CX * 9, -3, -1, off=8), B, CD, CX, H, H, taps=9,
+                           want_stats=form != "res_noq", like=d(gy), mask=mask_op, resid=resid, stat_q=q)
+    assert float((dx - dx2).abs().max()) <= 3e-6 * scale
+    close(dst, dst2, 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs dm_wgrad")
+    if form == "res_noq":
+        assert st is None
+    else:
+        qq = q.cpu().double()
+        want1, want2 = dx.cpu().double().sum((0, 2, 3)), (dx.cpu().double() * qq).sum((0, 2, 3))
+        close(st.sum(0)[:, 0].cpu(), want1, 1e-6, 1e-6 * float(dx_ref.abs().sum((0, 2, 3)).max()), "sum dx")
+        close(st.sum(0)[:, 1].cpu(), want2, 1e-6, 1e-6 * float((dx_ref.abs() * qq.abs()).sum((0, 2, 3)).max()), "sum dx * q")
+        close(st.sum(0), st2.sum(0), 1e-9, 1e-6 * float(dx_ref.abs().sum((0, 2, 3)).max()), "statistics vs dm_conv3x3")
+    # bit-reproducible
+    dst3 = torch.zeros(CD, CX, 3, 3, device=DEV)
+    dx3, st3 = ops.conv3x3_bwd_fused(dy_op, d(x), xcoef, d(w), dst3, B, CD, resid=resid, q=q, want_stats=form != "res_noq")
+    assert torch.equal(dx3, dx) and torch.equal(dst3, dst) and (st is None or torch.equal(st3, st))
+    assert not ops.conv3x3_bwd_fused_supported(32, 16, 32, 32) and not ops.conv3x3_bwd_fused_supported(64, 64, 16, 16)
+
+
 @pytest.mark.parametrize("B,CI,CO,H,W,mask", [(3, 8, 4, 32, 32, True), (70, 8, 4, 32, 32, True), (2, 8, 4, 64, 64, True),
                                              (5, 16, 8, 16, 16, False), (130, 16, 8, 16, 16, False), (2, 16, 8, 32, 32, False),
                                              (2, 16, 8, 8, 48, True)])
