@@ -145,12 +145,16 @@ void conv3x3_bwd_kernel(Operand dy, const float *__restrict__ x, const float *__
         const long long ob = (long long)b * CX * HW;
 #pragma unroll
         for (int rr = 0; rr < RPW; rr += 2) {
-            f32x4 acc[2];
+            f32x4 acc[2], rres[2], rq[2];
             const float *pa[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 pa[j] = sD + kq * PS + (wave + NW * (rr + j) + 2) * RS + m + 5;
+                // the epilogue's side inputs are requested now: their latency passes under the products
+                const long long o = ob + (long long)m * HW + (wave + NW * (rr + j)) * C3_HW + 4 * kq;
+                if (resid) rres[j] = *reinterpret_cast<const f32x4 *>(resid + o);
+                if (stats && q) rq[j] = *reinterpret_cast<const f32x4 *>(q + o);
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -169,10 +173,10 @@ void conv3x3_bwd_kernel(Operand dy, const float *__restrict__ x, const float *__
                 v.x = tv.x > 0.f ? v.x : 0.f; v.y = tv.y > 0.f ? v.y : 0.f;
                 v.z = tv.z > 0.f ? v.z : 0.f; v.w = tv.w > 0.f ? v.w : 0.f;
                 const long long o = ob + (long long)m * HW + y * C3_HW + 4 * kq;
-                if (resid) v += *reinterpret_cast<const f32x4 *>(resid + o);
+                if (resid) v += rres[j];
                 *reinterpret_cast<f32x4 *>(dx + o) = v;
                 if (stats) {
-                    const f32x4 qv = q ? *reinterpret_cast<const f32x4 *>(q + o) : v;
+                    const f32x4 qv = q ? rq[j] : v;
                     s1 += (double)((v.x + v.y) + (v.z + v.w));
                     s2 += (double)((v.x * qv.x + v.y * qv.y) + (v.z * qv.z + v.w * qv.w));
                 }

@@ -314,11 +314,15 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
 
     c3b = ops.bn_backward_finalize(st, cnt3, _w(L.bn3.weight), cx.saved3, G(L.bn3.weight), G(L.bn3.bias))
     da3 = Op(dy3, DM_LOAD_AFFINE2, c3b, p1=cx.a3)
-    ops.wgrad(da3, Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), G(L.enc7.weight), B, nh, nh, H3, W3, 4, pending=pending)
     _zero(G(L.enc7.bias), zero_fed_biases)
-    dy2, st = ops.conv3x3(da3, weight_view(_w(L.enc7.weight), 16, nh * 16, 4, 1), B, nh, 4 * nh, H3, W3, taps=9,
-                          pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a2, DM_LOAD_AFFINE, cx.coef2),
-                          stat_q=cx.a2)
+    if FUSED_BACKWARD and cx.coef2.dim() == 2 and ops.conv4x4s2_bwd_fused_supported(nh, nh, H3, W3):
+        # enc.7: data and weight gradient from ONE staging of the patch -- csrc/conv4x4s2_bwd.hip
+        dy2, st = ops.conv4x4s2_bwd_fused(da3, cx.a2, cx.coef2, _w(L.enc7.weight), G(L.enc7.weight), B, pending=pending)
+    else:
+        ops.wgrad(da3, Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), G(L.enc7.weight), B, nh, nh, H3, W3, 4, pending=pending)
+        dy2, st = ops.conv3x3(da3, weight_view(_w(L.enc7.weight), 16, nh * 16, 4, 1), B, nh, 4 * nh, H3, W3, taps=9,
+                              pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a2, DM_LOAD_AFFINE, cx.coef2),
+                              stat_q=cx.a2)
 
     c2b = ops.bn_backward_finalize(st, B * H2 * W2, _w(L.bn2.weight), cx.saved2, G(L.bn2.weight), G(L.bn2.bias))
     da2 = Op(dy2, DM_LOAD_AFFINE2, c2b, p1=cx.a2)

@@ -430,6 +430,34 @@ def conv3x3_bwd_fused(dy, x, xcoef, w, dst, B, CD, resid=None, q=None, want_stat
     return dx, stats
 
 
+def conv4x4s2_bwd_fused_supported(CD, CX, H, W):
+    return bool(L.load().dm_conv4x4s2_bwd_fused_supported(CD, CX, H, W))
+
+
+@_op
+def conv4x4s2_bwd_fused(dy, x, xcoef, w, dst, B, pending=None):
+    """Data AND weight gradient of Conv2d(16 -> 16, 4, 2, 1) (enc.7) that feeds a train-mode BatchNorm, one launch
+    (include/dynamorph_hip.h, dm_conv4x4s2_bwd_fused).  dy: Op of the output gradient (B, 16, 16, 16); x (B, 16, 32, 32): the
+    layer input raw, xcoef (16, 4) its BatchNorm + ReLU coefficients.  Returns (dx, stats (nslabs, 16, 2))."""
+    lib = L.load()
+    CX, CD = x.shape[1], w.shape[0]
+    H, W = x.shape[2] // 2, x.shape[3] // 2
+    nb = lib.dm_conv4x4s2_bwd_fused_num_blocks(B, CD, CX, H, W)
+    if nb <= 0:
+        raise ValueError(f"dm_conv4x4s2_bwd_fused: shape {CX} -> {CD} channels, {H}x{W} output grid not built")
+    dx = torch.empty_like(x)
+    stats = _new((nb, CX, 2), x, torch.float64)
+    slabs = _new((nb, CD * CX * 16), x)
+    d = dy.struct()
+    L.check(lib.dm_conv4x4s2_bwd_fused(C.byref(d), _ptr(x), _ptr(xcoef), _ptr(w), _ptr(dx), _ptr(stats, torch.float64),
+                                       _ptr(slabs), B, CD, CX, H, W, _stream()), "dm_conv4x4s2_bwd_fused")
+    if pending is not None:
+        pending.append((slabs, dst))
+    else:
+        reduce_slabs(slabs, dst)
+    return dx, stats
+
+
 def convT_bwd_fused_supported(CI, CO, H, W):
     return bool(L.load().dm_convT_bwd_fused_supported(CI, CO, H, W))
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 120
+#define DM_VERSION 121
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -289,6 +289,19 @@ int dm_conv3x3_bwd_fused_num_blocks(int B, int CD, int CX, int H, int W);
 int dm_conv3x3_bwd_fused(const dm_operand *dy, const float *x, const float *xcoef, const float *w, const float *resid,
                          const float *q, float *dx, double *stats, float *wslabs, int B, int CD, int CX, int H, int W,
                          void *stream);
+
+/* Backward of Conv2d(16 -> 16, 4, stride 2, padding 1) from a 32 x 32 to a 16 x 16 grid whose output feeds a train-mode
+ * BatchNorm (enc.7, vq_vae.py:284): aten::convolution_backward for input AND weight from ONE staging of a whole patch,
+ *   dy     the output gradient as an operand (AFFINE2 or IDENT), [B][16][16][16]
+ *   x      the layer input RAW [B][16][32][32]; xcoef [16][4] = (c0, -, c2, -): the forward saw t = relu(c0 x + c2)
+ *   w      [16][16][4][4];   dx [B][16][32][32] out = (t > 0) * (transposed convolution of dy with w)
+ *   stats  dm_conv4x4s2_bwd_fused_num_blocks slabs of [16][2] doubles: (sum dx, sum dx * x);  wslabs: as many slabs of 4096 floats
+ * H, W are the OUTPUT grid of the convolution (16, 16: dm_conv4x4s2_bwd_fused_supported); other shapes: dm_conv3x3
+ * (pixel shuffle) + dm_wgrad, or dm_conv_bwd_s2_fused for 8 -> 16 channels. */
+int dm_conv4x4s2_bwd_fused_supported(int CD, int CX, int H, int W);
+int dm_conv4x4s2_bwd_fused_num_blocks(int B, int CD, int CX, int H, int W);
+int dm_conv4x4s2_bwd_fused(const dm_operand *dy, const float *x, const float *xcoef, const float *w, float *dx, double *stats,
+                           float *wslabs, int B, int CD, int CX, int H, int W, void *stream);
 
 /* Backward of a thin ConvTranspose2d(CI -> CO, 4, stride 2, padding 1) (dec.0, dec.2: vq_vae.py:291-296):
  * aten::convolution_backward for input AND weight from ONE staging of

@@ -806,6 +806,50 @@ def test_conv3x3_backward_fused_equals_the_two_kernels(ops, B, CD, form):
     assert not ops.conv3x3_bwd_fused_supported(32, 16, 32, 32) and not ops.conv3x3_bwd_fused_supported(64, 64, 16, 16)
 
 
+@pytest.mark.parametrize("B,two", [(3, True), (70, True), (300, True), (2, False)])
+def test_conv4x4s2_backward_fused_equals_the_two_kernels(ops, B, two):
+    """dm_conv4x4s2_bwd_fused (data + weight gradient of enc.7 from one staging of the patch) against dm_conv3x3 (pixel
+    shuffle) + dm_wgrad and against autograd's conv2d backward in float64."""
+    C, H = 16, 16
+    g = torch.Generator().manual_seed(B * 5 + 1)
+    gy, y = torch.randn(B, C, H, H, generator=g), torch.randn(B, C, H, H, generator=g)
+    x = torch.randn(B, C, 2 * H, 2 * H, generator=g)
+    w = torch.randn(C, C, 4, 4, generator=g) * 0.2
+    cd = torch.randn(C, 4, generator=g) * 0.5
+    cx = torch.zeros(C, 4)
+    cx[:, 0] = torch.rand(C, generator=g) + 0.5
+    cx[:, 2] = torch.randn(C, generator=g) * 0.3
+    d = lambda t: t.to(DEV)
+    dy_op = ops.Op(d(gy), 4, d(cd), p1=d(y)) if two else ops.Op(d(gy))
+    da = (cd[:, 0].view(1, C, 1, 1).double() * gy.double() + cd[:, 1].view(1, C, 1, 1).double() * y.double()
+          + cd[:, 2].view(1, C, 1, 1).double()) if two else gy.double()
+    t = cx[:, 0].view(1, C, 1, 1).double() * x.double() + cx[:, 2].view(1, C, 1, 1).double()
+    dst = torch.zeros(C, C, 4, 4, device=DEV)
+    dx, st = ops.conv4x4s2_bwd_fused(dy_op, d(x), d(cx), d(w), dst, B)
+    t_in = t.clamp(min=0).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    F.conv2d(t_in, w64, stride=2, padding=1).backward(da)
+    dx_ref = t_in.grad * (t > 0)
+    near = t.abs() < 1e-5
+    scale = float(dx_ref.abs().max())
+    assert float(((dx.cpu().double() - dx_ref).abs() * ~near).max()) <= 3e-6 * scale
+    close(dst, w64.grad.float(), 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs float64")
+    dst2 = torch.zeros(C, C, 4, 4, device=DEV)
+    ops.wgrad(dy_op, ops.Op(d(x), 3, d(cx)), dst2, B, C, C, H, H, 4)
+    dx2, st2 = ops.conv3x3(dy_op, ops.weight_view(d(w), 16, C * 16, 4, 1), B, C, 4 * C, H, H, taps=9, pixel_shuffle=True,
+                           want_stats=True, like=d(gy), mask=ops.Op(d(x), 2, d(cx)), stat_q=d(x))
+    assert float((dx - dx2).abs().max()) <= 3e-6 * scale
+    close(dst, dst2, 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs dm_wgrad")
+    want1, want2 = dx.cpu().double().sum((0, 2, 3)), (dx.cpu().double() * x.double()).sum((0, 2, 3))
+    close(st.sum(0)[:, 0].cpu(), want1, 1e-6, 1e-6 * float(dx_ref.abs().sum((0, 2, 3)).max()), "sum dx")
+    close(st.sum(0)[:, 1].cpu(), want2, 1e-6, 1e-6 * float((dx_ref.abs() * x.double().abs()).sum((0, 2, 3)).max()), "sum dx * x")
+    close(st.sum(0), st2.sum(0), 1e-9, 1e-6 * float(dx_ref.abs().sum((0, 2, 3)).max()), "statistics vs dm_conv3x3")
+    dst3 = torch.zeros(C, C, 4, 4, device=DEV)
+    dx3, st3 = ops.conv4x4s2_bwd_fused(dy_op, d(x), d(cx), d(w), dst3, B)
+    assert torch.equal(dx3, dx) and torch.equal(dst3, dst) and torch.equal(st3, st)
+    assert not ops.conv4x4s2_bwd_fused_supported(16, 8, 32, 32)
+
+
 @pytest.mark.parametrize("B,CI,CO,H,W,mask", [(3, 8, 4, 32, 32, True), (70, 8, 4, 32, 32, True), (2, 8, 4, 64, 64, True),
                                              (5, 16, 8, 16, 16, False), (130, 16, 8, 16, 16, False), (2, 16, 8, 32, 32, False),
                                              (2, 16, 8, 8, 48, True)])
