@@ -57,6 +57,28 @@ flg = torch.randint(0, 3, (B,), device=dev, dtype=torch.int32); rog = torch.rand
 outg = torch.empty(B, 2, 128, 128, device=dev)
 cases["gather_aug"] = (lambda: ops.gather_augment(srcg, idsg, flg, rog, outg), B * 2 * 131072)
 
+# the fused backward kernels of round 4 at the C3 shapes (one staging, data + weight gradient)
+gh, rbk2 = (torch.randn(B, 16, 16, 16, device=dev) for _ in range(2))
+rak = torch.randn(B, 32, 16, 16, device=dev)
+cdk, cxk32 = torch.randn(16, 4, device=dev) * 0.5, torch.rand(32, 4, device=dev) + 0.5
+w11 = torch.randn(16, 32, 1, 1, device=dev) * 0.2; g11 = torch.zeros_like(w11)
+cases["bwd_1x1"] = (lambda: ops.conv1x1_bwd_fused(Op(gh, 4, cdk, p1=rbk2), rak, cxk32, w11, g11, B, 16, 32, 16, 16),
+                    B * (2 * 16384 + 32768 + 32768))
+dyr, rar = (torch.randn(B, 32, 16, 16, device=dev) for _ in range(2))
+hin, res_, qq = (torch.randn(B, 16, 16, 16, device=dev) for _ in range(3))
+cd32 = torch.randn(32, 4, device=dev) * 0.5
+w33 = torch.randn(32, 16, 3, 3, device=dev) * 0.2; g33 = torch.zeros_like(w33)
+cases["bwd_3x3_res"] = (lambda: ops.conv3x3_bwd_fused(Op(dyr, 4, cd32, p1=rar), hin, None, w33, g33, B, 32, resid=res_, q=qq),
+                        B * (2 * 32768 + 4 * 16384))
+a2k = torch.randn(B, 16, 32, 32, device=dev); cx16 = torch.rand(16, 4, device=dev) + 0.5
+w44 = torch.randn(16, 16, 4, 4, device=dev) * 0.2; g44 = torch.zeros_like(w44)
+cases["bwd_4x4s2"] = (lambda: ops.conv4x4s2_bwd_fused(Op(gh, 4, cdk, p1=rbk2), a2k, cx16, w44, g44, B), B * (2 * 16384 + 2 * 65536))
+d0k = torch.randn(B, 8, 32, 32, device=dev).clamp(min=0); g2k = torch.randn(B, 4, 64, 64, device=dev)
+wT2 = torch.randn(8, 4, 4, 4, device=dev) * 0.2; gT2 = torch.zeros_like(wT2)
+cases["bwd_convT_dec2"] = (lambda: ops.convT_bwd_fused(d0k, g2k, wT2, gT2, mask_relu=True, want_stats=True), B * (65536 + 2 * 32768))
+g0k = torch.randn(B, 8, 32, 32, device=dev); wT0 = torch.randn(16, 8, 4, 4, device=dev) * 0.2; gT0 = torch.zeros_like(wT0)
+cases["bwd_convT_dec0"] = (lambda: ops.convT_bwd_fused(zq, g0k, wT0, gT0), B * (32768 + 2 * 16384))
+
 # stress shape of BASELINE configs[4]: 4096 codes, 32 x 32 latents of KB_B5 patches (bench.py --workload c5 default batch)
 B5 = int(os.environ.get("KB_B5", "1024"))
 zq5 = torch.randn(B5, 16, 32, 32, device=dev); cbk5 = torch.randn(4096, 16, device=dev)

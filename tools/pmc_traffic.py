@@ -21,7 +21,12 @@ KEYS = {                       # key in the JSON -> substring of the kernel name
     "conv4x4s2_e1": "conv4x4s2_kernel",
     "vq_forward_mfma": ("vq_forward_mfma_kernel<16, true", ", true>("),   # K = 64: the whole codebook in one LDS piece (not the JOIN form)
     "vq_forward_join": "vq_forward_mfma_kernel<16, true, 3, true, true, true>",   # ... with the last residual join in its load path
-    "gather_augment": "gather_augment_tiled_kernel",             # train()'s resident feed: gather + flip / rot90 of a batch
+    "gather_augment": "gather_augment_tiled_kernel",
+    "conv1x1_bwd": "conv1x1_bwd_kernel<16, 32>",                 # round 4: data + weight gradient from one staging
+    "conv3x3_bwd_res": "conv3x3_bwd_kernel<32, 512>",
+    "conv4x4s2_bwd": "conv4x4s2_bwd_kernel",
+    "convT_bwd_dec2": "convT_bwd_kernel<8, 4, 32>",
+    "convT_bwd_dec0": "convT_bwd_kernel<16, 8, 16>",             # train()'s resident feed: gather + flip / rot90 of a batch
     "vq_forward_mfma_k4096": "vq_forward_mfma_kernel<16, false",  # K = 4096 (KB_B5 patches): codebook walks through LDS
     "vq_backward_mfma": "vq_backward_mfma_kernel",
     "latent_tail": "latent_tail_kernel",
