@@ -89,9 +89,9 @@ SIGNATURES = {
     "dm_conv1x1_bwd_fused_supported": (C.c_int, [C.c_int] * 4),
     "dm_conv1x1_bwd_fused_num_blocks": (C.c_int, [C.c_int] * 5),
     "dm_conv1x1_bwd_fused": (C.c_int, [OP, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
-    "dm_convT_bwd_fused_supported": (C.c_int, [C.c_int] * 4),
-    "dm_convT_bwd_fused_num_blocks": (C.c_int, [C.c_int] * 5),
-    "dm_convT_bwd_fused": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "dm_convt_bwd_fused_supported": (C.c_int, [C.c_int] * 4),
+    "dm_convt_bwd_fused_num_blocks": (C.c_int, [C.c_int] * 5),
+    "dm_convt_bwd_fused": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "dm_conv3x3_bwd_fused_supported": (C.c_int, [C.c_int] * 4),
     "dm_conv3x3_bwd_fused_num_blocks": (C.c_int, [C.c_int] * 5),
     "dm_conv3x3_bwd_fused": (C.c_int, [OP, vp, vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),

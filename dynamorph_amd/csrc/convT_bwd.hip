@@ -262,9 +262,9 @@ bool convT_bwd_shape(int CI, int CO, int H, int W) { return H > 0 && W > 0 && H 
 
 }  // namespace
 
-extern "C" int dm_convT_bwd_fused_supported(int CI, int CO, int H, int W) { return convT_bwd_shape(CI, CO, H, W) ? 1 : 0; }
+extern "C" int dm_convt_bwd_fused_supported(int CI, int CO, int H, int W) { return convT_bwd_shape(CI, CO, H, W) ? 1 : 0; }
 
-extern "C" int dm_convT_bwd_fused_num_blocks(int B, int CI, int CO, int H, int W)
+extern "C" int dm_convt_bwd_fused_num_blocks(int B, int CI, int CO, int H, int W)
 {
     if (B <= 0 || !convT_bwd_shape(CI, CO, H, W)) return -1;
     const long long ntiles = (long long)B * (H / CT_TH) * (W / convT_bwd_tw(CI, CO, W));
@@ -272,14 +272,14 @@ extern "C" int dm_convT_bwd_fused_num_blocks(int B, int CI, int CO, int H, int W
     return (int)(ntiles < cap ? ntiles : cap);
 }
 
-extern "C" int dm_convT_bwd_fused(const float *S, const float *G, const float *w, float *gin, double *stats, float *wslabs,
+extern "C" int dm_convt_bwd_fused(const float *S, const float *G, const float *w, float *gin, double *stats, float *wslabs,
                                   int mask_relu, int B, int CI, int CO, int H, int W, void *stream)
 {
-    DM_REQUIRE(S && G && w && gin && wslabs, "dm_convT_bwd_fused: NULL pointer");
-    DM_REQUIRE(B > 0 && convT_bwd_shape(CI, CO, H, W), "dm_convT_bwd_fused: ConvTranspose2d(%d -> %d) on %dx%d not built", CI, CO, H, W);
-    DM_REQUIRE((long long)B * CO * 4 * H * W < (1LL << 31), "dm_convT_bwd_fused: tensor too large");
+    DM_REQUIRE(S && G && w && gin && wslabs, "dm_convt_bwd_fused: NULL pointer");
+    DM_REQUIRE(B > 0 && convT_bwd_shape(CI, CO, H, W), "dm_convt_bwd_fused: ConvTranspose2d(%d -> %d) on %dx%d not built", CI, CO, H, W);
+    DM_REQUIRE((long long)B * CO * 4 * H * W < (1LL << 31), "dm_convt_bwd_fused: tensor too large");
     const int ntiles = B * (H / CT_TH) * (W / convT_bwd_tw(CI, CO, W));
-    const int grid = dm_convT_bwd_fused_num_blocks(B, CI, CO, H, W);
+    const int grid = dm_convt_bwd_fused_num_blocks(B, CI, CO, H, W);
     hipStream_t st = (hipStream_t)stream;
 #define DM_CTB(CI_, CO_, TW_)                                                                                          \
     hipLaunchKernelGGL((convT_bwd_kernel<CI_, CO_, TW_>), dim3(grid), dim3(DM_BLOCK), 0, st, S, G, w, gin, stats, wslabs, \
@@ -287,5 +287,5 @@ extern "C" int dm_convT_bwd_fused(const float *S, const float *G, const float *w
     if (CI == 8) DM_CTB(8, 4, 32);
     else DM_CTB(16, 8, 16);
 #undef DM_CTB
-    return dm_launch_status("dm_convT_bwd_fused");
+    return dm_launch_status("dm_convt_bwd_fused");
 }

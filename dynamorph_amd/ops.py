@@ -459,28 +459,28 @@ def conv4x4s2_bwd_fused(dy, x, xcoef, w, dst, B, pending=None):
 
 
 def convT_bwd_fused_supported(CI, CO, H, W):
-    return bool(L.load().dm_convT_bwd_fused_supported(CI, CO, H, W))
+    return bool(L.load().dm_convt_bwd_fused_supported(CI, CO, H, W))
 
 
 @_op
 def convT_bwd_fused(S, G, w, dst, mask_relu=False, want_stats=False, pending=None):
     """Input AND weight gradient of a thin ConvTranspose2d(CI -> CO, 4, 2, 1), one launch (include/dynamorph_hip.h,
-    dm_convT_bwd_fused).  S (B, CI, H, W): the layer input; G (B, CO, 2H, 2W): the output gradient; w (CI, CO, 4, 4);
+    dm_convt_bwd_fused).  S (B, CI, H, W): the layer input; G (B, CO, 2H, 2W): the output gradient; w (CI, CO, 4, 4);
     dst: the weight gradient.  Returns (gin, stats (nslabs, CI, 2) or None); the weight slabs are reduced into dst here, or
     queued on `pending`."""
     lib = L.load()
     B, CI, H, W = S.shape
     CO = w.shape[1]
     if tuple(G.shape) != (B, CO, 2 * H, 2 * W) or tuple(w.shape) != (CI, CO, 4, 4):
-        raise ValueError("dm_convT_bwd_fused: shapes do not match")
-    nb = lib.dm_convT_bwd_fused_num_blocks(B, CI, CO, H, W)
+        raise ValueError("dm_convt_bwd_fused: shapes do not match")
+    nb = lib.dm_convt_bwd_fused_num_blocks(B, CI, CO, H, W)
     if nb <= 0:
-        raise ValueError(f"dm_convT_bwd_fused: ConvTranspose2d({CI} -> {CO}) on {H}x{W} not built")
+        raise ValueError(f"dm_convt_bwd_fused: ConvTranspose2d({CI} -> {CO}) on {H}x{W} not built")
     gin = torch.empty_like(S)
     stats = _new((nb, CI, 2), S, torch.float64) if want_stats else None
     slabs = _new((nb, CI * CO * 16), S)
-    L.check(lib.dm_convT_bwd_fused(_ptr(S), _ptr(G), _ptr(w), _ptr(gin), _ptr(stats, torch.float64), _ptr(slabs),
-                                   1 if mask_relu else 0, B, CI, CO, H, W, _stream()), "dm_convT_bwd_fused")
+    L.check(lib.dm_convt_bwd_fused(_ptr(S), _ptr(G), _ptr(w), _ptr(gin), _ptr(stats, torch.float64), _ptr(slabs),
+                                   1 if mask_relu else 0, B, CI, CO, H, W, _stream()), "dm_convt_bwd_fused")
     if pending is not None:
         pending.append((slabs, dst))
     else:

@@ -309,13 +309,13 @@ int dm_conv4x4s2_bwd_fused(const dm_operand *dy, const float *x, const float *xc
  *   G      the output gradient [B][CO][2H][2W]
  *   w      [CI][CO][4][4] (the ConvTranspose2d weight)
  *   gin    [B][CI][H][W] out = sum_{co,ky,kx} G[co][2y+ky-1][2x+kx-1] w[ci][co][ky][kx], times [S > 0] when mask_relu
- *   stats  NULL, or dm_convT_bwd_fused_num_blocks slabs of [CI][2] doubles: (sum gin, 0) -- the bias gradient of the layer below
+ *   stats  NULL, or dm_convt_bwd_fused_num_blocks slabs of [CI][2] doubles: (sum gin, 0) -- the bias gradient of the layer below
  *   wslabs the same number of slabs of CI*CO*16 floats: partial dW; dm_reduce_slabs(_multi) adds them
- * Built for (CI, CO) = (8, 4) with W % 32 == 0 and (16, 8) with W % 16 == 0, H % 8 == 0 (dm_convT_bwd_fused_supported);
+ * Built for (CI, CO) = (8, 4) with W % 32 == 0 and (16, 8) with W % 16 == 0, H % 8 == 0 (dm_convt_bwd_fused_supported);
  * other shapes: dm_conv4x4s2 + dm_wgrad. */
-int dm_convT_bwd_fused_supported(int CI, int CO, int H, int W);
-int dm_convT_bwd_fused_num_blocks(int B, int CI, int CO, int H, int W);
-int dm_convT_bwd_fused(const float *S, const float *G, const float *w, float *gin, double *stats, float *wslabs,
+int dm_convt_bwd_fused_supported(int CI, int CO, int H, int W);
+int dm_convt_bwd_fused_num_blocks(int B, int CI, int CO, int H, int W);
+int dm_convt_bwd_fused(const float *S, const float *G, const float *w, float *gin, double *stats, float *wslabs,
                        int mask_relu, int B, int CI, int CO, int H, int W, void *stream);
 
 /* ===== BatchNorm2d in training mode (vq_vae.py:206,209,279-288) =============== */

@@ -854,7 +854,7 @@ def test_conv4x4s2_backward_fused_equals_the_two_kernels(ops, B, two):
                                              (5, 16, 8, 16, 16, False), (130, 16, 8, 16, 16, False), (2, 16, 8, 32, 32, False),
                                              (2, 16, 8, 8, 48, True)])
 def test_conv_transpose_backward_fused_equals_the_two_kernels(ops, B, CI, CO, H, W, mask):
-    """dm_convT_bwd_fused (input + weight gradient of dec.0 / dec.2 from one staging) against dm_conv4x4s2 + dm_wgrad and
+    """dm_convt_bwd_fused (input + weight gradient of dec.0 / dec.2 from one staging) against dm_conv4x4s2 + dm_wgrad and
     against autograd's conv_transpose2d backward in float64."""
     g = torch.Generator().manual_seed(B + CI + H)
     S = torch.randn(B, CI, H, W, generator=g)
