@@ -142,20 +142,31 @@ __global__ __launch_bounds__(256) void tm_gram_kernel(const float *__restrict__ 
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lr = threadIdx.x >> 3, lq = threadIdx.x & 7;     // staging: 8 threads per row, 32 rows per pass
+    // register-staged prefetch: the loads of K chunk c + 1 are in flight during the products of chunk c (round 4; the
+    // load -> barrier -> products form left every chunk's round trip exposed: 54 TFLOP/s at B = 768, n = 4096)
+    f32x4 va[2], vb[2];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = lr + 32 * pass;
+            va[pass] = (f32x4){0.f, 0.f, 0.f, 0.f}; vb[pass] = va[pass];
+            if (k0 < k_hi && i0 + r < B) va[pass] = *reinterpret_cast<const f32x4 *>(z + (long long)(i0 + r) * n + k0 + 4 * lq);
+            if (k0 < k_hi && j0 + r < B) vb[pass] = *reinterpret_cast<const f32x4 *>(z + (long long)(j0 + r) * n + k0 + 4 * lq);
+        }
+    };
+    issue(k_lo);
     for (int k0 = k_lo; k0 < k_hi; k0 += TM_KC) {
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int r = lr + 32 * pass;
-            f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
-            if (i0 + r < B) va = *reinterpret_cast<const f32x4 *>(z + (long long)(i0 + r) * n + k0 + 4 * lq);
-            if (j0 + r < B) vb = *reinterpret_cast<const f32x4 *>(z + (long long)(j0 + r) * n + k0 + 4 * lq);
-            *reinterpret_cast<f32x2 *>(sA + r * TM_LDA + 4 * lq) = (f32x2){va.x, va.y};
-            *reinterpret_cast<f32x2 *>(sA + r * TM_LDA + 4 * lq + 2) = (f32x2){va.z, va.w};
-            *reinterpret_cast<f32x2 *>(sB + r * TM_LDA + 4 * lq) = (f32x2){vb.x, vb.y};
-            *reinterpret_cast<f32x2 *>(sB + r * TM_LDA + 4 * lq + 2) = (f32x2){vb.z, vb.w};
+            *reinterpret_cast<f32x2 *>(sA + r * TM_LDA + 4 * lq) = (f32x2){va[pass].x, va[pass].y};
+            *reinterpret_cast<f32x2 *>(sA + r * TM_LDA + 4 * lq + 2) = (f32x2){va[pass].z, va[pass].w};
+            *reinterpret_cast<f32x2 *>(sB + r * TM_LDA + 4 * lq) = (f32x2){vb[pass].x, vb[pass].y};
+            *reinterpret_cast<f32x2 *>(sB + r * TM_LDA + 4 * lq + 2) = (f32x2){vb[pass].z, vb[pass].w};
         }
         __syncthreads();
+        issue(k0 + TM_KC);
         const float *pa = sA + (wr * 32 + (lane & 15)) * TM_LDA + (lane >> 4);
         const float *pb = sB + (wc * 32 + (lane & 15)) * TM_LDA + (lane >> 4);
 #pragma unroll
@@ -315,25 +326,42 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lr = threadIdx.x >> 3, lq = threadIdx.x & 7;     // S tile staging: 8 threads per row (32 columns j)
     const int zr = threadIdx.x >> 4, zq = threadIdx.x & 15;    // Z tile staging: 16 threads per row (64 columns d)
+    // register-staged prefetch of the next K chunk, as in tm_gram_kernel
+    float sv[2][4];
+    f32x4 zv[2];
+    const bool s_vec = (B & 3) == 0;                           // rows of S are 16-byte aligned: one load instead of four
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = lr + 32 * pass;
+            if (s_vec) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (i0 + r < B && k0 + 4 * lq < B) t = *reinterpret_cast<const f32x4 *>(S + (long long)(i0 + r) * B + k0 + 4 * lq);
+                sv[pass][0] = t.x; sv[pass][1] = t.y; sv[pass][2] = t.z; sv[pass][3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = k0 + 4 * lq + u;
+                    sv[pass][u] = (i0 + r < B && j < B) ? S[(long long)(i0 + r) * B + j] : 0.f;
+                }
+            }
+            const int jr = zr + 16 * pass;
+            zv[pass] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k0 + jr < B && d0 + 4 * zq < n) zv[pass] = *reinterpret_cast<const f32x4 *>(z + (long long)(k0 + jr) * n + d0 + 4 * zq);
+        }
+    };
+    issue(0);
     for (int k0 = 0; k0 < B; k0 += TM_KC) {
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int r = lr + 32 * pass;
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = k0 + 4 * lq + u;
-                v[u] = (i0 + r < B && j < B) ? S[(long long)(i0 + r) * B + j] : 0.f;
-            }
-            *reinterpret_cast<f32x2 *>(sS + r * TM_LDA + 4 * lq) = (f32x2){v[0], v[1]};
-            *reinterpret_cast<f32x2 *>(sS + r * TM_LDA + 4 * lq + 2) = (f32x2){v[2], v[3]};
-            const int jr = zr + 16 * pass;
-            f32x4 vz = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (k0 + jr < B && d0 + 4 * zq < n) vz = *reinterpret_cast<const f32x4 *>(z + (long long)(k0 + jr) * n + d0 + 4 * zq);
-            *reinterpret_cast<f32x4 *>(sZ + jr * TM_LDZ + 4 * zq) = vz;
+            *reinterpret_cast<f32x2 *>(sS + r * TM_LDA + 4 * lq) = (f32x2){sv[pass][0], sv[pass][1]};
+            *reinterpret_cast<f32x2 *>(sS + r * TM_LDA + 4 * lq + 2) = (f32x2){sv[pass][2], sv[pass][3]};
+            *reinterpret_cast<f32x4 *>(sZ + (zr + 16 * pass) * TM_LDZ + 4 * zq) = zv[pass];
         }
         __syncthreads();
+        issue(k0 + TM_KC);
         const float *pa = sS + (wr * 32 + (lane & 15)) * TM_LDA + (lane >> 4);
         const float *pb = sZ + (lane >> 4) * TM_LDZ + wc * 32 + (lane & 15);
 #pragma unroll

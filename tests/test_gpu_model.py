@@ -7,6 +7,8 @@ Gates (SURVEY.md section 7 "hard parts"):
   * end to end: losses within 1e-5; indices identical except where the reference's own
     best/second-best distance gap is below 1e-4 relative (count reported, must be tiny).
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -369,6 +371,34 @@ def test_fused_trainer_join_in_the_quantiser_changes_no_bit(golden, monkeypatch,
     assert res[True][0] == res[False][0]
     for k, v in res[True][1].items():
         assert torch.equal(v, res[False][1][k]), k
+
+
+@pytest.mark.parametrize("cls_name,kw,hw", [("VQ_VAE", {}, 128), ("VQ_VAE_z32", {}, 128),
+                                            ("VQ_VAE", dict(num_inputs=4, num_embeddings=512, channel_var=np.ones(4)), 256)])
+def test_fused_backward_kernels_against_the_two_kernel_path(monkeypatch, cls_name, kw, hw):
+    """Round 4's one-staging backward kernels (conv1x1 / conv3x3 / conv4x4s2 / transposed) against the data-gradient +
+    weight-gradient pairs they replace (DM_FUSED_BACKWARD=0), through the whole model: same losses, every parameter
+    gradient equal to accumulation-order tolerance -- on the default 16 x 16 latents (all five kernels), on VQ_VAE_z32 and on
+    256-pixel patches (32 x 32 latents: only the shapes they are built for switch over, the rest keeps the pairs)."""
+    import dynamorph_amd
+    import dynamorph_amd.engine as E
+    torch.manual_seed(31)
+    m0 = getattr(dynamorph_amd, cls_name)(**kw).to(DEV)
+    x = torch.randn(3, m0.num_inputs if hasattr(m0, "num_inputs") else 2, hw, hw, device=DEV)
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, "FUSED_BACKWARD", fused)
+        m = copy.deepcopy(m0)
+        _, ld = m(x)
+        ld["total_loss"].backward()
+        grads[fused] = ({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                        [float(ld[k]) for k in ("recon_loss", "commitment_loss", "total_loss")])
+    assert grads[True][1] == grads[False][1]
+    assert len(grads[True][0]) > 30
+    for k, g in grads[True][0].items():
+        ref = grads[False][0][k]
+        scale = float(ref.abs().max())
+        assert float((g - ref).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((g - ref).abs().max()), scale)
 
 
 def test_fused_trainer_prepare_captures_without_taking_a_step(golden):
