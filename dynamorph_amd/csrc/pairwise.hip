@@ -313,8 +313,17 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
     {   // row sums of S for the tile's 64 rows: 4 threads per row, fixed order
         const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
         float a = 0.f;
-        if (i0 + r < B)
-            for (int j = q; j < B; j += 4) a += S[(long long)(i0 + r) * B + j];
+        if (i0 + r < B) {
+            const float *__restrict__ row = S + (long long)(i0 + r) * B;
+            if ((B & 3) == 0) {                              // 16 bytes per load: a quarter of the round trips of this serial prologue
+                for (int j = 4 * q; j < B; j += 16) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + j);
+                    a += (v.x + v.y) + (v.z + v.w);
+                }
+            } else {
+                for (int j = q; j < B; j += 4) a += row[j];
+            }
+        }
         s_part[threadIdx.x] = a;
         __syncthreads();
         if (q == 0) s_rs[r] = (s_part[threadIdx.x] + s_part[threadIdx.x + 1]) + (s_part[threadIdx.x + 2] + s_part[threadIdx.x + 3]);

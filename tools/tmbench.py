@@ -20,7 +20,7 @@ def t_ms(fn, iters=10, warm=2):
 
 dev = "cuda:0"
 out = []
-for B, n in ((768, 4096), (768, 65536), (128, 4096)):
+for B, n in ((768, 4096), (2048, 4096), (768, 65536), (128, 4096)):
     z = torch.randn(B, n, device=dev)
     tm = torch.randint(0, 3, (B, B), device=dev).float()
     loss, S = ops.time_matching_forward(z, tm, 1, 1.1, 0.1, -0.5, 0.5)
