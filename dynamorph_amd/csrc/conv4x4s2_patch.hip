@@ -1,5 +1,5 @@
-// conv4x4s2_bwd.hip -- backward of Conv2d(16 -> 16, 4, stride 2, padding 1) from a 32 x 32 to a 16 x 16 grid whose output
-// feeds a train-mode BatchNorm: data AND weight gradient in one pass over one patch at a time.
+// conv4x4s2_patch.hip -- Conv2d(16 -> 16, 4, stride 2, padding 1) from a 32 x 32 to a 16 x 16 grid with ONE PATCH per workgroup
+// pass: the backward kernel (data AND weight gradient from one staging) and, below it, the forward kernel.
 //
 // Reference: enc.7 of VQ_VAE.enc (HiddenStateExtractor/vq_vae.py:284) as autograd differentiates it for
 // total_loss.backward() (run_training.py:406): aten::convolution_backward (input and weight) with BatchNorm's backward
@@ -230,4 +230,153 @@ extern "C" int dm_conv4x4s2_bwd_fused(const dm_operand *dy, const float *x, cons
     hipLaunchKernelGGL(conv4x4s2_bwd_kernel, dim3(grid), dim3(S2_NTH), S2_LDS_BYTES, (hipStream_t)stream, d, x, xcoef, w, dx, stats,
                        wslabs, B);
     return dm_launch_status("dm_conv4x4s2_bwd_fused");
+}
+
+// ================================================================================================================ forward
+// enc.7 forward on whole patches.  Rounds 1-3 ran conv4x4s2_kernel<16, 1, 8, 16, ..> on 8 x 16 output tiles: 67 us at
+// B = 2048 in the training step (a 27 us matrix floor, 34 us of traffic) and 45 us at B = 1024 in the inference path.  With the
+// transformed input patch (16 x 34 x 40 floats with its zero padding) in LDS once, every output row is 64 matrix instructions
+// with both operands on immediate LDS offsets: M = the 16 x of a row, N = co, K step (ci, ky) with k = kx.
+// Statistics: one slab per workgroup (batch statistics), or -- per_tile, the per-sample BatchNorm statistics of process_VAE --
+// per patch, written to the first of the two tile slabs the caller sized for conv4x4s2_kernel's 8-row tiles (the second: zeros).
+namespace {
+
+constexpr int F2_LDS_FLOATS = 16 * S2_PST + 64 * 64;
+constexpr size_t F2_LDS_BYTES = (size_t)F2_LDS_FLOATS * sizeof(float);
+
+__global__ __launch_bounds__(S2_NTH, 1)
+void conv4x4s2_patch_forward_kernel(Operand in, WeightView wv, const float *__restrict__ bias, int relu_out,
+                                    float *__restrict__ out, double *__restrict__ stats, int per_tile, int nslabs, int ntiles)
+{
+    constexpr int C = 16, NW = S2_NW, PST = S2_PST, RST = S2_RST;
+    extern __shared__ __attribute__((aligned(16))) float ldsf[];
+    float *sT = ldsf, *sW = ldsf + C * PST;
+    __shared__ double s_stat[NW][C][2];
+
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < C * PST / 4; i += S2_NTH) reinterpret_cast<f32x4 *>(ldsf)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // weights in operand order: step s = (ci, ky): B[k = kx = kq][n = co = m] = W[co][ci][ky][kx] through the caller's view
+    for (int s = wave; s < 64; s += NW)
+        sW[s * 64 + lane] = wv.w[wv.off + m * wv.sn + (s >> 2) * wv.sc + (s & 3) * wv.sky + kq * wv.skx];
+    const float bco = bias ? bias[m] : 0.f;
+    const bool affine = in.mode == DM_LOAD_AFFINE || in.mode == DM_LOAD_AFFINE_RELU;
+    const bool relu_in = in.mode == DM_LOAD_RELU || in.mode == DM_LOAD_AFFINE_RELU;
+    double s1 = 0.0, s2 = 0.0;
+
+    const int tq = (lane >> 3) * 32 + 4 * (lane & 7), tl = ((lane >> 3) + 1) * RST + 4 + 4 * (lane & 7);
+    f32x4 rx[8];
+    float c0[8], c2[8];                                          // coefficients of the planes this wave stages, for the patch in rx
+    auto issue = [&](int b) {
+        const long long xb = (long long)b * C * 1024;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int qp = e * NW + wave, ci = qp >> 2;
+            rx[e] = *reinterpret_cast<const f32x4 *>(in.p0 + xb + (long long)ci * 1024 + (qp & 3) * 256 + tq);
+            if (affine) {
+                const float *cf = in.coef + (long long)b * in.coef_bstride + ci * 4;
+                c0[e] = cf[0]; c2[e] = cf[2];
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    __syncthreads();
+
+    while (tile < ntiles) {
+        if (tile != (int)blockIdx.x) __syncthreads();            // the previous patch has been consumed
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int qp = e * NW + wave, ci = qp >> 2;
+            f32x4 v = rx[e];
+            if (affine) v = c0[e] * v + c2[e];
+            if (relu_in) v = dm_relu4(v);
+            *reinterpret_cast<f32x4 *>(sT + ci * PST + (qp & 3) * 8 * RST + tl) = v;
+        }
+        __syncthreads();
+        const int b = tile;
+        tile += gridDim.x;
+        if (tile < ntiles) issue(tile);                          // in flight during the products below
+
+        // rows y = wave, wave + 8: A[m = x][k = kx = kq] = T[ci][2y + ky - 1][2x + kx - 1] <-> sT[ci*PST + (2y + ky)*RST + 2x + kx + 3]
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const float *pa = sT + 2 * wave * RST + 2 * m + kq + 3;
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float wvs = sW[s * 64 + lane];
+            const int off = (s >> 2) * PST + (s & 3) * RST;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off], wvs, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off + 16 * RST], wvs, acc[1], 0, 0, 0);
+        }
+        float *ob = out + (long long)b * C * 256 + (long long)m * 256 + 4 * kq;
+        double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v = acc[j] + bco;
+            if (relu_out) v = dm_relu4(v);
+            *reinterpret_cast<f32x4 *>(ob + (wave + NW * j) * 16) = v;
+            p1 += (double)((v.x + v.y) + (v.z + v.w));
+            p2 += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+        }
+        if (stats && per_tile) {
+            // per-sample statistics: this patch's sums to its first slab, zeros to its second
+            p1 += __shfl_xor(p1, 16, 64); p2 += __shfl_xor(p2, 16, 64);
+            p1 += __shfl_xor(p1, 32, 64); p2 += __shfl_xor(p2, 32, 64);
+            if (lane < 16) { s_stat[wave][lane][0] = p1; s_stat[wave][lane][1] = p2; }
+            __syncthreads();
+            if (threadIdx.x < C) {
+                double ta = 0.0, tc = 0.0;
+#pragma unroll
+                for (int w8 = 0; w8 < NW; ++w8) { ta += s_stat[w8][threadIdx.x][0]; tc += s_stat[w8][threadIdx.x][1]; }
+                const int spp = nslabs / ntiles;                 // slabs the caller holds per patch
+                double *dst = stats + ((long long)b * spp * C + threadIdx.x) * 2;
+                dst[0] = ta; dst[1] = tc;
+                for (int k = 1; k < spp; ++k) { dst[(long long)k * C * 2] = 0.0; dst[(long long)k * C * 2 + 1] = 0.0; }
+            }
+        } else {
+            s1 += p1; s2 += p2;
+        }
+    }
+    if (stats && !per_tile) {
+        __syncthreads();
+        double a = s1, c = s2;
+        a += __shfl_xor(a, 16, 64); c += __shfl_xor(c, 16, 64);
+        a += __shfl_xor(a, 32, 64); c += __shfl_xor(c, 32, 64);
+        if (lane < 16) { s_stat[wave][lane][0] = a; s_stat[wave][lane][1] = c; }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            double ta = 0.0, tc = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < NW; ++w8) { ta += s_stat[w8][threadIdx.x][0]; tc += s_stat[w8][threadIdx.x][1]; }
+            stats[((long long)blockIdx.x * C + threadIdx.x) * 2 + 0] = ta;
+            stats[((long long)blockIdx.x * C + threadIdx.x) * 2 + 1] = tc;
+        }
+        for (int t2 = blockIdx.x + gridDim.x; t2 < nslabs; t2 += gridDim.x)         // slabs no workgroup owns
+            for (int i = threadIdx.x; i < C * 2; i += S2_NTH) stats[(long long)t2 * C * 2 + i] = 0.0;
+    }
+}
+
+}  // namespace
+
+// Called by dm_conv4x4s2 (conv_mfma.hip) for the shape this kernel is built for; returns false when it does not apply.
+// DM_PATCH_CONV=0 in the environment keeps the tiled kernel (A/B runs).
+bool dm_conv4x4s2_patch_forward(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                                int NOUT, int H, int W, int per_tile, int nslabs, hipStream_t stream, int *rc)
+{
+    static const bool off = [] { const char *e = getenv("DM_PATCH_CONV"); return e && e[0] == '0'; }();
+    if (off || CIN != 16 || Cphys != 16 || NOUT != 16 || H != 32 || W != 32) return false;
+    if (in.mode == DM_LOAD_AFFINE2 || in.ones || ep.mask.p0 || ep.resid || ep.stat_q || ep.bias_border) return false;
+    if (per_tile && (!ep.stats || nslabs % B != 0)) return false;
+    static bool attr_done = false;
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute((const void *)conv4x4s2_patch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)F2_LDS_BYTES);
+        if (e != hipSuccess) return false;
+        attr_done = true;
+    }
+    const int grid = B < 256 ? B : 256;
+    hipLaunchKernelGGL(conv4x4s2_patch_forward_kernel, dim3(grid), dim3(S2_NTH), F2_LDS_BYTES, stream, in, wv, ep.bias, ep.relu, out,
+                       ep.stats, per_tile, nslabs, B);
+    *rc = dm_launch_status("dm_conv4x4s2");
+    return true;
 }

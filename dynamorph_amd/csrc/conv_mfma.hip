@@ -47,6 +47,8 @@ int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scrat
 
 // arithmetic of the gradient kernels (defined with the C ABI at the end of this file; also used by wgrad_mfma.hip)
 bool dm_backward_split_bf16();
+bool dm_conv4x4s2_patch_forward(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                                int NOUT, int H, int W, int per_tile, int nslabs, hipStream_t stream, int *rc);
 #ifdef DM_MEASURE
 // Measurement builds only (make measure): DM_FORWARD_SPLIT=1 runs the FORWARD convolutions on the two-piece split-bf16
 // products too.  Results are then not fp32 (latents pick codes): this exists to bound what ANY bf16-piece arithmetic could
@@ -1410,6 +1412,12 @@ extern "C" int dm_conv4x4s2(const dm_operand *in, const dm_weight_view *w, float
     DM_REQUIRE(H % 2 == 0 && W % 2 == 0, "dm_conv4x4s2: H and W must be even (got %dx%d)", H, W);
     ConvArgs a{to_dev(in), to_dev(w), out, to_dev(ep), B, CIN - (in->ones_channel ? 1 : 0), CIN, NOUT, H, W,
                ep ? ep->stats_per_tile : 0, (hipStream_t)stream};
+    {   // enc.7's shape: the whole-patch kernel (conv4x4s2_patch.hip)
+        int rc = 0;
+        if (dm_conv4x4s2_patch_forward(a.in, a.wv, out, a.ep, B, a.Cphys, CIN, NOUT, H, W, a.per_tile,
+                                       dm_conv4x4s2_num_blocks(B, CIN, NOUT, H, W, a.per_tile), a.stream, &rc))
+            return rc;
+    }
     const int TW = conv4_fast_tw(CIN, NOUT, H, W);
     const bool border_ok = !(ep && ep->bias_border) || (CIN <= 5 && !ep->mask.p0 && !ep->resid && !ep->stat_q && W / 2 >= 8);
     if (TW && conv4_has_kernel(CIN, TW) && in->mode != DM_LOAD_AFFINE2 && border_ok) {

@@ -316,7 +316,7 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
     da3 = Op(dy3, DM_LOAD_AFFINE2, c3b, p1=cx.a3)
     _zero(G(L.enc7.bias), zero_fed_biases)
     if FUSED_BACKWARD and cx.coef2.dim() == 2 and ops.conv4x4s2_bwd_fused_supported(nh, nh, H3, W3):
-        # enc.7: data and weight gradient from ONE staging of the patch -- csrc/conv4x4s2_bwd.hip
+        # enc.7: data and weight gradient from ONE staging of the patch -- csrc/conv4x4s2_patch.hip
         dy2, st = ops.conv4x4s2_bwd_fused(da3, cx.a2, cx.coef2, _w(L.enc7.weight), G(L.enc7.weight), B, pending=pending)
     else:
         ops.wgrad(da3, Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), G(L.enc7.weight), B, nh, nh, H3, W3, 4, pending=pending)

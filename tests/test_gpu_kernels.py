@@ -332,6 +332,39 @@ def test_conv4x4s2(ops, cin, nout, hw, ones, mode):
     close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
 
 
+@pytest.mark.parametrize("B,mode,per_sample,relu", [(1, 3, False, False), (5, 0, False, False), (300, 3, False, False),
+                                                     (7, 1, False, True), (6, 2, True, False), (260, 3, True, False)])
+def test_conv4x4s2_whole_patch_forward_kernel(ops, B, mode, per_sample, relu):
+    """enc.7's shape (16 -> 16 channels, 32 x 32 -> 16 x 16) runs on the whole-patch kernel (conv4x4s2_patch.hip): every operand
+    mode, per-sample coefficients, output ReLU, batch statistics slabs and the per-patch slabs of the inference path."""
+    C = 16
+    x = rnd(B, C, 32, 32, seed=B)
+    w = rnd(C, C, 4, 4, seed=2, scale=0.2)
+    bias = rnd(C, seed=3)
+    if per_sample:
+        coef = torch.stack([rnd(B, C, seed=4).abs() + 0.5, torch.zeros(B, C), rnd(B, C, seed=5) * 0.3, torch.zeros(B, C)], 2)
+    else:
+        coef = torch.stack([rnd(C, seed=4).abs() + 0.5, torch.zeros(C), rnd(C, seed=5) * 0.3, torch.zeros(C)], 1)
+    ref = F.conv2d(load_ref(x, mode, coef), w, bias, stride=2, padding=1)
+    if relu:
+        ref = ref.clamp(min=0)
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, per_sample=per_sample),
+                            ops.weight_view(w.to(DEV), C * 16, 16, 4, 1), B, C, C, 32, 32, want_stats=True, bias=bias.to(DEV),
+                            relu=relu, per_tile=per_sample)
+    close(out, ref, 2e-5, 2e-5, "conv4x4s2 (whole patch)")
+    if per_sample:
+        assert st.shape[0] % B == 0
+        got = st.reshape(B, st.shape[0] // B, C, 2).sum(1).cpu()
+        want = torch.stack([ref.double().sum((2, 3)), (ref.double() ** 2).sum((2, 3))], 2)
+        close(got, want, 1e-5, 1e-3, "per-patch statistics")
+    else:
+        close(st.sum(0), _stats_ref(ref), 1e-5, 1e-3, "stats")
+    out2, st2 = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, per_sample=per_sample),
+                              ops.weight_view(w.to(DEV), C * 16, 16, 4, 1), B, C, C, 32, 32, want_stats=True, bias=bias.to(DEV),
+                              relu=relu, per_tile=per_sample)
+    assert torch.equal(out2, out) and torch.equal(st2, st)
+
+
 def test_conv4x4s2_epilogue_mask_resid_and_convT_view(ops):
     """Data gradient of a ConvTranspose2d(4,2,1): conv over g with the [ci][co] weight read in place."""
     B, ci, co, h = 2, 8, 4, 32          # convT: (B,ci,h,h) -> (B,co,2h,2h)
