@@ -301,12 +301,27 @@ void conv4x4s2_patch_forward_kernel(Operand in, WeightView wv, const float *__re
         // rows y = wave, wave + 8: A[m = x][k = kx = kq] = T[ci][2y + ky - 1][2x + kx - 1] <-> sT[ci*PST + (2y + ky)*RST + 2x + kx + 3]
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const float *pa = sT + 2 * wave * RST + 2 * m + kq + 3;
+        // the LDS operands of the next group of four K steps (one input channel) are requested before the products of this
+        // one: left to hipcc every read sinks next to its matrix instruction and its latency is paid per step
+        float ga[2][4], gb[2][4], gw[2][4];
+        auto fetch = [&](int g, int buf) {
 #pragma unroll
-        for (int s = 0; s < 64; ++s) {
-            const float wvs = sW[s * 64 + lane];
-            const int off = (s >> 2) * PST + (s & 3) * RST;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off], wvs, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off + 16 * RST], wvs, acc[1], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const int off = g * PST + j * RST;
+                ga[buf][j] = pa[off]; gb[buf][j] = pa[off + 16 * RST]; gw[buf][j] = sW[(4 * g + j) * 64 + lane];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (g + 1 < 16) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[g & 1][j], gw[g & 1][j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[g & 1][j], gw[g & 1][j], acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         float *ob = out + (long long)b * C * 256 + (long long)m * 256 + 4 * kq;
         double p1 = 0.0, p2 = 0.0;
