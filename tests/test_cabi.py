@@ -112,6 +112,23 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     args.C = 64
     assert lib.dm_latent_tail_forward(ctypes.byref(args), None) == -1 and b"built for 16 channels" in lib.dm_last_error()
     assert lib.dm_latent_tail_forward(None, None) == -1
+    # round 4 entry points: argument errors before any launch
+    op2 = _lib.Operand(None, None, None, 0, 0, 0)
+    assert lib.dm_conv1x1_bwd_fused(ctypes.byref(op2), None, None, None, None, None, None, 1, 16, 32, 16, 16, None) == -1
+    assert lib.dm_conv3x3_bwd_fused(ctypes.byref(op2), None, None, None, None, None, None, None, None, 1, 16, 16, 16, 16, None) == -1
+    assert lib.dm_conv4x4s2_bwd_fused(ctypes.byref(op2), None, None, None, None, None, None, 1, 16, 16, 16, 16, None) == -1
+    assert lib.dm_convt_bwd_fused(None, None, None, None, None, None, 0, 1, 8, 4, 32, 32, None) == -1
+    assert lib.dm_gather_augment(None, 0, None, None, None, None, 1, 2, 128, None) == -1
+    assert lib.dm_gather_rows(None, 0, None, None, 1, 16, None) == -1
+    assert lib.dm_csr_block(None, None, None, 0, None, 1, None, 1, None, None) == -1
+    assert lib.dm_vq_forward_join(None, None, None, None, None, None, None, None, None, 1, 16, 64, 16, 16, None, 0, None) == -1
+    assert lib.dm_augment_codes(None, 0, 1, None, None) == -1
+    import numpy as np
+    raw = np.array([3, 3, 1, 2, 0, 3, 7, 7], dtype=np.uint32)        # words & 3: 3 3 1 2 | 0 3 | 3 3
+    fl, ro = np.zeros(2, np.int32), np.zeros(2, np.int32)
+    used = lib.dm_augment_codes(raw.ctypes.data, len(raw), 2, fl.ctypes.data, ro.ctypes.data)
+    assert used == 6 and fl.tolist() == [1, 0] and ro.tolist() == [2, 3]
+    assert lib.dm_augment_codes(raw.ctypes.data, 3, 2, fl.ctypes.data, ro.ctypes.data) == -1      # ran out of words
     rc = lib.dm_dec_tail_train(None, None, None, None, None, None, None, 0, None, None, None, None, None, None, 1, 4, 2, 64, 66, None)
     assert rc == -1
 
