@@ -683,7 +683,9 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     feeder = None
     if feed != "sync":
         from . import feed as F
-        usable = dev.type == "cuda" and not custom_hooks and F.dataset_tensor(dataset) is not None
+        src = F.dataset_tensor(dataset)
+        usable = (dev.type == "cuda" and not custom_hooks and src is not None and src.dim() == 4 and src.shape[2] == src.shape[3]
+                  and (mask is None or F.dataset_tensor(mask) is not None))
         if usable:
             feeder = F.Feed(dataset, dev, mode=feed, mask=mask, relation_mat=relation_mat, batch_size=batch_size,
                             trainer=optimizer if isinstance(optimizer, FusedTrainer) else None)
