@@ -68,15 +68,22 @@ __device__ __forceinline__ float lane_from_right(float v)   // value of lane + 1
 // tile spans the whole row) instead of every input value crossing them first.
 // Output rows 2y-1 and 2y both read exactly the input rows y-1 ("P") and y ("C"):
 //   row 2y-1: P with ky = 2, C with ky = 0        row 2y: P with ky = 3, C with ky = 1
+// (the four channels of a lane's column as two register PAIRS: a product needs the value in both halves of a packed
+// operand, and v_pk_fma_f32 can take either half of a 64-bit operand for both of its lanes (op_sel) -- a splat of a lone
+// 32-bit register costs a v_mov_b32 per use instead: 36 per tile in the first form of this kernel)
 struct RowVals {
-    float v[TT_C];
+    f32x2 v[TT_C / 2];
 };
 __device__ __forceinline__ void load_row(const float *__restrict__ sA, int APS, int row, int lane, RowVals &r)
 {
 #pragma unroll
-    for (int ci = 0; ci < TT_C; ++ci) r.v[ci] = sA[ci * APS + row * TT_W + lane];
+    for (int ci = 0; ci < TT_C; ci += 2)
+        r.v[ci >> 1] = (f32x2){sA[ci * APS + row * TT_W + lane], sA[(ci + 1) * APS + row * TT_W + lane]};
 }
-// wp[ci][ky][0] = (w[ky][1], w[ky][2]) (own pair), wp[ci][ky][1] = (w[ky][3], w[ky][0]) (side pair) of W4[ci][co] for this wave's co
+// wp[ci][ky][0] = (w[ky][1], w[ky][2]) (own pair), wp[ci][ky][1] = (w[ky][3], w[ky][0]) (side pair) of W4[ci][co] for this wave's co.
+// ROT: w holds every kx quadruple rotated by one, (w1, w2, w3, w0) -- the LDS copy of the backward kernel -- so that a 16-byte
+// read lands both pairs in aligned register pairs (from the plain order each pair straddles two: 2 v_mov_b32 per pair).
+template <bool ROT>
 __device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, int wv, f32x2 (&wp)[TT_C][4][2])
 {
 #pragma unroll
@@ -84,8 +91,8 @@ __device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, 
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(w + (ci * TT_C + wv) * 16 + 4 * ky);
-            wp[ci][ky][0] = (f32x2){q.y, q.z};
-            wp[ci][ky][1] = (f32x2){q.w, q.x};
+            wp[ci][ky][0] = ROT ? (f32x2){q.x, q.y} : (f32x2){q.y, q.z};
+            wp[ci][ky][1] = ROT ? (f32x2){q.z, q.w} : (f32x2){q.w, q.x};
         }
 }
 __device__ __forceinline__ void convT_pair(const RowVals &P, const RowVals &C, const f32x2 (&wp)[TT_C][4][2], float bias,
@@ -95,7 +102,9 @@ __device__ __forceinline__ void convT_pair(const RowVals &P, const RowVals &C, c
     f32x2 slo, shi;
 #pragma unroll
     for (int ci = 0; ci < TT_C; ++ci) {
-        const f32x2 p = {P.v[ci], P.v[ci]}, c = {C.v[ci], C.v[ci]};
+        const f32x2 pp = P.v[ci >> 1], cc = C.v[ci >> 1];
+        const f32x2 p = (ci & 1) ? __builtin_shufflevector(pp, pp, 1, 1) : __builtin_shufflevector(pp, pp, 0, 0);
+        const f32x2 c = (ci & 1) ? __builtin_shufflevector(cc, cc, 1, 1) : __builtin_shufflevector(cc, cc, 0, 0);
         // one statement per product: each contracts to a single v_pk_fma_f32 on its accumulator; the first channel
         // starts the four sums (no registers zeroed first)
         if (ci == 0) {
@@ -151,7 +160,7 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
 
     const int wv = wave_index_vgpr();
     f32x2 wp[TT_C][4][2];
-    load_convT_weights(w4, wv, wp);
+    load_convT_weights<false>(w4, wv, wp);
     const float bias4 = b4[wv];
     float w6r[NIN][TT_C], b6r[NIN], ivar[NIN];
 #pragma unroll
@@ -285,7 +294,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     __shared__ __attribute__((aligned(16))) float sA[TT_C * APS];
     __shared__ __attribute__((aligned(16))) float sG[TT_C * GPS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
-    __shared__ __attribute__((aligned(16))) float s_w4[TT_C * TT_C * 16];   // dec.4 weights, re-read per phase (broadcast)
+    __shared__ __attribute__((aligned(16))) float s_w4[TT_C * TT_C * 16];   // dec.4 weights, re-read per phase (broadcast); kx order 1, 2, 3, 0
     __shared__ double s_part[4][NP];
 
     const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
@@ -317,7 +326,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     // wave-uniform weights: phase A (recompute, co = wave): W4[ci][wave][ky][kx]; phase 3 (data gradient, ci = wave):
     // W4[wave][co][ky][kx] (64 contiguous floats)
     const int wv = wave_index_vgpr();
-    s_w4[threadIdx.x] = w4[threadIdx.x];             // 256 threads, 256 weights
+    s_w4[threadIdx.x] = w4[(threadIdx.x & ~3) | ((threadIdx.x + 1) & 3)];   // 256 threads, 256 weights; (w1, w2, w3, w0) per ky: load_convT_weights
     const float bias4 = b4[wv];
     const float gs = (float)(2.0 * inv_count) * gscale_dev[0];
     float w6r[NIN][TT_C], gsv[NIN], b6r[NIN], ivar[NIN];
@@ -349,6 +358,11 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 
     // decoded / x rows of the g4 rows this wave handles in phase B (gr = wave + 4j).  They are requested one tile
     // ahead and only CONSUMED in phase B (consuming them earlier would put the s_waitcnt right after the issue).
+    // AHEAD = false: requested at the start of phase B instead, their latency exposed once per tile.  Where the rows in
+    // flight through the phases that hold the 64 weights put the kernel at the 256-register limit with spills in the
+    // loop: decoded AND x rows of three or four channels (60-80 registers), and the x rows alone in the full-row form
+    // (two more matrix steps per row than the WIDE form).
+    constexpr bool AHEAD = NIN <= 2 || (FUSED && WIDE);
     constexpr int BR = (GROWS + 3) / 4;
     f32x2 rdv[BR][NIN], rxv[BR][NIN];
     // one (row, channel) at a time through buffer descriptors rebased to the sample: rows outside the image (and
@@ -374,7 +388,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         if (!FUSED) rdv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rd, voff, 0, 0);
         rxv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rx, voff, 0, 0);
     };
-    {
+    if constexpr (AHEAD) {
         const RowCtx rc0 = rows_begin(tidx < ntiles, b, y0, x0);
 #pragma unroll
         for (int j = 0; j < BR; ++j)
@@ -385,9 +399,9 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 
     while (tidx < ntiles) {
         __syncthreads();                                   // previous tile done with sA and sG
-        stage.commit(sA, s_coef, TT_C, H2, W2, y0 - 2, x0, DM_LOAD_IDENT);
+        stage.template commit<false, true>(sA, s_coef, TT_C, H2, W2, y0 - 2, x0, DM_LOAD_IDENT);   // 192 staging threads: waves 0..2
         __syncthreads();
-        const int cb = b, cy0 = y0;
+        const int cb = b, cy0 = y0, cx0 = x0;
         const int colx = x0 + lane;                        // this lane's d2 column (WIDE: may be halo / outside the image)
         const bool colin = !WIDE || (unsigned)colx < (unsigned)W2;
         const bool ownl = !WIDE || (lane >= TT_HALO && lane < TT_W - TT_HALO && colx < W2);
@@ -398,7 +412,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
         {
         f32x2 wp[TT_C][4][2];                         // W4[ci][co = wave] as packed pairs, live in this phase only
-        load_convT_weights(s_w4, wv, wp);
+        load_convT_weights<true>(s_w4, wv, wp);
         RowVals P, C, N;                              // rows y-1, y and (read one row ahead of its use) y+1; sA row 0 <-> d2 row y0-2
         load_row(sA, APS, 1, lane, P);
         load_row(sA, APS, 2, lane, N);
@@ -425,6 +439,13 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         __syncthreads();
 
         // ---- phase B: g4 = (W6^T g_dec) * (d4 > 0) in place; dW6 / db6 / db4 partial sums ---------------------------
+        if constexpr (!AHEAD) {
+            const RowCtx rcc = rows_begin(true, cb, cy0, cx0);
+#pragma unroll
+            for (int j = 0; j < BR; ++j)
+#pragma unroll
+                for (int c = 0; c < NIN; ++c) issue_row(rcc, j, c);
+        }
         f32x2 tl = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
@@ -448,16 +469,18 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                         for (int co = 0; co < TT_C; ++co) dv += w6r[c][co] * d4v[co];
                     }
                     f32x2 t = dv - rxv[j][c];            // not FUSED: rows outside the image were loaded as 0
+                    // (own and live are 0 / 1 factors: folded into the channel's constants -- the products are the same to the
+                    //  bit and the kernel is bound by its vector instruction count; without WIDE both are wave-uniform)
+                    const float oiv = own * ivar[c];
                     if (mask && live) {
                         const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * colx);
                         t = dv * mv - rxv[j][c] * mv;
-                        if (FUSED) tl += (t * t * own) * ivar[c];
+                        if (FUSED) tl += (t * t) * oiv;
                         t = t * mv;
                     } else if (FUSED) {
-                        tl += (t * t * own) * ivar[c];
+                        tl += (t * t) * oiv;
                     }
-                    if (FUSED) t = t * (live ? 1.f : 0.f);
-                    gd[c] = t * gsv[c];
+                    gd[c] = t * ((!FUSED || live) ? gsv[c] : 0.f);   // FUSED: rows outside the image carry no gradient
                     gdo[c] = gd[c] * own;
                     pv[NIN * TT_C + c] += gdo[c];
                 }
@@ -494,9 +517,9 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         for (int co = 0; co < TT_C; ++co)
 #pragma unroll
             for (int ky = 0; ky < 4; ++ky) {
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + (wv * TT_C + co) * 16 + 4 * ky);
-                wm[co][ky] = (f32x2){q.y, q.z};
-                wo[co][ky] = (f32x2){q.w, q.x};
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + (wv * TT_C + co) * 16 + 4 * ky);   // (w1, w2, w3, w0)
+                wm[co][ky] = (f32x2){q.x, q.y};
+                wo[co][ky] = (f32x2){q.z, q.w};
             }
         f32x2 acc[TT_TH], side[TT_TH];                 // (started by their first product below, not zeroed)
         f32x2 nm[TT_C];                               // the next g4 row: LDS reads one row ahead of their use
@@ -539,9 +562,11 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         {
             constexpr int NR = BR * NIN;                   // next tile's (row, channel) requests, a third before each part
             auto issue_part = [&](int part) {
+                if constexpr (AHEAD) {
 #pragma unroll
-                for (int e = 0; e < NR; ++e)
-                    if (e >= part * NR / 3 && e < (part + 1) * NR / 3) issue_row(rcn, e / NIN, e % NIN);
+                    for (int e = 0; e < NR; ++e)
+                        if (e >= part * NR / 3 && e < (part + 1) * NR / 3) issue_row(rcn, e / NIN, e % NIN);
+                }
             };
             const float rm0 = (wave == 0 && wsy == 1) ? 0.f : 1.f;
             const float rm8 = wsy == 1 ? 1.f : 0.f;

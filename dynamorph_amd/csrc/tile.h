@@ -194,13 +194,21 @@ struct TileStage {
     // the physical channels.
     // One straight-line body per (KIND, ONES): the mode tests stay out of the element loop, so the coefficient reads
     // of a pass are requested together and the loop is a single basic block.
-    template <int KIND, bool ONES, bool SPLIT = false>
+    // WT ("whole-wave tail"): the caller staged with t = threadIdx.x and PER_C is a multiple of 64, so the threads without a
+    // position are whole waves and the test is a scalar branch -- no exec masking, no divergent join.  (Not only cheaper: in a
+    // kernel at the 256-register limit hipcc placed live-range copies in that join block AHEAD of the instruction that
+    // restores exec, and the wave that had skipped the block -- exec = 0 -- skipped the copies with it:
+    // dec_tail_backward_kernel<4, false, true>.)
+    template <int KIND, bool ONES, bool SPLIT = false, bool WT = false>
     __device__ __forceinline__ void commit_as(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
                                               int H, int W, int gy0, int gx0)
     {
+        static_assert(!WT || (PER_C % 64 == 0 && BLOCK % 64 == 0), "whole-wave tail needs PER_C in whole waves");
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            if ((rj[p] & 0xffff) == 0x7fff) continue;      // no position in this pass (at most the tail of the workgroup)
+            // no position in this pass (at most the tail of the workgroup)
+            if (WT) { if ((__builtin_amdgcn_readfirstlane(rj[p]) & 0xffff) == 0x7fff) continue; }
+            else if ((rj[p] & 0xffff) == 0x7fff) continue;
             const bool in = inside(p, H, W, gy0, gx0);
             float *__restrict__ dst = lds + loff[p];
             const f32x4 *__restrict__ ctab = reinterpret_cast<const f32x4 *>(s_coef) + cs;
@@ -239,23 +247,23 @@ struct TileStage {
     // already zero: elements outside the image were read as 0); RELU tiles only clamp; the AFFINE family takes the
     // per-channel coefficients from the LDS table.
     // SPLIT: every value is stored as its (hi, lo) bf16 pair (split_pack4) for the split-bf16 matrix products
-    template <bool SPLIT = false>
+    template <bool SPLIT = false, bool WT = false>
     __device__ __forceinline__ void commit(float *__restrict__ lds, const float *__restrict__ s_coef, int Cphys,
                                            int H, int W, int gy0, int gx0, int mode)
     {
         if (CIN > 1 && Cphys < CIN) {                      // (uniform) with a synthetic ones channel: rare, one body
-            if (mode == DM_LOAD_IDENT) commit_as<0, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
-            else if (mode == DM_LOAD_RELU) commit_as<1, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
-            else if (mode == DM_LOAD_AFFINE_RELU) commit_as<3, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
-            else commit_as<2, true, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            if (mode == DM_LOAD_IDENT) commit_as<0, true, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else if (mode == DM_LOAD_RELU) commit_as<1, true, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else if (mode == DM_LOAD_AFFINE_RELU) commit_as<3, true, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            else commit_as<2, true, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_IDENT) {
-            commit_as<0, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<0, false, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_RELU) {
-            commit_as<1, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<1, false, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else if (mode == DM_LOAD_AFFINE_RELU) {
-            commit_as<3, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<3, false, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         } else {
-            commit_as<2, false, SPLIT>(lds, s_coef, Cphys, H, W, gy0, gx0);
+            commit_as<2, false, SPLIT, WT>(lds, s_coef, Cphys, H, W, gy0, gx0);
         }
     }
 };
