@@ -260,16 +260,21 @@ template <int NS, bool FIRST, bool LAST>
 __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const float *__restrict__ sG, int aoff, int boff,
                                             float rowmul, bool first_bad, bool last_ok, f32x4 (&acc)[2])
 {
-    float a[2], bq[2];
-    a[0] = sA[aoff]; bq[0] = sG[boff];
+    // operands requested PD steps ahead (PD + 1 a power of two).  One step: three ahead measured SLOWER (0.2746 -> 0.2816 ms
+    // per launch in the step) -- the other wave of the SIMD fills a matrix instruction's wait, more reads in flight only
+    // queue ahead of its LDS traffic
+    constexpr int PD = 1;
+    float a[PD + 1], bq[PD + 1];
+#pragma unroll
+    for (int s = 0; s < PD && s < NS; ++s) { a[s] = sA[aoff + 4 * s]; bq[s] = sG[boff + 8 * s]; }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        if (s + 1 < NS) { a[(s + 1) & 1] = sA[aoff + 4 * (s + 1)]; bq[(s + 1) & 1] = sG[boff + 8 * (s + 1)]; }
+        if (s + PD < NS) { a[(s + PD) & PD] = sA[aoff + 4 * (s + PD)]; bq[(s + PD) & PD] = sG[boff + 8 * (s + PD)]; }
         __builtin_amdgcn_sched_barrier(0);
-        float av = a[s & 1] * rowmul;
+        float av = a[s & PD] * rowmul;
         if (FIRST && s == 0) av = first_bad ? 0.f : av;
         if (LAST && s == NS - 1) av = last_ok ? av : 0.f;
-        acc[s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[s & 1], acc[s & 1], 0, 0, 0);
+        acc[s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[s & PD], acc[s & 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -447,10 +452,20 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 for (int c = 0; c < NIN; ++c) issue_row(rcc, j, c);
         }
         f32x2 tl = {0.f, 0.f};
+        // (the d4 values of a row are read one row ahead of their use; only the last of a wave's rows can lie past the
+        //  tile -- wave + 16 >= GROWS for waves 2, 3 -- so the others need no test and form one block with their neighbours)
+        static_assert(4 * (BR - 1) + 3 >= GROWS && 4 * (BR - 2) + 3 < GROWS, "only the last row of a wave may be absent");
+        // (one or two input channels; with three or four the longer live ranges spill)
+        constexpr bool PF = NIN <= 2;
+        f32x2 d4n[TT_C];
+        if constexpr (PF) {
+#pragma unroll
+            for (int co = 0; co < TT_C; ++co) d4n[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + wave * TT_DRS + 2 * lane + 4);
+        }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             const int gr = wave + 4 * j;
-            if (gr < GROWS) {
+            if ((PF && j < BR - 1) || gr < GROWS) {
                 const int oy = 2 * cy0 - 1 + gr;
                 const bool live = oy >= 0 && oy < OH && colin;
                 // rows 2*y0 .. 2*y0+2*TH-1 (WIDE: and the owned columns) belong to this tile: the halo gets its g4 but
@@ -459,7 +474,13 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 f32x2 gd[NIN], gdo[NIN], d4v[TT_C];
 #pragma unroll
                 for (int co = 0; co < TT_C; ++co)
-                    d4v[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + gr * TT_DRS + 2 * lane + 4);
+                    d4v[co] = PF ? d4n[co] : *reinterpret_cast<const f32x2 *>(sG + co * GPS + gr * TT_DRS + 2 * lane + 4);
+                if (PF && j + 1 < BR) {
+                    const int gn = gr + 4 < GROWS ? gr + 4 : GROWS - 1;      // (an absent last row: any row, never used)
+#pragma unroll
+                    for (int co = 0; co < TT_C; ++co)
+                        d4n[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + gn * TT_DRS + 2 * lane + 4);
+                }
 #pragma unroll
                 for (int c = 0; c < NIN; ++c) {
                     f32x2 dv = rdv[j][c];
