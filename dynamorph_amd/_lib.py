@@ -144,6 +144,7 @@ SIGNATURES = {
     "dm_gather_rows": (C.c_int, [vp, i64, vp, vp, C.c_int, i64, vp]),
     "dm_csr_block": (C.c_int, [vp, vp, vp, i64, vp, C.c_int, vp, i64, vp, vp]),
     "dm_augment_codes": (i64, [vp, i64, i64, vp, vp]),
+    "dm_reorder_with_trajectories": (i64, [vp, i64, i64, vp, vp, vp, vp]),
 }
 
 _lib = None
@@ -165,7 +166,7 @@ call_device = _CallDevice()
 # entry points that only compute on the host (grid sizes, scratch sizes, capability queries): they touch no device, so
 # they are bound without the device guard and do NOT consume the device recorded for the launch being assembled
 HOST_ONLY_SUFFIXES = ("_num_blocks", "_num_slabs", "_scratch_floats", "_workspace_bytes", "_workspace_floats", "_supported")
-HOST_ONLY = ("dm_last_error", "dm_version", "dm_backward_precision", "dm_augment_codes")
+HOST_ONLY = ("dm_last_error", "dm_version", "dm_backward_precision", "dm_augment_codes", "dm_reorder_with_trajectories")
 
 
 def is_host_only(name):

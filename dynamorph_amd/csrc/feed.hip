@@ -6,6 +6,7 @@
 // masks, and the CSR relation matrix) is uploaded once and a batch is ONE kernel that gathers the chosen samples,
 // applies each sample's flip / rotation and writes straight into the input buffer the captured step replays on.
 #include "dm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -222,4 +223,82 @@ extern "C" int64_t dm_augment_codes(const uint32_t *raw, int64_t n_raw, int64_t 
         rot_code[s] = (int32_t)(raw[i++] & 3u);
     }
     return i;
+}
+
+// Host only.  run_training.py:97-140 (reorder_with_trajectories) puts the samples of a trajectory next to each other:
+// while samples remain, np.random.choice(list(pool)) picks one -- the pool is a Python set of small ints, whose list is
+// the remaining ids in ascending order, and choice() is one masked-rejection draw below len(pool) from the legacy
+// generator's 32-bit words (none when one sample remains) -- and the pick is followed by everything reachable from it over
+// the ADJACENT pairs (breadth first, neighbours in the order the relation dict lists them).  The reference rebuilds the
+// list for every pick (quadratic in the sample count: hours for 10^5 patches); here the k-th remaining id comes from a
+// Fenwick tree of counts.  adj_ptr / adj_idx: the adjacency of the value-2 pairs as CSR over the first id, insertion
+// order kept.  Returns the words consumed; -1: `raw` too short; -2: a reached sample has no adjacency row (the
+// reference's KeyError on relation_dict[elem]), -3: a reached sample had left the pool already (its KeyError on
+// inds_pool.remove); *err_id names it.
+extern "C" int64_t dm_reorder_with_trajectories(const uint32_t *raw, int64_t n_raw, int64_t n, const int64_t *adj_ptr,
+                                                const int64_t *adj_idx, int64_t *order, int64_t *err_id)
+{
+    if (!raw || !adj_ptr || !order || n < 0 || n_raw < 0) return -4;
+    if (n == 0) return 0;
+    int sh = 0;
+    while ((1LL << sh) < n) ++sh;                       // tree over [1, 2^sh]
+    const int64_t top = 1LL << sh;
+    int64_t *tree = (int64_t *)malloc((size_t)(top + 1) * sizeof(int64_t));
+    unsigned char *gone = (unsigned char *)calloc((size_t)n, 1);
+    int64_t *stamp = (int64_t *)calloc((size_t)n, sizeof(int64_t));
+    int64_t *traj = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+    if (!tree || !gone || !stamp || !traj) { free(tree); free(gone); free(stamp); free(traj); return -4; }
+    for (int64_t i = 1; i <= top; ++i) tree[i] = 0;
+    for (int64_t i = 1; i <= top; ++i) {                // linear build: every node passes its sum to its parent
+        if (i <= n) tree[i] += 1;
+        const int64_t p = i + (i & -i);
+        if (p <= top) tree[p] += tree[i];
+    }
+    int64_t used = 0, out = 0, left = n, rc = 0, pick_no = 0;
+    while (left > 0 && rc == 0) {
+        uint32_t k = 0;
+        const uint32_t rng = (uint32_t)(left - 1);
+        if (rng != 0) {
+            uint32_t mask = rng;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+            for (;;) {
+                if (used >= n_raw) { rc = -1; break; }
+                k = raw[used++] & mask;
+                if (k <= rng) break;
+            }
+            if (rc) break;
+        }
+        // the (k + 1)-th remaining id: descend the tree
+        int64_t pos = 0, need = (int64_t)k + 1;
+        for (int64_t step = top; step > 0; step >>= 1)
+            if (pos + step <= top && tree[pos + step] < need) { pos += step; need -= tree[pos]; }
+        const int64_t first = pos;                       // 0-based id
+        ++pick_no;
+        int64_t len = 0;
+        traj[len++] = first;
+        stamp[first] = pick_no;
+        if (adj_ptr[first + 1] > adj_ptr[first]) {       // in relation_dict: follow the trajectory (the list IS the queue)
+            for (int64_t q = 0; q < len && rc == 0; ++q) {
+                const int64_t e = traj[q];
+                if (adj_ptr[e + 1] == adj_ptr[e]) { rc = -2; if (err_id) *err_id = e; break; }
+                for (int64_t a = adj_ptr[e]; a < adj_ptr[e + 1]; ++a) {
+                    const int64_t v = adj_idx[a];
+                    if (v < 0 || v >= n) { rc = -3; if (err_id) *err_id = v; break; }   // never in the pool
+                    if (stamp[v] == pick_no) continue;   // `if not e in traj`
+                    stamp[v] = pick_no;
+                    traj[len++] = v;                     // (distinct ids below n: len <= n)
+                }
+            }
+        }
+        for (int64_t q = 0; q < len && rc == 0; ++q) {   // inds_in_order.extend(traj); inds_pool.remove(e)
+            const int64_t e = traj[q];
+            if (gone[e]) { rc = -3; if (err_id) *err_id = e; break; }
+            gone[e] = 1;
+            order[out++] = e;
+            for (int64_t i = e + 1; i <= top; i += i & -i) tree[i] -= 1;
+            --left;
+        }
+    }
+    free(tree); free(gone); free(stamp); free(traj);
+    return rc ? rc : used;
 }

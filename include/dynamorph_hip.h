@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 121
+#define DM_VERSION 122
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -583,6 +583,14 @@ int dm_csr_block(const int64_t *indptr, const int32_t *indices, const float *dat
  * numpy's legacy generator, exactly as n interleaved np.random.choice([0,1,2]) / np.random.choice([0,1,2,3]) calls
  * (run_training.py:399-402) consume them.  Returns the number of words consumed, -1 if `raw` is too short. */
 int64_t dm_augment_codes(const uint32_t *raw, int64_t n_raw, int64_t n, int32_t *flip_code, int32_t *rot_code);
+/* HOST function: the sample order of reorder_with_trajectories (run_training.py:97-140) for n samples -- random picks
+ * among the remaining ids, each followed by its trajectory over the ADJACENT (value 2) pairs, breadth first -- from a run
+ * of the legacy generator's 32-bit words, in O((n + pairs) log n) instead of the reference's O(n^2).  adj_ptr (n + 1) /
+ * adj_idx: the value-2 pairs as CSR over their first id, in the relation dict's order.  order: n ids out.  Returns the
+ * words consumed; -1 `raw` too short; -2 / -3 the reference's KeyError cases (a reached sample without an adjacency row /
+ * already taken), *err_id naming the sample; -4 bad argument or no memory. */
+int64_t dm_reorder_with_trajectories(const uint32_t *raw, int64_t n_raw, int64_t n, const int64_t *adj_ptr,
+                                     const int64_t *adj_idx, int64_t *order, int64_t *err_id);
 
 #ifdef __cplusplus
 }

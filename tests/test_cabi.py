@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header():
 def test_version_and_host_only_queries(lib):
     assert lib.dm_vq_backward_num_slabs(524288, 64, 16) == 512 and lib.dm_vq_backward_num_slabs(262144, 4096, 16) == 128
     assert lib.dm_vq_backward_num_slabs(3000, 64, 16) == 3 and lib.dm_vq_backward_num_slabs(1 << 22, 65536, 16) == 32
-    assert lib.dm_version() == 121          # 121: dm_conv4x4s2_bwd_fused; 120: dm_conv3x3_bwd_fused; 119: dm_convt_bwd_fused; 118: dm_conv1x1_bwd_fused; 117: dm_vq_loss_finalize_tm, dm_time_matching_backward_add; 116: dm_vq_forward_join; 115: dm_gather_augment, dm_gather_rows, dm_csr_block, dm_augment_codes; 114: latent tail from a2; 113: dm_latent_tail_forward; 112: the fused decoder tail takes any width that is a multiple of 4
+    assert lib.dm_version() == 122          # 122: dm_reorder_with_trajectories; 121: dm_conv4x4s2_bwd_fused; 120: dm_conv3x3_bwd_fused; 119: dm_convt_bwd_fused; 118: dm_conv1x1_bwd_fused; 117: dm_vq_loss_finalize_tm, dm_time_matching_backward_add; 116: dm_vq_forward_join; 115: dm_gather_augment, dm_gather_rows, dm_csr_block, dm_augment_codes; 114: latent tail from a2; 113: dm_latent_tail_forward; 112: the fused decoder tail takes any width that is a multiple of 4
     assert lib.dm_latent_tail_supported(16, 32, 16, 16, 2) == 1 and lib.dm_latent_tail_supported(16, 32, 32, 32, 2) == 0
     assert lib.dm_latent_tail_supported(64, 64, 16, 16, 2) == 0
     assert lib.dm_dec_tail_supported(4, 4, 128, 128) == 1 and lib.dm_dec_tail_supported(4, 2, 64, 64) == 1
@@ -129,6 +129,15 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     used = lib.dm_augment_codes(raw.ctypes.data, len(raw), 2, fl.ctypes.data, ro.ctypes.data)
     assert used == 6 and fl.tolist() == [1, 0] and ro.tolist() == [2, 3]
     assert lib.dm_augment_codes(raw.ctypes.data, 3, 2, fl.ctypes.data, ro.ctypes.data) == -1      # ran out of words
+    assert lib.dm_reorder_with_trajectories(None, 0, 1, None, None, None, None) == -4
+    # three samples, 0 <-> 2 adjacent: words & 3 = 3 (rejected), 1 -> second of {0, 1, 2} = 1 alone; then {0, 2}: word & 1 = 1
+    # -> 2, followed by its trajectory [2, 0]
+    raw = np.array([7, 5, 3], dtype=np.uint32)
+    ptr, idx, order = np.array([0, 1, 1, 2], np.int64), np.array([2, 0], np.int64), np.zeros(3, np.int64)
+    err = ctypes.c_int64(-1)
+    assert lib.dm_reorder_with_trajectories(raw.ctypes.data, 3, 3, ptr.ctypes.data, idx.ctypes.data, order.ctypes.data, ctypes.byref(err)) == 3
+    assert order.tolist() == [1, 2, 0]
+    assert lib.dm_reorder_with_trajectories(raw.ctypes.data, 1, 3, ptr.ctypes.data, idx.ctypes.data, order.ctypes.data, ctypes.byref(err)) == -1
     rc = lib.dm_dec_tail_train(None, None, None, None, None, None, None, 0, None, None, None, None, None, None, 1, 4, 2, 64, 66, None)
     assert rc == -1
 

@@ -266,3 +266,76 @@ def test_feed_host_helpers():
         for e in range(int(indptr[r]), int(indptr[r + 1])):
             dense[r, int(indices[e])] += float(data[e])
     assert n == 3 and np.array_equal(dense, np.asarray(coo.todense(), np.float32))
+
+
+# ------------------------------------------------------------------ the steps between the pickles and train()
+def _relations_of(g, name):
+    return {(int(a), int(b)): int(v) for (a, b), v in zip(g[f"{name}_pairs"], g[f"{name}_values"])}
+
+
+def _random_trajectories(rng, n, max_len, density=0.8):
+    ids, rel, at = rng.permutation(n), {}, 0
+    while at < n * density:
+        ln = int(rng.integers(2, max_len + 1))
+        tr = ids[at:at + ln]
+        at += ln
+        for i in range(len(tr)):
+            for j in range(len(tr)):
+                if i != j:
+                    rel[(int(tr[i]), int(tr[j]))] = 2 if abs(i - j) == 1 else 1
+    return rel
+
+
+def test_reorder_with_trajectories_matches_the_reference(golden):
+    """run_training.py:97-160 through dm_reorder_with_trajectories: the reference's order, reordered tensor, relation
+    matrix and generator position (fixture made by executing the reference's function), in O(n log n)."""
+    from torch.utils.data import TensorDataset
+    from dynamorph_amd import relations as R
+    g = golden("g10_relations.npz")
+    for name in "abcd":
+        n, seed, rel = int(g[f"{name}_n"]), int(g[f"{name}_seed"]), _relations_of(g, name)
+        ds, mat, inds = R.reorder_with_trajectories(TensorDataset(torch.arange(n, dtype=torch.float32).reshape(n, 1)), rel, seed=seed)
+        after = np.random.randint(0, 2 ** 31, size=4)
+        assert inds == g[f"{name}_order"].tolist() and all(type(i) is int for i in inds), name
+        assert np.array_equal(after, g[f"{name}_after"]), "numpy's generator is left where the reference leaves it"
+        assert np.array_equal(ds.tensors[0].numpy(), g[f"{name}_data"])
+        assert np.array_equal(np.asarray(mat.todense()), g[f"{name}_mat"]) and mat.shape == (n, n)
+    merged, labels = R.concat_relations([_relations_of(g, "cc_r1"), _relations_of(g, "cc_r2")], [g["cc_l1"], g["cc_l2"]], [0, 30])
+    assert list(merged.items()) == list(_relations_of(g, "cc_merged").items()) and np.array_equal(labels, g["cc_labels"])
+
+
+@pytest.mark.parametrize("n,max_len,seed", [(1, 2, 0), (2, 2, 1), (63, 3, 2), (64, 9, 3), (65, 4, None), (1500, 12, 123), (4097, 5, 9)])
+def test_reorder_order_against_the_literal_loop(n, max_len, seed):
+    """Against the oracle's literal restatement (list(pool) + np.random.choice per pick), sizes around the powers of two
+    of the rejection mask; seed None continues the current generator state as the reference does."""
+    from dynamorph_amd import relations as R
+    from oracle import relations_oracle as RO
+    rel = _random_trajectories(np.random.default_rng(n), n, max_len) if n > 1 else {}
+    np.random.seed(77)
+    state = np.random.get_state()
+    want = RO.reorder_indices(n, rel, seed)
+    want_after = np.random.randint(0, 2 ** 31, size=3)
+    np.random.set_state(state)
+    got = R.trajectory_order(n, rel, seed)
+    assert got.tolist() == want and np.array_equal(np.random.randint(0, 2 ** 31, size=3), want_after)
+    assert sorted(got.tolist()) == list(range(n))
+
+
+def test_reorder_keyerrors_of_the_reference():
+    """One-directional pairs: the reference raises KeyError from relation_dict[elem] (a reached sample that starts no
+    pair) or from inds_pool.remove (a trajectory reaching a sample that is gone); same exception, same sample."""
+    from dynamorph_amd import relations as R
+    from oracle import relations_oracle as RO
+    rng = np.random.default_rng(5)
+    random_directed = [{(int(a), int(b)): 2 for a, b in rng.integers(0, 4, (k, 2)) if a != b} for k in (2, 3, 4, 5, 6, 7)]
+    for rel in [{(0, 1): 2}, {(0, 1): 2, (1, 0): 2, (2, 1): 2, (1, 2): 2, (3, 0): 2}] + random_directed:
+        for seed in range(6):
+            try:
+                want = ("ok", RO.reorder_indices(4, rel, seed))
+            except KeyError as e:
+                want = ("KeyError", int(e.args[0]))
+            try:
+                got = ("ok", R.trajectory_order(4, rel, seed).tolist())
+            except KeyError as e:
+                got = ("KeyError", int(e.args[0]))
+            assert got == want, (rel, seed)

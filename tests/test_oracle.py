@@ -260,3 +260,22 @@ def test_chunked_distances_equal_the_full_tensor(golden):
     assert all(float(la[k]) == float(lb[k]) for k in la)
     for (k, p), (_, q_) in zip(a.named_parameters(), b.named_parameters()):
         assert p.grad is None and q_.grad is None or torch.equal(p.grad, q_.grad), k
+
+
+def _relations_of(g, name):
+    return {(int(a), int(b)): int(v) for (a, b), v in zip(g[f"{name}_pairs"], g[f"{name}_values"])}
+
+
+def test_relation_steps_against_the_reference(golden):
+    """concat_relations / reorder_with_trajectories (run_training.py:299-321, 97-160): the restatement gives the
+    reference's order, matrix and generator position (g10: produced by executing the reference's own two functions)."""
+    from oracle import relations_oracle as RO
+    g = golden("g10_relations.npz")
+    for name in "abcd":
+        n, seed, rel = int(g[f"{name}_n"]), int(g[f"{name}_seed"]), _relations_of(g, name)
+        order = RO.reorder_indices(n, rel, seed)
+        after = np.random.randint(0, 2 ** 31, size=4)
+        assert order == g[f"{name}_order"].tolist() and np.array_equal(after, g[f"{name}_after"]), name
+        assert np.array_equal(np.asarray(RO.relation_matrix(n, rel, order).todense()), g[f"{name}_mat"]), name
+    merged, labels = RO.concat_relations([_relations_of(g, "cc_r1"), _relations_of(g, "cc_r2")], [g["cc_l1"], g["cc_l2"]], [0, 30])
+    assert list(merged.items()) == list(_relations_of(g, "cc_merged").items()) and np.array_equal(labels, g["cc_labels"])
