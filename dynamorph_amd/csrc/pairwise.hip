@@ -129,12 +129,18 @@ constexpr int TM_T = 64;          // 64 x 64 output tile per workgroup: 4 waves,
 constexpr int TM_KC = 32;         // K staged per step
 constexpr int TM_LDA = TM_KC + 2; // LDS row stride of a K-major tile: == 2 (mod 32) banks, conflict-free operand reads
 
-// P[ks][i][j] = sum_{d in split ks} z[i][d] z[j][d]
-__global__ __launch_bounds__(256) void tm_gram_kernel(const float *__restrict__ z, float *__restrict__ P, int B, int n, int klen)
+// P[ks][i][j] = sum_{d in split ks} z[i][d] z[j][d] for the tiles ON AND ABOVE the diagonal: G is symmetric and the epilogue
+// reads one orientation of every entry (P[min][max]), so the nt (nt - 1) / 2 tiles below the diagonal are never formed --
+// at B = 2048 that is 496 of 1024 workgroups (blockIdx.x walks the upper triangle row by row)
+__global__ __launch_bounds__(256) void tm_gram_kernel(const float *__restrict__ z, float *__restrict__ P, int B, int n, int klen,
+                                                      int nt)
 {
     __shared__ float sA[TM_T * TM_LDA], sB[TM_T * TM_LDA];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-    const int i0 = blockIdx.y * TM_T, j0 = blockIdx.x * TM_T;
+    int tcol = blockIdx.x, trow = 0;
+    for (int len = nt; tcol >= len; --len) { tcol -= len; ++trow; }    // (uniform: at most nt scalar steps)
+    tcol += trow;
+    const int i0 = trow * TM_T, j0 = tcol * TM_T;
     const int k_lo = blockIdx.z * klen, k_hi = min(n, k_lo + klen);
     f32x4 acc[2][2];
 #pragma unroll
@@ -208,62 +214,108 @@ __device__ __forceinline__ void tm_value(const TmParams &p, float sim, float tm,
 
 constexpr float TM_NEAR = 1.f / 16.f;   // Gram distance below this share of |z_i|^2 + |z_j|^2: re-evaluate from differences
 
-// one thread per (i, j): sim from the Gram slabs (near pairs: from differences, by the wave), both orientations of the loss
-// term, S_ij split into its far part (for the gradient GEMM) and its near part (for tm_near_backward_kernel), loss
-// partials per workgroup.  S: (2, B, B).
+// The 64 x 64 tiles ON OR ABOVE the diagonal (the tiles tm_gram_kernel forms), TM_EP workgroups per tile (16 rows i each),
+// one thread per 4 of its pairs (i, j), i <= j: sim from the Gram slabs (near pairs: from differences, by the wave), BOTH
+// orientations of the loss term -- the pair's two entries of tm -- and S_ij = S_ji written to both places, the mirrored
+// entries through LDS.  (The first form, one thread per entry of the (B, B) matrix, read P and tm across the diagonal with a
+// stride of B floats between lanes: 0.22 of the 0.38 ms forward at B = 2048.)  S: (2, B, B), the far part (for the gradient
+// GEMM) and the near part (for tm_near_backward_kernel); loss partials per workgroup.
+// TM_ER rows i per workgroup = TM_T / TM_ER workgroups per tile: 16 rows, or 4 where 16 would leave most of the chip without a
+// workgroup (B <= 640: fewer than 66 tiles)
+template <int TM_ER>
 __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restrict__ z, const float *__restrict__ P, int ksplit,
                                                           const float *__restrict__ tm, int B, int n, TmParams p,
-                                                          float *__restrict__ S, double *__restrict__ loss_slabs)
+                                                          float *__restrict__ S, double *__restrict__ loss_slabs, int nt)
 {
+    __shared__ float sT[TM_T][TM_ER + 1];                // tm[j0 + r][ib + c]
+    __shared__ float sF[TM_ER][TM_T + 1], sN[TM_ER][TM_T + 1];   // far / near part of S by (i - ib, j - j0)
+    __shared__ double s_gi[TM_ER], s_gj[TM_T];           // Gram diagonal of the workgroup's rows i and the tile's columns j
     __shared__ double s_red[4];
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x, BB = (long long)B * B;
-    const int lane = threadIdx.x & 63;
+    int tcol = blockIdx.x, trow = 0;
+    for (int len = nt; tcol >= len; --len) { tcol -= len; ++trow; }
+    tcol += trow;
+    constexpr int TM_EP = TM_T / TM_ER;
+    const int ib = trow * TM_T + blockIdx.y * TM_ER, j0 = tcol * TM_T;
+    const bool diag = trow == tcol;
+    const long long BB = (long long)B * B;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, lane = tx;
+#pragma unroll
+    for (int k = 0; k < TM_T * TM_ER / 256; ++k) {
+        const int e = threadIdx.x + 256 * k, r = e / TM_ER, c = e % TM_ER;
+        sT[r][c] = (j0 + r < B && ib + c < B) ? tm[(long long)(j0 + r) * B + ib + c] : 0.f;
+    }
+    if (threadIdx.x < TM_ER + TM_T) {                    // chunk sums added in double, in a fixed order
+        const int g = threadIdx.x < TM_ER ? ib + (int)threadIdx.x : j0 + (int)threadIdx.x - TM_ER;
+        double d = 0.0;
+        if (g < B)
+            for (int ks = 0; ks < ksplit; ++ks) d += (double)P[ks * BB + (long long)g * B + g];
+        if (threadIdx.x < TM_ER) s_gi[threadIdx.x] = d; else s_gj[threadIdx.x - TM_ER] = d;
+    }
+    __syncthreads();
+    const float inv_count = p.mode == 0 ? 1.f : 1.f / (float)BB;
+    const int j = j0 + tx;
+    const double gjj = s_gj[tx];
     double val = 0.0;
-    int i = 0, j = 0;
-    float sim = 0.f;
-    bool near = false;
-    if (e < BB) {
-        i = (int)(e / B); j = (int)(e - (long long)i * B);
-        const int lo = i < j ? i : j, hi = i < j ? j : i;           // one orientation of the Gram entry: sim is symmetric to the bit
-        double gij = 0.0, gii = 0.0, gjj = 0.0;
-        for (int ks = 0; ks < ksplit; ++ks) {             // chunk sums added in double, in a fixed order
-            const float *__restrict__ Pk = P + ks * BB;
-            gij += (double)Pk[(long long)lo * B + hi];
-            gii += (double)Pk[(long long)lo * B + lo];
-            gjj += (double)Pk[(long long)hi * B + hi];
+#pragma unroll
+    for (int q = 0; q < TM_ER / 4; ++q) {
+        const int il = ty + 4 * q, i = ib + il;
+        const bool have = i < B && j < B && (!diag || i <= j);
+        float sim = 0.f;
+        bool near = false;
+        if (have) {
+            double gij = 0.0;
+            for (int ks = 0; ks < ksplit; ++ks) gij += (double)P[ks * BB + (long long)i * B + j];
+            const double gii = s_gi[il];
+            const double d2 = gii + gjj - 2.0 * gij;
+            sim = i == j ? 0.f : (float)(d2 / (double)n);
+            near = i != j && !(d2 >= (double)TM_NEAR * (gii + gjj));    // (also when the Gram value is not finite)
         }
-        const double d2 = gii + gjj - 2.0 * gij;
-        sim = i == j ? 0.f : (float)(d2 / (double)n);
-        near = i != j && !(d2 >= (double)TM_NEAR * (gii + gjj));    // (also when the Gram value is not finite)
-    }
-    // near pairs, one at a time, by the whole wave: sum of squared differences, 16 bytes per lane and step
-    unsigned long long todo = __ballot(near);
-    while (todo) {
-        const int l = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int pi = __shfl(i, l, 64), pj = __shfl(j, l, 64);
-        const float *__restrict__ zi = z + (long long)pi * n, *__restrict__ zj = z + (long long)pj * n;
-        double acc = 0.0;
-        for (int d = 4 * lane; d < n; d += 256) {          // n % 32 == 0: whole float4s
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(zi + d), b = *reinterpret_cast<const f32x4 *>(zj + d);
-            const f32x4 df = a - b;
-            acc += (double)((df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w));
+        // near pairs, one at a time, by the whole wave: sum of squared differences, 16 bytes per lane and step
+        unsigned long long todo = __ballot(near);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int pj = j0 + l;                         // (the wave shares i: lane l's pair is (i, j0 + l))
+            const float *__restrict__ zi = z + (long long)i * n, *__restrict__ zj = z + (long long)pj * n;
+            double acc = 0.0;
+            for (int d = 4 * lane; d < n; d += 256) {      // n % 32 == 0: whole float4s
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(zi + d), b = *reinterpret_cast<const f32x4 *>(zj + d);
+                const f32x4 df = a - b;
+                acc += (double)((df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w));
+            }
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane == l) sim = (float)(acc / (double)n);
         }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == l) sim = (float)(acc / (double)n);
+        float sij = 0.f;
+        if (have) {
+            float d_ij, d_ji;
+            double v_ij, v_ji;
+            tm_value(p, sim, tm[(long long)i * B + j], inv_count, v_ij, d_ij);
+            tm_value(p, sim, sT[tx][il], inv_count, v_ji, d_ji);
+            val += i == j ? v_ij : v_ij + v_ji;
+            sij = d_ij + d_ji;
+            S[(long long)i * B + j] = near ? 0.f : sij;
+            S[BB + (long long)i * B + j] = near ? sij : 0.f;
+        }
+        sF[il][tx] = near ? 0.f : sij;
+        sN[il][tx] = near ? sij : 0.f;
     }
-    if (e < BB) {
-        const float inv_count = p.mode == 0 ? 1.f : 1.f / (float)BB;
-        float d_ij, d_ji;
-        double v_ji;
-        tm_value(p, sim, tm[(long long)i * B + j], inv_count, val, d_ij);
-        tm_value(p, sim, tm[(long long)j * B + i], inv_count, v_ji, d_ji);
-        const float sij = d_ij + d_ji;
-        S[e] = near ? 0.f : sij;
-        S[BB + e] = near ? sij : 0.f;
+    __syncthreads();
+    // the mirrored entries: S[j][i] = S[i][j] (the loss counts both orientations of a pair, so S is symmetric)
+#pragma unroll
+    for (int k = 0; k < TM_T * TM_ER / 256; ++k) {
+        const int e = threadIdx.x + 256 * k, jl = e / TM_ER, c = e % TM_ER;
+        const int jj = j0 + jl, ii = ib + c;               // entry (jj, ii) <- the value at (i = ii, j = jj)
+        if (jj < B && ii < B && (!diag || ii < jj)) {
+            S[(long long)jj * B + ii] = sF[c][jl];
+            S[BB + (long long)jj * B + ii] = sN[c][jl];
+        }
     }
     const double tot = block_sum(val, s_red);
-    if (threadIdx.x == 0) { loss_slabs[2 * blockIdx.x] = tot; loss_slabs[2 * blockIdx.x + 1] = 0.0; }
+    if (threadIdx.x == 0) {
+        const long long slab = (long long)blockIdx.x * TM_EP + blockIdx.y;
+        loss_slabs[2 * slab] = tot; loss_slabs[2 * slab + 1] = 0.0;
+    }
 }
 
 // dz[i][d] += scale * g * sum_{j near i} S_ij (z[i][d] - z[j][d]): the near pairs' share of the gradient from differences.
@@ -400,7 +452,7 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
 
 int tm_ksplit(int B, int n)
 {
-    const int tiles = ((B + TM_T - 1) / TM_T) * ((B + TM_T - 1) / TM_T);
+    const int nt = (B + TM_T - 1) / TM_T, tiles = nt * (nt + 1) / 2;         // the upper triangle of tiles
     int ks = 1024 / tiles;
     const int maxks = n / 256 > 0 ? n / 256 : 1;
     if (ks > maxks) ks = maxks;
@@ -420,7 +472,17 @@ extern "C" int64_t dm_time_matching_workspace_floats(int B, int n)
     return (long long)tm_ksplit(B, n) * B * B + 4 * blocks + 4;
 }
 
-extern "C" int dm_time_matching_num_slabs(int B) { return (int)(((long long)B * B + 255) / 256); }
+static int tm_epilogue_rows(int B)                        // rows per workgroup of tm_epilogue_kernel
+{
+    const int nt = (B + TM_T - 1) / TM_T;
+    return 4 * (nt * (nt + 1) / 2) >= 256 ? 16 : 4;
+}
+
+extern "C" int dm_time_matching_num_slabs(int B)          // one per epilogue workgroup: TM_T / rows per tile on or above the diagonal
+{
+    const int nt = (B + TM_T - 1) / TM_T;
+    return (TM_T / tm_epilogue_rows(B)) * (nt * (nt + 1) / 2);
+}
 
 extern "C" int dm_time_matching_forward(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t,
                                         float w_n, float margin, float *workspace, int64_t workspace_floats, float *S,
@@ -435,10 +497,14 @@ extern "C" int dm_time_matching_forward(const float *z, const float *tm, int B, 
     const int ks = tm_ksplit(B, n), nt = (B + TM_T - 1) / TM_T;
     int klen = (n + ks - 1) / ks;
     klen = (klen + TM_KC - 1) / TM_KC * TM_KC;
-    hipLaunchKernelGGL(tm_gram_kernel, dim3(nt, nt, ks), dim3(256), 0, s, z, workspace, B, n, klen);
+    hipLaunchKernelGGL(tm_gram_kernel, dim3(nt * (nt + 1) / 2, 1, ks), dim3(256), 0, s, z, workspace, B, n, klen, nt);
     const TmParams p{mode, w_a, w_t, w_n, margin};
-    hipLaunchKernelGGL(tm_epilogue_kernel, dim3((unsigned)dm_time_matching_num_slabs(B)), dim3(256), 0, s, z, workspace, ks, tm, B,
-                       n, p, S, loss_slabs);
+    if (tm_epilogue_rows(B) == 16)
+        hipLaunchKernelGGL(tm_epilogue_kernel<16>, dim3(nt * (nt + 1) / 2, TM_T / 16), dim3(256), 0, s, z, workspace, ks, tm, B, n,
+                           p, S, loss_slabs, nt);
+    else
+        hipLaunchKernelGGL(tm_epilogue_kernel<4>, dim3(nt * (nt + 1) / 2, TM_T / 4), dim3(256), 0, s, z, workspace, ks, tm, B, n,
+                           p, S, loss_slabs, nt);
     return dm_launch_status("dm_time_matching_forward");
 }
 
