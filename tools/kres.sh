@@ -5,7 +5,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root/dynamorph_amd/csrc
 printf "%-100s %6s %8s %8s %5s\n" kernel VGPRs scratchB LDS_B occ
 for f in *.hip; do
-    extra=""; [ "$f" = vq.hip ] && extra="-ffp-contract=off"
+    extra=""; [ "$f" = vq.hip ] && extra="-ffp-contract=off"; [ "$f" = dec_tail.hip ] && extra="-fno-slp-vectorize"      # as the Makefile builds them
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $extra -I../../include -Rpass-analysis=kernel-resource-usage -c $f -o /tmp/kres_$$.o 2>&1 |
         grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* *//; s/ \[-Rpass.*//' | paste - - - - - |
         while IFS=$'\t' read -r name vg sc occ lds; do
