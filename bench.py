@@ -788,6 +788,10 @@ def main():
         c2 = c2_record(model)
         split = split_bf16_record(x, B, args)
         loop = train_loop_record(dev, 1e3 * elapsed / args.steps, B=B)
+        # the same entry point as run_training.py's main() drives it: cell masks and the relation matrix (time-matching term) on
+        loop["with_masks_and_relation_matrix"] = {
+            k: v for k, v in train_loop_record(dev, None, B=B, epochs=2, masks=True, relation=True).items()
+            if k in ("train_patches_per_s", "train_ms_per_step", "loop_patches_per_s", "val_patches_per_s", "timed_epochs")}
         c5 = c5_record(dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
