@@ -133,6 +133,8 @@ SIGNATURES = {
     "dm_time_matching_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, i64, vp, vp, vp]),
     "dm_time_matching_backward": (C.c_int, [vp, vp, vp, f32, vp, C.c_int, C.c_int, vp]),
     "dm_time_matching_backward_add": (C.c_int, [vp, vp, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
+    "dm_time_matching_forward_state": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, i64, vp, vp, vp, vp]),
+    "dm_time_matching_backward_state": (C.c_int, [vp, vp, vp, f32, vp, vp, C.c_int, C.c_int, vp, vp]),
     "dm_e1_compose": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_compose_border": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -129,13 +129,37 @@ constexpr int TM_T = 64;          // 64 x 64 output tile per workgroup: 4 waves,
 constexpr int TM_KC = 32;         // K staged per step
 constexpr int TM_LDA = TM_KC + 2; // LDS row stride of a K-major tile: == 2 (mod 32) banks, conflict-free operand reads
 
+// ---- the sparse form (mode 0 only).  vq_vae.py:331 sums sim * time_matching_mat: a pair with a zero entry adds nothing to the
+// loss or to its gradient, and the relation matrix of a batch holds a handful of entries per row (the frames of one
+// trajectory).  state[0] = number of nonzero entries of tm (tm_count_kernel); when it is at most TM_SPARSE_ROW per row
+// every kernel below reads that and the two GEMMs fall away: the Gram kernel returns, the epilogue takes EVERY related
+// pair from differences (the path of the near pairs: exact, as the reference computes them), the gradient kernel writes its
+// `add` operand through, and tm_near_backward_kernel adds the pairs' gradient row by row.  The decision is taken on the
+// device: nothing for the host to wait for, the same launches in a captured step whatever the matrix holds.
+constexpr int TM_SPARSE_ROW = 32;
+__device__ __forceinline__ bool tm_sparse(const int *state, int B) { return state && state[0] <= TM_SPARSE_ROW * B; }
+
+__global__ __launch_bounds__(256) void tm_count_kernel(const float *__restrict__ tm, long long BB, int *__restrict__ state)
+{
+    __shared__ int s_cnt[4];
+    int c = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < BB; e += (long long)gridDim.x * 256) c += tm[e] != 0.f;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(state, (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]));      // (integers: any order)
+}
+
+__global__ void tm_dense_state_kernel(int *__restrict__ state) { state[0] = 0x7fffffff; }   // mode 1: never sparse
+
 // P[ks][i][j] = sum_{d in split ks} z[i][d] z[j][d] for the tiles ON AND ABOVE the diagonal: G is symmetric and the epilogue
 // reads one orientation of every entry (P[min][max]), so the nt (nt - 1) / 2 tiles below the diagonal are never formed --
 // at B = 2048 that is 496 of 1024 workgroups (blockIdx.x walks the upper triangle row by row)
 __global__ __launch_bounds__(256) void tm_gram_kernel(const float *__restrict__ z, float *__restrict__ P, int B, int n, int klen,
-                                                      int nt)
+                                                      int nt, const int *__restrict__ state)
 {
     __shared__ float sA[TM_T * TM_LDA], sB[TM_T * TM_LDA];
+    if (tm_sparse(state, B)) return;                       // (uniform) the epilogue will not read P
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
     int tcol = blockIdx.x, trow = 0;
     for (int len = nt; tcol >= len; --len) { tcol -= len; ++trow; }    // (uniform: at most nt scalar steps)
@@ -225,7 +249,8 @@ constexpr float TM_NEAR = 1.f / 16.f;   // Gram distance below this share of |z_
 template <int TM_ER>
 __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restrict__ z, const float *__restrict__ P, int ksplit,
                                                           const float *__restrict__ tm, int B, int n, TmParams p,
-                                                          float *__restrict__ S, double *__restrict__ loss_slabs, int nt)
+                                                          float *__restrict__ S, double *__restrict__ loss_slabs, int nt,
+                                                          const int *__restrict__ state)
 {
     __shared__ float sT[TM_T][TM_ER + 1];                // tm[j0 + r][ib + c]
     __shared__ float sF[TM_ER][TM_T + 1], sN[TM_ER][TM_T + 1];   // far / near part of S by (i - ib, j - j0)
@@ -244,7 +269,8 @@ __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restric
         const int e = threadIdx.x + 256 * k, r = e / TM_ER, c = e % TM_ER;
         sT[r][c] = (j0 + r < B && ib + c < B) ? tm[(long long)(j0 + r) * B + ib + c] : 0.f;
     }
-    if (threadIdx.x < TM_ER + TM_T) {                    // chunk sums added in double, in a fixed order
+    const bool sparse = tm_sparse(state, B);
+    if (!sparse && threadIdx.x < TM_ER + TM_T) {         // chunk sums added in double, in a fixed order
         const int g = threadIdx.x < TM_ER ? ib + (int)threadIdx.x : j0 + (int)threadIdx.x - TM_ER;
         double d = 0.0;
         if (g < B)
@@ -262,7 +288,9 @@ __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restric
         const bool have = i < B && j < B && (!diag || i <= j);
         float sim = 0.f;
         bool near = false;
-        if (have) {
+        if (have && sparse) {                              // every related pair from differences, nothing else matters
+            near = i != j && (tm[(long long)i * B + j] != 0.f || sT[tx][il] != 0.f);
+        } else if (have) {
             double gij = 0.0;
             for (int ks = 0; ks < ksplit; ++ks) gij += (double)P[ks * BB + (long long)i * B + j];
             const double gii = s_gi[il];
@@ -278,7 +306,21 @@ __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restric
             const int pj = j0 + l;                         // (the wave shares i: lane l's pair is (i, j0 + l))
             const float *__restrict__ zi = z + (long long)i * n, *__restrict__ zj = z + (long long)pj * n;
             double acc = 0.0;
-            for (int d = 4 * lane; d < n; d += 256) {      // n % 32 == 0: whole float4s
+            int d = 4 * lane;
+            for (; d + 768 < n; d += 1024) {                // four steps' loads in flight together (the sparse form lives here)
+                f32x4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = *reinterpret_cast<const f32x4 *>(zi + d + 256 * u);
+                    b[u] = *reinterpret_cast<const f32x4 *>(zj + d + 256 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {               // (the same terms in the same order as the single steps below)
+                    const f32x4 df = a[u] - b[u];
+                    acc += (double)((df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w));
+                }
+            }
+            for (; d < n; d += 256) {                      // n % 32 == 0: whole float4s
                 const f32x4 a = *reinterpret_cast<const f32x4 *>(zi + d), b = *reinterpret_cast<const f32x4 *>(zj + d);
                 const f32x4 df = a - b;
                 acc += (double)((df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w));
@@ -320,11 +362,16 @@ __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restric
 
 // dz[i][d] += scale * g * sum_{j near i} S_ij (z[i][d] - z[j][d]): the near pairs' share of the gradient from differences.
 // One workgroup per row i; rows without a near pair (the usual case for most of them) leave after reading their S row.
+// The row's nonzero columns are compacted first (thread t owns the columns [t c, (t + 1) c): counts, a scan, the list in
+// ascending j -- a fixed order), so the sum walks the row's pairs, not its B columns (in the sparse form EVERY related pair
+// comes through here).  Dynamic LDS: B floats (the row) + B 16-bit column numbers.
 __global__ __launch_bounds__(256) void tm_near_backward_kernel(const float *__restrict__ z, const float *__restrict__ Snear,
                                                                const float *__restrict__ g_dev, float scale,
                                                                float *__restrict__ dz, int B, int n)
 {
     extern __shared__ float s_row[];                       // S_near[i][0..B)
+    unsigned short *s_col = reinterpret_cast<unsigned short *>(s_row + B);
+    __shared__ int s_cnt[256];
     __shared__ int s_any;
     const int i = blockIdx.x;
     if (threadIdx.x == 0) s_any = 0;
@@ -338,17 +385,37 @@ __global__ __launch_bounds__(256) void tm_near_backward_kernel(const float *__re
     if (any) s_any = 1;
     __syncthreads();
     if (!s_any) return;
+    const int c = (B + 255) / 256, j_lo = threadIdx.x * c, j_hi = min(B, j_lo + c);
+    int mine = 0;
+    for (int j = j_lo; j < j_hi; ++j) mine += s_row[j] != 0.f;
+    s_cnt[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                     // inclusive scan
+        const int v = threadIdx.x >= o ? s_cnt[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int at = s_cnt[threadIdx.x] - mine;
+    const int total = s_cnt[255];
+    for (int j = j_lo; j < j_hi; ++j)
+        if (s_row[j] != 0.f) s_col[at++] = (unsigned short)j;
+    __syncthreads();
     const float sc = scale * (g_dev ? g_dev[0] : 1.f);
     const float *__restrict__ zi = z + (long long)i * n;
     for (int d = 4 * threadIdx.x; d < n; d += 1024) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(zi + d);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < B; ++j) {                      // ascending j: a fixed order
-            const float sv = s_row[j];
-            if (sv != 0.f) acc += sv * (a - *reinterpret_cast<const f32x4 *>(z + (long long)j * n + d));
+        for (int k = 0; k < total; ++k) {                   // ascending j: a fixed order
+            const int j = s_col[k];
+            acc += s_row[j] * (a - *reinterpret_cast<const f32x4 *>(z + (long long)j * n + d));
         }
+        // (product and sum rounded separately: what is already in dz may be another gradient of the latents -- the `add` operand
+        //  of the call -- and the sum has to come out as the separate elementwise add of the unfused path does)
         f32x4 *o = reinterpret_cast<f32x4 *>(dz + (long long)i * n + d);
-        *o = *o + sc * acc;
+        const f32x4 cur = *o;
+        *o = (f32x4){__fadd_rn(cur.x, __fmul_rn(sc, acc.x)), __fadd_rn(cur.y, __fmul_rn(sc, acc.y)),
+                     __fadd_rn(cur.z, __fmul_rn(sc, acc.z)), __fadd_rn(cur.w, __fmul_rn(sc, acc.w))};
     }
 }
 
@@ -357,11 +424,22 @@ constexpr int TM_LDZ = TM_T + 16;  // LDS row stride of the [j][d] tile: == 16 (
 // add (optional): another gradient of the same latents (the quantiser's), added here instead of in a pass of its own
 __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restrict__ z, const float *__restrict__ S,
                                                           const float *__restrict__ g_dev, float scale,
-                                                          float *__restrict__ dz, int B, int n, const float *__restrict__ add)
+                                                          float *__restrict__ dz, int B, int n, const float *__restrict__ add,
+                                                          const int *__restrict__ state)
 {
     __shared__ float sS[TM_T * TM_LDA], sZ[TM_KC * TM_LDZ], s_rs[TM_T], s_part[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
     const int i0 = blockIdx.y * TM_T, d0 = blockIdx.x * TM_T;
+    if (tm_sparse(state, B)) {                             // (uniform) the far part of S is zero: dz = add + 0, 16 bytes per lane
+        for (int e = threadIdx.x; e < TM_T * (TM_T / 4); e += 256) {
+            const int i = i0 + e / (TM_T / 4), d = d0 + 4 * (e % (TM_T / 4));
+            if (i < B && d < n) {
+                const long long o = (long long)i * n + d;
+                *reinterpret_cast<f32x4 *>(dz + o) = add ? *reinterpret_cast<const f32x4 *>(add + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        return;
+    }
     {   // row sums of S for the tile's 64 rows: 4 threads per row, fixed order
         const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
         float a = 0.f;
@@ -484,9 +562,28 @@ extern "C" int dm_time_matching_num_slabs(int B)          // one per epilogue wo
     return (TM_T / tm_epilogue_rows(B)) * (nt * (nt + 1) / 2);
 }
 
+static int tm_forward_launch(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t, float w_n,
+                             float margin, float *workspace, int64_t workspace_floats, float *S, double *loss_slabs,
+                             int32_t *state, void *stream);
+
 extern "C" int dm_time_matching_forward(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t,
                                         float w_n, float margin, float *workspace, int64_t workspace_floats, float *S,
                                         double *loss_slabs, void *stream)
+{
+    return tm_forward_launch(z, tm, B, n, mode, w_a, w_t, w_n, margin, workspace, workspace_floats, S, loss_slabs, nullptr, stream);
+}
+
+extern "C" int dm_time_matching_forward_state(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t,
+                                              float w_n, float margin, float *workspace, int64_t workspace_floats, float *S,
+                                              double *loss_slabs, int32_t *state, void *stream)
+{
+    DM_REQUIRE(state, "dm_time_matching_forward_state: NULL pointer");
+    return tm_forward_launch(z, tm, B, n, mode, w_a, w_t, w_n, margin, workspace, workspace_floats, S, loss_slabs, state, stream);
+}
+
+static int tm_forward_launch(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t, float w_n,
+                             float margin, float *workspace, int64_t workspace_floats, float *S, double *loss_slabs,
+                             int32_t *state, void *stream)
 {
     DM_REQUIRE(z && tm && workspace && S && loss_slabs, "dm_time_matching_forward: NULL pointer");
     DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_forward: latent length %d is not a multiple of %d", n, TM_KC);
@@ -497,43 +594,69 @@ extern "C" int dm_time_matching_forward(const float *z, const float *tm, int B, 
     const int ks = tm_ksplit(B, n), nt = (B + TM_T - 1) / TM_T;
     int klen = (n + ks - 1) / ks;
     klen = (klen + TM_KC - 1) / TM_KC * TM_KC;
-    hipLaunchKernelGGL(tm_gram_kernel, dim3(nt * (nt + 1) / 2, 1, ks), dim3(256), 0, s, z, workspace, B, n, klen, nt);
+    // the sparse form: mode 0 only (in mode 1 the unrelated pairs carry the hinge term), and only where the caller keeps a state
+    // word for the backward call to read; the count always starts from zero
+    const int *st = nullptr;
+    if (state) {
+        if (hipMemsetAsync(state, 0, 4 * sizeof(int32_t), s) != hipSuccess) return dm_launch_status("dm_time_matching_forward");
+        if (mode == 0) {
+            const long long BB = (long long)B * B;
+            const int grid = (int)((BB + 255) / 256 < 1024 ? (BB + 255) / 256 : 1024);
+            hipLaunchKernelGGL(tm_count_kernel, dim3(grid), dim3(256), 0, s, tm, BB, (int *)state);
+            st = (const int *)state;
+        } else {
+            hipLaunchKernelGGL(tm_dense_state_kernel, dim3(1), dim3(1), 0, s, (int *)state);
+        }
+    }
+    hipLaunchKernelGGL(tm_gram_kernel, dim3(nt * (nt + 1) / 2, 1, ks), dim3(256), 0, s, z, workspace, B, n, klen, nt, st);
     const TmParams p{mode, w_a, w_t, w_n, margin};
     if (tm_epilogue_rows(B) == 16)
         hipLaunchKernelGGL(tm_epilogue_kernel<16>, dim3(nt * (nt + 1) / 2, TM_T / 16), dim3(256), 0, s, z, workspace, ks, tm, B, n,
-                           p, S, loss_slabs, nt);
+                           p, S, loss_slabs, nt, st);
     else
         hipLaunchKernelGGL(tm_epilogue_kernel<4>, dim3(nt * (nt + 1) / 2, TM_T / 4), dim3(256), 0, s, z, workspace, ks, tm, B, n,
-                           p, S, loss_slabs, nt);
+                           p, S, loss_slabs, nt, st);
     return dm_launch_status("dm_time_matching_forward");
 }
 
 static int tm_backward_launch(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
-                              float *dz, int B, int n, void *stream);
+                              float *dz, int B, int n, const int32_t *state, void *stream);
 
 extern "C" int dm_time_matching_backward(const float *z, const float *S, const float *g_loss_dev, float scale, float *dz,
                                          int B, int n, void *stream)
 {
-    return tm_backward_launch(z, S, g_loss_dev, scale, nullptr, dz, B, n, stream);
+    return tm_backward_launch(z, S, g_loss_dev, scale, nullptr, dz, B, n, nullptr, stream);
 }
 
 extern "C" int dm_time_matching_backward_add(const float *z, const float *S, const float *g_loss_dev, float scale,
                                              const float *add, float *dz, int B, int n, void *stream)
 {
     DM_REQUIRE(add, "dm_time_matching_backward_add: NULL pointer");
-    return tm_backward_launch(z, S, g_loss_dev, scale, add, dz, B, n, stream);
+    return tm_backward_launch(z, S, g_loss_dev, scale, add, dz, B, n, nullptr, stream);
+}
+
+extern "C" int dm_time_matching_backward_state(const float *z, const float *S, const float *g_loss_dev, float scale,
+                                               const float *add, float *dz, int B, int n, const int32_t *state, void *stream)
+{
+    DM_REQUIRE(state, "dm_time_matching_backward_state: NULL pointer");
+    return tm_backward_launch(z, S, g_loss_dev, scale, add, dz, B, n, state, stream);
 }
 
 static int tm_backward_launch(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
-                              float *dz, int B, int n, void *stream)
+                              float *dz, int B, int n, const int32_t *state, void *stream)
 {
     DM_REQUIRE(z && S && dz, "dm_time_matching_backward: NULL pointer");
     DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_backward: latent length %d is not a multiple of %d", n, TM_KC);
     DM_REQUIRE((long long)B * n < (1LL << 31), "dm_time_matching_backward: tensor too large");
     DM_REQUIRE(B <= 16384, "dm_time_matching_backward: batch %d too large (a row of S is staged in LDS)", B);
+    // (the write-through of the sparse form moves 16 bytes per lane: dz and add aligned, or the dense form)
+    const int *st = (((uintptr_t)dz | (uintptr_t)add) & 15) == 0 ? (const int *)state : nullptr;
     hipLaunchKernelGGL(tm_backward_kernel, dim3((n + TM_T - 1) / TM_T, (B + TM_T - 1) / TM_T), dim3(256), 0, (hipStream_t)stream,
-                       z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n, add);
-    hipLaunchKernelGGL(tm_near_backward_kernel, dim3((unsigned)B), dim3(256), (size_t)B * sizeof(float), (hipStream_t)stream, z,
+                       z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n, add, st);
+    const size_t near_lds = (size_t)B * (sizeof(float) + sizeof(unsigned short));
+    if (near_lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)tm_near_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)near_lds);
+    hipLaunchKernelGGL(tm_near_backward_kernel, dim3((unsigned)B), dim3(256), near_lds, (hipStream_t)stream, z,
                        S + (long long)B * B, g_loss_dev, scale * 2.f / (float)n, dz, B, n);
     return dm_launch_status("dm_time_matching_backward");
 }

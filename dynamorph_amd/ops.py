@@ -816,7 +816,7 @@ def time_matching_supported(B, n):
 
 
 @_op
-def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0, want_slabs=False):
+def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0, want_slabs=False, allow_sparse=True):
     """The whole pairwise term on the MFMA (include/dynamorph_hip.h, dm_time_matching_forward).  z (B, n), tm (B, B) float32.
     Returns (loss: 1-element device tensor, S (2, B, B) = dloss/dsim + its transpose, far pairs / near pairs, for
     time_matching_backward).  want_slabs: the partial losses (nslabs, 1, 2) float64 instead of their sum (the training
@@ -828,8 +828,17 @@ def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0, wa
     S = _new((2, B, B), z)
     nsl = lib.dm_time_matching_num_slabs(B)
     slabs = _new((nsl, 1, 2), z, torch.float64)
-    L.check(lib.dm_time_matching_forward(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),
-                                         _ptr(slabs, torch.float64), _stream()), "dm_time_matching_forward")
+    # the state word the backward call reads (the sparse form of mode 0: include/dynamorph_hip.h) travels with S as an
+    # attribute; an S that lost it (a copy, a slice) takes the dense form, which gives the same gradient
+    if not allow_sparse or mode != 0:                      # (mode 1 has no sparse form; tests / measurements: the dense form)
+        L.check(lib.dm_time_matching_forward(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),
+                                             _ptr(slabs, torch.float64), _stream()), "dm_time_matching_forward")
+        return (slabs, S) if want_slabs else (sum_slabs(slabs, _new((1,), z)), S)
+    state = torch.empty(4, dtype=torch.int32, device=z.device)
+    L.check(lib.dm_time_matching_forward_state(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),
+                                               _ptr(slabs, torch.float64), _ptr(state, torch.int32), _stream()),
+            "dm_time_matching_forward_state")
+    S._dm_tm_state = state
     if want_slabs:
         return slabs, S
     loss = sum_slabs(slabs, _new((1,), z))
@@ -843,9 +852,14 @@ def time_matching_backward(z, S, g_loss=None, scale=1.0, add=None):
     lib = L.load()
     B, n = z.shape
     dz = torch.empty_like(z)
+    if add is not None and add.numel() != z.numel():
+        raise ValueError("dm_time_matching_backward_add: `add` must have the latents' size")
+    state = getattr(S, "_dm_tm_state", None)
+    if state is not None:
+        L.check(lib.dm_time_matching_backward_state(_ptr(z), _ptr(S), _ptr(g_loss), scale, _ptr(add), _ptr(dz), B, n,
+                                                    _ptr(state, torch.int32), _stream()), "dm_time_matching_backward_state")
+        return dz
     if add is not None:
-        if add.numel() != z.numel():
-            raise ValueError("dm_time_matching_backward_add: `add` must have the latents' size")
         L.check(lib.dm_time_matching_backward_add(_ptr(z), _ptr(S), _ptr(g_loss), scale, _ptr(add), _ptr(dz), B, n, _stream()),
                 "dm_time_matching_backward_add")
         return dz

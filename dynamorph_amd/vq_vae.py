@@ -167,11 +167,14 @@ class _TimeMatchingFn(torch.autograd.Function):
         z = zf.detach().contiguous().float()
         loss, S = ops.time_matching_forward(z, tm.detach().contiguous().float(), mode, w_a, w_t, w_n, margin)
         ctx.save_for_backward(z, S)
+        ctx.tm_state = getattr(S, "_dm_tm_state", None)     # (saved tensors come back as new objects: attributes do not)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         z, S = ctx.saved_tensors
+        if ctx.tm_state is not None:
+            S._dm_tm_state = ctx.tm_state
         return (ops.time_matching_backward(z, S, g.reshape(1).contiguous().float()),) + (None,) * 6
 
 

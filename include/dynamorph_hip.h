@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 122
+#define DM_VERSION 123
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -523,6 +523,17 @@ int dm_time_matching_backward(const float *z, const float *S, const float *g_los
  * `dz` itself).  The training step adds the pairwise term's gradient to the quantiser's without an elementwise pass. */
 int dm_time_matching_backward_add(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
                                   float *dz, int B, int n, void *stream);
+/* The same pair with a STATE word the two calls share (4 int32 of caller memory, written by the forward call and read by
+ * the kernels of both).  mode 0 (vq_vae.py:331: sum of sim * time_matching_mat) only needs the pairs with a nonzero entry,
+ * and a batch's relation matrix holds a handful per row: the forward call counts them on the device, and at up to 32 per
+ * row the Gram product and the gradient product are skipped -- every related pair is evaluated from differences (exactly,
+ * as the reference does) and its gradient added row by row.  No host decision, the same launches either way (a captured
+ * step stays valid whatever the matrix holds); mode 1, or a denser matrix, runs the dense form.  `add` may be NULL. */
+int dm_time_matching_forward_state(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t, float w_n,
+                                   float margin, float *workspace, int64_t workspace_floats, float *S, double *loss_slabs,
+                                   int32_t *state, void *stream);
+int dm_time_matching_backward_state(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
+                                    float *dz, int B, int n, const int32_t *state, void *stream);
 
 /* ===== enc.0 o enc.1 composition (vq_vae.py:277-278) ========================== */
 

@@ -1340,6 +1340,48 @@ def test_time_matching_related_pairs_lie_close_together(ops, B, n, mode, only_ne
         assert float(ops.time_matching_backward(z2.to(DEV), S2, None, wm).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,n,frames", [(200, 4096, 8), (64, 1024, 4), (513, 256, 16)])
+def test_time_matching_sparse_form(ops, B, n, frames):
+    """vq_vae.py:331 (mode 0) only needs the pairs with a nonzero entry of time_matching_mat.  A batch's relation matrix --
+    trajectories of consecutive frames: adjacent frames 2, the rest of a trajectory 1 -- holds a handful per row: the device
+    counts them and both GEMMs fall away (S has no far part), every related pair is taken from differences.  Loss and
+    gradient against the reference's expression in float64, against the dense form of the same call, and the gradient
+    again from an S that lost its state word (the dense backward of an all-zero far part)."""
+    g = torch.Generator().manual_seed(B + frames)
+    z = torch.randn(B, n, generator=g) * 0.6 + 0.05
+    tm = torch.zeros(B, B)
+    for t0 in range(0, B - frames + 1, frames + 3):            # trajectories with unrelated samples between them
+        for a in range(frames):
+            z[t0 + a] = z[t0] + 0.02 * a * torch.randn(n, generator=g)
+            for b in range(frames):
+                if a != b:
+                    tm[t0 + a, t0 + b] = 2.0 if abs(a - b) == 1 else 1.0
+    tm[1, B - 1] = 1.0                                         # one-directional entries count as well
+    ref, gref = _tm_reference(z, tm, 0)
+    zd, tmd = z.to(DEV), tm.to(DEV)
+    loss, S = ops.time_matching_forward(zd, tmd, 0)
+    assert int(S._dm_tm_state[0]) == int((tm != 0).sum())
+    assert float(S[0].abs().max()) == 0.0 and bool((S[1].cpu() != 0)[0, 1])      # the sparse form ran: no far part
+    assert torch.equal(S[1].cpu() != 0, ((tm + tm.T) != 0) & ~torch.eye(B, dtype=torch.bool))
+    assert abs(float(loss) - ref) <= 1e-6 * abs(ref), (float(loss), ref)
+    other = torch.randn(B, n, generator=g).to(DEV)
+    dz = ops.time_matching_backward(zd, S, None, 3.0, add=other)
+    want = gref * 3.0 + other.cpu().double()
+    assert (dz.cpu().double() - want).abs().max() <= 2e-6 * (gref.abs().max() * 3.0) + 1e-6 * float(other.abs().max())
+    dz_plain = ops.time_matching_backward(zd, S, None, 3.0)
+    assert (dz_plain.cpu().double() - gref * 3.0).abs().max() <= 2e-6 * gref.abs().max() * 3.0
+    # the dense form of the same term, and the dense backward of this S
+    loss_d, S_d = ops.time_matching_forward(zd, tmd, 0, allow_sparse=False)
+    assert abs(float(loss_d) - float(loss)) <= 1e-5 * abs(ref)
+    dz_d = ops.time_matching_backward(zd, S_d, None, 3.0)
+    assert (dz_d - dz_plain).abs().max() <= 2e-5 * float(dz_plain.abs().max())
+    assert torch.equal(ops.time_matching_backward(zd, S.clone(), None, 3.0), dz_plain)
+    # a matrix with more than 32 entries per row stays dense
+    tm_dense = (torch.rand(B, B, generator=g) < 0.5).float().to(DEV)
+    _, S2 = ops.time_matching_forward(zd, tm_dense, 0)
+    assert float(S2[0].abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_zscore_patch_matches_numpy(ops, dtype):
     """pipeline/train_utils.py:252-274 zscore_patch (float64 numpy, population std, + eps) then .float()."""

@@ -34,3 +34,18 @@ for B, n in ((768, 4096), (2048, 4096), (768, 65536), (128, 4096)):
         rec["round1_pair_msd_ms"] = round(t_ms(lambda: ops.pair_msd(z), iters=3, warm=1), 4)
         rec["round1_pair_msd_backward_ms"] = round(t_ms(lambda: ops.pair_msd_backward(z, sim), iters=3, warm=1), 4)
     print(json.dumps(rec), flush=True)
+
+# mode 0 (vq_vae.py:331) on a batch's relation matrix -- trajectories of 8 consecutive frames, as train() feeds it -- : the sparse
+# form (related pairs from differences, no GEMM) against the dense form of the same call
+for B, n in ((2048, 4096), (768, 4096)):
+    z = torch.randn(B, n, device=dev)
+    i = torch.arange(B, device=dev)
+    same = (i[:, None] // 8) == (i[None, :] // 8)
+    tm = torch.where(same & (i[:, None] != i[None, :]), torch.where((i[:, None] - i[None, :]).abs() == 1, 2.0, 1.0), 0.0).float()
+    rec = {"B": B, "n": n, "mode": 0, "relation_entries_per_row": round(float((tm != 0).sum()) / B, 2)}
+    for name, sparse in (("sparse", True), ("dense", False)):
+        loss, S = ops.time_matching_forward(z, tm, 0, allow_sparse=sparse)
+        rec[name + "_forward_ms"] = round(t_ms(lambda: ops.time_matching_forward(z, tm, 0, allow_sparse=sparse)), 4)
+        rec[name + "_backward_ms"] = round(t_ms(lambda: ops.time_matching_backward(z, S, None, 0.005)), 4)
+        rec[name + "_loss"] = float(loss)
+    print(json.dumps(rec), flush=True)
