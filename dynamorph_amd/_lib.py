@@ -130,6 +130,7 @@ SIGNATURES = {
     "dm_time_matching_supported": (C.c_int, [C.c_int, C.c_int]),
     "dm_time_matching_workspace_floats": (i64, [C.c_int, C.c_int]),
     "dm_time_matching_num_slabs": (C.c_int, [C.c_int]),
+    "dm_time_matching_state_ints": (C.c_int, [C.c_int]),
     "dm_time_matching_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, i64, vp, vp, vp]),
     "dm_time_matching_backward": (C.c_int, [vp, vp, vp, f32, vp, C.c_int, C.c_int, vp]),
     "dm_time_matching_backward_add": (C.c_int, [vp, vp, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
@@ -167,7 +168,7 @@ call_device = _CallDevice()
 
 # entry points that only compute on the host (grid sizes, scratch sizes, capability queries): they touch no device, so
 # they are bound without the device guard and do NOT consume the device recorded for the launch being assembled
-HOST_ONLY_SUFFIXES = ("_num_blocks", "_num_slabs", "_scratch_floats", "_workspace_bytes", "_workspace_floats", "_supported")
+HOST_ONLY_SUFFIXES = ("_num_blocks", "_num_slabs", "_scratch_floats", "_workspace_bytes", "_workspace_floats", "_supported", "_state_ints")
 HOST_ONLY = ("dm_last_error", "dm_version", "dm_backward_precision", "dm_augment_codes", "dm_reorder_with_trajectories")
 
 

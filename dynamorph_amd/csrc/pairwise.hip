@@ -138,6 +138,24 @@ constexpr int TM_LDA = TM_KC + 2; // LDS row stride of a K-major tile: == 2 (mod
 // device: nothing for the host to wait for, the same launches in a captured step whatever the matrix holds.
 constexpr int TM_SPARSE_ROW = 32;
 __device__ __forceinline__ bool tm_sparse(const int *state, int B) { return state && state[0] <= TM_SPARSE_ROW * B; }
+// The state block: 4 header words ([0] = the count above) and a map of the far part of S, one int per (panel of 64 rows,
+// chunk of 32 columns), nonzero where the block holds a nonzero -- written by the epilogue (plain stores of 1: every writer
+// writes the same value, so no read-modify-write on words that a dense S has thousands of workgroups aiming at), read by the
+// gradient product, which only multiplies those chunks.  In the z16 / z32 form (mode 1) every pair has a distance to evaluate
+// (the hinge on unrelated pairs), but an unrelated pair beyond the margin carries no gradient: S is as sparse as the relation
+// matrix again once training has pushed such pairs apart.  A skipped chunk is all zeros: the sums are the same to the bit.
+constexpr int TM_STATE_HDR = 4;
+__host__ __device__ inline int tm_map_chunks(int B) { return (B + TM_KC - 1) / TM_KC; }
+__device__ __forceinline__ void tm_map_set(int *map, int B, int row, int col)
+{
+    map[(row / TM_T) * tm_map_chunks(B) + col / TM_KC] = 1;
+}
+
+__global__ __launch_bounds__(256) void tm_state_clear_kernel(int *__restrict__ state, int ints)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ints) state[i] = 0;
+}
 
 __global__ __launch_bounds__(256) void tm_count_kernel(const float *__restrict__ tm, long long BB, int *__restrict__ state)
 {
@@ -149,8 +167,6 @@ __global__ __launch_bounds__(256) void tm_count_kernel(const float *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(state, (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]));      // (integers: any order)
 }
-
-__global__ void tm_dense_state_kernel(int *__restrict__ state) { state[0] = 0x7fffffff; }   // mode 1: never sparse
 
 // P[ks][i][j] = sum_{d in split ks} z[i][d] z[j][d] for the tiles ON AND ABOVE the diagonal: G is symmetric and the epilogue
 // reads one orientation of every entry (P[min][max]), so the nt (nt - 1) / 2 tiles below the diagonal are never formed --
@@ -250,7 +266,7 @@ template <int TM_ER>
 __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restrict__ z, const float *__restrict__ P, int ksplit,
                                                           const float *__restrict__ tm, int B, int n, TmParams p,
                                                           float *__restrict__ S, double *__restrict__ loss_slabs, int nt,
-                                                          const int *__restrict__ state)
+                                                          const int *__restrict__ state, int *__restrict__ far_map)
 {
     __shared__ float sT[TM_T][TM_ER + 1];                // tm[j0 + r][ib + c]
     __shared__ float sF[TM_ER][TM_T + 1], sN[TM_ER][TM_T + 1];   // far / near part of S by (i - ib, j - j0)
@@ -282,6 +298,7 @@ __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restric
     const int j = j0 + tx;
     const double gjj = s_gj[tx];
     double val = 0.0;
+    bool any_far = false;
 #pragma unroll
     for (int q = 0; q < TM_ER / 4; ++q) {
         const int il = ty + 4 * q, i = ib + il;
@@ -341,6 +358,15 @@ __global__ __launch_bounds__(256) void tm_epilogue_kernel(const float *__restric
         }
         sF[il][tx] = near ? 0.f : sij;
         sN[il][tx] = near ? sij : 0.f;
+        any_far |= !near && sij != 0.f;
+    }
+    if (far_map) {                                         // the chunks of the far part this workgroup put a nonzero into
+        const unsigned long long bal = __ballot(any_far);  // (a wave's rows share the panel; its lanes span two chunks of columns)
+        if (lane == 0) {
+            if (bal & 0xffffffffull) tm_map_set(far_map, B, ib, j0);
+            if (bal >> 32) tm_map_set(far_map, B, ib, j0 + 32);
+            if (bal) tm_map_set(far_map, B, j0, ib);       // the mirrored entries: rows j0 .. j0 + 63, columns ib .. ib + TM_ER - 1
+        }
     }
     __syncthreads();
     // the mirrored entries: S[j][i] = S[i][j] (the loss counts both orientations of a pair, so S is symmetric)
@@ -430,33 +456,56 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
     __shared__ float sS[TM_T * TM_LDA], sZ[TM_KC * TM_LDZ], s_rs[TM_T], s_part[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
     const int i0 = blockIdx.y * TM_T, d0 = blockIdx.x * TM_T;
-    if (tm_sparse(state, B)) {                             // (uniform) the far part of S is zero: dz = add + 0, 16 bytes per lane
-        for (int e = threadIdx.x; e < TM_T * (TM_T / 4); e += 256) {
-            const int i = i0 + e / (TM_T / 4), d = d0 + 4 * (e % (TM_T / 4));
-            if (i < B && d < n) {
-                const long long o = (long long)i * n + d;
-                *reinterpret_cast<f32x4 *>(dz + o) = add ? *reinterpret_cast<const f32x4 *>(add + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+    // the chunks of 32 columns of S to multiply: all of them, or (state) those the epilogue marked for this panel of rows, in
+    // ascending order either way
+    __shared__ unsigned short s_list[512];                 // (B <= 16384)
+    __shared__ int s_scan[256];
+    const int nchunks = (B + TM_KC - 1) / TM_KC;
+    int nl;
+    {
+        const int *__restrict__ map = state ? state + TM_STATE_HDR + blockIdx.y * nchunks : nullptr;
+        auto live = [&](int c) { return c < nchunks && (!map || map[c] != 0); };
+        const int c_lo = 2 * threadIdx.x;                  // thread t owns chunks 2t, 2t + 1
+        const int mine = (int)live(c_lo) + (int)live(c_lo + 1);
+        s_scan[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
         }
-        return;
+        int at = s_scan[threadIdx.x] - mine;
+        if (live(c_lo)) s_list[at++] = (unsigned short)c_lo;
+        if (live(c_lo + 1)) s_list[at] = (unsigned short)(c_lo + 1);
+        nl = s_scan[255];
+        __syncthreads();
     }
-    {   // row sums of S for the tile's 64 rows: 4 threads per row, fixed order
+    {   // row sums of S for the tile's 64 rows: 4 threads per row, fixed order (a skipped chunk would have added zeros)
         const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
         float a = 0.f;
         if (i0 + r < B) {
             const float *__restrict__ row = S + (long long)(i0 + r) * B;
-            if ((B & 3) == 0) {                              // 16 bytes per load: a quarter of the round trips of this serial prologue
-                for (int j = 4 * q; j < B; j += 16) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + j);
-                    a += (v.x + v.y) + (v.z + v.w);
+            for (int li = 0; li < nl; ++li) {
+                const int k0 = TM_KC * s_list[li];
+                if ((B & 3) == 0) {                          // 16 bytes per load: a quarter of the round trips of this serial prologue
+#pragma unroll
+                    for (int h = 0; h < TM_KC; h += 16) {
+                        const int j = k0 + h + 4 * q;
+                        if (j < B) {
+                            const f32x4 v = *reinterpret_cast<const f32x4 *>(row + j);
+                            a += (v.x + v.y) + (v.z + v.w);
+                        }
+                    }
+                } else {
+                    for (int j = k0 + q; j < min(B, k0 + TM_KC); j += 4) a += row[j];
                 }
-            } else {
-                for (int j = q; j < B; j += 4) a += row[j];
             }
         }
         s_part[threadIdx.x] = a;
         __syncthreads();
         if (q == 0) s_rs[r] = (s_part[threadIdx.x] + s_part[threadIdx.x + 1]) + (s_part[threadIdx.x + 2] + s_part[threadIdx.x + 3]);
+        __syncthreads();                                    // (with no chunk to multiply nothing else stands before their use)
     }
     f32x4 acc[2][2];
 #pragma unroll
@@ -489,8 +538,8 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
             if (k0 + jr < B && d0 + 4 * zq < n) zv[pass] = *reinterpret_cast<const f32x4 *>(z + (long long)(k0 + jr) * n + d0 + 4 * zq);
         }
     };
-    issue(0);
-    for (int k0 = 0; k0 < B; k0 += TM_KC) {
+    if (nl > 0) issue(TM_KC * s_list[0]);
+    for (int li = 0; li < nl; ++li) {
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -500,7 +549,7 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
             *reinterpret_cast<f32x4 *>(sZ + (zr + 16 * pass) * TM_LDZ + 4 * zq) = zv[pass];
         }
         __syncthreads();
-        issue(k0 + TM_KC);
+        issue(li + 1 < nl ? TM_KC * s_list[li + 1] : B);    // (past the end: every lane's guard fails, nothing is loaded)
         const float *pa = sS + (wr * 32 + (lane & 15)) * TM_LDA + (lane >> 4);
         const float *pb = sZ + (lane >> 4) * TM_LDZ + wc * 32 + (lane & 15);
 #pragma unroll
@@ -556,6 +605,11 @@ static int tm_epilogue_rows(int B)                        // rows per workgroup 
     return 4 * (nt * (nt + 1) / 2) >= 256 ? 16 : 4;
 }
 
+extern "C" int dm_time_matching_state_ints(int B)         // the state block of the _state entries
+{
+    return TM_STATE_HDR + ((B + TM_T - 1) / TM_T) * tm_map_chunks(B);
+}
+
 extern "C" int dm_time_matching_num_slabs(int B)          // one per epilogue workgroup: TM_T / rows per tile on or above the diagonal
 {
     const int nt = (B + TM_T - 1) / TM_T;
@@ -597,25 +651,27 @@ static int tm_forward_launch(const float *z, const float *tm, int B, int n, int 
     // the sparse form: mode 0 only (in mode 1 the unrelated pairs carry the hinge term), and only where the caller keeps a state
     // word for the backward call to read; the count always starts from zero
     const int *st = nullptr;
+    int *far_map = nullptr;
     if (state) {
-        if (hipMemsetAsync(state, 0, 4 * sizeof(int32_t), s) != hipSuccess) return dm_launch_status("dm_time_matching_forward");
+        // (cleared by a kernel of this stream, ordered like every other launch of the call)
+        const int ints = dm_time_matching_state_ints(B);
+        hipLaunchKernelGGL(tm_state_clear_kernel, dim3((ints + 255) / 256), dim3(256), 0, s, (int *)state, ints);
+        far_map = (int *)state + TM_STATE_HDR;
         if (mode == 0) {
             const long long BB = (long long)B * B;
             const int grid = (int)((BB + 255) / 256 < 1024 ? (BB + 255) / 256 : 1024);
             hipLaunchKernelGGL(tm_count_kernel, dim3(grid), dim3(256), 0, s, tm, BB, (int *)state);
             st = (const int *)state;
-        } else {
-            hipLaunchKernelGGL(tm_dense_state_kernel, dim3(1), dim3(1), 0, s, (int *)state);
         }
     }
     hipLaunchKernelGGL(tm_gram_kernel, dim3(nt * (nt + 1) / 2, 1, ks), dim3(256), 0, s, z, workspace, B, n, klen, nt, st);
     const TmParams p{mode, w_a, w_t, w_n, margin};
     if (tm_epilogue_rows(B) == 16)
         hipLaunchKernelGGL(tm_epilogue_kernel<16>, dim3(nt * (nt + 1) / 2, TM_T / 16), dim3(256), 0, s, z, workspace, ks, tm, B, n,
-                           p, S, loss_slabs, nt, st);
+                           p, S, loss_slabs, nt, st, far_map);
     else
         hipLaunchKernelGGL(tm_epilogue_kernel<4>, dim3(nt * (nt + 1) / 2, TM_T / 4), dim3(256), 0, s, z, workspace, ks, tm, B, n,
-                           p, S, loss_slabs, nt, st);
+                           p, S, loss_slabs, nt, st, far_map);
     return dm_launch_status("dm_time_matching_forward");
 }
 
@@ -649,8 +705,7 @@ static int tm_backward_launch(const float *z, const float *S, const float *g_los
     DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_backward: latent length %d is not a multiple of %d", n, TM_KC);
     DM_REQUIRE((long long)B * n < (1LL << 31), "dm_time_matching_backward: tensor too large");
     DM_REQUIRE(B <= 16384, "dm_time_matching_backward: batch %d too large (a row of S is staged in LDS)", B);
-    // (the write-through of the sparse form moves 16 bytes per lane: dz and add aligned, or the dense form)
-    const int *st = (((uintptr_t)dz | (uintptr_t)add) & 15) == 0 ? (const int *)state : nullptr;
+    const int *st = (const int *)state;
     hipLaunchKernelGGL(tm_backward_kernel, dim3((n + TM_T - 1) / TM_T, (B + TM_T - 1) / TM_T), dim3(256), 0, (hipStream_t)stream,
                        z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n, add, st);
     const size_t near_lds = (size_t)B * (sizeof(float) + sizeof(unsigned short));

@@ -828,13 +828,14 @@ def time_matching_forward(z, tm, mode, w_a=0.0, w_t=0.0, w_n=0.0, margin=0.0, wa
     S = _new((2, B, B), z)
     nsl = lib.dm_time_matching_num_slabs(B)
     slabs = _new((nsl, 1, 2), z, torch.float64)
-    # the state word the backward call reads (the sparse form of mode 0: include/dynamorph_hip.h) travels with S as an
-    # attribute; an S that lost it (a copy, a slice) takes the dense form, which gives the same gradient
-    if not allow_sparse or mode != 0:                      # (mode 1 has no sparse form; tests / measurements: the dense form)
+    # the state block the backward call reads (the pair count of mode 0's sparse form and the map of S's nonzero blocks:
+    # include/dynamorph_hip.h) travels with S as an attribute; an S that lost it (a copy, a slice) takes the dense product,
+    # which gives the same gradient
+    if not allow_sparse:                                   # (tests / measurements: the stateless, dense form whatever tm holds)
         L.check(lib.dm_time_matching_forward(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),
                                              _ptr(slabs, torch.float64), _stream()), "dm_time_matching_forward")
         return (slabs, S) if want_slabs else (sum_slabs(slabs, _new((1,), z)), S)
-    state = torch.empty(4, dtype=torch.int32, device=z.device)
+    state = torch.empty(lib.dm_time_matching_state_ints(B), dtype=torch.int32, device=z.device)
     L.check(lib.dm_time_matching_forward_state(_ptr(z), _ptr(tm), B, n, mode, w_a, w_t, w_n, margin, _ptr(ws), wsf, _ptr(S),
                                                _ptr(slabs, torch.float64), _ptr(state, torch.int32), _stream()),
             "dm_time_matching_forward_state")

@@ -523,12 +523,16 @@ int dm_time_matching_backward(const float *z, const float *S, const float *g_los
  * `dz` itself).  The training step adds the pairwise term's gradient to the quantiser's without an elementwise pass. */
 int dm_time_matching_backward_add(const float *z, const float *S, const float *g_loss_dev, float scale, const float *add,
                                   float *dz, int B, int n, void *stream);
-/* The same pair with a STATE word the two calls share (4 int32 of caller memory, written by the forward call and read by
- * the kernels of both).  mode 0 (vq_vae.py:331: sum of sim * time_matching_mat) only needs the pairs with a nonzero entry,
- * and a batch's relation matrix holds a handful per row: the forward call counts them on the device, and at up to 32 per
- * row the Gram product and the gradient product are skipped -- every related pair is evaluated from differences (exactly,
- * as the reference does) and its gradient added row by row.  No host decision, the same launches either way (a captured
- * step stays valid whatever the matrix holds); mode 1, or a denser matrix, runs the dense form.  `add` may be NULL. */
+/* The same pair with a STATE block the two calls share (dm_time_matching_state_ints(B) int32 of caller memory, written by
+ * the forward call and read by the kernels of both).  (i) mode 0 (vq_vae.py:331: sum of sim * time_matching_mat) only needs
+ * the pairs with a nonzero entry, and a batch's relation matrix holds a handful per row: the forward call counts them on
+ * the device, and at up to 32 per row the Gram product is skipped -- every related pair is evaluated from differences
+ * (exactly, as the reference does) and its gradient added row by row.  (ii) In every mode the forward call marks which
+ * (64 rows x 32 columns) blocks of S hold a nonzero, and the gradient product multiplies only those: in the z16 / z32 form
+ * an unrelated pair beyond the hinge's margin has no gradient, so S is as sparse as the relation matrix once such pairs
+ * lie apart.  No host decision, the same launches either way (a captured step stays valid whatever the matrix holds), and
+ * the same sums to the bit as the stateless calls.  `add` may be NULL. */
+int dm_time_matching_state_ints(int B);
 int dm_time_matching_forward_state(const float *z, const float *tm, int B, int n, int mode, float w_a, float w_t, float w_n,
                                    float margin, float *workspace, int64_t workspace_floats, float *S, double *loss_slabs,
                                    int32_t *state, void *stream);

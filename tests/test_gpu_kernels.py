@@ -1382,6 +1382,44 @@ def test_time_matching_sparse_form(ops, B, n, frames):
     assert float(S2[0].abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("B,n,spread", [(200, 4096, 2.0), (513, 256, 2.0), (130, 1024, 0.3)])
+def test_time_matching_gradient_product_skips_empty_blocks(ops, B, n, spread):
+    """The z16 / z32 form (vae.py:327-336): every pair has a distance to evaluate, but an unrelated pair beyond the hinge's
+    margin has no gradient, so S is as sparse as the relation matrix once the latents lie apart (spread 2: sim ~ 8 > 1;
+    spread 0.3: most hinges active, S dense).  The forward call marks the nonzero (64 x 32) blocks of S and the gradient
+    product multiplies only those: bit-equal to the stateless product of the same S, and right against float64."""
+    g = torch.Generator().manual_seed(B)
+    z = torch.randn(B, n, generator=g) * spread
+    tm = torch.zeros(B, B)
+    for t0 in range(0, B - 7, 11):
+        for a in range(8):
+            z[t0 + a] = z[t0] + 0.4 * spread * torch.randn(n, generator=g)     # related, but not "near" (> 25 % apart)
+            for b in range(8):
+                if a != b:
+                    tm[t0 + a, t0 + b] = 2.0 if abs(a - b) == 1 else 1.0
+    ref, gref = _tm_reference(z, tm, 1)
+    zd, tmd = z.to(DEV), tm.to(DEV)
+    loss, S = ops.time_matching_forward(zd, tmd, 1, 1.1, 0.1, -0.5, 0.5)
+    assert abs(float(loss) - ref) <= 1e-5 * max(1.0, abs(ref))
+    nchunks, npanels = (B + 31) // 32, (B + 63) // 64
+    fmap = S._dm_tm_state[4:].cpu().numpy().reshape(npanels, nchunks)
+    marked, blocks = int((fmap != 0).sum()), npanels * nchunks
+    far = S[0].cpu()
+    for pnl in range(npanels):                                 # the map covers every nonzero of the far part
+        for c in range(nchunks):
+            if bool((far[64 * pnl:64 * pnl + 64, 32 * c:32 * c + 32] != 0).any()):
+                assert fmap[pnl, c] != 0, (pnl, c)
+    if spread > 1.0:
+        assert 0 < marked <= blocks // 2, (marked, blocks)    # far-apart latents: only the trajectories' blocks (along the diagonal)
+    else:
+        assert marked > blocks // 2
+    other = torch.randn(B, n, generator=g).to(DEV)
+    dz = ops.time_matching_backward(zd, S, None, 5.0, add=other)
+    assert torch.equal(dz, ops.time_matching_backward(zd, S.clone(), None, 5.0, add=other))   # (a copy of S: no state, every block)
+    want = gref * 5.0 + other.cpu().double()
+    assert (dz.cpu().double() - want).abs().max() <= 2e-5 * float(gref.abs().max()) * 5.0 + 1e-6 * float(other.abs().max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_zscore_patch_matches_numpy(ops, dtype):
     """pipeline/train_utils.py:252-274 zscore_patch (float64 numpy, population std, + eps) then .float()."""

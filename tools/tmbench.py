@@ -49,3 +49,19 @@ for B, n in ((2048, 4096), (768, 4096)):
         rec[name + "_backward_ms"] = round(t_ms(lambda: ops.time_matching_backward(z, S, None, 0.005)), 4)
         rec[name + "_loss"] = float(loss)
     print(json.dumps(rec), flush=True)
+
+# mode 1 (vae.py:327-336, what run_training.py's main trains) on the same relation matrix with latents that lie apart (unit-
+# variance elements: sim ~ 2 > margin / |w_n| = 1, every unrelated hinge inactive): the gradient product multiplies only the
+# blocks of S the forward call marked
+for B, n in ((2048, 4096), (768, 65536)):
+    z = torch.randn(B, n, device=dev)
+    i = torch.arange(B, device=dev)
+    same = (i[:, None] // 8) == (i[None, :] // 8)
+    tm = torch.where(same & (i[:, None] != i[None, :]), torch.where((i[:, None] - i[None, :]).abs() == 1, 2.0, 1.0), 0.0).float()
+    loss, S = ops.time_matching_forward(z, tm, 1, 1.1, 0.1, -0.5, 0.5)
+    rec = {"B": B, "n": n, "mode": 1, "relation_entries_per_row": 7.0,
+           "forward_ms": round(t_ms(lambda: ops.time_matching_forward(z, tm, 1, 1.1, 0.1, -0.5, 0.5)), 4),
+           "backward_marked_blocks_ms": round(t_ms(lambda: ops.time_matching_backward(z, S, None, 0.005)), 4)}
+    Sd = S.clone()
+    rec["backward_every_block_ms"] = round(t_ms(lambda: ops.time_matching_backward(z, Sd, None, 0.005)), 4)
+    print(json.dumps(rec), flush=True)
