@@ -768,6 +768,34 @@ def test_fused_trainer_time_matching(z16, use_graph):
         close(v, sd_r[k], 0, 2.5e-4 if "running" not in k else 2e-5, k)
 
 
+def test_captured_step_follows_the_relation_matrix_between_sparse_and_dense():
+    """The pairwise term chooses its form on the device (related pairs counted per call: sparse up to 32 per row, else the
+    dense products), so ONE captured step serves whatever matrix the feed writes into its buffer: a graph replayed with a
+    sparse, then a dense, then a sparse matrix again ends bit-equal to the eager trainer on the same sequence."""
+    import copy
+    import dynamorph_amd
+    from dynamorph_amd.train import FusedTrainer
+    torch.manual_seed(4)
+    m_g = dynamorph_amd.VQ_VAE().to(DEV)
+    m_e = copy.deepcopy(m_g)
+    B = 72
+    g = torch.Generator().manual_seed(12)
+    xs = [torch.randn(B, 2, 128, 128, generator=g).to(DEV) for _ in range(3)]
+    sparse = torch.zeros(B, B)
+    for i in range(B - 1):
+        if i % 8 != 7:
+            sparse[i, i + 1] = sparse[i + 1, i] = 2.0
+    dense = (torch.rand(B, B, generator=g) < 0.7).float() * torch.randint(1, 3, (B, B), generator=g).float()    # ~50 per row
+    assert int((dense != 0).sum()) > 32 * B >= int((sparse != 0).sum())
+    tms = [sparse.to(DEV), dense.to(DEV), sparse.to(DEV)]
+    tg, te = FusedTrainer(m_g, lr=1e-4, use_graph=True), FusedTrainer(m_e, lr=1e-4, use_graph=False)
+    for x, tm in zip(xs, tms):
+        vg, ve = tg.step(x, None, tm), te.step(x, None, tm)
+        assert torch.equal(vg, ve), (vg.tolist(), ve.tolist())
+    for (k, a), (_, b) in zip(m_g.state_dict().items(), m_e.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("kw,B,with_tm", [({}, 6, True), (dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512), 3, False)])
 def test_graphed_trainer_z32_equals_eager_adam(kw, B, with_tm):
     """GraphedTrainer (the autograd step of VQ_VAE_z32 replayed as a HIP graph, capturable Adam) against the same module
