@@ -161,7 +161,15 @@ __global__ __launch_bounds__(256) void tm_count_kernel(const float *__restrict__
 {
     __shared__ int s_cnt[4];
     int c = 0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < BB; e += (long long)gridDim.x * 256) c += tm[e] != 0.f;
+    if ((BB & 3) == 0) {                                   // 16 bytes per lane and step
+        const f32x4 *__restrict__ t4 = reinterpret_cast<const f32x4 *>(tm);
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (BB >> 2); e += (long long)gridDim.x * 256) {
+            const f32x4 v = t4[e];
+            c += (int)(v.x != 0.f) + (int)(v.y != 0.f) + (int)(v.z != 0.f) + (int)(v.w != 0.f);
+        }
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < BB; e += (long long)gridDim.x * 256) c += tm[e] != 0.f;
+    }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -507,6 +515,23 @@ __global__ __launch_bounds__(256) void tm_backward_kernel(const float *__restric
         if (q == 0) s_rs[r] = (s_part[threadIdx.x] + s_part[threadIdx.x + 1]) + (s_part[threadIdx.x + 2] + s_part[threadIdx.x + 3]);
         __syncthreads();                                    // (with no chunk to multiply nothing else stands before their use)
     }
+    if (nl == 0 && ((((uintptr_t)dz | (uintptr_t)add) & 15) == 0)) {
+        // (uniform) nothing marked for these rows -- the sparse form, or a panel of unrelated samples: dz = add + 0 * z, the
+        // value the general path below would store (a zero row sum times a finite latent), 16 bytes per lane, z not read
+        for (int e = threadIdx.x; e < TM_T * (TM_T / 4); e += 256) {
+            const int i = i0 + e / (TM_T / 4), d = d0 + 4 * (e % (TM_T / 4));
+            if (i < B && d < n) {
+                const long long o = (long long)i * n + d;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (add) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(add + o);
+                    v = (f32x4){__fadd_rn(a4.x, 0.f), __fadd_rn(a4.y, 0.f), __fadd_rn(a4.z, 0.f), __fadd_rn(a4.w, 0.f)};
+                }
+                *reinterpret_cast<f32x4 *>(dz + o) = v;
+            }
+        }
+        return;
+    }
     f32x4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -659,7 +684,8 @@ static int tm_forward_launch(const float *z, const float *tm, int B, int n, int 
         far_map = (int *)state + TM_STATE_HDR;
         if (mode == 0) {
             const long long BB = (long long)B * B;
-            const int grid = (int)((BB + 255) / 256 < 1024 ? (BB + 255) / 256 : 1024);
+            const long long units = (BB & 3) == 0 ? BB >> 2 : BB;
+            const int grid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
             hipLaunchKernelGGL(tm_count_kernel, dim3(grid), dim3(256), 0, s, tm, BB, (int *)state);
             st = (const int *)state;
         }
