@@ -129,6 +129,10 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     used = lib.dm_augment_codes(raw.ctypes.data, len(raw), 2, fl.ctypes.data, ro.ctypes.data)
     assert used == 6 and fl.tolist() == [1, 0] and ro.tolist() == [2, 3]
     assert lib.dm_augment_codes(raw.ctypes.data, 3, 2, fl.ctypes.data, ro.ctypes.data) == -1      # ran out of words
+    assert lib.dm_time_matching_forward_state(None, None, 4, 32, 0, 0.0, 0.0, 0.0, 0.0, None, 0, None, None, None, None) == -1
+    assert lib.dm_time_matching_backward_state(None, None, None, 1.0, None, None, 4, 32, None, None) == -1
+    assert lib.dm_time_matching_state_ints(2048) == 4 + 32 * 64 and lib.dm_time_matching_state_ints(1) == 5
+    assert lib.dm_time_matching_num_slabs(2048) == 4 * (32 * 33 // 2) and lib.dm_time_matching_num_slabs(64) == 16
     assert lib.dm_reorder_with_trajectories(None, 0, 1, None, None, None, None) == -4
     # three samples, 0 <-> 2 adjacent: words & 3 = 3 (rejected), 1 -> second of {0, 1, 2} = 1 alone; then {0, 2}: word & 1 = 1
     # -> 2, followed by its trajectory [2, 0]
