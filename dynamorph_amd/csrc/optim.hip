@@ -153,6 +153,54 @@ __global__ __launch_bounds__(256) void zscore_patch_kernel(const T *__restrict__
     for (int i = threadIdx.x; i < HW; i += blockDim.x) q[i] = (float)(((double)p[i] - mean) / denom);
 }
 
+// Dataset-wide per-channel z-score with GIVEN statistics (pipeline/train_utils.py:228-250 zscore as run_training.py:880 calls it,
+// followed by .astype(np.float32)): out = float((x - mean[c]) / denom[c]), denom = std + eps formed by the caller the way numpy
+// forms it.  TD / TQ: the types numpy's promotion rules give the difference and the quotient -- double throughout for a float64
+// dataset; for a float32 dataset and Python-float statistics the difference stays float32 and the quotient, divided by
+// `std + np.finfo(float).eps` (a float64 scalar), is float64 under NumPy 2 and float32 under NumPy 1: the caller asks numpy.
+// 16 bytes of output per lane; an element's channel from its plane index.
+template <typename TIN, typename TD, typename TQ>
+__global__ __launch_bounds__(256) void zscore_channels_kernel(const TIN *__restrict__ in, float *__restrict__ out,
+                                                              const double *__restrict__ mean, const double *__restrict__ denom,
+                                                              long long total4, int C, long long HW4)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i / HW4) % C);
+        const TD m = (TD)mean[c];
+        const TQ d = (TQ)denom[c];
+        const TIN *p = in + 4 * i;
+        // (IEEE operations, by name: a float `/` may come out as a reciprocal and a multiplication)
+        auto q = [m, d](TIN v) {
+            TD diff;
+            if constexpr (sizeof(TD) == 8) diff = __dsub_rn((double)v, (double)m); else diff = __fsub_rn((float)v, (float)m);
+            if constexpr (sizeof(TQ) == 8) return (float)__ddiv_rn((double)diff, (double)d);
+            else return __fdiv_rn((float)diff, (float)d);
+        };
+        f32x4 o;
+        o.x = q(p[0]); o.y = q(p[1]); o.z = q(p[2]); o.w = q(p[3]);
+        *reinterpret_cast<f32x4 *>(out + 4 * i) = o;
+    }
+}
+
+extern "C" int dm_zscore_channels(const void *in, int in_is_f64, int diff_f64, int quot_f64, float *out, const double *mean,
+                                  const double *denom, int64_t N, int C, int64_t HW, void *stream)
+{
+    DM_REQUIRE(in && out && mean && denom && N > 0 && C > 0 && HW > 0, "dm_zscore_channels: bad argument");
+    DM_REQUIRE(HW % 4 == 0, "dm_zscore_channels: H * W must be a multiple of 4");
+    DM_REQUIRE((diff_f64 || !in_is_f64) && (quot_f64 || !diff_f64), "dm_zscore_channels: types only widen (input <= difference <= quotient)");
+    const long long total4 = (long long)N * C * (HW / 4), HW4 = HW / 4;
+    const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+#define DM_ZS(TIN, TD, TQ) hipLaunchKernelGGL((zscore_channels_kernel<TIN, TD, TQ>), dim3(grid), dim3(256), 0, s, (const TIN *)in, out, \
+                                              mean, denom, total4, C, HW4)
+    if (in_is_f64) DM_ZS(double, double, double);
+    else if (diff_f64) DM_ZS(float, double, double);
+    else if (quot_f64) DM_ZS(float, float, double);
+    else DM_ZS(float, float, float);
+#undef DM_ZS
+    return dm_launch_status("dm_zscore_channels");
+}
+
 extern "C" int dm_adam(float *param, const float *grad, float *m, float *v, int64_t n,
                        float lr, float beta1, float beta2, float eps, const float *step_dev, void *stream)
 {

@@ -39,6 +39,27 @@ def dataset_tensor(dataset):
     return None
 
 
+def upload_zscored(raw, channel_mean, channel_std, device, chunk_bytes=1 << 29):
+    """What run_training.py:880 makes of a pickled dataset -- zscore(np.squeeze(dataset), channel_mean, channel_std)
+    .astype(np.float32) -- as a DEVICE tensor, without the host passes: the raw float64 / float32 patches go up in chunks
+    and are z-scored there (dm_zscore_channels, bit-equal to the numpy expression).  `raw`: (N, C, H, W) or
+    (N, C, 1, H, W) numpy array or host tensor.  The result can be handed to train() as the dataset: the resident feed uses
+    a device tensor where it lies."""
+    t = torch.as_tensor(raw)
+    if t.dim() == 5 and t.shape[2] == 1:
+        t = t[:, :, 0]
+    if t.dim() != 4 or t.dtype not in (torch.float64, torch.float32):
+        raise ValueError("upload_zscored: an (N, C, [1,] H, W) float64 or float32 array")
+    dev = torch.device(device)
+    out = torch.empty(tuple(t.shape), dtype=torch.float32, device=dev)
+    rows = max(1, chunk_bytes // max(1, t[0].numel() * t.element_size()))
+    with torch.cuda.device(dev):
+        for lo in range(0, t.shape[0], rows):
+            part = t[lo:lo + rows].contiguous().to(dev)
+            ops.zscore_channels(part, channel_mean, channel_std, out=out[lo:lo + rows])
+    return out
+
+
 def mask_plane(mask_tensor):
     """run_training.py:371-372 for every sample at once: the second mask channel (the large mask), {-1, 1} -> {0, 1}."""
     m = mask_tensor[:, 1:2, :, :]
@@ -116,7 +137,10 @@ class Feed:
     # ------------------------------------------------------------------------------------------ resident
     def _upload(self, t, chunk_bytes=1 << 29):
         """Host tensor -> fp32 device tensor in chunks (a pinned source goes at the link rate; a pageable one through the
-        runtime's staging; another dtype is converted on the way)."""
+        runtime's staging; another dtype is converted on the way).  A contiguous fp32 tensor already on this device (e.g.
+        from upload_zscored) is used where it lies."""
+        if t.is_cuda and t.device == self.dev and t.dtype == torch.float32 and t.is_contiguous():
+            return t
         out = torch.empty(tuple(t.shape), dtype=torch.float32, device=self.dev)
         rows = max(1, chunk_bytes // max(1, t[0].numel() * t.element_size()))
         nb = t.is_pinned() and t.dtype == torch.float32           # (anything else is staged by the runtime: blocking)

@@ -917,6 +917,42 @@ def adam_counted(param, grad, m, v, lr, beta1, beta2, eps, steps_done, steps_don
 
 
 @_op
+def zscore_channels(x, channel_mean, channel_std, out=None):
+    """float32(zscore(x, channel_mean, channel_std)) of pipeline/train_utils.py:228-250 for an (N, C, H, W) float64 or
+    float32 DEVICE tensor and GIVEN per-channel statistics (lists of Python floats, as the reference's config supplies them,
+    or numpy scalars / arrays): bit-equal to the numpy expression followed by .astype(np.float32) -- the type numpy would
+    compute in and the value of std + eps are worked out on the host with numpy itself."""
+    import numpy as np
+    lib = L.load()
+    if x.dtype not in (torch.float64, torch.float32):
+        raise ValueError("dm_zscore_channels: float64 or float32 input")
+    x = x.contiguous()
+    N, Cn, H, W = x.shape
+    if len(channel_mean) != Cn or len(channel_std) != Cn:
+        raise ValueError("dm_zscore_channels: one mean and one std per channel")
+    np_dt = np.float64 if x.dtype == torch.float64 else np.float32
+    mean, denom = np.empty(Cn), np.empty(Cn)
+    dts, qts = set(), set()
+    for c in range(Cn):
+        diff = np.zeros(1, np_dt) - channel_mean[c]              # numpy's own promotion rules decide the types
+        den = channel_std[c] + np.finfo(float).eps                # (the reference's expression: a float64 scalar)
+        quot = diff / den
+        dts.add(diff.dtype); qts.add(quot.dtype)
+        mean[c] = float(np.asarray(channel_mean[c]).astype(diff.dtype))      # the scalars as the array operations see them
+        denom[c] = float(np.asarray(den).astype(quot.dtype))
+    if len(dts) != 1 or len(qts) != 1 or not dts <= {np.dtype(np.float32), np.dtype(np.float64)}:
+        raise ValueError("dm_zscore_channels: statistics of mixed / unsupported types")
+    diff_f64, quot_f64 = dts.pop() == np.float64, qts.pop() == np.float64
+    md = torch.from_numpy(np.stack([mean, denom])).to(x.device)
+    if out is None:
+        out = torch.empty((N, Cn, H, W), dtype=torch.float32, device=x.device)
+    L.check(lib.dm_zscore_channels(C.c_void_p(x.data_ptr()), 1 if x.dtype == torch.float64 else 0, 1 if diff_f64 else 0,
+                                   1 if quot_f64 else 0, _ptr(out), C.c_void_p(md[0].data_ptr()), C.c_void_p(md[1].data_ptr()),
+                                   N, Cn, H * W, _stream()), "dm_zscore_channels")
+    return out
+
+
+@_op
 def zscore_patch(x):
     """x (N, C, H, W) float64 or float32 device tensor -> float32 z-scored patches (per patch and channel)."""
     lib = L.load()

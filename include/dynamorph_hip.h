@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 123
+#define DM_VERSION 124
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -571,6 +571,14 @@ int dm_adam_counted(float *param, const float *grad, float *m, float *v, int64_t
  * (patch, channel) planes, arithmetic in double; `in` is float64 (in_is_f64 = 1, what the reference z-scores) or
  * float32. */
 int dm_zscore_patch(const void *in, int in_is_f64, float *out, int planes, int HW, void *stream);
+/* Dataset-wide per-channel z-score with given statistics, then the cast to float32 (pipeline/train_utils.py:228-250 as
+ * run_training.py:880 applies it to the pickled patches before train()): out[n][c][.] = float((in - mean[c]) / denom[c]),
+ * in: (N, C, H*W) float64 or float32, mean / denom: C doubles on the device, denom = std + eps as numpy forms it.
+ * diff_f64 / quot_f64: the types numpy's expression gives the difference and the quotient (a float32 dataset against
+ * Python-float statistics: float32 difference; its quotient by `std + np.finfo(float).eps` is float64 under NumPy 2 and
+ * float32 under NumPy 1).  Bit-equal to the numpy expression. */
+int dm_zscore_channels(const void *in, int in_is_f64, int diff_f64, int quot_f64, float *out, const double *mean,
+                       const double *denom, int64_t N, int C, int64_t HW, void *stream);
 
 /* ===== on-device augmentation (run_training.py:396-403) ======================= */
 /* out[b] = rot90(flip(in[b], flip_code[b]), k = rot_code[b]) on square (C,H,H) patches;

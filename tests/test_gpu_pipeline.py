@@ -352,3 +352,57 @@ def test_encode_patches_on_a_device_that_is_not_current():
     b = encode_patches(m1, x, device="cuda:1", batch_size=2)
     assert torch.cuda.current_device() == 0
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------------------------ the dataset side of train(): run_training.py:880
+@pytest.mark.parametrize("dtype,stats", [("float64", "list"), ("float32", "list"), ("float32", "np64"), ("float64", "np32")])
+def test_zscore_channels_is_numpy_bit_for_bit(dtype, stats):
+    """pipeline/train_utils.py:228-250 with given statistics, then .astype(np.float32) (run_training.py:880): the device
+    expression runs in the type numpy's promotion rules pick (float32 stays float32 against Python floats, goes to double
+    against float64 scalars) and lands on the same bits."""
+    from dynamorph_amd import ops
+    from dynamorph_amd import train_utils as TU
+    rng = np.random.default_rng(3)
+    raw = (rng.normal(0.3, 0.2, (37, 2, 32, 32)) * np.array([1.0, 300.0]).reshape(1, 2, 1, 1)).astype(dtype)
+    mean, std = [0.4, 37.125], [0.05, 11.3]
+    if stats == "np64":
+        mean, std = list(np.array(mean, np.float64)), list(np.array(std, np.float64))
+    elif stats == "np32":
+        mean, std = list(np.array(mean, np.float32)), list(np.array(std, np.float32))
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        want = TU.zscore(raw, mean, std).astype(np.float32)
+    got = ops.zscore_channels(torch.from_numpy(raw).to(DEV), mean, std).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_upload_zscored_feeds_train_from_the_device(tmp_path):
+    """feed.upload_zscored: the pickled (N, C, 1, H, W) float64 patches z-scored on the device equal the host expression of
+    run_training.py:880 bit for bit, and train() takes the device tensor as its dataset (resident feed, used where it lies)
+    with the same result as from the host copy."""
+    import contextlib, copy, io
+    import dynamorph_amd
+    from dynamorph_amd import feed as F
+    from dynamorph_amd import train_utils as TU
+    from dynamorph_amd.train import train
+    rng = np.random.default_rng(5)
+    raw = rng.normal(0.5, 0.1, (24, 2, 1, 128, 128))
+    mean, std = [0.49, 0.51], [0.11, 0.09]
+    with contextlib.redirect_stdout(io.StringIO()):
+        host = TU.zscore(np.squeeze(raw), mean, std).astype(np.float32)
+    dev_t = F.upload_zscored(raw, mean, std, DEV, chunk_bytes=5 * 2 * 128 * 128 * 8)      # (several ragged chunks)
+    assert dev_t.is_cuda and dev_t.dtype == torch.float32 and np.array_equal(dev_t.cpu().numpy(), host)
+    torch.manual_seed(0)
+    m0 = dynamorph_amd.VQ_VAE().to(DEV)
+    out = {}
+    for name, data in (("host", torch.utils.data.TensorDataset(torch.from_numpy(host))), ("device", torch.utils.data.TensorDataset(dev_t))):
+        m = copy.deepcopy(m0)
+        np.random.seed(9)
+        st = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            train(m, data, str(tmp_path / name), n_epochs=2, lr=1e-3, batch_size=8, device=DEV, transform=True,
+                  val_split_ratio=0.25, patience=5, feed="resident", stats=st)
+        assert st["feed"] == "resident"
+        out[name] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, v in out["host"].items():
+        assert torch.equal(v, out["device"][k]), k
