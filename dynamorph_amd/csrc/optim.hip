@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void zscore_channels_kernel(const TIN *__restr
         const TD m = (TD)mean[c];
         const TQ d = (TQ)denom[c];
         const TIN *p = in + 4 * i;
-        // (IEEE operations, by name: a float `/` may come out as a reciprocal and a multiplication)
+        // (IEEE operations, by name: no compiler setting turns these into a reciprocal and a multiplication)
         auto q = [m, d](TIN v) {
             TD diff;
             if constexpr (sizeof(TD) == 8) diff = __dsub_rn((double)v, (double)m); else diff = __fsub_rn((float)v, (float)m);
