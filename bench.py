@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- cell-patches/s of the VQ-VAE hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N fresh ranks itself, dynamorph_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          (the same ranks started from outside)
 
 A "step" is one pass of the hot path over one batch of synthetic 2x128x128 fp32 patches that is already
 resident in HBM.  Default workload = BASELINE.json configs[2]/[3]: one TRAINING step (forward + backward +
@@ -71,7 +71,7 @@ def pmc_traffic(kernel_key, batch):
     itself).  None when no measurement for this kernel and batch has been committed."""
     stem = {"dec_tail_train": "dec_tail_backward_kernel", "conv4x4s2_e1": "conv4x4s2_kernel"}.get(
         kernel_key, kernel_key.split("_k4096")[0].replace("vq_forward_mfma", "vq_forward_mfma_kernel"))
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(kernel_key)
@@ -83,18 +83,23 @@ def pmc_traffic(kernel_key, batch):
     return None
 
 
-def profile_avg_us(kernel_stem, stats_csv="r04_c3_b2048_kernel_stats.csv"):
-    """Average per-dispatch duration (us) of a kernel inside the step, from this round's committed `rocprofv3 --kernel-trace
-    --stats` summary of `bench.py` (bench.py cannot run under the profiler itself); None when it is not committed."""
+PROFILE_STATS = ("r05_c3_b2048_kernel_stats.csv", "r04_c3_b2048_kernel_stats.csv")
+
+
+def profile_avg_us(kernel_stem):
+    """(average per-dispatch duration in us, file) of a kernel inside the step from the newest committed `rocprofv3
+    --kernel-trace --stats` summary of `bench.py` -- a RECORD of an earlier build, reported beside the live measurement under
+    its own name and never in place of it; (None, None) when there is none."""
     import csv
-    try:
-        with open(os.path.join(ROOT, "profiles", stats_csv)) as f:
-            for r in csv.DictReader(f):
-                if kernel_stem in r["Name"]:
-                    return round(float(r["AverageNs"]) / 1e3, 2)
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    for name in PROFILE_STATS:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                for r in csv.DictReader(f):
+                    if kernel_stem in r["Name"]:
+                        return round(float(r["AverageNs"]) / 1e3, 2), name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 EXAMPLE_CONFIG = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)     # config_example.yml:157-163
@@ -269,17 +274,16 @@ def north_star_targets(model, x):
     torch.cuda.synchronize()
     d_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev[4:])
     d_ms = d_ms[len(d_ms) // 2]                                # median of 20
-    prof_us = profile_avg_us("vq_forward_mfma_kernel<16, true, 3, true, true, false>")
+    prof_us, prof_file = profile_avg_us("vq_forward_mfma_kernel<16, true, 3, true, true, false>")
     f_ev = round(vq_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     f_prof = round(vq_bytes / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof_us else None
     vq = {"kernel": "vq_forward_mfma_kernel (MFMA filter + exact re-check)", "bytes": vq_bytes,
-          # per dispatch: the kernel's average duration inside the step from this round's committed rocprofv3 summary when
-          # there is one, else the live event interval (which also holds the event records' own few microseconds)
-          "frac_hbm": f_prof if f_prof else f_ev,
-          "frac_hbm_is": ("per dispatch inside the step: profiles/r04_c3_b2048_kernel_stats.csv average" if f_prof else
-                          "per dispatch: events around single launches behind their producer (median of 20)"),
-          "profile_avg_us": prof_us, "frac_hbm_profile": f_prof,
-          "dispatch_ms_events": round(d_ms, 5), "frac_hbm_events": f_ev,
+          # LIVE, per dispatch: events on the launch stream around single launches behind their producer (the interval also
+          # holds the event records' own few microseconds); the committed profile's average is a record beside it
+          "frac_hbm": f_ev,
+          "frac_hbm_is": "live, per dispatch: events around single launches behind their producer (median of 20)",
+          "dispatch_ms_events": round(d_ms, 5),
+          "frac_hbm_profile": f_prof, "profile_avg_us": prof_us, "profile_file": prof_file,
           "back_to_back_launch_ms": round(k_ms, 5),
           "frac_hbm_back_to_back": round(vq_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "call_ms": round(call_ms, 5),
           "call_frac_hbm": round(vq_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -302,15 +306,16 @@ def north_star_targets(model, x):
         j_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev[4:])
         j_ms = j_ms[len(j_ms) // 2]
         j_bytes = P * (4 * D * 4 + 8)
-        j_prof = profile_avg_us("vq_forward_mfma_kernel<16, true, 3, true, true, true>")
+        j_prof, j_file = profile_avg_us("vq_forward_mfma_kernel<16, true, 3, true, true, true>")
         jf_ev = round(j_bytes / (j_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         jf_prof = round(j_bytes / (j_prof * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if j_prof else None
         vq["in_step"] = {"kernel": "vq_forward_mfma_kernel<16, true, 3, true, true, JOIN> (dm_vq_forward_join: residual join + distance + "
                                    "argmin + gather + straight-through value + squared error + code counters)",
                          "bytes": j_bytes, "bytes_are": "rb + h_in read, z + quantised written (4 x 16 384 B per patch) + int64 codes",
-                         "frac_hbm": jf_prof if jf_prof else jf_ev, "profile_avg_us": j_prof, "frac_hbm_profile": jf_prof,
-                         "dispatch_ms_events": round(j_ms, 5), "frac_hbm_events": jf_ev,
-                         "vq_only_bytes_frac_hbm": round(vq_bytes / ((j_prof * 1e-6) if j_prof else (j_ms * 1e-3)) / 1e9 / HBM_PEAK_GBS, 4)}
+                         "frac_hbm": jf_ev, "frac_hbm_is": "live, per dispatch (events, median of 20)",
+                         "dispatch_ms_events": round(j_ms, 5),
+                         "frac_hbm_profile": jf_prof, "profile_avg_us": j_prof, "profile_file": j_file,
+                         "vq_only_bytes_frac_hbm": round(vq_bytes / (j_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del rb_src, h_src, rb_b, h_b
     del pad, z_src
     # ---- encoder forward convolutions, on the step's own activations
@@ -648,6 +653,12 @@ def cpu_baseline(workload, budget_s=25.0):
 
 def main():
     args = parse()
+    from dynamorph_amd import launch
+    if args.gpus > 1 and not launch.launched():
+        # started as a plain `python bench.py --gpus N`: this process stays off the GPU, starts N fresh ranks
+        # (torch.distributed.run, one per GPU), forwards rank 0's JSON line and leaves with the job's exit code
+        launch.check_devices(args.gpus)
+        sys.exit(launch.self_launch(__file__, sys.argv[1:], args.gpus))
     from dynamorph_amd import VQ_VAE
     from dynamorph_amd import dist as D
     from dynamorph_amd import engine as E
@@ -656,8 +667,8 @@ def main():
 
     rank, world, local = D.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    local = local % max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree")
+    local = local % max(torch.cuda.device_count(), 1)      # (gloo rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B = args.batch or {"c3": 2048, "c2": 1024, "c5": 1024, "z32ex": 768}[args.workload]

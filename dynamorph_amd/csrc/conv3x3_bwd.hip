@@ -250,8 +250,8 @@ extern "C" int dm_conv3x3_bwd_fused(const dm_operand *dy, const float *x, const 
     if (d.mode == DM_LOAD_IDENT) { d.coef = nullptr; d.p1 = nullptr; }
     const int grid = dm_conv3x3_bwd_fused_num_blocks(B, CD, CX, H, W);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DmPerDeviceOnce attr_done;
+    if (attr_done.need()) {
         hipError_t e = hipFuncSetAttribute((const void *)conv3x3_bwd_kernel<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)conv3x3_bwd_lds(32));
         if (e == hipSuccess)
@@ -261,7 +261,7 @@ extern "C" int dm_conv3x3_bwd_fused(const dm_operand *dy, const float *x, const 
             dm_set_error("dm_conv3x3_bwd_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return (int)e;
         }
-        attr_done = true;
+        attr_done.mark();
     }
     if (CD == 32)
         hipLaunchKernelGGL((conv3x3_bwd_kernel<32, 512>), dim3(grid), dim3(512), conv3x3_bwd_lds(32), st, d, x, xcoef, w, resid, q, dx,

@@ -216,15 +216,15 @@ extern "C" int dm_conv4x4s2_bwd_fused(const dm_operand *dy, const float *x, cons
     DM_REQUIRE(dy->coef_bstride == 0 && !dy->ones_channel, "dm_conv4x4s2_bwd_fused: shared coefficients only");
     Operand d = to_dev(dy);
     if (d.mode == DM_LOAD_IDENT) { d.coef = nullptr; d.p1 = nullptr; }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DmPerDeviceOnce attr_done;
+    if (attr_done.need()) {
         const hipError_t e = hipFuncSetAttribute((const void *)conv4x4s2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)S2_LDS_BYTES);
         if (e != hipSuccess) {
             dm_set_error("dm_conv4x4s2_bwd_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return (int)e;
         }
-        attr_done = true;
+        attr_done.mark();
     }
     const int grid = dm_conv4x4s2_bwd_fused_num_blocks(B, CD, CX, H, W);
     hipLaunchKernelGGL(conv4x4s2_bwd_kernel, dim3(grid), dim3(S2_NTH), S2_LDS_BYTES, (hipStream_t)stream, d, x, xcoef, w, dx, stats,
@@ -382,12 +382,12 @@ bool dm_conv4x4s2_patch_forward(const Operand &in, const WeightView &wv, float *
     if (off || CIN != 16 || Cphys != 16 || NOUT != 16 || H != 32 || W != 32) return false;
     if (in.mode == DM_LOAD_AFFINE2 || in.ones || ep.mask.p0 || ep.resid || ep.stat_q || ep.bias_border) return false;
     if (per_tile && (!ep.stats || nslabs % B != 0)) return false;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DmPerDeviceOnce attr_done;
+    if (attr_done.need()) {
         const hipError_t e = hipFuncSetAttribute((const void *)conv4x4s2_patch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)F2_LDS_BYTES);
         if (e != hipSuccess) return false;
-        attr_done = true;
+        attr_done.mark();
     }
     const int grid = B < 256 ? B : 256;
     hipLaunchKernelGGL(conv4x4s2_patch_forward_kernel, dim3(grid), dim3(S2_NTH), F2_LDS_BYTES, stream, in, wv, ep.bias, ep.relu, out,

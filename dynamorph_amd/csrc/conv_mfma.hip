@@ -1566,7 +1566,14 @@ static int fused_bwd_block()
 static int g_backward_split = -1;
 bool dm_backward_split_bf16()
 {
-    if (g_backward_split < 0) { const char *e = getenv("DM_BACKWARD_PRECISION"); g_backward_split = (e && e[0] == 's') ? 1 : 0; }
+    if (g_backward_split < 0) {
+        const char *e = getenv("DM_BACKWARD_PRECISION");
+        g_backward_split = (e && e[0] == 's') ? 1 : 0;
+        // an environment variable that changes results says so, once
+        if (g_backward_split)
+            fprintf(stderr, "libdynamorph_hip: DM_BACKWARD_PRECISION=%s -- gradient products run on split-bf16 operands "
+                            "(~2^-17 relative per product, not the fp32 chain); forward pass and codes unchanged\n", e);
+    }
     return g_backward_split != 0;
 }
 extern "C" int dm_backward_precision(int mode)
@@ -1611,8 +1618,8 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
                "dm_conv_bwd_s2_fused: the epilogue must mask by (and take its statistics against) the layer input");
     if (dm_check_operand(&ep->mask, "dm_conv_bwd_s2_fused(mask)")) return -1;
     using G = FusedBwdGeom<16, 8, 8, 32>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DmPerDeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 512, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e == hipSuccess)
@@ -1625,7 +1632,7 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
             e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
         if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
+        attr_set.mark();
     }
     const int ntiles = B * (H / 8) * (W / 32);
     const int grid = dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W);

@@ -279,6 +279,19 @@ __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const 
     }
 }
 
+#ifdef DM_MEASURE
+#define DT_DBG_PARAM , int dbg
+#define DT_DBG_ARG , tail_dbg()
+static int tail_dbg()
+{
+    static const int v = [] { const char *e = getenv("DM_DEC_TAIL_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+#else
+#define DT_DBG_PARAM
+#define DT_DBG_ARG
+#endif
+
 // ================================================================================== backward
 // FUSED (training pass, dm_dec_tail_train): decoded is not read but formed in phase B from the recomputed d4 tile
 // (dec.6 is 1x1), the reconstruction-loss partials are taken there too, and `decoded` never exists in HBM.
@@ -290,8 +303,15 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                               const float *__restrict__ mask, int MC, const float *__restrict__ cvar,
                               const float *__restrict__ gscale_dev, float *__restrict__ g2, double *__restrict__ part,
                               float *__restrict__ wslabs, int H2, int ntiles, double inv_count, int nslabs, int W2arg,
-                              int tiles_x)
+                              int tiles_x DT_DBG_PARAM)
 {
+#ifndef DM_MEASURE
+    constexpr int dbg = 0;
+#endif
+    // dbg (DM_DEC_TAIL_DBG, measurement build only; results are then wrong, the time is what is read): 1 no phase A products,
+    // 2 no phase B, 4 no phase 3 (data gradient), 8 no phase 4 (weight-gradient matrix instructions), 16 no loads / commits
+    // after the first tile, 32 no workgroup barriers inside the tile loop
+#define DT_SYNC() do { if (!(dbg & 32)) __syncthreads(); } while (0)
     constexpr int AROWS = TT_TH + 4, APS = AROWS * TT_W + 4;     // d2 rows y0-2 .. y0+TH+1
     constexpr int GROWS = 2 * TT_TH + 2, GPS = GROWS * TT_DRS;   // g4 rows 2*y0-1 .. 2*y0+2*TH ; col j <-> ox = j - 4
     constexpr int NP = NIN * TT_C + NIN + TT_C + TT_C;           // dW6 | db6 | db4 | db2
@@ -402,17 +422,20 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     }
     double loss = 0.0;
 
+    bool first_tile = true;
     while (tidx < ntiles) {
-        __syncthreads();                                   // previous tile done with sA and sG
-        stage.template commit<false, true>(sA, s_coef, TT_C, H2, W2, y0 - 2, x0, DM_LOAD_IDENT);   // 192 staging threads: waves 0..2
-        __syncthreads();
+        DT_SYNC();                                         // previous tile done with sA and sG
+        if (!(dbg & 16) || first_tile)
+            stage.template commit<false, true>(sA, s_coef, TT_C, H2, W2, y0 - 2, x0, DM_LOAD_IDENT);   // 192 staging threads: waves 0..2
+        first_tile = false;
+        DT_SYNC();
         const int cb = b, cy0 = y0, cx0 = x0;
         const int colx = x0 + lane;                        // this lane's d2 column (WIDE: may be halo / outside the image)
         const bool colin = !WIDE || (unsigned)colx < (unsigned)W2;
         const bool ownl = !WIDE || (lane >= TT_HALO && lane < TT_W - TT_HALO && colx < W2);
         const int next = tidx + gridDim.x;
         if (next < ntiles) tile_of(next, b, y0, x0);
-        const auto scx = stage.begin(in, next < ntiles, b, TT_C, H2, W2, y0 - 2, x0);   // requested during phase A
+        const auto scx = stage.begin(in, next < ntiles && !(dbg & 16), b, TT_C, H2, W2, y0 - 2, x0);   // requested during phase A
 
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
         {
@@ -432,20 +455,22 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             C = N;
             if (pr < TT_TH) load_row(sA, APS, pr + 3, lane, N);
             __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 1)) {
             f32x2 lo, hi;
             convT_pair(P, C, wp, bias4, lo, hi);
             float *row = sG + wave * GPS + 2 * pr * TT_DRS + 2 * lane + 4;
             *reinterpret_cast<f32x2 *>(row) = relu2(lo);
             *reinterpret_cast<f32x2 *>(row + TT_DRS) = relu2(hi);
+            }
             P = C;
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        __syncthreads();
+        DT_SYNC();
 
         // ---- phase B: g4 = (W6^T g_dec) * (d4 > 0) in place; dW6 / db6 / db4 partial sums ---------------------------
         if constexpr (!AHEAD) {
-            const RowCtx rcc = rows_begin(true, cb, cy0, cx0);
+            const RowCtx rcc = rows_begin(!(dbg & 16), cb, cy0, cx0);
 #pragma unroll
             for (int j = 0; j < BR; ++j)
 #pragma unroll
@@ -465,6 +490,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             const int gr = wave + 4 * j;
+            if (dbg & 2) break;
             if ((PF && j < BR - 1) || gr < GROWS) {
                 const int oy = 2 * cy0 - 1 + gr;
                 const bool live = oy >= 0 && oy < OH && colin;
@@ -522,12 +548,12 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
             }
         }
         if (FUSED) loss += (double)tl.x + (double)tl.y;
-        const RowCtx rcn = rows_begin(next < ntiles, b, y0, x0);   // next tile's rows: requested during the wgrad phase
-        __syncthreads();
+        const RowCtx rcn = rows_begin(next < ntiles && !(dbg & 16), b, y0, x0);   // next tile's rows: requested during the wgrad phase
+        DT_SYNC();
 
         // ---- phase 3: data gradient of dec.4 for input channel ci = wave:  g2[ci][y][x] = sum_co,ky,kx
         //      g4[co][2y-1+ky][2x-1+kx] * W4[ci][co][ky][kx], masked by d2 > 0 ------------------------------------------
-        {
+        if (!(dbg & 4)) {
         // per g4 value pair mid = (col 2x, 2x+1), left = col 2x-1, right = col 2x+2:
         //   g2[x] += left*w[ky][0] + mid.x*w[ky][1] + mid.y*w[ky][2] + right*w[ky][3]
         // left / right are the neighbours' mid.y / mid.x: instead of fetching them per value, every lane also accumulates
@@ -580,7 +606,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 
         // ---- phase 4 (MFMA): weight gradient of dec.4 (wgrad_steps).  Position rows Yr = 0..TH: this wave takes rows
         //      wave and wave+4 whole and a quarter of row TH.  Row 0 has no own d2 row for sy = 1, row TH none for sy = 0.
-        {
+        if (!(dbg & 8)) {
             constexpr int NR = BR * NIN;                   // next tile's (row, channel) requests, a third before each part
             auto issue_part = [&](int part) {
                 if constexpr (AHEAD) {
@@ -683,6 +709,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     }
 }
 
+#undef DT_SYNC
 int tail_tiles_x(int W2) { return W2 == TT_W ? 1 : (W2 + TT_OWN - 1) / TT_OWN; }               // (64 wide: one tile spans the row)
 int tail_grid(int ntiles) { return ntiles < TT_MAX_GRID ? ntiles : TT_MAX_GRID; }               // forward: 3 per CU
 int tail_grid_bwd(int ntiles) { return ntiles < 512 ? ntiles : 512; }                           // backward: 2 per CU
@@ -746,7 +773,7 @@ int tail_backward_launch(const char *who, bool fused, const float *d2, const flo
     hipStream_t st = (hipStream_t)stream;
 #define DM_TB(N_, F_, W_) hipLaunchKernelGGL((dec_tail_backward_kernel<N_, F_, W_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, \
                                              w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
-                                             part_slabs, w_slabs, H2, ntiles, inv_count, nslabs, W2, tiles_x)
+                                             part_slabs, w_slabs, H2, ntiles, inv_count, nslabs, W2, tiles_x DT_DBG_ARG)
 #define DM_TBN(F_, W_) switch (NIN) { case 1: DM_TB(1, F_, W_); break; case 2: DM_TB(2, F_, W_); break; case 3: DM_TB(3, F_, W_); break; default: DM_TB(4, F_, W_); }
     if (W2 == TT_W) {
         if (fused) { DM_TBN(true, false) } else { DM_TBN(false, false) }

@@ -191,4 +191,14 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
     }
     return r;
 }
+
+// One-off function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) belong to a DEVICE's copy of the kernel: a process
+// that drives a second GPU has to set them there too, so the "done" flag is per device ordinal.
+struct DmPerDeviceOnce {
+    bool done[64] = {};
+    int dev() const { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : -1; }
+    bool need() const { const int d = dev(); return d < 0 || !done[d]; }
+    void mark() { const int d = dev(); if (d >= 0) done[d] = true; }
+};
+
 #endif

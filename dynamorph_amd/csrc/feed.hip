@@ -166,6 +166,8 @@ extern "C" int dm_gather_augment(const float *src, int64_t n_src, const int32_t 
     DM_REQUIRE((const void *)src != (const void *)out, "dm_gather_augment: in-place not supported");
     DM_REQUIRE(ids || (int64_t)B <= n_src, "dm_gather_augment: B exceeds the number of source samples");
     if (H % FT == 0) {
+        // (the tiled form moves whole 16-byte row segments on both sides)
+        DM_REQUIRE((((uintptr_t)src | (uintptr_t)out) & 15) == 0, "dm_gather_augment: src and out must be 16-byte aligned");
         const long long blocks = (long long)B * C * (H / FT) * (H / FT);
         DM_REQUIRE(blocks < (1LL << 31), "dm_gather_augment: batch too large for one launch");
         hipLaunchKernelGGL(gather_augment_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, out,

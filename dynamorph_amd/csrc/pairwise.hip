@@ -669,6 +669,8 @@ static int tm_forward_launch(const float *z, const float *tm, int B, int n, int 
     DM_REQUIRE(mode == 0 || mode == 1, "dm_time_matching_forward: mode %d", mode);
     DM_REQUIRE((long long)B * n < (1LL << 31) && (long long)B * B < (1LL << 31), "dm_time_matching_forward: tensor too large");
     DM_REQUIRE(workspace_floats >= dm_time_matching_workspace_floats(B, n), "dm_time_matching_forward: workspace too small");
+    // (tm_count_kernel and the epilogue read tm 16 bytes at a time where B * B is a multiple of four)
+    DM_REQUIRE((((uintptr_t)tm | (uintptr_t)z | (uintptr_t)S) & 15) == 0, "dm_time_matching_forward: z, tm and S must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int ks = tm_ksplit(B, n), nt = (B + TM_T - 1) / TM_T;
     int klen = (n + ks - 1) / ks;
@@ -731,12 +733,20 @@ static int tm_backward_launch(const float *z, const float *S, const float *g_los
     DM_REQUIRE(dm_time_matching_supported(B, n), "dm_time_matching_backward: latent length %d is not a multiple of %d", n, TM_KC);
     DM_REQUIRE((long long)B * n < (1LL << 31), "dm_time_matching_backward: tensor too large");
     DM_REQUIRE(B <= 16384, "dm_time_matching_backward: batch %d too large (a row of S is staged in LDS)", B);
+    // (rows of S are read as 16-byte vectors where B is a multiple of four; z tiles always are)
+    DM_REQUIRE((((uintptr_t)S | (uintptr_t)z) & 15) == 0, "dm_time_matching_backward: z and S must be 16-byte aligned");
     const int *st = (const int *)state;
     hipLaunchKernelGGL(tm_backward_kernel, dim3((n + TM_T - 1) / TM_T, (B + TM_T - 1) / TM_T), dim3(256), 0, (hipStream_t)stream,
                        z, S, g_loss_dev, scale * 2.f / (float)n, dz, B, n, add, st);
     const size_t near_lds = (size_t)B * (sizeof(float) + sizeof(unsigned short));
-    if (near_lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)tm_near_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)near_lds);
+    if (near_lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)tm_near_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)near_lds);
+        if (e != hipSuccess) {
+            dm_set_error("dm_time_matching_backward: cannot reserve %zu bytes of LDS: %s", near_lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
     hipLaunchKernelGGL(tm_near_backward_kernel, dim3((unsigned)B), dim3(256), near_lds, (hipStream_t)stream, z,
                        S + (long long)B * B, g_loss_dev, scale * 2.f / (float)n, dz, B, n);
     return dm_launch_status("dm_time_matching_backward");

@@ -1801,9 +1801,14 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
         return dm_launch_status(who);
     }
 #define DM_VQ_BWD(DD)                                                                                          \
-    if (lds > 48 * 1024)                                                                                       \
-        (void)hipFuncSetAttribute((const void *)vq_backward_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                  (int)lds);                                                                   \
+    if (lds > 48 * 1024) {                                                                                     \
+        const hipError_t ea = hipFuncSetAttribute((const void *)vq_backward_kernel<DD>,                        \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        if (ea != hipSuccess) {                                                                                \
+            dm_set_error("%s: cannot reserve %zu bytes of LDS: %s", who, (size_t)lds, hipGetErrorString(ea));  \
+            return (int)ea;                                                                                    \
+        }                                                                                                      \
+    }                                                                                                          \
     hipLaunchKernelGGL(vq_backward_kernel<DD>, g3, dim3(VQ_BWD_BLOCK), lds, s, z, codebook,                    \
                        (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, dw_slabs, K, H * W, P, Kc)
     switch (D) {

@@ -28,6 +28,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if backend == "nccl":
+            if torch.cuda.device_count() <= local_rank:
+                raise SystemExit(f"rank {rank}: RCCL needs one GPU per rank, local rank {local_rank} has none among the "
+                                 f"{torch.cuda.device_count()} visible (DM_DIST_BACKEND=gloo rehearses on fewer)")
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)

@@ -109,18 +109,32 @@ class Feed:
         if mask is not None and (mten is None or mten.shape[0] != self.N or mten.shape[1] < 2):
             raise ValueError("Feed: masks must expose an (N, >= 2, H, W) tensor")
         self.has_mask = mten is not None
-        need = self.N * self.C * self.H * self.H * 4 + (self.N * mten.shape[2] * mten.shape[3] * 4 if self.has_mask else 0)
+        data_bytes = self.N * self.C * self.H * self.H * 4
+        mask_bytes = self.N * mten.shape[2] * mten.shape[3] * 4 if self.has_mask else 0
+        if mode not in ("auto", "resident", "stream"):
+            raise ValueError(f"Feed: unknown mode {mode!r}")
+        if src.is_cuda:
+            # a dataset that already lives in HBM (upload_zscored) IS resident: it is used where it lies, only the mask
+            # planes still have to fit, and the streaming path (host gather, pinned staging) has nothing to read from
+            if src.device != self.dev or src.dtype != torch.float32 or not src.is_contiguous():
+                raise ValueError(f"Feed: a device dataset must be a contiguous float32 tensor on {self.dev} "
+                                 f"(got {src.dtype} on {src.device}, contiguous={src.is_contiguous()})")
+            if mode == "stream":
+                raise ValueError("Feed: feed='stream' reads the dataset from host memory; this one is on the device")
+            if mode == "auto" and mask_bytes > resident_budget(self.dev):
+                raise ValueError(f"Feed: the dataset is on the device but its {mask_bytes} bytes of mask planes do not fit "
+                                 "beside it (DM_RESIDENT_BYTES / DM_RESIDENT_FRACTION)")
+            mode, data_bytes = "resident", 0
+        need = data_bytes + mask_bytes
         if mode == "auto":
             mode = "resident" if need <= resident_budget(self.dev) else "stream"
-        if mode not in ("resident", "stream"):
-            raise ValueError(f"Feed: unknown mode {mode!r}")
         self.mode = mode
         self.bytes_resident = 0
         with torch.cuda.device(self.dev):
             if mode == "resident":
                 self.data = self._upload(src)
                 self.mplane = self._upload(mask_plane(mten)) if self.has_mask else None
-                self.bytes_resident = need
+                self.bytes_resident = need              # what this feed added to HBM (a device dataset was there before)
             else:
                 self.mplane_host = mask_plane(mten) if self.has_mask else None
                 self._init_stream()

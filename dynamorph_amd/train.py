@@ -695,6 +695,10 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     if stats is not None:
         stats.update(feed=feeder.mode if feeder else "sync", phase_seconds={"train": [], "val": []}, phase_samples={})
 
+    # the reference's loop takes dataset[ids][0]; a bare tensor / ndarray (what upload_zscored returns) is indexed directly
+    bare = None
+    if torch.is_tensor(dataset) or isinstance(dataset, np.ndarray):
+        bare = torch.as_tensor(dataset)
     n_samples = len(dataset)
     # (an int array instead of the reference's list: the same draws shuffle it into the same order -- numpy's shuffle is
     # the same Fisher-Yates walk for both -- and slicing a phase into batches costs nothing)
@@ -758,7 +762,10 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                             _step_without_data(model, optimizer)
                         continue
                     ids_local = ids_local.tolist()                  # (the reference indexes with lists)
-                    batch = dataset[ids_local][0].to(dev)
+                    if bare is not None:
+                        batch = bare[ids_local].to(dev)             # a bare tensor / ndarray: dataset[ids][0] would be ONE sample
+                    else:
+                        batch = dataset[ids_local][0].to(dev)
                     kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_local, device=dev) if get_relation_tensor else None,
                           'batch_mask': get_mask(mask, ids_local, device=dev) if get_mask else None}
                     last = {}

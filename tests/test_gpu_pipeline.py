@@ -406,3 +406,37 @@ def test_upload_zscored_feeds_train_from_the_device(tmp_path):
         out[name] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     for k, v in out["host"].items():
         assert torch.equal(v, out["device"][k]), k
+
+
+def test_device_dataset_is_resident_whatever_the_budget_and_bare_tensors_take_the_sync_loop(tmp_path, monkeypatch):
+    """(1) feed='auto' with a dataset that already lives in HBM (upload_zscored's result) must not count it against
+    the resident budget and end in the streaming path (which gathers on the host); (2) a BARE tensor as the dataset in the
+    synchronous loop is indexed directly (dataset[ids][0] would be one sample of the batch); (3) feed='stream' with a device
+    dataset is a clear error."""
+    import contextlib, copy, io
+    import dynamorph_amd
+    from dynamorph_amd import feed as F
+    from dynamorph_amd.train import train
+    torch.manual_seed(3)
+    host = torch.randn(24, 2, 128, 128)
+    dev_t = host.to(DEV)
+    monkeypatch.setenv("DM_RESIDENT_BYTES", "1024")                     # far below the dataset's 3 MB
+    m0 = dynamorph_amd.VQ_VAE().to(DEV)
+    out = {}
+    for name, data, feed in (("auto-device-bare", dev_t, "auto"), ("sync-bare", host, "sync"),
+                             ("sync-dataset", torch.utils.data.TensorDataset(host), "sync")):
+        m = copy.deepcopy(m0)
+        np.random.seed(9)
+        st = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            train(m, data, str(tmp_path / name), n_epochs=2, lr=1e-3, batch_size=8, device=DEV, transform=None,
+                  val_split_ratio=0.25, patience=5, feed=feed, stats=st)
+        assert st["feed"] == ("resident" if feed == "auto" else "sync"), (name, st["feed"])
+        out[name] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, v in out["sync-dataset"].items():
+        assert torch.equal(v, out["sync-bare"][k]), k
+        assert torch.equal(v, out["auto-device-bare"][k]), k
+    with pytest.raises(ValueError, match="host memory"):
+        F.Feed(dev_t, DEV, mode="stream", batch_size=8)
+    with pytest.raises(ValueError, match="contiguous float32"):
+        F.Feed(dev_t.double(), DEV, mode="auto", batch_size=8)
