@@ -80,10 +80,8 @@ __device__ __forceinline__ void load_row(const float *__restrict__ sA, int APS, 
     for (int ci = 0; ci < TT_C; ci += 2)
         r.v[ci >> 1] = (f32x2){sA[ci * APS + row * TT_W + lane], sA[(ci + 1) * APS + row * TT_W + lane]};
 }
-// wp[ci][ky][0] = (w[ky][1], w[ky][2]) (own pair), wp[ci][ky][1] = (w[ky][3], w[ky][0]) (side pair) of W4[ci][co] for this wave's co.
-// ROT: w holds every kx quadruple rotated by one, (w1, w2, w3, w0) -- the LDS copy of the backward kernel -- so that a 16-byte
-// read lands both pairs in aligned register pairs (from the plain order each pair straddles two: 2 v_mov_b32 per pair).
-template <bool ROT>
+// wp[ci][ky][0] = (w[ky][1], w[ky][2]) (own pair), wp[ci][ky][1] = (w[ky][3], w[ky][0]) (side pair) of W4[ci][co] for this wave's co
+// (forward kernel: vector registers; the backward kernel keeps its weights in scalar registers, see there).
 __device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, int wv, f32x2 (&wp)[TT_C][4][2])
 {
 #pragma unroll
@@ -91,8 +89,8 @@ __device__ __forceinline__ void load_convT_weights(const float *__restrict__ w, 
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(w + (ci * TT_C + wv) * 16 + 4 * ky);
-            wp[ci][ky][0] = ROT ? (f32x2){q.x, q.y} : (f32x2){q.y, q.z};
-            wp[ci][ky][1] = ROT ? (f32x2){q.z, q.w} : (f32x2){q.w, q.x};
+            wp[ci][ky][0] = (f32x2){q.y, q.z};
+            wp[ci][ky][1] = (f32x2){q.w, q.x};
         }
 }
 __device__ __forceinline__ void convT_pair(const RowVals &P, const RowVals &C, const f32x2 (&wp)[TT_C][4][2], float bias,
@@ -160,7 +158,7 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
 
     const int wv = wave_index_vgpr();
     f32x2 wp[TT_C][4][2];
-    load_convT_weights<false>(w4, wv, wp);
+    load_convT_weights(w4, wv, wp);
     const float bias4 = b4[wv];
     float w6r[NIN][TT_C], b6r[NIN], ivar[NIN];
 #pragma unroll
@@ -279,6 +277,14 @@ __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const 
     }
 }
 
+// Resident workgroups per CU the backward kernel is built for (launch bound = register budget: 3 -> 168, 2 -> 256).  Three
+// where the instantiation fits 168 registers without scratch (profiles/r05_kernel_resources.txt), two elsewhere.
+template <int NIN, bool FUSED, bool WIDE, bool MASKED>
+constexpr int tail_bwd_occ()
+{
+    return (!WIDE && NIN <= 2) ? 3 : 2;
+}
+
 #ifdef DM_MEASURE
 #define DT_DBG_PARAM , int dbg
 #define DT_DBG_ARG , tail_dbg()
@@ -295,8 +301,10 @@ static int tail_dbg()
 // ================================================================================== backward
 // FUSED (training pass, dm_dec_tail_train): decoded is not read but formed in phase B from the recomputed d4 tile
 // (dec.6 is 1x1), the reconstruction-loss partials are taken there too, and `decoded` never exists in HBM.
-template <int NIN, bool FUSED, bool WIDE>
-__global__ __launch_bounds__(DM_BLOCK, 2)
+// MASKED: batch_mask given (vq_vae.py:320-321).  A template flag, not a branch: with the uniform branch in the row loop of
+// phase B the kernel needs 223 registers, without it 159 -- three resident workgroups per CU instead of two.
+template <int NIN, bool FUSED, bool WIDE, bool MASKED>
+__global__ __launch_bounds__(DM_BLOCK, (tail_bwd_occ<NIN, FUSED, WIDE, MASKED>()))
 void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restrict__ w4, const float *__restrict__ b4,
                               const float *__restrict__ w6, const float *__restrict__ b6, double *__restrict__ loss_slabs,
                               const float *__restrict__ decp, const float *__restrict__ x,
@@ -319,7 +327,6 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     __shared__ __attribute__((aligned(16))) float sA[TT_C * APS];
     __shared__ __attribute__((aligned(16))) float sG[TT_C * GPS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
-    __shared__ __attribute__((aligned(16))) float s_w4[TT_C * TT_C * 16];   // dec.4 weights, re-read per phase (broadcast); kx order 1, 2, 3, 0
     __shared__ double s_part[4][NP];
 
     const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
@@ -351,7 +358,6 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     // wave-uniform weights: phase A (recompute, co = wave): W4[ci][wave][ky][kx]; phase 3 (data gradient, ci = wave):
     // W4[wave][co][ky][kx] (64 contiguous floats)
     const int wv = wave_index_vgpr();
-    s_w4[threadIdx.x] = w4[(threadIdx.x & ~3) | ((threadIdx.x + 1) & 3)];   // 256 threads, 256 weights; (w1, w2, w3, w0) per ky: load_convT_weights
     const float bias4 = b4[wv];
     const float gs = (float)(2.0 * inv_count) * gscale_dev[0];
     float w6r[NIN][TT_C], gsv[NIN], b6r[NIN], ivar[NIN];
@@ -438,32 +444,58 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         const auto scx = stage.begin(in, next < ntiles && !(dbg & 16), b, TT_C, H2, W2, y0 - 2, x0);   // requested during phase A
 
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
+        // Two passes, one per output-row parity (d4 row 2y-1+par reads P = d2 row y-1 with ky = 2 + par and C = row y with
+        // ky = par): a pass holds 32 weights, in SGPRs (wave-uniform; see phase 3), as the pairs (w0, w1), (w2, w3) they are in
+        // memory.  A lane's value v = in[x] gives  T += v * (w0, w1) = (to the left neighbour's odd column, own even column),
+        // U += v * (w2, w3) = (own odd column, to the right neighbour's even column).
         {
-        f32x2 wp[TT_C][4][2];                         // W4[ci][co = wave] as packed pairs, live in this phase only
-        load_convT_weights<true>(s_w4, wv, wp);
-        RowVals P, C, N;                              // rows y-1, y and (read one row ahead of its use) y+1; sA row 0 <-> d2 row y0-2
-        load_row(sA, APS, 1, lane, P);
-        load_row(sA, APS, 2, lane, N);
+        const f32x2 biasT = {0.f, bias4}, biasU = {bias4, 0.f};
 #pragma unroll
-        for (int pr = 0; pr <= TT_TH; ++pr) {         // y = y0 + pr -> g4-tile rows 2pr (d4 row 2y-1) and 2pr+1 (row 2y)
-            {
-                constexpr int NE = decltype(stage)::N;
+        for (int par = 0; par < 2; ++par) {
+            int woff = wave * 16 + 4 * par;
+            asm volatile("" : "+s"(woff));
+            f32x2 w01[TT_C][2], w23[TT_C][2];          // [ci][t]: ky = par + 2t  (t = 0: row C, t = 1: row P)
 #pragma unroll
-                for (int e = 0; e < NE; ++e)
-                    if (e >= pr * NE / (TT_TH + 1) && e < (pr + 1) * NE / (TT_TH + 1)) stage.issue_one(e, scx);
+            for (int ci = 0; ci < TT_C; ++ci)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(w4 + woff + ci * (TT_C * 16) + 8 * t);
+                    w01[ci][t] = (f32x2){q.x, q.y};
+                    w23[ci][t] = (f32x2){q.z, q.w};
+                }
+            RowVals P, C, N;                          // rows y-1, y and (read one row ahead of its use) y+1; sA row 0 <-> d2 row y0-2
+            load_row(sA, APS, 1, lane, P);
+            load_row(sA, APS, 2, lane, N);
+#pragma unroll
+            for (int pr = 0; pr <= TT_TH; ++pr) {     // y = y0 + pr -> g4-tile row 2pr + par (d4 row 2y-1+par)
+                if (par == 0) {
+                    constexpr int NE = decltype(stage)::N;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e)
+                        if (e >= pr * NE / (TT_TH + 1) && e < (pr + 1) * NE / (TT_TH + 1)) stage.issue_one(e, scx);
+                }
+                C = N;
+                if (pr < TT_TH) load_row(sA, APS, pr + 3, lane, N);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 1)) {
+                    f32x2 T, U;
+#pragma unroll
+                    for (int ci = 0; ci < TT_C; ++ci) {
+                        const f32x2 pp = P.v[ci >> 1], cc = C.v[ci >> 1];
+                        const f32x2 pv2 = (ci & 1) ? __builtin_shufflevector(pp, pp, 1, 1) : __builtin_shufflevector(pp, pp, 0, 0);
+                        const f32x2 cv2 = (ci & 1) ? __builtin_shufflevector(cc, cc, 1, 1) : __builtin_shufflevector(cc, cc, 0, 0);
+                        if (ci == 0) { T = pv2 * w01[ci][1] + biasT; U = pv2 * w23[ci][1] + biasU; }
+                        else { T += pv2 * w01[ci][1]; U += pv2 * w23[ci][1]; }
+                        T += cv2 * w01[ci][0]; U += cv2 * w23[ci][0];
+                    }
+                    f32x2 o;
+                    o.x = T.y + lane_from_left(U.y);
+                    o.y = U.x + lane_from_right(T.x);
+                    *reinterpret_cast<f32x2 *>(sG + wave * GPS + (2 * pr + par) * TT_DRS + 2 * lane + 4) = relu2(o);
+                }
+                P = C;
+                __builtin_amdgcn_sched_barrier(0);
             }
-            C = N;
-            if (pr < TT_TH) load_row(sA, APS, pr + 3, lane, N);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 1)) {
-            f32x2 lo, hi;
-            convT_pair(P, C, wp, bias4, lo, hi);
-            float *row = sG + wave * GPS + 2 * pr * TT_DRS + 2 * lane + 4;
-            *reinterpret_cast<f32x2 *>(row) = relu2(lo);
-            *reinterpret_cast<f32x2 *>(row + TT_DRS) = relu2(hi);
-            }
-            P = C;
-            __builtin_amdgcn_sched_barrier(0);
         }
         }
         DT_SYNC();
@@ -519,8 +551,13 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     // (own and live are 0 / 1 factors: folded into the channel's constants -- the products are the same to the
                     //  bit and the kernel is bound by its vector instruction count; without WIDE both are wave-uniform)
                     const float oiv = own * ivar[c];
-                    if (mask && live) {
-                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oy) * OW + 2 * colx);
+                    if constexpr (MASKED) {
+                        // (read unconditionally, from the nearest row / column inside the image where the position lies outside:
+                        //  there dv and x are 0 (not FUSED) or the row's factors own and gsv are (FUSED), so any finite mask
+                        //  value gives the same zeros)
+                        const int oyc = oy < 0 ? 0 : (oy >= OH ? OH - 1 : oy);
+                        const int cxc = !WIDE ? colx : (colx < 0 ? 0 : (colx >= W2 ? W2 - 1 : colx));
+                        const f32x2 mv = *reinterpret_cast<const f32x2 *>(mask + ((cb * MC + (MC == 1 ? 0 : c)) * OH + oyc) * OW + 2 * cxc);
                         t = dv * mv - rxv[j][c] * mv;
                         if (FUSED) tl += (t * t) * oiv;
                         t = t * mv;
@@ -559,48 +596,59 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         // left / right are the neighbours' mid.y / mid.x: instead of fetching them per value, every lane also accumulates
         // side = mid * (w3, w0) -- what ITS pair contributes to the left (x) and right (y) neighbour -- and the side sums
         // cross the lanes once per output row
-        f32x2 wm[TT_C][4], wo[TT_C][4];               // W4[ci = wave][co][ky] as (w1, w2) and (w3, w0)
+        // Weights in SGPRs: W4[ci = wave][co][ky][kx] is wave-uniform, and a v_pk_fma_f32 takes one scalar register PAIR as an
+        // operand.  Two passes over the g4 rows, one per row parity (a row of parity par feeds ky = par and ky = par + 2 only), so
+        // that a pass holds 32 weights; the offset is hidden from the optimiser inside the tile loop so that the scalar loads
+        // stay in the phase (hoisted out of the loop the 96 weights of phases A and 3 would not fit the scalar file).
+        // Pairs as they lie in memory, (w0, w1) and (w2, w3): a lane's pair mid = (col 2x, col 2x+1) gives
+        //   R += (mid.y * w0, mid.x * w1) = (to the right neighbour, own)     S += (mid.y * w2, mid.x * w3) = (own, to the left neighbour)
+        f32x2 accR[TT_TH], accS[TT_TH];                // (started by their first product, not zeroed)
 #pragma unroll
-        for (int co = 0; co < TT_C; ++co)
+        for (int par = 0; par < 2; ++par) {
+            int woff = wave * (TT_C * 16) + 4 * par;
+            asm volatile("" : "+s"(woff));
+            f32x2 w01[TT_C][2], w23[TT_C][2];          // [co][t]: ky = par + 2t
 #pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(s_w4 + (wv * TT_C + co) * 16 + 4 * ky);   // (w1, w2, w3, w0)
-                wm[co][ky] = (f32x2){q.x, q.y};
-                wo[co][ky] = (f32x2){q.z, q.w};
-            }
-        f32x2 acc[TT_TH], side[TT_TH];                 // (started by their first product below, not zeroed)
-        f32x2 nm[TT_C];                               // the next g4 row: LDS reads one row ahead of their use
+            for (int co = 0; co < TT_C; ++co)
 #pragma unroll
-        for (int co = 0; co < TT_C; ++co) nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + 2 * lane + 4);
-#pragma unroll
-        for (int gr = 0; gr < GROWS; ++gr) {          // g4-tile row gr = 2r + ky: every row is read once, feeds <= 2 output rows
-            f32x2 mid[TT_C];
-#pragma unroll
-            for (int co = 0; co < TT_C; ++co) mid[co] = nm[co];
-            if (gr + 1 < GROWS) {
-#pragma unroll
-                for (int co = 0; co < TT_C; ++co)
-                    nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + (gr + 1) * TT_DRS + 2 * lane + 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int co = 0; co < TT_C; ++co) {
-                const int r1 = gr >> 1, k1 = gr & 1;               // ky = k1 for row r1, ky = k1 + 2 for row r1 - 1
-                if (r1 < TT_TH) {
-                    if (k1 == 0 && co == 0) { acc[r1] = mid[co] * wm[co][k1]; side[r1] = mid[co] * wo[co][k1]; }
-                    else { acc[r1] += mid[co] * wm[co][k1]; side[r1] += mid[co] * wo[co][k1]; }
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(w4 + woff + co * 16 + 8 * t);
+                    w01[co][t] = (f32x2){q.x, q.y};
+                    w23[co][t] = (f32x2){q.z, q.w};
                 }
-                if (r1 >= 1) { acc[r1 - 1] += mid[co] * wm[co][k1 + 2]; side[r1 - 1] += mid[co] * wo[co][k1 + 2]; }
+            f32x2 nm[TT_C];                            // the next g4 row of this parity: LDS reads one row ahead of their use
+#pragma unroll
+            for (int co = 0; co < TT_C; ++co) nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + par * TT_DRS + 2 * lane + 4);
+#pragma unroll
+            for (int i = 0; i <= TT_TH; ++i) {         // g4 row gr = 2i + par: ky = par of output row i, ky = par + 2 of row i - 1
+                f32x2 mid[TT_C];
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co) mid[co] = nm[co];
+                if (i < TT_TH) {
+#pragma unroll
+                    for (int co = 0; co < TT_C; ++co)
+                        nm[co] = *reinterpret_cast<const f32x2 *>(sG + co * GPS + (2 * i + 2 + par) * TT_DRS + 2 * lane + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co) {
+                    const f32x2 sw = __builtin_shufflevector(mid[co], mid[co], 1, 0);     // (mid.y, mid.x)
+                    if (i < TT_TH) {
+                        if (par == 0 && co == 0) { accR[i] = sw * w01[co][0]; accS[i] = sw * w23[co][0]; }
+                        else { accR[i] += sw * w01[co][0]; accS[i] += sw * w23[co][0]; }
+                    }
+                    if (i >= 1) { accR[i - 1] += sw * w01[co][1]; accS[i - 1] += sw * w23[co][1]; }
+                }
+                if (par == 1 && i >= 1) {              // output row r = i - 1 is complete
+                    const int r = i - 1;
+                    const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
+                    const float sum = (accR[r].y + accS[r].x) + (lane_from_left(accR[r].x) + lane_from_right(accS[r].y));
+                    const float v = (dd > 0.f && ownl) ? sum : 0.f;
+                    if (ownl) g2[((cb * TT_C + wave) * H2 + cy0 + r) * W2 + colx] = v;
+                    pb2 += v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if ((gr & 1) && gr >= 3) {                             // row r = (gr - 3) / 2 is complete
-                const int r = (gr - 3) >> 1;
-                const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
-                const float sum = (acc[r].x + acc[r].y) + (lane_from_right(side[r].x) + lane_from_left(side[r].y));
-                const float v = (dd > 0.f && ownl) ? sum : 0.f;
-                if (ownl) g2[((cb * TT_C + wave) * H2 + cy0 + r) * W2 + colx] = v;
-                pb2 += v;
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
         }
 
@@ -712,7 +760,15 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
 #undef DT_SYNC
 int tail_tiles_x(int W2) { return W2 == TT_W ? 1 : (W2 + TT_OWN - 1) / TT_OWN; }               // (64 wide: one tile spans the row)
 int tail_grid(int ntiles) { return ntiles < TT_MAX_GRID ? ntiles : TT_MAX_GRID; }               // forward: 3 per CU
-int tail_grid_bwd(int ntiles) { return ntiles < 512 ? ntiles : 512; }                           // backward: 2 per CU
+int tail_grid_bwd(int ntiles, int occ)                                                          // backward: occ per CU
+{
+    int cap = 256 * occ;
+#ifdef DM_MEASURE      // occupancy experiments: DM_DEC_TAIL_GRID=256 leaves one workgroup per CU
+    static const int env_cap = [] { const char *e = getenv("DM_DEC_TAIL_GRID"); return e ? atoi(e) : 0; }();
+    if (env_cap > 0) cap = env_cap;
+#endif
+    return ntiles < cap ? ntiles : cap;
+}
 
 int tail_checks(const char *who, int B, int C2, int NIN, int H2, int W2)
 {
@@ -768,18 +824,22 @@ int tail_backward_launch(const char *who, bool fused, const float *d2, const flo
     DM_REQUIRE(fused ? loss_slabs != nullptr : decoded != nullptr, "%s: NULL pointer", who);
     DM_REQUIRE(!mask || mask_channels == 1 || mask_channels == NIN, "%s: mask channels %d", who, mask_channels);
     if (tail_checks(who, B, C2, NIN, H2, W2)) return -1;
-    const int tiles_x = tail_tiles_x(W2), ntiles = B * (H2 / TT_TH) * tiles_x, grid = tail_grid_bwd(ntiles), nslabs = tail_grid(ntiles);
+    const int tiles_x = tail_tiles_x(W2), ntiles = B * (H2 / TT_TH) * tiles_x, nslabs = tail_grid(ntiles);
     const double inv_count = 1.0 / ((double)B * NIN * (2.0 * H2) * (2.0 * W2));
     hipStream_t st = (hipStream_t)stream;
-#define DM_TB(N_, F_, W_) hipLaunchKernelGGL((dec_tail_backward_kernel<N_, F_, W_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, \
-                                             w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
-                                             part_slabs, w_slabs, H2, ntiles, inv_count, nslabs, W2, tiles_x DT_DBG_ARG)
-#define DM_TBN(F_, W_) switch (NIN) { case 1: DM_TB(1, F_, W_); break; case 2: DM_TB(2, F_, W_); break; case 3: DM_TB(3, F_, W_); break; default: DM_TB(4, F_, W_); }
+    // (the slab buffers are sized for the forward kernel's grid, 3 per CU: the backward grid never exceeds it)
+#define DM_TB(N_, F_, W_, M_) { const int grid = tail_grid_bwd(ntiles, tail_bwd_occ<N_, F_, W_, M_>()); \
+                                hipLaunchKernelGGL((dec_tail_backward_kernel<N_, F_, W_, M_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, \
+                                                   w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
+                                                   part_slabs, w_slabs, H2, ntiles, inv_count, nslabs, W2, tiles_x DT_DBG_ARG); }
+#define DM_TBN(F_, W_, M_) switch (NIN) { case 1: DM_TB(1, F_, W_, M_) break; case 2: DM_TB(2, F_, W_, M_) break; case 3: DM_TB(3, F_, W_, M_) break; default: DM_TB(4, F_, W_, M_) }
+#define DM_TBM(F_, W_) if (mask) { DM_TBN(F_, W_, true) } else { DM_TBN(F_, W_, false) }
     if (W2 == TT_W) {
-        if (fused) { DM_TBN(true, false) } else { DM_TBN(false, false) }
+        if (fused) { DM_TBM(true, false) } else { DM_TBM(false, false) }
     } else {
-        if (fused) { DM_TBN(true, true) } else { DM_TBN(false, true) }
+        if (fused) { DM_TBM(true, true) } else { DM_TBM(false, true) }
     }
+#undef DM_TBM
 #undef DM_TBN
 #undef DM_TB
     return dm_launch_status(who);
