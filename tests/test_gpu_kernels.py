@@ -1195,6 +1195,51 @@ def test_vq_backward_large_codebooks(ops, K, D, H):
     close(dw_s, dw_ref, 1e-5, tol, "codebook gradient (slabs)")
 
 
+def test_vq_backward_atomic_form_repeated_behind_its_neighbours(ops):
+    """Round 4 saw test_vq_backward_large_codebooks[512-64-32] fail ONCE (atomic form: 1 008 of 32 768 floats -- 4 KiB minus
+    64 B -- off by ~4e-5, the magnitude of the 4 KiB codebook gradients the previous test leaves in the allocator's pool).
+    The pair of calls behind the calls of the tests that run before it, repeated; every workgroup's partial sum is known on
+    the host, so a failure says whether a flush was lost / doubled (kernel logic: whole 64-float rows) or whether the region
+    is page-shaped (stale memory under the zero fill).  Round 5: 1 000 repetitions of this in three allocation patterns
+    (tools/exp/vq_bwd_flake2.py, vq_bwd_flake3.py) without a mismatch."""
+    K, D, H, B = 512, 64, 32, 5
+    z, cb, g = rnd(B, D, H, H, seed=51), rnd(K, D, seed=52), rnd(B, D, H, H, seed=53)
+    zd, cbd, gd = z.to(DEV), cb.to(DEV), g.to(DEV)
+    idx, _, _, _ = ops.vq_forward(zd, cbd, want_out=False)
+    gl = torch.tensor([1.3], device=DEV)
+    ih = idx.cpu().reshape(-1)
+    contrib = 1.3 * 2 * (cb[ih].double() - z.permute(0, 2, 3, 1).reshape(-1, D).double()) / z.numel()
+    part = torch.zeros(5, K, D, dtype=torch.float64)            # the kernel's five workgroups take 1024 positions each
+    for w in range(5):
+        part[w].index_add_(0, ih[w * 1024:(w + 1) * 1024], contrib[w * 1024:(w + 1) * 1024])
+    ref = part.sum(0)
+    tol = 1e-5 * ref.abs() + 1e-6 * float(ref.abs().max())
+    # the neighbours' device-side allocation pattern: a large batch through the 64-code forms (4 KiB gradients, slabs)
+    zb, cbb = rnd(2048, 16, 16, 16, seed=61).to(DEV), rnd(64, 16, seed=62).to(DEV)
+    gb = rnd(2048, 16, 16, 16, seed=63).to(DEV)
+    idxb, _, _, _ = ops.vq_forward(zb, cbb, want_out=False)
+    for it in range(40):
+        _, small = ops.vq_backward(zb, cbb, idxb, gb, gl, 0.25, dw=torch.zeros(64, 16, device=DEV))
+        _, slabs = ops.vq_backward_slabs(zb, cbb, idxb, gb, gl, 0.25)
+        keep = ops.reduce_slabs(slabs, torch.empty_like(cbb))
+        del small, slabs, keep
+        dw0 = torch.zeros(K, D, device=DEV)
+        ptr = dw0.data_ptr()
+        _, dw_a = ops.vq_backward(zd, cbd, idx, gd, gl, 0.25, dw=dw0)
+        _, dw_s = ops.vq_backward(zd, cbd, idx, gd, gl, 0.25)
+        for name, got in (("atomic", dw_a), ("slab", dw_s)):
+            dd = got.cpu().double() - ref
+            ww = dd.abs() > tol
+            if bool(ww.any()):
+                flat = ww.reshape(-1).nonzero().reshape(-1)
+                who = [f"workgroup {w} {what}" for w in range(5) for sign, what in ((-1.0, "lost"), (1.0, "doubled"))
+                       if float((dd - sign * part[w])[ww].abs().max()) <= 1e-9]
+                raise AssertionError(
+                    f"iteration {it}, {name} form: {flat.numel()} floats off, flat {int(flat.min())}..{int(flat.max())}, "
+                    f"{torch.unique(flat // 16).numel()} 64-byte lines, first at byte {(ptr + 4 * int(flat.min())) % 4096} of its 4 KiB "
+                    f"page, max err {float(dd.abs().max()):.3e}; explained by a workgroup's partial sum: {who or 'no'}")
+
+
 @pytest.mark.parametrize("B,n", [(4, 4096), (19, 4096), (33, 100), (1, 64)])
 def test_pair_msd_forward_backward(ops, B, n):
     """Pairwise mean-squared latent distance of the time-matching loss (vq_vae.py:327-329) and its gradient."""
