@@ -52,6 +52,9 @@ class FusedTrainer:
         from .vq_vae import VQ_VAE, VQ_VAE_z32
         if not isinstance(model, (VQ_VAE, VQ_VAE_z32)):
             raise TypeError("FusedTrainer is built for VQ_VAE / VQ_VAE_z16 / VQ_VAE_z32; train other modules with a torch optimizer")
+        if getattr(model, "extra_loss", None) is not None:
+            raise TypeError("FusedTrainer: a model with extra_loss (vae.py:463-469) runs the caller's torch code every step; "
+                            "train it through autograd with a torch optimizer (train(..., fused=False) does)")
         self.model = model
         self._z32 = isinstance(model, VQ_VAE_z32)
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -569,7 +572,8 @@ class _EpochLosses:
 def _make_optimizer(model, lr, fused):
     from .vq_vae import VQ_VAE
     from .vq_vae import VQ_VAE_z32
-    fusable = isinstance(model, (VQ_VAE, VQ_VAE_z32))
+    # (a model with caller-supplied extra losses, vae.py:463-469, runs arbitrary torch code per step: the autograd path)
+    fusable = isinstance(model, (VQ_VAE, VQ_VAE_z32)) and getattr(model, "extra_loss", None) is None
     if D.world_size() > 1 and not (fused and fused != "graph" and fusable):
         # FusedTrainer broadcasts its flat buffer itself; any other module: same replica everywhere before the first step
         for t in list(model.parameters()) + list(model.buffers()):

@@ -488,11 +488,16 @@ class VQ_VAE_z32(nn.Module):
     def __init__(self, num_inputs=2, num_hiddens=16, num_residual_hiddens=32, num_residual_layers=2, num_embeddings=64,
                  commitment_cost=0.25, channel_var=np.ones(2), weight_matching=0.005, w_a=1.1, w_t=0.1, w_n=-0.5,
                  margin=0.5, extra_loss=None, device="cuda:0", **kwargs):
-        for k in ("gpu", "alpha"):
-            kwargs.pop(k, None)
+        kwargs.pop("gpu", None)
+        alpha = kwargs.pop("alpha", None)
         super(VQ_VAE_z32, self).__init__(**kwargs)
-        if extra_loss is not None:
-            raise NotImplementedError("extra_loss is not part of the HIP path")
+        if extra_loss is not None and not (isinstance(extra_loss, dict) and all(callable(f) for f in extra_loss.values())):
+            raise TypeError("extra_loss: None or {loss name: callable(labels, z_after_flat) -> (loss, frac_pos)}  [vae.py:382-383]")
+        # vae.py:467 multiplies every extra loss by self.alpha, which the reference's constructor never sets (its docstring
+        # lists `alpha`, its signature does not: the attribute has to be assigned by the caller).  Here `alpha=` is accepted
+        # and stored; without it the attribute is missing exactly as in the reference.
+        if alpha is not None:
+            self.alpha = alpha
         self.num_inputs = num_inputs
         self.num_hiddens = num_hiddens
         self.num_residual_layers = num_residual_layers
@@ -519,10 +524,12 @@ class VQ_VAE_z32(nn.Module):
             _BatchNorm2d(nh // 2),
             _ReLU(),
             _ConvTranspose2d(nh // 2, num_inputs, 4, stride=2, padding=1))
-        self.extra_loss = None
+        self.extra_loss = extra_loss
 
     def forward(self, inputs, labels=None, time_matching_mat=None, batch_mask=None):
-        """inputs (B, C, H, W) -> (decoded, loss dict)   [vae.py:430-470]"""
+        """inputs (B, C, H, W) -> (decoded, loss dict)   [vae.py:430-470].  extra_loss (vae.py:463-469): every
+        `loss_fn(labels, z_after.reshape(B, -1)) -> (loss, frac_pos)` is the caller's torch code on the device latents; its
+        gradient reaches the encoder through the quantiser's straight-through backward like the time-matching term's."""
         _require_gpu(inputs, "VQ_VAE_z32.forward")
         x = _prep(inputs)
         z_before = self.enc(x)
@@ -535,9 +542,17 @@ class VQ_VAE_z32(nn.Module):
             total_loss = total_loss + tml * self.weight_matching
         else:
             tml = 0
-        return decoded, {'recon_loss': recon_loss, 'commitment_loss': c_loss,
-                         'time_matching_loss': tml, 'perplexity': perplexity,
-                         'total_loss': total_loss}
+        loss_dict = {'recon_loss': recon_loss, 'commitment_loss': c_loss,
+                     'time_matching_loss': tml, 'perplexity': perplexity,
+                     'total_loss': total_loss}
+        if self.extra_loss is not None:                                   # vae.py:463-469
+            z_after_ = z_after.reshape((z_after.shape[0], -1))
+            for loss_name, loss_fn in self.extra_loss.items():
+                extra_loss, frac_pos = loss_fn(labels, z_after_)
+                total_loss = total_loss + extra_loss * self.alpha
+                loss_dict['total_loss'] = total_loss
+                loss_dict[loss_name] = extra_loss
+        return decoded, loss_dict
 
     def predict(self, inputs):
         """Prediction fn, same as forward pass."""

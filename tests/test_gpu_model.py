@@ -8,6 +8,7 @@ Gates (SURVEY.md section 7 "hard parts"):
     best/second-best distance gap is below 1e-4 relative (count reported, must be tiny).
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -468,6 +469,47 @@ def test_z32_time_matching_mask_and_gradients_against_reference(golden):
         scale = max(float(np.abs(ref).max()), 1e-6)
         err = float((p.grad.cpu() - torch.from_numpy(ref)).abs().max())
         assert err <= 4e-3 * scale + 1e-8, (k, err, scale)
+
+
+def test_z32_extra_loss_against_reference(golden):
+    """VQ_VAE_z32(extra_loss={name: fn}, alpha=...) (vae.py:463-469) against the vectors captured from the reference's class
+    (g8_z32_extra.npz): the caller's loss functions run in torch on the device latents, their gradient reaches the encoder
+    through the quantiser's straight-through backward.  Keys in the reference's order, losses within 1e-5, gradients within
+    the accumulation noise of fp32; FusedTrainer declines such a model and train() takes the autograd path for it."""
+    import sys
+    import dynamorph_amd
+    from dynamorph_amd.train import FusedTrainer, _make_optimizer
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    from extra_losses import EXTRA
+    g = golden("g8_z32_extra.npz")
+    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
+    m = dynamorph_amd.VQ_VAE_z32(extra_loss=dict(EXTRA), alpha=float(g["alpha"])).to(DEV)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd/")})
+    dec, ld = m(x, labels=torch.from_numpy(g["labels"]).to(DEV), time_matching_mat=torch.from_numpy(g["tm"]).to(DEV))
+    assert list(ld.keys()) == [str(k) for k in g["loss_keys"]]
+    close(dec, g["decoded"], 1e-4, 1e-4, "z32 decoded (extra losses)")
+    for k in ld:
+        if k == "perplexity":
+            continue
+        ref = float(g["loss/" + k])
+        assert abs(float(ld[k]) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(ld[k]), ref)
+    ld["total_loss"].backward()
+    for k, p in m.named_parameters():
+        if not p.requires_grad or k in Z32_BN_FED_BIASES:
+            continue
+        ref = g["grad/" + k]
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = float((p.grad.cpu() - torch.from_numpy(ref)).abs().max())
+        assert err <= 4e-3 * scale + 1e-8, (k, err, scale)
+    with pytest.raises(TypeError, match="extra_loss"):
+        FusedTrainer(m)
+    assert isinstance(_make_optimizer(m, 1e-3, True), torch.optim.Adam)
+    # the reference's constructor never sets alpha: without it the attribute is missing there and here
+    m2 = dynamorph_amd.VQ_VAE_z32(extra_loss=dict(EXTRA)).to(DEV)
+    with pytest.raises(AttributeError, match="alpha"):
+        m2(x, labels=torch.from_numpy(g["labels"]).to(DEV))
+    with pytest.raises(TypeError):
+        dynamorph_amd.VQ_VAE_z32(extra_loss=[EXTRA["class_spread"]])
 
 
 def test_z32_gradients_against_oracle():

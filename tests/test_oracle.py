@@ -211,6 +211,31 @@ def test_z32_time_matching_mask_and_gradients(golden):
     assert n == sum(1 for k in g if k.startswith("grad/"))
 
 
+def test_z32_extra_loss(golden):
+    """VQ_VAE_z32(extra_loss={name: fn}) (vae.py:463-469): the oracle against the vectors captured from the reference's own
+    class with the two losses of tests/helpers/extra_losses.py, labels, a time-matching matrix and the caller-assigned alpha
+    (tests/golden/make_golden_z32_extra.py) -- the loss dict's keys in the reference's order, every loss, every gradient."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    from extra_losses import EXTRA
+    g = golden("g8_z32_extra.npz")
+    x = torch.from_numpy(golden("g2_input.npz")["x"])
+    m = O.load_numpy_state(O.OracleVQVAEz32(extra_loss=dict(EXTRA)), g, prefix="sd/")
+    m.alpha = float(g["alpha"])
+    dec, ld = m(x, labels=torch.from_numpy(g["labels"]), time_matching_mat=torch.from_numpy(g["tm"]))
+    assert list(ld.keys()) == [str(k) for k in g["loss_keys"]]
+    assert np.array_equal(dec.detach().numpy(), g["decoded"])
+    for k in ld:
+        assert abs(float(ld[k]) - float(g["loss/" + k])) <= 2e-6 * max(1.0, abs(float(g["loss/" + k]))), k
+    ld["total_loss"].backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(p.grad.numpy(), g["grad/" + k], rtol=2e-5, atol=2e-7, err_msg=k)
+            n += 1
+    assert n == sum(1 for k in g if k.startswith("grad/"))
+
+
 def test_stress_codebooks(golden):
     for name, D, K in (("g9_vq_k4096.npz", 16, 4096), ("g9_vq_d64.npz", 64, 512)):
         g = golden(name)
