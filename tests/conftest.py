@@ -100,3 +100,17 @@ def grad_gate(model, g32, g64, keys=None, skip=(), factor=1.5, floor=2e-4, what=
     assert checked > 0
     print(f"{what}: {checked} gradients within the float64 yardstick; worst {worst[0]} {worst[1]:.2e} of scale")
     return checked
+
+
+LOSS_GATE_WORST = {}
+
+
+def loss_gate(got, ref, what, tol=1e-5):
+    """north_star: recon / commitment loss within 1e-5 (fp32) of the reference.  |got - ref| <= tol * max(1, |ref|); the
+    measured error of every call is kept (printed with -s, worst per label in LOSS_GATE_WORST) so that a gate can be read
+    against what the kernels actually deliver."""
+    got, ref = float(got), float(ref)
+    err = abs(got - ref) / max(1.0, abs(ref))
+    LOSS_GATE_WORST[what] = max(LOSS_GATE_WORST.get(what, 0.0), err)
+    print(f"loss gate {what}: {got:.8f} vs {ref:.8f}, error {err:.2e} of max(1, |ref|)")
+    assert err <= tol, (what, got, ref, err)

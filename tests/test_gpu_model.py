@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import codes_gate, grad_gate, oracle_truth
+from conftest import codes_gate, grad_gate, loss_gate, oracle_truth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -153,27 +153,26 @@ def test_forward_losses_and_reconstruction(golden, masked):
 
 
 def test_gradients_against_reference(golden):
+    """G6: every parameter gradient of total_loss.backward() as the REFERENCE computed it (fp32, CPU), judged on the float64
+    yardstick: the HIP gradient is as close to the float64 truth (the oracle run in double on the same weights and input)
+    as the reference's own fp32 gradient is, x 1.5 -- conftest.grad_gate, in place of a flat share of the tensor's scale."""
+    from oracle import vqvae_oracle as O
     m = fresh(golden)
-    x = torch.from_numpy(golden("g2_input.npz")["x"]).to(DEV)
-    g6 = golden("g6_grads.npz")
-    dec, ld = m(x)
+    xh = torch.from_numpy(golden("g2_input.npz")["x"])
+    g6, g1 = golden("g6_grads.npz"), golden("g1_state_dict.npz")
+    ref = O.OracleVQVAE()
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in g1.items()})
+    _, _, g64 = oracle_truth(ref, xh)
+    g32 = {k: torch.from_numpy(g6["grad/" + k]) for k in g64}              # the reference's own gradients, not the oracle's
+    dec, ld = m(xh.to(DEV))
     ld["total_loss"].backward()
     assert m.channel_var.grad is None
-    worst = {}
-    for k, p in m.named_parameters():
-        if not p.requires_grad:
-            continue
-        assert p.grad is not None, k
-        ref = torch.from_numpy(g6["grad/" + k])
-        scale = max(ref.abs().max().item(), 1e-6)
-        err = (p.grad.cpu() - ref).abs().max().item()
-        worst[k] = err / scale
-        if k in BN_FED_BIASES:
-            assert p.grad.abs().max().item() == 0.0, k               # exact zero by construction
-            assert ref.abs().max().item() < 1e-6, k                  # the reference only has rounding noise there
-            continue
-        assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
-    print("max relative grad error:", max(worst.items(), key=lambda kv: kv[1]))
+    for k in BN_FED_BIASES:
+        p = dict(m.named_parameters())[k]
+        assert p.grad.abs().max().item() == 0.0, k                        # exact zero by construction
+        assert g32[k].abs().max().item() < 1e-6, k                        # the reference only has rounding noise there
+    n = grad_gate(m, g32, g64, skip=BN_FED_BIASES, what="G6 gradients")
+    assert n == sum(1 for _, p in m.named_parameters() if p.requires_grad) - len(BN_FED_BIASES)
 
 
 def test_decoder_and_vq_gradients_in_isolation(golden):
@@ -210,8 +209,8 @@ def test_adam_steps_with_torch_optimizer(golden):
         ld["total_loss"].backward()
         opt.step()
         m.zero_grad()
-        got = [float(ld[k]) for k in ("recon_loss", "commitment_loss", "total_loss")]
-        np.testing.assert_allclose(got, g7["losses"][step][:3], rtol=0, atol=2e-5)
+        for i, k in enumerate(("recon_loss", "commitment_loss", "total_loss")):
+            loss_gate(ld[k], g7["losses"][step][i], f"torch Adam, step {step}, {k}")
         if step == 0:
             for k, v in m.state_dict().items():
                 if k in BN_FED_BIASES or "tracked" in k:
@@ -271,7 +270,7 @@ def test_z16_variant_time_matching(golden):
     dec, ld = m(x, time_matching_mat=torch.from_numpy(g["tm"]).to(DEV))
     assert list(ld.keys()) == ["recon_loss", "commitment_loss", "time_matching_loss", "perplexity", "total_loss"]
     for k in ("recon_loss", "commitment_loss", "time_matching_loss", "total_loss"):
-        assert abs(float(ld[k]) - float(g[k])) <= 2e-5, (k, float(ld[k]), float(g[k]))
+        loss_gate(ld[k], g[k], f"z16 time matching, {k}")
     ld["total_loss"].backward()
     for k in ("enc.10.weight", "enc.4.weight", "dec.0.weight"):
         p = dict(m.named_parameters())[k]
@@ -324,7 +323,8 @@ def test_fused_trainer_matches_reference_adam(golden, use_graph):
     tr = FusedTrainer(m, lr=1e-4, use_graph=use_graph)
     for step in range(3):
         vals = tr.step(x).tolist()
-        np.testing.assert_allclose(vals[:3], g7["losses"][step][:3], rtol=0, atol=2e-5)
+        for i, k in enumerate(("recon_loss", "commitment_loss", "total_loss")):
+            loss_gate(vals[i], g7["losses"][step][i], f"FusedTrainer(graph={use_graph}), step {step}, {k}")
         if step == 0:
             for k, v in m.state_dict().items():
                 if k in BN_FED_BIASES:
@@ -566,7 +566,7 @@ def test_shape_sweep_losses_and_gradients(B, nin, hw, masked):
     ld["total_loss"].backward()
     assert dec.shape == x.shape
     for k in ("recon_loss", "commitment_loss", "total_loss"):
-        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+        loss_gate(ld[k], ld_r[k], k)
     # every parameter gradient against the float64 yardstick (a code chosen differently at a near-tie moves the
     # gradients discretely at these batch sizes: the reference's own fp32-vs-float64 error then widens the gate by itself)
     grad_gate(m, g32, g64, skip=BN_FED_BIASES, floor=5e-4, what=f"shape sweep B={B} nin={nin} hw={hw}")
@@ -631,7 +631,7 @@ def test_z32_other_input_channel_counts(nin):
     _, ld = m(x.to(DEV))
     ld["total_loss"].backward()
     for k in ("recon_loss", "commitment_loss", "total_loss"):
-        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+        loss_gate(ld[k], ld_r[k], k)
     grad_gate(m, g32, g64, skip=Z32_BN_FED_BIASES, floor=5e-4, what=f"z32 nin={nin}")
 
 
@@ -683,7 +683,7 @@ def test_non_square_patches(H, W):
     ld["total_loss"].backward()
     close(dec, dec_r, 2e-4, 2e-4, "decoded")
     for k in ("recon_loss", "commitment_loss", "total_loss"):
-        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+        loss_gate(ld[k], ld_r[k], k)
     grad_gate(m, g32, g64, skip=BN_FED_BIASES, floor=5e-4, what=f"non-square {H}x{W}")
 
 
@@ -701,7 +701,7 @@ def test_other_residual_depths_and_codebook_sizes(nlayers, K):
     _, ld = m(x.to(DEV))
     ld["total_loss"].backward()
     for k in ("recon_loss", "commitment_loss", "total_loss"):
-        assert abs(float(ld[k]) - float(ld_r[k])) <= 2e-5 * max(1.0, abs(float(ld_r[k]))), (k, float(ld[k]), float(ld_r[k]))
+        loss_gate(ld[k], ld_r[k], k)
     skip = tuple(b for b in BN_FED_BIASES if "layers" not in b) + tuple(
         f"enc.12.layers.{i}.{j}.bias" for i in range(nlayers) for j in (1, 4))
     grad_gate(m, g32, g64, skip=skip, floor=5e-4, what=f"{nlayers} residual layers, K={K}")
