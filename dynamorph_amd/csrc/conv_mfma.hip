@@ -932,7 +932,16 @@ void bwd_s2_fused_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
 // together.
 // BF: split-bf16 operands (tile.h: split_pack4) -- both LDS tiles and the transposed-convolution weights hold (hi, lo) bf16
 // pairs, the products run on v_mfma_f32_16x16x32_bf16 at four K-steps per instruction pair: a quarter of the matrix time.
-template <int CD, int CX, int TH, int TW, bool BF>
+// ZF (round 5; a tile spans the row, TW == W): the data gradient without structural zeros.  Folding both x phases of an
+// output pixel pair into the 16-wide N dimension makes them share a window of THREE dy columns of which each uses two: a third
+// of the 24 K-steps multiplies zeros.  The centre column (kx = 1 + px) is used by BOTH phases; the outer ones by one each
+// (px = 0: column X - 1 with kx = 3; px = 1: column X + 1 with kx = 0).  So two products share ONE A operand (dy column c = the
+// M row's own column): "centre" with B = W[kx = 1 + px] and "side" with B = W[kx = 3 | 0], 8 K-steps each, and
+//     dx[X][px = 0] = centre[X] + side[X - 1],     dx[X][px = 1] = centre[X] + side[X + 1]:
+// the side accumulator shifted by one M row, a register rename inside a lane plus one cross-lane value per M tile
+// (ds_bpermute); columns -1 and W are the zero padding.  16 matrix instructions per M tile and phase row instead of 24, a
+// third of the A-operand LDS reads, 32 weight registers instead of 48.
+template <int CD, int CX, int TH, int TW, bool BF, bool ZF>
 __global__ __launch_bounds__(512, 2)
 void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
                          float *__restrict__ wslabs, int H, int W, int ntiles, int dbg)
@@ -1091,18 +1100,23 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
     } else {
         // ================================================================ waves 0..3: data gradient
         const int co = m & 7, pxl = m >> 3;
-        float wreg[2][1][KS];
+        constexpr int NTW = ZF ? 2 : 1, KSW = ZF ? (CD / 4) * 2 : KS;       // ZF: N tiles (centre, side) of 8 K-steps (cg4, a)
+        float wreg[2][NTW][KSW];
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
-                const int c = 4 * cg4 + kq;
-                const int ky = py + 3 - 2 * (py + a), kx = pxl + 3 - 2 * bb;
-                float wvl = 0.f;
-                if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
-                wreg[py][0][s] = BF ? split_pack1(wvl) : wvl;
-            }
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int s = 0; s < KSW; ++s) {
+                    int cg4, a, kx;
+                    if constexpr (ZF) { cg4 = s >> 1; a = s & 1; kx = t == 0 ? 1 + pxl : (pxl ? 0 : 3); }
+                    else { cg4 = s / (2 * TAPX); const int j = s % (2 * TAPX); a = j / TAPX; kx = pxl + 3 - 2 * (j % TAPX); }
+                    const int c = 4 * cg4 + kq;
+                    const int ky = py + 3 - 2 * (py + a);
+                    float wvl = 0.f;
+                    if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
+                    wreg[py][t][s] = BF ? split_pack1(wvl) : wvl;
+                }
         float mc0, mc2;
         mask_coef(ep, 0, co, mc0, mc2);
         double s1 = 0.0, s2 = 0.0;
@@ -1110,6 +1124,9 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
         EpiCtx<SIDE_MASK> cx;
         const long long sample_elems = (long long)CX * OH * OW;
         const int chan_off = (co * OH * OW + 8 * kq + 4 * pxl) * 4;
+        // ZF: the lane that holds the neighbouring M row of this lane's first (px = 0) or last (px = 1) row: 16 lanes down or up
+        const int nb_addr = ((pxl ? lane + 16 : lane - 16) & 63) * 4;
+        const bool grp_first = kq == 0, grp_last = kq == 3;
         __syncthreads();                                    // (coefficient tables)
         __syncthreads();                                    // tile 0 in buffer 0
         int p = 0;
@@ -1125,8 +1142,10 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                 int obase[MP];
 #pragma unroll
                 for (int i = 0; i < MP; ++i) {
+                    // ZF: a wave takes BOTH 16-position spans of a row (the side accumulators of neighbouring spans meet in
+                    // its registers); else M tile rw + RW * (MP * pass + i)
                     const int ti = rw + RW * (MP * pass + i);
-                    const int r = ti / CGN, cg = ti % CGN;
+                    const int r = ZF ? rw + RW * pass : ti / CGN, cg = ZF ? i : ti % CGN;
                     ap[i] = cur + r * RS + 16 * cg + abase;
                     obase[i] = chan_off + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
                 }
@@ -1135,20 +1154,49 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
                     EpiIn<SIDE_MASK> e[MP];
 #pragma unroll
                     for (int i = 0; i < MP; ++i) epilogue_loads<SIDE_MASK>(e[i], cx, obase[i] + py * OW * 4);
-                    f32x4 acc[MP][1];
+                    f32x4 acc[MP][NTW];
 #pragma unroll
-                    for (int i = 0; i < MP; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < MP; ++i)
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     auto off = [py](int s) {
-                        const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
-                        return 4 * cg4 * PS + (py + a) * RS + bb;
+                        if constexpr (ZF) return 4 * (s >> 1) * PS + (py + (s & 1)) * RS + 1;
+                        else {
+                            const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                            return 4 * cg4 * PS + (py + a) * RS + bb;
+                        }
                     };
-                    if constexpr (BF) mfma_tiles_split<MP, 1, KS>(ap, wreg[py], acc, off);
-                    else mfma_tiles<MP, 1, KS, TAPX * 2>(ap, wreg[py], acc, off);
+                    if constexpr (BF) mfma_tiles_split<MP, NTW, KSW>(ap, wreg[py], acc, off);
+                    else mfma_tiles<MP, NTW, KSW, ZF ? 4 : TAPX * 2>(ap, wreg[py], acc, off);
+                    f32x4 v[MP];
+                    if constexpr (ZF) {
+                        static_assert(MP == 2 && CGN == 2, "the two spans of a row in one wave");
+                        // row P of the side product goes to row P + 1 (px = 0) or P - 1 (px = 1) of the result; M row =
+                        // 16 i + 4 kq + register.  The one row per tile that crosses the lanes: the provider hands over its last
+                        // (px = 0) or first (px = 1) register, the receiver reads 16 lanes down / up (wrapping into the other span)
+                        float x[MP];
+#pragma unroll
+                        for (int i = 0; i < MP; ++i)
+                            x[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+                                       nb_addr, __builtin_bit_cast(int, pxl ? acc[i][1].x : acc[i][1].w)));
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) {
+                            const f32x4 c = acc[i][0], sd = acc[i][1];
+                            // px = 0: first lane group of span 0 meets column -1 (zero), of span 1 the last group of span 0
+                            // px = 1: last lane group of span 1 meets column W (zero), of span 0 the first group of span 1
+                            const float e0 = grp_first ? (i == 0 ? 0.f : x[0]) : x[i];
+                            const float e1 = grp_last ? (i == MP - 1 ? 0.f : x[MP - 1]) : x[i];
+                            v[i] = pxl ? (f32x4){c.x + sd.y, c.y + sd.z, c.z + sd.w, c.w + e1}
+                                       : (f32x4){c.x + e0, c.y + sd.x, c.z + sd.y, c.w + sd.z};
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) v[i] = acc[i][0];
+                    }
 #pragma unroll
                     for (int i = 0; i < MP; ++i) {
-                        const f32x4 v = acc[i][0];
-                        const f32x4 pv = lane_xor8(v);
-                        epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y}, ep, cx,
+                        const f32x4 pv = lane_xor8(v[i]);
+                        epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v[i].z, pv.w, v[i].w} : (f32x4){v[i].x, pv.x, v[i].y, pv.y}, ep, cx,
                                                  e[i], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
                     }
                 }
@@ -1625,23 +1673,30 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)bwd_s2_fused_kernel<16, 8, 8, 32, 256, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, false>,
+#define DM_SPLIT_ATTR(BF_, ZF_)                                                                                       \
+        if (e == hipSuccess)                                                                                         \
+            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, BF_, ZF_>,                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
+        DM_SPLIT_ATTR(false, false) DM_SPLIT_ATTR(true, false) DM_SPLIT_ATTR(false, true) DM_SPLIT_ATTR(true, true)
+#undef DM_SPLIT_ATTR
         if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set.mark();
     }
     const int ntiles = B * (H / 8) * (W / 32);
     const int grid = dm_conv_bwd_s2_fused_num_blocks(B, CD, CX, H, W);
-    if (fused_bwd_block() == 0 && dm_backward_split_bf16())
-        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, true>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream,
-                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg());
-    else if (fused_bwd_block() == 0)
-        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, false>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream,
-                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg());
+    // the data gradient without structural zeros where a tile spans the row (W == 32: enc.4 of 128-pixel patches);
+    // DM_FUSED_BWD_ZF=0 keeps the three-column mapping for A/B runs
+    static const bool zf_off = [] { const char *e = getenv("DM_FUSED_BWD_ZF"); return e && e[0] == '0'; }();
+    const bool zf = W == 32 && !zf_off;
+#define DM_SPLIT_LAUNCH(BF_, ZF_)                                                                                                  \
+        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, BF_, ZF_>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
+                           to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg())
+    if (fused_bwd_block() == 0 && dm_backward_split_bf16()) {
+        if (zf) DM_SPLIT_LAUNCH(true, true); else DM_SPLIT_LAUNCH(true, false);
+    } else if (fused_bwd_block() == 0) {
+        if (zf) DM_SPLIT_LAUNCH(false, true); else DM_SPLIT_LAUNCH(false, false);
+    }
+#undef DM_SPLIT_LAUNCH
     else if (fused_bwd_block() == 512)
         hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 512, true>), dim3(grid), dim3(512), G::LDS_BYTES, (hipStream_t)stream,
                            to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles);

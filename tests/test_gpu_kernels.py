@@ -1728,8 +1728,8 @@ def test_vq_bf16_split_filter_scales_and_clusters(ops, D, K, scale_z, scale_e):
 def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     """Kernel D (csrc/conv_mfma.hip): data gradient + weight gradient of a Conv2d(8 -> 16, 4, 2, 1) from one staging of
     (dy, a_out, a_in), with the BatchNorm-backward operand, the ReLU mask of the layer input and the (sum, sum * input)
-    statistics -- against torch autograd, and against the two kernels it replaces (the data gradient bit for bit: same
-    MFMA order; the weight gradient to summation order).  B = 300: more tiles than workgroups (persistent loop)."""
+    statistics -- against torch autograd, and against the two kernels it replaces (the data gradient bit for bit where the
+    MFMA order is the same, hw = 64; the weight gradient to summation order).  B = 300: more tiles than workgroups."""
     CD, CX, H, W = 16, 8, hw, hw
     prev = ops.backward_precision("f32")                     # (the bit-for-bit comparisons below)
     dy, a_out = rnd(B, CD, H, W, seed=1), rnd(B, CD, H, W, seed=2)
@@ -1758,7 +1758,15 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
                            want_stats=True, mask=ops.Op(aid, 2, cTd), stat_q=aid)
     dst2 = torch.empty_like(dst)
     ops.wgrad(dyop(), ops.Op(aid, 3, cTd), dst2, B, CD, CX, H, W, 4)
-    assert torch.equal(dx, dx2)
+    if hw == 32:
+        # a tile spans the row: kernel D takes the data gradient without structural zeros (round 5) -- the centre column's and the
+        # outer columns' products in two accumulators, added at the end -- so the sum's order differs from the two-kernel path's
+        # single chain; both stay within the same distance of the float64 result
+        e_d, e_2 = (dx.cpu().double() - dx_ref.double()).abs().max(), (dx2.cpu().double() - dx_ref.double()).abs().max()
+        assert float(e_d) <= 1.5 * float(e_2) + 1e-7, (float(e_d), float(e_2))
+        close(dx, dx2, 2e-6, 2e-6 * float(dx2.abs().max()), "fused vs separate data gradient")
+    else:
+        assert torch.equal(dx, dx2)                          # the three-column mapping: same MFMA order, bit for bit
     close(dst, dst2, 2e-5, 2e-5 * float(dst2.abs().max()), "fused vs separate weight gradient")
     close(st.sum(0), st2.sum(0), 1e-7, 1e-7 * float(st2.sum(0).abs().max()), "statistics vs separate")   # (fp32 quads, grouped by tile)
     # two runs agree to the bit (fixed slab order, no float atomics)
