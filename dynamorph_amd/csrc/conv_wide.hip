@@ -14,7 +14,7 @@
 // Same operands / epilogue / statistics-slab semantics as the thin kernels (dm_operand, dm_weight_view, dm_epilogue);
 // the fp32 MFMA (v_mfma_f32_16x16x4_f32) keeps full precision.  ds_read_b32 / ds_write banks are dword address mod 32
 // inside each 32-lane half: strides are chosen so that the two k lanes x 16 column lanes of a half hit 32 banks
-// (DESIGN.md section 3a has the measurements behind each of these choices).
+// (HISTORY.md section 3a has the measurements behind each of these choices).
 #include "dm_common.h"
 #include <stdlib.h>
 #include <type_traits>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel summary of two `rocprofv3 --pmc` SQ passes: instructions per wave, share of
+"""Per-kernel summary of two `rocprofv3 --pmc` SQ passes (see HISTORY.md section 4): instructions per wave, share of
 wave time spent issuing / parked / stalled, MFMA pipe share.  usage: sq_summary.py gpurun_out/sq1 gpurun_out/sq2 [out.json]
 With a third argument the MFMA-busy share and the instruction counts per kernel are also written as JSON (bench.py quotes
 them next to its own timings: it cannot run under the profiler itself)."""
