@@ -354,6 +354,10 @@ class FusedTrainer:
             torch.cuda.current_stream().wait_stream(s)
             for b, sv in zip(bufs, saved):
                 b.copy_(sv)
+            if self.world > 1:
+                # no collective of this process may be in flight while the stream is capturing (the broadcast of the
+                # constructor, the previous step's all-reduce: their completion is polled by the backend's watchdog thread)
+                torch.cuda.synchronize(self.flat.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 sout = fn(sx, smask, stm)
