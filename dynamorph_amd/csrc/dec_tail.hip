@@ -256,7 +256,7 @@ void dec_tail_forward_kernel(const float *__restrict__ d2, const float *__restri
 // Steps S0 .. S0+NS-1 of one position row (step s covers X = 4s .. 4s+3; s = 16 is X = 64, only sx = 1 is real).
 template <int NS, bool FIRST, bool LAST>
 __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const float *__restrict__ sG, int aoff, int boff,
-                                            float rowmul, bool first_bad, bool last_ok, f32x4 (&acc)[2])
+                                            bool first_bad, bool last_ok, f32x4 (&acc)[2])
 {
     // operands requested PD steps ahead (PD + 1 a power of two).  One step: three ahead measured SLOWER (0.2746 -> 0.2816 ms
     // per launch in the step) -- the other wave of the SIMD fills a matrix instruction's wait, more reads in flight only
@@ -269,7 +269,7 @@ __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const 
     for (int s = 0; s < NS; ++s) {
         if (s + PD < NS) { a[(s + PD) & PD] = sA[aoff + 4 * (s + PD)]; bq[(s + PD) & PD] = sG[boff + 8 * (s + PD)]; }
         __builtin_amdgcn_sched_barrier(0);
-        float av = a[s & PD] * rowmul;
+        float av = a[s & PD];
         if (FIRST && s == 0) av = first_bad ? 0.f : av;
         if (LAST && s == NS - 1) av = last_ok ? av : 0.f;
         acc[s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[s & PD], acc[s & 1], 0, 0, 0);
@@ -324,7 +324,8 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     constexpr int GROWS = 2 * TT_TH + 2, GPS = GROWS * TT_DRS;   // g4 rows 2*y0-1 .. 2*y0+2*TH ; col j <-> ox = j - 4
     constexpr int NP = NIN * TT_C + NIN + TT_C + TT_C;           // dW6 | db6 | db4 | db2
     constexpr int NV = NIN * TT_C + NIN + TT_C;                  // per-lane partials of phase B
-    __shared__ __attribute__((aligned(16))) float sA[TT_C * APS];
+    constexpr int ZOFF = TT_C * APS, ZLEN = 72;                  // zeros behind the tile: a weight-gradient row that reads as 0 (17 steps of 4)
+    __shared__ __attribute__((aligned(16))) float sA[TT_C * APS + ZLEN];
     __shared__ __attribute__((aligned(16))) float sG[TT_C * GPS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
     __shared__ double s_part[4][NP];
@@ -349,6 +350,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         stage.issue(in, b, TT_C, H2, W2, y0 - 2, x0);
     }
     if (threadIdx.x < TT_C) *reinterpret_cast<f32x4 *>(s_coef + threadIdx.x * 4) = (f32x4){1.f, 0.f, 0.f, -__builtin_inff()};
+    if (threadIdx.x < ZLEN) sA[ZOFF + threadIdx.x] = 0.f;
     // the padding columns of the g4 tile (ox = -4..-1 and 128..131) are zero for every tile
     for (int i = threadIdx.x; i < TT_C * GROWS * 2; i += DM_BLOCK) {
         const int row = i >> 1, side = i & 1;
@@ -528,7 +530,10 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 const bool live = oy >= 0 && oy < OH && colin;
                 // rows 2*y0 .. 2*y0+2*TH-1 (WIDE: and the owned columns) belong to this tile: the halo gets its g4 but
                 // adds nothing to the sums
-                const float own = (gr >= 1 && gr <= 2 * TT_TH && ownl) ? 1.f : 0.f;
+                // (full-row form: only a wave's first and last row can be halo -- gr = 0 or 2 TH + 1 -- or lie outside the image;
+                //  the rows between them are owned and live by construction and skip the 0 / 1 factors)
+                const bool maybe_halo = WIDE || j == 0 || j == BR - 1;
+                const float own = !maybe_halo ? 1.f : ((gr >= 1 && gr <= 2 * TT_TH && ownl) ? 1.f : 0.f);
                 f32x2 gd[NIN], gdo[NIN], d4v[TT_C];
 #pragma unroll
                 for (int co = 0; co < TT_C; ++co)
@@ -550,7 +555,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     f32x2 t = dv - rxv[j][c];            // not FUSED: rows outside the image were loaded as 0
                     // (own and live are 0 / 1 factors: folded into the channel's constants -- the products are the same to the
                     //  bit and the kernel is bound by its vector instruction count; without WIDE both are wave-uniform)
-                    const float oiv = own * ivar[c];
+                    const float oiv = maybe_halo ? own * ivar[c] : ivar[c];
                     if constexpr (MASKED) {
                         // (read unconditionally, from the nearest row / column inside the image where the position lies outside:
                         //  there dv and x are 0 (not FUSED) or the row's factors own and gsv are (FUSED), so any finite mask
@@ -564,8 +569,8 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     } else if (FUSED) {
                         tl += (t * t) * oiv;
                     }
-                    gd[c] = t * ((!FUSED || live) ? gsv[c] : 0.f);   // FUSED: rows outside the image carry no gradient
-                    gdo[c] = gd[c] * own;
+                    gd[c] = t * ((!FUSED || !maybe_halo || live) ? gsv[c] : 0.f);   // FUSED: rows outside the image carry no gradient
+                    gdo[c] = maybe_halo ? gd[c] * own : gd[c];
                     pv[NIN * TT_C + c] += gdo[c];
                 }
 #pragma unroll
@@ -577,9 +582,12 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     for (int c = 1; c < NIN; ++c) g4 += w6r[c][co] * gd[c];
 #pragma unroll
                     for (int c = 0; c < NIN; ++c) pv[c * TT_C + co] += gdo[c] * d4;
+                    // (a packed multiply by clamp(d4 * inf) does this in two instructions instead of four -- measured: no gain, a
+                    //  v_pk_* costs the port twice a plain instruction)
                     g4.x = d4.x > 0.f ? g4.x : 0.f;
                     g4.y = d4.y > 0.f ? g4.y : 0.f;
-                    pv[NIN * TT_C + NIN + co] += g4 * own;
+                    if (maybe_halo) pv[NIN * TT_C + NIN + co] += g4 * own;
+                    else pv[NIN * TT_C + NIN + co] += g4;
                     *reinterpret_cast<f32x2 *>(pd) = g4;
                 }
             }
@@ -663,39 +671,41 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                         if (e >= part * NR / 3 && e < (part + 1) * NR / 3) issue_row(rcn, e / NIN, e % NIN);
                 }
             };
-            const float rm0 = (wave == 0 && wsy == 1) ? 0.f : 1.f;
-            const float rm8 = wsy == 1 ? 1.f : 0.f;
+            // rows without an own d2 row for this lane's sy read zeros instead: the A operand's address goes to the zeroed
+            // tail of sA (one select per row call, not a multiplication per step)
+            const bool z0 = wave == 0 && wsy == 1, z8 = wsy != 1;
             if constexpr (!WIDE) {
                 issue_part(0);
-                wgrad_steps<17, true, true>(sA, sG, wa_base + wave * TT_W, wb_base + 2 * wave * TT_DRS, rm0, w_first_bad,
+                wgrad_steps<17, true, true>(sA, sG, z0 ? ZOFF : wa_base + wave * TT_W, wb_base + 2 * wave * TT_DRS, w_first_bad,
                                             w_last_ok, wacc);
                 issue_part(1);
-                wgrad_steps<17, true, true>(sA, sG, wa_base + (wave + 4) * TT_W, wb_base + 2 * (wave + 4) * TT_DRS, 1.f,
+                wgrad_steps<17, true, true>(sA, sG, wa_base + (wave + 4) * TT_W, wb_base + 2 * (wave + 4) * TT_DRS,
                                             w_first_bad, w_last_ok, wacc);
                 issue_part(2);
-                const int a8 = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
+                const int a8 = z8 ? ZOFF : wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
                 if (wave < 3)
-                    wgrad_steps<4, true, false>(sA, sG, a8, b8, rm8, w_first_bad && wave == 0, false, wacc);
+                    wgrad_steps<4, true, false>(sA, sG, a8, b8, w_first_bad && wave == 0, false, wacc);
                 else
-                    wgrad_steps<5, false, true>(sA, sG, a8, b8, rm8, false, w_last_ok, wacc);
+                    wgrad_steps<5, false, true>(sA, sG, a8, b8, false, w_last_ok, wacc);
             } else {
                 // owned d2 columns 4 .. 59 of the tile: the term (X, sx) has its d2 column at X - sx, so steps 1 .. 15 with
                 // X = 4 (sx = 1: column 3) struck from the first and only (X = 60, sx = 1: column 59) kept of the last --
                 // the full-row form's edge handling, one step in.  Columns beyond the image hold zeros in sA.
                 issue_part(0);
-                wgrad_steps<15, true, true>(sA, sG, wa_base + wave * TT_W + 4, wb_base + 2 * wave * TT_DRS + 8, rm0,
+                wgrad_steps<15, true, true>(sA, sG, z0 ? ZOFF : wa_base + wave * TT_W + 4, wb_base + 2 * wave * TT_DRS + 8,
                                             w_first_bad, w_last_ok, wacc);
                 issue_part(1);
                 wgrad_steps<15, true, true>(sA, sG, wa_base + (wave + 4) * TT_W + 4, wb_base + 2 * (wave + 4) * TT_DRS + 8,
-                                            1.f, w_first_bad, w_last_ok, wacc);
+                                            w_first_bad, w_last_ok, wacc);
                 issue_part(2);
-                const int a8 = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
+                const int a8r = wa_base + TT_TH * TT_W + 16 * wave, b8 = wb_base + 2 * TT_TH * TT_DRS + 32 * wave;
+                const int a8 = z8 ? ZOFF : a8r;
                 if (wave == 0)
-                    wgrad_steps<3, true, false>(sA, sG, a8 + 4, b8 + 8, rm8, w_first_bad, false, wacc);
+                    wgrad_steps<3, true, false>(sA, sG, z8 ? ZOFF : a8r + 4, b8 + 8, w_first_bad, false, wacc);
                 else if (wave < 3)
-                    wgrad_steps<4, false, false>(sA, sG, a8, b8, rm8, false, false, wacc);
+                    wgrad_steps<4, false, false>(sA, sG, a8, b8, false, false, wacc);
                 else
-                    wgrad_steps<4, false, true>(sA, sG, a8, b8, rm8, false, w_last_ok, wacc);
+                    wgrad_steps<4, false, true>(sA, sG, a8, b8, false, w_last_ok, wacc);
             }
         }
         tidx = next;
