@@ -213,9 +213,22 @@ def roofline_dominant_kernel(model, x, workload):
             fn()
     ms = event_time_ms(graphed(ten), iters=5, warmup=2) / 10.0
     achieved = algo_bytes / (ms * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key, B), "avg_launch_ms": round(ms, 4),
-            "algorithmic_bytes_per_launch": algo_bytes}
+    rec = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key, B), "avg_launch_ms": round(ms, 4),
+           "algorithmic_bytes_per_launch": algo_bytes}
+    if workload != "c2":
+        # the same launch against the OTHER roof: dec.4 (transposed 4x4/s2, c2 -> c2 channels) and dec.6 (1x1, c2 -> NIN), each
+        # forward + data gradient + weight gradient, in exact fp32 (64 FLOP per cycle and SIMD on either pipe, DESIGN.md
+        # section 3): 2 * 3 * H * W * (c2 * c2 * 4 + NIN * c2) FLOP per patch.  Its intensity lies above the machine balance
+        # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP per byte): by the roofline model this kernel is compute bound, the HBM fraction
+        # above is kept as the headline because SURVEY 8(d) prices the thin layers against HBM.
+        flops = 2.0 * 3 * B * H * W * (c2 * c2 * 4 + NIN * c2)
+        tf = flops / (ms * 1e-3) / 1e12
+        rec["compute"] = {"algorithmic_flops_per_launch": flops, "achieved_tflops": round(tf, 1), "peak_tflops": MFMA_F32_PEAK_TFLOPS,
+                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                          "flop_per_algorithmic_byte": round(flops / algo_bytes, 1),
+                          "machine_balance_flop_per_byte": round(MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9), 1)}
+    return rec
 
 
 def north_star_targets(model, x):
