@@ -8,6 +8,7 @@ size-independent properties of test_gpu_model.py::test_round_trip_properties_ful
 The oracle evaluates the VectorQuantizer distances in chunks of 64 samples (OracleVQ.chunk; the reference's single
 expression is 8.6 GB at this batch, 17 GB in float64) -- bit-identical, tests/test_oracle.py."""
 import copy
+import os
 import gc
 
 import numpy as np
@@ -171,6 +172,20 @@ def test_c5_at_its_bench_batch_1024_self_consistency():
     p = hist_b.double() / P
     perp = float(torch.exp(-(p * torch.log(p + 1e-10)).sum()))
     assert abs(scal[1] - perp) <= 1e-4 * perp
+    # 65 536 positions (64 random patches) of the model's own -- clustered -- latents against the C oracle (oracle/vq_oracle.c:
+    # the reference's distance arithmetic and first-minimum rule), bit for bit; the whole batch would cost the CPU 4 . 10^9 distances
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle")])
+    cvq = ctypes.CDLL(os.path.join(root, "oracle", "libvq_oracle.so"))
+    pick = torch.randperm(B, generator=torch.Generator().manual_seed(11))[:64].sort().values
+    z_sub = np.ascontiguousarray(z[pick.to(DEV)].cpu().numpy())
+    cb_h = np.ascontiguousarray(cb.cpu().numpy())
+    idx_ref = np.empty((64, 32, 32), np.int64)
+    as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    cvq.oracle_vq_encode(as_p(z_sub), as_p(cb_h), as_p(idx_ref), 64, 16, K, 32, 32)
+    assert np.array_equal(idx_b[pick.to(DEV)].cpu().numpy(), idx_ref)
     del idx_e, out_e, out_b, q, z
     gc.collect()
 
