@@ -578,6 +578,14 @@ def train_loop_record(dev, resident_ms_per_step, n=32768, B=2048, epochs=3, feed
     return rec
 
 
+def _nccl_version():
+    """RCCL's version as torch reports it; a reporting field must never cost the line its value."""
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:      # noqa: BLE001
+        return f"unavailable ({type(e).__name__})"
+
+
 def _host_cpu():
     """(model name, physical cores) of the host from lscpu; falls back to os.cpu_count() // 2."""
     import subprocess
@@ -793,7 +801,7 @@ def main():
                       "allreduce_host_us": parts["allreduce_host_us"] if world > 1 else None,
                       "fwd_bwd_graph_us": parts["fwd_bwd_us"], "adam_us": parts["adam_us"],
                       "fwd_bwd_host_us": parts["fwd_bwd_host_us"], "adam_host_us": parts["adam_host_us"],
-                      "nccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+                      "nccl_version": _nccl_version() if backend == "nccl" else None,
                       "rank_ms_per_step_min": round(min(rank_ms), 4), "rank_ms_per_step_max": round(max(rank_ms), 4),
                       "op": "all_reduce(SUM) of the flat fp32 gradient bucket, then x 1/world" if world > 1 else "none (one process)"}
         if world > 1:
