@@ -21,11 +21,11 @@ __device__ __forceinline__ float gen_load(const Operand &op, int b, int c, int y
     const long long off = (((long long)b * Cphys + c) * H + y) * W + x;
     float v = op.p0[off];
     if (op.mode == DM_LOAD_IDENT) return v;
-    if (op.mode == DM_LOAD_RELU) return v < 0.f ? 0.f : v;        // select: a NaN stays NaN
+    if (op.mode == DM_LOAD_RELU) return dm_relu(v);                // a NaN stays NaN
     const float *cf = op.coef + (long long)b * op.coef_bstride + c * 4;
     if (op.mode == DM_LOAD_AFFINE2) return cf[0] * v + (cf[1] * op.p1[off] + cf[2]);
     v = cf[0] * v + cf[2];
-    if (op.mode == DM_LOAD_AFFINE_RELU) v = v < 0.f ? 0.f : v;
+    if (op.mode == DM_LOAD_AFFINE_RELU) v = dm_relu(v);
     return v;
 }
 
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(Operand in, WeightVie
                     const int ry = oy == 0 ? 0 : (oy == OH - 1 ? 2 : 1), rx = ox == 0 ? 0 : (ox == OW - 1 ? 2 : 1);
                     v = acc + tb[ry * 3 + rx];
                 }
-                if (ep.relu) v = v < 0.f ? 0.f : v;
+                if (ep.relu) v = dm_relu(v);
                 const long long o = (((long long)b * CO + co) * OH + oy) * OW + ox;
                 float mval = 1.f;
                 if (ep.mask.p0) {

@@ -440,8 +440,7 @@ __global__ __launch_bounds__(256, (FORM == W_S1 && TAPS == 9 && NPW == 4) ? 3 : 
                         v += bias;
                     }
                     if (ep.relu) {
-                        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
-                        v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                        v = dm_relu4(v);
                     }
                     const long long o = (((long long)b * CO + chn) * OH + oy) * OW + ox;
                     if (ep.mask.p0) {
@@ -608,13 +607,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wide_kernel(Operand S, Operand T
                 const int idx = (part * SB + j) * 256 + tid, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
                 f32x4 v = sv[j];
                 if (smode == DM_LOAD_RELU) {
-                    v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                    v = dm_relu4(v);
                 } else if (smode == DM_LOAD_AFFINE2) {
                     v = s_cfS[cl * 4] * v + (s_cfS[cl * 4 + 1] * su[j] + s_cfS[cl * 4 + 2]);
                 } else if (smode >= DM_LOAD_AFFINE) {
                     v = s_cfS[cl * 4] * v + s_cfS[cl * 4 + 2];
                     if (smode == DM_LOAD_AFFINE_RELU) {
-                        v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                        v = dm_relu4(v);
                     }
                 }
                 if (cl >= ncs) v = (f32x4){0.f, 0.f, 0.f, 0.f};

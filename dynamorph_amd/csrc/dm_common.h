@@ -106,8 +106,10 @@ static inline int dm_check_operand(const dm_operand *o, const char *who)
 
 #ifdef __HIPCC__
 // ReLU as torch.relu defines it: negative numbers to 0, every NaN (either sign) kept -- fmaxf / v_max_f32 would return 0
-// for a NaN and hide it from everything downstream.
-__device__ __forceinline__ float dm_relu(float v) { return v < 0.f ? 0.f : v; }
+// for a NaN and hide it from everything downstream.  gfx950 has the IEEE 754-2019 maximum, which propagates NaNs, as ONE
+// instruction (v_maximum3_f32 v, v, 0, 0); the compare + select form costs two, and the vector instructions of every load
+// transform and epilogue share the issue port with the matrix instructions.
+__device__ __forceinline__ float dm_relu(float v) { return __builtin_elementwise_maximum(v, 0.f); }
 __device__ __forceinline__ f32x4 dm_relu4(f32x4 v) { return (f32x4){dm_relu(v.x), dm_relu(v.y), dm_relu(v.z), dm_relu(v.w)}; }
 
 // Load 4 contiguous elements of channel c / sample b through the operand's transform.
