@@ -709,7 +709,7 @@ struct FusedBwdGeom {
     static constexpr int LDS_FLOATS = (TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) + 2 * DM_COEF_MAX_C * 4;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4 + 8 * 16 * 2 * sizeof(double);
     // role-split form: two tile buffers + the coefficient tables + the statistics scratch
-    static constexpr size_t SPLIT_LDS_BYTES = (size_t)(2 * TILE_FLOATS + 2 * DM_COEF_MAX_C * 4) * 4 + 4 * 16 * 2 * sizeof(double);
+    static constexpr size_t SPLIT_LDS_BYTES = (size_t)(2 * TILE_FLOATS + 2 * DM_COEF_MAX_C * 4) * 4 + 8 * 16 * 2 * sizeof(double);
     static_assert(RED_FLOATS <= TILE_FLOATS, "the slab combine reuses a tile buffer");
 };
 
@@ -1234,6 +1234,321 @@ void bwd_s2_split_kernel(Operand dy, Operand tin, WeightView wv, float *__restri
     }
 }
 
+// ---- kernel D with three kinds of waves (round 5): 256 (2 + NDG) threads = 2 + NDG waves per SIMD, one barrier per tile as before.
+//   NDG groups of 4 waves   data gradient of tile i (products + epilogue); two groups: four rows of the tile each
+//   4 waves                 loads of tile i+1, BatchNorm-backward / ReLU transform, LDS writes into the other buffer -- vector work only
+//   4 waves                 weight-gradient products of tile i
+// In the two-role form a SIMD hosts two matrix-heavy waves and its port idles 37 % of the time (both waiting at once: LDS
+// reads behind the barrier, the loader's global loads, the epilogue's stores); the third wave's transform and commit fill
+// those gaps.  Every role stays below 168 registers: the staging registers (100) and the weight-gradient accumulators no
+// longer meet in one wave.
+template <int CD, int CX, int TH, int TW, bool BF, bool ZF, int NDG>
+__global__ __launch_bounds__(256 * (2 + NDG), 1)
+void bwd_s2_roles3_kernel(Operand dy, Operand tin, WeightView wv, float *__restrict__ dx, Epilogue ep,
+                         float *__restrict__ wslabs, int H, int W, int ntiles, int dbg)
+{
+    // dbg (DM_FUSED_BWD_DBG, measurements only; results are then wrong): 1 skips the weight-gradient products, 2 the data
+    // gradient, 4 the loads and commits of every tile but the first
+    using G = FusedBwdGeom<CD, CX, TH, TW>;
+    constexpr int RW = 4;                                   // waves per role
+    constexpr int IH = G::IH, RS = G::RS, COLS4 = G::COLS4, PS = G::PS;
+    constexpr int TROWS = G::TROWS, RST = G::RST, TCOLS4 = G::TCOLS4, PST = G::PST, NTT = G::NTT, N = G::N;
+    constexpr int BUF = CD * PS + CX * PST;                 // floats of one (da, T) tile pair
+    constexpr int CGN = TW / 16, MP = 2, NPASS = TH * CGN / (RW * MP), WROWS = TH / RW;
+    static_assert(TH * CGN == RW * MP * NPASS && TH == RW * WROWS, "tile split over the waves of a role");
+    constexpr int TAPX = 3, KS = (CD / 4) * 2 * TAPX;
+    extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+    float *s_coefD = fb_lds + 2 * BUF, *s_coefT = s_coefD + DM_COEF_MAX_C * 4;
+    double (*s_stat)[2] = reinterpret_cast<double (*)[2]>(s_coefT + DM_COEF_MAX_C * 4);
+
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    static_assert(NDG == 1 || NDG == 2, "one or two groups of data-gradient waves");
+    const int grp = wave / RW;                              // (wave-uniform) < NDG: data gradient, NDG: loads + commit, NDG + 1: weight gradient
+    const int role = grp < NDG ? 0 : grp - NDG + 1;
+    const int rw = wave & (RW - 1);
+    const int OH = 2 * H, OW = 2 * W;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    auto coords = [&](int t, int &tb, int &ty0, int &tx0) {
+        tx0 = (t % tiles_x) * TW; t /= tiles_x;
+        ty0 = (t % tiles_y) * TH; tb = t / tiles_y;
+    };
+    stage_coef(s_coefD, dy, 0, CD);
+    stage_coef(s_coefT, tin, 0, CX);
+    int tidx = blockIdx.x;
+
+    if (role == 1) {
+        // ================================================================ waves 4..7: loads, transform, commits
+        TileStage<CD, IH, COLS4, RS, PS, true, 256> stD;
+        TileStage<CX, TROWS, TCOLS4, RST, PST, false, 256> stT;
+        const int tl = (int)threadIdx.x - 256 * NDG;
+        stD.init(H, W, tl);
+        stT.init(OH, OW, tl);
+        int b, y0, x0;
+        if (tidx < ntiles) {
+            coords(tidx, b, y0, x0);
+            stD.issue(dy, b, CD, H, W, y0 - 1, x0 - 4);
+        }
+        __syncthreads();                                    // coefficient tables staged
+        if (tidx < ntiles) {
+            stD.template commit<BF>(fb_lds, s_coefD, CD, H, W, y0 - 1, x0 - 4, dy.mode);
+            stT.issue(tin, b, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4);
+            stT.template commit<BF>(fb_lds + CD * PS, s_coefT, CX, OH, OW, 2 * y0 - 1, 2 * x0 - 4, tin.mode);
+        }
+        __syncthreads();                                    // tile 0 in buffer 0
+        int p = 0;
+        while (tidx < ntiles) {
+            const int next = tidx + gridDim.x;
+            float *nxt = fb_lds + (1 - p) * BUF;
+            int nb = 0, ny0 = 0, nx0 = 0;
+            if (next < ntiles && !(dbg & 4)) {              // (uniform) the next tile into the other buffer (nobody reads it yet)
+                // the two tensors one after the other: these waves have the tile's whole duration for two round trips, and the
+                // staging registers of one tensor (56 / 44) fit where both (100) spilled
+                coords(next, nb, ny0, nx0);
+                stD.issue(dy, nb, CD, H, W, ny0 - 1, nx0 - 4);
+                stD.template commit<BF>(nxt, s_coefD, CD, H, W, ny0 - 1, nx0 - 4, dy.mode);
+                stT.issue(tin, nb, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4);
+                stT.template commit<BF>(nxt + CD * PS, s_coefT, CX, OH, OW, 2 * ny0 - 1, 2 * nx0 - 4, tin.mode);
+            }
+            __syncthreads();                                // tile i consumed by everybody, tile i+1 complete
+            p ^= 1;
+            tidx = next;
+        }
+        for (int w = 0; w < RW + 2; ++w) __syncthreads();      // (the other roles' slab combine and statistics)
+    } else if (role == 2) {
+        // ================================================================ waves 8..11: weight gradient
+        int bl[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+            const int n = 16 * t + m;
+            bl[t] = CD * PS + (n >> 4) * PST + ((n >> 2) & 3) * RST + (n & 3) + 3 + 8 * kq + 2 * rw * RST;
+        }
+        const int al = m * PS + (rw + 1) * RS + 4 + 4 * kq;
+        f32x4 wacc[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                    // coefficient tables staged
+        __syncthreads();                                    // tile 0 in buffer 0
+        int p = 0;
+        while (tidx < ntiles) {
+            const float *cur = fb_lds + p * BUF;
+            // ---- weight gradient of the current tile: position rows rw, rw + 4; spans of 16 positions; 4 K-steps per span
+            if (!(dbg & 1)) {
+                constexpr int NSPAN = TW / 16, NQ = WROWS * NSPAN * 4;
+                auto aoff = [](int q) { return (q / (NSPAN * 4)) * RW * RS + 16 * ((q >> 2) % NSPAN); };
+                auto boff = [](int q) { return (q / (NSPAN * 4)) * RW * 2 * RST + 32 * ((q >> 2) % NSPAN) + 2 * (q & 3); };
+                if constexpr (BF) {
+                    // a span of 16 positions = four K-steps = ONE operand: A from one 16-byte read, B four 4-byte reads per
+                    // N tile; units of (span, half of the N tiles), the next unit's operands requested before this one's products
+                    constexpr int NU = WROWS * NSPAN * 2, HT = NTT / 2;
+                    f32x4 av[2];
+                    float bv[2][HT][4];
+                    av[0] = *reinterpret_cast<const f32x4 *>(cur + al);
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bv[0][t][j] = cur[bl[t] + boff(j)];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int sp = u >> 1, half = u & 1;
+                        if (u + 1 < NU) {
+                            const int sp1 = (u + 1) >> 1, half1 = (u + 1) & 1;
+                            if (half1 == 0) av[sp1 & 1] = *reinterpret_cast<const f32x4 *>(cur + al + aoff(4 * sp1));
+#pragma unroll
+                            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) bv[(u + 1) & 1][t][j] = cur[bl[half1 * HT + t] + boff(4 * sp1 + j)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const dm_u32x4_t a4 = __builtin_bit_cast(dm_u32x4_t, av[sp & 1]);
+                        const dm_u32x4_t ar = dm_rot16(a4);
+#pragma unroll
+                        for (int t = 0; t < HT; ++t) {
+                            const float(&b)[4] = bv[u & 1][t];
+                            const dm_u32x4_t b4 = {__builtin_bit_cast(unsigned, b[0]), __builtin_bit_cast(unsigned, b[1]),
+                                                   __builtin_bit_cast(unsigned, b[2]), __builtin_bit_cast(unsigned, b[3])};
+                            wacc[half * HT + t] = dm_mfma_split(a4, ar, b4, wacc[half * HT + t]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                f32x4 av[2];
+                float bv[2][NTT];
+                av[0] = *reinterpret_cast<const f32x4 *>(cur + al);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) bv[0][t] = cur[bl[t]];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + 1 < NQ) {
+                        if (((q + 1) & 3) == 0) av[((q + 1) >> 2) & 1] = *reinterpret_cast<const f32x4 *>(cur + al + aoff(q + 1));
+#pragma unroll
+                        for (int t = 0; t < NTT; ++t) bv[(q + 1) & 1][t] = cur[bl[t] + boff(q + 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float a = av[(q >> 2) & 1][q & 3];
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[q & 1][t], wacc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                }
+            }
+            __syncthreads();                                // tile i consumed by everybody, tile i+1 complete
+            p ^= 1;
+            tidx += gridDim.x;
+        }
+        // ---- weight-gradient slab: the four weight-gradient waves in wave order (buffer 0 is free: the last barrier is behind us)
+        float *red = fb_lds;
+        for (int w = 0; w < RW; ++w) {
+            __syncthreads();
+            if (rw == w) {
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    f32x4 *pp = reinterpret_cast<f32x4 *>(red + (t * 64 + lane) * 4);
+                    if (w == 0) *pp = wacc[t];
+                    else *pp = *pp + wacc[t];
+                }
+            }
+        }
+        __syncthreads();
+        __syncthreads();                                    // (the statistics write-out of the other role)
+    } else {
+        // ================================================================ waves 0..3: data gradient
+        const int co = m & 7, pxl = m >> 3;
+        constexpr int NTW = ZF ? 2 : 1, KSW = ZF ? (CD / 4) * 2 : KS;       // ZF: N tiles (centre, side) of 8 K-steps (cg4, a)
+        float wreg[2][NTW][KSW];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int s = 0; s < KSW; ++s) {
+                    int cg4, a, kx;
+                    if constexpr (ZF) { cg4 = s >> 1; a = s & 1; kx = t == 0 ? 1 + pxl : (pxl ? 0 : 3); }
+                    else { cg4 = s / (2 * TAPX); const int j = s % (2 * TAPX); a = j / TAPX; kx = pxl + 3 - 2 * (j % TAPX); }
+                    const int c = 4 * cg4 + kq;
+                    const int ky = py + 3 - 2 * (py + a);
+                    float wvl = 0.f;
+                    if (ky >= 0 && ky <= 3 && kx >= 0 && kx <= 3) wvl = wv.w[wv.off + co * wv.sn + c * wv.sc + ky * wv.sky + kx * wv.skx];
+                    wreg[py][t][s] = BF ? split_pack1(wvl) : wvl;
+                }
+        float mc0, mc2;
+        mask_coef(ep, 0, co, mc0, mc2);
+        double s1 = 0.0, s2 = 0.0;
+        const int abase = kq * PS + m + 3;
+        EpiCtx<SIDE_MASK> cx;
+        const long long sample_elems = (long long)CX * OH * OW;
+        const int chan_off = (co * OH * OW + 8 * kq + 4 * pxl) * 4;
+        // ZF: the lane that holds the neighbouring M row of this lane's first (px = 0) or last (px = 1) row: 16 lanes down or up
+        const int nb_addr = ((pxl ? lane + 16 : lane - 16) & 63) * 4;
+        const bool grp_first = kq == 0, grp_last = kq == 3;
+        __syncthreads();                                    // (coefficient tables)
+        __syncthreads();                                    // tile 0 in buffer 0
+        int p = 0;
+        while (tidx < ntiles) {
+            int cb, cy0, cx0;
+            coords(tidx, cb, cy0, cx0);
+            const float *cur = fb_lds + p * BUF;
+            cx.rebase(ep, dx, sample_elems, cb);
+            if (!(dbg & 2)) {
+#pragma unroll
+            for (int pass0 = 0; pass0 < NPASS / NDG; ++pass0) {
+                const int pass = NDG == 1 ? pass0 : __builtin_amdgcn_readfirstlane(grp) + NDG * pass0;      // (two groups: one pass each)
+                const float *ap[MP];
+                int obase[MP];
+#pragma unroll
+                for (int i = 0; i < MP; ++i) {
+                    // ZF: a wave takes BOTH 16-position spans of a row (the side accumulators of neighbouring spans meet in
+                    // its registers); else M tile rw + RW * (MP * pass + i)
+                    const int ti = rw + RW * (MP * pass + i);
+                    const int r = ZF ? rw + RW * pass : ti / CGN, cg = ZF ? i : ti % CGN;
+                    ap[i] = cur + r * RS + 16 * cg + abase;
+                    obase[i] = chan_off + (2 * (cy0 + r) * OW + 2 * (cx0 + 16 * cg)) * 4;
+                }
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    EpiIn<SIDE_MASK> e[MP];
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) epilogue_loads<SIDE_MASK>(e[i], cx, obase[i] + py * OW * 4);
+                    f32x4 acc[MP][NTW];
+#pragma unroll
+                    for (int i = 0; i < MP; ++i)
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    auto off = [py](int s) {
+                        if constexpr (ZF) return 4 * (s >> 1) * PS + (py + (s & 1)) * RS + 1;
+                        else {
+                            const int cg4 = s / (2 * TAPX), j = s % (2 * TAPX), a = j / TAPX, bb = j % TAPX;
+                            return 4 * cg4 * PS + (py + a) * RS + bb;
+                        }
+                    };
+                    if constexpr (BF) mfma_tiles_split<MP, NTW, KSW>(ap, wreg[py], acc, off);
+                    else mfma_tiles<MP, NTW, KSW, ZF ? 4 : TAPX * 2>(ap, wreg[py], acc, off);
+                    f32x4 v[MP];
+                    if constexpr (ZF) {
+                        static_assert(MP == 2 && CGN == 2, "the two spans of a row in one wave");
+                        // row P of the side product goes to row P + 1 (px = 0) or P - 1 (px = 1) of the result; M row =
+                        // 16 i + 4 kq + register.  The one row per tile that crosses the lanes: the provider hands over its last
+                        // (px = 0) or first (px = 1) register, the receiver reads 16 lanes down / up (wrapping into the other span)
+                        float x[MP];
+#pragma unroll
+                        for (int i = 0; i < MP; ++i)
+                            x[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+                                       nb_addr, __builtin_bit_cast(int, pxl ? acc[i][1].x : acc[i][1].w)));
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) {
+                            const f32x4 c = acc[i][0], sd = acc[i][1];
+                            // px = 0: first lane group of span 0 meets column -1 (zero), of span 1 the last group of span 0
+                            // px = 1: last lane group of span 1 meets column W (zero), of span 0 the first group of span 1
+                            const float e0 = grp_first ? (i == 0 ? 0.f : x[0]) : x[i];
+                            const float e1 = grp_last ? (i == MP - 1 ? 0.f : x[MP - 1]) : x[i];
+                            v[i] = pxl ? (f32x4){c.x + sd.y, c.y + sd.z, c.z + sd.w, c.w + e1}
+                                       : (f32x4){c.x + e0, c.y + sd.x, c.z + sd.y, c.w + sd.z};
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) v[i] = acc[i][0];
+                    }
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) {
+                        const f32x4 pv = lane_xor8(v[i]);
+                        epilogue_tail<SIDE_MASK>(pxl ? (f32x4){pv.z, v[i].z, pv.w, v[i].w} : (f32x4){v[i].x, pv.x, v[i].y, pv.y}, ep, cx,
+                                                 e[i], mc0, mc2, obase[i] + py * OW * 4, s1, s2);
+                    }
+                }
+            }
+            }
+            __syncthreads();
+            p ^= 1;
+            tidx += gridDim.x;
+        }
+        // (the loaders combine their accumulators through LDS: RW + 1 barriers)
+        for (int w = 0; w < RW + 1; ++w) __syncthreads();
+        if (ep.stats) {
+            double a = s1, c = s2;
+            a += __shfl_xor(a, 16, 64); c += __shfl_xor(c, 16, 64);
+            a += __shfl_xor(a, 32, 64); c += __shfl_xor(c, 32, 64);
+            a += __shfl_xor(a, 8, 64); c += __shfl_xor(c, 8, 64);
+            if (lane < CX) { s_stat[(grp * RW + rw) * 16 + lane][0] = a; s_stat[(grp * RW + rw) * 16 + lane][1] = c; }
+        }
+        __syncthreads();
+        if (ep.stats && threadIdx.x < CX) {
+            double ta = 0.0, tc = 0.0;
+#pragma unroll
+            for (int w = 0; w < RW * NDG; ++w) { ta += s_stat[w * 16 + threadIdx.x][0]; tc += s_stat[w * 16 + threadIdx.x][1]; }
+            ep.stats[((long long)blockIdx.x * CX + threadIdx.x) * 2 + 0] = ta;
+            ep.stats[((long long)blockIdx.x * CX + threadIdx.x) * 2 + 1] = tc;
+        }
+    }
+    // (barriers after the tile loop: RW + 2 on either side)
+    // ---- all 512 threads: this workgroup's weight-gradient slab out of LDS.  red[(t * 64 + l) * 4 + j] is dy channel
+    //      4 (l >> 4) + j, column 16 t + (l & 15)
+    float *slab = wslabs + (long long)blockIdx.x * (CD * N);
+    for (int i = threadIdx.x; i < NTT * 256; i += 256 * (2 + NDG)) {
+        const int j = i & 3, l = (i >> 2) & 63, t = i >> 8;
+        slab[(4 * (l >> 4) + j) * N + 16 * t + (l & 15)] = fb_lds[i];
+    }
+}
+
 // ------------------------------------------------------------------------------ dispatch
 struct ConvArgs {
     Operand in; WeightView wv; float *out; Epilogue ep;
@@ -1679,6 +1994,12 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
         DM_SPLIT_ATTR(false, false) DM_SPLIT_ATTR(true, false) DM_SPLIT_ATTR(false, true) DM_SPLIT_ATTR(true, true)
 #undef DM_SPLIT_ATTR
+#define DM_ROLES3_ATTR(BF_, ZF_)                                                                                      \
+        if (e == hipSuccess)                                                                                         \
+            e = hipFuncSetAttribute((const void *)bwd_s2_roles3_kernel<16, 8, 8, 32, BF_, ZF_, 1>,                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
+        DM_ROLES3_ATTR(false, false) DM_ROLES3_ATTR(true, false) DM_ROLES3_ATTR(false, true) DM_ROLES3_ATTR(true, true)
+#undef DM_ROLES3_ATTR
         if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set.mark();
     }
@@ -1691,11 +2012,25 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
 #define DM_SPLIT_LAUNCH(BF_, ZF_)                                                                                                  \
         hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, BF_, ZF_>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
                            to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg())
-    if (fused_bwd_block() == 0 && dm_backward_split_bf16()) {
+    // three roles (768 threads) or two (512): DM_FUSED_BWD_ROLES=2 keeps the two-role form for A/B runs
+    static const int roles = [] { const char *e = getenv("DM_FUSED_BWD_ROLES"); return e ? atoi(e) : 3; }();
+    const bool roles3 = roles >= 3;
+#define DM_ROLES3_LAUNCH(BF_, ZF_)                                                                                                 \
+        /* (a second group of data-gradient waves, NDG = 2 / 1024 threads, measured slower: 240.6 against 227.4 us) */                 \
+        { hipLaunchKernelGGL((bwd_s2_roles3_kernel<16, 8, 8, 32, BF_, ZF_, 1>), dim3(grid), dim3(768), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
+                               to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg()); }
+    if (fused_bwd_block() == 0 && roles3) {
+        const bool bf = dm_backward_split_bf16();
+        if (bf && zf) DM_ROLES3_LAUNCH(true, true)
+        else if (bf) DM_ROLES3_LAUNCH(true, false)
+        else if (zf) DM_ROLES3_LAUNCH(false, true)
+        else DM_ROLES3_LAUNCH(false, false)
+    } else if (fused_bwd_block() == 0 && dm_backward_split_bf16()) {
         if (zf) DM_SPLIT_LAUNCH(true, true); else DM_SPLIT_LAUNCH(true, false);
     } else if (fused_bwd_block() == 0) {
         if (zf) DM_SPLIT_LAUNCH(false, true); else DM_SPLIT_LAUNCH(false, false);
     }
+#undef DM_ROLES3_LAUNCH
 #undef DM_SPLIT_LAUNCH
     else if (fused_bwd_block() == 512)
         hipLaunchKernelGGL((bwd_s2_fused_kernel<16, 8, 8, 32, 512, true>), dim3(grid), dim3(512), G::LDS_BYTES, (hipStream_t)stream,
