@@ -344,6 +344,154 @@ void conv4x4s2_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilog
     }
 }
 
+// ============================================================================ kernel A2 (round 5)
+// The first convolution (enc.0 o enc.1 composite: CIN -> 8 channels, 4x4 / stride 2, border-bias table) with the output positions
+// of a row taken in PAIRS.  With 8 output channels kernel A leaves half of the 16-wide N dimension empty: 8 K-steps (channel, ky)
+// x 4 taps kx per 16 positions, every second matrix column multiplying zeros.  Here an M row is the pair p = (X = 2p, 2p + 1) and
+// N = (member j, channel).  The two members' 4-tap windows, input columns 4p-1 .. 4p+2 and 4p+1 .. 4p+4, share the columns 4p+1,
+// 4p+2; the outer columns 4p-1, 4p (member 0) and 4p+3, 4p+4 (member 1) are the SAME pair of columns one M row apart.  So:
+//     centre product   A = columns 4p+1, 4p+2 of two input rows (k lanes = (ky & 1, column)), B = W[kx = 2, 3 | 0, 1]
+//     side product     A = columns 4p-1, 4p,                                             B = W[kx = 0, 1 | 2, 3]
+//     out[p][member 0] = centre[p] + side[p]          out[p][member 1] = centre[p] + side[p + 1]
+// CIN * 2 K-steps per product, every matrix column real.  A row of 64 positions = 32 pairs = two M tiles; the side product takes
+// a third M tile for its row 32 (the last position's outer columns; its other 15 rows are never read): 5 CIN * 2 = 20 matrix
+// instructions per row where kernel A issues 32.  The member-1 half takes its side value one M row up: a register rename inside a
+// lane and one ds_bpermute per M tile (kernel D's recipe).  Output quads are formed with the partner lane as in kernel C.
+template <int CIN, int TH, int WPS>
+__global__ __launch_bounds__(DM_BLOCK, WPS)
+void conv4x4s2_pair_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep, int Cphys, int H, int W, int ntiles,
+                           int nslabs, int per_tile)
+{
+    constexpr int NOUT = 8, TW = 64;
+    constexpr int IH = 2 * TH + 2, RS = 2 * TW + 8, COLS4 = RS / 4, PS = IH * RS;
+    constexpr int KS = CIN * 2, RPW = TH / 4;              // K-steps (channel, ky pair) per product; rows per wave
+    static_assert(TH % 4 == 0, "rows over four waves");
+    __shared__ __attribute__((aligned(16))) float tile[CIN * PS + 64];      // (+ the reach of the side product's third M tile)
+    __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
+    __shared__ double s_stat[4 * 16][2];
+
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int tiles_x = Wo / TW, tiles_y = Ho / TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int co = m & 7, mj = m >> 3;                     // the lane's output channel and pair member
+    const int kyl = kq >> 1, col = kq & 1;                 // k lane = (row of the ky pair, column of the column pair)
+
+    TileStage<CIN, IH, COLS4, RS, PS, false> stage;
+    stage.init(H, W);
+    int tidx = blockIdx.x, b = 0, oy0 = 0, ox0 = 0;
+    if (tidx < ntiles) {
+        int t = tidx;
+        ox0 = (t % tiles_x) * TW; t /= tiles_x;
+        oy0 = (t % tiles_y) * TH; b = t / tiles_y;
+        stage.issue(in, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+        stage_coef(s_coef, in, b, Cphys);
+    }
+    if (threadIdx.x < 64) tile[CIN * PS + threadIdx.x] = 0.f;
+
+    // bias_border[row class][column class] of the lane's channel
+    const float *tp = ep.bias_border + co;
+    const float tb00 = tp[0 * NOUT], tb01 = tp[1 * NOUT], tb02 = tp[2 * NOUT];
+    const float tb10 = tp[3 * NOUT], tb11 = tp[4 * NOUT], tb12 = tp[5 * NOUT];
+    const float tb20 = tp[6 * NOUT], tb21 = tp[7 * NOUT], tb22 = tp[8 * NOUT];
+    // B[k = kq][n = m]: K-step s = (channel s >> 1, ky pair s & 1): ky = 2 (s & 1) + kyl; centre kx = col + (member 0 ? 2 : 0),
+    // side kx = col + (member 0 ? 0 : 2)
+    float wc[1][KS], ws[1][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c = s >> 1, ky = 2 * (s & 1) + kyl;
+        const long long base = wv.off + co * wv.sn + c * wv.sc + ky * wv.sky;
+        wc[0][s] = wv.w[base + (col + (mj ? 0 : 2)) * wv.skx];
+        ws[0][s] = wv.w[base + (col + (mj ? 2 : 0)) * wv.skx];
+    }
+    float mc0, mc2;
+    mask_coef(ep, 0, co, mc0, mc2);
+    double s1 = 0.0, s2 = 0.0;
+    // A[m = pair][k = kq]: LDS column of input column x is x - (2 ox0 - 4); centre columns 4p + 5 + col, side columns 4p + 3 + col
+    const int abase = kyl * RS + 4 * m + 5 + col;
+    auto off = [](int s) { return (s >> 1) * PS + 2 * (s & 1) * RS; };
+    const int nb_addr = ((lane + 16) & 63) * 4;            // the lane that holds the next M row of this lane's last one
+    EpiCtx<SIDE_NONE> cx;
+    const long long sample_elems = (long long)NOUT * Ho * Wo;
+    const int chan_off = (co * Ho * Wo + 8 * kq + 4 * mj) * 4;      // the lane's channel plane + its output quad inside 32 positions
+    while (tidx < ntiles) {
+        __syncthreads();                                   // previous tile consumed; coefficient table visible
+        stage.commit(tile, s_coef, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4, in.mode);
+        __syncthreads();
+        const int cb = b, cy0 = oy0, cx0 = ox0;            // the tile now in LDS
+        const int next = tidx + gridDim.x;
+        {                                                  // (no next tile: empty descriptor, every load returns 0)
+            int t = next < ntiles ? next : tidx;
+            ox0 = (t % tiles_x) * TW; t /= tiles_x;
+            oy0 = (t % tiles_y) * TH; b = t / tiles_y;
+        }
+        const auto scx = stage.begin(in, next < ntiles, b, Cphys, H, W, 2 * oy0 - 1, 2 * ox0 - 4);
+        const bool recoef = next < ntiles && coef_changes(in, cb, b);       // (uniform) the next tile is another sample's
+        f32x4 cfn = {1.f, 0.f, 0.f, 0.f};
+        if (recoef) cfn = coef_fetch(in, b, Cphys);
+        cx.rebase(ep, out, sample_elems, cb);
+        constexpr int NE = decltype(stage)::N;
+#pragma unroll
+        for (int pp = 0; pp < RPW; ++pp) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (e >= pp * NE / RPW && e < (pp + 1) * NE / RPW) stage.issue_one(e, scx);
+            const int r = wave + 4 * pp;
+            const float *apc[2], *aps[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                aps[i] = tile + (2 * r) * RS + 64 * i + abase - 2;
+                if (i < 2) apc[i] = tile + (2 * r) * RS + 64 * i + abase;
+            }
+            f32x4 accC[2][1], accS[3][1];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                accS[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (i < 2) accC[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            mfma_tiles<2, 1, KS, KS < 4 ? KS : 4>(apc, wc, accC, off);
+            mfma_tiles<3, 1, KS, KS < 4 ? KS : 4>(aps, ws, accS, off);
+            // member 1 takes the side product one M row up: the row that crosses the lanes comes from 16 lanes up, wrapping into
+            // the next M tile's first lane group
+            float xs[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                xs[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb_addr, __builtin_bit_cast(int, accS[i][0].x)));
+            const int y = cy0 + r;
+            const bool r0 = y == 0, r2 = y == Ho - 1;
+            const float bl = r0 ? tb00 : (r2 ? tb20 : tb10);
+            const float bm = r0 ? tb01 : (r2 ? tb21 : tb11);
+            const float br = r0 ? tb02 : (r2 ? tb22 : tb12);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 c = accC[i][0], sd = accS[i][0];
+                const float up = kq == 3 ? xs[i + 1] : xs[i];
+                const f32x4 v = mj ? (f32x4){c.x + sd.y, c.y + sd.z, c.z + sd.w, c.w + up}
+                                   : (f32x4){c.x + sd.x, c.y + sd.y, c.z + sd.z, c.w + sd.w};
+                // lane (member j, channel): pairs 16 i + 4 kq + (0..3); with the partner lane's values: four consecutive positions
+                const f32x4 pv = lane_xor8(v);
+                f32x4 qd = mj ? (f32x4){pv.z, v.z, pv.w, v.w} : (f32x4){v.x, pv.x, v.y, pv.y};
+                const int xq = cx0 + 32 * i + 8 * kq + 4 * mj;
+                qd += (f32x4){xq == 0 ? bl : bm, bm, bm, xq + 3 == Wo - 1 ? br : bm};
+                qd = bias_relu(qd, ep, 0.f);
+                EpiIn<SIDE_NONE> e0;
+                epilogue_tail<SIDE_NONE>(qd, ep, cx, e0, mc0, mc2, chan_off + ((cy0 + r) * Wo + cx0 + 32 * i) * 4, s1, s2);
+            }
+        }
+        if (per_tile && ep.stats) {                         // per-sample BatchNorm statistics: one slab per TILE
+            double a1[1] = {s1 + __shfl_xor(s1, 8, 64)}, a2[1] = {s2 + __shfl_xor(s2, 8, 64)};      // the two members of a channel
+            stats_reduce<1, false>(a1, a2, s_stat, ep, NOUT, tidx);
+            s1 = 0.0; s2 = 0.0;
+        }
+        if (recoef) coef_put(s_coef, in, cfn, Cphys);   // visible after the barrier at the loop top
+        tidx = next;
+    }
+    if (ep.stats && !per_tile) {
+        double a1[1] = {s1 + __shfl_xor(s1, 8, 64)}, a2[1] = {s2 + __shfl_xor(s2, 8, 64)};
+        stats_reduce<1, false>(a1, a2, s_stat, ep, NOUT, blockIdx.x);
+        zero_unowned_slabs(ep, NOUT, nslabs);
+    }
+}
+
 // ============================================================================ kernel B
 template <int CIN, int NT, int NPASS, int TAPS, bool PIX, int TH, int TW, bool TWO, int SIDE, int WPS, bool BF = false>
 __global__ __launch_bounds__(DM_BLOCK, WPS)
@@ -1595,6 +1743,13 @@ int conv4_tw(int CIN, int Wo)
     return Wo < cap ? Wo : cap;
 }
 
+// the first convolution with output positions in pairs (kernel A2); DM_CONV4_PAIR=0 keeps kernel A for A/B runs
+bool conv4_pair_on()
+{
+    static const bool off = [] { const char *e = getenv("DM_CONV4_PAIR"); return e && e[0] == '0'; }();
+    return !off;
+}
+
 template <int CIN, int TW>
 void launch_conv4(const ConvArgs &a)
 {
@@ -1615,7 +1770,11 @@ void launch_conv4(const ConvArgs &a)
                                    dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
                                    a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),    \
                                    a.per_tile);                                                                       \
-        } else if (SIDE_ == SIDE_NONE && CIN <= 5 && a.ep.bias_border)                                            \
+        } else if (SIDE_ == SIDE_NONE && CIN <= 4 && TW == 64 && a.NOUT == 8 && a.ep.bias_border && !a.ep.relu && conv4_pair_on()) \
+            hipLaunchKernelGGL((conv4x4s2_pair_kernel<CIN <= 4 ? CIN : 1, TH, WPS>),                                   \
+                               dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
+                               a.out, a.ep, a.Cphys, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile), a.per_tile);    \
+        else if (SIDE_ == SIDE_NONE && CIN <= 5 && a.ep.bias_border)                                              \
             hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_NONE, WPS, true>),                              \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
                                a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
