@@ -415,14 +415,15 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     }
 }
 
+constexpr int SRM_MAX_SEGS = 32;       // (round 5: 32, was 16 -- decoder and encoder of a fused step in ONE launch)
 struct ReduceSegs {
-    const float *slabs[16];
-    float *dst[16];
-    int nslabs[16];
-    int E[16];
-    int stride[16];           // elements from one slab to the next (float slabs: E)
-    int dbl[16];              // 1: the slabs are (value, second value) double pairs of a statistics epilogue; the first is summed
-    int first_block[17];      // prefix sums of ceil(E / 64)
+    const float *slabs[SRM_MAX_SEGS];
+    float *dst[SRM_MAX_SEGS];
+    int nslabs[SRM_MAX_SEGS];
+    int E[SRM_MAX_SEGS];
+    int stride[SRM_MAX_SEGS];           // elements from one slab to the next (float slabs: E)
+    int dbl[SRM_MAX_SEGS];              // 1: the slabs are (value, second value) double pairs of a statistics epilogue; the first is summed
+    int first_block[SRM_MAX_SEGS + 1];  // prefix sums of ceil(E / 64)
     int nseg;
 };
 
@@ -536,11 +537,11 @@ void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
 
 extern "C" int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *stream)
 {
-    DM_REQUIRE(segs && nseg >= 1 && nseg <= 16, "dm_reduce_slabs_multi: 1..16 segments");
+    DM_REQUIRE(segs && nseg >= 1 && nseg <= SRM_MAX_SEGS, "dm_reduce_slabs_multi: 1..%d segments", SRM_MAX_SEGS);
     ReduceSegs rs;
     rs.nseg = nseg;
     int blocks = 0;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < SRM_MAX_SEGS; ++k) {
         const bool on = k < nseg;
         if (on) DM_REQUIRE(segs[k].slabs && segs[k].dst && segs[k].nslabs > 0 && segs[k].E > 0, "dm_reduce_slabs_multi: bad segment %d", k);
         rs.slabs[k] = on ? segs[k].slabs : nullptr; rs.dst[k] = on ? segs[k].dst : nullptr;
@@ -550,7 +551,7 @@ extern "C" int dm_reduce_slabs_multi(const dm_reduce_seg *segs, int nseg, void *
         rs.first_block[k] = blocks;
         if (on) blocks += (segs[k].E + SRM_EL - 1) / SRM_EL;
     }
-    rs.first_block[16] = blocks;
+    rs.first_block[SRM_MAX_SEGS] = blocks;
     hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, rs);
     return dm_launch_status("dm_reduce_slabs_multi");
 }

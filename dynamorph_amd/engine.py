@@ -438,15 +438,19 @@ def _head_backward_unfused(L, cx, d4, var, gscale, gdec_ext, G, pending):
     return g4
 
 
-def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
+def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True, pending=None):
     """gscale: 1-element device tensor = d(total)/d(recon_loss) (None: no loss term);
-    gdec_ext: upstream gradient w.r.t. decoded (None: none)."""
+    gdec_ext: upstream gradient w.r.t. decoded (None: none).
+    pending: the caller's list of (slabs, dst) pairs for ONE slab reduction of the whole backward pass -- the decoder's pairs
+    are appended and NOT reduced here (FusedTrainer: they ride in the encoder's launch); None: reduced here."""
     zq = cx.zq
     B, nh, H3, W3 = zq.shape
     c1, c2 = nh // 2, nh // 4
     NIN = L.dec6.weight.shape[0]
     var = _w(L.channel_var).reshape(-1) if L.channel_var is not None else torch.ones(NIN, device=zq.device)
-    pending = []
+    own_pending = pending is None
+    if own_pending:
+        pending = []
     if cx.deferred:
         if gdec_ext is not None or gscale is None:
             raise ValueError("decoder_backward: a deferred tail takes the reconstruction-loss gradient only")
@@ -486,7 +490,8 @@ def decoder_backward(L, cx, gscale, gdec_ext, G, want_gz=True):
         g_zq, _ = ops.convT_bwd_fused(zq.contiguous(), g0, _w(L.dec0.weight), G(L.dec0.weight), pending=pending)     # dec.0 likewise
     else:
         ops.wgrad(Op(zq), Op(g0), G(L.dec0.weight), B, nh, c1, H3, W3, 4, pending=pending)
-    ops.reduce_slabs_multi(pending)                  # all decoder weight gradients in one launch
+    if own_pending:
+        ops.reduce_slabs_multi(pending)              # all decoder weight gradients in one launch
     if not want_gz:
         return None
     if g_zq is None:

@@ -505,7 +505,7 @@ def reduce_slabs_multi(pending):
     queued by pend_stats."""
     lib = L.load()
     while pending:
-        chunk, pending[:] = pending[:16], pending[16:]
+        chunk, pending[:] = pending[:32], pending[32:]
         segs = (L.ReduceSeg * len(chunk))()
         for i, item in enumerate(chunk):
             if len(item) == 3:      # (stats (nslabs, N, 2) float64, dst, first column): a run of columns of a statistics slab

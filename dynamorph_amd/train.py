@@ -167,7 +167,8 @@ class FusedTrainer:
         # the tail of the decoder (dec.4, dec.6, loss) runs inside decoder_backward, fused with its own backward
         dec, dcx = E.decoder_forward(L, zq, x, mask, defer_tail=True)
         B, NIN, H, W = x.shape
-        g_zq = E.decoder_backward(L, dcx, self.w_recon, None, self.G)
+        dec_pending = []                 # the decoder's slabs ride in the encoder's single reduction at the end of the pass
+        g_zq = E.decoder_backward(L, dcx, self.w_recon, None, self.G, pending=dec_pending)
         # (recon, commitment, total, perplexity[, time matching]): the VectorQuantizer's scalars, the reconstruction loss and
         # the pairwise term on z_before (vq_vae.py:324-332) in one launch
         fin = (vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, dcx.loss_slabs, B * NIN * H * W,
@@ -190,7 +191,7 @@ class FusedTrainer:
         # codebook gradient as slabs, added in the encoder's single slab reduction: nothing to zero, no global atomics
         # (K <= 64: an ordered one-hot product on the matrix cores, bit-reproducible; larger K: LDS adds in arrival order)
         dz, cb_slabs = ops.vq_backward_slabs(z, L.codebook.weight.detach(), idx, g_zq, self.w_commit, cc)
-        extra = [(cb_slabs, gcb)]
+        extra = [(cb_slabs, gcb)] + dec_pending
         if tm_S is not None:
             dz = ops.time_matching_backward(zf, tm_S, None, wm, add=dz).reshape(z.shape)      # (summed in the kernel's store)
         elif tm_fallback is not None:

@@ -461,7 +461,7 @@ int dm_dec_tail_train(const float *d2, const float *w4, const float *b4, const f
                       int B, int C2, int NIN, int H2, int W2, void *stream);
 /* dst[e] = sum over slabs of slabs[slab][e], fixed order (bitwise reproducible). */
 int dm_reduce_slabs(const float *slabs, int nslabs, int E, float *dst, void *stream);
-/* The same for up to 16 (slabs, dst) pairs in ONE launch: the weight gradients of a whole backward pass. */
+/* The same for up to 32 (slabs, dst) pairs in ONE launch: the weight gradients of a whole backward pass. */
 typedef struct dm_reduce_seg {
     const float *slabs;
     float *dst;
