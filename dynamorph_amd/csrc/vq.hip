@@ -388,7 +388,9 @@ __global__ __launch_bounds__(1024) void vq_hist_reduce_kernel(const int *__restr
 //     reference's arithmetic and order, first minimum and torch.argmax(-dist) NaN rule included.  Codebooks of more than
 //     64 codes (round 3): only over the GROUPS of codes whose smallest filter score lies within tol of the best one -- the
 //     bound that clears the runner-up clears, code by code, every group whose minimum is farther away (s_pm in the kernel).
-//     4096 codes on N(0,1) latents: 1-3 of 6 groups of 768 instead of all of them, for the 10 % of positions that fail.
+//     4096 codes: 16 groups of 256 (one LDS buffer pair each; until round 5 six groups of 768, the LDS going to a 4096-entry
+//     counter array that large codebooks now keep in their global replicas): the re-checks of the 0.5-0.8 % of positions
+//     that fail went from 19 % of the kernel to 7 % on N(0,1) data (tools/exp/vq_parts.sh).
 // So the index is the reference's for every position; only the work per position differs.
 //
 // Layout: a wave owns a chunk of 64 consecutive positions of one sample; lane (h = lane >> 4, c = lane & 15) loads
@@ -414,6 +416,23 @@ __global__ __launch_bounds__(1024) void vq_hist_reduce_kernel(const int *__restr
 #define VQ2_STAMP(i)
 #define VQ2_USE(v)
 #endif
+
+#ifdef DM_MEASURE
+// measurement build only (make measure; DM_VQ_DBG): 1 the codebook piece is staged once (stale operands), 4 no exact re-checks;
+// compile time: -DVQ_DBG_NOEMBED no index bits in the scores, -DVQ_DBG_MINONLY the in-lane minimum only (no runner-up).
+// Results are then wrong; the time is what is read (tools/exp/vq_parts.sh).
+__device__ int vq_dbg_dev;
+#define VQ_DBG(bit) (vq_dbg_dev & (bit))
+#else
+#define VQ_DBG(bit) false
+#endif
+
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: no register in between; the LDS image is
+// lane-linear: wave-uniform base + 16 * lane, which is what a contiguous copy wants).  Completion is counted on vmcnt.
+__device__ __forceinline__ void vq2_glds16(const void *g, void *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
 
 __device__ __forceinline__ float vq2_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vq2_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -552,7 +571,13 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     static_assert(!BF || D % 16 == 0, "bf16-split filter: embedding_dim 16, 32 or 64");
     constexpr int AQ = BF ? 2 * UG : SQ;                           // 16-byte A operands per lane and code tile
     constexpr int CHUNK_F4 = 4 * AQ * 64;                          // 16-byte units of packed A operand per 64-code chunk
-    constexpr int PIECE = SINGLE ? 1 : (2048 / CHUNK_F4 > 0 ? 2048 / CHUNK_F4 : 1);   // code chunks per 32 KB LDS piece
+    // Large codebooks stream their packed A operands through TWO LDS buffers of PCH code chunks (16 KB each; one chunk each
+    // where a chunk is larger): the copy of the next buffer (global_load_lds, no registers) runs under the products of the
+    // current one, ONE barrier per buffer, and the stream wraps around from one chunk of positions to the next.  Up to round 5
+    // a single 32 KB piece was refilled through registers between two barriers, its load latency exposed 16 times per 256
+    // positions at 4096 codes: 12 % of the kernel (tools/exp/vq_parts.sh).  A codebook that fits both buffers is staged once.
+    constexpr int PCH = SINGLE ? 1 : (1024 / CHUNK_F4 > 0 ? 1024 / CHUNK_F4 : 1);     // code chunks per LDS buffer
+    constexpr int PIECE = 2 * PCH;
     constexpr float U = 5.9604645e-8f;                             // 2^-24
     // the header comment's bound: tol = 1.25 x (2 eta + 2 rho max(|z|^2 + s', 0)), eta = ETA u A, rho = (D/16 + 18) u.
     // f32 filter: ETA = D + 65 (D fused multiply-adds + the rounded norm, 64 of index bits).
@@ -571,7 +596,11 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     __shared__ f32x4 s_n[SINGLE ? 1 : PIECE * 16];
     constexpr int HROW = S + 1;                                       // f32x4 per code in s_H: D floats + 16 bytes of padding (banks)
     __shared__ f32x4 s_H[SINGLE ? 64 * HROW : 1];                    // small codebooks: the lane-ordered rows (cbH) for the gather
-    __shared__ int s_hist[SINGLE ? 64 : VQ_MAX_LDS_HIST];
+    // code counters of this workgroup: in LDS up to VQ2_MAX_LDS_HIST codes; larger codebooks add straight into the
+    // workgroup's global replica (one wave-wide atomic per 64 positions on scattered addresses, and no K-entry flush at the
+    // end) -- their LDS goes to the group minima below
+    constexpr int VQ2_MAX_LDS_HIST = 1024;
+    __shared__ int s_hist[SINGLE ? 64 : VQ2_MAX_LDS_HIST];
     __shared__ double s_red[NW];
     __shared__ float s_em[NW];
     __shared__ __attribute__((aligned(16))) float s_nrm[INL ? 64 : 4];
@@ -579,11 +608,11 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     // position that fails the tolerance test is re-evaluated exactly only against the groups that can hold a code within the
     // tolerance of its best score -- the same proven bound that clears the runner-up clears every code of a group whose
     // minimum is farther away.  Groups are whole LDS pieces; their number is what fits beside the piece at this occupancy.
-    constexpr int NG = SINGLE ? 1 : (MINW >= 3 ? (BF ? 6 : 4) : 16);      // (3 workgroups per CU: 53 KB each, 512-byte granules)
+    constexpr int NG = SINGLE ? 1 : (MINW >= 3 ? (BF ? 16 : 8) : 16);     // (3 workgroups per CU: 53 KB each, 512-byte granules)
     __shared__ unsigned short s_pm[SINGLE ? 2 : NG * BLOCK];
     const int lane = threadIdx.x & 63, h = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // provably wave-uniform: scalar branches
-    const bool lds_hist = K <= VQ_MAX_LDS_HIST;
+    const bool lds_hist = K <= (SINGLE ? 64 : VQ2_MAX_LDS_HIST);
 
     // Chunk bookkeeping in 32-bit scalars, advanced incrementally (a 64-bit `pos / HW` per iteration is a ~150-instruction
     // software division in front of the loads whose address it feeds).  All global traffic of the loop goes through
@@ -593,8 +622,21 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
     const unsigned qstep = (unsigned)NW * gridDim.x;
     const unsigned step_b = qstep / cps, step_c = qstep - step_b * cps;
     const int ncc = (K + 63) >> 6;                             // 64-code chunks
-    const int gch = ((ncc + NG - 1) / NG + PIECE - 1) / PIECE * PIECE;       // code chunks per group (whole pieces)
-    int staged = -1;                                           // first code chunk of the piece held in LDS
+    const int gch = ((ncc + NG - 1) / NG + PCH - 1) / PCH * PCH;             // code chunks per group (whole buffers)
+    const int nhp = (ncc + PCH - 1) / PCH;                     // buffers' worth of code chunks in the codebook
+    const bool resident = nhp <= 2;                            // (uniform) the whole codebook sits in the two buffers
+    unsigned hp_it = 0;                                        // buffers consumed so far (parity = the buffer in use)
+    // code chunks [hn * PCH, ...) into buffer b, asynchronously (whole waves, or the first lanes of wave 0: the LDS image of a
+    // global_load_lds is M0 = the first active lane's address + 16 * lane)
+    auto vq2_stage = [&](int hn, int b) {
+        if constexpr (!SINGLE) {
+            const int c0 = hn * PCH, n = min(PCH, ncc - c0);
+            const f32x4 *__restrict__ ga = reinterpret_cast<const f32x4 *>(cbA) + (long long)c0 * CHUNK_F4;
+            for (int i = threadIdx.x; i < n * CHUNK_F4; i += BLOCK) vq2_glds16(ga + i, s_A + b * PCH * CHUNK_F4 + i);
+            const f32x4 *__restrict__ gn = reinterpret_cast<const f32x4 *>(nrm) + (long long)c0 * 16;
+            for (int i = threadIdx.x; i < n * 16; i += BLOCK) vq2_glds16(gn + i, s_n + b * PCH * 16 + i);
+        }
+    };
     double sse = 0.0;
     int nflag = 0;
 #ifdef VQ2_STAMPS
@@ -761,6 +803,9 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
             asm volatile("" ::"v"(nreg[kt]));
         }
     } else {
+        // buffer 0 (and 1, where the codebook fits the two) on its way; the barrier below waits for it
+        vq2_stage(0, 0);
+        if (nhp == 2) vq2_stage(1, 1);
         float em = 0.f;
         bool bad = false;
         for (int k = threadIdx.x; k < K; k += BLOCK) {
@@ -871,9 +916,19 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
+#ifdef VQ_DBG_NOEMBED
+                        v[kt * 4 + r] = (float)acc[kt][r];
+#else
                         v[kt * 4 + r] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, (float)acc[kt][r]) & ~15u) | (unsigned)(kt * 4 + r));
+#endif
                 float t1, t2;
+#ifdef VQ_DBG_MINONLY
+                t1 = vq2_min3(vq2_min3(vq2_min3(v[0], v[1], v[2]), vq2_min3(v[3], v[4], v[5]), vq2_min3(v[6], v[7], v[8])),
+                              vq2_min3(vq2_min3(v[9], v[10], v[11]), vq2_min3(v[12], v[13], v[14]), v[15]), v[15]);
+                t2 = t1;
+#else
                 vq2_top2_16(v, t1, t2);
+#endif
                 if constexpr (SINGLE) { m1[t] = t1; m2[t] = t2; }
                 else {
                     m2[t] = vq2_min3(m2[t], t2, vq2_max(m1[t], t1));
@@ -887,23 +942,20 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
         if constexpr (SINGLE) {
             if (act) chunk_scores(nreg, [&](int kt, int sq) { return areg[kt][sq]; }, 0);
         } else {
-            for (int p0 = 0; p0 < ncc; p0 += PIECE) {
-                const int pn = min(PIECE, ncc - p0);
-                if (staged != p0) {                            // (one piece in all: staged once per workgroup)
-                    __syncthreads();                           // the previous piece has been consumed
-                    const f32x4 *__restrict__ ga = reinterpret_cast<const f32x4 *>(cbA) + (long long)p0 * CHUNK_F4;
-                    for (int i = threadIdx.x; i < pn * CHUNK_F4; i += BLOCK) s_A[i] = ga[i];
-                    const f32x4 *__restrict__ gn = reinterpret_cast<const f32x4 *>(nrm) + (long long)p0 * 16;
-                    for (int i = threadIdx.x; i < pn * 16; i += BLOCK) s_n[i] = gn[i];
-                    staged = p0;
-                    __syncthreads();
+            for (int hp = 0; hp < nhp; ++hp) {
+                const int p0 = hp * PCH, pn = min(PCH, ncc - p0);
+                const int buf = resident ? hp : (int)(hp_it & 1u);
+                if (!resident && !VQ_DBG(1)) {
+                    // the buffer the previous barrier freed takes the next PCH chunks (of the next chunk of positions at the end)
+                    const int hn = hp + 1 < nhp ? hp + 1 : 0;
+                    vq2_stage(hn, buf ^ 1);
                 }
                 if (act) {
                     for (int cc = 0; cc < pn; ++cc) {
                         f32x4 na[4];
 #pragma unroll
-                        for (int kt = 0; kt < 4; ++kt) na[kt] = s_n[cc * 16 + kt * 4 + h];
-                        const f32x4 *__restrict__ ab = s_A + cc * CHUNK_F4 + lane;
+                        for (int kt = 0; kt < 4; ++kt) na[kt] = s_n[(buf * PCH + cc) * 16 + kt * 4 + h];
+                        const f32x4 *__restrict__ ab = s_A + (buf * PCH + cc) * CHUNK_F4 + lane;
                         // (conflict-free ds_read_b128: consecutive lanes, consecutive 16-byte slots)
                         chunk_scores(na, [&](int kt, int sq) { return ab[(kt * AQ + sq) * 64]; }, p0 + cc);
                     }
@@ -930,6 +982,10 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
 #pragma unroll
                         for (int t = 0; t < 4; ++t) pmv[t] = 3.4028235e38f;
                     }
+                }
+                if (!resident) {
+                    __syncthreads();                           // (drains the copy: vmcnt(0)) the other buffer is complete, this one free
+                    ++hp_it;
                 }
             }
         }
@@ -999,7 +1055,7 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
             VQ2_USE(kown);
             VQ2_STAMP(4)                                       // reduce-scatter, tolerance
             // ---- exact re-check of the positions that failed the test: the whole wave, one position at a time ----
-            unsigned long long fm = __ballot(flagged);
+            unsigned long long fm = VQ_DBG(4) ? 0ull : __ballot(flagged);
             while (fm) {
                 const int fl = __builtin_ctzll(fm);
                 fm &= fm - 1;
@@ -1041,10 +1097,27 @@ __global__ __launch_bounds__(256, MINW) void vq_forward_mfma_kernel(
                         const float pg = __builtin_bit_cast(float, (unsigned)s_pm[g * BLOCK + wave * 64 + fl] << 16);
                         if (pg > thr) continue;
                         const int kend = min((g + 1) * gch * 64, K);
-                        for (int k = g * gch * 64 + lane; k < kend; k += 64) {
-                            const float dk = vq_exact_dist<D>(zv, cb + (long long)k * D);
-                            const bool bt = (bk == 0x7fffffff) | vq_better(dk, bd);      // (a lane's first code is taken as it is)
-                            bd = bt ? dk : bd; bk = bt ? k : bk;
+                        // (the rows of two codes per lane are requested before either is used: the loop is bound by the
+                        //  latency of these loads, one round trip per iteration)
+                        constexpr int UNR = D <= 16 ? 2 : 1;
+                        for (int k0 = g * gch * 64 + lane; k0 < kend; k0 += 64 * UNR) {
+                            float er[UNR][D];
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                const int k = min(k0 + 64 * u, K - 1);
+#pragma unroll
+                                for (int q = 0; q < D / 4; ++q) {
+                                    const f32x4 v = reinterpret_cast<const f32x4 *>(cb + (long long)k * D)[q];
+                                    er[u][4 * q] = v.x; er[u][4 * q + 1] = v.y; er[u][4 * q + 2] = v.z; er[u][4 * q + 3] = v.w;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                const int k = k0 + 64 * u;
+                                const float dk = vq_exact_dist<D>(zv, er[u]);
+                                const bool bt = k < kend && ((bk == 0x7fffffff) | vq_better(dk, bd));      // (a lane's first code is taken as it is)
+                                bd = bt ? dk : bd; bk = bt ? k : bk;
+                            }
                         }
                     }
                 }
@@ -1604,7 +1677,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
     const long long P = (long long)B * H * W;
     const Vq2Layout L = vq2_layout(K, D);
     float *ws = (float *)workspace;
-    const bool can2 = vq2_applicable(z, idx, out, workspace, D, H * W);
+    const bool can2 = vq2_applicable(z, idx, out, workspace, D, H * W) && ((uintptr_t)codebook & 15) == 0;
     DM_REQUIRE((variant != DM_VQ_MFMA && variant != DM_VQ_BF16) || can2,
                "dm_vq_forward: the MFMA variant needs embedding_dim 8/16/32/64, H*W %% 64 == 0 and 16-byte aligned tensors");
     const bool use2 = variant == DM_VQ_MFMA || variant == DM_VQ_BF16 || (variant == DM_VQ_AUTO && can2);
@@ -1621,6 +1694,13 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
     // (vq_prep_kernel cleared the counter replicas and all slabs: there are fewer workgroups than slabs)
     int *hrep = reinterpret_cast<int *>(ws + L.hrep);
     if (use2) {
+#ifdef DM_MEASURE
+        {
+            static const int dbg = [] { const char *e = getenv("DM_VQ_DBG"); return e ? atoi(e) : 0; }();
+            static bool sent = false;
+            if (!sent) { (void)hipMemcpyToSymbol(HIP_SYMBOL(vq_dbg_dev), &dbg, sizeof(int)); sent = true; }
+        }
+#endif
         const long long groups = ((P >> 6) + 3) / 4;
 #define DM_VQ2K(DD, SINGLE_, MINW, WGS, BF_, INL_, JOIN_)                                                            \
     {                                                                                                                \

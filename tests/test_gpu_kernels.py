@@ -120,7 +120,10 @@ def _c_oracle_idx(cvq, z, cb):
                                        # LDS pieces, every embedding_dim it is built for, chunk counts that are not a
                                        # multiple of the 4 waves of a workgroup
                                        (7, 16, 1, 8, 8), (3, 16, 65, 16, 16), (2, 16, 513, 16, 16), (1, 16, 1000, 32, 32),
-                                       (3, 8, 100, 8, 8), (3, 32, 300, 8, 16), (2, 64, 512, 16, 16), (5, 64, 129, 8, 8)])
+                                       (3, 8, 100, 8, 8), (3, 32, 300, 8, 16), (2, 64, 512, 16, 16), (5, 64, 129, 8, 8),
+                                       # more than 1024 codes: the counters go straight to the global replicas; code chunks
+                                       # streamed through the two LDS buffers with an odd and an even number of refills
+                                       (2, 16, 1100, 16, 16), (1, 16, 2049, 16, 32), (6, 32, 1025, 8, 8)])
 def test_vq_forward_vs_c_oracle(ops, cvq, B, D, K, H, W):
     z = rnd(B, D, H, W, seed=B + D + K).numpy()
     cb = rnd(K, D, seed=K).numpy()

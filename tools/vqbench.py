@@ -26,18 +26,33 @@ def t_ms(fn, iters=20, warm=3):
 
 
 SHAPES = {"headline": (2048, 16, 64, 16, 16), "stress": (256, 16, 4096, 32, 32), "example": (256, 64, 512, 32, 32),
-          "c2": (1024, 16, 64, 16, 16), "big": (8192, 16, 64, 16, 16), "tiny": (1, 16, 64, 16, 16), "small": (256, 16, 64, 16, 16)}
+          "c2": (1024, 16, 64, 16, 16), "c5init": (1024, 16, 4096, 32, 32), "c5model": (1024, 16, 4096, 32, 32), "big": (8192, 16, 64, 16, 16), "tiny": (1, 16, 64, 16, 16), "small": (256, 16, 64, 16, 16)}
 want = sys.argv[1:] or ["headline", "stress", "example", "c2"]
 dev = "cuda:0"
 for name in want:
     B, D, K, H, W = SHAPES[name]
     z = torch.randn(B, D, H, W, device=dev, generator=torch.Generator(dev).manual_seed(1))
     cb = torch.randn(K, D, device=dev, generator=torch.Generator(dev).manual_seed(2))
+    if name == "c5model":                                  # BASELINE configs[4] as bench.py times it: the model's own latents / codebook
+        import copy, numpy as np, dynamorph_amd
+        from dynamorph_amd import engine as E
+        torch.manual_seed(5)
+        m = dynamorph_amd.VQ_VAE(num_inputs=4, num_embeddings=K, channel_var=np.ones(4)).to(dev)
+        x = torch.randn(B, 4, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(77))
+        with torch.no_grad():
+            z, _ = E.encoder_forward(E.Layers(copy.deepcopy(m)), x)
+        cb = m.vq.w.weight.detach().clone()
+        del x, m
+        print(f"c5model: |z| rms {float(z.pow(2).mean().sqrt()):.3f}, codebook rms {float(cb.pow(2).mean().sqrt()):.2e}", flush=True)
+    if name == "c5init":                                   # the module's own initial codebook (vq_vae.py:40): uniform(-1/K, 1/K)
+        cb = (torch.rand(K, D, device=dev, generator=torch.Generator(dev).manual_seed(2)) * 2 - 1) / K
     P = B * H * W
     nbytes = P * (2 * D * 4 + 8)
     ref = None
     for vname, variant in (("exact", DM_VQ_EXACT), ("mfma", DM_VQ_MFMA), ("bf16", DM_VQ_BF16)):
         if variant == DM_VQ_BF16 and D % 16:
+            continue
+        if os.environ.get("VQBENCH_ONLY") and vname not in os.environ["VQBENCH_ONLY"].split(","):
             continue
         idx, out, slabs, hist, nre = ops.vq_forward(z, cb, variant=variant, want_rechecked=True)
         if ref is None:
@@ -50,5 +65,5 @@ for name in want:
         k21 = t_ms(lambda: ops.vq_forward_repeat(z, cb, 21, variant=variant, bufs=bufs), iters=5)
         kms = max((k21 - k1) / 20, 1e-6)
         print(f"{name:9s} {vname:6s} B={B} D={D} K={K} P={P}: {ms * 1e3:8.1f} us/call  kernel {kms * 1e3:7.1f} us = {nbytes / kms / 1e6 / 8000:.3f} of HBM peak"
-              f" ({2.0 * K * D * P / kms / 1e9:7.1f} TFLOP/s of filter product)  rechecked={int(nre.cpu())} ({int(nre.cpu()) / P:.2e})  same_idx={same}",
+              f" ({2.0 * K * D * P / kms / 1e9:7.1f} TFLOP/s of filter product)  rechecked={int(nre.cpu())} ({int(nre.cpu()) / P:.2e})  same_idx={same}  codes_used={int((hist > 0).sum())}",
               flush=True)
