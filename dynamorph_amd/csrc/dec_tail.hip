@@ -279,10 +279,10 @@ __device__ __forceinline__ void wgrad_steps(const float *__restrict__ sA, const 
 
 // Resident workgroups per CU the backward kernel is built for (launch bound = register budget: 3 -> 168, 2 -> 256).  Three
 // where the instantiation fits 168 registers without scratch (profiles/r05_kernel_resources.txt), two elsewhere.
-template <int NIN, bool FUSED, bool WIDE, bool MASKED>
+template <int NIN, bool FUSED, bool WIDE, bool MASKED, bool EDGE = false>
 constexpr int tail_bwd_occ()
 {
-    return (!WIDE && NIN <= 2) ? 3 : 2;
+    return (!WIDE && !EDGE && NIN <= 2) ? 3 : 2;
 }
 
 #ifdef DM_MEASURE
@@ -303,8 +303,14 @@ static int tail_dbg()
 // (dec.6 is 1x1), the reconstruction-loss partials are taken there too, and `decoded` never exists in HBM.
 // MASKED: batch_mask given (vq_vae.py:320-321).  A template flag, not a branch: with the uniform branch in the row loop of
 // phase B the kernel needs 223 registers, without it 159 -- three resident workgroups per CU instead of two.
-template <int NIN, bool FUSED, bool WIDE, bool MASKED>
-__global__ __launch_bounds__(DM_BLOCK, (tail_bwd_occ<NIN, FUSED, WIDE, MASKED>()))
+// EDGE (round 5; d2 a multiple of 64 wide, FUSED): tiles of 64 OWNED columns side by side instead of WIDE's 56 + halo (128
+// columns: two tiles instead of three).  What a tile needs from across its vertical seams is one d2 column (for the d4 of its
+// own first / last output column) and one g4 column (for its data and weight gradient): the d2 columns x0 - 1 and x0 + 64 come
+// in beside the tile (sE), the seam terms of phase A and the d4 / g4 of the two PAD columns of the g4 tile (ox = 2 x0 - 1 and
+// 2 x0 + 128, zero in the full-row form) are worked out by a few lanes per wave, and the lanes 0 / 63 pick their seam sums up
+// from LDS where the full-row form's lane shifts return the zero padding.  At the image border the seam values are zeros.
+template <int NIN, bool FUSED, bool WIDE, bool MASKED, bool EDGE = false>
+__global__ __launch_bounds__(DM_BLOCK, (tail_bwd_occ<NIN, FUSED, WIDE, MASKED, EDGE>()))
 void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restrict__ w4, const float *__restrict__ b4,
                               const float *__restrict__ w6, const float *__restrict__ b6, double *__restrict__ loss_slabs,
                               const float *__restrict__ decp, const float *__restrict__ x,
@@ -329,10 +335,19 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     __shared__ __attribute__((aligned(16))) float sG[TT_C * GPS];
     __shared__ __attribute__((aligned(16))) float s_coef[DM_COEF_MAX_C * 4];
     __shared__ double s_part[4][NP];
+    static_assert(!EDGE || (FUSED && !WIDE), "EDGE: the training kernel, tiles of 64 owned columns");
+    constexpr int PADL = 3, PADR = TT_DRS - 4;                                    // g4-tile columns of ox = 2 x0 - 1 and 2 x0 + 128
+    __shared__ __attribute__((aligned(16))) float s_w4e[EDGE ? TT_C * TT_C * 16 : 4];   // dec.4's weights for the seam lanes
+    __shared__ float sE[EDGE ? 2 * TT_C * AROWS : 1];                             // d2 columns x0 - 1 | x0 + 64: [side][ci][row]
+    // what lane 0 / lane 63 add to their output pair of phase A, as pairs (left seam: (e, 0); right seam: (0, e)), and a third
+    // array of zeros for the lanes between them: [kind][co][g4-tile row]; likewise the seam sums of phase 3: [kind][ci][row]
+    __shared__ __attribute__((aligned(8))) float sPA[EDGE ? 3 * TT_C * GROWS * 2 : 2];
+    __shared__ float sP3[EDGE ? 3 * TT_C * TT_TH : 1];
 
     const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W2 = WIDE ? W2arg : TT_W;
+    const int W2 = (WIDE || EDGE) ? W2arg : TT_W;
+    const int ekind = lane == 0 ? 0 : (lane == TT_W - 1 ? 1 : 2);
     const int tiles_y = H2 / TT_TH, OH = 2 * H2, OW = 2 * W2;
     Operand in;
     in.p0 = d2; in.p1 = nullptr; in.coef = nullptr; in.coef_bstride = 0; in.mode = DM_LOAD_IDENT; in.ones = 0;
@@ -341,13 +356,30 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     stage.init(H2, W2);
     // tile -> (sample, row band, column band); WIDE: lane <-> column x0 + lane, x0 = 56 * tx - 4 (header comment)
     auto tile_of = [&](int t, int &tb, int &ty0, int &tx0) {
-        if (WIDE) { const int q = t / tiles_x; tx0 = (t - q * tiles_x) * TT_OWN - TT_HALO; t = q; } else tx0 = 0;
+        if (WIDE) { const int q = t / tiles_x; tx0 = (t - q * tiles_x) * TT_OWN - TT_HALO; t = q; }
+        else if (EDGE) { const int q = t / tiles_x; tx0 = (t - q * tiles_x) * TT_W; t = q; }
+        else tx0 = 0;
         ty0 = (t % tiles_y) * TT_TH; tb = t / tiles_y;
     };
+    // EDGE: thread (side, ci, row) fetches its element of the two d2 columns beside the tile one tile ahead (0 outside the image)
+    const int e_side = threadIdx.x / (TT_C * AROWS), e_ci = (threadIdx.x / AROWS) % TT_C, e_row = threadIdx.x % AROWS;
+    auto edge_load = [&](bool live, int tb, int ty0, int tx0) {
+        const int y = ty0 - 2 + e_row, col = e_side ? tx0 + TT_W : tx0 - 1;
+        const bool ok = live && threadIdx.x < 2 * TT_C * AROWS && (unsigned)y < (unsigned)H2 && (unsigned)col < (unsigned)W2;
+        const float v = d2[ok ? ((tb * TT_C + e_ci) * H2 + y) * W2 + col : 0];
+        return ok ? v : 0.f;
+    };
+    float edge_v = 0.f;
     int tidx = blockIdx.x, b = 0, y0 = 0, x0 = 0;
     if (tidx < ntiles) {
         tile_of(tidx, b, y0, x0);
         stage.issue(in, b, TT_C, H2, W2, y0 - 2, x0);
+        if constexpr (EDGE) edge_v = edge_load(true, b, y0, x0);
+    }
+    if constexpr (EDGE) {
+        s_w4e[threadIdx.x] = w4[threadIdx.x];
+        for (int i = threadIdx.x; i < TT_C * GROWS * 2; i += DM_BLOCK) sPA[2 * TT_C * GROWS * 2 + i] = 0.f;
+        if (threadIdx.x < TT_C * TT_TH) sP3[2 * TT_C * TT_TH + threadIdx.x] = 0.f;
     }
     if (threadIdx.x < TT_C) *reinterpret_cast<f32x4 *>(s_coef + threadIdx.x * 4) = (f32x4){1.f, 0.f, 0.f, -__builtin_inff()};
     if (threadIdx.x < ZLEN) sA[ZOFF + threadIdx.x] = 0.f;
@@ -395,7 +427,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
     // flight through the phases that hold the 64 weights put the kernel at the 256-register limit with spills in the
     // loop: decoded AND x rows of three or four channels (60-80 registers), and the x rows alone in the full-row form
     // (two more matrix steps per row than the WIDE form).
-    constexpr bool AHEAD = NIN <= 2 || (FUSED && WIDE);
+    constexpr bool AHEAD = NIN <= 2 || (FUSED && (WIDE || EDGE));
     constexpr int BR = (GROWS + 3) / 4;
     f32x2 rdv[BR][NIN], rxv[BR][NIN];
     // one (row, channel) at a time through buffer descriptors rebased to the sample: rows outside the image (and
@@ -421,6 +453,22 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         if (!FUSED) rdv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rd, voff, 0, 0);
         rxv[j][c] = __builtin_amdgcn_raw_buffer_load_b64(rc.rx, voff, 0, 0);
     };
+    // EDGE: x at the two pad columns of the g4 tile, lane = (g4 row, side), for the wave that turns their d4 into g4 (phase B)
+    float rxe[EDGE ? NIN : 1];
+    const int p_gr = lane >> 1, p_side = lane & 1;
+    auto issue_pad = [&](const RowCtx &rc) {
+        if constexpr (EDGE) {
+            const int oy = 2 * rc.ty0 - 1 + p_gr, px = p_side ? 2 * (rc.tx0 + TT_W) : 2 * rc.tx0 - 1;
+            const bool ok = p_gr < GROWS && (unsigned)oy < (unsigned)OH && (unsigned)px < (unsigned)OW;
+#pragma unroll
+            for (int c = 0; c < NIN; ++c)
+                rxe[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc.rx, ok ? ((c * OH + oy) * OW + px) * 4 : 0x7ffffff0, 0, 0));
+        }
+    };
+    if constexpr (EDGE) {
+        const RowCtx rc0 = rows_begin(tidx < ntiles, b, y0, x0);
+        if (wave == 3) issue_pad(rc0);
+    }
     if constexpr (AHEAD) {
         const RowCtx rc0 = rows_begin(tidx < ntiles, b, y0, x0);
 #pragma unroll
@@ -435,6 +483,9 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         DT_SYNC();                                         // previous tile done with sA and sG
         if (!(dbg & 16) || first_tile)
             stage.template commit<false, true>(sA, s_coef, TT_C, H2, W2, y0 - 2, x0, DM_LOAD_IDENT);   // 192 staging threads: waves 0..2
+        if constexpr (EDGE) {
+            if (threadIdx.x < 2 * TT_C * AROWS) sE[threadIdx.x] = edge_v;
+        }
         first_tile = false;
         DT_SYNC();
         const int cb = b, cy0 = y0, cx0 = x0;
@@ -444,12 +495,40 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         const int next = tidx + gridDim.x;
         if (next < ntiles) tile_of(next, b, y0, x0);
         const auto scx = stage.begin(in, next < ntiles && !(dbg & 16), b, TT_C, H2, W2, y0 - 2, x0);   // requested during phase A
+        if constexpr (EDGE) edge_v = edge_load(next < ntiles, b, y0, x0);
 
         // ---- phase A: recompute d4[co = wave] on position rows y0-1 .. y0+TH -> sG rows 2*pr+py-1 -----------------
         // Two passes, one per output-row parity (d4 row 2y-1+par reads P = d2 row y-1 with ky = 2 + par and C = row y with
         // ky = par): a pass holds 32 weights, in SGPRs (wave-uniform; see phase 3), as the pairs (w0, w1), (w2, w3) they are in
         // memory.  A lane's value v = in[x] gives  T += v * (w0, w1) = (to the left neighbour's odd column, own even column),
         // U += v * (w2, w3) = (own odd column, to the right neighbour's even column).
+        if constexpr (EDGE) {
+            // lane = (g4-tile row gr, side): the seam term of the tile's own first / last output column (what the missing
+            // neighbour lane's side sum would have carried) and d4 of the pad column beyond it, for co = wave.
+            // d4 row 2y-1+par (y = cy0 + pr) reads d2 rows y-1 (ky = par + 2) and y (ky = par): sA / sE rows pr + 1, pr + 2.
+            //   left  (side 0): seam = sum in[x0-1] w[ky][3];  pad ox = 2x0-1:   sum in[x0-1] w[ky][2] + in[x0]    w[ky][0]
+            //   right (side 1): seam = sum in[x0+64] w[ky][0]; pad ox = 2x0+128: sum in[x0+64] w[ky][1] + in[x0+63] w[ky][3]
+            if (lane < 2 * GROWS) {
+                const int gr = lane >> 1, side = lane & 1, par = gr & 1, pr = gr >> 1;
+                const int kxE = side ? 0 : 3, kxA = side ? 1 : 2, kxB = side ? 3 : 0, colB = side ? TT_W - 1 : 0;
+                const bool outside = side ? cx0 + TT_W >= W2 : cx0 == 0;
+                float e = 0.f, dp = bias4;
+#pragma unroll
+                for (int ci = 0; ci < TT_C; ++ci)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = pr + 2 - t;
+                        const float ve = sE[(side * TT_C + ci) * AROWS + row], vb = sA[ci * APS + row * TT_W + colB];
+                        const float *__restrict__ wr = s_w4e + (ci * TT_C + wave) * 16 + (par + 2 * t) * 4;
+                        e = __builtin_fmaf(ve, wr[kxE], e);
+                        dp = __builtin_fmaf(ve, wr[kxA], dp);
+                        dp = __builtin_fmaf(vb, wr[kxB], dp);
+                    }
+                e = outside ? 0.f : e;
+                *reinterpret_cast<f32x2 *>(sPA + ((side * TT_C + wave) * GROWS + gr) * 2) = side ? (f32x2){0.f, e} : (f32x2){e, 0.f};
+                sG[wave * GPS + gr * TT_DRS + (side ? PADR : PADL)] = outside ? 0.f : dm_relu(dp);
+            }
+        }
         {
         const f32x2 biasT = {0.f, bias4}, biasU = {bias4, 0.f};
 #pragma unroll
@@ -493,6 +572,7 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                     f32x2 o;
                     o.x = T.y + lane_from_left(U.y);
                     o.y = U.x + lane_from_right(T.x);
+                    if constexpr (EDGE) o += *reinterpret_cast<const f32x2 *>(sPA + ((ekind * TT_C + wave) * GROWS + 2 * pr + par) * 2);
                     *reinterpret_cast<f32x2 *>(sG + wave * GPS + (2 * pr + par) * TT_DRS + 2 * lane + 4) = relu2(o);
                 }
                 P = C;
@@ -592,8 +672,43 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 }
             }
         }
+        if constexpr (EDGE) {
+            // the pad columns' d4 -> g4 (a neighbouring tile owns these pixels: no sums), lane = (g4-tile row, side), by the wave
+            // with the fewest rows of its own; a pad column outside the image holds d4 = 0 and stays 0
+            if (wave == 3 && lane < 2 * GROWS && !(dbg & 2)) {
+                const int oy = 2 * cy0 - 1 + p_gr, pj = p_side ? PADR : PADL;
+                const bool live = oy >= 0 && oy < OH;
+                float d4p[TT_C], gdp[NIN];
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co) d4p[co] = sG[co * GPS + p_gr * TT_DRS + pj];
+#pragma unroll
+                for (int c = 0; c < NIN; ++c) {
+                    float dv = b6r[c];
+#pragma unroll
+                    for (int co = 0; co < TT_C; ++co) dv += w6r[c][co] * d4p[co];
+                    float t = dv - rxe[c];
+                    if constexpr (MASKED) {
+                        const int px = p_side ? 2 * (cx0 + TT_W) : 2 * cx0 - 1;
+                        const int oyc = oy < 0 ? 0 : (oy >= OH ? OH - 1 : oy), pxc = px < 0 ? 0 : (px >= OW ? OW - 1 : px);
+                        const float mv = mask[((cb * MC + (MC == 1 ? 0 : c)) * OH + oyc) * OW + pxc];
+                        t = (dv * mv - rxe[c] * mv) * mv;
+                    }
+                    gdp[c] = t * (live ? gsv[c] : 0.f);
+                }
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co) {
+                    float g4 = w6r[0][co] * gdp[0];
+#pragma unroll
+                    for (int c = 1; c < NIN; ++c) g4 += w6r[c][co] * gdp[c];
+                    sG[co * GPS + p_gr * TT_DRS + pj] = d4p[co] > 0.f ? g4 : 0.f;
+                }
+            }
+        }
         if (FUSED) loss += (double)tl.x + (double)tl.y;
         const RowCtx rcn = rows_begin(next < ntiles && !(dbg & 16), b, y0, x0);   // next tile's rows: requested during the wgrad phase
+        if constexpr (EDGE) {
+            if (wave == 3) issue_pad(rcn);
+        }
         DT_SYNC();
 
         // ---- phase 3: data gradient of dec.4 for input channel ci = wave:  g2[ci][y][x] = sum_co,ky,kx
@@ -610,6 +725,21 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
         // stay in the phase (hoisted out of the loop the 96 weights of phases A and 3 would not fit the scalar file).
         // Pairs as they lie in memory, (w0, w1) and (w2, w3): a lane's pair mid = (col 2x, col 2x+1) gives
         //   R += (mid.y * w0, mid.x * w1) = (to the right neighbour, own)     S += (mid.y * w2, mid.x * w3) = (own, to the left neighbour)
+        if constexpr (EDGE) {
+            // lane = (output row r, side): what the pad column of g4 adds to g2 of the tile's first / last column, ci = wave
+            //   left: sum_co,ky g4[co][2r+ky][ox = 2x0-1] W[ci][co][ky][0];  right: ... [ox = 2x0+128] W[ci][co][ky][3]
+            if (lane < 2 * TT_TH) {
+                const int r = lane >> 1, side = lane & 1;
+                float sm = 0.f;
+#pragma unroll
+                for (int co = 0; co < TT_C; ++co)
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky)
+                        sm = __builtin_fmaf(sG[co * GPS + (2 * r + ky) * TT_DRS + (side ? PADR : PADL)],
+                                            s_w4e[(wave * TT_C + co) * 16 + ky * 4 + (side ? 3 : 0)], sm);
+                sP3[(side * TT_C + wave) * TT_TH + r] = sm;
+            }
+        }
         f32x2 accR[TT_TH], accS[TT_TH];                // (started by their first product, not zeroed)
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
@@ -650,7 +780,8 @@ void dec_tail_backward_kernel(const float *__restrict__ d2, const float *__restr
                 if (par == 1 && i >= 1) {              // output row r = i - 1 is complete
                     const int r = i - 1;
                     const float dd = sA[wave * APS + (r + 2) * TT_W + lane];
-                    const float sum = (accR[r].y + accS[r].x) + (lane_from_left(accR[r].x) + lane_from_right(accS[r].y));
+                    float sum = (accR[r].y + accS[r].x) + (lane_from_left(accR[r].x) + lane_from_right(accS[r].y));
+                    if constexpr (EDGE) sum += sP3[(ekind * TT_C + wave) * TT_TH + r];
                     const float v = (dd > 0.f && ownl) ? sum : 0.f;
                     if (ownl) g2[((cb * TT_C + wave) * H2 + cy0 + r) * W2 + colx] = v;
                     pb2 += v;
@@ -842,13 +973,25 @@ int tail_backward_launch(const char *who, bool fused, const float *d2, const flo
                                 hipLaunchKernelGGL((dec_tail_backward_kernel<N_, F_, W_, M_>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, b4, \
                                                    w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
                                                    part_slabs, w_slabs, H2, ntiles, inv_count, nslabs, W2, tiles_x DT_DBG_ARG); }
+    // EDGE: tiles of 64 owned columns (the slab buffers stay sized for the forward kernel's grid: nslabs)
+#define DM_TBE(N_, M_) { const int tx_ = W2 / TT_W, nt_ = B * (H2 / TT_TH) * tx_;                                               \
+                         const int grid = tail_grid_bwd(nt_, tail_bwd_occ<N_, true, false, M_, true>());                         \
+                         hipLaunchKernelGGL((dec_tail_backward_kernel<N_, true, false, M_, true>), dim3(grid), dim3(DM_BLOCK), 0, st, d2, w4, \
+                                            b4, w6, b6, loss_slabs, decoded, x, mask, mask_channels, channel_var, gscale_dev, g2, \
+                                            part_slabs, w_slabs, H2, nt_, inv_count, nslabs, W2, tx_ DT_DBG_ARG); }
+#define DM_TBEN(M_) switch (NIN) { case 1: DM_TBE(1, M_) break; case 2: DM_TBE(2, M_) break; case 3: DM_TBE(3, M_) break; default: DM_TBE(4, M_) }
 #define DM_TBN(F_, W_, M_) switch (NIN) { case 1: DM_TB(1, F_, W_, M_) break; case 2: DM_TB(2, F_, W_, M_) break; case 3: DM_TB(3, F_, W_, M_) break; default: DM_TB(4, F_, W_, M_) }
 #define DM_TBM(F_, W_) if (mask) { DM_TBN(F_, W_, true) } else { DM_TBN(F_, W_, false) }
+    static const bool edge_off = [] { const char *e = getenv("DM_DEC_TAIL_EDGE"); return e && e[0] == '0'; }();
     if (W2 == TT_W) {
         if (fused) { DM_TBM(true, false) } else { DM_TBM(false, false) }
+    } else if (fused && W2 % TT_W == 0 && !edge_off) {
+        if (mask) { DM_TBEN(true) } else { DM_TBEN(false) }
     } else {
         if (fused) { DM_TBM(true, true) } else { DM_TBM(false, true) }
     }
+#undef DM_TBEN
+#undef DM_TBE
 #undef DM_TBM
 #undef DM_TBN
 #undef DM_TB

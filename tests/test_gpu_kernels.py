@@ -1534,7 +1534,11 @@ def test_e1_border_bias_table_replaces_the_ones_channel(ops):
                                               # other widths: 64 lanes = 56 owned columns + 4 halo columns either side
                                               (4, True, 2, (128, 128)), (2, False, 3, (16, 32)), (3, True, 2, (24, 100)),
                                               (2, False, 2, (8, 56)), (2, True, 2, (16, 60)), (1, False, 5, (8, 4)),
-                                              (2, False, 1, (64, 256)), (4, False, 1, (128, 64))])
+                                              (2, False, 1, (64, 256)), (4, False, 1, (128, 64)),
+                                              # widths that are multiples of 64: the training kernel takes tiles of 64 owned
+                                              # columns with seam terms (two, three and five tiles per row; every channel count)
+                                              (3, True, 2, (16, 192)), (1, False, 3, (8, 128)), (4, False, 2, (24, 128)),
+                                              (2, True, 1, (8, 320)), (4, True, 70, (8, 128))])
 def test_dec_tail_fused_forward_backward(ops, nin, masked, B, hw):
     """dec.4 + ReLU + dec.6 + masked loss in one kernel, and its fused backward, vs the ATen composition."""
     c, (h, w) = 4, hw
