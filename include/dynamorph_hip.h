@@ -282,8 +282,9 @@ int dm_conv1x1_bwd_fused(const dm_operand *dy, const float *x, const float *xcoe
  *   dx     [B][16][16][16] out = (t > 0) * sum_{co,ky,kx} dy[co][y+1-ky][x+1-kx] w[co][ci][ky][kx]  (+ resid)
  *   stats  NULL or dm_conv3x3_bwd_fused_num_blocks slabs of [16][2] doubles: (sum dx, sum dx * q)   (q NULL: sum dx^2)
  *   wslabs the same number of slabs of CD*144 floats: partial dW; dm_reduce_slabs(_multi) adds them
- * Built for CD = 16 or 32 output channels, 16 input channels, H = W = 16 (dm_conv3x3_bwd_fused_supported); other shapes:
- * dm_conv3x3 + dm_wgrad. */
+ * Built for CD = 16 or 32 output channels, 16 input channels, H = W = 16 (a whole patch per workgroup) and, as bands of 8 rows
+ * with halo rows, CD = 32 on H = W = 32 (the residual layers on the latents of 256-pixel patches; tensors then [B][..][32][32])
+ * (dm_conv3x3_bwd_fused_supported); other shapes: dm_conv3x3 + dm_wgrad. */
 int dm_conv3x3_bwd_fused_supported(int CD, int CX, int H, int W);
 int dm_conv3x3_bwd_fused_num_blocks(int B, int CD, int CX, int H, int W);
 int dm_conv3x3_bwd_fused(const dm_operand *dy, const float *x, const float *xcoef, const float *w, const float *resid,

@@ -62,7 +62,8 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_conv4x4s2_bwd_fused_supported(16, 16, 16, 16) == 1 and lib.dm_conv4x4s2_bwd_fused_supported(16, 8, 32, 32) == 0
     assert lib.dm_conv4x4s2_bwd_fused_num_blocks(2048, 16, 16, 16, 16) == 256 and lib.dm_conv4x4s2_bwd_fused_num_blocks(5, 16, 16, 16, 16) == 5
     assert lib.dm_conv3x3_bwd_fused_supported(16, 16, 16, 16) == 1 and lib.dm_conv3x3_bwd_fused_supported(32, 16, 16, 16) == 1
-    assert lib.dm_conv3x3_bwd_fused_supported(32, 16, 32, 32) == 0 and lib.dm_conv3x3_bwd_fused_supported(64, 64, 16, 16) == 0
+    assert lib.dm_conv3x3_bwd_fused_supported(32, 16, 32, 32) == 1 and lib.dm_conv3x3_bwd_fused_supported(64, 64, 16, 16) == 0
+    assert lib.dm_conv3x3_bwd_fused_supported(32, 16, 32, 48) == 0 and lib.dm_conv3x3_bwd_fused_num_blocks(3, 32, 16, 32, 32) == 3
     assert lib.dm_conv3x3_bwd_fused_num_blocks(2048, 32, 16, 16, 16) == 256 and lib.dm_conv3x3_bwd_fused_num_blocks(2048, 16, 16, 16, 16) == 512
     assert lib.dm_convt_bwd_fused_supported(8, 4, 32, 32) == 1 and lib.dm_convt_bwd_fused_supported(16, 8, 16, 16) == 1
     assert lib.dm_convt_bwd_fused_supported(8, 4, 32, 16) == 0 and lib.dm_convt_bwd_fused_supported(4, 4, 64, 64) == 0

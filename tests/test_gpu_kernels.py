@@ -781,15 +781,18 @@ def test_conv1x1_backward_fused_equals_the_two_kernels(ops, B, H, W, two):
     assert not ops.conv1x1_bwd_fused_supported(CD, CX, 8, 8) and not ops.conv1x1_bwd_fused_supported(64, 64, 16, 16)
 
 
-@pytest.mark.parametrize("B,CD,form", [(3, 16, "enc10"), (70, 16, "enc10"), (5, 32, "res"), (300, 32, "res"), (4, 32, "res_noq"),
-                                       (2, 16, "ident")])
-def test_conv3x3_backward_fused_equals_the_two_kernels(ops, B, CD, form):
+@pytest.mark.parametrize("B,CD,form,hw", [(3, 16, "enc10", (16, 16)), (70, 16, "enc10", (16, 16)), (5, 32, "res", (16, 16)),
+                                          (300, 32, "res", (16, 16)), (4, 32, "res_noq", (16, 16)), (2, 16, "ident", (16, 16)),
+                                          # 32-column latent grids (32 x 32: C5, default-width z32): bands of 8 rows with halo rows
+                                          (3, 32, "res", (32, 32)), (70, 32, "res", (32, 32)), (3, 32, "res_noq", (32, 32)),
+                                          (300, 32, "res", (32, 32))])
+def test_conv3x3_backward_fused_equals_the_two_kernels(ops, B, CD, form, hw):
     """dm_conv3x3_bwd_fused (data + weight gradient of enc.10 / the ResidualBlock's 3x3 convolution from one staging of the
     patch) against dm_conv3x3 + dm_wgrad and against autograd's conv2d backward in float64."""
-    CX, H = 16, 16
+    CX, (H, W) = 16, hw
     g = torch.Generator().manual_seed(B * 3 + CD)
-    gy, y = torch.randn(B, CD, H, H, generator=g), torch.randn(B, CD, H, H, generator=g)
-    x = torch.randn(B, CX, H, H, generator=g)
+    gy, y = torch.randn(B, CD, H, W, generator=g), torch.randn(B, CD, H, W, generator=g)
+    x = torch.randn(B, CX, H, W, generator=g)
     w = torch.randn(CD, CX, 3, 3, generator=g) * 0.2
     cd = torch.randn(CD, 4, generator=g) * 0.5
     d = lambda t: t.to(DEV)
@@ -806,8 +809,8 @@ def test_conv3x3_backward_fused_equals_the_two_kernels(ops, B, CD, form):
         T_op, mask_op = ops.Op(d(x), 3, d(cx)), ops.Op(d(x), 2, d(cx))
     else:
         xcoef, t = None, x.double()
-        resid = d(torch.randn(B, CX, H, H, generator=g))
-        q = d(torch.randn(B, CX, H, H, generator=g)) if form == "res" else None
+        resid = d(torch.randn(B, CX, H, W, generator=g))
+        q = d(torch.randn(B, CX, H, W, generator=g)) if form == "res" else None
         T_op, mask_op = ops.Op(d(x), 1), ops.Op(d(x))
     dst = torch.zeros(CD, CX, 3, 3, device=DEV)
     dx, st = ops.conv3x3_bwd_fused(dy_op, d(x), xcoef, d(w), dst, B, CD, resid=resid, q=q, want_stats=form != "res_noq")
@@ -822,8 +825,8 @@ def test_conv3x3_backward_fused_equals_the_two_kernels(ops, B, CD, form):
     close(dst, w64.grad.float(), 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs float64")
     # the two kernels it replaces
     dst2 = torch.zeros(CD, CX, 3, 3, device=DEV)
-    ops.wgrad(dy_op, T_op, dst2, B, CD, CX, H, H, 3)
-    dx2, st2 = ops.conv3x3(dy_op, ops.weight_view(d(w), 9, CX * 9, -3, -1, off=8), B, CD, CX, H, H, taps=9,
+    ops.wgrad(dy_op, T_op, dst2, B, CD, CX, H, W, 3)
+    dx2, st2 = ops.conv3x3(dy_op, ops.weight_view(d(w), 9, CX * 9, -3, -1, off=8), B, CD, CX, H, W, taps=9,
                            want_stats=form != "res_noq", like=d(gy), mask=mask_op, resid=resid, stat_q=q)
     assert float((dx - dx2).abs().max()) <= 3e-6 * scale
     close(dst, dst2, 1e-5, 3e-5 * float(w64.grad.abs().max()), "weight gradient vs dm_wgrad")
@@ -839,7 +842,9 @@ def test_conv3x3_backward_fused_equals_the_two_kernels(ops, B, CD, form):
     dst3 = torch.zeros(CD, CX, 3, 3, device=DEV)
     dx3, st3 = ops.conv3x3_bwd_fused(dy_op, d(x), xcoef, d(w), dst3, B, CD, resid=resid, q=q, want_stats=form != "res_noq")
     assert torch.equal(dx3, dx) and torch.equal(dst3, dst) and (st is None or torch.equal(st3, st))
-    assert not ops.conv3x3_bwd_fused_supported(32, 16, 32, 32) and not ops.conv3x3_bwd_fused_supported(64, 64, 16, 16)
+    assert ops.conv3x3_bwd_fused_supported(32, 16, 32, 32) and not ops.conv3x3_bwd_fused_supported(32, 16, 32, 64)
+    assert not ops.conv3x3_bwd_fused_supported(16, 16, 32, 32)
+    assert not ops.conv3x3_bwd_fused_supported(64, 64, 16, 16)
 
 
 @pytest.mark.parametrize("B,two", [(3, True), (70, True), (300, True), (2, False)])
