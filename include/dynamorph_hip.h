@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 124
+#define DM_VERSION 125
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
