@@ -45,5 +45,5 @@ rm -rf $out/tb
 tools/sqprof.sh ${tag}_c3 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-targets --no-roofline > /dev/null 2>&1
 cp gpurun_out/${tag}_c3_sq.txt $out/${tag}_c3_b2048_sq_counters.txt 2>/dev/null
 cp gpurun_out/${tag}_c3_sq.json $out/${tag}_c3_b2048_sq_counters.json 2>/dev/null
-DM_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 > $out/${tag}_bench_dp2_gloo_rehearsal.json 2> $out/dp2.err
+DM_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 2> $out/dp2.err | grep '^{' > $out/${tag}_bench_dp2_gloo_rehearsal.json   # (gloo prints its connection lines on stdout)
 tail -c 600 $out/${tag}_c3_b2048_bench.json; echo; tail -3 $out/${tag}_c3_b2048_kernel_table.txt; tail -c 400 $out/${tag}_bench_dp2_gloo_rehearsal.json
