@@ -635,10 +635,13 @@ def test_z32_other_input_channel_counts(nin):
     grad_gate(m, g32, g64, skip=Z32_BN_FED_BIASES, floor=5e-4, what=f"z32 nin={nin}")
 
 
-@pytest.mark.parametrize("B,nin,masked,use_graph", [(5, 1, True, False), (3, 4, True, True), (6, 3, False, True)])
-def test_fused_trainer_shape_sweep(B, nin, masked, use_graph):
+@pytest.mark.parametrize("B,nin,masked,use_graph,hw", [(5, 1, True, False, 128), (3, 4, True, True, 128), (6, 3, False, True, 128),
+                                                       # 256-pixel patches: the decoder tail in 64-column tiles with seam terms,
+                                                       # the residual 3 x 3 backward in bands of the 32 x 32 latents
+                                                       (2, 4, True, True, 256), (3, 2, False, False, 256)])
+def test_fused_trainer_shape_sweep(B, nin, masked, use_graph, hw):
     """FusedTrainer (training tail in one kernel, slab codebook gradient, counted Adam) vs the oracle's
-    model(x) / backward / torch.optim.Adam.step for other channel counts, odd batches and masks."""
+    model(x) / backward / torch.optim.Adam.step for other channel counts, odd batches, masks and patch sizes."""
     import dynamorph_amd
     from dynamorph_amd.train import FusedTrainer
     from oracle import vqvae_oracle as O
@@ -647,8 +650,8 @@ def test_fused_trainer_shape_sweep(B, nin, masked, use_graph):
     ref = O.OracleVQVAE(**kw)
     m = dynamorph_amd.VQ_VAE(**kw).to(DEV)
     m.load_state_dict(ref.state_dict())
-    x = torch.randn(B, nin, 128, 128, generator=torch.Generator().manual_seed(B))
-    mask = ((torch.rand(B, 1, 128, 128, generator=torch.Generator().manual_seed(B + 7)) > 0.4).float() if masked else None)
+    x = torch.randn(B, nin, hw, hw, generator=torch.Generator().manual_seed(B))
+    mask = ((torch.rand(B, 1, hw, hw, generator=torch.Generator().manual_seed(B + 7)) > 0.4).float() if masked else None)
     opt = O.make_adam(ref, 1e-4)
     tr = FusedTrainer(m, lr=1e-4, use_graph=use_graph)
     xd, md = x.to(DEV), (None if mask is None else mask.to(DEV))
