@@ -848,7 +848,7 @@ void convT_phase_kernel(Operand in, WeightView wv, float *__restrict__ out, Epil
 // other's matrix phase instead of all eight waves of a CU committing at the same time).
 template <int CD, int CX, int TH, int TW>
 struct FusedBwdGeom {
-    static_assert(CD == 16 && CX == 8 && TH == 8 && TW % 16 == 0, "built for enc.4: 8 -> 16 channels");
+    static_assert(CD == 16 && CX == 8 && (TH == 8 || TH == 4) && TW % 16 == 0, "built for enc.4: 8 -> 16 channels");
     static constexpr int IH = TH + 2, RS = TW + 8, COLS4 = RS / 4, PSRAW = IH * RS;
     static constexpr int PS = PSRAW + ((16 - (PSRAW % 32)) + 32) % 32;            // == 16 (mod 32): kernel C's A reads
     static constexpr int TROWS = 2 * TH + 2, RST = 2 * TW + 8, TCOLS4 = RST / 4, PST = TROWS * RST;
@@ -1402,7 +1402,7 @@ void bwd_s2_roles3_kernel(Operand dy, Operand tin, WeightView wv, float *__restr
     constexpr int IH = G::IH, RS = G::RS, COLS4 = G::COLS4, PS = G::PS;
     constexpr int TROWS = G::TROWS, RST = G::RST, TCOLS4 = G::TCOLS4, PST = G::PST, NTT = G::NTT, N = G::N;
     constexpr int BUF = CD * PS + CX * PST;                 // floats of one (da, T) tile pair
-    constexpr int CGN = TW / 16, MP = 2, NPASS = TH * CGN / (RW * MP), WROWS = TH / RW;
+    constexpr int CGN = TW / 16, MP = ZF ? CGN : 2, NPASS = TH * CGN / (RW * MP), WROWS = TH / RW;     // ZF: a wave takes a whole row
     static_assert(TH * CGN == RW * MP * NPASS && TH == RW * WROWS, "tile split over the waves of a role");
     constexpr int TAPX = 3, KS = (CD / 4) * 2 * TAPX;
     extern __shared__ __attribute__((aligned(16))) float fb_lds[];
@@ -1633,7 +1633,7 @@ void bwd_s2_roles3_kernel(Operand dy, Operand tin, WeightView wv, float *__restr
                     else mfma_tiles<MP, NTW, KSW, ZF ? 4 : TAPX * 2>(ap, wreg[py], acc, off);
                     f32x4 v[MP];
                     if constexpr (ZF) {
-                        static_assert(MP == 2 && CGN == 2, "the two spans of a row in one wave");
+                        static_assert(MP == CGN, "every span of a row in one wave");
                         // row P of the side product goes to row P + 1 (px = 0) or P - 1 (px = 1) of the result; M row =
                         // 16 i + 4 kq + register.  The one row per tile that crosses the lanes: the provider hands over its last
                         // (px = 0) or first (px = 1) register, the receiver reads 16 lanes down / up (wrapping into the other span)
@@ -1645,10 +1645,10 @@ void bwd_s2_roles3_kernel(Operand dy, Operand tin, WeightView wv, float *__restr
 #pragma unroll
                         for (int i = 0; i < MP; ++i) {
                             const f32x4 c = acc[i][0], sd = acc[i][1];
-                            // px = 0: first lane group of span 0 meets column -1 (zero), of span 1 the last group of span 0
-                            // px = 1: last lane group of span 1 meets column W (zero), of span 0 the first group of span 1
-                            const float e0 = grp_first ? (i == 0 ? 0.f : x[0]) : x[i];
-                            const float e1 = grp_last ? (i == MP - 1 ? 0.f : x[MP - 1]) : x[i];
+                            // px = 0: first lane group of span 0 meets column -1 (zero), of span i > 0 the last group of span i - 1
+                            // px = 1: last lane group of the last span meets column W (zero), of span i the first group of span i + 1
+                            const float e0 = grp_first ? (i == 0 ? 0.f : x[i > 0 ? i - 1 : 0]) : x[i];
+                            const float e1 = grp_last ? (i == MP - 1 ? 0.f : x[i < MP - 1 ? i + 1 : MP - 1]) : x[i];
                             v[i] = pxl ? (f32x4){c.x + sd.y, c.y + sd.z, c.z + sd.w, c.w + e1}
                                        : (f32x4){c.x + e0, c.y + sd.x, c.z + sd.y, c.w + sd.z};
                         }
@@ -2159,6 +2159,9 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
         DM_ROLES3_ATTR(false, false) DM_ROLES3_ATTR(true, false) DM_ROLES3_ATTR(false, true) DM_ROLES3_ATTR(true, true)
 #undef DM_ROLES3_ATTR
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)bwd_s2_roles3_kernel<16, 8, 4, 64, false, true, 1>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedBwdGeom<16, 8, 4, 64>::SPLIT_LDS_BYTES);
         if (e != hipSuccess) { dm_set_error("dm_conv_bwd_s2_fused: cannot reserve %zu bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set.mark();
     }
@@ -2178,7 +2181,15 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
         /* (a second group of data-gradient waves, NDG = 2 / 1024 threads, measured slower: 240.6 against 227.4 us) */                 \
         { hipLaunchKernelGGL((bwd_s2_roles3_kernel<16, 8, 8, 32, BF_, ZF_, 1>), dim3(grid), dim3(768), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
                                to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg()); }
-    if (fused_bwd_block() == 0 && roles3) {
+    // 64-column grids (enc.4 of 256-pixel patches): tiles of 4 rows x 64 columns span the row, so the zero-free mapping applies
+    // (the same number of tiles, hence of slabs, as 8 x 32)
+    const bool zf64 = W == 64 && H % 4 == 0 && !zf_off && roles3 && fused_bwd_block() == 0 && !dm_backward_split_bf16();
+    if (zf64) {
+        using G64 = FusedBwdGeom<16, 8, 4, 64>;
+        hipLaunchKernelGGL((bwd_s2_roles3_kernel<16, 8, 4, 64, false, true, 1>), dim3(grid), dim3(768), G64::SPLIT_LDS_BYTES,
+                           (hipStream_t)stream, to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, B * (H / 4),
+                           fused_bwd_dbg());
+    } else if (fused_bwd_block() == 0 && roles3) {
         const bool bf = dm_backward_split_bf16();
         if (bf && zf) DM_ROLES3_LAUNCH(true, true)
         else if (bf) DM_ROLES3_LAUNCH(true, false)

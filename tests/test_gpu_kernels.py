@@ -1736,12 +1736,12 @@ def test_vq_bf16_split_filter_scales_and_clusters(ops, D, K, scale_z, scale_e):
     print(f"D={D} K={K} scales ({scale_z}, {scale_e}): {int(nre.cpu())} of {idx_b.numel()} positions re-evaluated exactly")
 
 
-@pytest.mark.parametrize("B,hw", [(3, 32), (2, 64), (5, 32), (300, 32)])
+@pytest.mark.parametrize("B,hw", [(3, 32), (2, 64), (5, 32), (300, 32), (70, 64), (2, 128)])
 def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     """Kernel D (csrc/conv_mfma.hip): data gradient + weight gradient of a Conv2d(8 -> 16, 4, 2, 1) from one staging of
     (dy, a_out, a_in), with the BatchNorm-backward operand, the ReLU mask of the layer input and the (sum, sum * input)
     statistics -- against torch autograd, and against the two kernels it replaces (the data gradient bit for bit where the
-    MFMA order is the same, hw = 64; the weight gradient to summation order).  B = 300: more tiles than workgroups."""
+    MFMA order is the same, hw = 128; the weight gradient to summation order).  B = 300: more tiles than workgroups."""
     CD, CX, H, W = 16, 8, hw, hw
     prev = ops.backward_precision("f32")                     # (the bit-for-bit comparisons below)
     dy, a_out = rnd(B, CD, H, W, seed=1), rnd(B, CD, H, W, seed=2)
@@ -1770,8 +1770,8 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
                            want_stats=True, mask=ops.Op(aid, 2, cTd), stat_q=aid)
     dst2 = torch.empty_like(dst)
     ops.wgrad(dyop(), ops.Op(aid, 3, cTd), dst2, B, CD, CX, H, W, 4)
-    if hw == 32:
-        # a tile spans the row: kernel D takes the data gradient without structural zeros (round 5) -- the centre column's and the
+    if hw in (32, 64):
+        # a tile spans the row (8 x 32 tiles at 32 columns, 4 x 64 at 64): kernel D takes the data gradient without structural zeros (round 5) -- the centre column's and the
         # outer columns' products in two accumulators, added at the end -- so the sum's order differs from the two-kernel path's
         # single chain; both stay within the same distance of the float64 result
         e_d, e_2 = (dx.cpu().double() - dx_ref.double()).abs().max(), (dx2.cpu().double() - dx_ref.double()).abs().max()
