@@ -578,14 +578,6 @@ def train_loop_record(dev, resident_ms_per_step, n=32768, B=2048, epochs=3, feed
     return rec
 
 
-def _nccl_version():
-    """RCCL's version as torch reports it; a reporting field must never cost the line its value."""
-    try:
-        return ".".join(str(v) for v in torch.cuda.nccl.version())
-    except Exception as e:      # noqa: BLE001
-        return f"unavailable ({type(e).__name__})"
-
-
 def _host_cpu():
     """(model name, physical cores) of the host from lscpu; falls back to os.cpu_count() // 2."""
     import subprocess
@@ -776,13 +768,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
-    rank_ms = [1e3 * elapsed / args.steps]
-    if world > 1:
-        # every rank's own wall time of the timed region (after the closing barrier they differ only by launch skew)
-        mine = torch.tensor([rank_ms[0]], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        torch.distributed.all_gather(allr, mine)
-        rank_ms = [float(t.item()) for t in allr]
+    # every rank's own wall time of the timed region (after the closing barrier they differ only by launch skew)
+    rank_ms = D.gather_rank_values(1e3 * elapsed / args.steps, device=dev)
     elapsed = D.max_over_ranks(elapsed, device=dev)
 
     losses = out.tolist() if args.workload in ("c3", "c5", "z32ex") else None
@@ -795,15 +782,20 @@ def main():
         for _ in range(20 if world > 1 else 5):
             trainer.step(x, *targs, timers=marks)
         parts = FusedTrainer.timer_summary(marks)
-        backend = dist.get_backend() if world > 1 else None
+        # backend, RCCL version, and that every rank holds bit-equal parameters after the steps above
+        evidence = D.collective_evidence(trainer.flat)
+        backend = evidence["backend"]
         collective = {"backend": backend, "world": world, "message_bytes": trainer.grad.numel() * 4,
+                      "replicas_bit_equal": evidence["replicas_bit_equal"],
                       "allreduce_us": parts["allreduce_us"] if world > 1 else None,
                       "allreduce_host_us": parts["allreduce_host_us"] if world > 1 else None,
                       "fwd_bwd_graph_us": parts["fwd_bwd_us"], "adam_us": parts["adam_us"],
                       "fwd_bwd_host_us": parts["fwd_bwd_host_us"], "adam_host_us": parts["adam_host_us"],
-                      "nccl_version": _nccl_version() if backend == "nccl" else None,
+                      "nccl_version": evidence["nccl_version"],
                       "rank_ms_per_step_min": round(min(rank_ms), 4), "rank_ms_per_step_max": round(max(rank_ms), 4),
-                      "op": "all_reduce(SUM) of the flat fp32 gradient bucket, then x 1/world" if world > 1 else "none (one process)"}
+                      "rank_ms_per_step": [round(v, 4) for v in rank_ms],
+                      "op": ("all_reduce(SUM) of the flat fp32 gradient bucket; x 1/world inside the fused Adam's load"
+                             if world > 1 else "none (one process)")}
         if world > 1:
             dist.barrier()
     if args.no_roofline or rank != 0:

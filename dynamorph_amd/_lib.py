@@ -141,6 +141,7 @@ SIGNATURES = {
     "dm_e1_chain": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dm_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
     "dm_adam_counted": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp, vp]),
+    "dm_adam_counted_scaled": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, vp]),
     "dm_zscore_patch": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "dm_zscore_channels": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.c_int, i64, vp]),
     "dm_augment": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

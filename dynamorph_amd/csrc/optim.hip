@@ -15,8 +15,11 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, long long n,
                                                    float lr, float b1, float b2, float eps,
-                                                   const float *__restrict__ step_dev, float *__restrict__ step_next)
+                                                   const float *__restrict__ step_dev, float *__restrict__ step_next,
+                                                   float grad_scale)
 {
+    // grad_scale: the bucket holds the SUM over ranks of the data-parallel exchange, 1 / world turns it into the mean here
+    // (the same single float product the separate "x 1/world" launch did; 1 in one process: g * 1.f == g bit for bit)
     // step_next given: step_dev holds the number of COMPLETED steps, this is step t = that + 1, and t is written to
     // step_next (a different word: the caller ping-pongs two counters, so no launch is spent on "step += 1")
     const double t = (double)step_dev[0] + (step_next ? 1.0 : 0.0);
@@ -27,7 +30,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     const float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = 1.f - b1, w2 = 1.f - b2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i];
+        const float gi = g[i] * grad_scale;
         const float mi = m[i] + w1 * (gi - m[i]);
         const float vi = v[i] * b2 + w2 * (gi * gi);
         m[i] = mi;
@@ -207,7 +210,7 @@ extern "C" int dm_adam(float *param, const float *grad, float *m, float *v, int6
     DM_REQUIRE(param && grad && m && v && step_dev && n > 0, "dm_adam: bad argument");
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n, lr,
-                       beta1, beta2, eps, step_dev, (float *)nullptr);
+                       beta1, beta2, eps, step_dev, (float *)nullptr, 1.f);
     return dm_launch_status("dm_adam");
 }
 
@@ -218,8 +221,20 @@ extern "C" int dm_adam_counted(float *param, const float *grad, float *m, float 
                "dm_adam_counted: bad argument");
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n, lr,
-                       beta1, beta2, eps, steps_done, steps_done_next);
+                       beta1, beta2, eps, steps_done, steps_done_next, 1.f);
     return dm_launch_status("dm_adam_counted");
+}
+
+extern "C" int dm_adam_counted_scaled(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1,
+                                      float beta2, float eps, float grad_scale, const float *steps_done,
+                                      float *steps_done_next, void *stream)
+{
+    DM_REQUIRE(param && grad && m && v && steps_done && steps_done_next && steps_done != steps_done_next && n > 0,
+               "dm_adam_counted_scaled: bad argument");
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n, lr,
+                       beta1, beta2, eps, steps_done, steps_done_next, grad_scale);
+    return dm_launch_status("dm_adam_counted_scaled");
 }
 
 extern "C" int dm_e1_compose(const float *w0, const float *b0, const float *w1, float *weff,

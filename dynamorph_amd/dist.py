@@ -76,6 +76,24 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_weight(n, rank, world):
+    """Weight of `rank`'s gradient in the data-parallel mean for a global batch of n samples cut by shard_range: every
+    loss is a mean over the LOCAL shard, so n_local * world / n makes mean-over-ranks the global-batch mean (1 for even
+    shards, 0 for an empty one; the weights of all ranks sum to `world`)."""
+    lo, hi = shard_range(n, rank, world)
+    return (hi - lo) * world / n
+
+
+def gather_rank_values(value, device=None, group=None):
+    """[value on rank 0, ..., value on rank world-1] on every rank (bench: each rank's own wall time of the timed region)."""
+    if world_size(group) == 1:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world_size(group))]
+    dist.all_gather(parts, mine, group=group)
+    return [float(t.item()) for t in parts]
+
+
 class FlatParams:
     """All trainable tensors of a module as views of ONE flat buffer, gradients as views of a second one."""
 
@@ -197,6 +215,28 @@ def gather_shards(local, group=None, dst=0):
                     dist.recv(torch.from_numpy(full[off:off + n]), src=to_global(r), group=hg)
             off += n
     return out[0] if single else type(local)(out)
+
+
+def collective_evidence(flat, group=None):
+    """What a reader needs to see that the collective library really carried the job: backend ("nccl" = RCCL on ROCm),
+    its version, the world size, and whether every rank's copy of `flat` (the flat parameter buffer after a step) is
+    bit-equal to rank 0's -- identical replicas are the invariant of data-parallel training with one all-reduce per step.
+    Collective: every rank calls it."""
+    w = world_size(group)
+    rec = {"backend": dist.get_backend(group) if w > 1 else None, "world": w, "nccl_version": None, "replicas_bit_equal": True}
+    if w == 1:
+        return rec
+    if rec["backend"] == "nccl":
+        try:
+            rec["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001  (a reporting field)
+            rec["nccl_version"] = f"unavailable ({type(e).__name__})"
+    ref = flat.detach().clone()
+    dist.broadcast(ref, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+    same = torch.tensor([1.0 if torch.equal(ref, flat.detach()) else 0.0], device=flat.device)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN, group=group)
+    rec["replicas_bit_equal"] = bool(same.item() == 1.0)
+    return rec
 
 
 def max_over_ranks(value, device=None, group=None):

@@ -95,6 +95,8 @@ class Feed:
 
     def __init__(self, dataset, device, mode="auto", mask=None, relation_mat=None, batch_size=None, trainer=None):
         self.dev = torch.device(device)
+        if self.dev.type == "cuda" and self.dev.index is None:      # 'cuda' names the current device: compare like with like
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.trainer = trainer
         src = dataset_tensor(dataset)
         if src is None or src.dim() != 4:

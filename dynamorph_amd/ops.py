@@ -910,10 +910,16 @@ def adam(param, grad, m, v, lr, beta1, beta2, eps, step_dev):
 
 
 @_op
-def adam_counted(param, grad, m, v, lr, beta1, beta2, eps, steps_done, steps_done_next):
+def adam_counted(param, grad, m, v, lr, beta1, beta2, eps, steps_done, steps_done_next, grad_scale=1.0):
+    """grad_scale != 1: the step reads grad * grad_scale (data parallel: the all-reduced SUM x 1 / world, in the load)."""
     lib = L.load()
-    L.check(lib.dm_adam_counted(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
-                                _ptr(steps_done), _ptr(steps_done_next), _stream()), "dm_adam_counted")
+    if grad_scale == 1.0:
+        L.check(lib.dm_adam_counted(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
+                                    _ptr(steps_done), _ptr(steps_done_next), _stream()), "dm_adam_counted")
+    else:
+        L.check(lib.dm_adam_counted_scaled(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps,
+                                           float(grad_scale), _ptr(steps_done), _ptr(steps_done_next), _stream()),
+                "dm_adam_counted_scaled")
 
 
 @_op

@@ -201,19 +201,21 @@ class FusedTrainer:
         return scalars
 
     def _allreduce(self, weight=1.0):
-        """Mean over ranks of the flat gradient bucket: ONE collective.  Every loss is a mean over the LOCAL batch, so with
-        equal shards the mean of the per-rank gradients is the gradient of the global-batch mean loss; a rank whose shard
-        of a ragged batch is smaller passes weight = n_local * world / n_global (0 for an empty shard)."""
+        """SUM over ranks of the flat gradient bucket: ONE collective and nothing behind it -- the "x 1 / world" of the mean
+        is applied by the optimizer's load (_adam, dm_adam_counted_scaled), so after the exchange the bucket holds the sum.
+        Every loss is a mean over the LOCAL batch, so with equal shards the mean of the per-rank gradients is the gradient
+        of the global-batch mean loss; a rank whose shard of a ragged batch is smaller passes weight = n_local * world /
+        n_global (0 for an empty shard)."""
         if self.world == 1:
             return
         if weight != 1.0:
             self.grad.mul_(float(weight))
-        D.allreduce_mean_(self.grad, self.group)
+        torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
     def _adam(self):
         a, b = self._step_slot, 1 - self._step_slot
         ops.adam_counted(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
-                         self.step_dev[a:a + 1], self.step_dev[b:b + 1])
+                         self.step_dev[a:a + 1], self.step_dev[b:b + 1], grad_scale=1.0 / self.world)
         self._step_slot = b
 
     def step_without_data(self):
@@ -490,6 +492,7 @@ def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, t
         vals = vals.tolist()                                           # one device sync per step (reference: five)
         loss_dict = dict(zip(LOSS_KEYS, vals))
         loss_dict["time_matching_loss"] = vals[4] if len(vals) > 4 else 0.
+        loss_dict = _in_model_order(model, loss_dict)
     else:
         _, loss_dict = model(batch, **model_kwargs)
         if training:
@@ -595,9 +598,10 @@ class _LossLog:
     the captured step overwrites its output tensor on the next replay) and the whole phase is read back ONCE, instead of
     the reference's float(loss) per key and step (run_training.py:409-414), which stalls the host on every step."""
 
-    def __init__(self, device, n_batches, width=8):
+    def __init__(self, device, n_batches, width=8, model=None):
         self.buf = torch.zeros((max(n_batches, 1), width), device=device)
         self.meta = []                      # (keys, number of values, samples) per logged batch
+        self.model = model
 
     def add(self, keys, vals, n):
         k = vals.numel()
@@ -611,11 +615,28 @@ class _LossLog:
         for (keys, k, n), row in zip(self.meta, host):
             d = dict(zip(keys, row[:k]))
             d.setdefault("time_matching_loss", 0.)
-            out.append((d, n))
+            out.append((_in_model_order(self.model, d) if self.model is not None else d, n))
         return out
 
 
 _FUSED_KEYS = LOSS_KEYS + ("time_matching_loss",)
+
+
+def loss_key_order(model):
+    """Key order of the loss dict the model's forward returns -- what run_one_batch's `for key, loss in
+    train_loss_dict.items()` (run_training.py:409) and with it the order of the epoch's writer.add_scalar rows follow:
+    vq_vae.py:333-338 (VQ_VAE: ..., total_loss, perplexity) and vae.py:337-342, 456-470 (VQ_VAE_z16 / VQ_VAE_z32: ...,
+    perplexity, total_loss).  The fused steps return a flat vector of values; their rows are put back in this order."""
+    z16 = getattr(model, "_z16_loss", False) or type(model).__name__ == "VQ_VAE_z32"
+    tail = ("perplexity", "total_loss") if z16 else ("total_loss", "perplexity")
+    return ("recon_loss", "commitment_loss", "time_matching_loss") + tail
+
+
+def _in_model_order(model, d):
+    order = loss_key_order(model)
+    out = {k: d[k] for k in order if k in d}
+    out.update((k, v) for k, v in d.items() if k not in out)        # (extra_loss entries keep their place at the end)
+    return out
 
 
 def _device_step(model, optimizer, x, kw, training, grad_weight):
@@ -646,7 +667,7 @@ def _device_step(model, optimizer, x, kw, training, grad_weight):
 
 def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10, lr=0.001, batch_size=16,
           device='cuda:0', shuffle_data=False, transform=None, val_split_ratio=0.15, patience=20,
-          get_relation_tensor=None, get_mask=None, writer=None, fused=True, feed="auto", stats=None):
+          get_relation_tensor=None, get_mask=None, writer=None, fused=True, feed="auto", stats=None, probe=None):
     """The training loop of run_training.py:455-551 -- Adam, a contiguous validation block at a random start, epoch and
     batch loops, TensorBoard-style scalars, EarlyStopping checkpoint of the state_dict to <output_dir>/model.pt -- made
     data parallel (one process per GPU, torch.distributed initialised by the launcher):
@@ -669,7 +690,11 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
     synchronous copy, float() per step) -- taken automatically on the CPU, for dataset objects that only support
     dataset[ids], and when the caller brings its own get_relation_tensor / get_mask.  All feeds produce the same batches.
     stats: a dict that receives {"feed", "phase_seconds": {phase: [per epoch]} (device time between the phase's first and
-    last launch; host wall time on the CPU), "phase_samples": {phase: n}, "epoch_seconds": [wall clock per epoch]}.
+    last launch; host wall time on the CPU), "phase_samples": {phase: n}, "epoch_seconds": [wall clock per epoch],
+    "step_losses": {phase: [per epoch: [loss dict of every batch, in order]]}}.
+    probe: callable(phase, epoch, ids, x, kwargs) called with every batch right before its step -- the sample ids of this
+    rank's shard, the (augmented) batch and the model kwargs exactly as the step is about to read them (the tests hold
+    them against what the reference's loop hands its model, tests/golden/g11_train_loop.npz); it must copy what it keeps.
 
     `dataset` is a TensorDataset-like object indexable with a list of ids (dataset[ids][0] -> host tensor)."""
     assert val_split_ratio is None or 0 < val_split_ratio < 1
@@ -702,7 +727,8 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
             raise ValueError(f"train: feed={feed!r} needs a CUDA device, a tensor-backed dataset and the default "
                              "get_relation_tensor / get_mask")
     if stats is not None:
-        stats.update(feed=feeder.mode if feeder else "sync", phase_seconds={"train": [], "val": []}, phase_samples={})
+        stats.update(feed=feeder.mode if feeder else "sync", phase_seconds={"train": [], "val": []}, phase_samples={},
+                     step_losses={"train": [], "val": []})
 
     # the reference's loop takes dataset[ids][0]; a bare tensor / ndarray (what upload_zscored returns) is indexed directly
     bare = None
@@ -749,9 +775,9 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
             for start in range(0, len(ids), batch_size):
                 ids_batch = ids[start:start + batch_size]
                 lo, hi = D.shard_range(len(ids_batch), rank, world)
-                plan.append((ids_batch[lo:hi], (hi - lo) * world / len(ids_batch)))
+                plan.append((ids_batch[lo:hi], D.shard_weight(len(ids_batch), rank, world)))
             if feeder is not None:
-                log = _LossLog(dev, len(plan))
+                log = _LossLog(dev, len(plan), model=model)
                 batches = feeder.phase([p[0] for p in plan], transform, fused=isinstance(optimizer, FusedTrainer))
                 for ids_local, weight in plan:
                     if not len(ids_local):
@@ -759,12 +785,15 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                             _step_without_data(model, optimizer)
                         continue
                     n, x, kw = next(batches)
+                    if probe is not None:
+                        probe(phase, epoch, ids_local, x, kw)
                     keys, vals = _device_step(model, optimizer, x, kw, training, weight)
                     log.add(keys, vals, n)
                 for _ in batches:                                   # (runs the generator to its end)
                     pass
                 logs[phase] = (log, losses)                         # read back after BOTH phases are enqueued
             else:
+                per_step = []
                 for ids_local, weight in plan:
                     if not len(ids_local):
                         if training:
@@ -778,10 +807,18 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
                     kw = {'time_matching_mat': get_relation_tensor(relation_mat, ids_local, device=dev) if get_relation_tensor else None,
                           'batch_mask': get_mask(mask, ids_local, device=dev) if get_mask else None}
                     last = {}
-                    run_one_batch(model, batch, last, optimizer=optimizer, model_kwargs=kw, transform=transform,
+                    if transform is not None:
+                        batch = _augment(batch)                     # (run_one_batch's first statement, run_training.py:396)
+                    if probe is not None:
+                        probe(phase, epoch, ids_local, batch, kw)
+                    run_one_batch(model, batch, last, optimizer=optimizer, model_kwargs=kw, transform=None,
                                   training=training, grad_weight=weight)
                     losses.add(last, len(ids_local))
+                    if stats is not None:
+                        per_step.append({k: v[-1] for k, v in last.items()})
                 epoch_means[phase] = losses.means()
+                if stats is not None:
+                    stats["step_losses"][phase].append(per_step)
             if stats is not None:
                 if timed:
                     marks[phase][1].record()
@@ -791,9 +828,12 @@ def train(model, dataset, output_dir, relation_mat=None, mask=None, n_epochs=10,
         # the epoch's one device synchronisation: the loss rows of both phases (the validation pass was enqueued behind the
         # training steps without waiting for them)
         for phase, (log, losses) in logs.items():
-            for row, n in log.rows():
+            rows = log.rows()
+            for row, n in rows:
                 losses.add({k: [v] for k, v in row.items()}, n)
             epoch_means[phase] = losses.means()
+            if stats is not None:
+                stats["step_losses"][phase].append([row for row, _ in rows])
         if timed:
             torch.cuda.synchronize(dev)
             for phase, (e0, e1) in marks.items():                   # device time between the phase's first and last launch

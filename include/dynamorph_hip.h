@@ -566,6 +566,11 @@ int dm_adam(float *param, const float *grad, float *m, float *v, int64_t n,
  * that to steps_done_next[0] (a different word; callers alternate two counters), so the step needs no "+= 1" launch. */
 int dm_adam_counted(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
                     float eps, const float *steps_done, float *steps_done_next, void *stream);
+/* The same on grad[i] * grad_scale: data parallel, the bucket holds the all-reduced SUM of the ranks' gradients and
+ * grad_scale = 1 / world makes it the mean inside the optimizer's load (no separate scaling launch behind the collective). */
+int dm_adam_counted_scaled(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float grad_scale, const float *steps_done, float *steps_done_next,
+                           void *stream);
 
 /* ===== per-patch z-score (pipeline/train_utils.py:252-274, applied at patch_VAE.py:413-419) ============ */
 /* out[plane] = float((in[plane] - mean) / (std + eps)), population std over the HW elements of each of the `planes`

@@ -67,6 +67,16 @@ def _worker(rank, world, port, out_dir):
     few = D.gather_shards(full[:1] if rank == world - 1 else full[:0])      # empty shards everywhere but on the last rank
     assert np.array_equal(few, full[:1]) if rank == 0 else few is None
     t = D.max_over_ranks(1.0 + rank)
+    # the helpers bench.py's N > 1 line and tests/test_gpu_dist.py's RCCL evidence are built from
+    ev_same = D.collective_evidence(fp.flat)                     # replicas identical after the broadcast
+    drift = fp.flat.clone()
+    if rank == world - 1:
+        drift[5] += 1e-7
+    ev_drift = D.collective_evidence(drift)                      # one rank one ulp-ish off: every rank must see it
+    assert ev_same == {"backend": "gloo", "world": world, "nccl_version": None, "replicas_bit_equal": True}
+    assert ev_drift["replicas_bit_equal"] is False
+    assert D.gather_rank_values(2.5 * rank) == [2.5 * k for k in range(world)]
+    assert abs(sum(D.gather_rank_values(D.shard_weight(7, rank, world))) - world) < 1e-12
     torch.save({"flat0": flat0, "local": local, "mean": fp.grad.clone(), "helper": helper, "tmax": t, "range": (lo, hi)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -200,38 +210,5 @@ def test_train_loop_world2_shards_batches_and_checkpoints_on_rank0(tmp_path, cas
     assert set(ck.keys()) == set(model.state_dict().keys())
 
 
-def test_single_process_train_keeps_the_reference_draws_and_aggregation(tmp_path):
-    """world == 1: split / shuffles from numpy's global generator in the reference's order (run_training.py:490-493,
-    536) and epoch losses as the mean of the per-batch values (run_training.py:538-543), ragged last batch included."""
-    sys.path.insert(0, ROOT)
-    from dynamorph_amd.train import train
-    from oracle import vqvae_oracle as O
-    torch.manual_seed(9)
-    model = O.OracleVQVAE()
-    n, batch = 9, 4
-    data = torch.randn(n, 2, 128, 128, generator=torch.Generator().manual_seed(4))
-    rows = {}
-
-    class Scalars:
-        def add_scalar(self, key, value, epoch):
-            rows.setdefault(key, []).append(float(value))
-    np.random.seed(21)
-    train(model, torch.utils.data.TensorDataset(data), str(tmp_path / "run"), n_epochs=1, lr=LR, batch_size=batch,
-          device="cpu", shuffle_data=True, val_split_ratio=0.25, patience=3, writer=Scalars(), fused=False)
-    after = np.random.randint(0, 1 << 30)
-    # the reference's draw order on the same seed
-    np.random.seed(21)
-    split = int(np.floor(0.25 * n))
-    start = np.random.randint(0, n - split)
-    ids = list(range(n))
-    np.random.shuffle(ids)
-    train_ids = ids[:start] + ids[start + split:]
-    np.random.shuffle(train_ids)                       # end of epoch 0
-    assert after == np.random.randint(0, 1 << 30)      # same number of draws, same stream position
-    torch.manual_seed(9)
-    ref = O.OracleVQVAE()
-    opt = O.make_adam(ref, LR)
-    train_ids = ids[:start] + ids[start + split:]
-    per_batch = [float(O.train_step(ref, opt, data[train_ids[s:s + batch]])["total_loss"]) for s in range(0, len(train_ids), batch)]
-    assert len(per_batch) == 2 and len(train_ids) % batch != 0
-    assert abs(rows["Loss/total_loss"][0] - sum(per_batch) / len(per_batch)) <= 1e-6 * max(1.0, abs(per_batch[0]))
+# (the one-process draws, aggregation and checkpoint of train() are held against the reference's own run in
+# tests/test_train_loop_golden.py)

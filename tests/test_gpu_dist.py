@@ -43,6 +43,20 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     train(model, data, os.path.join(out_dir, "run"), n_epochs=EPOCHS, lr=LR, batch_size=BATCH, device=dev,
           transform=None, val_split_ratio=0.2, patience=5)
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    # the gradient exchange on its own: different data per rank, two more steps, then every rank's flat parameter buffer
+    # must be bit-equal to rank 0's -- with the backend and (RCCL) version that carried the bucket
+    from dynamorph_amd.train import FusedTrainer
+    tr = FusedTrainer(model, lr=LR)
+    x = torch.randn(6, 2, 128, 128, generator=torch.Generator().manual_seed(70 + rank)).to(dev)
+    before = tr.flat.clone()
+    for _ in range(2):
+        tr.step(x)
+    ev = D.collective_evidence(tr.flat)
+    ev["moved"] = bool((tr.flat != before).any())
+    if rank == 0:
+        import json
+        with open(os.path.join(out_dir, "collective.json"), "w") as f:
+            json.dump(ev, f)
     if backend == "nccl":
         # the inference hand-over under RCCL: shards encoded per rank, results to rank 0 over the gloo side group
         from dynamorph_amd.patch_vae import encode_patches, encode_patches_sharded
@@ -100,6 +114,9 @@ def test_fused_training_loop_two_ranks_on_one_gpu(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     _check_against_one_process(tmp_path, world)
+    import json
+    ev = json.load(open(os.path.join(tmp_path, "collective.json")))
+    assert ev == {"backend": "gloo", "world": 2, "nccl_version": None, "replicas_bit_equal": True, "moved": True}
 
 
 @pytest.mark.timeout(900)
@@ -113,5 +130,11 @@ def test_fused_training_loop_over_rccl(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "nccl"), nprocs=world, join=True)
     _check_against_one_process(tmp_path, world)
+    import json
+    ev = json.load(open(os.path.join(tmp_path, "collective.json")))
+    print("collective:", ev)
+    # RCCL carried the bucket: the backend is nccl, the library reports a version, every rank's parameters are bit-equal
+    assert ev["backend"] == "nccl" and ev["world"] == 2 and ev["moved"] and ev["replicas_bit_equal"]
+    assert ev["nccl_version"] and not ev["nccl_version"].startswith("unavailable"), ev
     lat = torch.load(os.path.join(tmp_path, "latents.pt"))
     assert lat["z_b"].shape == (9, 4096) and lat["z_a"].shape == (9, 4096)

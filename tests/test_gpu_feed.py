@@ -11,45 +11,58 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _augment_reference(batch, flips, rots):
-    """The reference's loop body (run_training.py:397-403) with given codes."""
-    out = batch.clone()
-    for i in range(len(batch)):
-        img = batch[i]
-        if flips[i] != 0:
-            img = torch.flip(img, dims=(int(flips[i]),))
-        out[i] = torch.rot90(img, k=int(rots[i]), dims=[1, 2])
-    return out
+def _aug_cases(golden):
+    """The reference's own augmentation: batches that went through run_one_batch's loop (run_training.py:396-403) when
+    tests/golden/make_golden_train_loop.py executed it -- input, output, numpy seed, generator position afterwards."""
+    g = golden("g11_train_loop.npz")
+    for i in range(int(g["aug_cases"])):
+        yield (int(g[f"aug{i}/seed"]), torch.from_numpy(g[f"aug{i}/x_f16"].astype(np.float32)),
+               torch.from_numpy(g[f"aug{i}/y_f16"].astype(np.float32)), g[f"aug{i}/after"])
+    a = {k[2:]: v for k, v in g.items() if k.startswith("a/")}          # run a's first training batch: 8 x 2 x 128 x 128
+    n = int(a["step_len"][0])
+    data = torch.from_numpy(g["data_f16"].astype(np.float32))
+    yield ("run a", data, torch.from_numpy(a["first_train_x_f16"].astype(np.float32)), a["step_ids"][:n])
 
 
-@pytest.mark.parametrize("N,C,H,B", [(40, 2, 128, 24), (9, 1, 64, 9), (12, 4, 256, 5), (7, 3, 20, 7), (5, 2, 36, 3)])
-def test_gather_augment_equals_the_reference_loop(N, C, H, B):
+def test_gather_augment_equals_the_reference_loop(golden):
+    """dm_gather_augment with the codes ops.augment_codes draws from the reference's seed == what the reference's loop made
+    of the same batch, bit for bit; all 12 (flip, rotation) pairs occur over the cases; C in {1, 2, 3, 4}, H in {20 .. 128}."""
     from dynamorph_amd import ops
-    g = torch.Generator().manual_seed(N * 31 + H)
-    src = torch.randn(N, C, H, H, generator=g)
-    ids = torch.randperm(N, generator=g)[:B]
-    flips = torch.randint(0, 3, (B,), generator=g)
-    rots = torch.randint(0, 4, (B,), generator=g)
-    flips[:min(B, 12)] = torch.arange(12)[:min(B, 12)] % 3          # every one of the 12 (flip, rotation) pairs at least once
-    rots[:min(B, 12)] = torch.arange(12)[:min(B, 12)] // 3
-    want = _augment_reference(src[ids], flips, rots)
-    d = lambda t: t.to(DEV, torch.int32)
-    out = torch.full((B + 2, C, H, H), 7.0, device=DEV)
-    ops.gather_augment(src.to(DEV), d(ids), d(flips), d(rots), out, B)
-    assert torch.equal(out[:B].cpu(), want)
-    assert bool((out[B:] == 7.0).all())                              # rows past n are not touched
-    # no codes: a pure gather; no ids: the first B samples in order
-    ops.gather_augment(src.to(DEV), d(ids), None, None, out, B)
-    assert torch.equal(out[:B].cpu(), src[ids])
-    ops.gather_augment(src.to(DEV), None, d(flips), d(rots), out, B)
-    assert torch.equal(out[:B].cpu(), _augment_reference(src[:B], flips, rots))
-    # an id outside the dataset reads as zeros, never as a stray address
-    bad = d(ids).clone()
-    bad[0] = N + 5
-    ops.gather_augment(src.to(DEV), bad, None, None, out, B)
-    assert bool((out[0] == 0).all()) and torch.equal(out[1:B].cpu(), src[ids][1:])
-    with pytest.raises(ValueError):
-        ops.gather_augment(src.to(DEV), d(ids), None, None, torch.empty(B - 1, C, H, H, device=DEV), B)
+    d = lambda t: torch.as_tensor(t).to(DEV, torch.int32)
+    seen = set()
+    for seed, x, want, extra in _aug_cases(golden):
+        if seed == "run a":
+            # inside train(): the split start is drawn first (run_training.py:490), then the batch's codes; rows = data[ids]
+            np.random.seed(5)
+            np.random.randint(0, 24 - 6)
+            ids, B = torch.from_numpy(extra), len(extra)
+        else:
+            np.random.seed(seed)
+            ids, B = torch.arange(len(x)), len(x)
+        flips, rots = ops.augment_codes(B)
+        if seed != "run a":
+            assert np.array_equal(np.random.randint(0, 2 ** 31, size=2), extra), "generator position after the draws"
+        seen |= set(zip(flips.tolist(), rots.tolist()))
+        N, C, H = x.shape[0], x.shape[1], x.shape[2]
+        out = torch.full((B + 2, C, H, H), 7.0, device=DEV)
+        ops.gather_augment(x.to(DEV), d(ids), d(flips), d(rots), out, B)
+        assert torch.equal(out[:B].cpu(), want), (seed, tuple(x.shape))
+        assert bool((out[B:] == 7.0).all())                              # rows past n are not touched
+        # no codes: a pure gather; no ids: the first B samples in order
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(N))[:B]
+        ops.gather_augment(x.to(DEV), d(perm), None, None, out, B)
+        assert torch.equal(out[:B].cpu(), x[perm])
+        if seed != "run a":
+            ops.gather_augment(x.to(DEV), None, d(flips), d(rots), out, B)
+            assert torch.equal(out[:B].cpu(), want)
+        # an id outside the dataset reads as zeros, never as a stray address
+        bad = d(perm).clone()
+        bad[0] = N + 5
+        ops.gather_augment(x.to(DEV), bad, None, None, out, B)
+        assert bool((out[0] == 0).all()) and torch.equal(out[1:B].cpu(), x[perm][1:])
+        with pytest.raises(ValueError):
+            ops.gather_augment(x.to(DEV), d(perm), None, None, torch.empty(B - 1, C, H, H, device=DEV), B)
+    assert len(seen) == 12, sorted(seen)
 
 
 def test_gather_rows_and_csr_block():

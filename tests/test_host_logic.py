@@ -235,19 +235,29 @@ def test_deepcopy_and_pickle_give_an_independent_module():
         assert list(r.state_dict().keys()) == list(m.state_dict().keys())
 
 
-def test_augmentation_codes_follow_the_reference_draw_order():
-    """run_training.py:396-403 draws np.random.choice([0,1,2]) then np.random.choice([0,1,2,3]) per sample, interleaved;
-    ops.augment_codes must hand out the same codes from the same seed and leave numpy's generator where the loop leaves it."""
+def test_augmentation_codes_follow_the_reference_draw_order(golden):
+    """run_training.py:396-403 draws a flip and a rotation per sample from numpy's global generator; ops.augment_codes must
+    hand out the reference's codes from the same seed and leave the generator where the loop leaves it.  The codes are read
+    off the batches the REFERENCE's loop produced (g11_train_loop.npz aug cases): the (flip, rotation) pairs that map
+    each input sample onto its output."""
     from dynamorph_amd import ops
-    for n in (0, 1, 7, 2048, 5000):
-        np.random.seed(1000 + n)
-        want = [(int(np.random.choice([0, 1, 2])), int(np.random.choice([0, 1, 2, 3]))) for _ in range(n)]
-        after = np.random.randint(0, 1 << 30, size=4).tolist()
-        np.random.seed(1000 + n)
-        flips, rots = ops.augment_codes(n)
-        assert flips.dtype == np.int32 and rots.dtype == np.int32 and len(flips) == n
-        assert list(zip(flips.tolist(), rots.tolist())) == want
-        assert np.random.randint(0, 1 << 30, size=4).tolist() == after
+    g = golden("g11_train_loop.npz")
+    for i in range(int(g["aug_cases"])):
+        x = torch.from_numpy(g[f"aug{i}/x_f16"].astype(np.float32))
+        y = torch.from_numpy(g[f"aug{i}/y_f16"].astype(np.float32))
+        np.random.seed(int(g[f"aug{i}/seed"]))
+        flips, rots = ops.augment_codes(len(x))
+        assert flips.dtype == np.int32 and rots.dtype == np.int32 and len(flips) == len(x)
+        assert np.array_equal(np.random.randint(0, 2 ** 31, size=2), g[f"aug{i}/after"])
+        for b in range(len(x)):
+            fits = [(f, k) for f in (0, 1, 2) for k in (0, 1, 2, 3)
+                    if torch.equal(torch.rot90(x[b] if f == 0 else torch.flip(x[b], dims=(f,)), k=k, dims=[1, 2]), y[b])]
+            # (12 pairs, 8 distinct transforms: a flip + rotation can equal the other flip + another rotation)
+            assert (int(flips[b]), int(rots[b])) in fits and len(fits) <= 2, (i, b, fits)
+    for n in (0, 2048):                                    # nothing drawn for an empty batch; one vectorised draw for a large one
+        np.random.seed(3)
+        f, r = ops.augment_codes(n)
+        assert len(f) == n and len(r) == n and (n == 0 or (set(f.tolist()) == {0, 1, 2} and set(r.tolist()) == {0, 1, 2, 3}))
 
 
 def test_feed_host_helpers():
