@@ -365,6 +365,8 @@ extern "C" int dm_conv3x3_bwd_fused(const dm_operand *dy, const float *x, const 
     DM_REQUIRE(dy->mode == DM_LOAD_IDENT || dy->coef, "dm_conv3x3_bwd_fused: AFFINE2 needs coefficients");
     DM_REQUIRE(dy->coef_bstride == 0 && !dy->ones_channel, "dm_conv3x3_bwd_fused: shared coefficients only");
     DM_REQUIRE(!q || stats, "dm_conv3x3_bwd_fused: q without a statistics destination");
+    // (the band form reads the halo rows of a neighbouring band: dx written over an input would corrupt them)
+    DM_REQUIRE(dx != dy->p0 && dx != dy->p1 && dx != x, "dm_conv3x3_bwd_fused: dx must not alias dy or x");
     Operand d = to_dev(dy);
     if (d.mode == DM_LOAD_IDENT) { d.coef = nullptr; d.p1 = nullptr; }
     const int grid = dm_conv3x3_bwd_fused_num_blocks(B, CD, CX, H, W);

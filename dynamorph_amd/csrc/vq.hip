@@ -40,7 +40,8 @@ constexpr int VQ_MAX_LDS_HIST = 4096;
 constexpr int VQ2_HDR = 32;
 constexpr int VQ2_SLAB_ROWS = 1024, VQ2_SLAB_STRIDE = 72;
 constexpr float VQ2_PAD_NORM = 3.0e38f;
-struct Vq2Layout { long long cbT, cbA, cbB, nrm, cbH, hrep, total; int R; };
+struct Vq2Layout { long long cbT, cbA, cbB, nrm, cbH, hrep, cbP, nrmP, total; int R; };
+// (cbP, nrmP: the permuted bf16 operand and norms of vq_cells_kernel -- vq_cells.h -- for 64 < K <= 4096 at embedding_dim 16)
 
 // Code-usage counters: every workgroup flushing its LDS histogram into ONE set of K global counters serialises
 // (workgroups x K atomics on K addresses: 8 us of a 28 us kernel at 512 workgroups, K = 64).  The workgroups add into
@@ -67,6 +68,12 @@ Vq2Layout vq2_layout(int K, int D)
         const long long rep = (long long)L.R * K, slab = K <= 64 ? (long long)VQ2_SLAB_ROWS * VQ2_SLAB_STRIDE : 0;
         L.hrep = o; o += rep > slab ? rep : slab; o = (o + 3) & ~3LL;
     }
+    {
+        const long long K128 = ((long long)K + 127) / 128 * 128;
+        const bool cells = D == 16 && K > 64 && K <= 4096;
+        L.cbP = o; o += cells ? K128 * 16 : 0;
+        L.nrmP = o; o += cells ? K128 : 0;
+    }
     L.total = o;
     return L;
 }
@@ -78,6 +85,54 @@ __device__ __forceinline__ unsigned vq_bf16_rne(float v)
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     const bf16x2_t r = __builtin_convertvector((f32x2){v, 0.f}, bf16x2_t);
     return __builtin_bit_cast(unsigned, r) & 0xffffu;
+}
+
+// ---- large codebooks at embedding_dim 16: operand layout of vq_cells_kernel (vq_cells.h) ----
+constexpr int VQC_NT = 4;                       // position tiles of 32 per wave
+constexpr int VQC_GCH = 4;                      // chunks of 32 codes per group
+constexpr int VQC_GROUP = 32 * VQC_GCH;         // 128 codes
+constexpr int VQC_MAX_K = 4096;                 // norms and group minima are sized for this in LDS
+
+// row m of chunk cc of the permuted operand <-> code: register r = 4 j + i of lane half hf holds row 8 j + 4 hf + i; the
+// cell (j, hf, i >> 1) of group g owns the codes g * 128 + 8 * cell .. + 7 = (chunk in group) * 2 + (i & 1)
+__host__ __device__ __forceinline__ int vqc_code_of(int cc, int m)
+{
+    const int g = cc / VQC_GCH, ccl = cc % VQC_GCH, j = m >> 3, hf = (m >> 2) & 1, i = m & 3;
+    const int cell = (j * 2 + hf) * 2 + (i >> 1);
+    return g * VQC_GROUP + cell * 8 + ccl * 2 + (i & 1);
+}
+
+typedef unsigned vqc_u32x4 __attribute__((ext_vector_type(4)));
+typedef float vqc_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 vqc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vqc_bf16x2 __attribute__((ext_vector_type(2)));
+
+// (cbP, nrmP) of vq_prep_kernel for this kernel: cbP[cc][hi | lo][lane][4 x u32] = the 8 bf16 (heads resp. remainders of
+// -2 e) of dimensions 8 (lane >> 5) .. + 7 of row lane & 31; nrmP[cc * 32 + m] = |e|^2 of that row (VQ2_PAD_NORM beyond K)
+__device__ __forceinline__ void vqc_prep(const float *__restrict__ cb, unsigned *__restrict__ cbP, float *__restrict__ nrmP,
+                                         int K, int t0, int nt)
+{
+    const int K128 = (K + VQC_GROUP - 1) / VQC_GROUP * VQC_GROUP, NCH = K128 / 32;
+    for (int i = t0; i < NCH * 512; i += nt) {
+        const int q = i & 3, l = (i >> 2) & 63, hl = (i >> 8) & 1, cc = i >> 9;
+        const int code = vqc_code_of(cc, l & 31);
+        unsigned u = 0;
+        for (int e = 0; e < 2; ++e) {
+            const int d = 8 * (l >> 5) + 2 * q + e;
+            const float a = code < K ? -2.f * cb[(long long)code * 16 + d] : 0.f;
+            const unsigned hi = vq_bf16_rne(a);
+            const float rem = a - __builtin_bit_cast(float, hi << 16);
+            u |= (hl ? vq_bf16_rne(rem) : hi) << (16 * e);
+        }
+        cbP[i] = u;
+    }
+    for (int i = t0; i < K128; i += nt) {
+        const int code = vqc_code_of(i >> 5, i & 31);
+        double acc = 0.0;
+        if (code < K)
+            for (int d = 0; d < 16; ++d) { const double e = (double)cb[(long long)code * 16 + d]; acc += e * e; }
+        nrmP[i] = code < K ? (float)acc : VQ2_PAD_NORM;
+    }
 }
 
 __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__ ws, Vq2Layout L, int K, int D,
@@ -151,6 +206,7 @@ __global__ void vq_prep_kernel(const float *__restrict__ cb, float *__restrict__
         const long long k = i / D;
         cbH[i] = cb[k * D + 4 * s + h];
     }
+    if (L.nrmP > L.cbP) vqc_prep(cb, reinterpret_cast<unsigned *>(ws + L.cbP), ws + L.nrmP, K, t0, nt);
 }
 
 // first-minimum with torch.argmax(-dist) NaN semantics: a NaN distance beats any number,
@@ -529,6 +585,8 @@ __device__ __forceinline__ void vq2_swap(float &x, float &y)
     }
     x = __builtin_bit_cast(float, lo); y = __builtin_bit_cast(float, hi);
 }
+
+#include "vq_cells.h"
 
 // The kernel.  One 256-thread workgroup = 4 waves = 4 chunks of 64 positions per iteration, persistent over the chunks.
 // Per chunk and wave: 64 MFMAs (the scores of 64 codes x 64 positions), the in-lane top 2 of every lane's 16 scores per
@@ -1629,6 +1687,16 @@ bool vq2_auto_bf16()
 }
 // measurement knobs of the headline shape (embedding_dim 16, <= 64 codes): DM_VQ_OCC=4 takes the build bounded to 128
 // registers (4 waves per SIMD), DM_VQ_WGS=n launches n workgroups per CU instead of the occupancy's
+// 0: off, 3 / 4: products of the bf16 split in vq_cells_kernel (default 3)
+int vq2_cells()
+{
+    static const int v = [] {
+        const char *e = getenv("DM_VQ_CELLS"), *p = getenv("DM_VQ_CELLS_PROD");
+        if (e && e[0] == '0') return 0;
+        return (p && p[0] == '4') ? 4 : 3;
+    }();
+    return v;
+}
 bool vq2_force_prep() { static const bool v = [] { const char *e = getenv("DM_VQ_PREP"); return e && e[0] == '1'; }(); return v; }
 int vq2_occ() { static const int v = [] { const char *e = getenv("DM_VQ_OCC"); return e ? atoi(e) : 3; }(); return v; }
 int vq2_wgs(int dflt) { static const int v = [] { const char *e = getenv("DM_VQ_WGS"); return e ? atoi(e) : 0; }(); return v > 0 ? v : dflt; }
@@ -1728,7 +1796,24 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         const bool single = K <= 64;
         // bf16-split filter (DM_VQ_BF16; DM_VQ_AUTO takes it where it applies) or the f32 one (DM_VQ_MFMA)
         const bool bf = D % 16 == 0 && (variant == DM_VQ_BF16 || (variant == DM_VQ_AUTO && vq2_auto_bf16()));
+        // 64 < K <= 4096 at embedding_dim 16 (BASELINE configs[4]): the cell kernel of vq_cells.h -- DM_VQ_CELLS=0 keeps the
+        // streamed 16x16x32 kernel, DM_VQ_CELLS_PROD=4 all four products of the split (A/B measurements)
+        const bool cells = bf && D == 16 && K > 64 && K <= VQC_MAX_K && (H * W) % 128 == 0 && vq2_cells() > 0;
         for (int rep = 0; rep < repeats; ++rep) {
+            if (cells) {
+                const long long passes = P >> 7;
+                long long g_ = (passes + 3) / 4;
+                if (g_ > 512) g_ = 512;                              // two workgroups per CU, persistent over the passes
+                if (vq2_cells() == 4)
+                    hipLaunchKernelGGL((vq_cells_kernel<4>), dim3((unsigned)g_), dim3(256), 0, s, z, codebook,
+                                       reinterpret_cast<const vqc_u32x4 *>(ws + L.cbP), ws + L.nrmP, ws + L.nrm, (long long *)idx,
+                                       out, sse_slabs, hrep, L.R, (int *)ws, K, H * W, P);
+                else
+                    hipLaunchKernelGGL((vq_cells_kernel<3>), dim3((unsigned)g_), dim3(256), 0, s, z, codebook,
+                                       reinterpret_cast<const vqc_u32x4 *>(ws + L.cbP), ws + L.nrmP, ws + L.nrm, (long long *)idx,
+                                       out, sse_slabs, hrep, L.R, (int *)ws, K, H * W, P);
+                continue;
+            }
             switch (D) {
             case 8: if (single) DM_VQ2(8, true, 3, 3) else DM_VQ2(8, false, 3, 3) break;
             case 16:

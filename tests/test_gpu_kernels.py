@@ -253,9 +253,14 @@ def test_vq_mfma_near_ties_and_non_finite_values(ops, cvq, D, K, filt):
             zt, ct = torch.from_numpy(z).double().permute(0, 2, 3, 1).reshape(-1, D), torch.from_numpy(cb).double()
             d2 = torch.cdist(zt, ct).pow(2)
             fin = torch.isfinite(d2).all(1)
-            top = torch.topk(d2[fin], 2, dim=1, largest=False).values
-            near = int(((top[:, 1] - top[:, 0]) <= 1e-6 * top[:, 1]).sum()) + int((~fin).sum())
+            top, which = torch.topk(d2[fin], 2, dim=1, largest=False)
+            tied = (top[:, 1] - top[:, 0]) <= 1e-6 * top[:, 1]
+            near = int(tied.sum()) + int((~fin).sum())
             assert near >= n, near                            # the construction did produce near-ties
+            if filt == DM_VQ_BF16 and D == 16 and 64 < K <= 4096:
+                # vq_cells_kernel (csrc/vq_cells.h): two tied codes inside ONE cell of 8 consecutive codes are settled by the
+                # cell's own exact evaluation, without the re-check path (and without its counter)
+                near -= int((tied & (which[:, 0] // 8 == which[:, 1] // 8)).sum())
             assert nre >= near, (nre, near, P)
 
 
