@@ -69,9 +69,9 @@ def pmc_traffic(kernel_key, batch):
     """HBM bytes per launch of the roofline kernel, from the separate `rocprofv3 --pmc` passes summarised in
     profiles/r0N_pmc_traffic.json (tools/pmc_traffic.py writes it; bench.py cannot run under the profiler
     itself).  None when no measurement for this kernel and batch has been committed."""
-    stem = {"dec_tail_train": "dec_tail_backward_kernel", "conv4x4s2_e1": "conv4x4s2_kernel"}.get(
+    stem = {"dec_tail_train": "dec_tail_backward_kernel", "conv4x4s2_e1": "conv4x4s2_kernel", "vq_cells_k4096": "vq_cells_kernel"}.get(
         kernel_key, kernel_key.split("_k4096")[0].replace("vq_forward_mfma", "vq_forward_mfma_kernel"))
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest measurement that has this kernel
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(kernel_key)
@@ -83,7 +83,7 @@ def pmc_traffic(kernel_key, batch):
     return None
 
 
-PROFILE_STATS = ("r05_c3_b2048_kernel_stats.csv", "r04_c3_b2048_kernel_stats.csv")
+PROFILE_STATS = ("r06_c3_b2048_kernel_stats.csv", "r05_c3_b2048_kernel_stats.csv", "r04_c3_b2048_kernel_stats.csv")
 
 
 def profile_avg_us(kernel_stem):
@@ -127,8 +127,8 @@ def roofline_wide_conv(B):
 
 def roofline_vq_large_codebook(model, x):
     """c5 (BASELINE.json configs[4]: "LDS-tiled codebook distance kernel vs roofline"): the K = 4096 distance + argmin
-    kernel (vq_forward_mfma_kernel<16, false, ...>: the codebook walks through LDS in 32 KB pieces, MFMA filter + exact
-    re-check) on the model's own latents, alone, as T(21 launches) - T(1 launch) with events on the launch stream.  Compute
+    kernel (round 6: vq_cells_kernel, csrc/vq_cells.h -- matrix filter on the bf16 pipe + exact evaluation of the best cell /
+    exact re-check; DM_VQ_CELLS=0: the round-5 kernel that walks the codebook through LDS) on the model's own latents, alone, as T(21 launches) - T(1 launch) with events on the launch stream.  Compute
     bound: achieved = 2*K*D*P FLOP of the filter product / average launch, against the f32 MFMA peak."""
     from dynamorph_amd import engine as E
     from dynamorph_amd import ops
@@ -150,16 +150,28 @@ def roofline_vq_large_codebook(model, x):
     # the peak of the pipe the kernel runs on; the executed rate is reported beside it, not as `achieved`.
     bf16 = D % 16 == 0 and os.environ.get("DM_VQ_FILTER", "")[:1] != "f"
     peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
-    executed = useful * (4.0 if bf16 else 1.0)
-    return {"kernel": f"vq_forward_mfma_kernel<{D}, false, ..., {'bf16-split' if bf16 else 'f32'} filter> (K = {K} codes through LDS pieces; "
-                      "distance + first-min argmin + gather + straight-through value + squared error)", "bound": "mfma",
+    # which kernel dm_vq_forward takes (csrc/vq.hip, vq_forward_launch): 64 < K <= 4096 at embedding_dim 16 on grids that are a
+    # multiple of 128 positions run vq_cells_kernel (csrc/vq_cells.h): v_mfma_f32_32x32x16_bf16, THREE products of the split
+    cells = bf16 and D == 16 and 64 < K <= 4096 and (z.shape[2] * z.shape[3]) % 128 == 0 and os.environ.get("DM_VQ_CELLS", "")[:1] != "0"
+    products = (4 if os.environ.get("DM_VQ_CELLS_PROD", "")[:1] == "4" else 3) if cells else (4 if bf16 else 1)
+    executed = useful * products
+    if cells:
+        kname = (f"vq_cells_kernel<{products}> (K = {K} codes straight from L2 into a register ring, {products} products of the bf16 split on "
+                 "v_mfma_f32_32x32x16_bf16, cell minima + exact evaluation of the best cell; distance + first-min argmin + gather + "
+                 "straight-through value + squared error)")
+        pipe = "bf16 matrix (v_mfma_f32_32x32x16_bf16)"
+    else:
+        kname = (f"vq_forward_mfma_kernel<{D}, false, ..., {'bf16-split' if bf16 else 'f32'} filter> (K = {K} codes through LDS pieces; "
+                 "distance + first-min argmin + gather + straight-through value + squared error)")
+        pipe = "bf16 matrix (v_mfma_f32_16x16x32_bf16)" if bf16 else "f32 matrix (v_mfma_f32_16x16x4_f32)"
+    return {"kernel": kname, "bound": "mfma",
             "achieved": round(useful, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(useful / peak, 4),
-            "pipe": "bf16 matrix (v_mfma_f32_16x16x32_bf16)" if bf16 else "f32 matrix (v_mfma_f32_16x16x4_f32)",
-            "traffic": pmc_traffic("vq_forward_mfma_k4096", x.shape[0]), "avg_launch_ms": round(ms, 5),
+            "pipe": pipe,
+            "traffic": pmc_traffic("vq_cells_k4096" if cells else "vq_forward_mfma_k4096", x.shape[0]), "avg_launch_ms": round(ms, 5),
             "algorithmic_flops_per_launch": flops,
             "algorithmic_vs_f32_mfma_peak": round(useful / MFMA_F32_PEAK_TFLOPS, 4),
             "executed_tflops": round(executed, 2), "executed_frac_of_pipe_peak": round(executed / peak, 4),
-            "executed_flops_per_launch": flops * (4.0 if bf16 else 1.0),
+            "executed_flops_per_launch": flops * products,
             "algorithmic_bytes_per_launch": P * (2 * D * 4 + 8),
             "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()), "positions": P}
 
@@ -499,32 +511,6 @@ def c5_record(dev, steps=8, warmup=3, B=1024):
     return rec
 
 
-def split_bf16_record(x, B, args, steps=100, warmup=10):
-    """The same C3 step with the OPT-IN gradient arithmetic (include/dynamorph_hip.h, dm_backward_precision(1): fp32
-    operands of the backward matrix products as bf16 head + remainder pairs on the bf16 matrix instruction, ~2^-17 relative
-    per product; forward pass, codes and losses unchanged).  A sub-record: `value` above is the exact-fp32 default."""
-    from dynamorph_amd import VQ_VAE, ops
-    from dynamorph_amd.train import FusedTrainer
-    prev = ops.backward_precision("split-bf16")
-    try:
-        torch.manual_seed(0)
-        tr = FusedTrainer(VQ_VAE().to(x.device), lr=1e-4, use_graph=not args.no_graph)
-        for _ in range(warmup):
-            out = tr.step(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out = tr.step(x)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    finally:
-        ops.backward_precision(prev)
-    return {"value": round(B * steps / dt, 1), "unit": "patches/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
-            "backward_products": "split-bf16", "total_loss_after": round(float(out[2]), 6),
-            "note": "opt-in (DM_BACKWARD_PRECISION=split): gradients within ~1e-5 of their products' magnitude of the fp32 "
-                    "chain; not the headline value"}
-
-
 def train_loop_record(dev, resident_ms_per_step, n=32768, B=2048, epochs=3, feed="auto", transform=True, masks=False,
                       relation=False, pinned=False):
     """The product's own training entry point, dynamorph_amd.train.train() (run_training.py:455-551), end to end on a
@@ -806,11 +792,10 @@ def main():
         roof = roofline_vq_large_codebook(model, x)
     else:
         roof = roofline_dominant_kernel(model, x, args.workload)
-    targets = c2 = split = loop = c5 = None
+    targets = c2 = loop = c5 = None
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_targets:
         targets = north_star_targets(model, x)
         c2 = c2_record(model)
-        split = split_bf16_record(x, B, args)
         loop = train_loop_record(dev, 1e3 * elapsed / args.steps, B=B)
         # the same entry point as run_training.py's main() drives it: cell masks and the relation matrix (time-matching term) on
         loop["with_masks_and_relation_matrix"] = {
@@ -849,7 +834,6 @@ def main():
         if targets is not None:
             line["targets"] = targets
             line["c2"] = c2
-            line["split_bf16_backward"] = split
             line["train_loop"] = loop
             line["c5"] = c5
         if losses is not None:

@@ -1780,7 +1780,7 @@ void launch_conv4(const ConvArgs &a)
                                a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
                                a.per_tile);                                                                           \
         else if (SIDE_ != SIDE_NONE && dm_backward_split_bf16())        /* a data gradient: split-bf16 operands */ \
-            hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS, false, SIDE_ != SIDE_NONE>),             \
+            hipLaunchKernelGGL((conv4x4s2_kernel<CIN, 1, TH, TW, SIDE_, WPS, false, DM_BUILD_SPLIT_BF16 && SIDE_ != SIDE_NONE>),             \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
                                a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile),        \
                                a.per_tile);                                                                           \
@@ -1824,7 +1824,7 @@ void launch_conv3(const ConvArgs &a)
         constexpr bool GRAD = (TWO_ || SIDE_ != SIDE_NONE) && ((CIN / 4) * TAPS) % 4 == 0;   /* a data gradient */      \
         constexpr bool FWDK = ((CIN / 4) * TAPS) % 4 == 0;                                                        \
         if ((GRAD && dm_backward_split_bf16()) || DM_FWD_SPLIT(!GRAD && FWDK))                                    \
-            hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS, GRAD || (MEASURE_BF && FWDK)>),           \
+            hipLaunchKernelGGL((conv3x3_kernel<CIN, NT, NPASS, TAPS, PIX, TH, TW, TWO_, SIDE_, WPS, (DM_BUILD_SPLIT_BF16 && GRAD) || (MEASURE_BF && FWDK)>),           \
                                dim3(conv_grid(ntiles, WPS, a.per_tile, NPASS)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv, \
                                a.out, a.ep, a.Cphys, a.NOUT, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile), a.per_tile); \
         else                                                                                                      \
@@ -1855,7 +1855,7 @@ void launch_convT_phase(const ConvArgs &a)
         constexpr int WPS = clampi(conv_wps(LDS, KSW, F4, TWO_, 2, COUT == 16 ? 2 : 1, SIDE_), 1, 2);             \
         constexpr bool GRAD = TWO_ || SIDE_ != SIDE_NONE;                  /* a data gradient */                     \
         if ((GRAD && dm_backward_split_bf16()) || DM_FWD_SPLIT(!GRAD))                                            \
-            hipLaunchKernelGGL((convT_phase_kernel<CIN, COUT, TH, TW, TWO_, SIDE_, WPS, GRAD || MEASURE_BF>),         \
+            hipLaunchKernelGGL((convT_phase_kernel<CIN, COUT, TH, TW, TWO_, SIDE_, WPS, (DM_BUILD_SPLIT_BF16 && GRAD) || MEASURE_BF>),         \
                                dim3(conv_grid(ntiles, WPS, a.per_tile)), dim3(DM_BLOCK), 0, a.stream, a.in, a.wv,     \
                                a.out, a.ep, a.Cphys, a.H, a.W, ntiles, conv_slabs(ntiles, a.per_tile));               \
         else                                                                                                      \
@@ -2081,13 +2081,13 @@ static int fused_bwd_block()
     return v;
 }
 
-// Arithmetic of the BACKWARD matrix products (data and weight gradients): 0 = the f32-input instruction, bit for bit the
-// fp32 multiply-add chain (the default: every number the library produces by default is plain fp32 arithmetic);
-// 1 = split-bf16 operands (tile.h: ~2^-17 relative per product, a quarter of the matrix time) -- opt-in.
-// Process-wide; DM_BACKWARD_PRECISION=split in the environment starts with 1; dm_backward_precision(mode >= 0) sets it.
+// Arithmetic of the BACKWARD matrix products (data and weight gradients): the f32-input instruction, bit for bit the fp32
+// multiply-add chain -- every number the library produces is plain fp32 arithmetic.  The split-bf16 alternative of rounds
+// 4-5 is retired (dm_common.h, DM_BUILD_SPLIT_BF16): asking for it is an error unless a measurement build instantiated it.
 static int g_backward_split = -1;
 bool dm_backward_split_bf16()
 {
+#if DM_BUILD_SPLIT_BF16
     if (g_backward_split < 0) {
         const char *e = getenv("DM_BACKWARD_PRECISION");
         g_backward_split = (e && e[0] == 's') ? 1 : 0;
@@ -2097,11 +2097,20 @@ bool dm_backward_split_bf16()
                             "(~2^-17 relative per product, not the fp32 chain); forward pass and codes unchanged\n", e);
     }
     return g_backward_split != 0;
+#else
+    return false;
+#endif
 }
 extern "C" int dm_backward_precision(int mode)
 {
     const int cur = dm_backward_split_bf16() ? 1 : 0;
+#if DM_BUILD_SPLIT_BF16
     if (mode == 0 || mode == 1) g_backward_split = mode;
+#else
+    (void)g_backward_split;
+    DM_REQUIRE(mode != 1, "dm_backward_precision: the split-bf16 gradient kernels are not built (retired: slower than the "
+                          "exact fp32 path on these layer widths; -DDM_BUILD_SPLIT_BF16=1 builds them for measurements)");
+#endif
     return cur;
 }
 
@@ -2149,13 +2158,13 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 #define DM_SPLIT_ATTR(BF_, ZF_)                                                                                       \
         if (e == hipSuccess)                                                                                         \
-            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, BF_, ZF_>,                       \
+            e = hipFuncSetAttribute((const void *)bwd_s2_split_kernel<16, 8, 8, 32, DM_BUILD_SPLIT_BF16 && BF_, ZF_>,                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
         DM_SPLIT_ATTR(false, false) DM_SPLIT_ATTR(true, false) DM_SPLIT_ATTR(false, true) DM_SPLIT_ATTR(true, true)
 #undef DM_SPLIT_ATTR
 #define DM_ROLES3_ATTR(BF_, ZF_)                                                                                      \
         if (e == hipSuccess)                                                                                         \
-            e = hipFuncSetAttribute((const void *)bwd_s2_roles3_kernel<16, 8, 8, 32, BF_, ZF_, 1>,                   \
+            e = hipFuncSetAttribute((const void *)bwd_s2_roles3_kernel<16, 8, 8, 32, DM_BUILD_SPLIT_BF16 && BF_, ZF_, 1>,                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SPLIT_LDS_BYTES);
         DM_ROLES3_ATTR(false, false) DM_ROLES3_ATTR(true, false) DM_ROLES3_ATTR(false, true) DM_ROLES3_ATTR(true, true)
 #undef DM_ROLES3_ATTR
@@ -2172,14 +2181,14 @@ extern "C" int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *tin,
     static const bool zf_off = [] { const char *e = getenv("DM_FUSED_BWD_ZF"); return e && e[0] == '0'; }();
     const bool zf = W == 32 && !zf_off;
 #define DM_SPLIT_LAUNCH(BF_, ZF_)                                                                                                  \
-        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, BF_, ZF_>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
+        hipLaunchKernelGGL((bwd_s2_split_kernel<16, 8, 8, 32, DM_BUILD_SPLIT_BF16 && BF_, ZF_>), dim3(grid), dim3(512), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
                            to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg())
     // three roles (768 threads) or two (512): DM_FUSED_BWD_ROLES=2 keeps the two-role form for A/B runs
     static const int roles = [] { const char *e = getenv("DM_FUSED_BWD_ROLES"); return e ? atoi(e) : 3; }();
     const bool roles3 = roles >= 3;
 #define DM_ROLES3_LAUNCH(BF_, ZF_)                                                                                                 \
         /* (a second group of data-gradient waves, NDG = 2 / 1024 threads, measured slower: 240.6 against 227.4 us) */                 \
-        { hipLaunchKernelGGL((bwd_s2_roles3_kernel<16, 8, 8, 32, BF_, ZF_, 1>), dim3(grid), dim3(768), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
+        { hipLaunchKernelGGL((bwd_s2_roles3_kernel<16, 8, 8, 32, DM_BUILD_SPLIT_BF16 && BF_, ZF_, 1>), dim3(grid), dim3(768), G::SPLIT_LDS_BYTES, (hipStream_t)stream, \
                                to_dev(dy), to_dev(tin), to_dev(w), dx, to_dev(ep), w_slabs, H, W, ntiles, fused_bwd_dbg()); }
     // 64-column grids (enc.4 of 256-pixel patches): tiles of 4 rows x 64 columns span the row, so the zero-free mapping applies
     // (the same number of tiles, hence of slabs, as 8 x 32)

@@ -6,6 +6,15 @@
 #include <stdarg.h>
 #include "../../include/dynamorph_hip.h"
 
+// The opt-in split-bf16 operands of the gradient kernels (rounds 4-5: fp32 values as bf16 head + remainder pairs on the bf16
+// matrix instruction) are no longer built: since the fp32 kernels were restructured the narrow layers (4-32 channels) are
+// bound by their vector instructions, and the split -- 12 more of those per tile -- ran 2.7 % SLOWER than the exact fp32
+// step (BENCH_r05: 1.941 against 1.8905 ms).  The templates keep their BF parameter; -DDM_BUILD_SPLIT_BF16=1 instantiates
+// the split forms again (measurements only).
+#ifndef DM_BUILD_SPLIT_BF16
+#define DM_BUILD_SPLIT_BF16 0
+#endif
+
 #define DM_WAVE 64
 #define DM_BLOCK 256          // 4 waves: one per SIMD of a CU
 

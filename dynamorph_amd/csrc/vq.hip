@@ -369,6 +369,59 @@ __global__ __launch_bounds__(VQ_BLOCK, (D <= 16 ? 4 : (D <= 64 ? 2 : 1))) void v
     }
 }
 
+// Any embedding_dim (the reference's VectorQuantizer takes any width, vq_vae.py:35-50; num_hiddens = 24 / 48 / 96 ...): the
+// widths without a register-resident instantiation.  One wave per workgroup, a position per lane, the lane's z in LDS as
+// s_z[d][lane] (conflict-free; D x 256 bytes, dynamic), the code rows through wave-uniform (scalar) loads.  The reference's
+// arithmetic and order exactly as vq_forward_kernel: (z - e), its square, sums of 16 consecutive d, block sums in order,
+// first minimum with the argmax(-dist) NaN rule.  A coverage path: 3 K D vector operations per position, no matrix cores.
+__global__ __launch_bounds__(64) void vq_forward_any_kernel(
+    const float *__restrict__ z, const float *__restrict__ cb, long long *__restrict__ idx, float *__restrict__ out,
+    double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int K, int D, int HW, long long P)
+{
+    extern __shared__ float s_zany[];                       // [D][64]
+    int *__restrict__ hist = hrep + (long long)(blockIdx.x % (unsigned)R) * K;
+    const int lane = threadIdx.x;
+    double sse = 0.0;
+    for (long long p0 = (long long)blockIdx.x * 64; p0 < P; p0 += (long long)gridDim.x * 64) {
+        const long long pos = p0 + lane;
+        const bool active = pos < P;
+        const long long b = active ? pos / HW : 0, pp = active ? pos - b * HW : 0;
+        const long long base = b * (long long)D * HW + pp;
+        for (int d = 0; d < D; ++d) s_zany[d * 64 + lane] = active ? z[base + (long long)d * HW] : 0.f;
+        float bestd = __builtin_inff();
+        int bi = 0;
+        for (int k = 0; k < K; ++k) {
+            const float *__restrict__ e = cb + (long long)k * D;
+            float total = 0.f;
+            for (int d0 = 0; d0 < D; d0 += 16) {
+                float acc = 0.f;
+                const int d1 = d0 + 16 < D ? d0 + 16 : D;
+                for (int d = d0; d < d1; ++d) {
+                    const float diff = s_zany[d * 64 + lane] - e[d];
+                    const float sq = diff * diff;
+                    acc = (d == d0) ? sq : acc + sq;
+                }
+                total = (d0 == 0) ? acc : total + acc;
+            }
+            const bool bt = vq_better(total, bestd);
+            bestd = bt ? total : bestd; bi = bt ? k : bi;
+        }
+        if (active) {
+            if (idx) idx[pos] = (long long)bi;
+            const float *__restrict__ qv = cb + (long long)bi * D;
+            for (int d = 0; d < D; ++d) {
+                const float zv = s_zany[d * 64 + lane];
+                const float diff = qv[d] - zv;
+                if (out) out[base + (long long)d * HW] = zv + diff;     // z + (q - z), vq_vae.py:71
+                sse += (double)(diff * diff);
+            }
+            atomicAdd(&hist[bi], 1);
+        }
+    }
+    const double tot = wave_sum(sse);
+    if (lane == 0) sse_slabs[blockIdx.x] = tot;
+}
+
 // Sum of column k over the counter rows (replicas or per-workgroup slabs; rows and stride from the workspace header).
 __device__ __forceinline__ int vq_count_column(const int *__restrict__ hrep, int R, int stride, int k)
 {
@@ -1479,6 +1532,45 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
     }
 }
 
+// Any embedding_dim: vq_backward_kernel with the width at run time (the same LDS window of code gradients, the same
+// arithmetic per element; a coverage path for widths without an instantiation).
+__global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_any_kernel(
+    const float *__restrict__ z, const float *__restrict__ cb, const long long *__restrict__ idx,
+    const float *__restrict__ g_out, const float *__restrict__ g_loss_dev, float cc,
+    float *__restrict__ dz, float *__restrict__ dw, float *__restrict__ dw_slabs, int K, int D, int HW, long long P, int Kc)
+{
+    extern __shared__ float s_dw[];    // [Kc][D]
+    const long long k_lo = (long long)blockIdx.y * Kc;
+    const int kn = K - k_lo < Kc ? (int)(K - k_lo) : Kc;
+    for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
+    __syncthreads();
+    const float g_loss = g_loss_dev ? g_loss_dev[0] : 1.f;
+    const double N = (double)P * (double)D;
+    const float sz = (float)(2.0 * (double)cc / N) * g_loss;
+    const float sw = (float)(2.0 / N) * g_loss;
+    for (long long pos = (long long)blockIdx.x * VQ_BWD_BLOCK + threadIdx.x; pos < P; pos += (long long)gridDim.x * VQ_BWD_BLOCK) {
+        const long long b = pos / HW, p = pos - b * HW;
+        const long long base = b * (long long)D * HW + p;
+        const long long k = idx[pos];
+        if (k < k_lo || k >= k_lo + kn) continue;
+        const float *__restrict__ q = cb + k * D;
+        const int kl = (int)(k - k_lo);
+        for (int d = 0; d < D; ++d) {
+            const long long o = base + (long long)d * HW;
+            const float zv = z[o], qv = q[d], gv = g_out ? g_out[o] : 0.f;
+            if (dz) dz[o] = gv + sz * (zv - qv);
+            atomicAdd(&s_dw[kl * D + d], sw * (qv - zv));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) {
+        const float v = s_dw[i];
+        if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + k_lo * D + i] = v;
+        else if (v != 0.f) atomicAdd(&dw[k_lo * D + i], v);
+    }
+}
+
+
 // ---- codebooks of at most 64 codes (every configuration of the reference): the codebook gradient as a one-hot product
 // on the matrix cores.  dW[k][d] = sw * sum_p [idx[p] == k] (e_k[d] - z[p][d]) is (codes x positions) . (positions x D):
 // v_mfma_f32_16x16x4_f32 with A[i = code][kk = position] = 1.0 or 0.0 built from the indices and
@@ -1661,7 +1753,10 @@ __global__ __launch_bounds__(VQ_BWD2_BLOCK, WGS) void vq_backward_mfma_kernel(
     }
 }
 
-bool vq_dim_supported(int D) { return D == 8 || D == 16 || D == 32 || D == 64 || D == 128; }
+// widths with register-resident instantiations of the exact kernels; every other width 1 .. 512 takes vq_forward_any_kernel /
+// vq_backward_any_kernel (run-time width, the same arithmetic)
+bool vq_dim_built(int D) { return D == 8 || D == 16 || D == 32 || D == 64 || D == 128; }
+bool vq_dim_supported(int D) { return D >= 1 && D <= 512; }
 
 }  // namespace
 
@@ -1737,7 +1832,7 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
 {
     DM_REQUIRE(z && codebook && sse_slabs, "dm_vq_forward: NULL pointer");     // hist == NULL: the counters stay in their replicas
     DM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0, "dm_vq_forward: bad shape B=%d K=%d H=%d W=%d", B, K, H, W);
-    DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d not built (8/16/32/64/128)", D);
+    DM_REQUIRE(vq_dim_supported(D), "dm_vq_forward: embedding_dim %d outside 1 .. 512", D);
     DM_REQUIRE(workspace && workspace_bytes >= dm_vq_workspace_bytes(K, D), "dm_vq_forward: workspace too small");
     DM_REQUIRE(variant >= DM_VQ_AUTO && variant <= DM_VQ_BF16, "dm_vq_forward: bad variant %d", variant);
     DM_REQUIRE(variant != DM_VQ_BF16 || D % 16 == 0, "dm_vq_forward: the bf16-split filter needs embedding_dim 16, 32 or 64");
@@ -1827,6 +1922,23 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
         }
 #undef DM_VQ2
 #undef DM_VQ2K
+        if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, hrep, (int *)ws, K, (int *)hist);
+        return dm_launch_status("dm_vq_forward");
+    }
+    if (!vq_dim_built(D)) {
+        long long g_ = (P + 63) / 64;
+        if (g_ > nslabs) g_ = nslabs;                            // one squared-error slab per workgroup (the rest were zeroed)
+        if (g_ > 4096) g_ = 4096;
+        const size_t lds = (size_t)D * 64 * sizeof(float);
+        static DmPerDeviceOnce any_attr;
+        if (lds > 48 * 1024 && any_attr.need()) {
+            const hipError_t ea = hipFuncSetAttribute((const void *)vq_forward_any_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 4);
+            if (ea != hipSuccess) { dm_set_error("dm_vq_forward: cannot reserve LDS: %s", hipGetErrorString(ea)); return (int)ea; }
+            any_attr.mark();
+        }
+        for (int rep = 0; rep < repeats; ++rep)
+            hipLaunchKernelGGL(vq_forward_any_kernel, dim3((unsigned)g_), dim3(64), lds, s, z, codebook, (long long *)idx, out,
+                               sse_slabs, hrep, L.R, K, D, H * W, P);
         if (hist) hipLaunchKernelGGL(vq_hist_reduce_kernel, dim3((K + 63) / 64), dim3(1024), 0, s, hrep, (int *)ws, K, (int *)hist);
         return dm_launch_status("dm_vq_forward");
     }
@@ -1943,7 +2055,7 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
                        int B, int D, int K, int H, int W, void *stream)
 {
     DM_REQUIRE(z && codebook && idx && (dw || dw_slabs), "%s: NULL pointer", who);
-    DM_REQUIRE(vq_dim_supported(D), "%s: embedding_dim %d not built (8/16/32/64/128)", who, D);
+    DM_REQUIRE(vq_dim_supported(D), "%s: embedding_dim %d outside 1 .. 512", who, D);
     const long long P = (long long)B * H * W;
     int Kc = VQ_BWD_LDS / (D * (int)sizeof(float));
     if (Kc > K) Kc = K;
@@ -1976,6 +2088,18 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
     }                                                                                                          \
     hipLaunchKernelGGL(vq_backward_kernel<DD>, g3, dim3(VQ_BWD_BLOCK), lds, s, z, codebook,                    \
                        (const long long *)idx, g_out, g_loss_dev, commitment_cost, dz, dw, dw_slabs, K, H * W, P, Kc)
+    if (!vq_dim_built(D)) {
+        if (lds > 48 * 1024) {
+            const hipError_t ea = hipFuncSetAttribute((const void *)vq_backward_any_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) {
+                dm_set_error("%s: cannot reserve %zu bytes of LDS: %s", who, (size_t)lds, hipGetErrorString(ea));
+                return (int)ea;
+            }
+        }
+        hipLaunchKernelGGL(vq_backward_any_kernel, g3, dim3(VQ_BWD_BLOCK), lds, s, z, codebook, (const long long *)idx, g_out,
+                           g_loss_dev, commitment_cost, dz, dw, dw_slabs, K, D, H * W, P, Kc);
+        return dm_launch_status(who);
+    }
     switch (D) {
     case 8: DM_VQ_BWD(8); break;
     case 16: DM_VQ_BWD(16); break;

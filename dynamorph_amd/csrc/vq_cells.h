@@ -30,13 +30,15 @@
 
 // (constants, the row <-> code permutation and the operand preparation: vq.hip, above vq_prep_kernel)
 
-#ifdef DM_MEASURE
-// measurement build only (DM_VQ_DBG bits): 4 no exact re-checks, 8 no exact evaluation of the best cell, 16 no group ends,
-// 32 no cell minima.  Results are then wrong; the time is what is read.
-#define VQC_DBG(bit) (vq_dbg_dev & (bit))
-#else
-#define VQC_DBG(bit) false
+// measurement builds only (tools/exp/vq_cells_parts.sh; results are wrong, the time is what is read): compile-time switches
+// -DVQC_OFF=bits: 4 no exact re-checks, 8 no exact evaluation of the best cell, 16 no group ends, 32 no cell minima
+#ifndef VQC_OFF
+#define VQC_OFF 0
 #endif
+#ifndef VQC_ZPREFETCH
+#define VQC_ZPREFETCH 0          // 1: the next pass's latents are requested before this pass's tail (measured: no gain, more spills)
+#endif
+#define VQC_DBG(bit) ((VQC_OFF & (bit)) != 0)
 
 template <int NPROD>
 __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
@@ -58,7 +60,11 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
     constexpr float ETA = 2.f + 16.f + 256.f + (NPROD == 3 ? 256.f : 0.f) + 50.f * NPROD;
     constexpr float TOL_A = 2.5f * ETA * U, TOL_D = 2.5f * (D / 16 + 18) * U;
     __shared__ __attribute__((aligned(16))) float s_nrm[VQC_MAX_K];
-    __shared__ unsigned s_pm[4][VQC_MAX_K / VQC_GROUP][64];        // per wave and group: the owned positions' group minima (2 x bf16)
+    // per wave and group: the group minima of the lane's two owned positions, the top 24 bits of each (rounded toward -inf: 16
+    // significand bits, 1.5e-5 relative -- a sixth of the tolerance; bf16 minima, 4e-3, sent a flagged position through 5-15
+    // groups of 128 codes instead of the one or two that really hold a candidate) as 32 + 16 bits
+    __shared__ unsigned s_pm[4][VQC_MAX_K / VQC_GROUP][64];
+    __shared__ unsigned short s_pmh[4][VQC_MAX_K / VQC_GROUP][64];
     __shared__ float s_em[4];
     __shared__ double s_red[4];
     const int lane = threadIdx.x & 63, kh = lane >> 5, n = lane & 31;
@@ -93,15 +99,23 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
 #pragma unroll
     for (int c = 0; c < VQC_GCH; ++c) { ah[c] = aP[(c * 2) * 64]; al[c] = aP[(c * 2 + 1) * 64]; }
 
+    // the lane's 8 dimensions of its 4 positions 4 n + t of a pass; the NEXT pass's are requested before this pass's tail
+    f32x4 zq[8];
+    auto load_z = [&](unsigned pass) {
+        const unsigned pc = pass < npass ? pass : npass - 1;                 // (past the end: a harmless reload)
+        const unsigned b = pc / pps, pw = pc - b * pps;
+        const float *__restrict__ zb = z + (long long)b * D * HW + (long long)pw * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zq[i] = *reinterpret_cast<const f32x4 *>(zb + (long long)(8 * kh + i) * HW + 4 * n);
+    };
+    if (VQC_ZPREFETCH) load_z(blockIdx.x * 4u + (unsigned)wave);
+
     for (unsigned pass = blockIdx.x * 4u + (unsigned)wave; pass < npass; pass += gridDim.x * 4u) {
         const unsigned b = pass / pps, pw = pass - b * pps;
-        const float *__restrict__ zb = z + (long long)b * D * HW + (long long)pw * 128;
         // ---- B operands: (z_hi, z_lo) of the lane's 8 dimensions for its 4 positions 4 n + t
         vqc_u32x4 Zh[NT], Zl[NT];
         {
-            f32x4 zq[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) zq[i] = *reinterpret_cast<const f32x4 *>(zb + (long long)(8 * kh + i) * HW + 4 * n);
+            if (!VQC_ZPREFETCH) load_z(pass);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 unsigned hp[4], lp[4];
@@ -170,19 +184,18 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                     m1[t] = M1[u];
                 }
             }
-            // both halves' minima of the two owned positions (slot s = tile 2 kh + s), bf16 rounded toward -inf, NaN kept
-            unsigned packed = 0;
+            // both halves' minima of the two owned positions (slot s = tile 2 kh + s), top 24 bits, toward -inf, NaN kept
+            unsigned t24[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float x = gm[s], y = gm[s + 2];
                 vq2_swap<32>(x, y);
                 const float pmin = vq2_min(x, y);
                 const unsigned pb = __builtin_bit_cast(unsigned, pmin);
-                unsigned ph = pb >> 16;
-                ph += (pmin < 0.f && (pb & 0xffffu)) ? 1u : 0u;
-                ph = pmin != pmin ? 0xffffu : ph;
-                packed |= ph << (16 * s);
+                t24[s] = (pb >> 8) + ((pmin < 0.f && (pb & 0xffu)) ? 1u : 0u);
             }
+            const unsigned packed = t24[0] | (t24[1] << 24);
+            s_pmh[wave][g][lane] = (unsigned short)(t24[1] >> 8);
             s_pm[wave][g][lane] = packed;
         };
 
@@ -241,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
         cells(NT - 1, 0, 8, VQC_GCH == 1);
         if (!VQC_DBG(16)) group_end(NG - 1);
 
+        if (VQC_ZPREFETCH) load_z(pass + gridDim.x * 4u);
         // ---- the tail: everything of a position is in its owner's registers ----
         const long long own = (long long)pw * 128 + 4 * n + 2 * kh;                 // first owned position inside the sample
         f32x2 zf[D];
@@ -278,10 +292,10 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
             int bk = 0x7fffffff;
             if (VQC_DBG(8)) bk = min(base, K - 1);
 #pragma unroll
-            for (int c0 = 0; c0 < (VQC_DBG(8) ? 0 : 8); c0 += 2) {
-                float er[2][D];
+            for (int c0 = 0; c0 < (VQC_DBG(8) ? 0 : 8); c0 += 4) {
+                float er[4][D];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     const int k = min(base + c0 + u, K - 1);
 #pragma unroll
                     for (int q4 = 0; q4 < D / 4; ++q4) {
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     const int k = base + c0 + u;
                     const float dk = vq_exact_dist<D>(zv, er[u]);
                     const bool bt = k < K && ((bk == 0x7fffffff) | vq_better(dk, bd));
@@ -314,10 +328,17 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                 const float thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thrv[s]), fl));
                 float bd = __builtin_inff();
                 int bk = 0x7fffffff;
-                for (int g = 0; g < NG; ++g) {
-                    const unsigned pk = s_pm[wave][g][fl];
-                    const float pg = __builtin_bit_cast(float, (s ? pk >> 16 : pk & 0xffffu) << 16);
-                    if (pg > thr) continue;
+                // lane g looks at group g's minimum (one LDS read for all groups); the groups to visit are the set bits
+                unsigned gmask;
+                {
+                    const int gq = lane < NG ? lane : 0;
+                    const unsigned pk = s_pm[wave][gq][fl];
+                    const float pg = __builtin_bit_cast(float, (s ? (pk >> 24) | ((unsigned)s_pmh[wave][gq][fl] << 8) : pk & 0xffffffu) << 8);
+                    gmask = (unsigned)__ballot(lane < NG && !(pg > thr));
+                }
+                while (gmask) {
+                    const int g = __builtin_ctz(gmask);
+                    gmask &= gmask - 1;
                     float er[2][D];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {

@@ -515,7 +515,7 @@ void launch_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
                                Hs, Ws, ntiles);
         return;
     }
-    constexpr bool CAN_BF = (TW / 4) % 4 == 0;             // position steps of a row in quads
+    constexpr bool CAN_BF = DM_BUILD_SPLIT_BF16 && (TW / 4) % 4 == 0;             // position steps of a row in quads (retired: dm_common.h)
     if (CAN_BF && dm_backward_split_bf16()) {
         if (S.mode == DM_LOAD_AFFINE2)
             hipLaunchKernelGGL((wgrad_kernel<CS, CT, KK, TH, TW, true, CAN_BF>), dim3(grid), dim3(DM_BLOCK), 0, st, S, T, slabs,

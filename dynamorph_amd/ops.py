@@ -337,11 +337,13 @@ def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
 
 
 def backward_precision(mode=None):
-    """Arithmetic of the backward matrix products: "f32" (default: the exact fp32 chain) or "split-bf16" (opt-in: fp32
-    values as bf16 head + remainder pairs on the bf16 matrix instruction, ~2^-17 relative per product) --
-    include/dynamorph_hip.h, dm_backward_precision.  mode None: query.  Returns the previous setting."""
+    """Arithmetic of the backward matrix products: "f32", the exact fp32 chain -- the only one built (the split-bf16 opt-in
+    of earlier rounds is retired: include/dynamorph_hip.h, dm_backward_precision; asking for it raises).  mode None: query."""
     names = ("f32", "split-bf16")
+    if mode is not None and mode not in names:
+        raise ValueError(f"backward_precision: {mode!r} (one of {names})")
     prev = L.load().dm_backward_precision(-1 if mode is None else names.index(mode))
+    L.check(min(prev, 0), "dm_backward_precision")
     return names[prev]
 
 

@@ -52,9 +52,11 @@ class FusedTrainer:
         from .vq_vae import VQ_VAE, VQ_VAE_z32
         if not isinstance(model, (VQ_VAE, VQ_VAE_z32)):
             raise TypeError("FusedTrainer is built for VQ_VAE / VQ_VAE_z16 / VQ_VAE_z32; train other modules with a torch optimizer")
-        if getattr(model, "extra_loss", None) is not None:
-            raise TypeError("FusedTrainer: a model with extra_loss (vae.py:463-469) runs the caller's torch code every step; "
-                            "train it through autograd with a torch optimizer (train(..., fused=False) does)")
+        # (a VQ_VAE_z32 with extra_loss, vae.py:463-469: the caller's torch code runs on z_after between the forward and the
+        # backward half of the step, _step_with_extra_losses; it needs the labels: step(..., labels=...))
+        self._extra = getattr(model, "extra_loss", None) is not None
+        if self._extra and not hasattr(model, "alpha"):
+            raise AttributeError("FusedTrainer: extra_loss needs model.alpha (vae.py:467; pass alpha= to VQ_VAE_z32)")
         self.model = model
         self._z32 = isinstance(model, VQ_VAE_z32)
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -104,53 +106,134 @@ class FusedTrainer:
         val = torch.where(hinge, torch.clamp(val + model.margin, min=0), val)
         return val.mean(), wts * live / float(sim.numel())
 
-    def _forward_backward_z32(self, x, mask, tm):
-        """VQ_VAE_z32 (vae.py:430-470): two-conv stem + residual stack | VectorQuantizer | residual stack + BatchNorm tail,
-        the weighted-hinge time-matching term on z_after.  Same kernels as the autograd path (dynamorph_amd.vq_vae), called
-        in order on the flat gradient views: no autograd bookkeeping, ONE slab reduction for the whole backward pass, the
-        four scalars from one launch -- and a launch sequence a HIP graph can replay."""
+    def _z32_forward_part(self, x, mask, tm):
+        """VQ_VAE_z32 (vae.py:430-470), forward half of the step: two-conv stem + residual stack | VectorQuantizer | residual
+        stack + BatchNorm tail, the weighted-hinge time-matching term on z_after.  Same kernels as the autograd path
+        (dynamorph_amd.vq_vae), called in order: no autograd bookkeeping -- and a launch sequence a HIP graph can replay.
+        Returns the state the backward half reads (st.scalars: recon, commitment, total, perplexity[, time matching];
+        st.zq: z_after, what a caller-supplied extra loss acts on, vae.py:463-469)."""
+        import types
         m = self.model
         enc, dec = m.enc, m.dec
-        er, dr = enc[5]._handles(), dec[0]._handles()
-        cc = float(m.commitment_cost)
+        st = types.SimpleNamespace(er=enc[5]._handles(), dr=dec[0]._handles(), cc=float(m.commitment_cost))
         B, NIN, H, W = x.shape
-        h, scx = E.z32_stem_forward(enc[0], enc[1], enc[3], enc[4], x)
-        z, esaved = E.residual_forward(er, h)
-        zq, idx, vqs = E.vq_forward(m.vq.w.weight, z, cc, defer_scalars=True)
-        r, dsaved = E.residual_forward(dr, zq)
-        _, tcx = E.z32_tail_forward(dec[1], dec[2], dec[4], r, x, mask, m.channel_var)
+        h, st.scx = E.z32_stem_forward(enc[0], enc[1], enc[3], enc[4], x)
+        st.z, st.esaved = E.residual_forward(st.er, h)
+        st.zq, st.idx, vqs = E.vq_forward(m.vq.w.weight, st.z, st.cc, defer_scalars=True)
+        r, st.dsaved = E.residual_forward(st.dr, st.zq)
+        _, st.tcx = E.z32_tail_forward(dec[1], dec[2], dec[4], r, x, mask, m.channel_var)
         # the pairwise term acts on z_after (vae.py:441-455); its gradient reaches z through the straight-through value
-        tm_S = tm_fallback = None
-        fin = (vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, tcx.loss_slabs, B * NIN * H * W, 1.0, 1.0)
+        st.tm_S = st.tm_fallback = st.zf = None
+        st.wm = float(m.weight_matching)
+        fin = (vqs.slabs, vqs.ws, vqs.K, vqs.D, vqs.positions, vqs.cc, st.tcx.loss_slabs, B * NIN * H * W, 1.0, 1.0)
         if tm is not None:
-            zf = zq.reshape(B, -1)
-            wm = float(m.weight_matching)
+            st.zf = st.zq.reshape(B, -1)
             tmf = tm.to(torch.float32).contiguous()
-            if ops.time_matching_supported(zf.shape[0], zf.shape[1]):
-                tm_slabs, tm_S = ops.time_matching_forward(zf, tmf, *_tm_args(m, True), want_slabs=True)
-                scalars = ops.vq_loss_finalize_tm(*fin, tm_slabs, wm)        # the five scalars in one launch
+            if ops.time_matching_supported(st.zf.shape[0], st.zf.shape[1]):
+                tm_slabs, st.tm_S = ops.time_matching_forward(st.zf, tmf, *_tm_args(m, True), want_slabs=True)
+                st.scalars = ops.vq_loss_finalize_tm(*fin, tm_slabs, st.wm)        # the five scalars in one launch
             else:
-                tml, g_sim = self._time_matching(ops.pair_msd(zf), tmf, True)      # (VQ_VAE_z32: always the weighted-hinge form)
-                tm_fallback = ops.pair_msd_backward(zf, (g_sim * wm).contiguous()).reshape(zq.shape)
-                scalars = _with_matching(ops.vq_loss_finalize(*fin), tml, wm)
+                tml, g_sim = self._time_matching(ops.pair_msd(st.zf), tmf, True)      # (VQ_VAE_z32: always the weighted-hinge form)
+                st.tm_fallback = ops.pair_msd_backward(st.zf, (g_sim * st.wm).contiguous()).reshape(st.zq.shape)
+                st.scalars = _with_matching(ops.vq_loss_finalize(*fin), tml, st.wm)
         else:
-            scalars = ops.vq_loss_finalize(*fin)
+            st.scalars = ops.vq_loss_finalize(*fin)
+        return st
+
+    def _z32_backward_part(self, st, g_extra=None):
+        """Backward half: decoder tail, decoder residual stack, the time-matching and (g_extra: d(sum of alpha * extra
+        losses) / d z_after, from the caller's torch code) extra-loss gradients joining at z_after, the quantiser's
+        straight-through backward, encoder -- ONE slab reduction for every weight / bias / codebook gradient."""
+        m = self.model
+        enc, dec = m.enc, m.dec
         pending = []
-        g_r = E.z32_tail_backward(dec[1], dec[2], dec[4], tcx, self.w_recon, None, self.G, pending=pending,
+        g_r = E.z32_tail_backward(dec[1], dec[2], dec[4], st.tcx, self.w_recon, None, self.G, pending=pending,
                                   zero_fed_biases=False)
-        g_zq, _ = E.residual_backward(dr, dsaved, g_r, self.G, None, pending=pending, zero_fed_biases=False)
-        if tm_S is not None:
-            g_zq = ops.time_matching_backward(zf, tm_S, None, wm, add=g_zq).reshape(zq.shape)     # (summed in the kernel's store)
-        elif tm_fallback is not None:
-            g_zq = g_zq + tm_fallback
+        g_zq, _ = E.residual_backward(st.dr, st.dsaved, g_r, self.G, None, pending=pending, zero_fed_biases=False)
+        if st.tm_S is not None:
+            g_zq = ops.time_matching_backward(st.zf, st.tm_S, None, st.wm, add=g_zq).reshape(st.zq.shape)     # (summed in the kernel's store)
+        elif st.tm_fallback is not None:
+            g_zq = g_zq + st.tm_fallback
+        if g_extra is not None:
+            g_zq = g_zq + g_extra
         gcb = self.G(m.vq.w.weight)
-        dz, cb_slabs = ops.vq_backward_slabs(z, m.vq.w.weight.detach(), idx, g_zq, self.w_commit, cc)
+        dz, cb_slabs = ops.vq_backward_slabs(st.z, m.vq.w.weight.detach(), st.idx, g_zq, self.w_commit, st.cc)
         pending.append((cb_slabs, gcb))
-        g_h, stats = E.residual_backward(er, esaved, dz, self.G, scx.a2, pending=pending, zero_fed_biases=False)
-        E.z32_stem_backward(enc[0], enc[1], enc[3], enc[4], scx, g_h, self.G, stats=stats, pending=pending,
+        g_h, stats = E.residual_backward(st.er, st.esaved, dz, self.G, st.scx.a2, pending=pending, zero_fed_biases=False)
+        E.z32_stem_backward(enc[0], enc[1], enc[3], enc[4], st.scx, g_h, self.G, stats=stats, pending=pending,
                             zero_fed_biases=False)
         ops.reduce_slabs_multi(pending)                     # every weight / bias / codebook gradient of the step
-        return scalars
+        return st.scalars
+
+    def _forward_backward_z32(self, x, mask, tm):
+        return self._z32_backward_part(self._z32_forward_part(x, mask, tm))
+
+    def _extra_losses(self, zq, labels):
+        """The caller's extra losses (vae.py:463-469) on z_after, as torch code between the two halves of the step:
+        returns (sum of alpha * loss as a device scalar, its gradient w.r.t. z_after, {name: loss})."""
+        m = self.model
+        leaf = zq.detach().requires_grad_(True)
+        flat = leaf.reshape((leaf.shape[0], -1))
+        total, named = None, {}
+        with torch.enable_grad():
+            for name, fn in m.extra_loss.items():
+                loss, _frac_pos = fn(labels, flat)
+                named[name] = loss.detach()
+                total = loss * m.alpha if total is None else total + loss * m.alpha
+            total.backward()
+        g = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+        return total.detach(), g.contiguous(), named
+
+    def _step_with_extra_losses(self, x, mask, tm, labels):
+        """One forward + backward of a VQ_VAE_z32 with extra_loss: the two halves as captured HIP graphs (one pair per input
+        shape), the caller's torch code on z_after in between.  Returns the step's scalars with total_loss including the
+        extra terms; self.last_extra_losses = {name: device scalar}."""
+        if not self.use_graph:
+            st = self._z32_forward_part(x, mask, tm)
+            total, g, named = self._extra_losses(st.zq, labels)
+            scal = self._z32_backward_part(st, g)
+        else:
+            key = ("extra", tuple(x.shape), None if mask is None else tuple(mask.shape), None if tm is None else tuple(tm.shape))
+            ent = self._graphs.get(key)
+            if ent is None:
+                sx = x.clone()
+                smask = mask.clone() if mask is not None else None
+                stm = tm.clone().float() if tm is not None else None
+                bufs = list(self.model.buffers())
+                saved = [b.clone() for b in bufs]
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                              # warm-up (allocator, lazy init): really executes
+                    st = self._z32_forward_part(sx, smask, stm)
+                    self._z32_backward_part(st, torch.zeros_like(st.zq))
+                torch.cuda.current_stream().wait_stream(side)
+                for b, sv in zip(bufs, saved):
+                    b.copy_(sv)                                            # ... so the running statistics are put back
+                if self.world > 1:
+                    torch.cuda.synchronize(self.flat.device)
+                gF = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gF):
+                    st = self._z32_forward_part(sx, smask, stm)
+                gx = torch.zeros_like(st.zq)
+                gB = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gB, pool=gF.pool()):
+                    scal = self._z32_backward_part(st, gx)
+                ent = self._graphs[key] = (gF, gB, st, gx, scal, sx, smask, stm)
+            gF, gB, st, gx, scal, sx, smask, stm = ent
+            if x.data_ptr() != sx.data_ptr():
+                sx.copy_(x)
+            if mask is not None:
+                smask.copy_(mask)
+            if tm is not None:
+                stm.copy_(tm)
+            gF.replay()
+            total, g, named = self._extra_losses(st.zq, labels)
+            gx.copy_(g)
+            gB.replay()
+        self.last_extra_losses = named
+        out = scal.clone()
+        out[2] += total                                                    # total_loss += alpha * extra (vae.py:467)
+        return out
 
     def forward_backward(self, x, mask=None, time_matching_mat=None):
         """One forward + backward; returns the device tensor (recon, commitment, total, perplexity[, time matching])."""
@@ -226,7 +309,7 @@ class FusedTrainer:
             self._allreduce()
             self._adam()
 
-    def step(self, x, mask=None, time_matching_mat=None, grad_weight=1.0, timers=None):
+    def step(self, x, mask=None, time_matching_mat=None, grad_weight=1.0, timers=None, labels=None):
         """One optimisation step on a device batch; returns the device tensor of LOSS_KEYS values (+ the time-matching
         loss as a fifth entry when a matrix is given).  grad_weight: see _allreduce.
         timers: a list -> this step appends (events, host_times): four events on the launch stream and four
@@ -240,7 +323,9 @@ class FusedTrainer:
         with torch.cuda.device(self.flat.device):       # graph capture / replay and the streams are the model's device's
             mark = _Marks() if timers is not None else None
             if mark: mark()
-            if not self.use_graph:
+            if self._extra:
+                out = self._step_with_extra_losses(x, mask, time_matching_mat, labels)
+            elif not self.use_graph:
                 out = self.forward_backward(x, mask, time_matching_mat)
             else:
                 out = self._graph_step(x, mask, time_matching_mat)
@@ -487,12 +572,15 @@ def run_one_batch(model, batch, train_loss, model_kwargs=None, optimizer=None, t
     if transform is not None:
         batch = _augment(batch)
     if isinstance(optimizer, (FusedTrainer, GraphedTrainer)) and training:
-        kw = {"grad_weight": grad_weight} if isinstance(optimizer, FusedTrainer) else {}
+        # (train_with_loader hands the labels of the extra losses through model_kwargs, run_training.py:596-599)
+        kw = {"grad_weight": grad_weight, "labels": model_kwargs.get("labels")} if isinstance(optimizer, FusedTrainer) else {}
         vals = optimizer.step(batch, model_kwargs.get("batch_mask"), model_kwargs.get("time_matching_mat"), **kw)
         vals = vals.tolist()                                           # one device sync per step (reference: five)
         loss_dict = dict(zip(LOSS_KEYS, vals))
         loss_dict["time_matching_loss"] = vals[4] if len(vals) > 4 else 0.
         loss_dict = _in_model_order(model, loss_dict)
+        if getattr(optimizer, "_extra", False):                        # vae.py:469: one entry per extra loss, after total_loss
+            loss_dict.update({k: float(v) for k, v in optimizer.last_extra_losses.items()})
     else:
         _, loss_dict = model(batch, **model_kwargs)
         if training:

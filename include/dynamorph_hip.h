@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 125
+#define DM_VERSION 126
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -230,14 +230,10 @@ int64_t dm_conv3x3_scratch_floats(int CIN, int NOUT, int H, int W, int taps, int
  *   w_slabs out: num_blocks slabs of CD*CX*16 floats, each in the weight's own layout; dm_reduce_slabs(_multi) adds them
  * Built for CD = 16, CX = 8, H % 8 == 0, W % 32 == 0 (dm_conv_bwd_s2_fused_supported); batch-statistics coefficients
  * (coef_bstride = 0) only. */
-/* Arithmetic of the backward matrix products (gradients only; the forward pass is always exact fp32):
- *   0  the f32-input matrix instruction: bit for bit the fp32 multiply-add chain (default);
- *   1  split-bf16 operands: every fp32 value as a (bf16 head, bf16 remainder) pair, four products per pair on the bf16
- *      matrix instruction -- the fp32 product to ~2^-17 relative, a quarter of the matrix time.  Opt-in: gradients then
- *      differ from the fp32 chain by ~1e-5 of their products' magnitude (below the reference's own fp32 accumulation
- *      noise against float64, tests/conftest.py::grad_gate), latents, codes and losses not at all.
- * Process-wide.  mode 0 / 1 sets it, any other value only queries; returns the previous setting.  DM_BACKWARD_PRECISION=split
- * in the environment starts with 1. */
+/* Arithmetic of the backward matrix products: 0 = the f32-input matrix instruction, bit for bit the fp32 multiply-add
+ * chain -- the only arithmetic the library is built with.  mode 1 (split-bf16 operands, an opt-in of earlier rounds) is
+ * retired: it was slower than the exact path on these layer widths; asking for it returns -1 (dm_last_error).  Any other
+ * value only queries; returns the current setting (0). */
 int dm_backward_precision(int mode);
 int dm_conv_bwd_s2_fused_supported(int CD, int CX, int H, int W);
 int dm_conv_bwd_s2_fused_num_blocks(int B, int CD, int CX, int H, int W);

@@ -12,7 +12,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "split_bf16: kernel test that runs the gradient kernels with the opt-in split-bf16 operands")
 
 
 def pytest_collection_modifyitems(config, items):

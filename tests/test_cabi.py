@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header():
 def test_version_and_host_only_queries(lib):
     assert lib.dm_vq_backward_num_slabs(524288, 64, 16) == 512 and lib.dm_vq_backward_num_slabs(262144, 4096, 16) == 128
     assert lib.dm_vq_backward_num_slabs(3000, 64, 16) == 3 and lib.dm_vq_backward_num_slabs(1 << 22, 65536, 16) == 32
-    assert lib.dm_version() == 125          # 125: dm_conv3x3_bwd_fused on 32 x 32 latents (CD = 32), the training decoder tail in 64-column tiles; 124: dm_zscore_channels; 123: dm_time_matching_forward_state / _backward_state; 122: dm_reorder_with_trajectories; 121: dm_conv4x4s2_bwd_fused; 120: dm_conv3x3_bwd_fused; 119: dm_convt_bwd_fused; 118: dm_conv1x1_bwd_fused; 117: dm_vq_loss_finalize_tm, dm_time_matching_backward_add; 116: dm_vq_forward_join; 115: dm_gather_augment, dm_gather_rows, dm_csr_block, dm_augment_codes; 114: latent tail from a2; 113: dm_latent_tail_forward; 112: the fused decoder tail takes any width that is a multiple of 4
+    assert lib.dm_version() == 126          # 126: vq_cells_kernel (large codebooks), dm_adam_counted_scaled, split-bf16 gradient kernels retired; 125: dm_conv3x3_bwd_fused on 32 x 32 latents (CD = 32), the training decoder tail in 64-column tiles; 124: dm_zscore_channels; 123: dm_time_matching_forward_state / _backward_state; 122: dm_reorder_with_trajectories; 121: dm_conv4x4s2_bwd_fused; 120: dm_conv3x3_bwd_fused; 119: dm_convt_bwd_fused; 118: dm_conv1x1_bwd_fused; 117: dm_vq_loss_finalize_tm, dm_time_matching_backward_add; 116: dm_vq_forward_join; 115: dm_gather_augment, dm_gather_rows, dm_csr_block, dm_augment_codes; 114: latent tail from a2; 113: dm_latent_tail_forward; 112: the fused decoder tail takes any width that is a multiple of 4
     assert lib.dm_latent_tail_supported(16, 32, 16, 16, 2) == 1 and lib.dm_latent_tail_supported(16, 32, 32, 32, 2) == 0
     assert lib.dm_latent_tail_supported(64, 64, 16, 16, 2) == 0
     assert lib.dm_dec_tail_supported(4, 4, 128, 128) == 1 and lib.dm_dec_tail_supported(4, 2, 64, 64) == 1
@@ -57,7 +57,9 @@ def test_version_and_host_only_queries(lib):
     # ... + the bf16-split A operand (twice the f32 one)
     # (<= 64 codes: 1024 per-workgroup counter rows of 72 ints instead of the 64 replicas)
     assert lib.dm_vq_workspace_bytes(64, 16) == (32 + 64 * 16 + 64 * 16 + 2 * 64 * 16 + 64 + 64 * 16 + 1024 * 72) * 4
-    assert lib.dm_vq_workspace_bytes(4096, 16) == (32 + 4096 * 16 * 5 + 4096 + 16 * 4096) * 4
+    # (64 < K <= 4096 at embedding_dim 16: + the permuted bf16 operand and norms of vq_cells_kernel, 16 + 1 floats per code)
+    assert lib.dm_vq_workspace_bytes(4096, 16) == (32 + 4096 * 16 * 5 + 4096 + 16 * 4096 + 17 * 4096) * 4
+    assert lib.dm_vq_workspace_bytes(100, 16) - lib.dm_vq_workspace_bytes(100, 8) > 17 * 128 * 4        # (K rounded up to 128)
     assert lib.dm_vq_num_blocks(524288) == 2048
     assert lib.dm_conv4x4s2_bwd_fused_supported(16, 16, 16, 16) == 1 and lib.dm_conv4x4s2_bwd_fused_supported(16, 8, 32, 32) == 0
     assert lib.dm_conv4x4s2_bwd_fused_num_blocks(2048, 16, 16, 16, 16) == 256 and lib.dm_conv4x4s2_bwd_fused_num_blocks(5, 16, 16, 16, 16) == 5
@@ -154,3 +156,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DynamorphHipError):
         _lib.load()
+
+
+def test_backward_precision_split_is_retired():
+    """dm_backward_precision: the exact fp32 chain is the only arithmetic built; asking for the split-bf16 opt-in of earlier
+    rounds is an error (host-only call, no GPU needed), the query answers "f32"."""
+    from dynamorph_amd import ops
+    assert ops.backward_precision() == "f32"
+    assert ops.backward_precision("f32") == "f32"
+    import pytest
+    with pytest.raises(ValueError, match="not built"):
+        ops.backward_precision("split-bf16")
+    assert ops.backward_precision() == "f32"

@@ -23,15 +23,6 @@ def ops():
     return o
 
 
-@pytest.fixture(autouse=True)
-def backward_products(request, ops):
-    """The gradient kernels run on the f32-input matrix instruction by default (bit for bit the fp32 chain: tolerances of a
-    few 1e-5 below); tests marked split_bf16 run them with the opt-in split-bf16 operands."""
-    prev = ops.backward_precision("split-bf16" if request.node.get_closest_marker("split_bf16") else "f32")
-    yield
-    ops.backward_precision(prev)
-
-
 @pytest.fixture(scope="module")
 def cvq():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
@@ -123,13 +114,21 @@ def _c_oracle_idx(cvq, z, cb):
                                        (3, 8, 100, 8, 8), (3, 32, 300, 8, 16), (2, 64, 512, 16, 16), (5, 64, 129, 8, 8),
                                        # more than 1024 codes: the counters go straight to the global replicas; code chunks
                                        # streamed through the two LDS buffers with an odd and an even number of refills
-                                       (2, 16, 1100, 16, 16), (1, 16, 2049, 16, 32), (6, 32, 1025, 8, 8)])
+                                       (2, 16, 1100, 16, 16), (1, 16, 2049, 16, 32), (6, 32, 1025, 8, 8),
+                                       # vq_cells_kernel (64 < K <= 4096 at embedding_dim 16, grids of 128 positions): code counts
+                                       # that are not a multiple of the 128-code groups (padded cells), one group, all 32 groups,
+                                       # more passes than waves (B = 40: 80 passes of 128 positions)
+                                       (3, 16, 200, 16, 16), (2, 16, 129, 8, 16), (1, 16, 3000, 16, 16), (2, 16, 128, 16, 8),
+                                       (1, 16, 4096, 32, 32), (40, 16, 777, 16, 16),
+                                       # widths without an instantiation: vq_forward_any_kernel (run-time embedding_dim)
+                                       (2, 12, 40, 8, 8), (3, 24, 64, 16, 16), (2, 48, 100, 8, 8), (2, 96, 64, 8, 8),
+                                       (1, 5, 4, 4, 4), (2, 20, 33, 5, 7), (1, 200, 17, 4, 4)])
 def test_vq_forward_vs_c_oracle(ops, cvq, B, D, K, H, W):
     z = rnd(B, D, H, W, seed=B + D + K).numpy()
     cb = rnd(K, D, seed=K).numpy()
     idx_ref = _c_oracle_idx(cvq, z, cb)
     q = cb[idx_ref].transpose(0, 3, 1, 2)
-    variants = [DM_VQ_AUTO, DM_VQ_EXACT] + ([DM_VQ_MFMA] if (H * W) % 64 == 0 and D <= 64 else []) + (
+    variants = [DM_VQ_AUTO, DM_VQ_EXACT] + ([DM_VQ_MFMA] if (H * W) % 64 == 0 and D in (8, 16, 32, 64) else []) + (
         [DM_VQ_BF16] if (H * W) % 64 == 0 and D in (16, 32, 64) else [])
     for variant in variants:
         idx, out, slabs, hist = ops.vq_forward(torch.from_numpy(z).to(DEV), torch.from_numpy(cb).to(DEV), variant=variant)
@@ -1173,7 +1172,9 @@ def test_vq_backward_one_hot_product_is_ordered(ops, B, K, D, H):
     close(ops.reduce_slabs(slabs_n, torch.empty_like(cbd)), (dw_ref / 1.3).float(), 1e-5, 1e-6 * float(dw_ref.abs().max()), "dw, g_loss 1")
 
 
-@pytest.mark.parametrize("K,D,H", [(512, 64, 32), (4096, 16, 32), (300, 128, 8)])
+@pytest.mark.parametrize("K,D,H", [(512, 64, 32), (4096, 16, 32), (300, 128, 8),
+                                   # widths without an instantiation: vq_backward_any_kernel (run-time embedding_dim)
+                                   (64, 12, 8), (100, 24, 16), (64, 48, 8), (40, 96, 8), (7, 5, 4)])
 def test_vq_backward_large_codebooks(ops, K, D, H):
     """Codebooks above the LDS window (config_example.yml: 512 x 64; the stress case: 4096 x 16) go through windows
     of codes; both forms against embedding_dense_backward / mse_loss_backward restated with index_add."""
@@ -1510,7 +1511,7 @@ def test_augment_matches_torch(ops):
 def test_bad_arguments_raise(ops):
     x = rnd(1, 16, 16, 16).to(DEV)
     with pytest.raises(ValueError):
-        ops.vq_forward(rnd(1, 5, 4, 4).to(DEV), rnd(4, 5).to(DEV))       # embedding_dim 5 not built
+        ops.vq_forward(rnd(1, 513, 4, 4).to(DEV), rnd(4, 513).to(DEV))   # embedding_dim outside 1 .. 512
     with pytest.raises(ValueError):
         ops.conv3x3(ops.Op(x), ops.weight_view(x, 1, 1, 1, 1), 1, 16, 16, 16, 16, taps=5)   # only 3x3 and 1x1
     with pytest.raises(ValueError):
@@ -1748,7 +1749,6 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     statistics -- against torch autograd, and against the two kernels it replaces (the data gradient bit for bit where the
     MFMA order is the same, hw = 128; the weight gradient to summation order).  B = 300: more tiles than workgroups."""
     CD, CX, H, W = 16, 8, hw, hw
-    prev = ops.backward_precision("f32")                     # (the bit-for-bit comparisons below)
     dy, a_out = rnd(B, CD, H, W, seed=1), rnd(B, CD, H, W, seed=2)
     coefD = torch.stack([rnd(CD, seed=3), rnd(CD, seed=4) * 0.1, rnd(CD, seed=5) * 0.1, torch.zeros(CD)], 1)
     a_in = rnd(B, CX, 2 * H, 2 * W, seed=6)
@@ -1793,88 +1793,4 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
     with pytest.raises(ValueError, match="layer input"):       # a mask that is not the layer input is refused on the host
         ops.conv_bwd_s2_fused(dyop(), ops.Op(aid, 3, cTd), ops.weight_view(wd, 16, CX * 16, 4, 1), dstb, B, CD, CX, H, W,
                               mask=ops.Op(aid.clone(), 2, cTd))
-    # split-bf16 operands (opt-in): the same gradients to ~2^-17 of the products' magnitude
-    assert ops.backward_precision("split-bf16") == "f32"
-    dsts = torch.empty_like(dst)
-    dxs, sts = run(dsts)
-    mag_dx = F.conv_transpose2d(da.abs(), w.abs(), None, stride=2, padding=1)       # sum |da| |w| per output element
-    err = (dxs.cpu() - dx_ref).abs()
-    assert bool((err <= 2e-5 * mag_dx + 1e-30).all()), float((err / (mag_dx + 1e-30)).max())
-    xa = t_in.abs().requires_grad_(True)
-    wa = w.abs().clone().requires_grad_(True)
-    F.conv2d(xa, wa, None, stride=2, padding=1).backward(da.abs())
-    errw = (dsts.cpu() - wt.grad).abs()
-    assert bool((errw <= 2e-5 * wa.grad + 1e-30).all()), float((errw / (wa.grad + 1e-30)).max())
-    close(sts.sum(0), st.sum(0), 3e-5, 3e-5 * float(st.sum(0).abs().max()), "statistics under split-bf16")
-    dsts2 = torch.empty_like(dst)
-    dxs2, sts2 = run(dsts2)
-    assert torch.equal(dsts, dsts2) and torch.equal(dxs, dxs2)         # still reproducible to the bit
-    ops.backward_precision(prev)
 
-
-@pytest.mark.split_bf16
-@pytest.mark.parametrize("cs,ct,k,hs,B", [(16, 8, 4, 32, 5), (16, 16, 4, 16, 9), (16, 16, 3, 16, 7), (32, 16, 3, 16, 7), (16, 32, 1, 16, 7),
-                                          (8, 4, 4, 32, 3), (4, 4, 4, 64, 3)])
-def test_wgrad_split_bf16(ops, cs, ct, k, hs, B):
-    """Weight gradients with split-bf16 operands (opt-in, dm_backward_precision): every element within 2e-5 of the sum of
-    the products' magnitudes (2^-17 per product plus the fp32 accumulation), reproducible to the bit."""
-    assert ops.backward_precision() == "split-bf16"
-    stride, pad = (2, 1) if k == 4 else (1, k // 2)
-    S = rnd(B, cs, hs, hs, seed=1)
-    T = rnd(B, ct, hs * stride, hs * stride, seed=2)
-    t = T.clone().requires_grad_(True)
-    w = torch.zeros(cs, ct, k, k, requires_grad=True)
-    F.conv2d(t, w, None, stride=stride, padding=pad).backward(S)
-    wm = torch.zeros(cs, ct, k, k, requires_grad=True)
-    F.conv2d(T.abs(), wm, None, stride=stride, padding=pad).backward(S.abs())
-    dst, dst2 = torch.empty(cs, ct, k, k, device=DEV), torch.empty(cs, ct, k, k, device=DEV)
-    Sd, Td = S.to(DEV), T.to(DEV)
-    ops.wgrad(ops.Op(Sd), ops.Op(Td), dst, B, cs, ct, hs, hs, k)
-    ops.wgrad(ops.Op(Sd), ops.Op(Td), dst2, B, cs, ct, hs, hs, k)
-    err = (dst.cpu() - w.grad).abs()
-    assert bool((err <= 2e-5 * wm.grad + 1e-30).all()), float((err / (wm.grad + 1e-30)).max())
-    assert float((err / (wm.grad + 1e-30)).max()) > 1e-8          # (it IS the split path: the f32 chain is ~1e-7 here)
-    assert torch.equal(dst, dst2)
-
-
-@pytest.mark.split_bf16
-def test_data_gradients_split_bf16(ops):
-    """The data-gradient kernels with split-bf16 operands: 3x3 / 1x1 (BatchNorm-backward operand, mask, residual join),
-    the phase-decomposed transposed convolution (enc.7) and the 4x4/s2 form (decoder), each within 2e-5 of the products'
-    magnitude sum of the float64 result."""
-    def gate(out, ref, mag, what):
-        err = (out.detach().cpu().double() - ref.double()).abs()
-        assert bool((err <= 2e-5 * mag.double() + 1e-30).all()), (what, float((err / (mag.double() + 1e-30)).max()))
-    B, ci, co, h = 3, 16, 32, 16
-    w = rnd(co, ci, 3, 3, seed=1, scale=0.2)
-    dy, a = rnd(B, co, h, h, seed=2), rnd(B, co, h, h, seed=3)
-    coef = torch.stack([rnd(co, seed=4), rnd(co, seed=5) * 0.1, rnd(co, seed=6) * 0.1, torch.zeros(co)], 1)
-    prev = rnd(B, ci, h, h, seed=7)
-    resid = rnd(B, ci, h, h, seed=10)
-    da = load_ref(dy, 4, coef, a)
-    ref = F.conv_transpose2d(da.double(), w.double(), None, padding=1) * (prev > 0) + resid
-    mag = F.conv_transpose2d(da.abs(), w.abs(), None, padding=1) + resid.abs()
-    out, _ = ops.conv3x3(ops.Op(dy.to(DEV), 4, coef.to(DEV), p1=a.to(DEV)), ops.weight_view(w.to(DEV), 9, ci * 9, -3, -1, off=8),
-                         B, co, ci, h, h, taps=9, want_stats=True, mask=ops.Op(prev.to(DEV)), resid=resid.to(DEV), stat_q=prev.to(DEV))
-    gate(out, ref, mag, "3x3 data gradient")
-    # enc.7-like: Conv2d(16 -> 16, 4, 2, 1) data gradient = transposed convolution by phase, AFFINE2 operand, AFFINE mask
-    wt = rnd(16, 16, 4, 4, seed=11, scale=0.2)
-    dy7, a7 = rnd(B, 16, 16, 16, seed=12), rnd(B, 16, 16, 16, seed=13)
-    cf7 = torch.stack([rnd(16, seed=14), rnd(16, seed=15) * 0.1, rnd(16, seed=16) * 0.1, torch.zeros(16)], 1)
-    ain = rnd(B, 16, 32, 32, seed=17)
-    mc = torch.stack([rnd(16, seed=18).abs() + 0.5, torch.zeros(16), rnd(16, seed=19) * 0.2, torch.zeros(16)], 1)
-    da7 = load_ref(dy7, 4, cf7, a7)
-    ref7 = F.conv_transpose2d(da7.double(), wt.double(), None, stride=2, padding=1) * (load_ref(ain, 2, mc) > 0)
-    mag7 = F.conv_transpose2d(da7.abs(), wt.abs(), None, stride=2, padding=1)
-    out7, _ = ops.conv3x3(ops.Op(dy7.to(DEV), 4, cf7.to(DEV), p1=a7.to(DEV)), ops.weight_view(wt.to(DEV), 16, 16 * 16, 4, 1), B, 16, 64,
-                          16, 16, taps=9, pixel_shuffle=True, want_stats=True, mask=ops.Op(ain.to(DEV), 2, mc.to(DEV)), stat_q=ain.to(DEV))
-    gate(out7, ref7, mag7, "transposed convolution by phase")
-    # decoder-like: data gradient of ConvTranspose2d(8 -> 4) = 4x4/s2 convolution over g with a ReLU mask
-    wd = rnd(8, 4, 4, 4, seed=21, scale=0.2)
-    g = rnd(B, 4, 64, 64, seed=22)
-    act = rnd(B, 8, 32, 32, seed=23)
-    refd = F.conv2d(g.double(), wd.double(), None, stride=2, padding=1) * (act > 0)
-    magd = F.conv2d(g.abs(), wd.abs(), None, stride=2, padding=1)
-    outd, _ = ops.conv4x4s2(ops.Op(g.to(DEV)), ops.weight_view(wd.to(DEV), 4 * 16, 16, 4, 1), B, 4, 8, 64, 64, want_stats=True,
-                            mask=ops.Op(act.to(DEV)))
-    gate(outd, refd, magd, "4x4/s2 data gradient")

@@ -28,6 +28,7 @@ KEYS = {                       # key in the JSON -> substring of the kernel name
     "convT_bwd_dec2": "convT_bwd_kernel<8, 4, 32>",
     "convT_bwd_dec0": "convT_bwd_kernel<16, 8, 16>",             # train()'s resident feed: gather + flip / rot90 of a batch
     "vq_forward_mfma_k4096": "vq_forward_mfma_kernel<16, false",  # K = 4096 (KB_B5 patches): codebook walks through LDS
+    "vq_cells_k4096": "vq_cells_kernel",                         # round 6: K = 4096, operands straight from L2 (csrc/vq_cells.h)
     "vq_backward_mfma": "vq_backward_mfma_kernel",
     "latent_tail": "latent_tail_kernel",
     "copy_calib": "elementwise_kernel",

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the round's judged artefacts under gpurun_out/refresh (run from the repo root on the GPU box, copy into profiles/ afterwards):
-#   tools/refresh_profiles.sh r05
+#   tools/refresh_profiles.sh r06
 set -e
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/refresh
 mkdir -p $out
