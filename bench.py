@@ -140,6 +140,8 @@ def roofline_vq_large_codebook(model, x):
     t1 = event_time_ms(lambda: ops.vq_forward_repeat(z, cbk, 1, bufs=bufs), iters=10, warmup=3)
     t21 = event_time_ms(lambda: ops.vq_forward_repeat(z, cbk, 21, bufs=bufs), iters=5, warmup=1)
     ms = max((t21 - t1) / 20.0, 1e-6)
+    ops.vq_forward_repeat(z, cbk, 1, bufs=bufs)      # (the re-check counter below is per LAUNCH: rounds 3-5 read it after the
+    torch.cuda.synchronize()                          #  21-launch call and reported 21 launches' worth -- 12.5 % instead of 0.6 %)
     K, D = cbk.shape
     P = z.shape[0] * z.shape[2] * z.shape[3]
     flops = 2.0 * K * D * P                      # the filter product |e|^2 - 2 z.e as an f32 GEMM: the algorithmic count

@@ -77,13 +77,15 @@ def oracle_truth(ref, x, **kw):
     return ld, g32, g64
 
 
-def grad_gate(model, g32, g64, keys=None, skip=(), factor=1.5, floor=2e-4, what=""):
+def grad_gate(model, g32, g64, keys=None, skip=(), factor=1.5, floor=2e-4, what="", factor_for=None, enforce=True):
     """Every gradient of the HIP `model` (p.grad) is as close to the float64 truth as the reference's own fp32 CPU path is
     (x factor), or within floor x the tensor's scale -- the yardstick of test_oracle_parity_fresh_seed_larger_batch, in
     place of the flat 2 % of scale the shape sweeps used until round 2 (a dropped tile row or a missing tap at B = 2..7
-    hid under that)."""
+    hid under that).  factor_for: {tensor name: its own factor} for documented outliers; enforce=False only prints the table
+    of ratios (hip error / reference fp32 error), for comparisons that are recorded but not gated."""
     worst = ("", 0.0)
     checked = 0
+    ratios = []
     for k, p in model.named_parameters():
         if not p.requires_grad or k in skip or (keys is not None and k not in keys) or k not in g64:
             continue
@@ -92,12 +94,22 @@ def grad_gate(model, g32, g64, keys=None, skip=(), factor=1.5, floor=2e-4, what=
         scale = max(truth.abs().max().item(), 1e-6)
         e_ref = (g32[k].double() - truth).abs().max().item()
         e_hip = (p.grad.detach().cpu().double() - truth).abs().max().item()
-        assert e_hip <= max(factor * e_ref, floor * scale) + 1e-9, (what, k, "hip", e_hip, "fp32 reference", e_ref, "scale", scale)
+        f = (factor_for or {}).get(k, factor)
+        ratios.append((e_hip / max(e_ref, 1e-30), k, e_hip, e_ref, scale))
+        if enforce:
+            assert e_hip <= max(f * e_ref, floor * scale) + 1e-9, (what, k, "hip", e_hip, "fp32 reference", e_ref, "scale", scale)
         checked += 1
         if e_hip / scale > worst[1]:
             worst = (k, e_hip / scale)
     assert checked > 0
-    print(f"{what}: {checked} gradients within the float64 yardstick; worst {worst[0]} {worst[1]:.2e} of scale")
+    if not enforce:
+        print(f"{what} (recorded, not gated): hip error / reference fp32 error per tensor, largest first")
+        for r, k, eh, er, sc in sorted(ratios, reverse=True)[:12]:
+            print(f"    {k:32s} ratio {r:8.2f}   hip {eh:.2e}  reference {er:.2e}  scale {sc:.2e}")
+        return checked
+    top = max(ratios)
+    print(f"{what}: {checked} gradients within the float64 yardstick; worst {worst[0]} {worst[1]:.2e} of scale; "
+          f"largest hip / reference error ratio {top[0]:.2f} ({top[1]})")
     return checked
 
 

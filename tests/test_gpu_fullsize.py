@@ -65,24 +65,36 @@ def test_c3_training_step_at_batch_2048_against_the_oracle():
     # tools/exp/e1_accuracy.py -- and turns 2 near-ties of this batch the other way; with the reference's codes in the yardstick
     # nine gradients sat 2-150 x beyond the reference's error, tools/exp/c3_grad_ratios.py.)
     nflip = int((idx != idx_r).sum())
-    if nflip:
-        ref.vq.force_idx = idx.clone()
-        print(f"{nflip} near-tie codes differ: the float64 and fp32 yardsticks use the HIP path's codes")
+    # (codes_gate has already restricted flips to the reference's own near-ties and to 1e-5 of the positions; at this batch
+    #  rounds 5-6 see 0-2, and more than 4 would mean the encoder's latents drifted: the forced comparison must not hide that)
+    assert nflip <= 4, nflip
 
-    # float64 truth of the gradients first (its graph is freed before the fp32 run starts)
-    ref64 = copy.deepcopy(ref).double()
-    _, ld64 = ref64(x.double())
-    ld64["total_loss"].backward()
-    g64 = {k: p.grad for k, p in ref64.named_parameters() if p.grad is not None}
-    del ld64
-    gc.collect()
-    opt = O.make_adam(ref, 1e-4)
-    _, ld_r = ref(x)
-    ld_r["total_loss"].backward()
-    g32 = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
-    opt.step()
-    ld_r = {k: float(v) for k, v in ld_r.items()}
-    gc.collect()
+    def yardsticks(model32):
+        """(float64 gradients, fp32 gradients, fp32 losses, the stepped fp32 model) of `model32` on the batch; the float64
+        graph is freed before the fp32 run starts."""
+        m64 = copy.deepcopy(model32).double()
+        _, l64 = m64(x.double())
+        l64["total_loss"].backward()
+        g64_ = {k: p.grad for k, p in m64.named_parameters() if p.grad is not None}
+        del l64, m64
+        gc.collect()
+        opt_ = O.make_adam(model32, 1e-4)
+        _, l32 = model32(x)
+        l32["total_loss"].backward()
+        g32_ = {k: p.grad.clone() for k, p in model32.named_parameters() if p.grad is not None}
+        opt_.step()
+        l32 = {k: float(v) for k, v in l32.items()}
+        gc.collect()
+        return g64_, g32_, l32
+
+    unforced = None
+    if nflip:
+        # the comparison WITHOUT the forcing is kept visible (printed below, not asserted): the reference's own codes in
+        # both yardsticks
+        unforced = yardsticks(copy.deepcopy(ref))[:2]
+        ref.vq.force_idx = idx.clone()
+        print(f"{nflip} near-tie codes differ: the gated float64 and fp32 yardsticks use the HIP path's codes")
+    g64, g32, ld_r = yardsticks(ref)
 
     tr = FusedTrainer(m, lr=1e-4, use_graph=True)
     vals = tr.step(xd).tolist()
@@ -90,9 +102,12 @@ def test_c3_training_step_at_batch_2048_against_the_oracle():
         assert abs(vals[i] - ld_r[k]) <= 1e-5, (k, vals[i], ld_r[k])                 # the north star's tolerance
     assert abs(vals[3] - ld_r["perplexity"]) <= 1e-3 * ld_r["perplexity"]
     tr.expose_grads()
-    # (factor 2: each tensor's ratio is the quotient of two fp32 error maxima, 35 of them; with the kernels of round 5 34 sit
-    #  below 1.5 and enc.2.weight at 1.53 -- 6.1e-7 against the reference's 4.0e-7 on a gradient of scale 1.1e-3)
-    grad_gate(m, g32, g64, skip=BN_FED_BIASES, factor=2.0, what="C3 step at B = 2048")
+    # (each tensor's ratio is the quotient of two fp32 error maxima, 35 of them: 34 sit below 1.5; the documented outlier is
+    #  enc.2.weight at 1.53 -- 6.1e-7 against the reference's 4.0e-7 on a gradient of scale 1.1e-3 -- with its own factor)
+    grad_gate(m, g32, g64, skip=BN_FED_BIASES, factor=1.5, factor_for={"enc.2.weight": 2.0}, what="C3 step at B = 2048")
+    if unforced is not None:
+        grad_gate(m, unforced[1], unforced[0], skip=BN_FED_BIASES, enforce=False,
+                  what=f"C3 step at B = 2048 against the reference's OWN codes ({nflip} of 524 288 differ)")
     # one Adam step at lr = 1e-4 moves every weight by at most lr; where the reference's own gradient is above its fp32
     # noise the step has the same direction
     sd_r = ref.state_dict()
@@ -126,17 +141,25 @@ def test_c2_latents_of_1024_patches_against_the_oracle_loop():
     m.load_state_dict(ref.state_dict())
     x = torch.randn(N, 2, 128, 128, generator=torch.Generator().manual_seed(4321))
     torch.set_num_threads(min(torch.get_num_threads(), 16))
+    ref64 = copy.deepcopy(ref).double()
     with torch.no_grad():
         zb_r, za_r = O.encode_per_sample(ref, x)          # patch_VAE.py:445-452: 1024 batch-of-one calls, train-mode BN
+        zb_64, _ = O.encode_per_sample(ref64, x.double())  # the float64 yardstick of the latents
     zb, za = encode_patches(m, x, device=DEV, batch_size=1024)
     assert zb.shape == (N, 4096) and za.shape == (N, 4096) and zb.dtype == np.float32
-    err = np.abs(zb - zb_r.reshape(N, -1).numpy())
-    assert err.max() <= 3e-4, err.max()
+    # the latents on the float64 yardstick: as close to float64 as the reference's own fp32 latents are (x 1.5) -- until
+    # round 5 a flat 3e-4 against the fp32 reference, ~300 x the error either of them has
+    truth = zb_64.reshape(N, -1).numpy()
+    e_ref = np.abs(zb_r.reshape(N, -1).numpy().astype(np.float64) - truth).max()
+    e_hip = np.abs(zb.astype(np.float64) - truth).max()
+    print(f"C2 latents against float64: HIP {e_hip:.2e}, fp32 reference {e_ref:.2e}")
+    assert e_hip <= 1.5 * e_ref + 1e-7, (e_hip, e_ref)
+    del ref64, zb_64, truth
     # quantised latents: equal wherever the code is the same; codes may differ only at the reference's own near-ties
     diff = (np.abs(za.reshape(N, 16, 16, 16) - za_r.numpy()) > 1e-3).any(axis=1)
     codes_gate(diff, zb_r, ref.vq.w.weight.detach(), "C2, N = 1024: all 262 144 positions")
     same = ~diff
-    assert np.abs(za.reshape(N, 16, 16, 16) - za_r.numpy()).transpose(0, 2, 3, 1)[same].max() <= 3e-4
+    assert np.abs(za.reshape(N, 16, 16, 16) - za_r.numpy()).transpose(0, 2, 3, 1)[same].max() <= 1e-5
     # the side effect the loop has on the checkpointed buffers: 1024 momentum updates of the running statistics
     sd_r = ref.state_dict()
     for k, v in m.state_dict().items():

@@ -686,7 +686,13 @@ def test_other_channel_widths(name, kw):
     ref.load_state_dict({k: v.double() for k, v in m.state_dict().items()})     # identical (fp32-rounded) weights
     x = torch.randn(2, 2, 128, 128, generator=torch.Generator().manual_seed(8))
     mask = (torch.rand(2, 1, 128, 128, generator=torch.Generator().manual_seed(9)) > 0.3).float()
+    # ReLU gates the float64 run decides by less than fp32 rounding can move them: count them (see the gate below)
+    near_zero = []
+    hooks = [mod.register_forward_hook(lambda _m, a, _o: near_zero.append(int((a[0].abs() < 4e-7 * a[0].abs().max()).sum())))
+             for mod in ref.modules() if isinstance(mod, torch.nn.ReLU)]
     dec_r, ld_r = ref(x.double(), batch_mask=mask.double())
+    for h in hooks:
+        h.remove()
     ld_r["total_loss"].backward()
     dec, ld = m(x.to(DEV), batch_mask=mask.to(DEV))
     ld["total_loss"].backward()
@@ -704,14 +710,26 @@ def test_other_channel_widths(name, kw):
             continue
         rel[k] = (p.grad.cpu().double() - b).abs().max().item() / b.abs().max().item()
     assert len(rel) >= 20
-    # Exact kernels agree with float64 to ~1e-6.  One ReLU gate whose pre-activation lies within fp32 rounding of zero
-    # may open in fp32 and stay shut in float64 (or the reverse); that moves the small-batch gradients upstream of it by
-    # a percent or two (one element of a 512-element sum), in the fp32 oracle just as here.  So: most parameters tight,
-    # none beyond what a single flipped gate explains.
+    # Exact kernels agree with float64 to ~1e-6: most parameters tight.
     tight = [k for k, e in rel.items() if e <= 2e-4]
     assert len(tight) >= 0.5 * len(rel), sorted(rel.items(), key=lambda kv: -kv[1])[:5]
-    worst = max(rel.items(), key=lambda kv: kv[1])
-    assert worst[1] <= 5e-2, worst
+    # The rest on the float64 yardstick with the reference's own fp32 error as the measure (conftest.grad_gate), floor 1e-3 of
+    # the tensor's scale (until round 5 a flat 5e-2, which a dropped tap at B = 2 could hide under).  The one thing that
+    # legitimately exceeds it: a ReLU gate whose pre-activation lies within fp32 rounding of zero opens in one fp32
+    # implementation and stays shut in float64 (or the reverse), which moves the small-batch gradients upstream of it by up
+    # to a percent or two.  The float64 run COUNTS such pre-activations (|x| below 4e-7 of the layer's largest); each of
+    # them widens the floor by 5e-3 (the old flat 5e-2 is the cap).
+    fragile = sum(near_zero)
+    assert len(near_zero) >= 5
+    print(f"{name} {kw['num_hiddens']}: {fragile} ReLU inputs within fp32 rounding of zero in the float64 run")
+    ref32 = (O.OracleVQVAEz32 if name == "VQ_VAE_z32" else O.OracleVQVAE)(**kw)
+    ref32.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    _, ld32 = ref32(x, batch_mask=mask)
+    ld32["total_loss"].backward()
+    g32 = {k: p.grad for k, p in ref32.named_parameters() if p.grad is not None}
+    g64 = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    zero = [k for k, b in g64.items() if b.abs().max().item() < 1e-9]
+    grad_gate(m, g32, g64, skip=zero, factor=1.5, floor=min(5e-2, 1e-3 + 5e-3 * fragile), what=f"{name} {kw['num_hiddens']}")
 
 
 def test_fused_trainer_reference_example_width():
