@@ -1792,6 +1792,8 @@ int vq2_cells()
     }();
     return v;
 }
+// start delay of the CUs' second workgroups in percent of one pass's matrix time (DM_VQ_CELLS_STAGGER; 0 = none)
+int vq2_cells_stagger_pct() { static const int v = [] { const char *e = getenv("DM_VQ_CELLS_STAGGER"); return e ? atoi(e) : 90; }(); return v; }
 bool vq2_force_prep() { static const bool v = [] { const char *e = getenv("DM_VQ_PREP"); return e && e[0] == '1'; }(); return v; }
 int vq2_occ() { static const int v = [] { const char *e = getenv("DM_VQ_OCC"); return e ? atoi(e) : 3; }(); return v; }
 int vq2_wgs(int dflt) { static const int v = [] { const char *e = getenv("DM_VQ_WGS"); return e ? atoi(e) : 0; }(); return v > 0 ? v : dflt; }
@@ -1899,14 +1901,19 @@ int vq_forward_launch(const float *z, const float *codebook, int64_t *idx, float
                 const long long passes = P >> 7;
                 long long g_ = (passes + 3) / 4;
                 if (g_ > 512) g_ = 512;                              // two workgroups per CU, persistent over the passes
-                if (vq2_cells() == 4)
+                // half a pass in units of 64 cycles (s_sleep): a pass streams K / 32 chunks of 12 (16) matrix instructions of 32
+                // cycles; only where both slots of the CUs are taken and every wave has more than one pass
+                const int prod = vq2_cells();
+                const long long chunk_cycles = (long long)(prod == 4 ? 16 : 12) * 32;
+                int stagger = (g_ > 256 && passes >= 2 * g_ * 4) ? (int)(((K + 31) / 32) * chunk_cycles * vq2_cells_stagger_pct() / 100 / 64) : 0;
+                if (prod == 4)
                     hipLaunchKernelGGL((vq_cells_kernel<4>), dim3((unsigned)g_), dim3(256), 0, s, z, codebook,
                                        reinterpret_cast<const vqc_u32x4 *>(ws + L.cbP), ws + L.nrmP, ws + L.nrm, (long long *)idx,
-                                       out, sse_slabs, hrep, L.R, (int *)ws, K, H * W, P);
+                                       out, sse_slabs, hrep, L.R, (int *)ws, K, H * W, P, stagger);
                 else
                     hipLaunchKernelGGL((vq_cells_kernel<3>), dim3((unsigned)g_), dim3(256), 0, s, z, codebook,
                                        reinterpret_cast<const vqc_u32x4 *>(ws + L.cbP), ws + L.nrmP, ws + L.nrm, (long long *)idx,
-                                       out, sse_slabs, hrep, L.R, (int *)ws, K, H * W, P);
+                                       out, sse_slabs, hrep, L.R, (int *)ws, K, H * W, P, stagger);
                 continue;
             }
             switch (D) {

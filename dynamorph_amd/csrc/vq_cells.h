@@ -40,11 +40,28 @@
 #endif
 #define VQC_DBG(bit) ((VQC_OFF & (bit)) != 0)
 
+// diagnostic build only (-DVQ2_STAMPS, tools/exp/vq_cells_stamps.py): s_memtime at the phase boundaries of a pass, per-wave sums
+// added into the workspace header -- the shipped library has no stamp
+#ifdef VQ2_STAMPS
+#define VQC_STAMP(i)                                                                                      \
+    {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        unsigned long long t_;                                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        st_sum[i] += t_ - st_prev;                                                                        \
+        st_prev = t_;                                                                                     \
+    }
+#else
+#define VQC_STAMP(i)
+#endif
+
 template <int NPROD>
 __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const vqc_u32x4 *__restrict__ cbP,
     const float *__restrict__ nrmP, const float *__restrict__ nrm, long long *__restrict__ idx, float *__restrict__ out,
-    double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int *__restrict__ hdr, int K, int HW, long long P)
+    double *__restrict__ sse_slabs, int *__restrict__ hrep, int R, int *__restrict__ hdr, int K, int HW, long long P,
+    int stagger)
 {
     constexpr int D = 16, NT = VQC_NT;
     static_assert(NPROD == 3 || NPROD == 4, "three or four products of the bf16 split");
@@ -91,9 +108,20 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
         emax = fmaxf(fmaxf(s_em[0], s_em[1]), fmaxf(s_em[2], s_em[3]));
     }
 
+    // Stagger (guide: two waves that run the same program on one SIMD reach their matrix work and their vector-only tails
+    // together): the second workgroup of every CU -- the upper half of the grid, dispatched after the lower half has taken one
+    // slot per CU -- starts `stagger` x 64 cycles late, about half a pass, so that one wave's tail (exact cell evaluation,
+    // re-checks, stores: a quarter of its time, no matrix work) runs beside the other wave's code stream.  Measured: 2-4 %
+    // (404 -> 387-398 us); pairing the late half by parity or by XCD neighbours instead gains nothing.
+    if (stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2)
+        for (int i = 0; i < stagger; i += 127) __builtin_amdgcn_s_sleep(127);
     const unsigned npass = (unsigned)(P >> 7), pps = (unsigned)HW >> 7;      // passes of 128 positions; per sample
     double sse = 0.0;
     int nflag = 0;
+#ifdef VQ2_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
     const vqc_u32x4 *__restrict__ aP = cbP + lane;
     vqc_u32x4 ah[VQC_GCH], al[VQC_GCH];                                       // the operand ring: chunks cc .. cc + 3
 #pragma unroll
@@ -131,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                 Zl[t] = (vqc_u32x4){lp[0], lp[1], lp[2], lp[3]};
             }
         }
+        VQC_STAMP(0)                                           // latents loaded, operands split
         float cm[NT][8], m1[NT], m2[NT];
         int G1[NT];
 #pragma unroll
@@ -246,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                 al[ccl] = aP[(nxt * 2 + 1) * 64];
             }
         }
+        VQC_STAMP(1)                                           // the code stream
         // drain: the last tile's accumulators have no matrix instruction behind them -- wait them out explicitly
         // (16 passes of the last instruction; s_nop counts issue cycles)
         __builtin_amdgcn_sched_barrier(0);
@@ -254,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
         cells(NT - 1, 0, 8, VQC_GCH == 1);
         if (!VQC_DBG(16)) group_end(NG - 1);
 
+        VQC_STAMP(2)                                           // drain + last group end
         if (VQC_ZPREFETCH) load_z(pass + gridDim.x * 4u);
         // ---- the tail: everything of a position is in its owner's registers ----
         const long long own = (long long)pw * 128 + 4 * n + 2 * kh;                 // first owned position inside the sample
@@ -313,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
             }
             kown[s] = bk == 0x7fffffff ? 0 : bk;
         }
+        VQC_STAMP(3)                                           // owned latents, merge, exact evaluation of the best cells
         // ---- exact re-check of the positions the filter could not settle: the whole wave, one position at a time, over the
         // groups whose minimum lies within the tolerance of the best score (a NaN on either side keeps the group)
 #pragma unroll
@@ -336,6 +368,10 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                     const float pg = __builtin_bit_cast(float, (s ? (pk >> 24) | ((unsigned)s_pmh[wave][gq][fl] << 8) : pk & 0xffffffu) << 8);
                     gmask = (unsigned)__ballot(lane < NG && !(pg > thr));
                 }
+#ifdef VQ2_STAMPS
+                st_sum[6] += __builtin_popcount(gmask);        // (counts, not cycles: groups visited / positions re-checked)
+                st_sum[7] += 1;
+#endif
                 while (gmask) {
                     const int g = __builtin_ctz(gmask);
                     gmask &= gmask - 1;
@@ -378,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                 ++nflag;
             }
         }
+        VQC_STAMP(4)                                           // exact re-checks
         // ---- gather, straight-through value z + (q - z) (vq_vae.py:71), squared error, stores, counters ----
         float ssef = 0.f;
         f32x2 o[D];
@@ -407,9 +444,14 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
         }
         atomicAdd(&hist[kown[0]], 1);
         atomicAdd(&hist[kown[1]], 1);
+        VQC_STAMP(5)                                           // gather, value, stores, counters
     }
 
     const double tot = block_sum(sse, s_red);
     if (threadIdx.x == 0) sse_slabs[blockIdx.x] = tot;
     if (lane == 0 && nflag) atomicAdd(hdr, nflag);
+#ifdef VQ2_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4) + i, st_sum[i]);
+#endif
 }
