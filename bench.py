@@ -102,6 +102,27 @@ def profile_avg_us(kernel_stem):
     return None, None
 
 
+PROFILE_SQ = ("r06_c3_b2048_sq_counters.json", "r05_c3_b2048_sq_counters.json")
+
+
+def profile_mfma_busy(kernel):
+    """(SQ_VALU_MFMA_BUSY_CYCLES per SIMD as a percentage of the cycles a wave of `kernel` is resident, file) from the newest
+    committed `rocprofv3 --pmc` summary (tools/sqprof.sh -> profiles/r0N_c3_b2048_sq_counters.json): the north star's "MFMA
+    utilisation ... evidenced by rocprof MFMA-busy".  A RECORD of a profiled run, reported beside the live FLOP-based
+    fraction under its own name; (None, None) when there is none."""
+    stem = kernel.rstrip(">")
+    for name in PROFILE_SQ:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                ks = json.load(f).get("kernels", {})
+        except (OSError, ValueError):
+            continue
+        for k, v in ks.items():
+            if k.startswith(stem):
+                return v.get("mfma_busy_pct_of_wave_cycles"), name
+    return None, None
+
+
 EXAMPLE_CONFIG = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512)     # config_example.yml:157-163
 
 
@@ -373,6 +394,9 @@ def north_star_targets(model, x):
                "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
         if kernel:
             rec["kernel"] = kernel
+            busy, bfile = profile_mfma_busy(kernel)
+            if busy is not None:
+                rec["mfma_busy_pct_profile"], rec["mfma_busy_profile_file"] = busy, bfile
         if note:
             rec["note"] = note
         convs.append(rec)
@@ -383,7 +407,7 @@ def north_star_targets(model, x):
         lambda: ops.conv4x4s2(Op(x), weight_view(weff, (NIN + 1) * 16, 16, 4, 1), B, NIN, c1, H, W, out=a1, want_stats=True,
                               bias_border=border),
         note="HBM bound: reads x and writes a1, 262 144 B per patch; the reference's two layers would be 4 456 448 MACs per patch",
-        kernel="conv4x4s2_kernel<2, 1, 8, 64, 0, 3, true>")
+        kernel="conv4x4s2_pair_kernel<2, 8, 3>")
     add("enc.4 (4x4/s2, 8->16)", 2097152,
         lambda: ops.conv4x4s2(Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), weight_view(w(L.enc4.weight), c1 * 16, 16, 4, 1), B, c1, nh,
                               H1, W1, out=a2, want_stats=True, bias=w(L.enc4.bias)),
@@ -412,6 +436,16 @@ def north_star_targets(model, x):
     total = {"flops": tot_fl, "ms": round(tot_ms, 5),
              "frac_mfma": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
     total["note"] = "frac_mfma = executed FLOPs / average launch (graph replay of 10 launches) / 157.3 TFLOP/s: clock- and prologue-inclusive"
+    # the counter the north star names, from the committed profile: matrix-pipe busy cycles over the encoder's forward
+    # convolutions, weighted by their (live) launch times
+    wsum = sum(c["avg_launch_ms"] * (2 if "each of 2" in c["layer"] else 1) for c in convs if "mfma_busy_pct_profile" in c)
+    if wsum > 0:
+        total["mfma_busy_pct_profile_time_weighted"] = round(
+            sum(c["mfma_busy_pct_profile"] * c["avg_launch_ms"] * (2 if "each of 2" in c["layer"] else 1)
+                for c in convs if "mfma_busy_pct_profile" in c) / wsum, 1)
+        total["mfma_busy_is"] = ("SQ_VALU_MFMA_BUSY_CYCLES / cycles a wave is resident, per kernel, from the committed rocprofv3 --pmc "
+                                 "summary (a record of a profiled run, 1.7-1.9 GHz; the FLOP fraction above prices the same launches "
+                                 "against the 2.4 GHz peak)")
     return {"vq": vq, "enc_convs": convs, "enc_convs_total": total}
 
 
