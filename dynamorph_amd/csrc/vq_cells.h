@@ -31,9 +31,13 @@
 // (constants, the row <-> code permutation and the operand preparation: vq.hip, above vq_prep_kernel)
 
 // measurement builds only (tools/exp/vq_cells_parts.sh; results are wrong, the time is what is read): compile-time switches
-// -DVQC_OFF=bits: 4 no exact re-checks, 8 no exact evaluation of the best cell, 16 no group ends, 32 no cell minima
+// -DVQC_OFF=bits: 4 no exact re-checks, 8 no exact evaluation of the best cell, 16 no group ends, 32 no cell minima,
+// 64 the operand ring is never refilled (stale codes), 128 the norms are read once per pass, 256 every other group end skipped
 #ifndef VQC_OFF
 #define VQC_OFF 0
+#endif
+#ifndef VQC_CELL_BATCH
+#define VQC_CELL_BATCH 4         // rows of the best cell requested together (8: measured below)
 #endif
 #ifndef VQC_ZPREFETCH
 #define VQC_ZPREFETCH 0          // 1: the next pass's latents are requested before this pass's tail (measured: no gain, more spills)
@@ -266,13 +270,15 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                     if (!VQC_DBG(32)) cells(pt, 4, 8, pfirst);
                     __builtin_amdgcn_sched_barrier(0);
                     // the previous group is complete once the last tile of its last chunk has been folded in
-                    if (t == 0 && ccl == 0 && g > 0 && !VQC_DBG(16)) group_end(g - 1);
-                    if (t == 1) read_norms(nrb[(ccl + 1) & 1], cc + 1 < NCH ? cc + 1 : 0);
+                    if (t == 0 && ccl == 0 && g > 0 && !VQC_DBG(16) && !(VQC_DBG(256) && (g & 1))) group_end(g - 1);
+                    if (t == 1 && !VQC_DBG(128)) read_norms(nrb[(ccl + 1) & 1], cc + 1 < NCH ? cc + 1 : 0);
                 }
                 // this ring slot's next chunk (the stream wraps into the next pass)
                 const int nxt = cc + VQC_GCH < NCH ? cc + VQC_GCH : cc + VQC_GCH - NCH;
-                ah[ccl] = aP[(nxt * 2) * 64];
-                al[ccl] = aP[(nxt * 2 + 1) * 64];
+                if (!VQC_DBG(64)) {
+                    ah[ccl] = aP[(nxt * 2) * 64];
+                    al[ccl] = aP[(nxt * 2 + 1) * 64];
+                }
             }
         }
         VQC_STAMP(1)                                           // the code stream
@@ -323,10 +329,10 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
             int bk = 0x7fffffff;
             if (VQC_DBG(8)) bk = min(base, K - 1);
 #pragma unroll
-            for (int c0 = 0; c0 < (VQC_DBG(8) ? 0 : 8); c0 += 4) {
-                float er[4][D];
+            for (int c0 = 0; c0 < (VQC_DBG(8) ? 0 : 8); c0 += VQC_CELL_BATCH) {
+                float er[VQC_CELL_BATCH][D];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < VQC_CELL_BATCH; ++u) {
                     const int k = min(base + c0 + u, K - 1);
 #pragma unroll
                     for (int q4 = 0; q4 < D / 4; ++q4) {
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < VQC_CELL_BATCH; ++u) {
                     const int k = base + c0 + u;
                     const float dk = vq_exact_dist<D>(zv, er[u]);
                     const bool bt = k < K && ((bk == 0x7fffffff) | vq_better(dk, bd));

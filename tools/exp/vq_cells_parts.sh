@@ -1,10 +1,11 @@
 #!/bin/bash
 # vq_cells_kernel (csrc/vq_cells.h) with parts compiled out (results are wrong with any bit set; the time is what is read).
-# VQC_OFF bits: 4 no exact re-checks, 8 no exact evaluation of the best cell, 16 no group ends, 32 no cell minima.
+# VQC_OFF bits: 4 no exact re-checks, 8 no exact evaluation of the best cell, 16 no group ends, 32 no cell minima,
+# 64 operand ring never refilled, 128 norms read once per pass (16 / 32 make every position degenerate: not timeable).
 #   tools/exp/vq_cells_parts.sh build     here (hipcc cross-compiles): one library per variant next to the package's
 #   gpurun -- tools/exp/vq_cells_parts.sh on the GPU box
 cd "$(dirname "$0")/../.."
-VARIANTS="0 4 12 28 60 16 8"
+VARIANTS="${VARIANTS:-0 4 12 64 128 192}"
 if [ "$1" = build ]; then
   cd dynamorph_amd/csrc && mkdir -p build_measure
   for v in $VARIANTS; do
