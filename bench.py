@@ -415,7 +415,7 @@ def north_star_targets(model, x):
     add("enc.7 (4x4/s2, 16->16)", 1048576,
         lambda: ops.conv4x4s2(Op(cx.a2, DM_LOAD_AFFINE_RELU, cx.coef2), weight_view(w(L.enc7.weight), nh * 16, 16, 4, 1), B, nh, nh,
                               H2, W2, out=a3, want_stats=True, bias=w(L.enc7.bias)),
-        kernel="conv4x4s2_kernel<16, 1, 8, 16, 0, 2, false>")
+        kernel="conv4x4s2_patch_forward_kernel")
     add("enc.10 (3x3, 16->16)", 589824,
         lambda: ops.conv3x3(Op(cx.a3, DM_LOAD_AFFINE_RELU, cx.coef3), weight_view(w(L.enc10.weight), nh * 9, 9, 3, 1), B, nh, nh,
                             H3, W3, taps=9, out=a4, want_stats=True, bias=w(L.enc10.bias)),
