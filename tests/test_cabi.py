@@ -168,3 +168,24 @@ def test_backward_precision_split_is_retired():
     with pytest.raises(ValueError, match="not built"):
         ops.backward_precision("split-bf16")
     assert ops.backward_precision() == "f32"
+
+
+def test_band_kernel_has_no_scratch_behind_its_counted_wait(tmp_path):
+    """conv3x3_bwd_kernel<32, 512, BAND = true> (csrc/conv3x3_bwd.hip) orders its global -> LDS halo requests with a hand-counted
+    `s_waitcnt vmcnt(RPW)`: the count assumes that the only vector-memory operations issued after the requests are the RPW
+    stores of dx.  A register spill is a vector-memory operation on gfx9 and would break that count silently, so the build
+    is checked: the instantiation has no scratch and no scratch instruction (hipcc cross-compiles here, no GPU needed)."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "dynamorph_amd", "csrc", "conv3x3_bwd.hip")
+    asm = tmp_path / "conv3x3_bwd.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           "-S", "--cuda-device-only", "-o", str(asm), src], stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    name = "_ZN12_GLOBAL__N_118conv3x3_bwd_kernelILi32ELi512ELb1EEE"
+    start = text.index("\n" + name)
+    body = text[start:text.index("s_endpgm", start)]
+    assert "global_load_lds_dwordx4" in body                      # it IS the band form (the halo rows come in by LDS-DMA)
+    assert "scratch_" not in body
+    meta = text[text.index(".amdhsa_kernel " + name):]
+    assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[:meta.index(".end_amdhsa_kernel")])
