@@ -39,6 +39,9 @@
 #ifndef VQC_CELL_BATCH
 #define VQC_CELL_BATCH 4         // rows of the best cell requested together (8: measured below)
 #endif
+#ifndef VQC_ZF_EARLY
+#define VQC_ZF_EARLY 1
+#endif
 #ifndef VQC_ZPREFETCH
 #define VQC_ZPREFETCH 0          // 1: the next pass's latents are requested before this pass's tail (measured: no gain, more spills)
 #endif
@@ -282,6 +285,13 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
             }
         }
         VQC_STAMP(1)                                           // the code stream
+        // the owned positions' complete latent vectors are requested here: they land under the drain and the last group end
+        const long long own = (long long)pw * 128 + 4 * n + 2 * kh;                 // first owned position inside the sample
+        f32x2 zf[D];
+        if (VQC_ZF_EARLY) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) zf[d] = *reinterpret_cast<const f32x2 *>(z + ((long long)b * D + d) * HW + own);
+        }
         // drain: the last tile's accumulators have no matrix instruction behind them -- wait them out explicitly
         // (16 passes of the last instruction; s_nop counts issue cycles)
         __builtin_amdgcn_sched_barrier(0);
@@ -293,10 +303,10 @@ __global__ __launch_bounds__(256, 2) void vq_cells_kernel(
         VQC_STAMP(2)                                           // drain + last group end
         if (VQC_ZPREFETCH) load_z(pass + gridDim.x * 4u);
         // ---- the tail: everything of a position is in its owner's registers ----
-        const long long own = (long long)pw * 128 + 4 * n + 2 * kh;                 // first owned position inside the sample
-        f32x2 zf[D];
+        if (!VQC_ZF_EARLY) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) zf[d] = *reinterpret_cast<const f32x2 *>(z + ((long long)b * D + d) * HW + own);
+            for (int d = 0; d < D; ++d) zf[d] = *reinterpret_cast<const f32x2 *>(z + ((long long)b * D + d) * HW + own);
+        }
         float a1[2], thrv[2];
         int kown[2];
         bool flagged[2];
