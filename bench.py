@@ -337,6 +337,19 @@ def north_star_targets(model, x):
           "call_frac_hbm": round(vq_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
           "call_with_hist_ms": round(call_hist_ms, 5),
           "rechecked_positions": int(bufs[4][:1].view(torch.int32).item()) // 1}
+    # the same kernel on four times the positions (the batch repeated): how much of the stand-alone launch's shortfall is the
+    # launch's size -- 2.7 chunks per resident wave at B = 2048 -- and not the kernel's loop
+    try:
+        z4 = z.repeat(4, 1, 1, 1)
+        bufs4 = ops.vq_forward_repeat(z4, cbk, 1)
+        u1 = event_time_ms(lambda: ops.vq_forward_repeat(z4, cbk, 1, bufs=bufs4), iters=10, warmup=3)
+        u11 = event_time_ms(lambda: ops.vq_forward_repeat(z4, cbk, 11, bufs=bufs4), iters=5, warmup=1)
+        k4_ms = max((u11 - u1) / 10.0, 1e-6)
+        vq["back_to_back_launch_ms_at_4x_batch"] = round(k4_ms, 5)
+        vq["frac_hbm_at_4x_batch"] = round(4 * vq_bytes / (k4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        del z4, bufs4
+    except torch.cuda.OutOfMemoryError:
+        pass
     # the quantiser as the STEP dispatches it since round 4: the encoder's last residual join in its load path
     # (dm_vq_forward_join reads rb and h_in, writes z, the quantised value and the codes: twice the bytes in one launch)
     sv = cx.res[-1] if cx.res else None
