@@ -18,8 +18,8 @@
 //   * A position is settled by the filter when its second best CELL is farther than the proven tolerance from its best
 //     cell: every code outside the best cell is then farther than the tolerance from the best score, so the reference's
 //     argmin lies inside that cell, and the owning lane evaluates the cell's 8 codes in the reference's arithmetic and
-//     order (first minimum).  Otherwise the position goes to the exact re-check over the groups whose minimum is within
-//     the tolerance, as before.
+//     order (first minimum).  Otherwise the position goes to the exact re-check over the groups whose minimum (kept per
+//     position and group with 24 bits, rounded toward -inf) is within the tolerance: one LDS read and a ballot name them.
 //   * No LDS stream and no barrier in the loop: the A operand of a chunk (32 codes: 2 x 16 bytes per lane) comes straight
 //     from L2 into a register ring four chunks ahead; a wave keeps 128 positions (4 tiles) so that every operand fetched
 //     is used by 12 matrix instructions.  The norms (16 KB) stay in LDS; waves never wait for each other.
