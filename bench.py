@@ -509,7 +509,7 @@ def c2_record(model, steps=50, warmup=3, B=1024):
             "unit": "patches/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "hip_graph": True}
 
 
-def c5_record(dev, steps=8, warmup=3, B=1024):
+def c5_record(dev, steps=30, warmup=5, B=1024):
     """BASELINE.json configs[4]'s single-GPU leg beside the headline line, budgeted to a few seconds: the large-codebook
     stress model (4-channel 256 x 256 patches, 4096 codes) training step at its bench batch, and its K = 4096 distance /
     argmin kernel timed per dispatch on the model's own latents (`python bench.py --workload c5` is the full record)."""
