@@ -284,8 +284,10 @@ def residual_backward(res_layers, saved, g_h, G, q_below, pending=None, zero_fed
     return g_h, stats
 
 
-def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
-    """Accumulates nothing: every parameter gradient G(p) is overwritten.  No gradient flows to x.
+def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=(), want_dx=False):
+    """Accumulates nothing: every parameter gradient G(p) is overwritten.  want_dx: also returns the gradient w.r.t. the input
+    patches (the reference's training never asks for it; autograd there would answer) -- the data gradient of the composite
+    enc.0 o enc.1 convolution, a transposed convolution with the composite weights' image channels.
     zero_fed_biases=False skips writing the (identically zero) gradients of the conv biases that feed a
     BatchNorm -- for callers whose gradient buffer is zero there already (FusedTrainer)."""
     pending = list(pending_extra)                    # (slabs, dst) pairs that ride along in the one slab reduction
@@ -346,6 +348,13 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=()):
     ops.e1_chain(dweff, _w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight),
                  G(L.enc0.weight), G(L.enc0.bias), G(L.enc1.weight))
     _zero(G(L.enc1.bias), zero_fed_biases)
+    if want_dx:
+        # a1 = conv(x, Weff[:, :NIN]) + border bias: dx = ConvTranspose(da1, Weff[:, :NIN]) (phase-decomposed kernel family;
+        # the ones channel of the composite carries no gradient to x)
+        weff, _ = e1_operands(L)
+        dx, _ = ops.conv3x3(da1, weight_view(weff, 16, (NIN + 1) * 16, 4, 1), B, c1, 4 * NIN, H1, W1, taps=9, pixel_shuffle=True)
+        return dx
+    return None
 
 
 # ------------------------------------------------------------------------------------ VQ
@@ -523,7 +532,7 @@ def z32_stem_forward(conv0, bn0, conv1, bn1, x, per_sample=False):
     return h, cx
 
 
-def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G, stats=None, pending=None, zero_fed_biases=True):
+def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G, stats=None, pending=None, zero_fed_biases=True, want_dx=False):
     """stats: the (sum g, sum g*a2) slabs when the caller's last kernel already produced them (residual_backward with
     q_below = cx.a2); pending: the caller's list for ONE slab reduction of the whole backward pass (None: reduced here);
     zero_fed_biases=False: the gradient buffer is zero already (FusedTrainer) -- the identically zero gradients of the
@@ -552,6 +561,10 @@ def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G, stats=None, pending=No
     _zero(G(conv0.bias), zero_fed_biases)
     if own:
         ops.reduce_slabs_multi(pending)
+    if want_dx:          # the gradient w.r.t. the input patches: conv0's data gradient (see encoder_backward)
+        dx, _ = ops.conv3x3(da1, weight_view(_w(conv0.weight), 16, NIN * 16, 4, 1), B, c1, 4 * NIN, H1, W1, taps=9, pixel_shuffle=True)
+        return dx
+    return None
 
 
 def z32_tail_forward(up0, bn, up1, r, x, mask, channel_var):

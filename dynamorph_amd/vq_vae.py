@@ -65,11 +65,9 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_z):
         G = _GradBag()
-        E.encoder_backward(ctx.layers, ctx.cx, g_z, G)
+        dx = E.encoder_backward(ctx.layers, ctx.cx, g_z, G, want_dx=ctx.needs_input_grad[0])
         ctx.cx = None
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the input patches is not implemented (the reference never asks for it)")
-        return (None, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[3:])
+        return (dx, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[3:])
 
 
 class _ResidualFn(torch.autograd.Function):
@@ -111,6 +109,21 @@ class _VQFn(torch.autograd.Function):
         return dz, (dw if ctx.needs_input_grad[1] else None), None
 
 
+def _recon_input_grad(cx, channel_var, gscale):
+    """d(recon_loss) / d(inputs) of vq_vae.py:320-322 -- mean(((decoded - inputs) * mask)^2 / channel_var) -- for callers that
+    differentiate w.r.t. the patches (saliency maps; the reference's training never does): 2 (inputs - decoded) mask^2 /
+    (N channel_var), times the upstream gradient.  Plain elementwise torch on the device tensors the forward kept."""
+    if gscale is None or cx.x is None or getattr(cx, "dec", None) is None:
+        return None
+    x, dec = cx.x, cx.dec
+    g = (x - dec) * (2.0 / x.numel())
+    if cx.mask is not None:
+        g = g * (cx.mask * cx.mask)
+    if channel_var is not None:
+        g = g / channel_var.detach().reshape(1, -1, 1, 1)
+    return g * gscale.reshape(())
+
+
 class _DecoderFn(torch.autograd.Function):
     """decoded (and, when x is given, the masked reconstruction loss of vq_vae.py:320-322)."""
 
@@ -134,9 +147,10 @@ class _DecoderFn(torch.autograd.Function):
             g_dec = g_dec.contiguous()
         if gscale is None and g_dec is None:
             return (None,) * (4 + len(ctx.params))
+        g_x = _recon_input_grad(ctx.cx, ctx.layers.channel_var, gscale) if ctx.needs_input_grad[1] else None
         g_zq = E.decoder_backward(ctx.layers, ctx.cx, gscale, g_dec, G, want_gz=ctx.needs_input_grad[0])
         ctx.cx = None
-        return (g_zq, None, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[4:])
+        return (g_zq, g_x, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[4:])
 
 
 # ================================================================================ modules
@@ -417,12 +431,10 @@ class _Z32StemFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_h):
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the input patches is not implemented (the reference never asks for it)")
         G = _GradBag()
-        E.z32_stem_backward(*ctx.mods, ctx.cx, g_h, G)
+        dx = E.z32_stem_backward(*ctx.mods, ctx.cx, g_h, G, want_dx=ctx.needs_input_grad[0])
         ctx.cx = None
-        return (None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[2:])
+        return (dx, None) + G.grads_for(ctx.params, ctx.needs_input_grad[2:])
 
 
 class _Z32TailFn(torch.autograd.Function):
@@ -431,7 +443,7 @@ class _Z32TailFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, r, x, mask, channel_var, mods, *params):
         dec, cx = E.z32_tail_forward(*mods, r, x, mask, channel_var)
-        ctx.mods, ctx.cx, ctx.params = mods, cx, params
+        ctx.mods, ctx.cx, ctx.params, ctx.cvar = mods, cx, params, channel_var
         ctx.set_materialize_grads(False)
         if x is None:
             return dec, None
@@ -447,9 +459,10 @@ class _Z32TailFn(torch.autograd.Function):
         if gscale is None and g_dec is None:
             return (None,) * (5 + len(ctx.params))
         G = _GradBag()
+        g_x = _recon_input_grad(ctx.cx, ctx.cvar, gscale) if ctx.needs_input_grad[1] else None
         g_r = E.z32_tail_backward(*ctx.mods, ctx.cx, gscale, g_dec, G, want_gr=ctx.needs_input_grad[0])
         ctx.cx = None
-        return (g_r, None, None, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[5:])
+        return (g_r, g_x, None, None, None) + G.grads_for(ctx.params, ctx.needs_input_grad[5:])
 
 
 class _Z32Encoder(nn.Sequential):

@@ -879,6 +879,74 @@ def test_fused_trainer_z32_against_reference_vectors(golden):
     assert n >= 30
 
 
+@pytest.mark.parametrize("family,masked,with_tm", [("VQ_VAE", False, False), ("VQ_VAE", True, True), ("VQ_VAE_z16", True, True),
+                                                   ("VQ_VAE_z32", True, True)])
+def test_gradient_with_respect_to_the_input_patches(family, masked, with_tm):
+    """d(total_loss) / d(inputs) -- what autograd answers on the reference when a caller asks (saliency maps; its training never
+    does): the encoder's path (the data gradient of the first convolution) plus the reconstruction loss' own dependence on
+    the inputs, against the oracle's autograd on the float64 yardstick."""
+    import copy
+    import dynamorph_amd
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(91)
+    ref = (O.OracleVQVAEz32 if family == "VQ_VAE_z32" else O.OracleVQVAE)(**({"variant": "z16"} if family == "VQ_VAE_z16" else {}))
+    B = 3
+    x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(92))
+    kw = {}
+    if masked:
+        kw["batch_mask"] = (torch.rand(B, 1, 128, 128, generator=torch.Generator().manual_seed(93)) > 0.35).float()
+    if with_tm:
+        kw["time_matching_mat"] = torch.tensor([[2., 1., 0.], [1., 2., 1.], [0., 1., 2.]])
+    m = getattr(dynamorph_amd, family)().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    # a code that differs at a reference near-tie (conftest.codes_gate admits nothing else) changes the gradient around that
+    # position discretely: the yardsticks are then evaluated with the HIP path's codes (OracleVQ.force_idx)
+    with torch.no_grad():
+        probe, mp = copy.deepcopy(ref), copy.deepcopy(m)
+        z_r = probe.enc(x)
+        idx_r = probe.vq.encode_inputs(z_r)
+        idx = mp.vq.encode_inputs(mp.enc(x.to(DEV))).cpu()
+    codes_gate(idx != idx_r, z_r, probe.vq.w.weight.detach(), f"{family}, input gradient")
+    if bool((idx != idx_r).any()):
+        ref.vq.force_idx = idx.clone()
+    grads = {}
+    near_zero = []                                      # ReLU inputs the float64 run decides by less than fp32 rounding can move
+    for tag, model, cast in (("f32", ref, torch.float32), ("f64", copy.deepcopy(ref).double(), torch.float64)):
+        hooks = [mod.register_forward_hook(lambda _m, a, _o: near_zero.append(int((a[0].abs() < 4e-7 * a[0].abs().max()).sum())))
+                 for mod in model.modules() if isinstance(mod, torch.nn.ReLU)] if tag == "f64" else []
+        xi = x.detach().clone().to(cast).requires_grad_(True)
+        _, ld = model(xi, **{k: v.to(cast) for k, v in kw.items()})
+        for h in hooks:
+            h.remove()
+        ld["total_loss"].backward()
+        grads[tag] = xi.grad
+    xd = x.detach().to(DEV).requires_grad_(True)
+    _, ld = m(xd, **{k: v.to(DEV) for k, v in kw.items()})
+    ld["total_loss"].backward()
+    assert xd.grad is not None and xd.grad.shape == x.shape
+    truth = grads["f64"]
+    scale = truth.abs().max().item()
+    e_ref = (grads["f32"].double() - truth).abs().max().item()
+    e_hip = (xd.grad.cpu().double() - truth).abs().max().item()
+    fragile = sum(near_zero)
+    err = (xd.grad.cpu().double() - truth).abs()
+    tight = max(1.5 * e_ref, 2e-4 * scale) + 1e-12
+    off = int((err > tight).sum())
+    print(f"{family}: input gradient scale {scale:.2e}, error of the HIP path {e_hip:.2e}, of the fp32 reference {e_ref:.2e}; "
+          f"{off} of {err.numel()} elements beyond {tight:.1e}, {fragile} ReLU inputs within fp32 rounding of zero")
+    # everything tight -- except around a ReLU gate that fp32 rounding can flip (the float64 run counts the candidates): such a
+    # gate changes the input gradient inside ITS receptive field only (at most 64 x 64 pixels x 2 channels) and by a few percent
+    assert scale > 0 and off <= 8192 * fragile and e_hip <= (5e-2 * scale if fragile else tight), (family, e_hip, e_ref, scale, off, fragile)
+    # and the parameters' gradients are what they are without the input gradient
+    m2 = getattr(dynamorph_amd, family)().to(DEV)
+    m2.load_state_dict(ref.state_dict())
+    _, ld2 = m2(x.to(DEV), **{k: v.to(DEV) for k, v in kw.items()})
+    ld2["total_loss"].backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), k
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_fused_trainer_z32_with_extra_losses_against_reference_vectors(golden, use_graph):
     """FusedTrainer on a VQ_VAE_z32 with extra_loss (vae.py:463-469): the caller's torch functions run on z_after between the
