@@ -665,6 +665,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_wide_kernel(Operand S, Operand T
 
 }  // namespace
 
+bool dm_stream_conv1x1(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                       int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st);
+
 // ---- entry points used by the dispatchers in conv_mfma.hip / wgrad_mfma.hip (not part of the public header) ----------
 // base grid (output pixels for the strided / plain forms, input pixels for the transposed form) must tile by 8 x 16
 static int wide_disabled()
@@ -730,6 +733,7 @@ long long dm_wide_conv_scratch_floats(int form, int CIN, int NOUT, int taps)
 int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scratch, float *out, const Epilogue &ep, int B,
                  int Cphys, int CIN, int NOUT, int H, int W, int taps, int nslabs, int per_tile, hipStream_t st)
 {
+    if (form == W_S1 && taps == 1 && dm_stream_conv1x1(in, wv, out, ep, B, Cphys, CIN, NOUT, H, W, nslabs, per_tile, st)) return 0;
     const int BH = form == W_S2 ? H / 2 : H, BW = form == W_S2 ? W / 2 : W;
     const long long ntiles = (long long)B * (BH / 8) * (BW / 16);
     long long gx = per_tile ? B : ntiles;
@@ -758,6 +762,12 @@ int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scrat
     return 0;
 }
 
+// streaming forms of the memory-bound layers (wide_stream.hip)
+bool dm_stream_wgrad1x1_shape(int B, int CS, int CT, int Hs, int Ws);
+int dm_stream_wgrad1x1_slabs(int B, int Hs, int Ws);
+bool dm_stream_wgrad1x1(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int Hs, int Ws, int nslabs,
+                        hipStream_t st);
+
 bool dm_wide_wgrad_ok(int Hs, int Ws) { return !(wide_disabled() & 2) && Hs > 0 && Ws > 0 && Hs % 8 == 0 && Ws % 16 == 0; }
 
 static void wide_wgrad_grid(int CS, int CT, int k, int &gy, int &gz, int &cap)
@@ -772,6 +782,7 @@ static void wide_wgrad_grid(int CS, int CT, int k, int &gy, int &gz, int &cap)
 
 int dm_wide_wgrad_slabs(int B, int CS, int CT, int Hs, int Ws, int k)
 {
+    if (k == 1 && dm_stream_wgrad1x1_shape(B, CS, CT, Hs, Ws)) return dm_stream_wgrad1x1_slabs(B, Hs, Ws);
     int gy, gz, cap;
     wide_wgrad_grid(CS, CT, k, gy, gz, cap);
     const long long units = (long long)B * (Hs / 8) * (Ws / 16);
@@ -781,6 +792,7 @@ int dm_wide_wgrad_slabs(int B, int CS, int CT, int Hs, int Ws, int k)
 int dm_wide_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int CTphys, int Hs, int Ws,
                   int k, int nslabs, hipStream_t st)
 {
+    if (k == 1 && dm_stream_wgrad1x1(S, T, slabs, B, CS, CT, Hs, Ws, nslabs, st)) return 0;
     int gy, gz, cap;
     wide_wgrad_grid(CS, CT, k, gy, gz, cap);
     int gx = dm_wide_wgrad_slabs(B, CS, CT, Hs, Ws, k);

@@ -1,0 +1,374 @@
+// wide_stream.hip -- the wide family's memory-bound layers as streaming kernels: operands straight from global memory
+// into the matrix instruction's registers, no LDS tile, no workgroup barrier.
+//
+// conv_wide.hip's implicit GEMM stages every operand through LDS in chunks of 8 channels between two barriers.  That is the
+// right shape for the 3x3 / 4x4 layers at 64 channels (MFMA bound), and the wrong one where a layer moves more bytes than
+// it multiplies: the 1x1 convolutions of the residual blocks (64 -> 64: 6.4 GFLOP against 0.4-0.8 GB at B = 768) ran at
+// 1.3-2 TB/s because each 16 KB chunk waited out its own global round trip.  For a 1x1 layer the matrix instruction's
+// operand layout IS a memory layout: lane (i = l % 16, k = l / 16) of v_mfma_f32_16x16x4_f32 holds element (row i, k) of A
+// and (k, column i) of B.  With pixels as the K dimension a lane loads FOUR consecutive pixels of ITS channel (one 16-byte
+// load; the four lanes k = 0..3 of a channel cover 64 contiguous bytes) and the four values feed four K steps -- K step j
+// pairs lane k with pixel 4 k + j on both operands, which is all a sum over pixels needs.  Every wave runs its own stream of
+// 32-pixel groups (whole 128-byte lines per channel row), D groups in flight in registers, and nothing but the final slab write is shared.
+#include "dm_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+__device__ __forceinline__ f32x4 sx_max(f32x4 v, float lo)
+{
+    return (f32x4){__builtin_elementwise_maximum(v.x, lo), __builtin_elementwise_maximum(v.y, lo),
+                   __builtin_elementwise_maximum(v.z, lo), __builtin_elementwise_maximum(v.w, lo)};
+}
+
+// coefficient triple of an operand's channel c as the stream kernels apply it: y = max(c0 * x + (c1 * u + c2), lo) -- the
+// identity for the modes without coefficients (1 * x + 0: a -0 becomes +0, which no sum can tell apart), lo = 0 for the
+// ReLU modes and -inf otherwise (maximum(x, -inf) = x, a NaN stays a NaN: dm_relu's instruction either way)
+struct StreamCoef {
+    float c0, c1, c2;
+};
+__device__ __forceinline__ StreamCoef stream_coef(const Operand &op, int c)
+{
+    StreamCoef r{1.f, 0.f, 0.f};
+    if (op.mode >= DM_LOAD_AFFINE) {
+        const float *cf = op.coef + c * 4;
+        r.c0 = cf[0];
+        r.c1 = op.mode == DM_LOAD_AFFINE2 ? cf[1] : 0.f;
+        r.c2 = cf[2];
+    }
+    return r;
+}
+__device__ __forceinline__ float stream_floor(const Operand &op)
+{
+    return (op.mode == DM_LOAD_RELU || op.mode == DM_LOAD_AFFINE_RELU) ? 0.f : -__builtin_inff();
+}
+
+// ------------------------------------------------------------------------------------ weight gradient of a 1x1 layer
+// dW[cs][ct] = sum over samples and pixels of S'[cs][px] * T'[ct][px].  M = S channels (MT tiles of 16), N = T channels
+// (NT tiles), K = pixels.  Wave w of a workgroup owns M tile w % MT and NT * MT / 4 of the N tiles; its lanes load the S
+// rows of their own channel once per group and the T rows of NTW channels.  A workgroup takes a contiguous range of the
+// B * HW / 32 pixel groups (coefficients are shared by all samples: batch-statistics BatchNorm, the host checks), so the
+// stream runs across sample boundaries; its partial result is slab blockIdx.x.
+// S2: the S operand is AFFINE2 (two tensors).  D: groups of 32 pixels in flight per wave.
+template <int MT, int NT, bool S2, int D>
+__global__ __launch_bounds__(256, D <= 1 ? 4 : 3) void wgrad1x1_stream_kernel(Operand S, Operand T, float *__restrict__ slabs,
+                                                                            int B, int CS, int CT, int HW, int nslabs)
+{
+    constexpr int NG = 4 / MT, NTW = NT / NG;
+    static_assert(MT * NG == 4 && NTW * NG == NT, "four waves share MT x NT tiles");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kq = lane >> 4;
+    const int mt = wave % MT, ng = wave / MT;
+    const int gpp = HW >> 5;                                     // groups of 32 pixels per plane
+    const long long total = (long long)B * gpp;
+    const int q0 = (int)(total * blockIdx.x / gridDim.x), q1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int n = q1 - q0;
+
+    const int cs = mt * 16 + p, ct0 = ng * NTW * 16 + p;
+    const StreamCoef sc = stream_coef(S, cs);
+    const float slo = stream_floor(S), tlo = stream_floor(T);
+    StreamCoef tc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) tc[t] = stream_coef(T, ct0 + 16 * t);
+
+    const unsigned bytesS = (unsigned)((long long)B * CS * HW * 4), bytesT = (unsigned)((long long)B * CT * HW * 4);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.p0), 0, bytesS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S2 ? S.p1 : S.p0), 0, bytesS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T.p0), 0, bytesT, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.p0), 0, 0, 0x00020000);
+    const int voS = (cs * HW + 4 * kq) * 4, voT = (ct0 * HW + 4 * kq) * 4;
+    const int tstep = 16 * HW * 4;                              // bytes between the T channels of consecutive N tiles
+
+    // cursor of the next group to request: byte offsets of (sample, group) in S and T
+    int cb = q0 / gpp, cr = q0 - cb * gpp;
+    unsigned offS = (unsigned)(((long long)cb * CS * HW + cr * 32) * 4), offT = (unsigned)(((long long)cb * CT * HW + cr * 32) * 4);
+    const unsigned wrapS = (unsigned)(CS - 1) * HW * 4, wrapT = (unsigned)(CT - 1) * HW * 4;
+
+    // a stage = one group of 32 pixels: per channel row the two 64-byte halves of a 128-byte line, requested back to back
+    f32x4 rs[D][2], ru[D][2], rt[D][NTW][2];
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // live == false: empty descriptors, the loads return zeros without touching memory (the requests themselves stay
+    // unconditional: a load under a branch makes hipcc wait for everything in flight where the paths join)
+    auto issue = [&](auto dc, bool live) {
+        constexpr int d = decltype(dc)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rs[d][h] = __builtin_amdgcn_raw_buffer_load_b128(live ? rS : dead, voS, offS + 64 * h, 0);
+        if (S2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ru[d][h] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, voS, offS + 64 * h, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                rt[d][t][h] = __builtin_amdgcn_raw_buffer_load_b128(live ? rT : dead, voT, offT + t * tstep + 64 * h, 0);
+        offS += 128; offT += 128;
+        if (++cr == gpp) { cr = 0; offS += wrapS; offT += wrapT; }
+        __builtin_amdgcn_sched_barrier(0);          // requests leave in stage order: the oldest stage is the one waited for
+    };
+    auto multiply = [&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a = sc.c0 * rs[d][h] + (S2 ? sc.c1 * ru[d][h] + sc.c2 : (f32x4){sc.c2, sc.c2, sc.c2, sc.c2});
+            a = sx_max(a, slo);
+            f32x4 bt[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bt[t] = sx_max(tc[t].c0 * rt[d][t][h] + tc[t].c2, tlo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bt[t][j], acc[t], 0, 0, 0);
+        }
+    };
+    auto prologue = [&](auto self, auto dc) -> void {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d < D) { issue(dc, d < n); self(self, std::integral_constant<int, d + 1>{}); }
+    };
+    auto round = [&](auto self, auto dc, int i) -> void {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d < D) {
+            if (i + d < n) multiply(dc);
+            issue(dc, i + d + D < n);
+            self(self, std::integral_constant<int, d + 1>{}, i);
+        }
+    };
+    prologue(prologue, std::integral_constant<int, 0>{});
+    for (int i = 0; i < n; i += D) round(round, std::integral_constant<int, 0>{}, i);
+
+    // lane holds dW[cs = 16 mt + 4 kq + i][ct = 16 (ng NTW + t) + p]
+    const long long E = (long long)CS * CT;
+    float *row = slabs + (long long)blockIdx.x * E;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row[(long long)(mt * 16 + kq * 4 + i) * CT + (ng * NTW + t) * 16 + p] = acc[t][i];
+    for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+        for (long long e = threadIdx.x; e < E; e += 256) slabs[(long long)sl * E + e] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------- 1x1 convolution
+// out[co][px] = epilogue(sum over ci of W[co][ci] * in'[ci][px]).  M = output channels (the weights are the A operand and
+// stay in registers: MT x KS values per lane), N = pixels, K = input channels.  Lane (p, kq) of a K step loads the four
+// pixels px0 + 4 p .. + 3 of channel 4 ks + kq -- 16 lanes = 256 contiguous bytes of a channel row -- and the four values
+// are the B operands of four N tiles: N tile j, column p is pixel px0 + 4 p + j.  The accumulator of (M tile mt, N tile j)
+// then holds, per lane, channels 16 mt + 4 kq + i of that pixel, so the four N tiles of one (mt, i) are a float4 of
+// consecutive pixels: 256-byte row segments again on the way out (gate, residual and statistics operands come in the same
+// way).  A wave owns units of 64 pixels, R K steps of loads in flight across unit boundaries; the operand coefficients and
+// the epilogue's per-channel constants sit in LDS tables (written once per workgroup).
+template <int KS4, int MT, bool IN2, int R>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep,
+                                                                int B, int HW, int nslabs)
+{
+    constexpr int KS = 4 * KS4, CIN = 4 * KS, CO = 16 * MT;
+    static_assert(KS % R == 0, "the ring divides the K loop");
+    __shared__ __attribute__((aligned(16))) float s_cf[CIN * 4];        // (c0, c1, c2, floor) of input channel ci
+    __shared__ __attribute__((aligned(16))) float s_ep[CO * 4];         // (bias, gate c0, gate c2, -) of output channel co
+    __shared__ double s_red[4 * CO * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < CIN; i += 256) {
+        const StreamCoef c = stream_coef(in, i);
+        s_cf[i * 4] = c.c0; s_cf[i * 4 + 1] = c.c1; s_cf[i * 4 + 2] = c.c2; s_cf[i * 4 + 3] = stream_floor(in);
+    }
+    for (int i = tid; i < CO; i += 256) {
+        float mc0 = 1.f, mc2 = 0.f;
+        if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) { mc0 = ep.mask.coef[i * 4]; mc2 = ep.mask.coef[i * 4 + 2]; }
+        s_ep[i * 4] = ep.bias ? ep.bias[i] : 0.f; s_ep[i * 4 + 1] = mc0; s_ep[i * 4 + 2] = mc2; s_ep[i * 4 + 3] = 0.f;
+    }
+    float wA[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wA[mt][ks] = wv.w[wv.off + (long long)(16 * mt + p) * wv.sn + (long long)(4 * ks + kq) * wv.sc];
+    __syncthreads();
+
+    const int upp = HW >> 6;                                     // units of 64 pixels per plane
+    const long long total = (long long)B * upp;
+    const int u0 = (int)(total * blockIdx.x / gridDim.x), u1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int n = (u1 - u0 - wave + 3) >> 2;                     // this wave's units: u0 + wave, + 4, ...
+    const unsigned bytesI = (unsigned)((long long)B * CIN * HW * 4);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(IN2 ? in.p1 : in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, 0, 0x00020000);
+    const int voI = (kq * HW + 4 * p) * 4;
+    const int kstep = 4 * HW * 4;                                // bytes between the channel quads of consecutive K steps
+    auto unit_in = [&](int u) { const int b = u / upp, r = u - b * upp; return (unsigned)(((long long)b * CIN * HW + r * 64) * 4); };
+    auto unit_out = [&](int u) { const int b = u / upp, r = u - b * upp; return ((long long)b * CO * HW + r * 64); };
+
+    f32x4 rx[R], ru[R];
+    double st1 = 0.0, st2 = 0.0;                                 // lane p of row kq: channel 16 (p >> 2) + 4 kq + (p & 3)
+    unsigned offI = unit_in(u0 + wave < u1 ? u0 + wave : u0);
+    auto issue = [&](auto slot, int ks, bool live) {
+        constexpr int sl = decltype(slot)::value;
+        rx[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, voI, offI + ks * kstep, 0);
+        if (IN2) ru[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, voI, offI + ks * kstep, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto prologue = [&](auto self, auto kc) -> void {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < R) { issue(kc, k, n > 0); self(self, std::integral_constant<int, k + 1>{}); }
+    };
+    prologue(prologue, std::integral_constant<int, 0>{});
+
+    for (int it = 0; it < n; ++it) {
+        const int u = u0 + wave + 4 * it;
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool more = it + 1 < n;
+        const unsigned offN = unit_in(more ? u + 4 : u);
+        auto kloop = [&](auto self, auto kc) -> void {
+            constexpr int ks = decltype(kc)::value;
+            if constexpr (ks < KS) {
+                constexpr int sl = ks % R;
+                const f32x4 cf = *reinterpret_cast<const f32x4 *>(&s_cf[(4 * ks + kq) * 4]);
+                f32x4 x = cf.x * rx[sl] + (IN2 ? cf.y * ru[sl] + cf.z : (f32x4){cf.z, cf.z, cf.z, cf.z});
+                x = sx_max(x, cf.w);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[mt][ks], x[j], acc[mt][j], 0, 0, 0);
+                // the slot is free: K step ks + R of this unit, or ks + R - KS of the wave's next one
+                if constexpr (ks + R < KS) {
+                    issue(std::integral_constant<int, sl>{}, ks + R, true);
+                } else {
+                    if (ks + R == KS) offI = offN;
+                    issue(std::integral_constant<int, sl>{}, ks + R - KS, more);
+                }
+                self(self, std::integral_constant<int, ks + 1>{});
+            }
+        };
+        kloop(kloop, std::integral_constant<int, 0>{});
+
+        // ---- epilogue of the unit: (mt, i) -> channel 16 mt + 4 kq + i, pixels px0 + 4 p .. + 3
+        const long long ob = unit_out(u) + 4 * p;
+        float sel1 = 0.f, sel2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = 16 * mt + 4 * kq + i;
+                const f32x4 ec = *reinterpret_cast<const f32x4 *>(&s_ep[co * 4]);
+                const long long o = ob + (long long)co * HW;
+                f32x4 v = (f32x4){acc[mt][0][i], acc[mt][1][i], acc[mt][2][i], acc[mt][3][i]} + ec.x;
+                if (ep.relu) v = dm_relu4(v);
+                f32x4 m = v;
+                if (ep.mask.p0) {
+                    m = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o);
+                    v.x = (ec.y * m.x + ec.z) > 0.f ? v.x : 0.f; v.y = (ec.y * m.y + ec.z) > 0.f ? v.y : 0.f;
+                    v.z = (ec.y * m.z + ec.z) > 0.f ? v.z : 0.f; v.w = (ec.y * m.w + ec.z) > 0.f ? v.w : 0.f;
+                }
+                if (ep.resid) v += *reinterpret_cast<const f32x4 *>(ep.resid + o);
+                *reinterpret_cast<f32x4 *>(out + o) = v;
+                if (ep.stats) {
+                    f32x4 q = v;
+                    if (ep.stat_q) q = ep.stat_q == ep.mask.p0 ? m : *reinterpret_cast<const f32x4 *>(ep.stat_q + o);
+                    float a = (v.x + v.y) + (v.z + v.w), c = (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
+                    // sum over the 16 lanes of the row (the unit's 64 pixels); lane p == 4 mt + i keeps it
+                    a += dpp_mov<0xB1>(a); c += dpp_mov<0xB1>(c);
+                    a += dpp_mov<0x4E>(a); c += dpp_mov<0x4E>(c);
+                    a += dpp_mov<0x141>(a); c += dpp_mov<0x141>(c);
+                    a += dpp_mov<0x140>(a); c += dpp_mov<0x140>(c);
+                    sel1 = p == 4 * mt + i ? a : sel1;
+                    sel2 = p == 4 * mt + i ? c : sel2;
+                }
+            }
+        if (ep.stats && MT * 4 > p) { st1 += (double)sel1; st2 += (double)sel2; }
+    }
+
+    if (ep.stats) {
+        // lane (p, kq) holds channel 16 (p >> 2) + 4 kq + (p & 3) of this wave
+        if (p < 4 * MT) {
+            const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
+            s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2;
+        }
+        __syncthreads();
+        for (int i = tid; i < CO * 2; i += 256) {
+            double s = 0.0;
+            for (int w = 0; w < 4; ++w) s += s_red[(w * CO + (i >> 1)) * 2 + (i & 1)];
+            ep.stats[((long long)blockIdx.x * CO + (i >> 1)) * 2 + (i & 1)] = s;
+        }
+        for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+            for (int i = tid; i < CO * 2; i += 256) ep.stats[((long long)sl * CO + (i >> 1)) * 2 + (i & 1)] = 0.0;
+    }
+}
+
+int stream_switch()
+{
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution
+    return v;
+}
+int stream_depth()
+{
+    static const int v = getenv("DM_WIDE_STREAM_DEPTH") ? atoi(getenv("DM_WIDE_STREAM_DEPTH")) : 2;
+    return v;
+}
+
+}  // namespace
+
+// ---- entry points used by conv_wide.hip's dispatchers (not part of the public header) ----------------------------------
+// shapes the 1x1 streaming weight gradient is built for (operands are checked at the launch: dm_stream_wgrad1x1 returns
+// false and the caller falls back to the tiled kernel, which accepts any slab count)
+bool dm_stream_wgrad1x1_shape(int B, int CS, int CT, int Hs, int Ws)
+{
+    if (!(stream_switch() & 1)) return false;
+    const long long HW = (long long)Hs * Ws;
+    return (CS == 64 || CS == 32) && (CT == 64 || CT == 32) && HW % 32 == 0 && (long long)B * 64 * HW * 4 < (1LL << 32);
+}
+
+int dm_stream_wgrad1x1_slabs(int B, int Hs, int Ws)
+{
+    const long long groups = (long long)B * Hs * Ws / 32;
+    return (int)(groups < 768 ? groups : 768);                 // three workgroups per CU, one contiguous range each
+}
+
+bool dm_stream_wgrad1x1(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int Hs, int Ws, int nslabs,
+                        hipStream_t st)
+{
+    if (!dm_stream_wgrad1x1_shape(B, CS, CT, Hs, Ws) || T.ones || S.ones || T.mode == DM_LOAD_AFFINE2) return false;
+    if ((S.mode >= DM_LOAD_AFFINE && S.coef_bstride) || (T.mode >= DM_LOAD_AFFINE && T.coef_bstride)) return false;
+    int grid = dm_stream_wgrad1x1_slabs(B, Hs, Ws);
+    if (grid > nslabs) grid = nslabs;
+    const int HW = Hs * Ws;
+    const bool two = S.mode == DM_LOAD_AFFINE2, deep = stream_depth() >= 2;
+#define DM_SW(MT_, NT_)                                                                                                  \
+    if (CS == 16 * MT_ && CT == 16 * NT_) {                                                                              \
+        if (two && deep) hipLaunchKernelGGL((wgrad1x1_stream_kernel<MT_, NT_, true, 2>), dim3(grid), dim3(256), 0, st, S, T, slabs, B, CS, CT, HW, nslabs); \
+        else if (two) hipLaunchKernelGGL((wgrad1x1_stream_kernel<MT_, NT_, true, 1>), dim3(grid), dim3(256), 0, st, S, T, slabs, B, CS, CT, HW, nslabs); \
+        else if (deep) hipLaunchKernelGGL((wgrad1x1_stream_kernel<MT_, NT_, false, 2>), dim3(grid), dim3(256), 0, st, S, T, slabs, B, CS, CT, HW, nslabs); \
+        else hipLaunchKernelGGL((wgrad1x1_stream_kernel<MT_, NT_, false, 1>), dim3(grid), dim3(256), 0, st, S, T, slabs, B, CS, CT, HW, nslabs); \
+    }
+    DM_SW(4, 4) DM_SW(4, 2) DM_SW(2, 4) DM_SW(2, 2)
+#undef DM_SW
+    return true;
+}
+
+// 1x1 convolution, 64 -> 64 / 32 -> 32 ... channels (multiples of 16 up to 64 on both sides), shared coefficients, statistics
+// per workgroup.  Returns false when the call is not one the streaming kernel takes (the caller runs the tiled kernel).
+bool dm_stream_conv1x1(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                       int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st)
+{
+    if (!(stream_switch() & 2) || per_tile || Cphys != CIN || in.ones || ep.bias_border) return false;
+    const long long HW = (long long)H * W;
+    if (!((CIN == 64 || CIN == 32) && (NOUT == 64 || NOUT == 32)) || HW % 64 || (long long)B * 64 * HW * 4 >= (1LL << 32)) return false;
+    if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
+    if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
+    long long units = (long long)B * HW / 64;
+    int grid = (int)(units / 4 < 512 ? (units + 3) / 4 : 512);
+    if (ep.stats && grid > nslabs) grid = nslabs;
+    if (grid < 1) grid = 1;
+    const bool two = in.mode == DM_LOAD_AFFINE2;
+#define DM_SC(K4_, MT_)                                                                                                      \
+    if (CIN == 16 * K4_ && NOUT == 16 * MT_) {                                                                                \
+        if (two) hipLaunchKernelGGL((conv1x1_stream_kernel<K4_, MT_, true, 4>), dim3(grid), dim3(256), 0, st, in, wv, out, ep, B, (int)HW, nslabs); \
+        else hipLaunchKernelGGL((conv1x1_stream_kernel<K4_, MT_, false, 8>), dim3(grid), dim3(256), 0, st, in, wv, out, ep, B, (int)HW, nslabs); \
+    }
+    DM_SC(4, 4) DM_SC(4, 2) DM_SC(2, 4) DM_SC(2, 2)
+#undef DM_SC
+    return true;
+}

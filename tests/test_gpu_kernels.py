@@ -1794,3 +1794,67 @@ def test_conv_bwd_s2_fused_matches_autograd_and_the_two_kernels(ops, B, hw):
         ops.conv_bwd_s2_fused(dyop(), ops.Op(aid, 3, cTd), ops.weight_view(wd, 16, CX * 16, 4, 1), dstb, B, CD, CX, H, W,
                               mask=ops.Op(aid.clone(), 2, cTd))
 
+
+
+@pytest.mark.parametrize("B,cs,ct,hs,ws,smode,tmode", [(5, 64, 64, 16, 16, 4, 3), (3, 64, 64, 8, 16, 0, 1), (2, 32, 64, 16, 32, 3, 0),
+                                                       (7, 64, 32, 16, 16, 1, 3), (4, 32, 32, 8, 32, 4, 0), (1, 64, 64, 8, 16, 4, 3),
+                                                       (200, 64, 64, 16, 16, 4, 3)])
+def test_stream_wgrad_1x1(ops, B, cs, ct, hs, ws, smode, tmode):
+    """wide_stream.hip: the 1x1 weight gradient with both operands loaded straight into the matrix instruction's layout
+    (contiguous pixel ranges per workgroup, across sample boundaries; fewer groups than workgroups; every operand mode)."""
+    dy, a = rnd(B, cs, hs, ws, seed=1), rnd(B, cs, hs, ws, seed=2)
+    coef = torch.stack([rnd(cs, seed=3), rnd(cs, seed=4) * 0.1, rnd(cs, seed=5) * 0.1, torch.zeros(cs)], 1)
+    t = rnd(B, ct, hs, ws, seed=6)
+    tcoef = torch.stack([rnd(ct, seed=7), torch.zeros(ct), rnd(ct, seed=8) * 0.2, torch.zeros(ct)], 1)
+    w = torch.zeros(cs, ct, 1, 1, requires_grad=True)
+    F.conv2d(load_ref(t.double(), tmode, tcoef.double()), w.double(), None).backward(load_ref(dy.double(), smode, coef.double(), a.double()))
+    dst = torch.empty(cs, ct, 1, 1, device=DEV)
+    ops.wgrad(ops.Op(dy.to(DEV), smode, coef.to(DEV) if smode >= 2 else None, p1=a.to(DEV) if smode == 4 else None),
+              ops.Op(t.to(DEV), tmode, tcoef.to(DEV) if tmode >= 2 else None), dst, B, cs, ct, hs, ws, 1)
+    close(dst, w.grad.float(), 5e-5, 5e-5 * max(w.grad.abs().max().item(), 1e-6), "stream wgrad 1x1")
+
+
+@pytest.mark.parametrize("B,cin,nout,h,w,mode,transposed,epi", [
+    (3, 64, 64, 16, 16, 3, False, "stats"), (2, 64, 64, 8, 16, 4, True, "gate+q"), (5, 32, 64, 16, 16, 1, False, "all"),
+    (2, 64, 32, 16, 32, 0, True, "none"), (7, 32, 32, 8, 16, 4, False, "gate"), (1, 64, 64, 8, 16, 3, False, "all"),
+    (150, 64, 64, 16, 16, 4, True, "gate+q")])
+def test_stream_conv_1x1(ops, B, cin, nout, h, w, mode, transposed, epi):
+    """wide_stream.hip: the 1x1 convolution with the weights in registers and the activations loaded straight into the matrix
+    instruction's layout -- forward (BatchNorm + ReLU folded into the load, statistics) and data-gradient form (AFFINE2 load,
+    transposed weight view, gate, statistics against the gate's tensor), bias / ReLU / residual, units across sample boundaries."""
+    x, x1 = rnd(B, cin, h, w, seed=1), rnd(B, cin, h, w, seed=2)
+    coef = torch.stack([rnd(cin, seed=3).abs() + 0.5, rnd(cin, seed=4) * 0.2, rnd(cin, seed=5) * 0.3, torch.zeros(cin)], 1)
+    xin = load_ref(x.double(), mode, coef.double(), x1.double())
+    inp = ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, p1=x1.to(DEV) if mode == 4 else None)
+    if transposed:
+        wt = rnd(cin, nout, 1, 1, seed=6, scale=0.2)
+        wv, wref = ops.weight_view(wt.to(DEV), 1, nout, 0, 0), wt.permute(1, 0, 2, 3)
+    else:
+        wt = rnd(nout, cin, 1, 1, seed=6, scale=0.2)
+        wv, wref = ops.weight_view(wt.to(DEV), cin, 1, 0, 0), wt
+    kw, ref = {}, None
+    bias = rnd(nout, seed=7) if epi == "all" else None
+    ref = F.conv2d(xin, wref.double(), bias.double() if bias is not None else None)
+    if bias is not None:
+        kw.update(bias=bias.to(DEV), relu=True)
+        ref = F.relu(ref)
+    gate, q, resid = rnd(B, nout, h, w, seed=8), rnd(B, nout, h, w, seed=9), rnd(B, nout, h, w, seed=10)
+    mcoef = torch.stack([rnd(nout, seed=11), torch.zeros(nout), rnd(nout, seed=12) * 0.3, torch.zeros(nout)], 1)
+    if epi in ("gate", "gate+q", "all"):
+        kw.update(mask=ops.Op(gate.to(DEV), 2, mcoef.to(DEV)))
+        ref = ref * ((mcoef[:, 0].view(1, -1, 1, 1) * gate + mcoef[:, 2].view(1, -1, 1, 1)) > 0)
+    if epi == "all":
+        kw.update(resid=resid.to(DEV))
+        ref = ref + resid
+    sq = None
+    if epi == "gate+q":
+        gd = kw["mask"].p0
+        kw.update(stat_q=gd)                       # the training step's form: statistics against the gate's own tensor
+        sq = gate
+    elif epi == "all":
+        kw.update(stat_q=q.to(DEV))
+        sq = q
+    out, st = ops.conv3x3(inp, wv, B, cin, nout, h, w, taps=1, want_stats=epi != "none", **kw)
+    close(out, ref.float(), 5e-5, 5e-5, "stream conv 1x1")
+    if st is not None:
+        close_stats(st.sum(0), ref.float(), sq)
