@@ -768,6 +768,11 @@ int dm_stream_wgrad1x1_slabs(int B, int Hs, int Ws);
 bool dm_stream_wgrad1x1(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int Hs, int Ws, int nslabs,
                         hipStream_t st);
 
+bool dm_stream_wgrad_s2_thin_shape(int B, int CS, int CT, int Hs, int Ws);
+int dm_stream_wgrad_s2_thin_slabs(int B, int Hs, int Ws);
+bool dm_stream_wgrad_s2_thin(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int Hs, int Ws, int nslabs,
+                             hipStream_t st);
+
 bool dm_wide_wgrad_ok(int Hs, int Ws) { return !(wide_disabled() & 2) && Hs > 0 && Ws > 0 && Hs % 8 == 0 && Ws % 16 == 0; }
 
 static void wide_wgrad_grid(int CS, int CT, int k, int &gy, int &gz, int &cap)
@@ -783,6 +788,7 @@ static void wide_wgrad_grid(int CS, int CT, int k, int &gy, int &gz, int &cap)
 int dm_wide_wgrad_slabs(int B, int CS, int CT, int Hs, int Ws, int k)
 {
     if (k == 1 && dm_stream_wgrad1x1_shape(B, CS, CT, Hs, Ws)) return dm_stream_wgrad1x1_slabs(B, Hs, Ws);
+    if (k == 4 && dm_stream_wgrad_s2_thin_shape(B, CS, CT, Hs, Ws)) return dm_stream_wgrad_s2_thin_slabs(B, Hs, Ws);
     int gy, gz, cap;
     wide_wgrad_grid(CS, CT, k, gy, gz, cap);
     const long long units = (long long)B * (Hs / 8) * (Ws / 16);
@@ -793,6 +799,7 @@ int dm_wide_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
                   int k, int nslabs, hipStream_t st)
 {
     if (k == 1 && dm_stream_wgrad1x1(S, T, slabs, B, CS, CT, Hs, Ws, nslabs, st)) return 0;
+    if (k == 4 && CT == CTphys && dm_stream_wgrad_s2_thin(S, T, slabs, B, CS, CT, Hs, Ws, nslabs, st)) return 0;
     int gy, gz, cap;
     wide_wgrad_grid(CS, CT, k, gy, gz, cap);
     int gx = dm_wide_wgrad_slabs(B, CS, CT, Hs, Ws, k);

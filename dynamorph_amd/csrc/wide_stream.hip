@@ -150,6 +150,150 @@ __global__ __launch_bounds__(256, D <= 1 ? 4 : 3) void wgrad1x1_stream_kernel(Op
         for (long long e = threadIdx.x; e < E; e += 256) slabs[(long long)sl * E + e] = 0.f;
 }
 
+// --------------------------------------------------- weight gradient of a 4x4 / stride 2 layer with few T channels
+// dW[cs][ct][ky][kx] = sum of S'[cs][y][x] * T'[ct][2 y + ky - 1][2 x + kx - 1]: the first convolution of the wide encoder
+// and the last transposed convolution of its decoder (T = the image side, 1-4 channels, twice the S grid).  6.4 GFLOP against
+// 0.5-0.9 GB at B = 768: the tiled kernel spent 19 us per 32 KB unit on dependent round trips (0.6-1.0 TB/s).  M = S
+// channels, N = (T channel, tap): one N tile of 16 taps per T channel, lane p = tap (ky, kx) = (p >> 2, p & 3); K = S pixels,
+// the S rows loaded as in the 1x1 kernel.  For K step j lane (p, kq) needs T at column 2 (x0 + 4 kq + j) + kx - 1: the
+// elements 0, 2, 4, 6 of the 8 floats from column 2 x0 + 8 kq + kx - 1 on (two unaligned 16-byte loads; the taps of a row
+// read overlapping lines, which the vector L1 absorbs -- T is an eighth of the bytes).  Rows above / below the image and
+// the columns -1 / Wt are zeroed after the transform.  Every wave owns ALL MT x NT tiles over its own stages of 32 pixels; the
+// four waves of a workgroup add up through LDS into slab blockIdx.x.
+template <int MT, int NT, bool S2, int D>
+__global__ __launch_bounds__(256, 3) void wgrad_s2_thin_stream_kernel(Operand S, Operand T, float *__restrict__ slabs, int B,
+                                                                      int CS, int Hs, int Ws, int nslabs)
+{
+    constexpr int CT = NT;
+    __shared__ float s_acc[4 * MT * NT * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kq = lane >> 4;
+    const int ky = p >> 2, kx = p & 3;
+    const int Ht = 2 * Hs, Wt = 2 * Ws, gx = Ws >> 5;
+    const long long total = (long long)B * Hs * gx;              // stages of 32 pixels
+    const int w4 = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int q0 = (int)(total * w4 / nw), q1 = (int)(total * (w4 + 1) / nw);
+    const int n = q1 - q0;
+
+    StreamCoef sc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) sc[mt] = stream_coef(S, mt * 16 + p);
+    StreamCoef tc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tc[t] = stream_coef(T, t);
+    const float slo = stream_floor(S), tlo = stream_floor(T);
+    const bool t_ident = T.mode == DM_LOAD_IDENT;
+
+    const unsigned bytesS = (unsigned)((long long)B * CS * Hs * Ws * 4), bytesT = (unsigned)((long long)B * CT * Ht * Wt * 4);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.p0), 0, bytesS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S2 ? S.p1 : S.p0), 0, bytesS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T.p0), 0, bytesT, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.p0), 0, 0, 0x00020000);
+    const int voS = (p * Hs * Ws + 4 * kq) * 4, sstep = 16 * Hs * Ws * 4;
+    // T: byte offset of the lane's first element relative to (sample, row 2 y, column 2 x0).  At the tensor's first row the
+    // sum is negative for the lanes of row -1 (zeroed anyway) and -4 for tap (1, 0) of the first column: a negative offset
+    // fails the descriptor's range check for ALL FOUR dwords, so those lanes load from offset 0 and take their elements one
+    // position further left (multiply())
+    const int voT = ((ky - 1) * Wt + 8 * kq + kx - 1) * 4, tstep = Ht * Wt * 4;
+
+    int cb = q0 / (Hs * gx), cy = (q0 - cb * Hs * gx) / gx, cxg = q0 - (cb * Hs + cy) * gx;     // cursor of the next request
+    f32x4 rs[D][MT][2], ru[D][MT][2], rt[D][NT][2][2];
+    int sy[D], sx[D];                                            // row and first column of the stage in each slot
+    bool s0[D];                                                  // the stage is the tensor's first
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](auto dc, bool live) {
+        constexpr int d = decltype(dc)::value;
+        const unsigned offS = (unsigned)((((long long)cb * CS * Hs + cy) * Ws + cxg * 32) * 4);
+        const int baseT = (int)((((long long)cb * CT * Ht + 2 * cy) * Wt + cxg * 64) * 4);
+        sy[d] = cy; sx[d] = cxg * 32; s0[d] = (cb | cy | cxg) == 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                rs[d][mt][h] = __builtin_amdgcn_raw_buffer_load_b128(live ? rS : dead, voS, offS + mt * sstep + 64 * h, 0);
+                if (S2) ru[d][mt][h] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, voS, offS + mt * sstep + 64 * h, 0);
+            }
+        const int vt = baseT + voT, vt0 = vt < 0 ? 0 : vt;       // (negative for channel 0 only: a channel is more than a row)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int v = t == 0 && h == 0 ? vt0 : vt + t * tstep + 128 * h;
+                rt[d][t][h][0] = __builtin_amdgcn_raw_buffer_load_b128(live ? rT : dead, v, 0, 0);
+                rt[d][t][h][1] = __builtin_amdgcn_raw_buffer_load_b128(live ? rT : dead, v + 16, 0, 0);
+            }
+        if (++cxg == gx) { cxg = 0; if (++cy == Hs) { cy = 0; ++cb; } }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto multiply = [&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        const bool row_out = (sy[d] == 0 && ky == 0) || (sy[d] == Hs - 1 && ky == 3);
+        const bool first = row_out || (sx[d] == 0 && kq == 0 && kx == 0);               // column -1: K step 0 of half 0
+        const bool last = row_out || (sx[d] + 32 == Ws && kq == 3 && kx == 3);           // column Wt: K step 3 of half 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = sx_max(sc[mt].c0 * rs[d][mt][h] + (S2 ? sc[mt].c1 * ru[d][mt][h] + sc[mt].c2
+                                                             : (f32x4){sc[mt].c2, sc[mt].c2, sc[mt].c2, sc[mt].c2}), slo);
+            f32x4 bt[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 e = (f32x4){rt[d][t][h][0].x, rt[d][t][h][0].z, rt[d][t][h][1].x, rt[d][t][h][1].z};
+                if (t == 0 && h == 0 && s0[d] && ky == 1 && kq == 0 && kx == 0)      // loaded from column 0 instead of -1
+                    e = (f32x4){0.f, rt[d][t][h][0].y, rt[d][t][h][0].w, rt[d][t][h][1].y};
+                if (!t_ident) e = sx_max(tc[t].c0 * e + tc[t].c2, tlo);
+                e.x = (h == 0 ? first : row_out) ? 0.f : e.x;
+                e.y = row_out ? 0.f : e.y;
+                e.z = row_out ? 0.f : e.z;
+                e.w = (h == 1 ? last : row_out) ? 0.f : e.w;
+                bt[t] = e;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], bt[t][j], acc[mt][t], 0, 0, 0);
+        }
+    };
+    auto prologue = [&](auto self, auto dc) -> void {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d < D) { issue(dc, d < n); self(self, std::integral_constant<int, d + 1>{}); }
+    };
+    auto round = [&](auto self, auto dc, int i) -> void {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d < D) {
+            if (i + d < n) multiply(dc);
+            issue(dc, i + d + D < n);
+            self(self, std::integral_constant<int, d + 1>{}, i);
+        }
+    };
+    prologue(prologue, std::integral_constant<int, 0>{});
+    for (int i = 0; i < n; i += D) round(round, std::integral_constant<int, 0>{}, i);
+
+    // the four waves' partial sums -> slab blockIdx.x; lane holds dW[cs = 16 mt + 4 kq + i][ct = t][tap = p]
+    const int E = CS * CT * 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_acc[wave * (MT * NT * 256) + ((mt * 16 + kq * 4 + i) * CT + t) * 16 + p] = acc[mt][t][i];
+    __syncthreads();
+    float *row = slabs + (long long)blockIdx.x * E;
+    for (int e = threadIdx.x; e < MT * NT * 256; e += 256)
+        row[e] = (s_acc[e] + s_acc[MT * NT * 256 + e]) + (s_acc[2 * MT * NT * 256 + e] + s_acc[3 * MT * NT * 256 + e]);
+    for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+        for (int e = threadIdx.x; e < E; e += 256) slabs[(long long)sl * E + e] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------- 1x1 convolution
 // out[co][px] = epilogue(sum over ci of W[co][ci] * in'[ci][px]).  M = output channels (the weights are the A operand and
 // stay in registers: MT x KS values per lane), N = pixels, K = input channels.  Lane (p, kq) of a K step loads the four
@@ -300,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Operand in, Weig
 
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient
     return v;
 }
 int stream_depth()
@@ -370,5 +514,37 @@ bool dm_stream_conv1x1(const Operand &in, const WeightView &wv, float *out, cons
     }
     DM_SC(4, 4) DM_SC(4, 2) DM_SC(2, 4) DM_SC(2, 2)
 #undef DM_SC
+    return true;
+}
+
+// weight gradient of a 4x4 / stride 2 layer with 16 / 32 / 64 S channels and 1-4 T channels
+bool dm_stream_wgrad_s2_thin_shape(int B, int CS, int CT, int Hs, int Ws)
+{
+    if (!(stream_switch() & 4)) return false;
+    return (CS == 16 || CS == 32 || CS == 64) && CT >= 1 && CT <= (CS == 64 ? 1 : 4) && Ws % 32 == 0 &&
+           (long long)B * CS * Hs * Ws * 4 < (1LL << 31) && (long long)B * CT * Hs * Ws * 16 < (1LL << 31);
+}
+
+int dm_stream_wgrad_s2_thin_slabs(int B, int Hs, int Ws)
+{
+    const long long stages = (long long)B * Hs * (Ws / 32);
+    return (int)(stages / 4 < 768 ? (stages + 3) / 4 : 768);
+}
+
+bool dm_stream_wgrad_s2_thin(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int Hs, int Ws, int nslabs,
+                             hipStream_t st)
+{
+    if (!dm_stream_wgrad_s2_thin_shape(B, CS, CT, Hs, Ws) || T.ones || S.ones || T.mode == DM_LOAD_AFFINE2) return false;
+    if ((S.mode >= DM_LOAD_AFFINE && S.coef_bstride) || (T.mode >= DM_LOAD_AFFINE && T.coef_bstride)) return false;
+    int grid = dm_stream_wgrad_s2_thin_slabs(B, Hs, Ws);
+    if (grid > nslabs) grid = nslabs;
+    const bool two = S.mode == DM_LOAD_AFFINE2;
+#define DM_ST(MT_, NT_)                                                                                                      \
+    if (CS == 16 * MT_ && CT == NT_) {                                                                                        \
+        if (two) hipLaunchKernelGGL((wgrad_s2_thin_stream_kernel<MT_, NT_, true, 1>), dim3(grid), dim3(256), 0, st, S, T, slabs, B, CS, Hs, Ws, nslabs); \
+        else hipLaunchKernelGGL((wgrad_s2_thin_stream_kernel<MT_, NT_, false, 1>), dim3(grid), dim3(256), 0, st, S, T, slabs, B, CS, Hs, Ws, nslabs); \
+    }
+    DM_ST(1, 1) DM_ST(1, 2) DM_ST(1, 3) DM_ST(1, 4) DM_ST(2, 1) DM_ST(2, 2) DM_ST(2, 3) DM_ST(2, 4) DM_ST(4, 1)
+#undef DM_ST
     return true;
 }

@@ -1858,3 +1858,23 @@ def test_stream_conv_1x1(ops, B, cin, nout, h, w, mode, transposed, epi):
     close(out, ref.float(), 5e-5, 5e-5, "stream conv 1x1")
     if st is not None:
         close_stats(st.sum(0), ref.float(), sq)
+
+
+@pytest.mark.parametrize("B,cs,ct,hs,ws,smode,tmode", [(3, 32, 2, 64, 64, 4, 0), (2, 32, 2, 8, 32, 3, 0), (2, 16, 4, 16, 32, 0, 3),
+                                                       (5, 32, 1, 16, 64, 1, 1), (2, 64, 1, 8, 32, 4, 3), (1, 32, 3, 8, 32, 4, 0),
+                                                       (40, 32, 2, 64, 64, 4, 0)])
+def test_stream_wgrad_4x4s2_few_t_channels(ops, B, cs, ct, hs, ws, smode, tmode):
+    """wide_stream.hip: weight gradient of the wide encoder's first convolution / the decoder's last transposed convolution
+    (T = the image side with 1-4 channels): taps as the N dimension, T read by unaligned loads straight from global memory,
+    borders zeroed after the transform; stages across row and sample boundaries."""
+    dy, a = rnd(B, cs, hs, ws, seed=1), rnd(B, cs, hs, ws, seed=2)
+    coef = torch.stack([rnd(cs, seed=3), rnd(cs, seed=4) * 0.1, rnd(cs, seed=5) * 0.1, torch.zeros(cs)], 1)
+    t = rnd(B, ct, 2 * hs, 2 * ws, seed=6)
+    tcoef = torch.stack([rnd(ct, seed=7), torch.zeros(ct), rnd(ct, seed=8) * 0.2 + 0.3, torch.zeros(ct)], 1)
+    w = torch.zeros(cs, ct, 4, 4, requires_grad=True, dtype=torch.float64)
+    F.conv2d(load_ref(t.double(), tmode, tcoef.double()), w, None, stride=2, padding=1).backward(
+        load_ref(dy.double(), smode, coef.double(), a.double()))
+    dst = torch.empty(cs, ct, 4, 4, device=DEV)
+    ops.wgrad(ops.Op(dy.to(DEV), smode, coef.to(DEV) if smode >= 2 else None, p1=a.to(DEV) if smode == 4 else None),
+              ops.Op(t.to(DEV), tmode, tcoef.to(DEV) if tmode >= 2 else None), dst, B, cs, ct, hs, ws, 4)
+    close(dst, w.grad.float(), 5e-5, 5e-5 * max(w.grad.abs().max().item(), 1e-6), "stream wgrad 4x4/s2")
