@@ -294,6 +294,78 @@ __global__ __launch_bounds__(256, 3) void wgrad_s2_thin_stream_kernel(Operand S,
         for (int e = threadIdx.x; e < E; e += 256) slabs[(long long)sl * E + e] = 0.f;
 }
 
+// Epilogue of a unit of 64 output pixels shared by the streaming convolutions: acc[mt][j][i] is channel 16 mt + 4 kq + i of
+// pixel 4 p + j, so the four N tiles of one (mt, i) are a float4 of consecutive pixels.  ob: offset of (sample, channel 0, the
+// lane's first pixel); cstride: elements per channel plane; s_ep[co] = (bias, gate c0, gate c2, -).  Statistics: the sum over
+// the 16 lanes of a row (the unit's 64 pixels) in float, then lane p == 4 mt + i of row kq adds it to ITS channel's double.
+// PRE: the gate's values were requested ahead (gm[mt][i], same addresses as the output).
+template <int MT, bool PRE = false>
+__device__ __forceinline__ void stream_epilogue(const f32x4 (&acc)[MT][4], const Epilogue &ep, const float *s_ep, float *__restrict__ out,
+                                                long long ob, long long cstride, int p, int kq, double &st1, double &st2,
+                                                const f32x4 (*gm)[4] = nullptr)
+{
+    float sel1 = 0.f, sel2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = 16 * mt + 4 * kq + i;
+            const f32x4 ec = *reinterpret_cast<const f32x4 *>(&s_ep[co * 4]);
+            const long long o = ob + (long long)co * cstride;
+            f32x4 v = (f32x4){acc[mt][0][i], acc[mt][1][i], acc[mt][2][i], acc[mt][3][i]} + ec.x;
+            if (ep.relu) v = dm_relu4(v);
+            f32x4 m = v;
+            if (ep.mask.p0) {
+                m = PRE ? gm[mt][i] : *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o);
+                v.x = (ec.y * m.x + ec.z) > 0.f ? v.x : 0.f; v.y = (ec.y * m.y + ec.z) > 0.f ? v.y : 0.f;
+                v.z = (ec.y * m.z + ec.z) > 0.f ? v.z : 0.f; v.w = (ec.y * m.w + ec.z) > 0.f ? v.w : 0.f;
+            }
+            if (ep.resid) v += *reinterpret_cast<const f32x4 *>(ep.resid + o);
+            *reinterpret_cast<f32x4 *>(out + o) = v;
+            if (ep.stats) {
+                f32x4 q = v;
+                if (ep.stat_q) q = ep.stat_q == ep.mask.p0 ? m : *reinterpret_cast<const f32x4 *>(ep.stat_q + o);
+                float a = (v.x + v.y) + (v.z + v.w), c = (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
+                a += dpp_mov<0xB1>(a); c += dpp_mov<0xB1>(c);
+                a += dpp_mov<0x4E>(a); c += dpp_mov<0x4E>(c);
+                a += dpp_mov<0x141>(a); c += dpp_mov<0x141>(c);
+                a += dpp_mov<0x140>(a); c += dpp_mov<0x140>(c);
+                sel1 = p == 4 * mt + i ? a : sel1;
+                sel2 = p == 4 * mt + i ? c : sel2;
+            }
+        }
+    if (ep.stats && MT * 4 > p) { st1 += (double)sel1; st2 += (double)sel2; }
+}
+
+// the workgroup's statistics slab from its four waves' per-lane sums (lane (p, kq): channel 16 (p >> 2) + 4 kq + (p & 3))
+template <int CO>
+__device__ __forceinline__ void stream_stats_out(const Epilogue &ep, double *s_red, double st1, double st2, int nslabs)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    if (p < CO / 4) {
+        const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
+        s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2;
+    }
+    __syncthreads();
+    for (int i = tid; i < CO * 2; i += 256) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += s_red[(w * CO + (i >> 1)) * 2 + (i & 1)];
+        ep.stats[((long long)blockIdx.x * CO + (i >> 1)) * 2 + (i & 1)] = s;
+    }
+    for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+        for (int i = tid; i < CO * 2; i += 256) ep.stats[((long long)sl * CO + (i >> 1)) * 2 + (i & 1)] = 0.0;
+}
+
+// the epilogue's per-channel constants (bias, gate coefficients) -> s_ep[CO][4]; the caller synchronises
+__device__ __forceinline__ void stream_stage_ep(const Epilogue &ep, float *s_ep, int CO)
+{
+    for (int i = threadIdx.x; i < CO; i += 256) {
+        float mc0 = 1.f, mc2 = 0.f;
+        if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) { mc0 = ep.mask.coef[i * 4]; mc2 = ep.mask.coef[i * 4 + 2]; }
+        s_ep[i * 4] = ep.bias ? ep.bias[i] : 0.f; s_ep[i * 4 + 1] = mc0; s_ep[i * 4 + 2] = mc2; s_ep[i * 4 + 3] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- 1x1 convolution
 // out[co][px] = epilogue(sum over ci of W[co][ci] * in'[ci][px]).  M = output channels (the weights are the A operand and
 // stay in registers: MT x KS values per lane), N = pixels, K = input channels.  Lane (p, kq) of a K step loads the four
@@ -317,11 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Operand in, Weig
         const StreamCoef c = stream_coef(in, i);
         s_cf[i * 4] = c.c0; s_cf[i * 4 + 1] = c.c1; s_cf[i * 4 + 2] = c.c2; s_cf[i * 4 + 3] = stream_floor(in);
     }
-    for (int i = tid; i < CO; i += 256) {
-        float mc0 = 1.f, mc2 = 0.f;
-        if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) { mc0 = ep.mask.coef[i * 4]; mc2 = ep.mask.coef[i * 4 + 2]; }
-        s_ep[i * 4] = ep.bias ? ep.bias[i] : 0.f; s_ep[i * 4 + 1] = mc0; s_ep[i * 4 + 2] = mc2; s_ep[i * 4 + 3] = 0.f;
-    }
+    stream_stage_ep(ep, s_ep, CO);
     float wA[MT][KS];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -389,62 +457,123 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Operand in, Weig
         };
         kloop(kloop, std::integral_constant<int, 0>{});
 
-        // ---- epilogue of the unit: (mt, i) -> channel 16 mt + 4 kq + i, pixels px0 + 4 p .. + 3
-        const long long ob = unit_out(u) + 4 * p;
-        float sel1 = 0.f, sel2 = 0.f;
+        stream_epilogue<MT>(acc, ep, s_ep, out, unit_out(u) + 4 * p, HW, p, kq, st1, st2);
+    }
+
+    if (ep.stats) stream_stats_out<CO>(ep, s_red, st1, st2, nslabs);
+}
+
+// ------------------------------------------------------- 4x4 / stride 2 convolution with few input channels
+// out[co][oy][ox] = sum over (ci, ky, kx) of W[co][ci][ky][kx] * in'[ci][2 oy + ky - 1][2 ox + kx - 1]: the wide encoder's first
+// convolution (image -> 32 channels) and the data gradient of the decoder's last transposed convolution; 64 output columns
+// (128-pixel patches).  K = (ci, ky, kx): K step (ci, kx), lane row kq = ky, so the four rows of lanes read four DIFFERENT
+// input rows and nothing is requested twice.  A unit is one output row; for N tile j lane p holds pixel 4 p + j, whose input
+// column is 8 p + kx - 1 + 2 j: lane p loads the 8 aligned floats 8 p .. 8 p + 7 of its row (16 lanes = 512 contiguous bytes),
+// takes column 8 p - 1 from lane p - 1 and 8 p + 8 from lane p + 1 (DPP row shifts: the lanes beyond the row's ends read the 0
+// of the padding) and has the operands of all four kx: (a-1, a1, a3, a5), (a0, a2, a4, a6), (a1, a3, a5, a7), (a2, a4, a6, a8).
+// Two loads per input channel and unit instead of one pair per K step -- the form with kq = kx and unaligned 8-float windows
+// asked the texture addresser for four times the bytes and ran at 1.8 TB/s.  Rows -1 / H (first and last output row) are
+// zeroed after the transform.  The next unit's inputs are requested once this unit's are transformed, its gate values once
+// this unit's are used: vector memory returns in order, a gate load issued inside the epilogue would wait for everything
+// requested before it.
+template <int CIN, int MT>
+__global__ __launch_bounds__(256, (CIN * MT >= 6 || MT == 4) ? 2 : 3) void conv_s2_thin_stream_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep,
+                                                                     int B, int H, int nslabs)
+{
+    constexpr int KS = 4 * CIN, CO = 16 * MT, W = 128, OW = 64;
+    __shared__ __attribute__((aligned(16))) float s_ep[CO * 4];
+    __shared__ double s_red[4 * CO * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    stream_stage_ep(ep, s_ep, CO);
+    float wA[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wA[mt][ks] = wv.w[wv.off + (long long)(16 * mt + p) * wv.sn + (long long)(ks >> 2) * wv.sc + (long long)kq * wv.sky + (long long)(ks & 3) * wv.skx];
+    StreamCoef ic[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) ic[c] = stream_coef(in, c);
+    const float ilo = stream_floor(in);
+    const bool ident = in.mode == DM_LOAD_IDENT;
+    __syncthreads();
+
+    const int OH = H >> 1;
+    const long long total = (long long)B * OH;
+    const int u0 = (int)(total * blockIdx.x / gridDim.x), u1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int n = (u1 - u0 - wave + 3) >> 2;                     // this wave's output rows: u0 + wave, + 4, ...
+    const unsigned bytesI = (unsigned)((long long)B * CIN * H * W * 4), bytesO = (unsigned)((long long)B * CO * OH * OW * 4);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ep.mask.p0 ? ep.mask.p0 : in.p0), 0,
+                                                                        ep.mask.p0 ? bytesO : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, 0, 0x00020000);
+    const int vl = ((kq - 1) * W + 8 * p) * 4;                   // the lane's row and columns relative to (row 2 oy, column 0)
+    const int vg = (4 * kq * OH * OW + 4 * p) * 4;               // gate: channel 4 kq of an M tile, pixels 4 p ..
+
+    f32x4 x0[CIN], x1[CIN], gm[MT][4];
+    auto issue_in = [&](int u, bool live) {
+        const int b = u / OH, oy = u - b * OH;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            int v = (int)((((long long)b * CIN + c) * H + 2 * oy) * W * 4) + vl;
+            v = v < 0 ? 0 : v;                                   // row -1 of the tensor's first plane (zeroed below)
+            x0[c] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v, 0, 0);
+            x1[c] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v + 16, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto issue_gate = [&](int u, bool live) {
+        const int b = u / OH, oy = u - b * OH;
+        const unsigned sb = (unsigned)((((long long)b * CO * OH + oy) * OW) * 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = 16 * mt + 4 * kq + i;
-                const f32x4 ec = *reinterpret_cast<const f32x4 *>(&s_ep[co * 4]);
-                const long long o = ob + (long long)co * HW;
-                f32x4 v = (f32x4){acc[mt][0][i], acc[mt][1][i], acc[mt][2][i], acc[mt][3][i]} + ec.x;
-                if (ep.relu) v = dm_relu4(v);
-                f32x4 m = v;
-                if (ep.mask.p0) {
-                    m = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o);
-                    v.x = (ec.y * m.x + ec.z) > 0.f ? v.x : 0.f; v.y = (ec.y * m.y + ec.z) > 0.f ? v.y : 0.f;
-                    v.z = (ec.y * m.z + ec.z) > 0.f ? v.z : 0.f; v.w = (ec.y * m.w + ec.z) > 0.f ? v.w : 0.f;
-                }
-                if (ep.resid) v += *reinterpret_cast<const f32x4 *>(ep.resid + o);
-                *reinterpret_cast<f32x4 *>(out + o) = v;
-                if (ep.stats) {
-                    f32x4 q = v;
-                    if (ep.stat_q) q = ep.stat_q == ep.mask.p0 ? m : *reinterpret_cast<const f32x4 *>(ep.stat_q + o);
-                    float a = (v.x + v.y) + (v.z + v.w), c = (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
-                    // sum over the 16 lanes of the row (the unit's 64 pixels); lane p == 4 mt + i keeps it
-                    a += dpp_mov<0xB1>(a); c += dpp_mov<0xB1>(c);
-                    a += dpp_mov<0x4E>(a); c += dpp_mov<0x4E>(c);
-                    a += dpp_mov<0x141>(a); c += dpp_mov<0x141>(c);
-                    a += dpp_mov<0x140>(a); c += dpp_mov<0x140>(c);
-                    sel1 = p == 4 * mt + i ? a : sel1;
-                    sel2 = p == 4 * mt + i ? c : sel2;
-                }
-            }
-        if (ep.stats && MT * 4 > p) { st1 += (double)sel1; st2 += (double)sel2; }
-    }
+            for (int i = 0; i < 4; ++i)
+                gm[mt][i] = __builtin_amdgcn_raw_buffer_load_b128(live ? rG : dead, vg, sb + (unsigned)((16 * mt + i) * OH * OW * 4), 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    issue_in(n > 0 ? u0 + wave : 0, n > 0);
+    issue_gate(n > 0 ? u0 + wave : 0, n > 0);
 
-    if (ep.stats) {
-        // lane (p, kq) holds channel 16 (p >> 2) + 4 kq + (p & 3) of this wave
-        if (p < 4 * MT) {
-            const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
-            s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2;
+    double st1 = 0.0, st2 = 0.0;
+    for (int it = 0; it < n; ++it) {
+        const int u = u0 + wave + 4 * it;
+        const int b = u / OH, oy = u - b * OH;
+        const bool more = it + 1 < n;
+        f32x4 e[CIN][4];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            f32x4 a0 = x0[c], a1 = x1[c];
+            if (!ident) { a0 = sx_max(ic[c].c0 * a0 + ic[c].c2, ilo); a1 = sx_max(ic[c].c0 * a1 + ic[c].c2, ilo); }
+            if ((oy == 0 && kq == 0) || (oy == OH - 1 && kq == 3)) { a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0; }
+            const float am = dpp_mov<0x111>(a1.w), ap = dpp_mov<0x101>(a0.x);      // row_shr:1 / row_shl:1, 0 beyond the row
+            e[c][0] = (f32x4){am, a0.y, a0.w, a1.y};
+            e[c][1] = (f32x4){a0.x, a0.z, a1.x, a1.z};
+            e[c][2] = (f32x4){a0.y, a0.w, a1.y, a1.w};
+            e[c][3] = (f32x4){a0.z, a1.x, a1.z, ap};
         }
-        __syncthreads();
-        for (int i = tid; i < CO * 2; i += 256) {
-            double s = 0.0;
-            for (int w = 0; w < 4; ++w) s += s_red[(w * CO + (i >> 1)) * 2 + (i & 1)];
-            ep.stats[((long long)blockIdx.x * CO + (i >> 1)) * 2 + (i & 1)] = s;
-        }
-        for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
-            for (int i = tid; i < CO * 2; i += 256) ep.stats[((long long)sl * CO + (i >> 1)) * 2 + (i & 1)] = 0.0;
+        issue_in(more ? u + 4 : u, more);
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[mt][ks], e[ks >> 2][ks & 3][j], acc[mt][j], 0, 0, 0);
+        stream_epilogue<MT, true>(acc, ep, s_ep, out, (((long long)b * CO * OH + oy) * OW) + 4 * p, (long long)OH * OW, p, kq, st1, st2, gm);
+        issue_gate(more ? u + 4 : u, more);
     }
+    if (ep.stats) stream_stats_out<CO>(ep, s_red, st1, st2, nslabs);
 }
 
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution
     return v;
 }
 int stream_depth()
@@ -546,5 +675,26 @@ bool dm_stream_wgrad_s2_thin(const Operand &S, const Operand &T, float *slabs, i
     }
     DM_ST(1, 1) DM_ST(1, 2) DM_ST(1, 3) DM_ST(1, 4) DM_ST(2, 1) DM_ST(2, 2) DM_ST(2, 3) DM_ST(2, 4) DM_ST(4, 1)
 #undef DM_ST
+    return true;
+}
+
+// 4x4 / stride 2 convolution, 1-4 input channels -> 16 / 32 / 64 output channels, 128-column input
+bool dm_stream_conv_s2_thin(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                            int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st)
+{
+    if (!(stream_switch() & 8) || per_tile || Cphys != CIN || in.ones || ep.bias_border || in.mode == DM_LOAD_AFFINE2) return false;
+    if (CIN < 1 || CIN > 4 || !(NOUT == 16 || NOUT == 32 || (NOUT == 64 && CIN <= 2)) || W != 128 || H % 2) return false;
+    if ((long long)B * NOUT * (H / 2) * (W / 2) * 4 >= (1LL << 32) || (long long)B * CIN * H * W * 4 >= (1LL << 31)) return false;
+    if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
+    if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
+    const long long units = (long long)B * (H / 2);
+    int grid = (int)(units / 4 < 768 ? (units + 3) / 4 : 768);
+    if (ep.stats && grid > nslabs) grid = nslabs;
+    if (grid < 1) grid = 1;
+#define DM_CT(C_, MT_)                                                                                                       \
+    if (CIN == C_ && NOUT == 16 * MT_)                                                                                        \
+        hipLaunchKernelGGL((conv_s2_thin_stream_kernel<C_, MT_>), dim3(grid), dim3(256), 0, st, in, wv, out, ep, B, H, nslabs);
+    DM_CT(1, 1) DM_CT(2, 1) DM_CT(3, 1) DM_CT(4, 1) DM_CT(1, 2) DM_CT(2, 2) DM_CT(3, 2) DM_CT(4, 2) DM_CT(1, 4) DM_CT(2, 4)
+#undef DM_CT
     return true;
 }

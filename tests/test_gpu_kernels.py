@@ -1878,3 +1878,44 @@ def test_stream_wgrad_4x4s2_few_t_channels(ops, B, cs, ct, hs, ws, smode, tmode)
     ops.wgrad(ops.Op(dy.to(DEV), smode, coef.to(DEV) if smode >= 2 else None, p1=a.to(DEV) if smode == 4 else None),
               ops.Op(t.to(DEV), tmode, tcoef.to(DEV) if tmode >= 2 else None), dst, B, cs, ct, hs, ws, 4)
     close(dst, w.grad.float(), 5e-5, 5e-5 * max(w.grad.abs().max().item(), 1e-6), "stream wgrad 4x4/s2")
+
+
+@pytest.mark.parametrize("B,cin,nout,h,w,mode,epi", [(3, 2, 32, 128, 128, 0, "bias"), (2, 2, 32, 128, 128, 0, "gate+q"),
+                                                     (2, 1, 16, 16, 128, 3, "all"), (2, 4, 32, 8, 128, 1, "gate"),
+                                                     (1, 3, 16, 4, 128, 3, "all"), (20, 2, 64, 32, 128, 0, "bias"),
+                                                     (2, 2, 32, 6, 128, 2, "none")])
+def test_stream_conv_4x4s2_few_input_channels(ops, B, cin, nout, h, w, mode, epi):
+    """wide_stream.hip: the wide encoder's first convolution (image -> 32 channels) and the data gradient of the decoder's last
+    transposed convolution: K = (channel, ky, kx), input rows read by unaligned loads, zero padding applied AFTER the operand
+    transform, rows outside the image skipped; bias / ReLU / gate / residual / statistics."""
+    x = rnd(B, cin, h, w, seed=1)
+    coef = torch.stack([rnd(cin, seed=3).abs() + 0.5, torch.zeros(cin), rnd(cin, seed=5) * 0.3 + 0.2, torch.zeros(cin)], 1)
+    xin = load_ref(x.double(), mode, coef.double())
+    wt = rnd(nout, cin, 4, 4, seed=6, scale=0.2)
+    kw = {}
+    bias = rnd(nout, seed=7) if epi in ("bias", "all") else None
+    ref = F.conv2d(xin, wt.double(), bias.double() if bias is not None else None, stride=2, padding=1)
+    if bias is not None:
+        kw.update(bias=bias.to(DEV))
+    if epi == "all":
+        kw.update(relu=True)
+        ref = F.relu(ref)
+    oh, ow = h // 2, w // 2
+    gate, q, resid = rnd(B, nout, oh, ow, seed=8), rnd(B, nout, oh, ow, seed=9), rnd(B, nout, oh, ow, seed=10)
+    mcoef = torch.stack([rnd(nout, seed=11), torch.zeros(nout), rnd(nout, seed=12) * 0.3, torch.zeros(nout)], 1)
+    if epi in ("gate", "gate+q", "all"):
+        kw.update(mask=ops.Op(gate.to(DEV), 2, mcoef.to(DEV)))
+        ref = ref * ((mcoef[:, 0].view(1, -1, 1, 1) * gate + mcoef[:, 2].view(1, -1, 1, 1)) > 0)
+    sq = None
+    if epi == "all":
+        kw.update(resid=resid.to(DEV), stat_q=q.to(DEV))
+        ref = ref + resid
+        sq = q
+    elif epi == "gate+q":
+        kw.update(stat_q=kw["mask"].p0)
+        sq = gate
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None), ops.weight_view(wt.to(DEV), cin * 16, 16, 4, 1),
+                            B, cin, nout, h, w, want_stats=epi != "none", **kw)
+    close(out, ref.float(), 5e-5, 5e-5, "stream conv 4x4/s2")
+    if st is not None:
+        close_stats(st.sum(0), ref.float(), sq)
