@@ -26,10 +26,10 @@ constexpr int WKC = 8;                 // input channels per K chunk
 constexpr int WIDE_MAX_BLOCKS = 768;   // persistent grid cap (x dimension)
 
 // coefficient rows of channels [c_first, c_first + nch) of sample b -> s_cf[nch][4] (caller synchronises)
-__device__ __forceinline__ void stage_coef(const Operand &op, float *s_cf, int nch, int c_first, int Cphys, int b, int tid)
+__device__ __forceinline__ void stage_coef(const Operand &op, float *s_cf, int nch, int c_first, int Cphys, int b, int tid, int nth = 256)
 {
     if (op.mode < DM_LOAD_AFFINE) return;
-    for (int i = tid; i < nch * 4; i += 256) {
+    for (int i = tid; i < nch * 4; i += nth) {
         const int c = c_first + (i >> 2);
         s_cf[i] = c < Cphys ? op.coef[(long long)b * op.coef_bstride + c * 4 + (i & 3)] : 0.f;
     }
@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256) void wide_pack_kernel(WeightView wv, float *__
 // halo scalars, so a thread handles 2-5 float4 and 1-2 scalars per chunk instead of 6-20 scalars, each of which cost
 // ~25 integer instructions of index arithmetic (measured: 10 VALU instructions per MFMA, no overlap with the MFMAs).
 // P1: also prefetch the second tensor of an AFFINE2 operand (otherwise commit() reads it: exposed latency, rare path).
-template <class G, int NCH, bool P1>
+template <class G, int NCH, bool P1, int NTH = 256>
 struct RowPrefetch {
-    static constexpr int NU4 = NCH * G::ROWS * G::QW, J4 = (NU4 + 255) / 256;
-    static constexpr int NH = G::HALO ? NCH * G::ROWS * 2 : 0, JH = (NH + 255) / 256;
+    static constexpr int NU4 = NCH * G::ROWS * G::QW, J4 = (NU4 + NTH - 1) / NTH;
+    static constexpr int NH = G::HALO ? NCH * G::ROWS * 2 : 0, JH = (NH + NTH - 1) / NTH;
     f32x4 v[J4], u[P1 ? J4 : 1];
     float hv[JH ? JH : 1], hu[(P1 && JH) ? JH : 1];
     int b, c0, gy0, gxi;
@@ -137,7 +137,7 @@ struct RowPrefetch {
     {
         if constexpr (K < J4) {
             constexpr int j = K;
-            const int unit = j * 256 + tid, row = unit / G::QW, q = unit - row * G::QW;
+            const int unit = j * NTH + tid, row = unit / G::QW, q = unit - row * G::QW;
             const int c = row / G::ROWS, iy = row - c * G::ROWS, chn = c0 + c, gy = gy0 + iy;
             const bool inimg = unit < NU4 && chn < CINl && (unsigned)gy < (unsigned)Hh;
             const bool phys = inimg && chn < Cph;
@@ -148,7 +148,7 @@ struct RowPrefetch {
             if (P1) u[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
         } else if constexpr (K < NSLOT) {
             constexpr int j = K - J4;
-            const int unit = j * 256 + tid, row = unit >> 1, side = unit & 1;
+            const int unit = j * NTH + tid, row = unit >> 1, side = unit & 1;
             const int c = row / G::ROWS, iy = row - c * G::ROWS, chn = c0 + c, gy = gy0 + iy;
             const int gx = side ? gxi + 4 * G::QW : gxi - 1;
             const bool inimg = unit < NH && chn < CINl && (unsigned)gy < (unsigned)Hh && (unsigned)gx < (unsigned)Ww;
@@ -197,7 +197,7 @@ struct RowPrefetch {
         const bool slow_p1 = !P1 && mode == DM_LOAD_AFFINE2;
 #pragma unroll
         for (int j = 0; j < J4; ++j) {
-            const int unit = j * 256 + tid, row = unit / G::QW, q = unit - row * G::QW;
+            const int unit = j * NTH + tid, row = unit / G::QW, q = unit - row * G::QW;
             if (unit >= NU4) continue;
             const int c = row / G::ROWS, iy = row - c * G::ROWS;
             f32x4 x = v[j];
@@ -220,7 +220,7 @@ struct RowPrefetch {
         }
 #pragma unroll
         for (int j = 0; j < JH; ++j) {
-            const int unit = j * 256 + tid, row = unit >> 1, side = unit & 1;
+            const int unit = j * NTH + tid, row = unit >> 1, side = unit & 1;
             if (unit >= NH) continue;
             const int c = row / G::ROWS, iy = row - c * G::ROWS;
             float x = hv[j];
@@ -663,6 +663,161 @@ __global__ __launch_bounds__(256, 2) void wgrad_wide_kernel(Operand S, Operand T
             for (long long e = tid; e < E; e += 256) slabs[(long long)sl * E + e] = 0.f;
 }
 
+
+// ---- weight gradient of the 64-channel layers in ONE pass (3x3: 64 x 64, 4x4 / stride 2: 64 x 32) ---------------------------
+// wgrad_wide_kernel above covers N = (T channel, tap) in passes of 16 N tiles -- three passes over 64 x 9 columns, each staging
+// the S tile again -- and stages a unit between two barriers with the loads exposed: 40 % of its wave time was waiting
+// (profiles/r06_z32ex_sq_counters.txt), 0.56 of what the clock allows.  Here a workgroup of EIGHT waves owns all N tiles
+// (wave = M tile of 16 S channels x one half of the N tiles: 18 or 16 accumulators), both operand tiles of a unit (8 x 16
+// S pixels) sit in LDS once (100-117 KB: one workgroup per CU, two waves per SIMD as before), and the NEXT unit's S and T rows
+// are requested into registers a few at a time between the matrix steps of this one; after the K loop the workgroup
+// transforms and writes them (commit) between two barriers.  The K loop is straight-line code: 32 K steps of one A read and
+// NTW B reads whose addresses are a per-tile base register plus an immediate.
+template <int KK, int NCT>
+struct Wg1Geom : WgGeom<KK> {
+    using G0 = WgGeom<KK>;
+    static constexpr int NT = NCT * G0::T2 / 16, NTW = NT / 2;          // N tiles, N tiles per wave
+    static_assert(NT * 16 == NCT * G0::T2 && NTW * 2 == NT, "the two halves split the N tiles evenly");
+};
+
+template <int KK, int NCT, bool S2>
+__global__ __launch_bounds__(512, 1) void wgrad_wide1_kernel(Operand S, Operand T, float *__restrict__ slabs, int B, int Hs, int Ws,
+                                                            int nslabs)
+{
+    using G = Wg1Geom<KK, NCT>;
+    constexpr int CS = 64, NTW = G::NTW, T2 = G::T2;
+    __shared__ __attribute__((aligned(16))) float s_S[64 * WG_CSS];
+    __shared__ __attribute__((aligned(16))) float s_T[NCT * G::CHS];
+    __shared__ float s_cfS[64 * 4], s_cfT[NCT * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    const int mt = wave & 3, nh = wave >> 2;
+    const int Ht = Hs * G::S, Wt = Ws * G::S;
+    const int tx_n = Ws >> 4, tps = (Hs >> 3) * tx_n;
+    const long long E = (long long)CS * NCT * T2;
+
+    // LDS offset of this lane's (T channel, tap) of the wave's N tile t at pixel (0, kq); rows add ROWSTEP, K steps add 4
+    int tb[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int n = (nh * NTW + t) * 16 + p, ctl = n / T2, tap = n - ctl * T2;
+        const int ky = tap / KK, kx = tap - ky * KK;
+        int o = ctl * G::CHS + kq;
+        if (KK == 4) o += (kx & 1) * G::PLS + ky * G::RS + (kx >> 1) + ((kx & 1) ? 0 : 1);
+        else if (KK == 3) o += ky * G::RS + kx + G::OFFC - 1;
+        tb[t] = o;
+    }
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // shared coefficients (batch statistics: the host checks coef_bstride == 0)
+    stage_coef(S, s_cfS, 64, 0, CS, 0, tid, 512);
+    stage_coef(T, s_cfT, NCT, 0, NCT, 0, tid, 512);
+
+    RowPrefetch<G, NCT, false, 512> pt;
+    constexpr int JS = 64 * 8 * 4 / 512;                         // S tile: 64 channels x 8 rows x 4 float4 = 4 per thread
+    f32x4 sv[JS], su[S2 ? JS : 1];
+    __amdgpu_buffer_rsrc_t rS0, rS1;
+    int sbase = 0;
+    int tq = tid;                                                // the staging code's copy of the thread id (see the unit loop)
+    auto s_begin = [&](int u, bool live) {
+        const int b = u / tps, r = u - b * tps;
+        const int y0 = (r / tx_n) << 3, x0 = (r - (r / tx_n) * tx_n) << 4;
+        const long long se = (long long)CS * Hs * Ws;
+        const int bytes = live ? (int)(se * 4) : 0;
+        rS0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S.p0 + se * b), 0, bytes, 0x00020000);
+        rS1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((S2 ? S.p1 : S.p0) + se * b), 0, S2 ? bytes : 0, 0x00020000);
+        sbase = (y0 * Ws + x0) * 4;
+        pt.begin(T, live, b, 0, NCT, NCT, G::S * y0 - G::R, G::S * x0, Ht, Wt);
+    };
+    constexpr int NSLOT = JS + decltype(pt)::NSLOT;
+    auto slot = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        if constexpr (K < JS) {
+            const int idx = K * 512 + tq, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
+            const int off = sbase + ((cl * Hs + rr) * Ws + c4 * 4) * 4;
+            sv[K] = __builtin_amdgcn_raw_buffer_load_b128(rS0, off, 0, 0);
+            if constexpr (S2) su[K] = __builtin_amdgcn_raw_buffer_load_b128(rS1, off, 0, 0);
+        } else if constexpr (K < NSLOT) {
+            pt.template slot<K - JS>(tq);
+        }
+    };
+    auto slots_from = [&](auto self, auto kc, auto endc) -> void {
+        constexpr int K = decltype(kc)::value, END = decltype(endc)::value;
+        if constexpr (K < END && K < NSLOT) { slot(kc); self(self, std::integral_constant<int, K + 1>{}, endc); }
+    };
+    auto commit = [&]() {
+        const int smode = S.mode;
+#pragma unroll
+        for (int j = 0; j < JS; ++j) {
+            const int idx = j * 512 + tq, cl = idx >> 5, rr = (idx >> 2) & 7, c4 = idx & 3;
+            f32x4 v = sv[j];
+            if constexpr (S2) {
+                v = s_cfS[cl * 4] * v + (s_cfS[cl * 4 + 1] * su[j] + s_cfS[cl * 4 + 2]);
+            } else if (smode == DM_LOAD_RELU) {
+                v = dm_relu4(v);
+            } else if (smode >= DM_LOAD_AFFINE) {
+                v = s_cfS[cl * 4] * v + s_cfS[cl * 4 + 2];
+                if (smode == DM_LOAD_AFFINE_RELU) v = dm_relu4(v);
+            }
+            f32x2 *dst = reinterpret_cast<f32x2 *>(&s_S[cl * WG_CSS + rr * 16 + c4 * 4]);     // rows are only 8-byte aligned
+            dst[0] = (f32x2){v.x, v.y};
+            dst[1] = (f32x2){v.z, v.w};
+        }
+        pt.commit(T, s_cfT, s_T, NCT, Ht, Wt, tq);
+    };
+
+    const int units = B * tps;
+    int u = blockIdx.x;
+    s_begin(u < units ? u : 0, u < units);
+    slots_from(slots_from, std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{});
+    __syncthreads();                                             // the coefficient tables
+    for (; u < units; u += gridDim.x) {
+        tq = threadIdx.x;
+        asm volatile("" : "+v"(tq));       // staging index arithmetic is redone per unit, not hoisted into dozens of registers
+        commit();
+        __syncthreads();
+        const int un = u + gridDim.x;
+        s_begin(un < units ? un : u, un < units);
+        // K = the 128 pixels: 8 rows x 4 steps of 4 columns; every LDS address is a base register + immediate.  The operands of
+        // step s + 1 are requested before the products of step s are issued; the next unit's loads go out a few per step.
+        const float *sp = s_S + (mt * 16 + p) * WG_CSS + kq;
+        // ONE set of B registers: the read of step s + 1 into b[t] follows the product of step s that consumed b[t] (LDS returns
+        // in order, so product t of the next step waits for read t only) -- a second set cost 18 registers and spilled
+        float av = sp[0], bv[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bv[t] = s_T[tb[t]];
+        auto kloop = [&](auto self, auto sc) -> void {
+            constexpr int st = decltype(sc)::value;
+            if constexpr (st < 32) {
+                constexpr int rn = (st + 1) >> 2, kn = (st + 1) & 3;
+                float an = 0.f;
+                if constexpr (st + 1 < 32) an = sp[rn * 16 + kn * 4];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+                    if constexpr (st + 1 < 32) bv[t] = s_T[tb[t] + rn * G::ROWSTEP + kn * 4];
+                }
+                constexpr int SPI = (NSLOT + 27) / 28;          // all requests leave in the first 28 steps: a round trip of lead
+                slots_from(slots_from, std::integral_constant<int, st * SPI>{}, std::integral_constant<int, (st + 1) * SPI>{});
+                av = an;
+                self(self, std::integral_constant<int, st + 1>{});
+            }
+        };
+        kloop(kloop, std::integral_constant<int, 0>{});
+        __syncthreads();                                         // every wave is done with s_S / s_T
+    }
+
+    // lane holds R[cs = 16 mt + 4 kq + j][n = 16 (nh NTW + t) + p]
+    float *row = slabs + (long long)blockIdx.x * E;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[(long long)(mt * 16 + kq * 4 + j) * (NCT * T2) + (nh * NTW + t) * 16 + p] = acc[t][j];
+    for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+        for (long long e = tid; e < E; e += 512) slabs[(long long)sl * E + e] = 0.f;
+}
+
 }  // namespace
 
 bool dm_stream_conv1x1(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
@@ -789,10 +944,21 @@ static void wide_wgrad_grid(int CS, int CT, int k, int &gy, int &gz, int &cap)
     if (cap > 512) cap = 512;
 }
 
+static int wide_wgrad_one_pass()
+{
+    static const int v = getenv("DM_WIDE_WGRAD1") ? atoi(getenv("DM_WIDE_WGRAD1")) : 1;
+    return v;
+}
+static bool wide_wgrad1_shape(int CS, int CT, int k) { return wide_wgrad_one_pass() && CS == 64 && ((k == 3 && CT == 64) || (k == 4 && CT == 32)); }
+
 int dm_wide_wgrad_slabs(int B, int CS, int CT, int Hs, int Ws, int k)
 {
     if (k == 1 && dm_stream_wgrad1x1_shape(B, CS, CT, Hs, Ws)) return dm_stream_wgrad1x1_slabs(B, Hs, Ws);
     if (k == 4 && dm_stream_wgrad_s2_thin_shape(B, CS, CT, Hs, Ws)) return dm_stream_wgrad_s2_thin_slabs(B, Hs, Ws);
+    if (wide_wgrad1_shape(CS, CT, k)) {
+        const long long units = (long long)B * (Hs / 8) * (Ws / 16);
+        return (int)(units < 256 ? units : 256);                // one workgroup of eight waves per CU
+    }
     int gy, gz, cap;
     wide_wgrad_grid(CS, CT, k, gy, gz, cap);
     const long long units = (long long)B * (Hs / 8) * (Ws / 16);
@@ -804,6 +970,18 @@ int dm_wide_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
 {
     if (k == 1 && dm_stream_wgrad1x1(S, T, slabs, B, CS, CT, Hs, Ws, nslabs, st)) return 0;
     if (k == 4 && CT == CTphys && dm_stream_wgrad_s2_thin(S, T, slabs, B, CS, CT, Hs, Ws, nslabs, st)) return 0;
+    if (wide_wgrad1_shape(CS, CT, k) && CT == CTphys && !T.ones && T.mode != DM_LOAD_AFFINE2 &&
+        !(S.mode >= DM_LOAD_AFFINE && S.coef_bstride) && !(T.mode >= DM_LOAD_AFFINE && T.coef_bstride)) {
+        const long long units = (long long)B * (Hs / 8) * (Ws / 16);
+        int g1 = (int)(units < 256 ? units : 256);
+        if (g1 > nslabs) g1 = nslabs;
+        const bool two = S.mode == DM_LOAD_AFFINE2;
+        if (k == 3 && two) hipLaunchKernelGGL((wgrad_wide1_kernel<3, 64, true>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);
+        else if (k == 3) hipLaunchKernelGGL((wgrad_wide1_kernel<3, 64, false>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);
+        else if (two) hipLaunchKernelGGL((wgrad_wide1_kernel<4, 32, true>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);
+        else hipLaunchKernelGGL((wgrad_wide1_kernel<4, 32, false>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);
+        return 0;
+    }
     int gy, gz, cap;
     wide_wgrad_grid(CS, CT, k, gy, gz, cap);
     int gx = dm_wide_wgrad_slabs(B, CS, CT, Hs, Ws, k);
