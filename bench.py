@@ -576,6 +576,45 @@ def c5_record(dev, steps=30, warmup=5, B=1024):
     return rec
 
 
+def example_tm_matrix(B, dev):
+    """The relation matrix of the z32ex workload: adjacent frames of one trajectory, 4 consecutive samples per group."""
+    i = torch.arange(B)
+    d = (i[:, None] - i[None, :]).abs()
+    same = (i[:, None] // 4) == (i[None, :] // 4)
+    m = torch.zeros(B, B)
+    m[same & (d == 1)] = 2.0
+    m[same & (d == 2)] = 1.0
+    return m.to(dev)
+
+
+def z32ex_record(dev, steps=20, warmup=4, B=768):
+    """SURVEY section 8(f) row 2 beside the headline line, budgeted to a few seconds: VQ_VAE_z32 as the reference's example
+    configuration trains it (config_example.yml:156-186: 64 / 64 / 512, batch 768, time-matching term on) through FusedTrainer
+    (`python bench.py --workload z32ex` is the full record)."""
+    from dynamorph_amd import VQ_VAE_z32
+    from dynamorph_amd.train import FusedTrainer
+    torch.manual_seed(0)
+    model = VQ_VAE_z32(weight_matching=100., margin=1., w_a=1., w_t=0.5, w_n=-0.5, **EXAMPLE_CONFIG).to(dev)
+    x = torch.randn(B, 2, 128, 128, generator=torch.Generator().manual_seed(1234)).to(dev)
+    tm = example_tm_matrix(B, dev)
+    tr = FusedTrainer(model, lr=1e-4)
+    for _ in range(warmup):
+        out = tr.step(x, None, tm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.step(x, None, tm)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rec = {"workload": "z32ex: VQ_VAE_z32(num_hiddens=64, num_residual_hiddens=64, num_embeddings=512) training step with the "
+                       "time-matching term, 2x128x128 fp32, batch %d" % B,
+           "value": round(B * steps / el, 1), "unit": "patches/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps,
+           "total_loss_after": round(float(out[2]), 6)}
+    del tr, model, x, tm
+    torch.cuda.empty_cache()
+    return rec
+
+
 def train_loop_record(dev, resident_ms_per_step, n=32768, B=2048, epochs=3, feed="auto", transform=True, masks=False,
                       relation=False, pinned=False):
     """The product's own training entry point, dynamorph_amd.train.train() (run_training.py:455-551), end to end on a
@@ -754,12 +793,7 @@ def main():
             raise SystemExit("--workload z32ex is a single-GPU measurement")
         from dynamorph_amd import VQ_VAE_z32
         model = VQ_VAE_z32(weight_matching=100., margin=1., w_a=1., w_t=0.5, w_n=-0.5, **EXAMPLE_CONFIG).to(dev)
-        tm_mat = torch.zeros(B, B)
-        for i in range(B):
-            for j in range(max(0, i - 2), min(B, i + 3)):
-                if j != i and j // 4 == i // 4:
-                    tm_mat[i, j] = 2.0 if abs(i - j) == 1 else 1.0
-        tm_mat = tm_mat.to(dev)
+        tm_mat = example_tm_matrix(B, dev)
         if args.no_fused:
             opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
@@ -857,7 +891,7 @@ def main():
         roof = roofline_vq_large_codebook(model, x)
     else:
         roof = roofline_dominant_kernel(model, x, args.workload)
-    targets = c2 = loop = c5 = None
+    targets = c2 = loop = c5 = z32 = None
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_targets:
         targets = north_star_targets(model, x)
         c2 = c2_record(model)
@@ -867,6 +901,7 @@ def main():
             k: v for k, v in train_loop_record(dev, None, B=B, epochs=2, masks=True, relation=True).items()
             if k in ("train_patches_per_s", "train_ms_per_step", "loop_patches_per_s", "val_patches_per_s", "timed_epochs")}
         c5 = c5_record(dev)
+        z32 = z32ex_record(dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload)
@@ -901,6 +936,7 @@ def main():
             line["c2"] = c2
             line["train_loop"] = loop
             line["c5"] = c5
+            line["z32ex"] = z32
         if losses is not None:
             line["final_losses"] = dict(zip(("recon", "commitment", "total", "perplexity"), [round(v, 6) for v in losses]))
         print(json.dumps(line), flush=True)

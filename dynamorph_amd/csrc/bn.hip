@@ -238,14 +238,16 @@ __global__ __launch_bounds__(256) void bn_backward_finalize_kernel(
     const double sum_dy = block_sum(s1, s_red);
     const double sum_dya = block_sum(s2, s_red);
     if (threadIdx.x == 0) {
-        const double n = (double)count;
+        // count == 0: fixed statistics (eval() mode: `saved` holds the running mean and 1 / sqrt(running_var + eps)) -- the
+        // batch-mean terms of the gradient vanish, da = scale * dy
+        const double inv_n = count > 0 ? 1.0 / (double)count : 0.0;
         const double mean = (double)mean_f, invstd = (double)invstd_f;
         const double g = (double)g_f;
         const double sum_dyxh = invstd * (sum_dya - mean * sum_dy);
         if (dgamma) dgamma[c] = (float)sum_dyxh;
         if (dbeta) dbeta[c] = (float)sum_dy;
         const double scale = g * invstd;
-        const double c1 = sum_dy / n, c2 = sum_dyxh / n;
+        const double c1 = sum_dy * inv_n, c2 = sum_dyxh * inv_n;
         const double Bc = -scale * invstd * c2;
         coef_bwd[c * 4 + 0] = (float)scale;
         coef_bwd[c * 4 + 1] = (float)Bc;
@@ -391,7 +393,7 @@ extern "C" int dm_bn_backward_finalize(const double *stats, int nslabs, int C, i
                                        float *coef_bwd, void *stream)
 {
     DM_REQUIRE(stats && saved && coef_bwd, "dm_bn_backward_finalize: NULL pointer");
-    DM_REQUIRE(nslabs > 0 && C > 0 && count > 0, "dm_bn_backward_finalize: bad sizes");
+    DM_REQUIRE(nslabs > 0 && C > 0 && count >= 0, "dm_bn_backward_finalize: bad sizes");
     hipLaunchKernelGGL(bn_backward_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslabs, C,
                        (long long)count, gamma, saved, dgamma, dbeta, coef_bwd);
     return dm_launch_status("dm_bn_backward_finalize");

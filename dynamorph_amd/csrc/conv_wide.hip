@@ -21,6 +21,9 @@
 
 namespace {
 
+#ifndef DM_WIDE_OCC3
+#define DM_WIDE_OCC3 0              // 1: every form compiled for three workgroups per CU (measurement builds)
+#endif
 enum { W_S2 = 0, W_S1 = 1, W_PIX = 2 };
 constexpr int WKC = 8;                 // input channels per K chunk
 constexpr int WIDE_MAX_BLOCKS = 768;   // persistent grid cap (x dimension)
@@ -246,7 +249,7 @@ struct RowPrefetch {
 //                  other slabs are zeroed (per-sample BatchNorm sums the slabs of a sample).
 // wpk: the packed weights (wide_pack_kernel, same <FORM, TAPS, NPW>).
 template <int FORM, int TAPS, int NPW>
-__global__ __launch_bounds__(256, (FORM == W_S1 && TAPS == 9 && NPW == 4) ? 3 : 2) void conv_wide_kernel(Operand in, const float *__restrict__ wpk, float *__restrict__ out,
+__global__ __launch_bounds__(256, ((FORM == W_S1 && TAPS == 9 && NPW == 4) || DM_WIDE_OCC3) ? 3 : 2) void conv_wide_kernel(Operand in, const float *__restrict__ wpk, float *__restrict__ out,
                                                         Epilogue ep, int B, int Cphys, int CIN, int NOUT, int H, int W,
                                                         int nslabs, int per_tile)
 {

@@ -82,10 +82,13 @@ def _bn_coef(stats, bn, count, per_sample, nbatch, defer=None):
     running statistics instead; its coefficients are three tiny device ops, no HIP kernel needed.
     defer: list collecting the running-statistics updates of the per-sample path (ops.bn_running_replay)."""
     if not bn.training:
-        scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = bn.weight.detach() * invstd
         coef = torch.stack([scale, torch.zeros_like(scale), bn.bias.detach() - bn.running_mean * scale,
                             torch.zeros_like(scale)], 1).contiguous()
-        return coef, None
+        if per_sample:
+            return coef, None
+        return coef, torch.stack([bn.running_mean, invstd], 1).contiguous()     # what _bn_backward takes in eval() mode
     momentum = 0.1 if bn.momentum is None else bn.momentum
     spg = stats.shape[0] // nbatch if per_sample else 1
     return ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
@@ -95,6 +98,12 @@ def _bn_coef(stats, bn, count, per_sample, nbatch, defer=None):
 
 def _w(p):
     return p.detach()
+
+
+def _bn_backward(stats, count, bn, saved, G):
+    """native_batch_norm_backward's reductions for `bn` from the (sum dy, sum dy * a) slabs -> the AFFINE2 coefficients of
+    da; eval() mode (fixed statistics: count 0) keeps only da = gamma * invstd * dy."""
+    return ops.bn_backward_finalize(stats, count if bn.training else 0, _w(bn.weight), saved, G(bn.weight), G(bn.bias))
 
 
 # ------------------------------------------------------------------------------- encoder
@@ -239,6 +248,17 @@ def residual_forward(res_layers, h, per_sample=False, defer=None, defer_last_joi
     return h, saved
 
 
+def _fed_bias(gbias, bn, coef_bwd, G, zero=True):
+    """Gradient of a convolution bias that feeds the BatchNorm `bn`: identically zero in train mode (the batch mean removes a
+    constant; zero=False: the caller's buffer holds the zero already); in eval() mode the sum of the BatchNorm's input
+    gradient over the positions, gamma / sqrt(running_var + eps) * dbeta."""
+    if bn.training:
+        if zero:
+            gbias.zero_()
+    else:
+        torch.mul(coef_bwd[:, 0], G(bn.bias), out=gbias)
+
+
 def _zero(t, do=True):
     if do:
         t.zero_()
@@ -259,9 +279,9 @@ def residual_backward(res_layers, saved, g_h, G, q_below, pending=None, zero_fed
         nrh = ca.weight.shape[0]
         if s.savedb is None or s.coefb.dim() != 2:
             raise NotImplementedError("backward needs batch-statistics BatchNorm (train mode, per_sample=False)")
-        cb_bwd = ops.bn_backward_finalize(stats, cnt, _w(bnb.weight), s.savedb, G(bnb.weight), G(bnb.bias))
+        cb_bwd = _bn_backward(stats, cnt, bnb, s.savedb, G)
         da_rb = Op(g_h, DM_LOAD_AFFINE2, cb_bwd, p1=s.rb)
-        _zero(G(cb.bias), zero_fed_biases)
+        _fed_bias(G(cb.bias), bnb, cb_bwd, G, zero_fed_biases)
         if FUSED_BACKWARD and s.coefa.dim() == 2 and ops.conv1x1_bwd_fused_supported(nh, nrh, H, W):
             # the 1x1 convolution's data and weight gradient from ONE staging of (g_h, rb, ra) -- csrc/conv1x1_bwd.hip
             dy_ra, st = ops.conv1x1_bwd_fused(da_rb, s.ra, s.coefa, _w(cb.weight), G(cb.weight), B, nh, nrh, H, W, pending=pending)
@@ -269,9 +289,9 @@ def residual_backward(res_layers, saved, g_h, G, q_below, pending=None, zero_fed
             ops.wgrad(da_rb, Op(s.ra, DM_LOAD_AFFINE_RELU, s.coefa), G(cb.weight), B, nh, nrh, H, W, 1, pending=pending)
             dy_ra, st = ops.conv3x3(da_rb, weight_view(_w(cb.weight), 1, nrh, 0, 0), B, nh, nrh, H, W, taps=1, want_stats=True,
                                     like=g_h, mask=Op(s.ra, DM_LOAD_AFFINE, s.coefa), stat_q=s.ra)
-        ca_bwd = ops.bn_backward_finalize(st, cnt, _w(bna.weight), s.saveda, G(bna.weight), G(bna.bias))
+        ca_bwd = _bn_backward(st, cnt, bna, s.saveda, G)
         da_ra = Op(dy_ra, DM_LOAD_AFFINE2, ca_bwd, p1=s.ra)
-        _zero(G(ca.bias), zero_fed_biases)
+        _fed_bias(G(ca.bias), bna, ca_bwd, G, zero_fed_biases)
         q = saved[i - 1].rb if i > 0 else q_below
         if FUSED_BACKWARD and ops.conv3x3_bwd_fused_supported(nrh, nh, H, W):
             # the 3x3 convolution's data and weight gradient from ONE staging of the patch -- csrc/conv3x3_bwd.hip
@@ -293,8 +313,6 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=(), want
     pending = list(pending_extra)                    # (slabs, dst) pairs that ride along in the one slab reduction
     if cx.per_sample and cx.B > 1:
         raise NotImplementedError("backward through per-sample BatchNorm statistics with B > 1")
-    if cx.saved1 is None:
-        raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
     B, x = cx.B, cx.x
     NIN, nh, c1 = L.nin, L.nh, L.nh // 2
     H1, W1, H2, W2, H3, W3 = cx.dims
@@ -302,9 +320,9 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=(), want
 
     g_h, stats = residual_backward(L.res, cx.res, g_z, G, cx.a4, pending=pending, zero_fed_biases=zero_fed_biases)
     cnt3 = B * H3 * W3
-    c4b = ops.bn_backward_finalize(stats, cnt3, _w(L.bn4.weight), cx.saved4, G(L.bn4.weight), G(L.bn4.bias))
+    c4b = _bn_backward(stats, cnt3, L.bn4, cx.saved4, G)
     da4 = Op(g_h, DM_LOAD_AFFINE2, c4b, p1=cx.a4)
-    _zero(G(L.enc10.bias), zero_fed_biases)
+    _fed_bias(G(L.enc10.bias), L.bn4, c4b, G, zero_fed_biases)
     if FUSED_BACKWARD and cx.coef3.dim() == 2 and ops.conv3x3_bwd_fused_supported(nh, nh, H3, W3):
         # enc.10: data and weight gradient from ONE staging of the patch -- csrc/conv3x3_bwd.hip
         dy3, st = ops.conv3x3_bwd_fused(da4, cx.a3, cx.coef3, _w(L.enc10.weight), G(L.enc10.weight), B, nh, q=cx.a3,
@@ -314,9 +332,9 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=(), want
         dy3, st = ops.conv3x3(da4, weight_view(_w(L.enc10.weight), 9, nh * 9, -3, -1, off=8), B, nh, nh, H3, W3, taps=9,
                               want_stats=True, like=g_h, mask=Op(cx.a3, DM_LOAD_AFFINE, cx.coef3), stat_q=cx.a3)
 
-    c3b = ops.bn_backward_finalize(st, cnt3, _w(L.bn3.weight), cx.saved3, G(L.bn3.weight), G(L.bn3.bias))
+    c3b = _bn_backward(st, cnt3, L.bn3, cx.saved3, G)
     da3 = Op(dy3, DM_LOAD_AFFINE2, c3b, p1=cx.a3)
-    _zero(G(L.enc7.bias), zero_fed_biases)
+    _fed_bias(G(L.enc7.bias), L.bn3, c3b, G, zero_fed_biases)
     if FUSED_BACKWARD and cx.coef2.dim() == 2 and ops.conv4x4s2_bwd_fused_supported(nh, nh, H3, W3):
         # enc.7: data and weight gradient from ONE staging of the patch -- csrc/conv4x4s2_patch.hip
         dy2, st = ops.conv4x4s2_bwd_fused(da3, cx.a2, cx.coef2, _w(L.enc7.weight), G(L.enc7.weight), B, pending=pending)
@@ -326,9 +344,9 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=(), want
                               pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a2, DM_LOAD_AFFINE, cx.coef2),
                               stat_q=cx.a2)
 
-    c2b = ops.bn_backward_finalize(st, B * H2 * W2, _w(L.bn2.weight), cx.saved2, G(L.bn2.weight), G(L.bn2.bias))
+    c2b = _bn_backward(st, B * H2 * W2, L.bn2, cx.saved2, G)
     da2 = Op(dy2, DM_LOAD_AFFINE2, c2b, p1=cx.a2)
-    _zero(G(L.enc4.bias), zero_fed_biases)
+    _fed_bias(G(L.enc4.bias), L.bn2, c2b, G, zero_fed_biases)
     if FUSED_BACKWARD and ops.conv_bwd_s2_fused_supported(nh, c1, H2, W2):
         # enc.4: data gradient + weight gradient from ONE staging of (dy2, a2, a1) -- csrc/conv_mfma.hip, kernel D
         dy1, st = ops.conv_bwd_s2_fused(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), weight_view(_w(L.enc4.weight), 16, c1 * 16, 4, 1),
@@ -340,14 +358,14 @@ def encoder_backward(L, cx, g_z, G, zero_fed_biases=True, pending_extra=(), want
                               pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
                               stat_q=cx.a1)
 
-    c1b = ops.bn_backward_finalize(st, B * H1 * W1, _w(L.bn1.weight), cx.saved1, G(L.bn1.weight), G(L.bn1.bias))
+    c1b = _bn_backward(st, B * H1 * W1, L.bn1, cx.saved1, G)
     da1 = Op(dy1, DM_LOAD_AFFINE2, c1b, p1=cx.a1)
     dweff = torch.empty((c1, NIN + 1, 4, 4), device=x.device, dtype=torch.float32)
     ops.wgrad(da1, Op(x, ones=True), dweff, B, c1, NIN + 1, H1, W1, 4, pending=pending)
     ops.reduce_slabs_multi(pending)                  # all encoder weight gradients in one launch
     ops.e1_chain(dweff, _w(L.enc0.weight), _w(L.enc0.bias), _w(L.enc1.weight),
                  G(L.enc0.weight), G(L.enc0.bias), G(L.enc1.weight))
-    _zero(G(L.enc1.bias), zero_fed_biases)
+    _fed_bias(G(L.enc1.bias), L.bn1, c1b, G, zero_fed_biases)
     if want_dx:
         # a1 = conv(x, Weff[:, :NIN]) + border bias: dx = ConvTranspose(da1, Weff[:, :NIN]) (phase-decomposed kernel family;
         # the ones channel of the composite carries no gradient to x)
@@ -539,8 +557,6 @@ def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G, stats=None, pending=No
     conv biases that feed a BatchNorm are not written."""
     if getattr(cx, "per_sample", False) and cx.dims[0] > 1:
         raise NotImplementedError("backward through per-sample BatchNorm statistics with B > 1")
-    if cx.saved1 is None or cx.saved2 is None:
-        raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
     B, NIN, c1, nh, H1, W1, H2, W2 = cx.dims
     g_h = g_h.contiguous()
     own = pending is None
@@ -548,17 +564,17 @@ def z32_stem_backward(conv0, bn0, conv1, bn1, cx, g_h, G, stats=None, pending=No
         pending = []
     if stats is None:
         stats = ops.channel_stats(g_h, cx.a2)
-    c2b = ops.bn_backward_finalize(stats, B * H2 * W2, _w(bn1.weight), cx.saved2, G(bn1.weight), G(bn1.bias))
+    c2b = _bn_backward(stats, B * H2 * W2, bn1, cx.saved2, G)
     da2 = Op(g_h, DM_LOAD_AFFINE2, c2b, p1=cx.a2)
     ops.wgrad(da2, Op(cx.a1, DM_LOAD_AFFINE_RELU, cx.coef1), G(conv1.weight), B, nh, c1, H2, W2, 4, pending=pending)
-    _zero(G(conv1.bias), zero_fed_biases)            # feeds a train-mode BatchNorm: identically zero
+    _fed_bias(G(conv1.bias), bn1, c2b, G, zero_fed_biases)
     dy1, st = ops.conv3x3(da2, weight_view(_w(conv1.weight), 16, c1 * 16, 4, 1), B, nh, 4 * c1, H2, W2, taps=9,
                           pixel_shuffle=True, want_stats=True, like=g_h, mask=Op(cx.a1, DM_LOAD_AFFINE, cx.coef1),
                           stat_q=cx.a1)
-    c1b = ops.bn_backward_finalize(st, B * H1 * W1, _w(bn0.weight), cx.saved1, G(bn0.weight), G(bn0.bias))
+    c1b = _bn_backward(st, B * H1 * W1, bn0, cx.saved1, G)
     da1 = Op(dy1, DM_LOAD_AFFINE2, c1b, p1=cx.a1)
     ops.wgrad(da1, Op(cx.x), G(conv0.weight), B, c1, NIN, H1, W1, 4, pending=pending)
-    _zero(G(conv0.bias), zero_fed_biases)
+    _fed_bias(G(conv0.bias), bn0, c1b, G, zero_fed_biases)
     if own:
         ops.reduce_slabs_multi(pending)
     if want_dx:          # the gradient w.r.t. the input patches: conv0's data gradient (see encoder_backward)
@@ -586,8 +602,6 @@ def z32_tail_forward(up0, bn, up1, r, x, mask, channel_var):
 def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True, pending=None, zero_fed_biases=True):
     """gscale: 1-element device tensor d(total)/d(recon_loss) or None; gdec_ext: upstream gradient w.r.t. decoded or None.
     pending / zero_fed_biases: as in z32_stem_backward."""
-    if cx.savedd is None:
-        raise NotImplementedError("backward in eval() mode (the reference path never leaves train mode)")
     B, nh, c1, NIN, H2, W2 = cx.dims
     own = pending is None
     if own:
@@ -605,11 +619,11 @@ def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True, pendi
               pending=pending)
     dy, st = ops.conv4x4s2(Op(g), weight_view(_w(up1.weight), NIN * 16, 16, 4, 1), B, NIN, c1, 4 * H2, 4 * W2,
                            want_stats=True, mask=Op(cx.d1, DM_LOAD_AFFINE, cx.coefd), stat_q=cx.d1)
-    cdb = ops.bn_backward_finalize(st, B * 4 * H2 * W2, _w(bn.weight), cx.savedd, G(bn.weight), G(bn.bias))
+    cdb = _bn_backward(st, B * 4 * H2 * W2, bn, cx.savedd, G)
     # the weight-gradient kernel takes the BatchNorm-backward transform on its S operand only: materialise it here
     da = ops.apply(Op(dy, DM_LOAD_AFFINE2, cdb, p1=cx.d1), B, c1, 2 * H2, 2 * W2)
     ops.wgrad(Op(cx.r), Op(da), G(up0.weight), B, nh, c1, H2, W2, 4, pending=pending)
-    _zero(G(up0.bias), zero_fed_biases)
+    _fed_bias(G(up0.bias), bn, cdb, G, zero_fed_biases)
     g_r = None
     if want_gr:
         g_r, _ = ops.conv4x4s2(Op(da), weight_view(_w(up0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H2, 2 * W2)

@@ -380,7 +380,8 @@ int dm_latent_tail_supported(int C, int CR, int H, int W, int nres);
 int dm_latent_tail_forward(const dm_latent_tail_args *args, void *stream);
 
 /* Backward finalize: slabs hold (sum dy, sum dy*a).  Writes dgamma, dbeta and the
- * AFFINE2 coefficients (A,B,C) with da = A*dy + B*a + C. */
+ * AFFINE2 coefficients (A,B,C) with da = A*dy + B*a + C.  count == 0: fixed statistics (eval() mode; saved = running mean and
+ * 1 / sqrt(running_var + eps)): da = gamma * invstd * dy, dgamma / dbeta as always. */
 int dm_bn_backward_finalize(const double *stats, int nslabs, int C, int64_t count,
                             const float *gamma, const float *saved, float *dgamma, float *dbeta,
                             float *coef_bwd, void *stream);

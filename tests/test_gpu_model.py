@@ -947,6 +947,50 @@ def test_gradient_with_respect_to_the_input_patches(family, masked, with_tm):
             assert torch.equal(p.grad, q.grad), k
 
 
+@pytest.mark.parametrize("family", ["VQ_VAE", "VQ_VAE_z16", "VQ_VAE_z32"])
+def test_backward_in_eval_mode(family):
+    """model.eval(); total_loss.backward() -- the reference's training never leaves train mode (run_training.py:522-531 even
+    validates in it), autograd there would answer: every BatchNorm normalises with its running statistics, whose backward is
+    dx = gamma / sqrt(running_var + eps) * dy with the usual weight / bias sums (dm_bn_backward_finalize, count 0).  Against
+    the oracle in eval() mode on the float64 yardstick, running statistics moved off their initial values by two training
+    forwards first; the running statistics stay what they were."""
+    import copy
+    import dynamorph_amd
+    from conftest import grad_gate, loss_gate, oracle_truth
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(95)
+    ref = (O.OracleVQVAEz32 if family == "VQ_VAE_z32" else O.OracleVQVAE)(**({"variant": "z16"} if family == "VQ_VAE_z16" else {}))
+    B = 4
+    gen = torch.Generator().manual_seed(96)
+    with torch.no_grad():
+        for _ in range(2):
+            ref(torch.randn(B, 2, 128, 128, generator=gen) * 1.3 + 0.2)
+    x = torch.randn(B, 2, 128, 128, generator=gen)
+    ref.eval()
+    m = getattr(dynamorph_amd, family)().to(DEV)
+    m.load_state_dict(ref.state_dict())
+    m.eval()
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    with torch.no_grad():
+        probe = copy.deepcopy(ref)
+        z_r = probe.enc(x)
+        idx_r = probe.vq.encode_inputs(z_r)
+        idx = m.vq.encode_inputs(m.enc(x.to(DEV))).cpu()
+    codes_gate(idx != idx_r, z_r, probe.vq.w.weight.detach(), f"{family}, eval mode")
+    if bool((idx != idx_r).any()):
+        ref.vq.force_idx = idx.clone()
+    ld_ref, g32, g64 = oracle_truth(ref, x)
+    _, ld = m(x.to(DEV))
+    ld["total_loss"].backward()
+    for k in ("recon_loss", "commitment_loss", "total_loss"):
+        loss_gate(ld[k], ld_ref[k], f"{family} eval {k}")
+    n = grad_gate(m, g32, g64, what=f"{family}, eval mode", factor=2.0)
+    assert n >= 30
+    for k, v in m.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_fused_trainer_z32_with_extra_losses_against_reference_vectors(golden, use_graph):
     """FusedTrainer on a VQ_VAE_z32 with extra_loss (vae.py:463-469): the caller's torch functions run on z_after between the

@@ -2,6 +2,9 @@
 operand modes the training step uses.  DM_ONLY=<substring> selects; DM_B overrides the batch."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from dynamorph_amd import _lib
+if os.environ.get("DM_LIB"):
+    _lib.LIB_PATH = os.environ["DM_LIB"]
 from dynamorph_amd import ops
 ONLY = os.environ.get("DM_ONLY", "")
 B = int(os.environ.get("DM_B", "768"))
