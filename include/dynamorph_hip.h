@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 126
+#define DM_VERSION 127
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
