@@ -571,9 +571,111 @@ __global__ __launch_bounds__(256, (CIN * MT >= 6 || MT == 4) ? 2 : 3) void conv_
     if (ep.stats) stream_stats_out<CO>(ep, s_red, st1, st2, nslabs);
 }
 
+// -------------------------------------------- ConvTranspose2d(C -> 1 / 2 channels, 4, 2, 1): the wide decoder's last layer
+// out[co][2 y + py][2 x + px] = bias + sum over (ci, a, b) of in'[ci][y - 1 + py + a][x - 1 + px + b] * W[ci][co][3 - py - 2 a][3 - px - 2 b].
+// Eight outputs per input pixel: on the matrix cores M or N would be 8 of 16 and 5 of every 9 taps structural zeros (the tiled
+// kernel ran it at 11 TFLOP/s of useful products, 550 us for 0.5 GB).  Here it is what the thin family's decoder tail does: vector
+// units, one lane = 4 consecutive input pixels of a row (16 lanes = a 64-pixel row, the wave's four rows of lanes = four
+// image rows), the weights of one input channel -- 16 taps x (co 0, co 1) -- in SCALAR registers as the pairs v_pk_fma_f32
+// multiplies a broadcast input value with (packed [ci][tap][co] by convT_thin_pack_kernel).  Per input channel a lane loads its
+// row and the rows above and below (three 16-byte loads), takes columns 4 c - 1 and 4 c + 4 from its neighbours by DPP
+// (the row's ends read the padding's 0) and issues 64 packed multiply-adds.  Rows -1 / H are zeroed after the transform, in the
+// units that touch them (a wave-uniform branch).
+__global__ __launch_bounds__(256) void convT_thin_pack_kernel(WeightView wv, float *__restrict__ wp, int CIN, int COUT)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < CIN * 32; i += gridDim.x * 256) {
+        const int ci = i >> 5, tap = (i >> 1) & 15, co = i & 1;
+        wp[i] = co < COUT ? wv.w[wv.off + (long long)co * wv.sn + (long long)ci * wv.sc + (tap >> 2) * wv.sky + (tap & 3) * wv.skx] : 0.f;
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256, 4) void convT_thin_stream_kernel(Operand in, const float *__restrict__ wp, float *__restrict__ out,
+                                                                   Epilogue ep, int B, int CIN, int H)
+{
+    constexpr int W = 64, OW = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane >> 4, c = lane & 15;
+    const int upb = H >> 2;                                      // units of 4 rows per sample
+    const int units = B * upb;
+    const unsigned bytesI = (unsigned)((long long)B * CIN * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, bytesI, 0x00020000);
+    const bool aff = in.mode >= DM_LOAD_AFFINE;
+    const float lo = stream_floor(in);
+    const float b0 = ep.bias ? ep.bias[0] : 0.f, b1 = (ep.bias && COUT > 1) ? ep.bias[1] : 0.f;
+    const int OH = 2 * H;
+
+    for (int u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+        const int b = u / upb, y = ((u - b * upb) << 2) + r;
+        const bool top = y == 0, bot = y == H - 1;               // the lane's row -1 / row H: zero padding
+        const bool edge = (u - b * upb) == 0 || (u - b * upb) == upb - 1;
+        // byte offsets of the lane's three rows in channel 0 (clamped into the tensor where the row is padding)
+        const int plane = H * W * 4;
+        const int o1 = ((b * CIN * H + y) * W + 4 * c) * 4;
+        const int o0 = top ? o1 : o1 - W * 4, o2 = bot ? o1 : o1 + W * 4;
+        f32x2 acc[4][2][2];                                      // [pixel][py][px] x (co 0, co 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q >> 1][q & 1] = (f32x2){0.f, 0.f};
+        f32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(rI, o0, 0, 0), n1 = __builtin_amdgcn_raw_buffer_load_b128(rI, o1, 0, 0),
+              n2 = __builtin_amdgcn_raw_buffer_load_b128(rI, o2, 0, 0);
+#pragma unroll 2
+        for (int ci = 0; ci < CIN; ++ci) {
+            f32x4 v0 = n0, v1 = n1, v2 = n2;
+            {
+                const int cn = ci + 1 < CIN ? ci + 1 : ci;       // (the last round re-reads its own rows: harmless)
+                n0 = __builtin_amdgcn_raw_buffer_load_b128(rI, o0, cn * plane, 0);
+                n1 = __builtin_amdgcn_raw_buffer_load_b128(rI, o1, cn * plane, 0);
+                n2 = __builtin_amdgcn_raw_buffer_load_b128(rI, o2, cn * plane, 0);
+            }
+            float k0 = 1.f, k2 = 0.f;
+            if (aff) { k0 = in.coef[ci * 4]; k2 = in.coef[ci * 4 + 2]; }
+            v0 = sx_max(k0 * v0 + k2, lo); v1 = sx_max(k0 * v1 + k2, lo); v2 = sx_max(k0 * v2 + k2, lo);
+            if (edge) {
+                if (top) v0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (bot) v2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            // rows as 6 columns: 4 c - 1 (from the left neighbour), 4 c .. 4 c + 3, 4 c + 4 (from the right neighbour)
+            float t[3][6];
+            t[0][0] = dpp_mov<0x111>(v0.w); t[0][1] = v0.x; t[0][2] = v0.y; t[0][3] = v0.z; t[0][4] = v0.w; t[0][5] = dpp_mov<0x101>(v0.x);
+            t[1][0] = dpp_mov<0x111>(v1.w); t[1][1] = v1.x; t[1][2] = v1.y; t[1][3] = v1.z; t[1][4] = v1.w; t[1][5] = dpp_mov<0x101>(v1.x);
+            t[2][0] = dpp_mov<0x111>(v2.w); t[2][1] = v2.x; t[2][2] = v2.y; t[2][3] = v2.z; t[2][4] = v2.w; t[2][5] = dpp_mov<0x101>(v2.x);
+            const f32x2 *w2 = reinterpret_cast<const f32x2 *>(wp + ci * 32);      // [tap = 4 ky + kx] -> (co 0, co 1): scalar loads
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px)
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) {
+                            const f32x2 wv2 = w2[(3 - py - 2 * a) * 4 + (3 - px - 2 * bb)];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float x = t[py + a][i + px + bb];      // row y - 1 + py + a, column 4 c + i - 1 + px + bb
+                                acc[i][py][px] += (f32x2){x, x} * wv2;
+                            }
+                        }
+        }
+        // lane holds, per (co, py): output row 2 y + py, columns 8 c .. 8 c + 7 in the order (pixel i, px)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const float bias = co ? b1 : b0;
+                f32x4 lo4 = (f32x4){acc[0][py][0][co], acc[0][py][1][co], acc[1][py][0][co], acc[1][py][1][co]} + bias;
+                f32x4 hi4 = (f32x4){acc[2][py][0][co], acc[2][py][1][co], acc[3][py][0][co], acc[3][py][1][co]} + bias;
+                if (ep.relu) { lo4 = dm_relu4(lo4); hi4 = dm_relu4(hi4); }
+                float *o = out + (((long long)b * COUT + co) * OH + 2 * y + py) * OW + 8 * c;
+                *reinterpret_cast<f32x4 *>(o) = lo4;
+                *reinterpret_cast<f32x4 *>(o + 4) = hi4;
+            }
+    }
+}
+
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution
     return v;
 }
 int stream_depth()
@@ -696,5 +798,21 @@ bool dm_stream_conv_s2_thin(const Operand &in, const WeightView &wv, float *out,
         hipLaunchKernelGGL((conv_s2_thin_stream_kernel<C_, MT_>), dim3(grid), dim3(256), 0, st, in, wv, out, ep, B, H, nslabs);
     DM_CT(1, 1) DM_CT(2, 1) DM_CT(3, 1) DM_CT(4, 1) DM_CT(1, 2) DM_CT(2, 2) DM_CT(3, 2) DM_CT(4, 2) DM_CT(1, 4) DM_CT(2, 4)
 #undef DM_CT
+    return true;
+}
+
+// ConvTranspose2d(4, 2, 1) from up to 64 channels on a 64-column grid to 1 or 2 channels, no gate / residual / statistics
+bool dm_stream_convT_thin(const Operand &in, const WeightView &wv, float *scratch, float *out, const Epilogue &ep, int B, int Cphys,
+                          int CIN, int NOUT, int H, int W, int per_tile, hipStream_t st)
+{
+    if (!(stream_switch() & 16) || per_tile || Cphys != CIN || in.ones || in.mode == DM_LOAD_AFFINE2) return false;
+    if (!(NOUT == 4 || NOUT == 8) || W != 64 || H % 4 || CIN < 1 || CIN > 64 || !scratch) return false;
+    if (ep.mask.p0 || ep.resid || ep.stats || ep.bias_border) return false;
+    if ((in.mode >= DM_LOAD_AFFINE && in.coef_bstride) || (long long)B * CIN * H * W * 4 >= (1LL << 31)) return false;
+    hipLaunchKernelGGL(convT_thin_pack_kernel, dim3((CIN * 32 + 255) / 256), dim3(256), 0, st, wv, scratch, CIN, NOUT / 4);
+    const long long units = (long long)B * (H / 4);
+    const int grid = (int)(units / 4 < 1024 ? (units + 3) / 4 : 1024);
+    if (NOUT == 8) hipLaunchKernelGGL((convT_thin_stream_kernel<2>), dim3(grid), dim3(256), 0, st, in, (const float *)scratch, out, ep, B, CIN, H);
+    else hipLaunchKernelGGL((convT_thin_stream_kernel<1>), dim3(grid), dim3(256), 0, st, in, (const float *)scratch, out, ep, B, CIN, H);
     return true;
 }

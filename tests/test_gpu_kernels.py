@@ -1919,3 +1919,21 @@ def test_stream_conv_4x4s2_few_input_channels(ops, B, cin, nout, h, w, mode, epi
     close(out, ref.float(), 5e-5, 5e-5, "stream conv 4x4/s2")
     if st is not None:
         close_stats(st.sum(0), ref.float(), sq)
+
+
+@pytest.mark.parametrize("B,ci,co,h,mode,relu", [(3, 32, 2, 64, 3, False), (2, 32, 1, 8, 0, True), (5, 64, 2, 16, 1, False),
+                                                 (1, 8, 2, 4, 2, False), (2, 17, 2, 12, 3, True), (70, 32, 2, 64, 3, False)])
+def test_stream_conv_transpose_to_few_channels(ops, B, ci, co, h, mode, relu):
+    """wide_stream.hip: ConvTranspose2d(C -> 1 / 2, 4, 2, 1) on a 64-column grid -- the wide decoder's last layer -- on the vector
+    units: weights as scalar-register pairs, one lane = 4 pixels, neighbours by DPP, padding rows zeroed AFTER the transform."""
+    w = 64
+    x = rnd(B, ci, h, w, seed=1)
+    coef = torch.stack([rnd(ci, seed=3).abs() + 0.5, torch.zeros(ci), rnd(ci, seed=5) * 0.3 + 0.2, torch.zeros(ci)], 1)
+    wt = rnd(ci, co, 4, 4, seed=2, scale=0.2)
+    bias = rnd(co, seed=4)
+    ref = F.conv_transpose2d(load_ref(x.double(), mode, coef.double()), wt.double(), bias.double(), stride=2, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    out, _ = ops.conv3x3(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None), ops.weight_view(wt.to(DEV), 16, co * 16, 4, 1),
+                         B, ci, 4 * co, h, w, taps=9, pixel_shuffle=True, bias=bias.to(DEV), relu=relu)
+    close(out, ref.float(), 5e-5, 5e-5, "stream conv transpose")
