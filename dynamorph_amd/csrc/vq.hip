@@ -1475,12 +1475,16 @@ __global__ __launch_bounds__(1024) void vq_loss_finalize_kernel(const double *__
     }
 }
 
-// 1024-thread workgroups walking the positions with a grid stride: the codebook gradient is accumulated in LDS
+// 1024-thread workgroups (16 waves) walking the positions with a grid stride: the codebook gradient is accumulated in LDS
 // over ALL of a workgroup's positions and flushed once, so the global float atomics (K*D addresses that every
 // workgroup hits) number grid*K*D instead of (P/256)*K*D -- at B = 2048 that flush, not the streaming, was the cost.
 // Codebooks larger than the LDS window (512 x 64, 4096 x 16) are split into windows of codes over grid.y.
 constexpr int VQ_BWD_BLOCK = 1024;
-constexpr int VQ_BWD_LDS = 128 * 1024;     // codebook-gradient window per workgroup (gfx950: 160 KB of LDS per CU)
+constexpr int VQ_BWD_LDS = 136 * 1024;     // codebook-gradient window per workgroup (gfx950: 160 KB of LDS per CU)
+// rows of the window are D + 1 floats apart: a wave adds into cell (code, d) for 64 positions at once -- the same d, 64 different
+// codes -- and with rows of D = 16 / 64 floats every lane hit the same one or two LDS banks (a 32- to 64-way conflict per
+// instruction: at 512 x 64 a third of the kernel's time)
+__host__ __device__ constexpr int vq_bwd_row(int D) { return D + 1; }
 // grid (x: positions, grid stride; y: windows of Kc codes).  A workgroup only touches the positions whose code falls
 // into its window, so z / g_out / dz are still streamed once; idx is read once per window.
 template <int D>
@@ -1490,43 +1494,112 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_kernel(
     float *__restrict__ dz, float *__restrict__ dw, float *__restrict__ dw_slabs, int K, int HW, long long P,
     int Kc)
 {
-    extern __shared__ float s_dw[];    // [Kc][D]
+    extern __shared__ float s_dw[];    // [Kc][D + 1]
+    constexpr int RS = vq_bwd_row(D);
     const long long k_lo = (long long)blockIdx.y * Kc;
     const int kn = K - k_lo < Kc ? (int)(K - k_lo) : Kc;
-    for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
+    for (int i = threadIdx.x; i < kn * RS; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
     __syncthreads();
     const float g_loss = g_loss_dev ? g_loss_dev[0] : 1.f;
     const double N = (double)P * (double)D;
     const float sz = (float)(2.0 * (double)cc / N) * g_loss;   // d/dz of cc * mse(q.detach(), z)
     const float sw = (float)(2.0 / N) * g_loss;                // d/dq of mse(q, z.detach())
-    for (long long pos = (long long)blockIdx.x * VQ_BWD_BLOCK + threadIdx.x; pos < P;
-         pos += (long long)gridDim.x * VQ_BWD_BLOCK) {
-        const long long b = pos / HW, p = pos - b * HW;
-        const long long base = b * (long long)D * HW + p;
-        const long long k = idx[pos];
-        if (k < k_lo || k >= k_lo + kn) continue;
-        const float *__restrict__ q = cb + k * D;
-        const int kl = (int)(k - k_lo);
-        constexpr int DC = D < 16 ? D : 16;                // d in chunks of 16 (register budget of a 1024-thread group)
+    // Every (code, d) cell of the window belongs to ONE wave: wave w owns the dimensions [w DPW, (w + 1) DPW) and walks ALL of
+    // the workgroup's positions, 64 per chunk (lane = position), in a fixed order.  The cell's additions are then program-ordered
+    // inside one wave (chunk by chunk; the lanes of one ds_add_f32 that hit the same cell are served in lane order), so the
+    // window -- and with the slab form the whole gradient -- is the same from launch to launch.  (Until round 6 a thread owned a
+    // position and added into all D cells of its code: 16 waves raced on every cell and 4-6 % of the gradient's elements
+    // differed in the last bits between launches, which Adam turns into +- lr on elements whose sign that decides.)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int DPW = (D + 15) / 16, CH = DPW >= 4 ? 2 : 4;   // dimensions per wave; chunks of 64 positions per stage
+    static_assert(D < 16 || D % 16 == 0, "the waves split the dimensions evenly");
+    const int d_lo = wave * DPW;
+    // Two stages in flight.  Only the codebook row, the window test and the addresses of the store and the LDS addition depend
+    // on a position's code; the codes themselves, z and the upstream gradient depend on the position alone and are requested
+    // one stage ahead -- a wave used to wait out two dependent round trips (codes, then everything else) per 256 positions
+    // with nothing else in flight, which was the whole kernel at D = 16.
+    // (sample, offset) of a stage's first position advance without a division: with H W a multiple of a stage's positions all
+    // of them lie in one sample (`whole`).
+    struct Stage {
+        long long k[CH], base[CH];
+        float zv[DPW][CH], gv[DPW][CH];
+    };
+    const bool whole = HW % (64 * CH) == 0;
+    const long long stride = (long long)gridDim.x * (64 * CH), stride_b = stride / HW, stride_r = stride - stride_b * HW;
+    long long sb = ((long long)blockIdx.x * (64 * CH)) / HW, sr = ((long long)blockIdx.x * (64 * CH)) - sb * HW;
+    auto request = [&](Stage &S, long long c0) {
 #pragma unroll
-        for (int d0 = 0; d0 < D; d0 += DC) {
-            float zv[DC], gv[DC], qv[DC];
-#pragma unroll
-            for (int j = 0; j < DC; ++j) {                 // all loads of the chunk first: one round trip, not DC
-                const long long o = base + (long long)(d0 + j) * HW;
-                zv[j] = z[o]; qv[j] = q[d0 + j];
-                gv[j] = g_out ? g_out[o] : 0.f;
+        for (int c = 0; c < CH; ++c) {
+            const long long pos = c0 + 64 * c + lane;
+            const bool in = pos < P;
+            const long long pp = in ? pos : 0;
+            const long long kk = idx[pp];
+            S.k[c] = in ? kk : -1;
+            if (whole) {
+                S.base[c] = in ? sb * (long long)D * HW + sr + 64 * c + lane : 0;
+            } else {
+                const long long b = pp / HW;
+                S.base[c] = b * (long long)D * HW + (pp - b * HW);
             }
 #pragma unroll
-            for (int j = 0; j < DC; ++j) {
-                if (dz) dz[base + (long long)(d0 + j) * HW] = gv[j] + sz * (zv[j] - qv[j]);
-                atomicAdd(&s_dw[kl * D + d0 + j], sw * (qv[j] - zv[j]));
+            for (int j = 0; j < DPW; ++j) {
+                const long long o = S.base[c] + (long long)(d_lo + j) * HW;
+                S.zv[j][c] = z[o];
+                S.gv[j][c] = g_out ? g_out[o] : 0.f;
             }
+        }
+        sb += stride_b; sr += stride_r;
+        if (sr >= HW) { sr -= HW; ++sb; }
+    };
+    auto process = [&](const Stage &S) {
+        int kl[CH];
+        bool hit[CH];
+        // the wave's DPW dimensions of each position's code: ONE vector load per position where DPW is 2 / 4 / 8
+        float qd[CH][DPW];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            hit[c] = S.k[c] >= k_lo && S.k[c] < k_lo + kn;
+            kl[c] = hit[c] ? (int)(S.k[c] - k_lo) : 0;
+            const float *q = cb + (hit[c] ? S.k[c] : 0) * D + d_lo;
+            if constexpr (DPW % 4 == 0) {
+#pragma unroll
+                for (int j = 0; j < DPW; j += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(q + j);
+                    qd[c][j] = v.x; qd[c][j + 1] = v.y; qd[c][j + 2] = v.z; qd[c][j + 3] = v.w;
+                }
+            } else if constexpr (DPW == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(q);
+                qd[c][0] = v.x; qd[c][1] = v.y;
+            } else {
+                qd[c][0] = q[0];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DPW; ++j)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (hit[c]) {
+                    const int d = d_lo + j;
+                    if (dz) dz[S.base[c] + (long long)d * HW] = S.gv[j][c] + sz * (S.zv[j][c] - qd[c][j]);
+                    atomicAdd(&s_dw[kl[c] * RS + d], sw * (qd[c][j] - S.zv[j][c]));
+                }
+    };
+    if (d_lo < D) {
+        Stage sa, sbuf;
+        long long c0 = (long long)blockIdx.x * (64 * CH);
+        if (c0 < P) request(sa, c0);
+        while (c0 < P) {
+            const long long c1 = c0 + stride, c2 = c1 + stride;
+            if (c1 < P) request(sbuf, c1);
+            process(sa);
+            if (c2 < P) request(sa, c2);
+            if (c1 < P) process(sbuf);
+            c0 = c2;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) {
-        const float v = s_dw[i];
+        const float v = s_dw[(i / D) * RS + i % D];
         if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + k_lo * D + i] = v;   // dm_reduce_slabs adds them in slab order
         else if (v != 0.f) atomicAdd(&dw[k_lo * D + i], v);
     }
@@ -1539,32 +1612,38 @@ __global__ __launch_bounds__(VQ_BWD_BLOCK) void vq_backward_any_kernel(
     const float *__restrict__ g_out, const float *__restrict__ g_loss_dev, float cc,
     float *__restrict__ dz, float *__restrict__ dw, float *__restrict__ dw_slabs, int K, int D, int HW, long long P, int Kc)
 {
-    extern __shared__ float s_dw[];    // [Kc][D]
+    extern __shared__ float s_dw[];    // [Kc][D + 1]
+    const int RS = vq_bwd_row(D);
     const long long k_lo = (long long)blockIdx.y * Kc;
     const int kn = K - k_lo < Kc ? (int)(K - k_lo) : Kc;
-    for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
+    for (int i = threadIdx.x; i < kn * RS; i += VQ_BWD_BLOCK) s_dw[i] = 0.f;
     __syncthreads();
     const float g_loss = g_loss_dev ? g_loss_dev[0] : 1.f;
     const double N = (double)P * (double)D;
     const float sz = (float)(2.0 * (double)cc / N) * g_loss;
     const float sw = (float)(2.0 / N) * g_loss;
-    for (long long pos = (long long)blockIdx.x * VQ_BWD_BLOCK + threadIdx.x; pos < P; pos += (long long)gridDim.x * VQ_BWD_BLOCK) {
-        const long long b = pos / HW, p = pos - b * HW;
-        const long long base = b * (long long)D * HW + p;
-        const long long k = idx[pos];
-        if (k < k_lo || k >= k_lo + kn) continue;
-        const float *__restrict__ q = cb + k * D;
-        const int kl = (int)(k - k_lo);
-        for (int d = 0; d < D; ++d) {
-            const long long o = base + (long long)d * HW;
-            const float zv = z[o], qv = q[d], gv = g_out ? g_out[o] : 0.f;
-            if (dz) dz[o] = gv + sz * (zv - qv);
-            atomicAdd(&s_dw[kl * D + d], sw * (qv - zv));
+    // (waves own dimensions, as in vq_backward_kernel: the cells' additions are ordered)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dpw = (D + 15) / 16, d_lo = wave * dpw, d_hi = d_lo + dpw < D ? d_lo + dpw : D;
+    if (d_lo < D)
+        for (long long c0 = (long long)blockIdx.x * 64; c0 < P; c0 += (long long)gridDim.x * 64) {
+            const long long pos = c0 + lane;
+            const long long k = pos < P ? idx[pos] : -1;
+            if (k < k_lo || k >= k_lo + kn) continue;
+            const long long b = pos / HW;
+            const long long base = b * (long long)D * HW + (pos - b * HW);
+            const float *__restrict__ q = cb + k * D;
+            const int kl = (int)(k - k_lo);
+            for (int d = d_lo; d < d_hi; ++d) {
+                const long long o = base + (long long)d * HW;
+                const float zv = z[o], qv = q[d], gv = g_out ? g_out[o] : 0.f;
+                if (dz) dz[o] = gv + sz * (zv - qv);
+                atomicAdd(&s_dw[kl * RS + d], sw * (qv - zv));
+            }
         }
-    }
     __syncthreads();
     for (int i = threadIdx.x; i < kn * D; i += VQ_BWD_BLOCK) {
-        const float v = s_dw[i];
+        const float v = s_dw[(i / D) * RS + i % D];
         if (dw_slabs) dw_slabs[(long long)blockIdx.x * K * D + k_lo * D + i] = v;
         else if (v != 0.f) atomicAdd(&dw[k_lo * D + i], v);
     }
@@ -2064,9 +2143,9 @@ int vq_backward_launch(const char *who, const float *z, const float *codebook, c
     DM_REQUIRE(z && codebook && idx && (dw || dw_slabs), "%s: NULL pointer", who);
     DM_REQUIRE(vq_dim_supported(D), "%s: embedding_dim %d outside 1 .. 512", who, D);
     const long long P = (long long)B * H * W;
-    int Kc = VQ_BWD_LDS / (D * (int)sizeof(float));
+    int Kc = VQ_BWD_LDS / (vq_bwd_row(D) * (int)sizeof(float));
     if (Kc > K) Kc = K;
-    const size_t lds = (size_t)Kc * D * sizeof(float);
+    const size_t lds = (size_t)Kc * vq_bwd_row(D) * sizeof(float);
     const int grid = vq_backward_grid(P, K, D);
     const dim3 g3((unsigned)grid, (unsigned)((K + Kc - 1) / Kc));
     hipStream_t s = (hipStream_t)stream;

@@ -1937,3 +1937,27 @@ def test_stream_conv_transpose_to_few_channels(ops, B, ci, co, h, mode, relu):
     out, _ = ops.conv3x3(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None), ops.weight_view(wt.to(DEV), 16, co * 16, 4, 1),
                          B, ci, 4 * co, h, w, taps=9, pixel_shuffle=True, bias=bias.to(DEV), relu=relu)
     close(out, ref.float(), 5e-5, 5e-5, "stream conv transpose")
+
+
+@pytest.mark.parametrize("K,D,B,H", [(512, 64, 5, 32), (4096, 16, 4, 64), (300, 32, 3, 16), (100, 24, 3, 16)])
+def test_vq_backward_large_codebooks_is_bit_reproducible(ops, K, D, B, H):
+    """Codebooks above 64 codes accumulate the codebook gradient in an LDS window.  Until round 6 every wave added into every
+    cell (4-6 % of the elements differed in their last bits from launch to launch, and Adam turns a sign decided by that into
+    +- lr); now a cell belongs to one wave, which adds in position order: repeated launches are bit-equal, and equal to the
+    float64 sum to rounding."""
+    z = rnd(B, D, H, H, seed=1).to(DEV)
+    cb = rnd(K, D, seed=2).to(DEV)
+    idx = torch.cdist(z.permute(0, 2, 3, 1).reshape(-1, D), cb).argmin(1).reshape(B, H, H)
+    g = rnd(B, D, H, H, seed=3).to(DEV)
+    gl = torch.ones(1, device=DEV)
+    outs = []
+    for _ in range(4):
+        dz, slabs = ops.vq_backward_slabs(z, cb, idx, g, gl, 0.25)
+        outs.append((dz.clone(), ops.reduce_slabs(slabs, torch.empty_like(cb)).clone()))
+    for dz, dw in outs[1:]:
+        assert torch.equal(dz, outs[0][0]) and torch.equal(dw, outs[0][1])
+    n = float(B * H * H * D)
+    q = cb[idx.reshape(-1)].double()
+    zf = z.permute(0, 2, 3, 1).reshape(-1, D).double()
+    ref = torch.zeros(K, D, dtype=torch.float64, device=DEV).index_add_(0, idx.reshape(-1), (2.0 / n) * (q - zf))
+    close(outs[0][1], ref.float(), 1e-5, 1e-5 * float(ref.abs().max()), "codebook gradient")

@@ -1067,13 +1067,5 @@ def test_fused_trainer_z32_equals_eager_adam(kw, B, with_tm, use_graph):
             assert int(sd1[k]) == int(sd2[k]) == 3, k
         elif k in Z32_BN_FED_BIASES:
             continue                                           # (torch's Adam random-walks on the autograd path's rounding noise)
-        elif k == "vq.w.weight" and sd1[k].shape[0] > 64:
-            # codebooks beyond 64 codes: the codebook gradient is summed with LDS / global float atomics (csrc/vq.hip,
-            # vq_backward_kernel: 1.98 -> 0.11 ms against 16.8 M global atomics), so its rounding differs from launch to launch
-            # -- between the two runs here too -- and Adam's first steps are lr * sign(gradient): an element whose sign that
-            # rounding decides moves by up to 2 lr per step.  Bounded, not hidden: a handful of elements, never beyond the walk.
-            d = (sd1[k] - sd2[k]).abs()
-            tol = 2.5e-4 * max(1.0, sd1[k].abs().max().item())
-            assert d.max().item() <= 2.5 * 1e-3 * 3 and (d > tol).float().mean().item() <= 1e-3, (k, d.max().item(), int((d > tol).sum()))
         else:
             assert (sd1[k] - sd2[k]).abs().max().item() <= 2.5e-4 * max(1.0, sd1[k].abs().max().item()), k
