@@ -9,7 +9,9 @@
 // and (k, column i) of B.  With pixels as the K dimension a lane loads FOUR consecutive pixels of ITS channel (one 16-byte
 // load; the four lanes k = 0..3 of a channel cover 64 contiguous bytes) and the four values feed four K steps -- K step j
 // pairs lane k with pixel 4 k + j on both operands, which is all a sum over pixels needs.  Every wave runs its own stream of
-// 32-pixel groups (whole 128-byte lines per channel row), D groups in flight in registers, and nothing but the final slab write is shared.
+// 32-pixel groups (whole 128-byte lines per channel row), D groups in flight in registers, and nothing but the final slab
+// write is shared.  The image-side 4x4 / stride 2 layers (1-4 channels) follow the same idea with the taps as a matrix
+// dimension; the last transposed convolution (eight outputs per input pixel) is vector-unit work and sits here too.
 #include "dm_common.h"
 #include <stdlib.h>
 #include <type_traits>
