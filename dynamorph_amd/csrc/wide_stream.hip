@@ -621,7 +621,6 @@ __global__ __launch_bounds__(256, 4) void convT_thin_stream_kernel(Operand in, c
             for (int q = 0; q < 4; ++q) acc[i][q >> 1][q & 1] = (f32x2){0.f, 0.f};
         f32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(rI, o0, 0, 0), n1 = __builtin_amdgcn_raw_buffer_load_b128(rI, o1, 0, 0),
               n2 = __builtin_amdgcn_raw_buffer_load_b128(rI, o2, 0, 0);
-#pragma unroll 2
         for (int ci = 0; ci < CIN; ++ci) {
             f32x4 v0 = n0, v1 = n1, v2 = n2;
             {
