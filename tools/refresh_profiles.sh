@@ -25,6 +25,7 @@ python3 tools/kstats_summary.py $out/c3 41 > $out/${tag}_c3_b2048_kernel_table.t
 python3 tools/kstats_summary.py $out/c2 35 > $out/${tag}_c2_b1024_kernel_table.txt
 python3 tools/kstats_summary.py $out/c5 19 > $out/${tag}_c5_k4096_256px_b1024_kernel_table.txt
 python3 tools/kstats_summary.py $out/z32 19 > $out/${tag}_z32ex_b768_kernel_table.txt
+python3 tools/exp/step_launches.py $out/z32 adam_kernel 30 > $out/${tag}_z32ex_b768_step_launches.txt
 rm -rf $out/c3 $out/c2 $out/c5 $out/z32
 # HBM bytes per launch of the roofline kernels: the two counters in their own passes, no trace domains with them
 cd /tmp
@@ -33,6 +34,13 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $roo
 cd $root
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write 2048 > $out/${tag}_pmc_traffic.json
 rm -rf $out/pmc_fetch $out/pmc_write
+# ... and of the example configuration's rebuilt kernels, layer by layer at B = 768
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/zf -- python3 $root/tools/exp/z32_layers.py > $out/z32_layers_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/zw -- python3 $root/tools/exp/z32_layers.py > $out/z32_layers_write.log 2>&1
+cd $root
+python3 tools/exp/z32_pmc.py $out/zf $out/zw > $out/${tag}_z32ex_pmc_traffic.json
+rm -rf $out/zf $out/zw
 python3 tools/vqbench.py > $out/${tag}_vq_kernels.txt 2>&1
 # train() end to end (resident / streaming / synchronous feeds) and the kernels of the resident loop
 python3 tools/trainbench.py --full > $out/${tag}_trainbench.jsonl 2> $out/trainbench.err
