@@ -674,9 +674,144 @@ __global__ __launch_bounds__(256, 4) void convT_thin_stream_kernel(Operand in, c
     }
 }
 
+// ------------------------------------------------ 4x4 / stride 2 convolution 32 -> 64 channels on a 64 x 64 grid (-> 32 x 32)
+// The wide encoder's second convolution and the data gradient of the decoder's first transposed convolution: 51.5 GFLOP per
+// launch at B = 768, matrix bound -- the tiled kernel ran it at 70-80 TFLOP/s (two passes of 32 output channels, each staging
+// the input again; a chunk of 8 channels between two barriers with 128 matrix instructions per wave to hide its loads behind).
+// Here the WEIGHTS are what sits in LDS -- all of them, 128 KB, written once per workgroup in the order the A operand reads
+// them ([K step = (ci, kx)][M tile][ky][co % 16]: 64 consecutive floats per read) -- and the activations go straight from
+// global memory into the B operand as in conv_s2_thin_stream_kernel (K step (ci, kx), rows of lanes = ky, two aligned loads
+// per input channel, neighbours by DPP).  Eight waves per workgroup (one workgroup per CU), each with its own stream of
+// units and no barrier after the weights are in.  A unit is two output rows x 32 pixels: lanes p < 8 hold row oy, the others
+// row oy + 1, pixel 4 (p & 7) + j in N tile j.
+template <bool AFF>
+__global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep,
+                                                                     int B, int nslabs)
+{
+    constexpr int CIN = 32, CO = 64, MT = 4, H = 64, W = 64, OH = 32, OW = 32, KS = CIN * 4, R = 4;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];          // [KS][MT][4 ky][16]: 128 KB
+    __shared__ __attribute__((aligned(16))) float s_ep[CO * 4];
+    __shared__ double s_red[8 * CO * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < KS * MT * 64; i += 512) {
+        const int ks = i >> 8, mt = (i >> 6) & 3, ky = (i >> 4) & 3, m = i & 15;
+        s_w[i] = wv.w[wv.off + (long long)(16 * mt + m) * wv.sn + (long long)(ks >> 2) * wv.sc + (long long)ky * wv.sky + (long long)(ks & 3) * wv.skx];
+    }
+    for (int i = tid; i < CO; i += 512) {
+        float mc0 = 1.f, mc2 = 0.f;
+        if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) { mc0 = ep.mask.coef[i * 4]; mc2 = ep.mask.coef[i * 4 + 2]; }
+        s_ep[i * 4] = ep.bias ? ep.bias[i] : 0.f; s_ep[i * 4 + 1] = mc0; s_ep[i * 4 + 2] = mc2; s_ep[i * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+
+    const int upb = OH >> 1;                                     // units of two output rows per sample
+    const long long total = (long long)B * upb;
+    const int u0 = (int)(total * blockIdx.x / gridDim.x), u1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int n = (u1 - u0 - wave + 7) >> 3;                     // this wave's units: u0 + wave, + 8, ...
+    const unsigned bytesI = (unsigned)((long long)B * CIN * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, 0, 0x00020000);
+    const int half = p >> 3, pc = p & 7;
+    const float ilo = stream_floor(in);
+    const float *sa = s_w + kq * 16 + p;                         // + (ks * MT + mt) * 64
+
+    f32x4 x0[R], x1[R];
+    int vbase = 0;                                               // byte offset of the lane's row / columns in channel 0 of the unit in flight
+    bool rowbad = false;
+    auto unit_begin = [&](int u) {
+        const int b = u / upb, oy = ((u - b * upb) << 1) + half;
+        const int r = 2 * oy + kq - 1;
+        const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
+        vbase = ((b * CIN * H + rc) * W + 8 * pc) * 4;
+        return r != rc;
+    };
+    auto issue = [&](auto slot, int ci, bool live) {
+        constexpr int sl = decltype(slot)::value;
+        x0[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, vbase, ci * (H * W * 4), 0);
+        x1[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, vbase + 16, ci * (H * W * 4), 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    bool nextbad = unit_begin(n > 0 ? u0 + wave : 0);
+    {
+        auto pro = [&](auto self, auto kc) -> void {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < R) { issue(kc, k, n > 0); self(self, std::integral_constant<int, k + 1>{}); }
+        };
+        pro(pro, std::integral_constant<int, 0>{});
+    }
+
+    double st1 = 0.0, st2 = 0.0;
+    for (int it = 0; it < n; ++it) {
+        const int u = u0 + wave + 8 * it;
+        const int b = u / upb, oy = ((u - b * upb) << 1) + half;
+        const bool more = it + 1 < n;
+        rowbad = nextbad;
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int cb = 0; cb < CIN; cb += R) {
+            // R input channels per round: their loads were requested a round ago; the slots are refilled as they are consumed
+            if (cb + R == CIN) nextbad = unit_begin(more ? u + 8 : u);          // the refills below belong to the next unit
+            auto chan = [&](auto self, auto cc) -> void {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c < R) {
+                    const int ci = cb + c;
+                    f32x4 a0 = x0[c], a1 = x1[c];
+                    if (AFF) {
+                        const StreamCoef kc = stream_coef(in, ci);
+                        a0 = sx_max(kc.c0 * a0 + kc.c2, ilo); a1 = sx_max(kc.c0 * a1 + kc.c2, ilo);
+                    }
+                    if (rowbad) { a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0; }
+                    float am = dpp_mov<0x111>(a1.w), ap = dpp_mov<0x101>(a0.x);
+                    am = pc == 0 ? 0.f : am;                                     // the lane to the left belongs to the other row
+                    ap = pc == 7 ? 0.f : ap;
+                    {
+                        const int cn = cb + R + c;                               // this slot's next channel: this unit's, or the next unit's
+                        issue(cc, cn < CIN ? cn : cn - CIN, cn < CIN ? true : more);
+                    }
+                    const f32x4 e0 = (f32x4){am, a0.y, a0.w, a1.y}, e1 = (f32x4){a0.x, a0.z, a1.x, a1.z};
+                    const f32x4 e2 = (f32x4){a0.y, a0.w, a1.y, a1.w}, e3 = (f32x4){a0.z, a1.x, a1.z, ap};
+                    const float *wp = sa + ci * (4 * MT * 64);
+                    auto step = [&](const f32x4 &e, int kx) {
+                        float wa[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) wa[mt] = wp[(kx * MT + mt) * 64];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt], e[j], acc[mt][j], 0, 0, 0);
+                    };
+                    step(e0, 0); step(e1, 1); step(e2, 2); step(e3, 3);
+                    self(self, std::integral_constant<int, c + 1>{});
+                }
+            };
+            // (vbase switches to the next unit before the LAST round's refills; rows of THIS unit were all requested by then)
+            chan(chan, std::integral_constant<int, 0>{});
+        }
+        stream_epilogue<MT>(acc, ep, s_ep, out, (((long long)b * CO * OH + oy) * OW) + 4 * pc, (long long)OH * OW, p, kq, st1, st2);
+    }
+    if (ep.stats) {
+        if (true) {
+            const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
+            s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2;
+        }
+        __syncthreads();
+        for (int i = tid; i < CO * 2; i += 512) {
+            double sum = 0.0;
+            for (int w = 0; w < 8; ++w) sum += s_red[(w * CO + (i >> 1)) * 2 + (i & 1)];
+            ep.stats[((long long)blockIdx.x * CO + (i >> 1)) * 2 + (i & 1)] = sum;
+        }
+        for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+            for (int i = tid; i < CO * 2; i += 512) ep.stats[((long long)sl * CO + (i >> 1)) * 2 + (i & 1)] = 0.0;
+    }
+}
+
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS
     return v;
 }
 int stream_depth()
@@ -815,5 +950,33 @@ bool dm_stream_convT_thin(const Operand &in, const WeightView &wv, float *scratc
     const int grid = (int)(units / 4 < 1024 ? (units + 3) / 4 : 1024);
     if (NOUT == 8) hipLaunchKernelGGL((convT_thin_stream_kernel<2>), dim3(grid), dim3(256), 0, st, in, (const float *)scratch, out, ep, B, CIN, H);
     else hipLaunchKernelGGL((convT_thin_stream_kernel<1>), dim3(grid), dim3(256), 0, st, in, (const float *)scratch, out, ep, B, CIN, H);
+    return true;
+}
+
+// 4x4 / stride 2 convolution 32 -> 64 channels on a 64 x 64 input (the wide encoder's second convolution, the data gradient
+// of the decoder's first transposed convolution)
+bool dm_stream_conv_s2_wide(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                            int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st)
+{
+    if (!(stream_switch() & 32) || per_tile || Cphys != CIN || in.ones || ep.bias_border || in.mode == DM_LOAD_AFFINE2) return false;
+    if (CIN != 32 || NOUT != 64 || H != 64 || W != 64 || (long long)B * 64 * 32 * 32 * 4 >= (1LL << 31)) return false;
+    if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
+    if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
+    static bool attr = false;
+    const int lds = 128 * 1024;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return false;
+        attr = true;
+    }
+    const long long units = (long long)B * 16;
+    int grid = (int)(units / 8 < 256 ? (units + 7) / 8 : 256);
+    if (ep.stats && grid > nslabs) grid = nslabs;
+    if (grid < 1) grid = 1;
+    if (in.mode >= DM_LOAD_AFFINE || in.mode == DM_LOAD_RELU)
+        hipLaunchKernelGGL((conv_s2_wide_stream_kernel<true>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
+    else
+        hipLaunchKernelGGL((conv_s2_wide_stream_kernel<false>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
     return true;
 }

@@ -1961,3 +1961,41 @@ def test_vq_backward_large_codebooks_is_bit_reproducible(ops, K, D, B, H):
     zf = z.permute(0, 2, 3, 1).reshape(-1, D).double()
     ref = torch.zeros(K, D, dtype=torch.float64, device=DEV).index_add_(0, idx.reshape(-1), (2.0 / n) * (q - zf))
     close(outs[0][1], ref.float(), 1e-5, 1e-5 * float(ref.abs().max()), "codebook gradient")
+
+
+@pytest.mark.parametrize("B,mode,epi", [(3, 3, "bias+stats"), (5, 0, "none"), (2, 1, "gate+q"), (1, 2, "all"), (70, 3, "bias+stats")])
+def test_stream_conv_4x4s2_32_to_64_weights_in_lds(ops, B, mode, epi):
+    """wide_stream.hip: the wide encoder's second convolution (32 -> 64 channels, 64 x 64 -> 32 x 32) with all weights resident
+    in LDS and the activations loaded straight into the matrix instruction's layout: two output rows per unit, the row seam
+    between the two halves of a lane row, padding rows zeroed after the transform, every epilogue operand."""
+    cin, nout, h, w = 32, 64, 64, 64
+    x = rnd(B, cin, h, w, seed=1)
+    coef = torch.stack([rnd(cin, seed=3).abs() + 0.5, torch.zeros(cin), rnd(cin, seed=5) * 0.3 + 0.2, torch.zeros(cin)], 1)
+    xin = load_ref(x.double(), mode, coef.double())
+    wt = rnd(nout, cin, 4, 4, seed=6, scale=0.1)
+    kw = {}
+    bias = rnd(nout, seed=7) if epi in ("bias+stats", "all") else None
+    ref = F.conv2d(xin, wt.double(), bias.double() if bias is not None else None, stride=2, padding=1)
+    if bias is not None:
+        kw.update(bias=bias.to(DEV))
+    if epi == "all":
+        kw.update(relu=True)
+        ref = F.relu(ref)
+    gate, q, resid = rnd(B, nout, 32, 32, seed=8), rnd(B, nout, 32, 32, seed=9), rnd(B, nout, 32, 32, seed=10)
+    mcoef = torch.stack([rnd(nout, seed=11), torch.zeros(nout), rnd(nout, seed=12) * 0.3, torch.zeros(nout)], 1)
+    if epi in ("gate+q", "all"):
+        kw.update(mask=ops.Op(gate.to(DEV), 2, mcoef.to(DEV)))
+        ref = ref * ((mcoef[:, 0].view(1, -1, 1, 1) * gate + mcoef[:, 2].view(1, -1, 1, 1)) > 0)
+    sq = None
+    if epi == "all":
+        kw.update(resid=resid.to(DEV), stat_q=q.to(DEV))
+        ref = ref + resid
+        sq = q
+    elif epi == "gate+q":
+        kw.update(stat_q=kw["mask"].p0)
+        sq = gate
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None), ops.weight_view(wt.to(DEV), cin * 16, 16, 4, 1),
+                            B, cin, nout, h, w, want_stats=epi != "none", **kw)
+    close(out, ref.float(), 5e-5, 5e-5, "stream conv 4x4/s2 32 -> 64")
+    if st is not None:
+        close_stats(st.sum(0), ref.float(), sq)
