@@ -809,9 +809,211 @@ __global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in,
     }
 }
 
+// --------------------------------------- ConvTranspose2d(64 -> 32, 4, 2, 1) on a 32 x 32 grid (-> 64 x 64), weights in LDS
+// The wide decoder's first transposed convolution and the data gradient of the encoder's second convolution: the mirror image
+// of conv_s2_wide_stream_kernel.  out[co][2 y + py][2 x + px] = sum over (ci, a, b) of in'[ci][y - 1 + py + a][x - 1 + px + b] *
+// W[ci][co][3 - py - 2 a][3 - px - 2 b]: per output parity a 2 x 2 convolution over 64 channels, K = 256.  M = output channels
+// (2 tiles), N = input pixels, K step = 4 input channels (lane row kq = channel) x one (parity, tap): 16 of them per channel
+// quad, 128 matrix instructions, no structural zero.  All weights (128 KB) sit in LDS as the A operand reads them; a lane loads
+// its pixel quad of the rows y - 1, y, y + 1 of ITS channel (three 16-byte loads per K step, neighbours by DPP) and every
+// (dy, dx) shift of them is a B operand.  A unit is two input rows x 32 pixels (lanes p < 8: row y, the others y + 1); the four
+// parities of a lane's four pixels leave as 8 consecutive output columns per (channel, output row).
+template <bool IN2>
+__global__ __launch_bounds__(512, 1) void convT_wide_stream_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep,
+                                                                   int B, int nslabs)
+{
+    constexpr int CIN = 64, CO = 32, MT = 2, H = 32, W = 32, OH = 64, OW = 64, KS = CIN / 4, R = 2;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];          // [KS][16 taps][MT][4 ci][16 co]: 128 KB
+    __shared__ __attribute__((aligned(16))) float s_cf[CIN * 4];
+    __shared__ __attribute__((aligned(16))) float s_ep[CO * 4];
+    __shared__ double s_red[8 * CO * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < KS * 16 * MT * 64; i += 512) {
+        const int ks = i >> 11, tap = (i >> 7) & 15, mt = (i >> 6) & 1, c = (i >> 4) & 3, m = i & 15;
+        s_w[i] = wv.w[wv.off + (long long)(16 * mt + m) * wv.sn + (long long)(4 * ks + c) * wv.sc + (long long)(tap >> 2) * wv.sky + (long long)(tap & 3) * wv.skx];
+    }
+    for (int i = tid; i < CIN; i += 512) {
+        const StreamCoef c = stream_coef(in, i);
+        s_cf[i * 4] = c.c0; s_cf[i * 4 + 1] = c.c1; s_cf[i * 4 + 2] = c.c2; s_cf[i * 4 + 3] = stream_floor(in);
+    }
+    for (int i = tid; i < CO; i += 512) {
+        float mc0 = 1.f, mc2 = 0.f;
+        if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) { mc0 = ep.mask.coef[i * 4]; mc2 = ep.mask.coef[i * 4 + 2]; }
+        s_ep[i * 4] = ep.bias ? ep.bias[i] : 0.f; s_ep[i * 4 + 1] = mc0; s_ep[i * 4 + 2] = mc2; s_ep[i * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+
+    const int upb = H >> 1;
+    const long long total = (long long)B * upb;
+    const int u0 = (int)(total * blockIdx.x / gridDim.x), u1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int n = (u1 - u0 - wave + 7) >> 3;                     // this wave's units: u0 + wave, + 8, ...
+    const unsigned bytesI = (unsigned)((long long)B * CIN * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(IN2 ? in.p1 : in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, 0, 0x00020000);
+    const int half = p >> 3, pc = p & 7;
+    const float *sa = s_w + kq * 16 + p;                         // + ((ks * 16 + tap) * MT + mt) * 64
+
+    f32x4 r0[R], r1[R], r2[R], q0[IN2 ? R : 1], q1[IN2 ? R : 1], q2[IN2 ? R : 1];
+    int v0 = 0, v1 = 0, v2 = 0;                                  // byte offsets of the lane's three rows in channel kq of the unit in flight
+    bool top = false, bot = false;
+    auto unit_begin = [&](int u, bool &t, bool &bo) {
+        const int b = u / upb, y = ((u - b * upb) << 1) + half;
+        t = y == 0; bo = y == H - 1;
+        v1 = (((b * CIN + kq) * H + y) * W + 4 * pc) * 4;
+        v0 = t ? v1 : v1 - W * 4;
+        v2 = bo ? v1 : v1 + W * 4;
+    };
+    auto issue = [&](auto slot, int ks, bool live) {
+        constexpr int sl = decltype(slot)::value;
+        const int so = ks * (4 * H * W * 4);
+        r0[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v0, so, 0);
+        r1[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v1, so, 0);
+        r2[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v2, so, 0);
+        if constexpr (IN2) {
+            q0[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, v0, so, 0);
+            q1[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, v1, so, 0);
+            q2[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, v2, so, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    bool ntop = false, nbot = false;
+    unit_begin(n > 0 ? u0 + wave : 0, ntop, nbot);
+    issue(std::integral_constant<int, 0>{}, 0, n > 0);
+    issue(std::integral_constant<int, 1>{}, 1, n > 0);
+
+    double st1 = 0.0, st2 = 0.0;
+    for (int it = 0; it < n; ++it) {
+        const int u = u0 + wave + 8 * it;
+        const int b = u / upb, y = ((u - b * upb) << 1) + half;
+        const bool more = it + 1 < n;
+        top = ntop; bot = nbot;
+        f32x4 acc[2][2][MT][4];                                  // [py][px][mt][pixel j] x 4 channels
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q >> 1][q & 1][mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kb = 0; kb < KS; kb += R) {
+            if (kb + R == KS) unit_begin(more ? u + 8 : u, ntop, nbot);     // the refills of the last round belong to the next unit
+            auto kstep = [&](auto self, auto cc) -> void {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c < R) {
+                    const int ks = kb + c;
+                    const f32x4 cf = *reinterpret_cast<const f32x4 *>(&s_cf[(4 * ks + kq) * 4]);
+                    f32x4 a0 = r0[c], a1 = r1[c], a2 = r2[c];
+                    if constexpr (IN2) {
+                        a0 = cf.x * a0 + (cf.y * q0[c] + cf.z); a1 = cf.x * a1 + (cf.y * q1[c] + cf.z); a2 = cf.x * a2 + (cf.y * q2[c] + cf.z);
+                    } else {
+                        a0 = cf.x * a0 + cf.z; a1 = cf.x * a1 + cf.z; a2 = cf.x * a2 + cf.z;
+                    }
+                    a0 = sx_max(a0, cf.w); a1 = sx_max(a1, cf.w); a2 = sx_max(a2, cf.w);
+                    if (top) a0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (bot) a2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    {
+                        const int kn = kb + R + c;
+                        issue(cc, kn < KS ? kn : kn - KS, kn < KS ? true : more);
+                    }
+                    // rows as 6 columns: 4 pc - 1 (left neighbour; 0 at the row's start), 4 pc .. + 3, 4 pc + 4 (right neighbour)
+                    float t[3][6];
+                    const bool ls = pc == 0, rs = pc == 7;
+#define DM_ROW6(T, A)                                                                                            \
+                    { const float l = dpp_mov<0x111>(A.w), r = dpp_mov<0x101>(A.x);                               \
+                      T[0] = ls ? 0.f : l; T[1] = A.x; T[2] = A.y; T[3] = A.z; T[4] = A.w; T[5] = rs ? 0.f : r; }
+                    DM_ROW6(t[0], a0) DM_ROW6(t[1], a1) DM_ROW6(t[2], a2)
+#undef DM_ROW6
+                    const float *wp = sa + ks * (16 * MT * 64);
+#pragma unroll
+                    for (int py = 0; py < 2; ++py)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                                for (int bb = 0; bb < 2; ++bb) {
+                                    const int tap = (3 - py - 2 * a) * 4 + (3 - px - 2 * bb);
+                                    float wa[MT];
+#pragma unroll
+                                    for (int mt = 0; mt < MT; ++mt) wa[mt] = wp[(tap * MT + mt) * 64];
+#pragma unroll
+                                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                            acc[py][px][mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt], t[py + a][j + px + bb], acc[py][px][mt][j], 0, 0, 0);
+                                }
+                    self(self, std::integral_constant<int, c + 1>{});
+                }
+            };
+            kstep(kstep, std::integral_constant<int, 0>{});
+        }
+        // ---- epilogue: (mt, i) -> channel 16 mt + 4 kq + i; per output row 2 y + py the lane's 8 columns 8 pc .. 8 pc + 7 = (pixel j, px)
+        float sel1 = 0.f, sel2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = 16 * mt + 4 * kq + i;
+                const f32x4 ec = *reinterpret_cast<const f32x4 *>(&s_ep[co * 4]);
+                float sa1 = 0.f, sa2 = 0.f;
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const long long o = (((long long)b * CO + co) * OH + 2 * y + py) * OW + 8 * pc;
+                    f32x4 lo = (f32x4){acc[py][0][mt][0][i], acc[py][1][mt][0][i], acc[py][0][mt][1][i], acc[py][1][mt][1][i]} + ec.x;
+                    f32x4 hi = (f32x4){acc[py][0][mt][2][i], acc[py][1][mt][2][i], acc[py][0][mt][3][i], acc[py][1][mt][3][i]} + ec.x;
+                    if (ep.relu) { lo = dm_relu4(lo); hi = dm_relu4(hi); }
+                    f32x4 ml = lo, mh = hi;
+                    if (ep.mask.p0) {
+                        ml = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o); mh = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o + 4);
+                        lo.x = (ec.y * ml.x + ec.z) > 0.f ? lo.x : 0.f; lo.y = (ec.y * ml.y + ec.z) > 0.f ? lo.y : 0.f;
+                        lo.z = (ec.y * ml.z + ec.z) > 0.f ? lo.z : 0.f; lo.w = (ec.y * ml.w + ec.z) > 0.f ? lo.w : 0.f;
+                        hi.x = (ec.y * mh.x + ec.z) > 0.f ? hi.x : 0.f; hi.y = (ec.y * mh.y + ec.z) > 0.f ? hi.y : 0.f;
+                        hi.z = (ec.y * mh.z + ec.z) > 0.f ? hi.z : 0.f; hi.w = (ec.y * mh.w + ec.z) > 0.f ? hi.w : 0.f;
+                    }
+                    if (ep.resid) { lo += *reinterpret_cast<const f32x4 *>(ep.resid + o); hi += *reinterpret_cast<const f32x4 *>(ep.resid + o + 4); }
+                    *reinterpret_cast<f32x4 *>(out + o) = lo;
+                    *reinterpret_cast<f32x4 *>(out + o + 4) = hi;
+                    if (ep.stats) {
+                        f32x4 ql = lo, qh = hi;
+                        if (ep.stat_q) {
+                            if (ep.stat_q == ep.mask.p0) { ql = ml; qh = mh; }
+                            else { ql = *reinterpret_cast<const f32x4 *>(ep.stat_q + o); qh = *reinterpret_cast<const f32x4 *>(ep.stat_q + o + 4); }
+                        }
+                        sa1 += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                        sa2 += ((lo.x * ql.x + lo.y * ql.y) + (lo.z * ql.z + lo.w * ql.w)) + ((hi.x * qh.x + hi.y * qh.y) + (hi.z * qh.z + hi.w * qh.w));
+                    }
+                }
+                if (ep.stats) {
+                    sa1 += dpp_mov<0xB1>(sa1); sa2 += dpp_mov<0xB1>(sa2);
+                    sa1 += dpp_mov<0x4E>(sa1); sa2 += dpp_mov<0x4E>(sa2);
+                    sa1 += dpp_mov<0x141>(sa1); sa2 += dpp_mov<0x141>(sa2);
+                    sa1 += dpp_mov<0x140>(sa1); sa2 += dpp_mov<0x140>(sa2);
+                    sel1 = p == 4 * mt + i ? sa1 : sel1;
+                    sel2 = p == 4 * mt + i ? sa2 : sel2;
+                }
+            }
+        if (ep.stats && p < 4 * MT) { st1 += (double)sel1; st2 += (double)sel2; }
+    }
+    if (ep.stats) {
+        if (p < 4 * MT) {
+            const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
+            s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2;
+        }
+        __syncthreads();
+        for (int i = tid; i < CO * 2; i += 512) {
+            double sum = 0.0;
+            for (int w = 0; w < 8; ++w) sum += s_red[(w * CO + (i >> 1)) * 2 + (i & 1)];
+            ep.stats[((long long)blockIdx.x * CO + (i >> 1)) * 2 + (i & 1)] = sum;
+        }
+        for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+            for (int i = tid; i < CO * 2; i += 512) ep.stats[((long long)sl * CO + (i >> 1)) * 2 + (i & 1)] = 0.0;
+    }
+}
+
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS, 6: its transposed mirror 64 -> 32
     return v;
 }
 int stream_depth()
@@ -978,5 +1180,33 @@ bool dm_stream_conv_s2_wide(const Operand &in, const WeightView &wv, float *out,
         hipLaunchKernelGGL((conv_s2_wide_stream_kernel<true>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
     else
         hipLaunchKernelGGL((conv_s2_wide_stream_kernel<false>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
+    return true;
+}
+
+// ConvTranspose2d(64 -> 32, 4, 2, 1) on a 32 x 32 input (the wide decoder's first transposed convolution, the data gradient of
+// the encoder's second convolution)
+bool dm_stream_convT_wide(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                          int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st)
+{
+    if (!(stream_switch() & 64) || per_tile || Cphys != CIN || in.ones || ep.bias_border) return false;
+    if (CIN != 64 || NOUT != 128 || H != 32 || W != 32 || (long long)B * 64 * 32 * 32 * 4 >= (1LL << 31)) return false;
+    if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
+    if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
+    static bool attr = false;
+    const int lds = 128 * 1024;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)convT_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)convT_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return false;
+        attr = true;
+    }
+    const long long units = (long long)B * 16;
+    int grid = (int)(units / 8 < 256 ? (units + 7) / 8 : 256);
+    if (ep.stats && grid > nslabs) grid = nslabs;
+    if (grid < 1) grid = 1;
+    if (in.mode == DM_LOAD_AFFINE2)
+        hipLaunchKernelGGL((convT_wide_stream_kernel<true>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
+    else
+        hipLaunchKernelGGL((convT_wide_stream_kernel<false>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
     return true;
 }

@@ -1999,3 +1999,42 @@ def test_stream_conv_4x4s2_32_to_64_weights_in_lds(ops, B, mode, epi):
     close(out, ref.float(), 5e-5, 5e-5, "stream conv 4x4/s2 32 -> 64")
     if st is not None:
         close_stats(st.sum(0), ref.float(), sq)
+
+
+@pytest.mark.parametrize("B,mode,epi", [(3, 0, "bias+stats"), (2, 4, "gate+q"), (5, 3, "none"), (1, 4, "all"), (40, 0, "bias+stats")])
+def test_stream_conv_transpose_64_to_32_weights_in_lds(ops, B, mode, epi):
+    """wide_stream.hip: ConvTranspose2d(64 -> 32, 4, 2, 1) on a 32 x 32 grid with all weights resident in LDS -- forward form
+    (bias, statistics) and data-gradient form (BatchNorm backward folded into an AFFINE2 load, gate, statistics against the
+    gate's tensor): every (parity, tap) a matrix step, the lanes' pixel quads and their DPP neighbours, two rows per unit."""
+    ci, co, h, w = 64, 32, 32, 32
+    x, x1 = rnd(B, ci, h, w, seed=1), rnd(B, ci, h, w, seed=2)
+    coef = torch.stack([rnd(ci, seed=3).abs() + 0.5, rnd(ci, seed=4) * 0.2, rnd(ci, seed=5) * 0.3 + 0.1, torch.zeros(ci)], 1)
+    xin = load_ref(x.double(), mode, coef.double(), x1.double())
+    wt = rnd(ci, co, 4, 4, seed=6, scale=0.1)
+    kw = {}
+    bias = rnd(co, seed=7) if epi in ("bias+stats", "all") else None
+    ref = F.conv_transpose2d(xin, wt.double(), bias.double() if bias is not None else None, stride=2, padding=1)
+    if bias is not None:
+        kw.update(bias=bias.to(DEV))
+    if epi == "all":
+        kw.update(relu=True)
+        ref = F.relu(ref)
+    gate, q, resid = rnd(B, co, 64, 64, seed=8), rnd(B, co, 64, 64, seed=9), rnd(B, co, 64, 64, seed=10)
+    mcoef = torch.stack([rnd(co, seed=11), torch.zeros(co), rnd(co, seed=12) * 0.3, torch.zeros(co)], 1)
+    if epi in ("gate+q", "all"):
+        kw.update(mask=ops.Op(gate.to(DEV), 2, mcoef.to(DEV)))
+        ref = ref * ((mcoef[:, 0].view(1, -1, 1, 1) * gate + mcoef[:, 2].view(1, -1, 1, 1)) > 0)
+    sq = None
+    if epi == "all":
+        kw.update(resid=resid.to(DEV), stat_q=q.to(DEV))
+        ref = ref + resid
+        sq = q
+    elif epi == "gate+q":
+        kw.update(stat_q=kw["mask"].p0)
+        sq = gate
+    inp = ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, p1=x1.to(DEV) if mode == 4 else None)
+    out, st = ops.conv3x3(inp, ops.weight_view(wt.to(DEV), 16, co * 16, 4, 1), B, ci, 4 * co, h, w, taps=9, pixel_shuffle=True,
+                          want_stats=epi != "none", **kw)
+    close(out, ref.float(), 5e-5, 5e-5, "stream conv transpose 64 -> 32")
+    if st is not None:
+        close_stats(st.sum(0), ref.float(), sq)

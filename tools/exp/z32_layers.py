@@ -51,3 +51,6 @@ t("wgrad up1 (S d1 aff-relu, T g)", lambda: ops.wgrad(Op(x64, 3, cf32), Op(g128)
 t("wgrad conv1 (S 64 aff2, T 32ch)", lambda: ops.wgrad(Op(g32, 4, cf64, p1=a32), Op(x64, 3, cf32), d44, B, C, C // 2, HW, HW, 4), 2 * P * C * (C // 2) * 16, 2 * T32 + T64)
 t("dgrad up1 (conv s2 2->32)", lambda: ops.conv4x4s2(Op(g128), ops.weight_view(wu1, 16, NIN * 16, 4, 1), B, NIN, C // 2, 128, 128, want_stats=True,
                                                   mask=Op(x64, 2, cf32), stat_q=x64), 2 * B * 64 * 64 * 32 * NIN * 16, T128 + 2 * T64)
+t("dgrad conv1 (convT 64->32 aff2)", lambda: ops.conv3x3(Op(g32, 4, cf64, p1=a32), ops.weight_view(w4, 16, (C // 2) * 16, 4, 1), B, C, 4 * (C // 2), HW, HW, taps=9,
+                                                        pixel_shuffle=True, want_stats=True, mask=Op(x64, 2, cf32), stat_q=x64), 2 * P * C * (C // 2) * 16, 2 * T32 + 2 * T64)
+t("dgrad up0 (conv s2 32->64)", lambda: ops.conv4x4s2(Op(x64), ops.weight_view(w4, (C // 2) * 16, 16, 4, 1), B, C // 2, C, 64, 64), 2 * P * C * (C // 2) * 16, T64 + T32)
