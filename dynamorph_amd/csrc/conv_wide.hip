@@ -838,6 +838,9 @@ bool dm_stream_conv_s2_wide(const Operand &in, const WeightView &wv, float *out,
 bool dm_stream_convT_wide(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
                           int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st);
 
+bool dm_stream_conv3x3_wide(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                            int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st);
+
 // ---- entry points used by the dispatchers in conv_mfma.hip / wgrad_mfma.hip (not part of the public header) ----------
 // base grid (output pixels for the strided / plain forms, input pixels for the transposed form) must tile by 8 x 16
 static int wide_disabled()
@@ -906,6 +909,7 @@ int dm_wide_conv(int form, const Operand &in, const WeightView &wv, float *scrat
     if (form == W_PIX && CIN * 32 <= dm_wide_conv_scratch_floats(form, CIN, NOUT, taps) &&
         dm_stream_convT_thin(in, wv, scratch, out, ep, B, Cphys, CIN, NOUT, H, W, per_tile, st))
         return 0;
+    if (form == W_S1 && taps == 9 && dm_stream_conv3x3_wide(in, wv, out, ep, B, Cphys, CIN, NOUT, H, W, nslabs, per_tile, st)) return 0;
     if (form == W_PIX && dm_stream_convT_wide(in, wv, out, ep, B, Cphys, CIN, NOUT, H, W, nslabs, per_tile, st)) return 0;
     if (form == W_S2 && dm_stream_conv_s2_wide(in, wv, out, ep, B, Cphys, CIN, NOUT, H, W, nslabs, per_tile, st)) return 0;
     if (form == W_S2 && dm_stream_conv_s2_thin(in, wv, out, ep, B, Cphys, CIN, NOUT, H, W, nslabs, per_tile, st)) return 0;

@@ -1011,9 +1011,154 @@ __global__ __launch_bounds__(512, 1) void convT_wide_stream_kernel(Operand in, W
     }
 }
 
+// ------------------------------------------------------- 3x3 convolution 64 -> 64 channels on a 32 x 32 grid, weights in LDS
+// The residual blocks' 3x3 layers (forward and data gradient): the third member of the family above.  All 147 KB of weights in
+// LDS as the A operand reads them ([K step = 4 input channels][tap][M tile][ci % 4][co % 16]); a lane loads its pixel quad of
+// the rows y - 1, y, y + 1 of its channel and every (dy, dx) shift is a B operand: 9 taps x 4 M tiles x 4 pixel tiles = 144
+// matrix instructions per three loads.  Two rows of 32 pixels per unit, eight independent waves per workgroup.
+template <bool IN2>
+__global__ __launch_bounds__(512, 1) void conv3x3_wide_stream_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep,
+                                                                     int B, int nslabs)
+{
+    constexpr int CIN = 64, CO = 64, MT = 4, H = 32, W = 32, KS = CIN / 4, R = 2;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];          // [KS][9 taps][MT][4 ci][16 co]: 144 KB
+    __shared__ __attribute__((aligned(16))) float s_cf[CIN * 4];
+    __shared__ __attribute__((aligned(16))) float s_ep[CO * 4];
+    __shared__ double s_red[4 * CO * 2];                                 // (two waves share a row: see the end)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < KS * 9 * MT * 64; i += 512) {
+        const int m = i & 15, c = (i >> 4) & 3, mt = (i >> 6) & 3, r = i >> 8, tap = r % 9, ks = r / 9;
+        s_w[i] = wv.w[wv.off + (long long)(16 * mt + m) * wv.sn + (long long)(4 * ks + c) * wv.sc + (long long)(tap / 3) * wv.sky + (long long)(tap % 3) * wv.skx];
+    }
+    for (int i = tid; i < CIN; i += 512) {
+        const StreamCoef c = stream_coef(in, i);
+        s_cf[i * 4] = c.c0; s_cf[i * 4 + 1] = c.c1; s_cf[i * 4 + 2] = c.c2; s_cf[i * 4 + 3] = stream_floor(in);
+    }
+    for (int i = tid; i < CO; i += 512) {
+        float mc0 = 1.f, mc2 = 0.f;
+        if (ep.mask.p0 && ep.mask.mode >= DM_LOAD_AFFINE) { mc0 = ep.mask.coef[i * 4]; mc2 = ep.mask.coef[i * 4 + 2]; }
+        s_ep[i * 4] = ep.bias ? ep.bias[i] : 0.f; s_ep[i * 4 + 1] = mc0; s_ep[i * 4 + 2] = mc2; s_ep[i * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+
+    const int upb = H >> 1;
+    const long long total = (long long)B * upb;
+    const int u0 = (int)(total * blockIdx.x / gridDim.x), u1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int n = (u1 - u0 - wave + 7) >> 3;
+    const unsigned bytesI = (unsigned)((long long)B * CIN * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(IN2 ? in.p1 : in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, 0, 0x00020000);
+    const int half = p >> 3, pc = p & 7;
+    const float *sa = s_w + kq * 16 + p;                         // + ((ks * 9 + tap) * MT + mt) * 64
+
+    f32x4 r0[R], r1[R], r2[R], q0[IN2 ? R : 1], q1[IN2 ? R : 1], q2[IN2 ? R : 1];
+    int v0 = 0, v1 = 0, v2 = 0;
+    bool top = false, bot = false, ntop = false, nbot = false;
+    auto unit_begin = [&](int u, bool &t, bool &bo) {
+        const int b = u / upb, y = ((u - b * upb) << 1) + half;
+        t = y == 0; bo = y == H - 1;
+        v1 = (((b * CIN + kq) * H + y) * W + 4 * pc) * 4;
+        v0 = t ? v1 : v1 - W * 4;
+        v2 = bo ? v1 : v1 + W * 4;
+    };
+    auto issue = [&](auto slot, int ks, bool live) {
+        constexpr int sl = decltype(slot)::value;
+        const int so = ks * (4 * H * W * 4);
+        r0[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v0, so, 0);
+        r1[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v1, so, 0);
+        r2[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, v2, so, 0);
+        if constexpr (IN2) {
+            q0[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, v0, so, 0);
+            q1[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, v1, so, 0);
+            q2[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, v2, so, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    unit_begin(n > 0 ? u0 + wave : 0, ntop, nbot);
+    issue(std::integral_constant<int, 0>{}, 0, n > 0);
+    issue(std::integral_constant<int, 1>{}, 1, n > 0);
+
+    double st1 = 0.0, st2 = 0.0;
+    for (int it = 0; it < n; ++it) {
+        const int u = u0 + wave + 8 * it;
+        const int b = u / upb, y = ((u - b * upb) << 1) + half;
+        const bool more = it + 1 < n;
+        top = ntop; bot = nbot;
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kb = 0; kb < KS; kb += R) {
+            if (kb + R == KS) unit_begin(more ? u + 8 : u, ntop, nbot);
+            auto kstep = [&](auto self, auto cc) -> void {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c < R) {
+                    const int ks = kb + c;
+                    const f32x4 cf = *reinterpret_cast<const f32x4 *>(&s_cf[(4 * ks + kq) * 4]);
+                    f32x4 a0 = r0[c], a1 = r1[c], a2 = r2[c];
+                    if constexpr (IN2) {
+                        a0 = cf.x * a0 + (cf.y * q0[c] + cf.z); a1 = cf.x * a1 + (cf.y * q1[c] + cf.z); a2 = cf.x * a2 + (cf.y * q2[c] + cf.z);
+                    } else {
+                        a0 = cf.x * a0 + cf.z; a1 = cf.x * a1 + cf.z; a2 = cf.x * a2 + cf.z;
+                    }
+                    a0 = sx_max(a0, cf.w); a1 = sx_max(a1, cf.w); a2 = sx_max(a2, cf.w);
+                    if (top) a0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (bot) a2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    {
+                        const int kn = kb + R + c;
+                        issue(cc, kn < KS ? kn : kn - KS, kn < KS ? true : more);
+                    }
+                    float t[3][6];
+                    const bool ls = pc == 0, rs = pc == 7;
+#define DM_ROW6(T, A)                                                                                            \
+                    { const float l = dpp_mov<0x111>(A.w), r = dpp_mov<0x101>(A.x);                               \
+                      T[0] = ls ? 0.f : l; T[1] = A.x; T[2] = A.y; T[3] = A.z; T[4] = A.w; T[5] = rs ? 0.f : r; }
+                    DM_ROW6(t[0], a0) DM_ROW6(t[1], a1) DM_ROW6(t[2], a2)
+#undef DM_ROW6
+                    const float *wp = sa + ks * (9 * MT * 64);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            float wa[MT];
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) wa[mt] = wp[((ky * 3 + kx) * MT + mt) * 64];
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt], t[ky][j + kx], acc[mt][j], 0, 0, 0);
+                        }
+                    self(self, std::integral_constant<int, c + 1>{});
+                }
+            };
+            kstep(kstep, std::integral_constant<int, 0>{});
+        }
+        stream_epilogue<MT>(acc, ep, s_ep, out, (((long long)b * CO * H + y) * W) + 4 * pc, (long long)H * W, p, kq, st1, st2);
+    }
+    if (ep.stats) {
+        // eight waves, four rows of s_red: waves w and w + 4 add up through two rounds
+        const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
+        if (wave < 4) { s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2; }
+        __syncthreads();
+        if (wave >= 4) { s_red[((wave - 4) * CO + co) * 2] += st1; s_red[((wave - 4) * CO + co) * 2 + 1] += st2; }
+        __syncthreads();
+        for (int i = tid; i < CO * 2; i += 512) {
+            double sum = 0.0;
+            for (int w = 0; w < 4; ++w) sum += s_red[(w * CO + (i >> 1)) * 2 + (i & 1)];
+            ep.stats[((long long)blockIdx.x * CO + (i >> 1)) * 2 + (i & 1)] = sum;
+        }
+        for (int sl = blockIdx.x + gridDim.x; sl < nslabs; sl += gridDim.x)
+            for (int i = tid; i < CO * 2; i += 512) ep.stats[((long long)sl * CO + (i >> 1)) * 2 + (i & 1)] = 0.0;
+    }
+}
+
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS, 6: its transposed mirror 64 -> 32
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS, 6: its transposed mirror 64 -> 32, 7 / 8: 3x3 64 -> 64 with the weights in LDS (forward form / forms with a gate)
     return v;
 }
 int stream_depth()
@@ -1208,5 +1353,33 @@ bool dm_stream_convT_wide(const Operand &in, const WeightView &wv, float *out, c
         hipLaunchKernelGGL((convT_wide_stream_kernel<true>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
     else
         hipLaunchKernelGGL((convT_wide_stream_kernel<false>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
+    return true;
+}
+
+// 3x3 convolution 64 -> 64 channels on a 32 x 32 grid (the wide residual blocks; forward and data-gradient form)
+bool dm_stream_conv3x3_wide(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
+                            int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st)
+{
+    const int bit = ep.mask.p0 ? 256 : 128;
+    if (!(stream_switch() & bit) || per_tile || Cphys != CIN || in.ones || ep.bias_border) return false;
+    if (CIN != 64 || NOUT != 64 || H != 32 || W != 32 || (long long)B * 64 * 32 * 32 * 4 >= (1LL << 31)) return false;
+    if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
+    if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
+    static bool attr = false;
+    const int lds = 9 * 64 * 64 * 4;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)conv3x3_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv3x3_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return false;
+        attr = true;
+    }
+    const long long units = (long long)B * 16;
+    int grid = (int)(units / 8 < 256 ? (units + 7) / 8 : 256);
+    if (ep.stats && grid > nslabs) grid = nslabs;
+    if (grid < 1) grid = 1;
+    if (in.mode == DM_LOAD_AFFINE2)
+        hipLaunchKernelGGL((conv3x3_wide_stream_kernel<true>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
+    else
+        hipLaunchKernelGGL((conv3x3_wide_stream_kernel<false>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
     return true;
 }

@@ -2038,3 +2038,35 @@ def test_stream_conv_transpose_64_to_32_weights_in_lds(ops, B, mode, epi):
     close(out, ref.float(), 5e-5, 5e-5, "stream conv transpose 64 -> 32")
     if st is not None:
         close_stats(st.sum(0), ref.float(), sq)
+
+
+@pytest.mark.parametrize("B,mode,dgrad,epi", [(3, 1, False, "stats"), (2, 4, True, "all"), (5, 3, False, "none"), (1, 4, True, "all"),
+                                              (40, 1, False, "stats")])
+def test_stream_conv_3x3_64_channels_weights_in_lds(ops, B, mode, dgrad, epi):
+    """wide_stream.hip: the wide residual blocks' 3x3 convolution (64 -> 64 on 32 x 32) with all weights resident in LDS --
+    forward form (ReLU on the load, statistics) and data-gradient form (AFFINE2 load, transposed + flipped weight view, gate,
+    residual, statistics against a third tensor)."""
+    c, h = 64, 32
+    x, x1 = rnd(B, c, h, h, seed=1), rnd(B, c, h, h, seed=2)
+    coef = torch.stack([rnd(c, seed=3).abs() + 0.5, rnd(c, seed=4) * 0.2, rnd(c, seed=5) * 0.3, torch.zeros(c)], 1)
+    xin = load_ref(x.double(), mode, coef.double(), x1.double())
+    wt = rnd(c, c, 3, 3, seed=6, scale=0.05)
+    inp = ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, p1=x1.to(DEV) if mode == 4 else None)
+    if dgrad:
+        xg = torch.zeros(B, c, h, h, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xg, wt.double(), None, padding=1).backward(xin)
+        ref = xg.grad
+        wv = ops.weight_view(wt.to(DEV), 9, c * 9, -3, -1, off=8)
+    else:
+        ref = F.conv2d(xin, wt.double(), None, padding=1)
+        wv = ops.weight_view(wt.to(DEV), c * 9, 9, 3, 1)
+    kw, sq = {}, None
+    gate, q, resid = rnd(B, c, h, h, seed=8), rnd(B, c, h, h, seed=9), rnd(B, c, h, h, seed=10)
+    if epi == "all":
+        kw.update(mask=ops.Op(gate.to(DEV)), resid=resid.to(DEV), stat_q=q.to(DEV))
+        ref = ref * (gate > 0) + resid
+        sq = q
+    out, st = ops.conv3x3(inp, wv, B, c, c, h, h, taps=9, want_stats=epi != "none", **kw)
+    close(out, ref.float(), 5e-5, 5e-5, "stream conv 3x3")
+    if st is not None:
+        close_stats(st.sum(0), ref.float(), sq)
