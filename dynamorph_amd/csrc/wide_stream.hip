@@ -301,32 +301,52 @@ __global__ __launch_bounds__(256, 3) void wgrad_s2_thin_stream_kernel(Operand S,
 // lane's first pixel); cstride: elements per channel plane; s_ep[co] = (bias, gate c0, gate c2, -).  Statistics: the sum over
 // the 16 lanes of a row (the unit's 64 pixels) in float, then lane p == 4 mt + i of row kq adds it to ITS channel's double.
 // PRE: the gate's values were requested ahead (gm[mt][i], same addresses as the output).
+// obytes != 0: gate / residual / statistics operands are read through buffer descriptors (an empty one where the operand is
+// absent), all four rows of an M tile requested before the first is used -- as plain loads under their `if (operand)` each was
+// its own dependent round trip, up to 48 per unit in the data-gradient forms.
 template <int MT, bool PRE = false>
 __device__ __forceinline__ void stream_epilogue(const f32x4 (&acc)[MT][4], const Epilogue &ep, const float *s_ep, float *__restrict__ out,
                                                 long long ob, long long cstride, int p, int kq, double &st1, double &st2,
-                                                const f32x4 (*gm)[4] = nullptr)
+                                                const f32x4 (*gm)[4] = nullptr, int co0 = 0, unsigned obytes = 0)
 {
     float sel1 = 0.f, sel2 = 0.f;
+    const bool q_is_gate = ep.stat_q && ep.stat_q == ep.mask.p0;
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ep.mask.p0 ? ep.mask.p0 : out), 0,
+                                                                        (ep.mask.p0 && !PRE) ? obytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ep.resid ? ep.resid : out), 0,
+                                                                        ep.resid ? obytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ep.stat_q ? ep.stat_q : out), 0,
+                                                                        (ep.stats && ep.stat_q && !q_is_gate) ? obytes : 0u, 0x00020000);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 bm[4], br[4], bq[4];
+        if (obytes) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = (int)((ob + (long long)(co0 + 16 * mt + 4 * kq + i) * cstride) * 4);
+                bm[i] = __builtin_amdgcn_raw_buffer_load_b128(rM, off, 0, 0);
+                br[i] = __builtin_amdgcn_raw_buffer_load_b128(rR, off, 0, 0);
+                bq[i] = __builtin_amdgcn_raw_buffer_load_b128(rQ, off, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int co = 16 * mt + 4 * kq + i;
+            const int co = co0 + 16 * mt + 4 * kq + i;
             const f32x4 ec = *reinterpret_cast<const f32x4 *>(&s_ep[co * 4]);
             const long long o = ob + (long long)co * cstride;
             f32x4 v = (f32x4){acc[mt][0][i], acc[mt][1][i], acc[mt][2][i], acc[mt][3][i]} + ec.x;
             if (ep.relu) v = dm_relu4(v);
             f32x4 m = v;
             if (ep.mask.p0) {
-                m = PRE ? gm[mt][i] : *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o);
+                m = PRE ? gm[mt][i] : (obytes ? bm[i] : *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o));
                 v.x = (ec.y * m.x + ec.z) > 0.f ? v.x : 0.f; v.y = (ec.y * m.y + ec.z) > 0.f ? v.y : 0.f;
                 v.z = (ec.y * m.z + ec.z) > 0.f ? v.z : 0.f; v.w = (ec.y * m.w + ec.z) > 0.f ? v.w : 0.f;
             }
-            if (ep.resid) v += *reinterpret_cast<const f32x4 *>(ep.resid + o);
+            if (ep.resid) v += obytes ? br[i] : *reinterpret_cast<const f32x4 *>(ep.resid + o);
             *reinterpret_cast<f32x4 *>(out + o) = v;
             if (ep.stats) {
                 f32x4 q = v;
-                if (ep.stat_q) q = ep.stat_q == ep.mask.p0 ? m : *reinterpret_cast<const f32x4 *>(ep.stat_q + o);
+                if (ep.stat_q) q = q_is_gate ? m : (obytes ? bq[i] : *reinterpret_cast<const f32x4 *>(ep.stat_q + o));
                 float a = (v.x + v.y) + (v.z + v.w), c = (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
                 a += dpp_mov<0xB1>(a); c += dpp_mov<0xB1>(c);
                 a += dpp_mov<0x4E>(a); c += dpp_mov<0x4E>(c);
@@ -336,6 +356,7 @@ __device__ __forceinline__ void stream_epilogue(const f32x4 (&acc)[MT][4], const
                 sel2 = p == 4 * mt + i ? c : sel2;
             }
         }
+    }
     if (ep.stats && MT * 4 > p) { st1 += (double)sel1; st2 += (double)sel2; }
 }
 
@@ -459,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Operand in, Weig
         };
         kloop(kloop, std::integral_constant<int, 0>{});
 
+        // (the batched descriptor form of the epilogue's operand loads spills here: 241 against 220 us in the data-gradient form)
         stream_epilogue<MT>(acc, ep, s_ep, out, unit_out(u) + 4 * p, HW, p, kq, st1, st2);
     }
 
@@ -791,7 +813,8 @@ __global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in,
             // (vbase switches to the next unit before the LAST round's refills; rows of THIS unit were all requested by then)
             chan(chan, std::integral_constant<int, 0>{});
         }
-        stream_epilogue<MT>(acc, ep, s_ep, out, (((long long)b * CO * OH + oy) * OW) + 4 * pc, (long long)OH * OW, p, kq, st1, st2);
+        stream_epilogue<MT>(acc, ep, s_ep, out, (((long long)b * CO * OH + oy) * OW) + 4 * pc, (long long)OH * OW, p, kq, st1, st2, nullptr, 0,
+                            (unsigned)((long long)B * CO * OH * OW * 4));
     }
     if (ep.stats) {
         if (true) {
@@ -948,8 +971,16 @@ __global__ __launch_bounds__(512, 1) void convT_wide_stream_kernel(Operand in, W
             };
             kstep(kstep, std::integral_constant<int, 0>{});
         }
-        // ---- epilogue: (mt, i) -> channel 16 mt + 4 kq + i; per output row 2 y + py the lane's 8 columns 8 pc .. 8 pc + 7 = (pixel j, px)
+        // ---- epilogue: (mt, i) -> channel 16 mt + 4 kq + i; per output row 2 y + py the lane's 8 columns 8 pc .. 8 pc + 7 = (pixel j, px).
+        // Gate / residual / statistics operands through descriptors (empty where absent), the four float4 of a channel's two
+        // output rows requested together: as plain loads under their `if` each was its own dependent round trip.
         float sel1 = 0.f, sel2 = 0.f;
+        const unsigned obytes = (unsigned)((long long)B * CO * OH * OW * 4);
+        const bool q_is_gate = ep.stat_q && ep.stat_q == ep.mask.p0;
+        const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ep.mask.p0 ? ep.mask.p0 : out), 0, ep.mask.p0 ? obytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ep.resid ? ep.resid : out), 0, ep.resid ? obytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ep.stat_q ? ep.stat_q : out), 0,
+                                                                            (ep.stats && ep.stat_q && !q_is_gate) ? obytes : 0u, 0x00020000);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -957,29 +988,33 @@ __global__ __launch_bounds__(512, 1) void convT_wide_stream_kernel(Operand in, W
                 const int co = 16 * mt + 4 * kq + i;
                 const f32x4 ec = *reinterpret_cast<const f32x4 *>(&s_ep[co * 4]);
                 float sa1 = 0.f, sa2 = 0.f;
+                f32x4 bm[2][2], br[2][2], bq[2][2];
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const int off = (int)(((((long long)b * CO + co) * OH + 2 * y + py) * OW + 8 * pc) * 4);
+                    bm[py][0] = __builtin_amdgcn_raw_buffer_load_b128(rM, off, 0, 0); bm[py][1] = __builtin_amdgcn_raw_buffer_load_b128(rM, off + 16, 0, 0);
+                    br[py][0] = __builtin_amdgcn_raw_buffer_load_b128(rR, off, 0, 0); br[py][1] = __builtin_amdgcn_raw_buffer_load_b128(rR, off + 16, 0, 0);
+                    bq[py][0] = __builtin_amdgcn_raw_buffer_load_b128(rQ, off, 0, 0); bq[py][1] = __builtin_amdgcn_raw_buffer_load_b128(rQ, off + 16, 0, 0);
+                }
 #pragma unroll
                 for (int py = 0; py < 2; ++py) {
                     const long long o = (((long long)b * CO + co) * OH + 2 * y + py) * OW + 8 * pc;
                     f32x4 lo = (f32x4){acc[py][0][mt][0][i], acc[py][1][mt][0][i], acc[py][0][mt][1][i], acc[py][1][mt][1][i]} + ec.x;
                     f32x4 hi = (f32x4){acc[py][0][mt][2][i], acc[py][1][mt][2][i], acc[py][0][mt][3][i], acc[py][1][mt][3][i]} + ec.x;
                     if (ep.relu) { lo = dm_relu4(lo); hi = dm_relu4(hi); }
-                    f32x4 ml = lo, mh = hi;
+                    const f32x4 ml = bm[py][0], mh = bm[py][1];
                     if (ep.mask.p0) {
-                        ml = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o); mh = *reinterpret_cast<const f32x4 *>(ep.mask.p0 + o + 4);
                         lo.x = (ec.y * ml.x + ec.z) > 0.f ? lo.x : 0.f; lo.y = (ec.y * ml.y + ec.z) > 0.f ? lo.y : 0.f;
                         lo.z = (ec.y * ml.z + ec.z) > 0.f ? lo.z : 0.f; lo.w = (ec.y * ml.w + ec.z) > 0.f ? lo.w : 0.f;
                         hi.x = (ec.y * mh.x + ec.z) > 0.f ? hi.x : 0.f; hi.y = (ec.y * mh.y + ec.z) > 0.f ? hi.y : 0.f;
                         hi.z = (ec.y * mh.z + ec.z) > 0.f ? hi.z : 0.f; hi.w = (ec.y * mh.w + ec.z) > 0.f ? hi.w : 0.f;
                     }
-                    if (ep.resid) { lo += *reinterpret_cast<const f32x4 *>(ep.resid + o); hi += *reinterpret_cast<const f32x4 *>(ep.resid + o + 4); }
+                    if (ep.resid) { lo += br[py][0]; hi += br[py][1]; }
                     *reinterpret_cast<f32x4 *>(out + o) = lo;
                     *reinterpret_cast<f32x4 *>(out + o + 4) = hi;
                     if (ep.stats) {
                         f32x4 ql = lo, qh = hi;
-                        if (ep.stat_q) {
-                            if (ep.stat_q == ep.mask.p0) { ql = ml; qh = mh; }
-                            else { ql = *reinterpret_cast<const f32x4 *>(ep.stat_q + o); qh = *reinterpret_cast<const f32x4 *>(ep.stat_q + o + 4); }
-                        }
+                        if (ep.stat_q) { ql = q_is_gate ? ml : bq[py][0]; qh = q_is_gate ? mh : bq[py][1]; }
                         sa1 += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
                         sa2 += ((lo.x * ql.x + lo.y * ql.y) + (lo.z * ql.z + lo.w * ql.w)) + ((hi.x * qh.x + hi.y * qh.y) + (hi.z * qh.z + hi.w * qh.w));
                     }
@@ -1137,7 +1172,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wide_stream_kernel(Operand in,
             };
             kstep(kstep, std::integral_constant<int, 0>{});
         }
-        stream_epilogue<MT>(acc, ep, s_ep, out, (((long long)b * CO * H + y) * W) + 4 * pc, (long long)H * W, p, kq, st1, st2);
+        stream_epilogue<MT>(acc, ep, s_ep, out, (((long long)b * CO * H + y) * W) + 4 * pc, (long long)H * W, p, kq, st1, st2, nullptr, 0,
+                            (unsigned)((long long)B * CO * H * W * 4));
     }
     if (ep.stats) {
         // eight waves, four rows of s_red: waves w and w + 4 add up through two rounds
@@ -1158,7 +1194,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wide_stream_kernel(Operand in,
 
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0xff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS, 6: its transposed mirror 64 -> 32, 7 / 8: 3x3 64 -> 64 with the weights in LDS (forward form / forms with a gate)
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0x1ff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS, 6: its transposed mirror 64 -> 32, 7 / 8: 3x3 64 -> 64 with the weights in LDS (forward form / forms with a gate)
     return v;
 }
 int stream_depth()
