@@ -127,8 +127,10 @@ EXAMPLE_CONFIG = dict(num_hiddens=64, num_residual_hiddens=64, num_embeddings=51
 
 
 def roofline_wide_conv(B):
-    """z32ex: the 3x3 64 -> 64 convolution of the residual blocks on the 32 x 32 latent (conv_wide_kernel<1, 9, 4>, the
-    largest share of that step), alone, timed with events.  MFMA bound: achieved = 2*P*64*64*9 FLOP / duration."""
+    """z32ex: the 3x3 64 -> 64 convolution of the residual blocks on the 32 x 32 latent (the largest share of that step; since
+    round 6 conv3x3_wide_stream_kernel -- all weights resident in LDS, activations straight into the matrix instruction's B
+    operand; DM_WIDE_STREAM=0: the tiled conv_wide_kernel<1, 9, 4>), forward form, alone, timed with events.  MFMA bound:
+    achieved = 2*P*64*64*9 FLOP / duration."""
     from dynamorph_amd import ops
     C, HW = 64, 32
     x = torch.randn(B, C, HW, HW, device="cuda")
@@ -141,7 +143,9 @@ def roofline_wide_conv(B):
     ms = event_time_ms(fn)
     flops = 2.0 * B * HW * HW * C * C * 9
     ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "wide_pack_kernel + conv_wide_kernel<1, 9, 4> (residual 3x3, 64 -> 64 channels, 32 x 32)", "bound": "mfma",
+    stream = int(os.environ.get("DM_WIDE_STREAM", "511")) & 128
+    return {"kernel": ("conv3x3_wide_stream_kernel<false>" if stream else "wide_pack_kernel + conv_wide_kernel<1, 9, 4>") +
+                      " (residual 3x3, 64 -> 64 channels, 32 x 32, forward form)", "bound": "mfma",
             "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
             "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops}
 

@@ -20,6 +20,11 @@ KEYS = {   # key -> (substring of the kernel name, algorithmic bytes, what moves
     "convT_thin": ("convT_thin_stream_kernel<2>", T64 + T128, "32-channel input + image-side output"),
     "wgrad_wide1_3x3": ("wgrad_wide1_kernel<3, 64, true", 3 * T32, "dy + partner + the layer input"),
     "wgrad_wide1_4x4": ("wgrad_wide1_kernel<4, 32, true", 2 * T32 + T64, "dy + partner (64 channels) + the 32-channel input"),
+    "conv3x3_wide_stream_fwd": ("conv3x3_wide_stream_kernel<false>", 2 * T32, "input + output (forward form)"),
+    "conv3x3_wide_stream_dgrad": ("conv3x3_wide_stream_kernel<true>", 5 * T32, "as tools/exp/z32_layers.py launches it: dy, its BatchNorm-backward partner (also the residual: read twice), the gate (also the statistics operand) + output"),
+    "conv_s2_wide_stream": ("conv_s2_wide_stream_kernel<true>", T64 + T32, "32-channel input + 64-channel output"),
+    "convT_wide_stream_fwd": ("convT_wide_stream_kernel<false>", T32 + T64, "64-channel input + 32-channel output"),
+    "convT_wide_stream_dgrad": ("convT_wide_stream_kernel<true>", 2 * T32 + 2 * T64, "two input tensors + gate + output"),
     "conv_wide_3x3": ("conv_wide_kernel<1, 9, 4>", 2 * T32, "input + output (forward form)"),
 }
 fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
