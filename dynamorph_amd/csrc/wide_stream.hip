@@ -1345,14 +1345,11 @@ bool dm_stream_conv_s2_wide(const Operand &in, const WeightView &wv, float *out,
     if (CIN != 32 || NOUT != 64 || H != 64 || W != 64 || (long long)B * 64 * 32 * 32 * 4 >= (1LL << 31)) return false;
     if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
     if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
-    static bool attr = false;
     const int lds = 128 * 1024;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+    // (per launch, as dm_vq_backward does: the attribute belongs to the current device's copy of the kernel)
+    if (hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
             hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return false;
-        attr = true;
-    }
+        return false;
     const long long units = (long long)B * 16;
     int grid = (int)(units / 8 < 256 ? (units + 7) / 8 : 256);
     if (ep.stats && grid > nslabs) grid = nslabs;
@@ -1373,14 +1370,11 @@ bool dm_stream_convT_wide(const Operand &in, const WeightView &wv, float *out, c
     if (CIN != 64 || NOUT != 128 || H != 32 || W != 32 || (long long)B * 64 * 32 * 32 * 4 >= (1LL << 31)) return false;
     if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
     if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
-    static bool attr = false;
     const int lds = 128 * 1024;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void *)convT_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+    // (per launch, as dm_vq_backward does: the attribute belongs to the current device's copy of the kernel)
+    if (hipFuncSetAttribute((const void *)convT_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
             hipFuncSetAttribute((const void *)convT_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return false;
-        attr = true;
-    }
+        return false;
     const long long units = (long long)B * 16;
     int grid = (int)(units / 8 < 256 ? (units + 7) / 8 : 256);
     if (ep.stats && grid > nslabs) grid = nslabs;
@@ -1401,14 +1395,11 @@ bool dm_stream_conv3x3_wide(const Operand &in, const WeightView &wv, float *out,
     if (CIN != 64 || NOUT != 64 || H != 32 || W != 32 || (long long)B * 64 * 32 * 32 * 4 >= (1LL << 31)) return false;
     if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
     if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
-    static bool attr = false;
     const int lds = 9 * 64 * 64 * 4;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void *)conv3x3_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+    // (per launch, as dm_vq_backward does: the attribute belongs to the current device's copy of the kernel)
+    if (hipFuncSetAttribute((const void *)conv3x3_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
             hipFuncSetAttribute((const void *)conv3x3_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return false;
-        attr = true;
-    }
+        return false;
     const long long units = (long long)B * 16;
     int grid = (int)(units / 8 < 256 ? (units + 7) / 8 : 256);
     if (ep.stats && grid > nslabs) grid = nslabs;
