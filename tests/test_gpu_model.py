@@ -814,6 +814,31 @@ def test_captured_step_follows_the_relation_matrix_between_sparse_and_dense():
         assert torch.equal(a, b), k
 
 
+def test_wide_family_streaming_kernels_against_the_tiled_kernels(tmp_path):
+    """The example configuration's step through round 6's kernels (wide_stream.hip, wgrad_wide1_kernel) and through the tiled
+    kernels of rounds 1-5 (DM_WIDE_STREAM=0 DM_WIDE_WGRAD1=0; the switches are read once per process, hence two child
+    processes): same losses to 1e-6, every gradient and BatchNorm running statistic within the accumulation-order tolerance of
+    the fused-against-unfused check -- the tiled kernels stay the reference implementation of the shapes the new ones take."""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "wide_step.py")
+    outs = {}
+    for tag, env in (("stream", {}), ("tiled", {"DM_WIDE_STREAM": "0", "DM_WIDE_WGRAD1": "0"})):
+        f = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, helper, f], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = torch.load(f)
+    a, b = outs["stream"], outs["tiled"]
+    for k, v in b["losses"].items():
+        assert abs(a["losses"][k] - v) <= 1e-6 * max(1.0, abs(v)), (k, a["losses"][k], v)
+    assert len(b["grads"]) >= 40
+    for k, g in b["grads"].items():
+        scale = float(g.abs().max())
+        assert float((a["grads"][k] - g).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((a["grads"][k] - g).abs().max()), scale)
+    for k, v in b["buffers"].items():
+        assert float((a["buffers"][k] - v).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
+
+
 def _states_after_adam_step(m1, m2, step, lr, skip=()):
     """Two optimisers stepping the same model from the same values: after the FIRST step everything agrees to 1e-6 (same
     kernels, same gradients; the optimisers round the update an ulp apart at most).  After that Adam compounds that ulp: an
