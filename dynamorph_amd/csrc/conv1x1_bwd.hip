@@ -16,6 +16,12 @@
 // plus the (sum dx, sum dx*x) slabs BatchNorm's backward of the layer below needs.  201 MB moved once.
 #include "dm_common.h"
 
+// 64 -> 64 channels (the wide residual blocks): wide_stream.hip
+bool dm_stream_conv1x1_bwd_shape(int CD, int CX, int H, int W);
+int dm_stream_conv1x1_bwd_slabs(int B, int H, int W);
+int dm_stream_conv1x1_bwd(const Operand &dy, const float *x, const float *xcoef, const float *w, float *dx, double *stats,
+                          float *wslabs, int B, int H, int W, hipStream_t st);
+
 namespace {
 
 constexpr int C1_TP = 256;                  // positions per tile (one 16 x 16 latent)
@@ -188,10 +194,14 @@ bool conv1x1_bwd_shape(int CD, int CX, int H, int W)
 
 }  // namespace
 
-extern "C" int dm_conv1x1_bwd_fused_supported(int CD, int CX, int H, int W) { return conv1x1_bwd_shape(CD, CX, H, W) ? 1 : 0; }
+extern "C" int dm_conv1x1_bwd_fused_supported(int CD, int CX, int H, int W)
+{
+    return (conv1x1_bwd_shape(CD, CX, H, W) || dm_stream_conv1x1_bwd_shape(CD, CX, H, W)) ? 1 : 0;
+}
 
 extern "C" int dm_conv1x1_bwd_fused_num_blocks(int B, int CD, int CX, int H, int W)
 {
+    if (B > 0 && dm_stream_conv1x1_bwd_shape(CD, CX, H, W)) return dm_stream_conv1x1_bwd_slabs(B, H, W);
     if (B <= 0 || !conv1x1_bwd_shape(CD, CX, H, W)) return -1;
     const long long ntiles = (long long)B * (H * W / C1_TP);
     return (int)(ntiles < C1_MAX_GRID ? ntiles : C1_MAX_GRID);
@@ -201,13 +211,18 @@ extern "C" int dm_conv1x1_bwd_fused(const dm_operand *dy, const float *x, const 
                                     double *stats, float *wslabs, int B, int CD, int CX, int H, int W, void *stream)
 {
     DM_REQUIRE(dy && dy->p0 && x && xcoef && w && dx && stats && wslabs, "dm_conv1x1_bwd_fused: NULL pointer");
-    DM_REQUIRE(B > 0 && conv1x1_bwd_shape(CD, CX, H, W), "dm_conv1x1_bwd_fused: shape %d -> %d channels on %dx%d not built", CX, CD, H, W);
+    DM_REQUIRE(B > 0 && (conv1x1_bwd_shape(CD, CX, H, W) || dm_stream_conv1x1_bwd_shape(CD, CX, H, W)),
+               "dm_conv1x1_bwd_fused: shape %d -> %d channels on %dx%d not built", CX, CD, H, W);
     DM_REQUIRE(dy->mode == DM_LOAD_IDENT || dy->mode == DM_LOAD_AFFINE2, "dm_conv1x1_bwd_fused: dy operand must be IDENT or AFFINE2");
     DM_REQUIRE(dy->mode == DM_LOAD_IDENT || dy->coef, "dm_conv1x1_bwd_fused: AFFINE2 needs coefficients");
     DM_REQUIRE(dy->coef_bstride == 0 && !dy->ones_channel, "dm_conv1x1_bwd_fused: shared coefficients only");
     DM_REQUIRE((long long)B * CX * H * W < (1LL << 31), "dm_conv1x1_bwd_fused: tensor too large");
     Operand d = to_dev(dy);
     if (d.mode == DM_LOAD_IDENT) { d.coef = nullptr; d.p1 = nullptr; }
+    if (dm_stream_conv1x1_bwd_shape(CD, CX, H, W)) {
+        dm_stream_conv1x1_bwd(d, x, xcoef, w, dx, stats, wslabs, B, H, W, (hipStream_t)stream);
+        return dm_launch_status("dm_conv1x1_bwd_fused");
+    }
     const int grid = dm_conv1x1_bwd_fused_num_blocks(B, CD, CX, H, W);
     const int ntiles = B * (H * W / C1_TP);
     hipLaunchKernelGGL((conv1x1_bwd_kernel<16, 32>), dim3(grid), dim3(DM_BLOCK), 0, (hipStream_t)stream, d, x, xcoef, w, dx, stats,

@@ -1192,9 +1192,188 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wide_stream_kernel(Operand in,
     }
 }
 
+// ------------------------------------------- backward of the wide residual blocks' 1x1 convolution (64 -> 64), both gradients
+// dm_conv1x1_bwd_fused at 64 channels.  As two launches (data gradient + weight gradient, above) the pair read dy, its
+// BatchNorm-backward partner and the layer input twice from HBM (1.4 GB at B = 768, 209 + 146 us); here a wave takes 64 pixels
+// through BOTH products before it moves on, so the second reading comes out of L2:
+//     part 1   dx[ci][px] = (a0 x + a2 > 0) * sum_co W[co][ci] * da[co][px]       (M = ci from W^T in LDS, N = pixels, K = co)
+//     part 2   dW[co][ci] += sum_px da[co][px] * relu(a0 x + a2)[ci][px]           (M = co, N = ci, K = pixels)
+// with da = c0 dy + c1 y + c2 (BatchNorm backward folded into the load).  Part 1 reads da as the B operand (lane = pixel quad
+// of channel 4 ks + kq), part 2 as the A operand (lane = four pixels of channel 16 mt + p): the same bytes in the other of the
+// two layouts wide_stream.hip's header describes.  Every wave is on its own (no barrier after the tables are in) and writes its
+// own statistics and weight slab.
+template <bool IN2>
+__global__ __launch_bounds__(256, 2) void conv1x1_bwd_wide_stream_kernel(Operand dy, const float *__restrict__ x, const float *__restrict__ xcoef,
+                                                                         const float *__restrict__ w, float *__restrict__ dx,
+                                                                         double *__restrict__ stats, float *__restrict__ wslabs,
+                                                                         int B, int HW, int nslabs)
+{
+    constexpr int C = 64, MT = 4;
+    __shared__ __attribute__((aligned(16))) float s_wt[16 * MT * 64];    // [ks][mt][co % 4][ci % 16] = w[co = 4 ks + ..][ci = 16 mt + ..]
+    __shared__ __attribute__((aligned(16))) float s_cd[C * 4];           // (c0, c1, c2, -) of output-gradient channel co
+    __shared__ __attribute__((aligned(16))) float s_cx[C * 4];           // (a0, -, a2, -) of layer-input channel ci
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < 16 * MT * 64; i += 256) {
+        const int m = i & 15, c = (i >> 4) & 3, mt = (i >> 6) & 3, ks = i >> 8;
+        s_wt[i] = w[(4 * ks + c) * C + 16 * mt + m];
+    }
+    for (int i = tid; i < C; i += 256) {
+        const StreamCoef c = stream_coef(dy, i);
+        s_cd[i * 4] = c.c0; s_cd[i * 4 + 1] = c.c1; s_cd[i * 4 + 2] = c.c2; s_cd[i * 4 + 3] = 0.f;
+        s_cx[i * 4] = xcoef[i * 4]; s_cx[i * 4 + 1] = 0.f; s_cx[i * 4 + 2] = xcoef[i * 4 + 2]; s_cx[i * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+
+    const int upp = HW >> 6;
+    const long long total = (long long)B * upp;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int u0 = (int)(total * gw / nw), u1 = (int)(total * (gw + 1) / nw);
+    const unsigned bytes = (unsigned)((long long)B * C * HW * 4);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy.p0), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(IN2 ? dy.p1 : dy.p0), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, bytes, 0x00020000);
+    const int vo1 = (kq * HW + 4 * p) * 4;                       // part 1: channel 4 ks + kq, pixels 4 p ..
+    const int voe = (4 * kq * HW + 4 * p) * 4;                   // its epilogue: channel 16 mt + 4 kq + i, pixels 4 p ..
+    const int vo2 = (p * HW + 4 * kq) * 4;                       // part 2: channel 16 t + p, pixels 16 g + 4 kq ..
+
+    f32x4 aw[MT][MT];                                            // dW[co = 16 mt + 4 kq + i][ci = 16 nt + p], over all of the wave's units
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < MT; ++b2) aw[a][b2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    double st1 = 0.0, st2 = 0.0;                                 // lane p of row kq: channel 16 (p >> 2) + 4 kq + (p & 3)
+
+    for (int u = u0; u < u1; ++u) {
+        const int b = u / upp, r = u - b * upp;
+        const unsigned ub = (unsigned)(((long long)b * C * HW + r * 64) * 4);
+        // ---- part 1: the data gradient
+        f32x4 ax[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ax[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            constexpr int R = 2;
+            f32x4 rd[R], ry[R];
+            auto issue = [&](auto slot, int ks) {
+                constexpr int sl = decltype(slot)::value;
+                rd[sl] = __builtin_amdgcn_raw_buffer_load_b128(rD, vo1, ub + ks * (4 * HW * 4), 0);
+                if constexpr (IN2) ry[sl] = __builtin_amdgcn_raw_buffer_load_b128(rY, vo1, ub + ks * (4 * HW * 4), 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            issue(std::integral_constant<int, 0>{}, 0); issue(std::integral_constant<int, 1>{}, 1);
+            auto kloop = [&](auto self, auto kc) -> void {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks < 16) {
+                    constexpr int sl = ks % R;
+                    const f32x4 cf = *reinterpret_cast<const f32x4 *>(&s_cd[(4 * ks + kq) * 4]);
+                    f32x4 v;
+                    if constexpr (IN2) v = cf.x * rd[sl] + (cf.y * ry[sl] + cf.z);
+                    else v = cf.x * rd[sl] + cf.z;
+                    float wa[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) wa[mt] = s_wt[(ks * MT + mt) * 64 + kq * 16 + p];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ax[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt], v[j], ax[mt][j], 0, 0, 0);
+                    if constexpr (ks + R < 16) issue(std::integral_constant<int, sl>{}, ks + R);
+                    self(self, std::integral_constant<int, ks + 1>{});
+                }
+            };
+            kloop(kloop, std::integral_constant<int, 0>{});
+        }
+        // ---- part 2: the weight gradient, 16 pixels per step (the unit's bytes again, now out of L2); the loads of step g + 1
+        //      are in flight while step g multiplies
+        {
+            f32x4 ld[2][MT], ly[IN2 ? 2 : 1][MT], lx[2][MT];
+            auto req = [&](auto sc, int g) {
+                constexpr int sl = decltype(sc)::value;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const unsigned so = ub + (unsigned)((16 * t) * HW * 4 + g * 64);
+                    ld[sl][t] = __builtin_amdgcn_raw_buffer_load_b128(rD, vo2, so, 0);
+                    if constexpr (IN2) ly[sl][t] = __builtin_amdgcn_raw_buffer_load_b128(rY, vo2, so, 0);
+                    lx[sl][t] = __builtin_amdgcn_raw_buffer_load_b128(rX, vo2, so, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mul = [&](auto sc) {
+                constexpr int sl = decltype(sc)::value;
+                f32x4 da[MT], tx[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const f32x4 cd = *reinterpret_cast<const f32x4 *>(&s_cd[(16 * t + p) * 4]);
+                    const f32x4 cx = *reinterpret_cast<const f32x4 *>(&s_cx[(16 * t + p) * 4]);
+                    if constexpr (IN2) da[t] = cd.x * ld[sl][t] + (cd.y * ly[sl][t] + cd.z);
+                    else da[t] = cd.x * ld[sl][t] + cd.z;
+                    tx[t] = dm_relu4(cx.x * lx[sl][t] + cx.z);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b2 = 0; b2 < MT; ++b2) aw[a][b2] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[a][j], tx[b2][j], aw[a][b2], 0, 0, 0);
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+        // its epilogue: (mt, i) -> channel ci = 16 mt + 4 kq + i, pixels 4 p ..: gate by the layer input, store, statistics
+            {
+                float sel1 = 0.f, sel2 = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 xr[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rX, voe, ub + (unsigned)((16 * mt + i) * HW * 4), 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ci = 16 * mt + 4 * kq + i;
+                        const float a0 = s_cx[ci * 4], a2 = s_cx[ci * 4 + 2];
+                        const f32x4 q = xr[i];
+                        f32x4 v = (f32x4){ax[mt][0][i], ax[mt][1][i], ax[mt][2][i], ax[mt][3][i]};
+                        v.x = (a0 * q.x + a2) > 0.f ? v.x : 0.f; v.y = (a0 * q.y + a2) > 0.f ? v.y : 0.f;
+                        v.z = (a0 * q.z + a2) > 0.f ? v.z : 0.f; v.w = (a0 * q.w + a2) > 0.f ? v.w : 0.f;
+                        *reinterpret_cast<f32x4 *>(dx + ((long long)b * C + ci) * HW + r * 64 + 4 * p) = v;
+                        float sa = (v.x + v.y) + (v.z + v.w), sc = (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
+                        sa += dpp_mov<0xB1>(sa); sc += dpp_mov<0xB1>(sc);
+                        sa += dpp_mov<0x4E>(sa); sc += dpp_mov<0x4E>(sc);
+                        sa += dpp_mov<0x141>(sa); sc += dpp_mov<0x141>(sc);
+                        sa += dpp_mov<0x140>(sa); sc += dpp_mov<0x140>(sc);
+                        sel1 = p == 4 * mt + i ? sa : sel1;
+                        sel2 = p == 4 * mt + i ? sc : sel2;
+                    }
+                }
+                st1 += (double)sel1; st2 += (double)sel2;
+            }
+            req(I0{}, 0);
+            req(I1{}, 1); mul(I0{});
+            req(I0{}, 2); mul(I1{});
+            req(I1{}, 3); mul(I0{});
+            mul(I1{});
+        }
+    }
+    // the wave's slabs: statistics (sum dx, sum dx * x) per channel and dW[co][ci]
+    {
+        const int ci = 16 * (p >> 2) + 4 * kq + (p & 3);
+        stats[((long long)gw * C + ci) * 2] = st1; stats[((long long)gw * C + ci) * 2 + 1] = st2;
+        float *row = wslabs + (long long)gw * C * C;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < MT; ++b2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) row[(16 * a + 4 * kq + i) * C + 16 * b2 + p] = aw[a][b2][i];
+    }
+    for (int sl = nw + gw; sl < nslabs; sl += nw) {
+        for (int i = lane; i < C * 2; i += 64) stats[(long long)sl * C * 2 + i] = 0.0;
+        for (int i = lane; i < C * C; i += 64) wslabs[(long long)sl * C * C + i] = 0.f;
+    }
+}
+
 int stream_switch()
 {
-    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0x1ff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS, 6: its transposed mirror 64 -> 32, 7 / 8: 3x3 64 -> 64 with the weights in LDS (forward form / forms with a gate)
+    static const int v = getenv("DM_WIDE_STREAM") ? atoi(getenv("DM_WIDE_STREAM")) : 0x3ff;   // bit 0: 1x1 weight gradient, 1: 1x1 convolution, 2: thin 4x4/s2 weight gradient, 3: thin 4x4/s2 convolution, 4: thin transposed convolution, 5: 4x4/s2 convolution 32 -> 64 with the weights resident in LDS, 6: its transposed mirror 64 -> 32, 7 / 8: 3x3 64 -> 64 with the weights in LDS (forward form / forms with a gate), 9: both gradients of the 1x1 64 -> 64 in one launch
     return v;
 }
 int stream_depth()
@@ -1409,4 +1588,28 @@ bool dm_stream_conv3x3_wide(const Operand &in, const WeightView &wv, float *out,
     else
         hipLaunchKernelGGL((conv3x3_wide_stream_kernel<false>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
     return true;
+}
+
+// dm_conv1x1_bwd_fused at 64 -> 64 channels: slabs = waves (every wave writes its own statistics and weight slab)
+bool dm_stream_conv1x1_bwd_shape(int CD, int CX, int H, int W)
+{
+    return (stream_switch() & 512) && CD == 64 && CX == 64 && H > 0 && W > 0 && ((long long)H * W) % 64 == 0;
+}
+
+int dm_stream_conv1x1_bwd_slabs(int B, int H, int W)
+{
+    const long long units = (long long)B * H * W / 64;
+    const long long wg = units / 4 < 512 ? (units + 3) / 4 : 512;
+    return (int)(wg * 4);
+}
+
+int dm_stream_conv1x1_bwd(const Operand &dy, const float *x, const float *xcoef, const float *w, float *dx, double *stats,
+                          float *wslabs, int B, int H, int W, hipStream_t st)
+{
+    const int nslabs = dm_stream_conv1x1_bwd_slabs(B, H, W);
+    if (dy.mode == DM_LOAD_AFFINE2)
+        hipLaunchKernelGGL((conv1x1_bwd_wide_stream_kernel<true>), dim3(nslabs / 4), dim3(256), 0, st, dy, x, xcoef, w, dx, stats, wslabs, B, H * W, nslabs);
+    else
+        hipLaunchKernelGGL((conv1x1_bwd_wide_stream_kernel<false>), dim3(nslabs / 4), dim3(256), 0, st, dy, x, xcoef, w, dx, stats, wslabs, B, H * W, nslabs);
+    return 0;
 }

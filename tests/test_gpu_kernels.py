@@ -782,7 +782,7 @@ def test_conv1x1_backward_fused_equals_the_two_kernels(ops, B, H, W, two):
     dst3 = torch.zeros(CD, CX, 1, 1, device=DEV)
     dx3, st3 = ops.conv1x1_bwd_fused(dy_op, d(x), d(cx), d(w), dst3, B, CD, CX, H, W)
     assert torch.equal(dx3, dx) and torch.equal(st3, st) and torch.equal(dst3, dst)
-    assert not ops.conv1x1_bwd_fused_supported(CD, CX, 8, 8) and not ops.conv1x1_bwd_fused_supported(64, 64, 16, 16)
+    assert not ops.conv1x1_bwd_fused_supported(CD, CX, 8, 8) and not ops.conv1x1_bwd_fused_supported(48, 48, 16, 16)
 
 
 @pytest.mark.parametrize("B,CD,form,hw", [(3, 16, "enc10", (16, 16)), (70, 16, "enc10", (16, 16)), (5, 32, "res", (16, 16)),
@@ -2070,3 +2070,29 @@ def test_stream_conv_3x3_64_channels_weights_in_lds(ops, B, mode, dgrad, epi):
     close(out, ref.float(), 5e-5, 5e-5, "stream conv 3x3")
     if st is not None:
         close_stats(st.sum(0), ref.float(), sq)
+
+
+@pytest.mark.parametrize("B,H,W,two", [(3, 32, 32, True), (2, 8, 16, False), (7, 16, 16, True), (70, 32, 32, True)])
+def test_stream_conv1x1_backward_fused_64_channels(ops, B, H, W, two):
+    """wide_stream.hip: dm_conv1x1_bwd_fused at 64 -> 64 channels (the wide residual blocks): data gradient with the layer
+    input's ReLU gate, its (sum dx, sum dx * x) statistics and the weight gradient from one pass over the operands, every wave
+    with its own slabs -- against float64."""
+    C = 64
+    dy, y = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=2)
+    coef = torch.stack([rnd(C, seed=3), rnd(C, seed=4) * 0.1, rnd(C, seed=5) * 0.1, torch.zeros(C)], 1)
+    x = rnd(B, C, H, W, seed=6)
+    xcoef = torch.stack([rnd(C, seed=7).abs() + 0.5, torch.zeros(C), rnd(C, seed=8) * 0.3, torch.zeros(C)], 1)
+    w = rnd(C, C, 1, 1, seed=9, scale=0.1)
+    da = load_ref(dy.double(), 4, coef.double(), y.double()) if two else dy.double()
+    t = xcoef[:, 0].double().view(1, -1, 1, 1) * x.double() + xcoef[:, 2].double().view(1, -1, 1, 1)
+    xin = t.clamp(min=0).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    F.conv2d(xin, wd, None).backward(da)
+    dx_ref = xin.grad * (t > 0)
+    assert ops.conv1x1_bwd_fused_supported(C, C, H, W)
+    dst = torch.empty(C, C, 1, 1, device=DEV)
+    op = ops.Op(dy.to(DEV), 4, coef.to(DEV), p1=y.to(DEV)) if two else ops.Op(dy.to(DEV))
+    dx, st = ops.conv1x1_bwd_fused(op, x.to(DEV), xcoef.to(DEV), w.to(DEV), dst, B, C, C, H, W)
+    close(dx, dx_ref.float(), 5e-5, 5e-5, "fused 1x1 backward: dx")
+    close(dst, wd.grad.float(), 5e-5, 5e-5 * float(wd.grad.abs().max()), "fused 1x1 backward: dW")
+    close_stats(st.sum(0), dx_ref.float(), x)

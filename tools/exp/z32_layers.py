@@ -54,3 +54,4 @@ t("dgrad up1 (conv s2 2->32)", lambda: ops.conv4x4s2(Op(g128), ops.weight_view(w
 t("dgrad conv1 (convT 64->32 aff2)", lambda: ops.conv3x3(Op(g32, 4, cf64, p1=a32), ops.weight_view(w4, 16, (C // 2) * 16, 4, 1), B, C, 4 * (C // 2), HW, HW, taps=9,
                                                         pixel_shuffle=True, want_stats=True, mask=Op(x64, 2, cf32), stat_q=x64), 2 * P * C * (C // 2) * 16, 2 * T32 + 2 * T64)
 t("dgrad up0 (conv s2 32->64)", lambda: ops.conv4x4s2(Op(x64), ops.weight_view(w4, (C // 2) * 16, 16, 4, 1), B, C // 2, C, 64, 64), 2 * P * C * (C // 2) * 16, T64 + T32)
+t("res 1x1 backward fused", lambda: ops.conv1x1_bwd_fused(Op(g32, 4, cf64, p1=a32), x32, cf64, w1, d11, B, C, C, HW, HW), 4 * P * C * C, 4 * T32)
