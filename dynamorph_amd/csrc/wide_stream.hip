@@ -1195,7 +1195,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wide_stream_kernel(Operand in,
 // ------------------------------------------- backward of the wide residual blocks' 1x1 convolution (64 -> 64), both gradients
 // dm_conv1x1_bwd_fused at 64 channels.  As two launches (data gradient + weight gradient, above) the pair read dy, its
 // BatchNorm-backward partner and the layer input twice from HBM (1.4 GB at B = 768, 209 + 146 us); here a wave takes 64 pixels
-// through BOTH products before it moves on, so the second reading comes out of L2:
+// through BOTH products before it moves on (237-275 us for both; by the counters the second reading still comes from HBM more
+// often than from L2 -- 2 048 waves x 48 KB of unit in flight exceed it -- the gain is one launch and one set of prologues):
 //     part 1   dx[ci][px] = (a0 x + a2 > 0) * sum_co W[co][ci] * da[co][px]       (M = ci from W^T in LDS, N = pixels, K = co)
 //     part 2   dW[co][ci] += sum_px da[co][px] * relu(a0 x + a2)[ci][px]           (M = co, N = ci, K = pixels)
 // with da = c0 dy + c1 y + c2 (BatchNorm backward folded into the load).  Part 1 reads da as the B operand (lane = pixel quad
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_wide_stream_kernel(Operand
             };
             kloop(kloop, std::integral_constant<int, 0>{});
         }
-        // ---- part 2: the weight gradient, 16 pixels per step (the unit's bytes again, now out of L2); the loads of step g + 1
+        // ---- part 2: the weight gradient, 16 pixels per step (the unit's bytes again); the loads of step g + 1
         //      are in flight while step g multiplies
         {
             f32x4 ld[2][MT], ly[IN2 ? 2 : 1][MT], lx[2][MT];

@@ -14,6 +14,7 @@ KEYS = {   # key -> (substring of the kernel name, algorithmic bytes, what moves
     "wgrad1x1_stream": ("wgrad1x1_stream_kernel<4, 4, true", 3 * T32, "dy + its BatchNorm-backward partner + the layer input"),
     "conv1x1_stream_fwd": ("conv1x1_stream_kernel<4, 4, false", 2 * T32, "input + output"),
     "conv1x1_stream_dgrad": ("conv1x1_stream_kernel<4, 4, true", 4 * T32, "two input tensors + gate + output"),
+    "conv1x1_bwd_fused": ("conv1x1_bwd_wide_stream_kernel<true>", 4 * T32, "dy + partner + the layer input + dx (the weight gradient reads the first three again)"),
     "wgrad_s2_thin_conv0": ("wgrad_s2_thin_stream_kernel<2, 2, true", 2 * T64 + T128, "dy + partner (32 channels) + the image"),
     "wgrad_s2_thin_up1": ("wgrad_s2_thin_stream_kernel<2, 2, false", T64 + T128, "d1 + the image-side gradient"),
     "conv_s2_thin": ("conv_s2_thin_stream_kernel<2, 2>", (2 * T128 + 3 * T64) // 2, "mean of the two forms the bench launches: first convolution (image + 32-channel output) and the data gradient of the last transposed convolution (+ the gate tensor)"),
