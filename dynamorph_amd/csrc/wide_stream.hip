@@ -817,10 +817,8 @@ __global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in,
                             (unsigned)((long long)B * CO * OH * OW * 4));
     }
     if (ep.stats) {
-        if (true) {
-            const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
-            s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2;
-        }
+        const int co = 16 * (p >> 2) + 4 * kq + (p & 3);
+        s_red[(wave * CO + co) * 2] = st1; s_red[(wave * CO + co) * 2 + 1] = st2;
         __syncthreads();
         for (int i = tid; i < CO * 2; i += 512) {
             double sum = 0.0;
