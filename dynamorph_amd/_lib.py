@@ -99,6 +99,7 @@ SIGNATURES = {
     "dm_conv4x4s2_bwd_fused_num_blocks": (C.c_int, [C.c_int] * 5),
     "dm_conv4x4s2_bwd_fused": (C.c_int, [OP, vp, vp, vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "dm_wgrad_num_blocks": (C.c_int, [C.c_int] * 6),
+    "dm_wgrad_t_affine2_supported": (C.c_int, [C.c_int] * 5),
     "dm_wgrad": (C.c_int, [OP, OP, vp, vp] + [C.c_int] * 6 + [vp]),
     "dm_bn_finalize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, vp, f32, f32, vp, vp, C.c_int, vp]),
     "dm_bn_backward_finalize": (C.c_int, [vp, C.c_int, C.c_int, i64, vp, vp, vp, vp, vp, vp]),

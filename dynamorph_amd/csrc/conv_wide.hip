@@ -683,7 +683,7 @@ struct Wg1Geom : WgGeom<KK> {
     static_assert(NT * 16 == NCT * G0::T2 && NTW * 2 == NT, "the two halves split the N tiles evenly");
 };
 
-template <int KK, int NCT, bool S2>
+template <int KK, int NCT, bool S2, bool TTWO = false>
 __global__ __launch_bounds__(512, 1) void wgrad_wide1_kernel(Operand S, Operand T, float *__restrict__ slabs, int B, int Hs, int Ws,
                                                             int nslabs)
 {
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_wide1_kernel(Operand S, Operand 
     stage_coef(S, s_cfS, 64, 0, CS, 0, tid, 512);
     stage_coef(T, s_cfT, NCT, 0, NCT, 0, tid, 512);
 
-    RowPrefetch<G, NCT, false, 512> pt;
+    RowPrefetch<G, NCT, TTWO, 512> pt;                           // TTWO: the T operand is AFFINE2 (its second tensor is prefetched too)
     constexpr int JS = 64 * 8 * 4 / 512;                         // S tile: 64 channels x 8 rows x 4 float4 = 4 per thread
     f32x4 sv[JS], su[S2 ? JS : 1];
     __amdgpu_buffer_rsrc_t rS0, rS1;
@@ -953,6 +953,9 @@ int dm_stream_wgrad_s2_thin_slabs(int B, int Hs, int Ws);
 bool dm_stream_wgrad_s2_thin(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int Hs, int Ws, int nslabs,
                              hipStream_t st);
 
+// T as an AFFINE2 operand (two tensors): only where the one-pass kernel prefetches both
+bool dm_wide_wgrad_t_affine2_ok(int CS, int CT, int Hs, int Ws, int k);
+
 bool dm_wide_wgrad_ok(int Hs, int Ws) { return !(wide_disabled() & 2) && Hs > 0 && Ws > 0 && Hs % 8 == 0 && Ws % 16 == 0; }
 
 static void wide_wgrad_grid(int CS, int CT, int k, int &gy, int &gz, int &cap)
@@ -971,6 +974,11 @@ static int wide_wgrad_one_pass()
     return v;
 }
 static bool wide_wgrad1_shape(int CS, int CT, int k) { return wide_wgrad_one_pass() && CS == 64 && ((k == 3 && CT == 64) || (k == 4 && CT == 32)); }
+
+bool dm_wide_wgrad_t_affine2_ok(int CS, int CT, int Hs, int Ws, int k)
+{
+    return k == 4 && wide_wgrad1_shape(CS, CT, k) && dm_wide_wgrad_ok(Hs, Ws);
+}
 
 int dm_wide_wgrad_slabs(int B, int CS, int CT, int Hs, int Ws, int k)
 {
@@ -991,12 +999,16 @@ int dm_wide_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int C
 {
     if (k == 1 && dm_stream_wgrad1x1(S, T, slabs, B, CS, CT, Hs, Ws, nslabs, st)) return 0;
     if (k == 4 && CT == CTphys && dm_stream_wgrad_s2_thin(S, T, slabs, B, CS, CT, Hs, Ws, nslabs, st)) return 0;
-    if (wide_wgrad1_shape(CS, CT, k) && CT == CTphys && !T.ones && T.mode != DM_LOAD_AFFINE2 &&
+    if (wide_wgrad1_shape(CS, CT, k) && CT == CTphys && !T.ones && (T.mode != DM_LOAD_AFFINE2 || (k == 4 && S.mode != DM_LOAD_AFFINE2)) &&
         !(S.mode >= DM_LOAD_AFFINE && S.coef_bstride) && !(T.mode >= DM_LOAD_AFFINE && T.coef_bstride)) {
         const long long units = (long long)B * (Hs / 8) * (Ws / 16);
         int g1 = (int)(units < 256 ? units : 256);
         if (g1 > nslabs) g1 = nslabs;
         const bool two = S.mode == DM_LOAD_AFFINE2;
+        if (T.mode == DM_LOAD_AFFINE2) {       // the decoder's first transposed convolution: T = BatchNorm backward of its output gradient
+            hipLaunchKernelGGL((wgrad_wide1_kernel<4, 32, false, true>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);
+            return 0;
+        }
         if (k == 3 && two) hipLaunchKernelGGL((wgrad_wide1_kernel<3, 64, true>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);
         else if (k == 3) hipLaunchKernelGGL((wgrad_wide1_kernel<3, 64, false>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);
         else if (two) hipLaunchKernelGGL((wgrad_wide1_kernel<4, 32, true>), dim3(g1), dim3(512), 0, st, S, T, slabs, B, Hs, Ws, nslabs);

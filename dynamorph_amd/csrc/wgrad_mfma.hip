@@ -26,6 +26,7 @@ int dm_generic_wgrad(const Operand &S, const Operand &T, float *slabs, int B, in
                      int KK, int nslabs, hipStream_t st);
 // arbitrary channel counts on the MFMA, 8 x 16 tiles (conv_wide.hip)
 bool dm_wide_wgrad_ok(int Hs, int Ws);
+bool dm_wide_wgrad_t_affine2_ok(int CS, int CT, int Hs, int Ws, int k);
 int dm_wide_wgrad_slabs(int B, int CS, int CT, int Hs, int Ws, int k);
 int dm_wide_wgrad(const Operand &S, const Operand &T, float *slabs, int B, int CS, int CT, int CTphys, int Hs, int Ws,
                   int k, int nslabs, hipStream_t st);
@@ -589,6 +590,11 @@ static bool wgrad_has_kernel(int CS, int CT, int Hs, int Ws, int k)
     return false;
 }
 
+extern "C" int dm_wgrad_t_affine2_supported(int CS, int CT, int Hs, int Ws, int k)
+{
+    return (!wgrad_has_kernel(CS, CT, Hs, Ws, k) && dm_wide_wgrad_t_affine2_ok(CS, CT, Hs, Ws, k)) ? 1 : 0;
+}
+
 extern "C" int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k)
 {
     if (B <= 0 || (k != 4 && k != 3 && k != 1)) return -1;
@@ -612,7 +618,8 @@ extern "C" int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, 
     const int TW = wgrad_tw(Ws);
     const bool fast = wgrad_has_kernel(CS, CT, Hs, Ws, k);
     const int grid = dm_wgrad_num_blocks(B, CS, CT, Hs, Ws, k);
-    DM_REQUIRE(T->mode != DM_LOAD_AFFINE2, "dm_wgrad: T operand cannot be AFFINE2");
+    DM_REQUIRE(T->mode != DM_LOAD_AFFINE2 || (dm_wgrad_t_affine2_supported(CS, CT, Hs, Ws, k) && S->mode != DM_LOAD_AFFINE2 && !T->ones_channel),
+               "dm_wgrad: T operand cannot be AFFINE2 for this shape (dm_wgrad_t_affine2_supported)");
     const int CTphys = CT - (T->ones_channel ? 1 : 0);
     DM_REQUIRE(CTphys > 0, "dm_wgrad: no physical T channel");
     hipStream_t st = (hipStream_t)stream;

@@ -706,11 +706,11 @@ __global__ __launch_bounds__(256, 4) void convT_thin_stream_kernel(Operand in, c
 // per input channel, neighbours by DPP).  Eight waves per workgroup (one workgroup per CU), each with its own stream of
 // units and no barrier after the weights are in.  A unit is two output rows x 32 pixels: lanes p < 8 hold row oy, the others
 // row oy + 1, pixel 4 (p & 7) + j in N tile j.
-template <bool AFF>
+template <bool AFF, bool IN2 = false>
 __global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in, WeightView wv, float *__restrict__ out, Epilogue ep,
                                                                      int B, int nslabs)
 {
-    constexpr int CIN = 32, CO = 64, MT = 4, H = 64, W = 64, OH = 32, OW = 32, KS = CIN * 4, R = 4;
+    constexpr int CIN = 32, CO = 64, MT = 4, H = 64, W = 64, OH = 32, OW = 32, KS = CIN * 4, R = IN2 ? 2 : 4;   // (IN2: an AFFINE2 input, two tensors)
     extern __shared__ __attribute__((aligned(16))) float s_w[];          // [KS][MT][4 ky][16]: 128 KB
     __shared__ __attribute__((aligned(16))) float s_ep[CO * 4];
     __shared__ double s_red[8 * CO * 2];
@@ -732,12 +732,13 @@ __global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in,
     const int n = (u1 - u0 - wave + 7) >> 3;                     // this wave's units: u0 + wave, + 8, ...
     const unsigned bytesI = (unsigned)((long long)B * CIN * H * W * 4);
     const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, bytesI, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(IN2 ? in.p1 : in.p0), 0, bytesI, 0x00020000);
     const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in.p0), 0, 0, 0x00020000);
     const int half = p >> 3, pc = p & 7;
     const float ilo = stream_floor(in);
     const float *sa = s_w + kq * 16 + p;                         // + (ks * MT + mt) * 64
 
-    f32x4 x0[R], x1[R];
+    f32x4 x0[R], x1[R], y0[IN2 ? R : 1], y1[IN2 ? R : 1];
     int vbase = 0;                                               // byte offset of the lane's row / columns in channel 0 of the unit in flight
     bool rowbad = false;
     auto unit_begin = [&](int u) {
@@ -751,6 +752,10 @@ __global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in,
         constexpr int sl = decltype(slot)::value;
         x0[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, vbase, ci * (H * W * 4), 0);
         x1[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rI : dead, vbase + 16, ci * (H * W * 4), 0);
+        if constexpr (IN2) {
+            y0[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, vbase, ci * (H * W * 4), 0);
+            y1[sl] = __builtin_amdgcn_raw_buffer_load_b128(live ? rU : dead, vbase + 16, ci * (H * W * 4), 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     bool nextbad = unit_begin(n > 0 ? u0 + wave : 0);
@@ -782,7 +787,10 @@ __global__ __launch_bounds__(512, 1) void conv_s2_wide_stream_kernel(Operand in,
                 if constexpr (c < R) {
                     const int ci = cb + c;
                     f32x4 a0 = x0[c], a1 = x1[c];
-                    if (AFF) {
+                    if constexpr (IN2) {
+                        const StreamCoef kc = stream_coef(in, ci);
+                        a0 = kc.c0 * a0 + (kc.c1 * y0[c] + kc.c2); a1 = kc.c0 * a1 + (kc.c1 * y1[c] + kc.c2);
+                    } else if (AFF) {
                         const StreamCoef kc = stream_coef(in, ci);
                         a0 = sx_max(kc.c0 * a0 + kc.c2, ilo); a1 = sx_max(kc.c0 * a1 + kc.c2, ilo);
                     }
@@ -1519,20 +1527,23 @@ bool dm_stream_convT_thin(const Operand &in, const WeightView &wv, float *scratc
 bool dm_stream_conv_s2_wide(const Operand &in, const WeightView &wv, float *out, const Epilogue &ep, int B, int Cphys, int CIN,
                             int NOUT, int H, int W, int nslabs, int per_tile, hipStream_t st)
 {
-    if (!(stream_switch() & 32) || per_tile || Cphys != CIN || in.ones || ep.bias_border || in.mode == DM_LOAD_AFFINE2) return false;
+    if (!(stream_switch() & 32) || per_tile || Cphys != CIN || in.ones || ep.bias_border) return false;
     if (CIN != 32 || NOUT != 64 || H != 64 || W != 64 || (long long)B * 64 * 32 * 32 * 4 >= (1LL << 31)) return false;
     if (in.mode >= DM_LOAD_AFFINE && in.coef_bstride) return false;
     if (ep.mask.p0 && (ep.mask.mode == DM_LOAD_RELU || ep.mask.mode > DM_LOAD_AFFINE || ep.mask.coef_bstride || ep.mask.ones)) return false;
     const int lds = 128 * 1024;
     // (per launch, as dm_vq_backward does: the attribute belongs to the current device's copy of the kernel)
     if (hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv_s2_wide_stream_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return false;
     const long long units = (long long)B * 16;
     int grid = (int)(units / 8 < 256 ? (units + 7) / 8 : 256);
     if (ep.stats && grid > nslabs) grid = nslabs;
     if (grid < 1) grid = 1;
-    if (in.mode >= DM_LOAD_AFFINE || in.mode == DM_LOAD_RELU)
+    if (in.mode == DM_LOAD_AFFINE2)
+        hipLaunchKernelGGL((conv_s2_wide_stream_kernel<true, true>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
+    else if (in.mode >= DM_LOAD_AFFINE || in.mode == DM_LOAD_RELU)
         hipLaunchKernelGGL((conv_s2_wide_stream_kernel<true>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);
     else
         hipLaunchKernelGGL((conv_s2_wide_stream_kernel<false>), dim3(grid), dim3(512), lds, st, in, wv, out, ep, B, nslabs);

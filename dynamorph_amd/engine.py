@@ -620,13 +620,16 @@ def z32_tail_backward(up0, bn, up1, cx, gscale, gdec_ext, G, want_gr=True, pendi
     dy, st = ops.conv4x4s2(Op(g), weight_view(_w(up1.weight), NIN * 16, 16, 4, 1), B, NIN, c1, 4 * H2, 4 * W2,
                            want_stats=True, mask=Op(cx.d1, DM_LOAD_AFFINE, cx.coefd), stat_q=cx.d1)
     cdb = _bn_backward(st, B * 4 * H2 * W2, bn, cx.savedd, G)
-    # the weight-gradient kernel takes the BatchNorm-backward transform on its S operand only: materialise it here
-    da = ops.apply(Op(dy, DM_LOAD_AFFINE2, cdb, p1=cx.d1), B, c1, 2 * H2, 2 * W2)
-    ops.wgrad(Op(cx.r), Op(da), G(up0.weight), B, nh, c1, H2, W2, 4, pending=pending)
+    # da = BatchNorm backward of dy.  The weight-gradient kernels take that transform on their S operand; as the T operand only
+    # where the one-pass kernel prefetches both tensors (the example widths) -- elsewhere da is materialised here
+    da = Op(dy, DM_LOAD_AFFINE2, cdb, p1=cx.d1)
+    if not ops.wgrad_t_affine2_supported(nh, c1, H2, W2, 4):
+        da = Op(ops.apply(da, B, c1, 2 * H2, 2 * W2))
+    ops.wgrad(Op(cx.r), da, G(up0.weight), B, nh, c1, H2, W2, 4, pending=pending)
     _fed_bias(G(up0.bias), bn, cdb, G, zero_fed_biases)
     g_r = None
     if want_gr:
-        g_r, _ = ops.conv4x4s2(Op(da), weight_view(_w(up0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H2, 2 * W2)
+        g_r, _ = ops.conv4x4s2(da, weight_view(_w(up0.weight), c1 * 16, 16, 4, 1), B, c1, nh, 2 * H2, 2 * W2)
     if own:
         ops.reduce_slabs_multi(pending)
     return g_r

@@ -336,6 +336,11 @@ def wgrad(S, T, dst, B, CS, CT, Hs, Ws, k, pending=None):
     return dst
 
 
+def wgrad_t_affine2_supported(CS, CT, Hs, Ws, k):
+    """True where dm_wgrad takes T as an AFFINE2 operand (a BatchNorm backward folded into the load of the output gradient)."""
+    return bool(L.load().dm_wgrad_t_affine2_supported(CS, CT, Hs, Ws, k))
+
+
 def backward_precision(mode=None):
     """Arithmetic of the backward matrix products: "f32", the exact fp32 chain -- the only one built (the split-bf16 opt-in
     of earlier rounds is retired: include/dynamorph_hip.h, dm_backward_precision; asking for it raises).  mode None: query."""

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DM_VERSION 127
+#define DM_VERSION 128
 
 /* ---- on-load operand transform ------------------------------------------
  * A kernel never reads a bare activation: BatchNorm-apply, ReLU and the
@@ -246,8 +246,12 @@ int dm_conv_bwd_s2_fused(const dm_operand *dy, const dm_operand *in, const dm_we
  * input, T = output gradient, R = dW [ci][co][k][k].  Partial results go to
  * `slabs` (nblocks x CS*CT*k*k floats, nblocks = dm_wgrad_num_blocks) and are
  * summed in slab order into `dst` (deterministic). Replaces
- * aten::convolution_backward(weight). */
+ * aten::convolution_backward(weight).
+ * T may be an AFFINE2 operand (two tensors: a BatchNorm backward folded into the load) only where
+ * dm_wgrad_t_affine2_supported says so (the wide decoder's first transposed convolution: S plain, 64 x 32 channels, k = 4);
+ * elsewhere the caller materialises it (dm_apply). */
 int dm_wgrad_num_blocks(int B, int CS, int CT, int Hs, int Ws, int k);
+int dm_wgrad_t_affine2_supported(int CS, int CT, int Hs, int Ws, int k);
 int dm_wgrad(const dm_operand *S, const dm_operand *T, float *slabs, float *dst,
              int B, int CS, int CT, int Hs, int Ws, int k, void *stream);   /* dst = NULL: leave the slabs unreduced */
 

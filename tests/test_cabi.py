@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header():
 def test_version_and_host_only_queries(lib):
     assert lib.dm_vq_backward_num_slabs(524288, 64, 16) == 512 and lib.dm_vq_backward_num_slabs(262144, 4096, 16) == 128
     assert lib.dm_vq_backward_num_slabs(3000, 64, 16) == 3 and lib.dm_vq_backward_num_slabs(1 << 22, 65536, 16) == 32
-    assert lib.dm_version() == 127          # 127: streaming kernels of the wide family (wide_stream.hip), one-pass 64-channel weight gradients, dm_bn_backward_finalize with count 0 (eval mode); 126: vq_cells_kernel (large codebooks), dm_adam_counted_scaled, split-bf16 gradient kernels retired; 125: dm_conv3x3_bwd_fused on 32 x 32 latents (CD = 32), the training decoder tail in 64-column tiles; 124: dm_zscore_channels; 123: dm_time_matching_forward_state / _backward_state; 122: dm_reorder_with_trajectories; 121: dm_conv4x4s2_bwd_fused; 120: dm_conv3x3_bwd_fused; 119: dm_convt_bwd_fused; 118: dm_conv1x1_bwd_fused; 117: dm_vq_loss_finalize_tm, dm_time_matching_backward_add; 116: dm_vq_forward_join; 115: dm_gather_augment, dm_gather_rows, dm_csr_block, dm_augment_codes; 114: latent tail from a2; 113: dm_latent_tail_forward; 112: the fused decoder tail takes any width that is a multiple of 4
+    assert lib.dm_version() == 128          # 128: dm_wgrad_t_affine2_supported (T as an AFFINE2 operand of the one-pass weight gradient), dm_conv1x1_bwd_fused at 64 channels; 127: streaming kernels of the wide family (wide_stream.hip), one-pass 64-channel weight gradients, dm_bn_backward_finalize with count 0 (eval mode); 126: vq_cells_kernel (large codebooks), dm_adam_counted_scaled, split-bf16 gradient kernels retired; 125: dm_conv3x3_bwd_fused on 32 x 32 latents (CD = 32), the training decoder tail in 64-column tiles; 124: dm_zscore_channels; 123: dm_time_matching_forward_state / _backward_state; 122: dm_reorder_with_trajectories; 121: dm_conv4x4s2_bwd_fused; 120: dm_conv3x3_bwd_fused; 119: dm_convt_bwd_fused; 118: dm_conv1x1_bwd_fused; 117: dm_vq_loss_finalize_tm, dm_time_matching_backward_add; 116: dm_vq_forward_join; 115: dm_gather_augment, dm_gather_rows, dm_csr_block, dm_augment_codes; 114: latent tail from a2; 113: dm_latent_tail_forward; 112: the fused decoder tail takes any width that is a multiple of 4
     assert lib.dm_latent_tail_supported(16, 32, 16, 16, 2) == 1 and lib.dm_latent_tail_supported(16, 32, 32, 32, 2) == 0
     assert lib.dm_latent_tail_supported(64, 64, 16, 16, 2) == 0
     assert lib.dm_dec_tail_supported(4, 4, 128, 128) == 1 and lib.dm_dec_tail_supported(4, 2, 64, 64) == 1
@@ -72,7 +72,12 @@ def test_version_and_host_only_queries(lib):
     assert lib.dm_convt_bwd_fused_num_blocks(2048, 8, 4, 32, 32) == 768 and lib.dm_convt_bwd_fused_num_blocks(2, 16, 8, 16, 16) == 4
     assert lib.dm_convt_bwd_fused_num_blocks(2048, 16, 8, 16, 16) == 512
     assert lib.dm_conv1x1_bwd_fused_supported(16, 32, 16, 16) == 1 and lib.dm_conv1x1_bwd_fused_supported(16, 32, 8, 8) == 0
-    assert lib.dm_conv1x1_bwd_fused_supported(64, 64, 16, 16) == 0 and lib.dm_conv1x1_bwd_fused_num_blocks(2048, 16, 32, 16, 16) == 512
+    assert lib.dm_conv1x1_bwd_fused_supported(48, 48, 16, 16) == 0 and lib.dm_conv1x1_bwd_fused_num_blocks(2048, 16, 32, 16, 16) == 512
+    # 64 -> 64 channels (wide_stream.hip): one statistics / weight slab per WAVE
+    assert lib.dm_conv1x1_bwd_fused_supported(64, 64, 32, 32) == 1 and lib.dm_conv1x1_bwd_fused_num_blocks(768, 64, 64, 32, 32) == 2048
+    assert lib.dm_conv1x1_bwd_fused_num_blocks(3, 64, 64, 32, 32) == 48
+    assert lib.dm_wgrad_t_affine2_supported(64, 32, 32, 32, 4) == 1 and lib.dm_wgrad_t_affine2_supported(64, 64, 32, 32, 3) == 0
+    assert lib.dm_wgrad_t_affine2_supported(16, 8, 32, 32, 4) == 0
     assert lib.dm_conv1x1_bwd_fused_num_blocks(3, 16, 32, 32, 32) == 12
     assert lib.dm_vq_forward_join_supported(16, 64, 16, 16) == 1 and lib.dm_vq_forward_join_supported(16, 4096, 32, 32) == 0
     assert lib.dm_vq_forward_join_supported(8, 64, 16, 16) == 0 and lib.dm_vq_forward_join_supported(16, 64, 10, 10) == 0

@@ -1963,15 +1963,17 @@ def test_vq_backward_large_codebooks_is_bit_reproducible(ops, K, D, B, H):
     close(outs[0][1], ref.float(), 1e-5, 1e-5 * float(ref.abs().max()), "codebook gradient")
 
 
-@pytest.mark.parametrize("B,mode,epi", [(3, 3, "bias+stats"), (5, 0, "none"), (2, 1, "gate+q"), (1, 2, "all"), (70, 3, "bias+stats")])
+@pytest.mark.parametrize("B,mode,epi", [(3, 3, "bias+stats"), (5, 0, "none"), (2, 1, "gate+q"), (1, 2, "all"), (70, 3, "bias+stats"),
+                                        (3, 4, "none"), (2, 4, "bias+stats")])
 def test_stream_conv_4x4s2_32_to_64_weights_in_lds(ops, B, mode, epi):
     """wide_stream.hip: the wide encoder's second convolution (32 -> 64 channels, 64 x 64 -> 32 x 32) with all weights resident
     in LDS and the activations loaded straight into the matrix instruction's layout: two output rows per unit, the row seam
     between the two halves of a lane row, padding rows zeroed after the transform, every epilogue operand."""
     cin, nout, h, w = 32, 64, 64, 64
-    x = rnd(B, cin, h, w, seed=1)
-    coef = torch.stack([rnd(cin, seed=3).abs() + 0.5, torch.zeros(cin), rnd(cin, seed=5) * 0.3 + 0.2, torch.zeros(cin)], 1)
-    xin = load_ref(x.double(), mode, coef.double())
+    x, x1 = rnd(B, cin, h, w, seed=1), rnd(B, cin, h, w, seed=2)
+    coef = torch.stack([rnd(cin, seed=3).abs() + 0.5, rnd(cin, seed=4) * 0.2 if mode == 4 else torch.zeros(cin),
+                        rnd(cin, seed=5) * 0.3 + 0.2, torch.zeros(cin)], 1)
+    xin = load_ref(x.double(), mode, coef.double(), x1.double())
     wt = rnd(nout, cin, 4, 4, seed=6, scale=0.1)
     kw = {}
     bias = rnd(nout, seed=7) if epi in ("bias+stats", "all") else None
@@ -1994,7 +1996,8 @@ def test_stream_conv_4x4s2_32_to_64_weights_in_lds(ops, B, mode, epi):
     elif epi == "gate+q":
         kw.update(stat_q=kw["mask"].p0)
         sq = gate
-    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None), ops.weight_view(wt.to(DEV), cin * 16, 16, 4, 1),
+    out, st = ops.conv4x4s2(ops.Op(x.to(DEV), mode, coef.to(DEV) if mode >= 2 else None, p1=x1.to(DEV) if mode == 4 else None),
+                            ops.weight_view(wt.to(DEV), cin * 16, 16, 4, 1),
                             B, cin, nout, h, w, want_stats=epi != "none", **kw)
     close(out, ref.float(), 5e-5, 5e-5, "stream conv 4x4/s2 32 -> 64")
     if st is not None:
@@ -2096,3 +2099,24 @@ def test_stream_conv1x1_backward_fused_64_channels(ops, B, H, W, two):
     close(dx, dx_ref.float(), 5e-5, 5e-5, "fused 1x1 backward: dx")
     close(dst, wd.grad.float(), 5e-5, 5e-5 * float(wd.grad.abs().max()), "fused 1x1 backward: dW")
     close_stats(st.sum(0), dx_ref.float(), x)
+
+
+@pytest.mark.parametrize("B,tmode", [(3, 4), (1, 4), (40, 4), (2, 0)])
+def test_wide_wgrad_one_pass_with_an_affine2_t_operand(ops, B, tmode):
+    """dm_wgrad with T as an AFFINE2 operand (dm_wgrad_t_affine2_supported: the wide decoder's first transposed convolution, whose
+    output gradient carries a BatchNorm backward): the one-pass kernel prefetches both tensors of T; elsewhere the call is refused."""
+    cs, ct, hs = 64, 32, 32
+    assert ops.wgrad_t_affine2_supported(cs, ct, hs, hs, 4) and not ops.wgrad_t_affine2_supported(64, 64, hs, hs, 3)
+    s_ = rnd(B, cs, hs, hs, seed=1)
+    t, t1 = rnd(B, ct, 2 * hs, 2 * hs, seed=2), rnd(B, ct, 2 * hs, 2 * hs, seed=3)
+    tcoef = torch.stack([rnd(ct, seed=4), rnd(ct, seed=5) * 0.3, rnd(ct, seed=6) * 0.2, torch.zeros(ct)], 1)
+    w = torch.zeros(cs, ct, 4, 4, requires_grad=True, dtype=torch.float64)
+    F.conv2d(load_ref(t.double(), tmode, tcoef.double(), t1.double()), w, None, stride=2, padding=1).backward(s_.double())
+    dst = torch.empty(cs, ct, 4, 4, device=DEV)
+    top = ops.Op(t.to(DEV), tmode, tcoef.to(DEV) if tmode >= 2 else None, p1=t1.to(DEV) if tmode == 4 else None)
+    ops.wgrad(ops.Op(s_.to(DEV)), top, dst, B, cs, ct, hs, hs, 4)
+    close(dst, w.grad.float(), 5e-5, 5e-5 * float(w.grad.abs().max()), "one-pass wgrad, AFFINE2 T")
+    if tmode == 4:
+        with pytest.raises(ValueError, match="AFFINE2"):
+            ops.wgrad(ops.Op(rnd(2, 16, 16, 16, seed=1).to(DEV)), ops.Op(rnd(2, 16, 32, 32, seed=2).to(DEV), 4,
+                      torch.zeros(16, 4, device=DEV), p1=rnd(2, 16, 32, 32, seed=3).to(DEV)), torch.empty(16, 16, 4, 4, device=DEV), 2, 16, 16, 16, 16, 4)
